@@ -1,0 +1,231 @@
+/*
+ * rb_oracle.h -- CPU ORACLE for the rustybam CIGAR-walk hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load or call anything in oracle/.  The product
+ * library (rustybam_amd/csrc, include/rustybam_amd.h) never links, includes or calls it.
+ *
+ * It is a plain-C restatement of the reference algorithm (mrvollger/rustybam v0.1.33),
+ * deliberately keeping the reference's PER-BASE formulation (aligned_pairs expansion +
+ * binary search over per-base arrays) so that it shares no algorithmic structure with
+ * the op-space HIP kernels it checks.  Each function cites the reference file:line it
+ * follows.
+ *
+ * PARITY PINNING.  The Rust reference cannot be built in this environment (no
+ * cargo/rustc, un-vendored crates), so there is no oracle/_ref.  The oracle is pinned by
+ * the reference's own known-answer tests (tests/golden/known_answers.json, KA1..KA12 of
+ * SURVEY.md section 4) and cross-checked against the independent digests recorded in
+ * SURVEY.md section 8c.  The following third-party behaviours have NO reference test and
+ * are "parity unpinned":
+ *   - which duplicate Rust's slice::binary_search returns (both std generations are
+ *     implemented: RBO_BSEARCH_MODERN = rustc >= 1.82, RBO_BSEARCH_LEGACY = 1.52..1.81);
+ *   - the text of Rust's f32 Display (shortest round-trip, positional) in `rb stats`;
+ *   - rust-htslib 0.44.1 CIGAR text parser corner cases (missing digits, overflow);
+ *   - bio 1.6.0 BED reader corner cases (ragged columns);
+ *   - rayon par_bridge output order (we use the single-thread order).
+ */
+#ifndef RB_ORACLE_H
+#define RB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* BAM op codes, packed op = len << 4 | code (rust_htslib Cigar enum; paf.rs:946-996) */
+enum { RBO_M = 0, RBO_I = 1, RBO_D = 2, RBO_N = 3, RBO_S = 4, RBO_H = 5, RBO_P = 6, RBO_EQ = 7, RBO_X = 8 };
+
+enum { RBO_BSEARCH_MODERN = 0, RBO_BSEARCH_LEGACY = 1 };
+
+/* Outcomes.  "PANIC_*" are the places where the reference aborts the process. */
+enum {
+    RBO_OK = 0,
+    RBO_NONE_INDEL = 1,        /* liftover.rs:52-54  start_idx > end_idx -> None            */
+    RBO_NONE_NOMATCH = 2,      /* liftover.rs:65-75  no M/=/X op in the clipped cigar       */
+    RBO_NONE_EMPTY = 3,        /* liftover.rs:87-89  empty cigar after trimming             */
+    RBO_NONE_INVERTED = 4,     /* liftover.rs:90-96  st > en                                */
+    RBO_NONE_INTEGRITY = 5,    /* liftover.rs:99-102 check_integrity failed                 */
+    RBO_PANIC_NOTFOUND = 16,   /* liftover.rs:31/42, paf.rs:792-793 binary search Err       */
+    RBO_PANIC_EMPTY_CIGAR = 17,/* paf.rs:663 first().unwrap() on an empty cigar             */
+    RBO_PANIC_INTEGRITY_T = 18,/* paf.rs:827 via unwrap at paf.rs:70 / :782                 */
+    RBO_PANIC_INTEGRITY_Q = 19,/* paf.rs:839                                                 */
+    RBO_PANIC_ALL_INDEL = 20,  /* paf.rs:757 truncate underflow when every op is I/D        */
+    RBO_PANIC_ASSERT = 21,     /* paf.rs:787-788 asserts in truncate_record_by_query        */
+    RBO_PANIC_OVERFLOW = 22    /* u32 sum overflow in infer_n_bases (paf.rs:632-647)        */
+};
+
+typedef struct {
+    char *q_name;
+    uint64_t q_len, q_st, q_en;
+    char strand;
+    char *t_name;
+    uint64_t t_len, t_st, t_en;
+    uint64_t nmatch, aln_len, mapq;
+    uint32_t *cigar; /* packed len<<4|op */
+    size_t n_cigar;
+    char *id;
+    /* per-base expansion (paf.rs:362-364) */
+    uint64_t *tpos_aln, *qpos_aln;
+    uint8_t *long_cigar;
+    size_t n_aln;
+    int contained;
+} rbo_rec;
+
+typedef struct {
+    char *name;
+    uint64_t st, en;
+    char *id;
+} rbo_region;
+
+typedef struct {
+    rbo_rec *recs;
+    size_t n, cap;
+} rbo_paf;
+
+typedef struct {
+    rbo_region *r;
+    size_t n, cap;
+} rbo_bed;
+
+/* --- record lifecycle --- */
+void rbo_rec_init(rbo_rec *r);
+void rbo_rec_free(rbo_rec *r);
+void rbo_rec_clone(rbo_rec *dst, const rbo_rec *src); /* deep copy incl. expansion */
+void rbo_rec_drop_aln(rbo_rec *r);
+void rbo_paf_free(rbo_paf *p);
+void rbo_bed_free(rbo_bed *b);
+
+/* --- text boundary (paf.rs:379-430, :62-78, :923-944; bed.rs:146-194) --- */
+/* returns 0 ok, 1 = line skipped (numeric column unparsable), <0 = reference would panic */
+int rbo_parse_cigar(const char *s, size_t n, uint32_t **ops, size_t *n_ops);
+int rbo_rec_from_line(const char *line, rbo_rec *out);
+int rbo_paf_from_file(const char *path, rbo_paf *out); /* runs check_integrity per record */
+void rbo_rec_print(const rbo_rec *r, FILE *f);
+size_t rbo_cigar_to_string(const uint32_t *ops, size_t n, char **out);
+int rbo_bed_from_file(const char *path, rbo_bed *out);
+void rbo_region_default_id(rbo_region *r);
+
+/* --- primitives --- */
+int rbo_consumes_reference(uint32_t op);
+int rbo_consumes_query(uint32_t op);
+int rbo_is_match(uint32_t op);
+int rbo_infer_n_bases(const rbo_rec *r, uint64_t out4[4]);       /* paf.rs:631-654 */
+int rbo_check_integrity(rbo_rec *r);                             /* paf.rs:825-857 */
+int rbo_remove_trailing_indels(rbo_rec *r);                      /* paf.rs:656-783 */
+int rbo_aligned_pairs(rbo_rec *r);                               /* paf.rs:501-538 */
+/* binary searches; return 0 and *idx on Ok, 1 on Err (not found) */
+int rbo_tpos_to_idx(const rbo_rec *r, uint64_t tpos, int policy, size_t *idx);             /* paf.rs:541-544 */
+int rbo_tpos_to_idx_match(const rbo_rec *r, uint64_t tpos, int right, int policy, size_t *idx); /* :547-561 */
+int rbo_qpos_to_idx(const rbo_rec *r, uint64_t qpos, int policy, size_t *idx);             /* paf.rs:564-573 */
+int rbo_qpos_to_idx_match(const rbo_rec *r, uint64_t qpos, int right, int policy, size_t *idx); /* :576-590 */
+
+/* --- liftover (liftover.rs) --- */
+int rbo_trim_paf_rec_to_rgn(const rbo_region *rgn, const rbo_rec *paf, int policy, rbo_rec *out); /* :17-105 */
+int rbo_trim_paf_by_rgns(const rbo_bed *rgns, const rbo_paf *paf, int invert_query, int policy,
+                         rbo_paf *out);                                                          /* :134-167 */
+int rbo_break_paf_on_indels(const rbo_rec *paf, uint32_t break_length, int policy, rbo_paf *out); /* :182-226 */
+
+/* --- trim-paf (trim_overlap.rs, paf.rs:210-305, :785-823) --- */
+int rbo_truncate_record_by_query(rbo_rec *r, uint64_t new_q_st, uint64_t new_q_en, int policy);
+int rbo_trim_overlapping_pafs(rbo_rec *left, rbo_rec *right, int match_score, int diff_score, int indel_score,
+                              int policy, uint64_t *split_idx, int *split_score);
+int rbo_overlapping_paf_recs(rbo_paf *paf, int match_score, int diff_score, int indel_score,
+                             int remove_contained, int policy);
+
+/* --- invert (paf.rs:1050-1094) --- */
+void rbo_paf_swap_query_and_target(const rbo_rec *in, rbo_rec *out);
+
+/* --- stats (bamstats.rs:16-36, :107-154, :225-270) --- */
+typedef struct {
+    uint32_t equal, diff, ins, del, matches, ins_events, del_events;
+    float id_by_all, id_by_events, id_by_matches;
+} rbo_stats;
+void rbo_stats_from_cigar(const uint32_t *ops, size_t n, rbo_stats *s);
+size_t rbo_f32_display(float v, char *buf, size_t cap); /* Rust `{}` for f32 */
+void rbo_print_stats_header(int qbed, FILE *f);
+void rbo_print_stats(const rbo_rec *r, const rbo_stats *s, int qbed, FILE *f);
+
+/* ------------------------------------------------------------------------------------------
+ * Flat-array API (what tests/bench compare the HIP path with).  Same data model as
+ * include/rustybam_amd.h: packed ops, op offsets, header SoA, window SoA.  All outputs
+ * are malloc'ed and owned by the caller (free with rbo_free).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t t_bases, q_bases; /* from infer_n_bases on the ORIGINAL cigar */
+    uint32_t nmatch, aln_len;
+    uint32_t equal, diff, ins, del, matches, ins_events, del_events;
+    float id_by_all, id_by_events, id_by_matches;
+    uint32_t status;       /* RBO_OK or the panic check_integrity (paf.rs:70) would raise */
+    uint32_t _pad;
+} rbo_reduce_row; /* 64 B */
+
+typedef struct {
+    uint64_t t_st, t_en, q_st, q_en; /* after remove_trailing_indels */
+    uint32_t first_op, n_ops;        /* kept op range inside the original record */
+    uint32_t lead_ops, trail_ops;    /* how many were stripped (for the _TO.<..>.<..> id) */
+    uint32_t nmatch, aln_len;        /* of the normalized record */
+    uint32_t status, _pad;
+} rbo_norm_row; /* 64 B */
+
+typedef struct {
+    uint32_t rec, win;
+    uint32_t status;
+    uint32_t flags; /* bit0: returned the record unchanged with its own id (liftover.rs:23-25) */
+    uint64_t t_st, t_en, q_st, q_en;
+    uint32_t nmatch, aln_len;
+    uint64_t out_off; /* into out_ops */
+    uint32_t out_n, _pad;
+} rbo_hit_row; /* 72 B */
+
+void rbo_free(void *p);
+
+int rbo_reduce_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                      const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, rbo_reduce_row *out);
+
+int rbo_normalize_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                         const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                         rbo_norm_row *out);
+
+/* liftover of every record against every window of the same contig, canonical order
+ * (contig first appearance -> record -> window).  n_threads <= 1 is serial. */
+int rbo_liftover_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                        const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                        const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
+                        const uint64_t *w_en, int policy, int n_threads, rbo_hit_row **hits, uint64_t *n_hits,
+                        uint32_t **out_ops, uint64_t *n_out);
+
+/* break-paf: every record, record order; win field = piece ordinal within the record */
+int rbo_break_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                     const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                     uint32_t max_size, int policy, int n_threads, rbo_hit_row **hits, uint64_t *n_hits,
+                     uint32_t **out_ops, uint64_t *n_out);
+
+typedef struct {
+    uint64_t split_idx;
+    int32_t split_score;
+    uint32_t status;
+    /* left then right, after truncate_record_by_query */
+    uint64_t t_st[2], t_en[2], q_st[2], q_en[2];
+    uint32_t nmatch[2], aln_len[2];
+    uint64_t out_off[2];
+    uint32_t out_n[2];
+} rbo_pair_row;
+
+/* trim one (left,right) pair list: pairs index into the record arrays */
+int rbo_overlap_split_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                             const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
+                             const uint8_t *strand, uint64_t n_pairs, const uint32_t *left, const uint32_t *right,
+                             int match_score, int diff_score, int indel_score, int policy, rbo_pair_row *rows,
+                             uint32_t **out_ops, uint64_t *n_out);
+
+/* swap query/target of each record (paf.rs:1068-1094): I<->D, reverse op order on '-' */
+int rbo_swap_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint8_t *strand,
+                    uint32_t *out_ops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
