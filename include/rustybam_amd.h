@@ -1,0 +1,246 @@
+/*
+ * rustybam_amd.h -- C ABI of the MI355X (gfx950) CIGAR-walk engine.
+ *
+ * Drop-in boundary for the per-record CIGAR walk of mrvollger/rustybam v0.1.33.  The
+ * reference has no FFI seam; the entry points below are what a Rust host would bind with
+ * `extern "C"` in place of the following calls (file:line into the reference's src/):
+ *
+ *   rb_dev_scan_records   <- PafRecord::check_integrity / infer_n_bases   paf.rs:825-857, :631-654
+ *                            (called per record by Paf::from_file         paf.rs:70)
+ *                            PafRecord::remove_trailing_indels            paf.rs:656-783
+ *                            bamstats::add_stats_from_cigar/stats_from_paf bamstats.rs:107-154, :91-105
+ *   rb_dev_liftover       <- liftover::trim_paf_by_rgns                   liftover.rs:134-167
+ *                            (= trim_helper :107-132 + trim_paf_rec_to_rgn :17-105, which in turn
+ *                             replace aligned_pairs paf.rs:501-538, tpos_to_idx(_match) :541-561,
+ *                             subset_cigar/collapse_long_cigar :593-620, paf_overlaps_rgn :622-627)
+ *   rb_dev_break          <- liftover::break_paf_on_indels                liftover.rs:182-226
+ *   rb_dev_swap           <- paf::paf_swap_query_and_target               paf.rs:1050-1094
+ *
+ * Conventions
+ *   - Plain C types only.  Every `rb_dev_*` pointer argument is a DEVICE pointer (HBM) owned by
+ *     the caller; the call enqueues kernels on the context's HIP stream and returns without
+ *     synchronising.  `rb_host_*` take HOST pointers and do H2D / kernels / D2H themselves.
+ *   - Return value: RB_OK (0) or a negative rb_error; no exceptions or unwinding cross the ABI.
+ *     Where the reference would panic or silently drop a (record, window) pair the outcome is
+ *     a per-record / per-hit `status` in the result rows (enum rb_status).
+ *   - One context per host thread; a context pins one device and one stream.
+ *   - The library never falls back to the CPU: without a usable gfx950 device every compute
+ *     entry point fails with RB_E_NO_DEVICE.
+ *
+ * Data model (all little-endian, in HBM):
+ *   ops[]      u32  packed BAM encoding  len << 4 | op   (M0 I1 D2 N3 S4 H5 P6 =7 X8); len < 2^28
+ *   op_off[]   u64  [n_rec + 1] exclusive prefix of ops-per-record
+ *   t_st,t_en,q_st,q_en u64 [n_rec];  strand u8 ('+' / '-');  contig u32 (dense ids, host keeps names)
+ *   windows: contig u32, st u64, en u64   [n_win]  in BED file order
+ */
+#ifndef RUSTYBAM_AMD_H
+#define RUSTYBAM_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB_ABI_VERSION 1
+
+enum rb_op { RB_OP_M = 0, RB_OP_I = 1, RB_OP_D = 2, RB_OP_N = 3, RB_OP_S = 4, RB_OP_H = 5, RB_OP_P = 6, RB_OP_EQ = 7, RB_OP_X = 8 };
+
+typedef enum rb_error {
+    RB_OK = 0,
+    RB_E_INVALID = -1,   /* bad argument */
+    RB_E_NO_DEVICE = -2, /* no gfx950 device / HIP runtime unusable: there is NO CPU fallback */
+    RB_E_HIP = -3,       /* a HIP call failed; see rb_ctx_last_error */
+    RB_E_CAPACITY = -4,  /* caller-provided output buffer too small; counters say what is needed */
+    RB_E_NOMEM = -5
+} rb_error;
+
+/* Per-record and per-hit outcome.  0 = Some(record).  1..5 = the reference returns None (pair is
+ * silently dropped).  >= 16 = the reference panics at the cited line. */
+typedef enum rb_status {
+    RB_ST_OK = 0,
+    RB_ST_NONE_INDEL = 1,         /* liftover.rs:52-54   start_idx > end_idx                    */
+    RB_ST_NONE_NOMATCH = 2,       /* liftover.rs:65-75                                          */
+    RB_ST_NONE_EMPTY = 3,         /* liftover.rs:87-89                                          */
+    RB_ST_NONE_INVERTED = 4,      /* liftover.rs:90-96                                          */
+    RB_ST_NONE_INTEGRITY = 5,     /* liftover.rs:99-102                                         */
+    RB_ST_PANIC_NOTFOUND = 16,    /* liftover.rs:31 / :42, paf.rs:792-793                       */
+    RB_ST_PANIC_EMPTY_CIGAR = 17, /* paf.rs:663                                                 */
+    RB_ST_PANIC_INTEGRITY_T = 18, /* paf.rs:827 through .unwrap() at paf.rs:70 / :782           */
+    RB_ST_PANIC_INTEGRITY_Q = 19, /* paf.rs:839                                                 */
+    RB_ST_PANIC_ALL_INDEL = 20,   /* paf.rs:757                                                 */
+    RB_ST_PANIC_ASSERT = 21,      /* paf.rs:787-788                                             */
+    RB_ST_PANIC_OVERFLOW = 22     /* u32 overflow of a CIGAR length sum (paf.rs:632-647)        */
+} rb_status;
+
+/* Rust slice::binary_search duplicate policy, low bit of `bsearch_policy`.
+ * RB_LIFT_EARLY_EXIT may be OR-ed in: stop walking a record once all its windows are resolved
+ * (same results; the reference always walks every record, so benchmarks leave it off). */
+enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY = 1 /* 1.52 .. 1.81 */, RB_LIFT_EARLY_EXIT = 16 };
+
+/* rb_norm_row.flags / rb_reduce_row.flags */
+enum {
+    RB_F_REGULAR = 1u << 0,   /* only M I D = X ops, every len >= 1, no two adjacent ops of one type */
+    RB_F_STRIPPED = 1u << 1,  /* leading/trailing indels were removed (host appends _TO.<..>.<..>) */
+    RB_F_HAS_M = 1u << 2      /* cigar contains 'M' (bamstats.rs:145 warning)                      */
+};
+/* rb_hit_row.flags */
+enum {
+    RB_HIT_INSIDE = 1u << 0,  /* liftover.rs:23-25: record returned unchanged and keeps its OWN id */
+    RB_HIT_GENERIC = 1u << 1  /* resolved by the generic (serial) kernel, informational             */
+};
+
+/* ---- result rows (written by the device; 72 / 64 / 64 bytes) ---------------------------------- */
+typedef struct rb_reduce_row { /* check_integrity + stats of the ORIGINAL record */
+    uint64_t t_bases, q_bases;                  /* infer_n_bases: reference / query consuming      */
+    uint32_t nmatch, aln_len;                   /* M+=+X lengths (quirk 9.3.1), all lengths        */
+    uint32_t equal, diff, ins, del, matches;    /* bamstats.rs:26-30 (diff = X + M, matches = M)   */
+    uint32_t ins_events, del_events;
+    float id_by_all, id_by_events, id_by_matches; /* bamstats.rs:138-142, f32                      */
+    uint32_t status;                            /* RB_ST_OK / PANIC_INTEGRITY_* / PANIC_OVERFLOW    */
+    uint32_t flags;
+} rb_reduce_row;
+
+typedef struct rb_norm_row { /* the record after remove_trailing_indels (paf.rs:656-783) */
+    uint64_t t_st, t_en, q_st, q_en;
+    uint32_t first_op, n_ops;    /* kept op range, relative to the record's first op */
+    uint32_t lead_ops, trail_ops;
+    uint32_t nmatch, aln_len;    /* of the kept range */
+    uint32_t status;
+    uint32_t flags;
+} rb_norm_row;
+
+typedef struct rb_hit_row { /* one (record, window) pair that passed paf_overlaps_rgn */
+    uint32_t rec, win;           /* record index in the batch; window index in BED order (break: piece #) */
+    uint16_t status, flags;
+    uint32_t out_n;              /* ops in the clipped cigar */
+    uint64_t t_st, t_en, q_st, q_en;
+    uint32_t nmatch, aln_len;
+    uint64_t out_off;            /* first op of the clipped cigar in out_ops[] */
+} rb_hit_row;
+
+typedef struct rb_pair_row { /* trim-paf: one (left, right) overlap pair, 128 bytes */
+    uint64_t split_idx;          /* trim_overlap.rs:69-76 */
+    int32_t split_score;
+    uint32_t status;
+    uint64_t t_st[2], t_en[2], q_st[2], q_en[2]; /* [0]=left [1]=right after truncate_record_by_query */
+    uint32_t nmatch[2], aln_len[2];
+    uint64_t out_off[2];
+    uint32_t out_n[2];
+    uint64_t _pad;
+} rb_pair_row;
+
+typedef struct rb_counters { /* device-written job summary, 64 bytes */
+    uint64_t n_hits;             /* rows the job wants to write                                  */
+    uint64_t out_ops_needed;     /* upper bound of out_ops[] capacity that makes the job fit      */
+    uint64_t out_ops_used;       /* highest op index written + 1                                  */
+    uint64_t n_generic;          /* hits routed to the generic kernel                             */
+    uint32_t overflow;           /* != 0: rows or out_ops capacity exceeded, results incomplete   */
+    uint32_t _pad[7];
+} rb_counters;
+
+/* ---- views over caller-owned device memory ---------------------------------------------------- */
+typedef struct rb_batch_view {
+    uint64_t n_rec, n_ops;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint64_t *t_st, *t_en, *q_st, *q_en;
+    const uint8_t *strand;
+    const uint32_t *contig;
+} rb_batch_view;
+
+typedef struct rb_windows_view {
+    uint64_t n_win;
+    const uint32_t *contig;
+    const uint64_t *st, *en;
+} rb_windows_view;
+
+typedef struct rb_ctx rb_ctx;
+typedef struct rb_plan rb_plan; /* host-built schedule for one (batch, windows) pair */
+
+/* ---- context ---------------------------------------------------------------------------------- */
+int rb_abi_version(void);
+int rb_device_count(void);
+/* `hip_stream`: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL for a private one. */
+int rb_ctx_create(int device, void *hip_stream, rb_ctx **out);
+void rb_ctx_destroy(rb_ctx *ctx);
+const char *rb_ctx_last_error(const rb_ctx *ctx);
+int rb_ctx_sync(rb_ctx *ctx);
+void *rb_ctx_stream(rb_ctx *ctx);
+
+/* device memory helpers for hosts without their own allocator (the C++ host and ctypes tests) */
+int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr);
+int rb_dev_free(rb_ctx *ctx, void *dev_ptr);
+int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);   /* async */
+int rb_dev_download(rb_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes); /* synchronises */
+int rb_dev_memset(rb_ctx *ctx, void *dev_dst, int value, size_t bytes);              /* async */
+
+/* ---- K1: one pass over every record's ops ----------------------------------------------------- *
+ * reduce_rows and/or norm_rows may be NULL.  [n_rec] each. */
+int rb_dev_scan_records(rb_ctx *ctx, const rb_batch_view *batch, rb_reduce_row *reduce_rows, rb_norm_row *norm_rows);
+
+/* ---- schedule (host side, no device work besides small uploads) ------------------------------- *
+ * Built from HOST copies of the small per-record / per-window arrays:
+ *   - canonical output order: contigs by first appearance, then record order (liftover.rs:151-164)
+ *   - longest-first launch order (load balance; does not affect results)
+ *   - windows grouped by contig in BED order, with a per-contig "monotone" flag
+ * `windows` may be NULL (break-paf / stats only).  */
+int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_off_host, const uint32_t *contig_host,
+                   uint64_t n_win, const uint32_t *w_contig_host, const uint64_t *w_st_host, const uint64_t *w_en_host,
+                   rb_plan **out);
+void rb_plan_destroy(rb_plan *plan);
+/* bytes of device workspace rb_dev_liftover / rb_dev_break need for this plan and row capacity */
+size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap);
+
+/* ---- liftover --------------------------------------------------------------------------------- *
+ * For every record (status OK in norm_rows) and every window of the same contig with
+ * t_en > st && t_st < en, in canonical order, writes one rb_hit_row and the clipped cigar.
+ *   rows      [rows_cap]      out_ops [out_cap]      counters [1]      workspace [rb_plan_workspace_bytes]
+ * On capacity overflow counters->overflow != 0 and counters say what is needed; the caller
+ * enlarges and calls again (the host wrapper below does that). */
+int rb_dev_liftover(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *batch, const rb_norm_row *norm_rows,
+                    int bsearch_policy, void *workspace, rb_hit_row *rows, uint64_t rows_cap, uint32_t *out_ops,
+                    uint64_t out_cap, rb_counters *counters);
+
+/* ---- break-paf -------------------------------------------------------------------------------- *
+ * Pieces between indels longer than max_size, record order then piece order; same row shape,
+ * rb_hit_row.win = piece ordinal among the candidate windows of the record. */
+int rb_dev_break(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *batch, const rb_norm_row *norm_rows,
+                 uint32_t max_size, int bsearch_policy, void *workspace, rb_hit_row *rows, uint64_t rows_cap,
+                 uint32_t *out_ops, uint64_t out_cap, rb_counters *counters);
+
+/* ---- invert ----------------------------------------------------------------------------------- *
+ * out_ops[op_off[r] .. op_off[r+1]) = I<->D swapped, order reversed when strand[r] == '-'.
+ * (The header swap t<->q is a host-side field swap.) */
+int rb_dev_swap(rb_ctx *ctx, const rb_batch_view *batch, uint32_t *out_ops);
+
+/* ---- host-buffer wrappers (H2D, kernels, D2H; results malloc'ed, free with rb_host_free) ------ */
+int rb_host_scan_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off,
+                         const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
+                         const uint8_t *strand, rb_reduce_row *reduce_rows, rb_norm_row *norm_rows);
+int rb_host_liftover(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                     const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                     const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
+                     const uint64_t *w_en, int bsearch_policy, rb_norm_row *norm_rows_out /* [n_rec] or NULL */,
+                     rb_hit_row **rows, uint64_t *n_rows, uint32_t **out_ops, uint64_t *n_out, rb_counters *counters);
+int rb_host_break(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                  const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                  uint32_t max_size, int bsearch_policy, rb_norm_row *norm_rows_out, rb_hit_row **rows,
+                  uint64_t *n_rows, uint32_t **out_ops, uint64_t *n_out, rb_counters *counters);
+int rb_host_swap(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint8_t *strand,
+                 uint32_t *out_ops);
+void rb_host_free(void *p);
+
+/* ---- synthetic workload generator (bench and tests, not a reference function) -- *
+ * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and
+ * device versions produce identical bytes.  n_ops per record comes from rb_synth_n_ops. */
+uint32_t rb_synth_n_ops(uint64_t seed, uint64_t record, uint32_t lo, uint32_t hi);
+void rb_synth_fill_ops_host(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops);
+int rb_dev_synth_fill_ops(rb_ctx *ctx, uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off_dev,
+                          uint32_t *ops_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUSTYBAM_AMD_H */

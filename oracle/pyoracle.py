@@ -38,7 +38,7 @@ PAIR_DT = np.dtype(
     [("split_idx", "<u8"), ("split_score", "<i4"), ("status", "<u4"), ("t_st", "<u8", 2), ("t_en", "<u8", 2),
      ("q_st", "<u8", 2), ("q_en", "<u8", 2), ("nmatch", "<u4", 2), ("aln_len", "<u4", 2), ("out_off", "<u8", 2),
      ("out_n", "<u4", 2)])
-assert REDUCE_DT.itemsize == 64 and NORM_DT.itemsize == 64 and HIT_DT.itemsize == 72
+assert REDUCE_DT.itemsize == 72 and NORM_DT.itemsize == 64 and HIT_DT.itemsize == 72
 
 
 def build(force=False):

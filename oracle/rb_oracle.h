@@ -160,7 +160,7 @@ typedef struct {
     float id_by_all, id_by_events, id_by_matches;
     uint32_t status;       /* RBO_OK or the panic check_integrity (paf.rs:70) would raise */
     uint32_t _pad;
-} rbo_reduce_row; /* 64 B */
+} rbo_reduce_row; /* 72 B */
 
 typedef struct {
     uint64_t t_st, t_en, q_st, q_en; /* after remove_trailing_indels */

@@ -1,0 +1,191 @@
+"""ctypes binding of include/rustybam_amd.h (plumbing for tests and bench.py)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+HEADER = os.path.join(ROOT, "include", "rustybam_amd.h")
+
+BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT = 0, 1, 16
+
+REDUCE_DT = np.dtype(
+    [("t_bases", "<u8"), ("q_bases", "<u8"), ("nmatch", "<u4"), ("aln_len", "<u4"), ("equal", "<u4"),
+     ("diff", "<u4"), ("ins", "<u4"), ("del", "<u4"), ("matches", "<u4"), ("ins_events", "<u4"),
+     ("del_events", "<u4"), ("id_by_all", "<f4"), ("id_by_events", "<f4"), ("id_by_matches", "<f4"),
+     ("status", "<u4"), ("flags", "<u4")])
+NORM_DT = np.dtype(
+    [("t_st", "<u8"), ("t_en", "<u8"), ("q_st", "<u8"), ("q_en", "<u8"), ("first_op", "<u4"), ("n_ops", "<u4"),
+     ("lead_ops", "<u4"), ("trail_ops", "<u4"), ("nmatch", "<u4"), ("aln_len", "<u4"), ("status", "<u4"),
+     ("flags", "<u4")])
+HIT_DT = np.dtype(
+    [("rec", "<u4"), ("win", "<u4"), ("status", "<u2"), ("flags", "<u2"), ("out_n", "<u4"), ("t_st", "<u8"),
+     ("t_en", "<u8"), ("q_st", "<u8"), ("q_en", "<u8"), ("nmatch", "<u4"), ("aln_len", "<u4"), ("out_off", "<u8")])
+COUNTERS_DT = np.dtype(
+    [("n_hits", "<u8"), ("out_ops_needed", "<u8"), ("out_ops_used", "<u8"), ("n_generic", "<u8"),
+     ("overflow", "<u4"), ("_pad", "<u4", 7)])
+assert REDUCE_DT.itemsize == 72 and NORM_DT.itemsize == 64 and HIT_DT.itemsize == 64 and COUNTERS_DT.itemsize == 64
+
+
+class RbError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, "librustybam_amd.so")
+
+
+_lib = None
+
+
+def lib():
+    """Load the product library.  Raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RbError(f"{p} is missing: run `make -C rustybam_amd/csrc` (or __graft_entry__.build())")
+        _lib = C.CDLL(p)
+        _lib.rb_ctx_last_error.restype = C.c_char_p
+        _lib.rb_ctx_stream.restype = C.c_void_p
+        _lib.rb_plan_workspace_bytes.restype = C.c_size_t
+        _lib.rb_synth_n_ops.restype = C.c_uint32
+        _lib.rb_synth_n_ops.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    return _lib
+
+
+def declared_symbols():
+    """Every function name declared in include/rustybam_amd.h."""
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rb_[a-z0-9_]+)\s*\(", txt)))
+
+
+def exported_symbols():
+    out = []
+    L = lib()
+    for s in declared_symbols():
+        try:
+            getattr(L, s)
+            out.append(s)
+        except AttributeError:
+            pass
+    return out
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def _arr(x, dt):
+    return np.ascontiguousarray(x, dtype=dt)
+
+
+class BatchView(C.Structure):
+    _fields_ = [("n_rec", C.c_uint64), ("n_ops", C.c_uint64), ("ops", C.c_void_p), ("op_off", C.c_void_p),
+                ("t_st", C.c_void_p), ("t_en", C.c_void_p), ("q_st", C.c_void_p), ("q_en", C.c_void_p),
+                ("strand", C.c_void_p), ("contig", C.c_void_p)]
+
+
+class Engine:
+    """One rb_ctx.  `stream` is a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+
+    def __init__(self, device=0, stream=None):
+        self.L = lib()
+        self.ctx = C.c_void_p()
+        rc = self.L.rb_ctx_create(C.c_int(device), C.c_void_p(stream or 0), C.byref(self.ctx))
+        if rc != 0:
+            raise RbError(f"rb_ctx_create(device={device}) failed with {rc}: no usable gfx950 device "
+                          f"(there is no CPU fallback)")
+
+    def close(self):
+        if self.ctx:
+            self.L.rb_ctx_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RbError(f"{what} failed with {rc}: {self.L.rb_ctx_last_error(self.ctx).decode()}")
+
+    def sync(self):
+        self._chk(self.L.rb_ctx_sync(self.ctx), "rb_ctx_sync")
+
+    # ---- host-buffer wrappers ----
+    def scan_records(self, ops, op_off, t_st, t_en, q_st, q_en, strand):
+        ops, op_off = _arr(ops, np.uint32), _arr(op_off, np.uint64)
+        n = len(op_off) - 1
+        ops = np.concatenate([ops, np.zeros(4, np.uint32)])
+        red, norm = np.zeros(n, REDUCE_DT), np.zeros(n, NORM_DT)
+        a = [_arr(x, np.uint64) for x in (t_st, t_en, q_st, q_en)]
+        s = _arr(strand, np.uint8)
+        self._chk(self.L.rb_host_scan_records(self.ctx, C.c_uint64(n), _p(ops), _p(op_off), *map(_p, a), _p(s),
+                                              _p(red), _p(norm)), "rb_host_scan_records")
+        return red, norm
+
+    def _lift(self, fn, what, n, args):
+        rows, out = C.c_void_p(), C.c_void_p()
+        nr, no = C.c_uint64(), C.c_uint64()
+        norm = np.zeros(n, NORM_DT)
+        cnt = np.zeros(1, COUNTERS_DT)
+        self._chk(fn(self.ctx, *args, _p(norm), C.byref(rows), C.byref(nr), C.byref(out), C.byref(no), _p(cnt)), what)
+
+        def take(ptr, k, dt):
+            if k == 0:
+                r = np.zeros(0, dt)
+            else:
+                buf = (C.c_char * (k * np.dtype(dt).itemsize)).from_address(ptr.value)
+                r = np.frombuffer(buf, dtype=dt).copy()
+            self.L.rb_host_free(ptr)
+            return r
+        return take(rows, nr.value, HIT_DT), take(out, no.value, np.uint32), norm, cnt[0]
+
+    def liftover(self, ops, op_off, t_st, t_en, q_st, q_en, strand, contig, w_contig, w_st, w_en,
+                 policy=BSEARCH_MODERN):
+        ops, op_off = _arr(ops, np.uint32), _arr(op_off, np.uint64)
+        n = len(op_off) - 1
+        ops = np.concatenate([ops, np.zeros(4, np.uint32)])
+        a = [_arr(x, np.uint64) for x in (t_st, t_en, q_st, q_en)]
+        s, c = _arr(strand, np.uint8), _arr(contig, np.uint32)
+        wc, ws, we = _arr(w_contig, np.uint32), _arr(w_st, np.uint64), _arr(w_en, np.uint64)
+        args = [C.c_uint64(n), _p(ops), _p(op_off), *map(_p, a), _p(s), _p(c), C.c_uint64(len(ws)), _p(wc), _p(ws),
+                _p(we), C.c_int(policy)]
+        return self._lift(self.L.rb_host_liftover, "rb_host_liftover", n, args)
+
+    def break_paf(self, ops, op_off, t_st, t_en, q_st, q_en, strand, max_size, policy=BSEARCH_MODERN):
+        ops, op_off = _arr(ops, np.uint32), _arr(op_off, np.uint64)
+        n = len(op_off) - 1
+        ops = np.concatenate([ops, np.zeros(4, np.uint32)])
+        a = [_arr(x, np.uint64) for x in (t_st, t_en, q_st, q_en)]
+        s = _arr(strand, np.uint8)
+        args = [C.c_uint64(n), _p(ops), _p(op_off), *map(_p, a), _p(s), C.c_uint32(max_size), C.c_int(policy)]
+        return self._lift(self.L.rb_host_break, "rb_host_break", n, args)
+
+    def swap(self, ops, op_off, strand):
+        ops, op_off, s = _arr(ops, np.uint32), _arr(op_off, np.uint64), _arr(strand, np.uint8)
+        n = len(op_off) - 1
+        out = np.zeros(len(ops) + 4, np.uint32)
+        src = np.concatenate([ops, np.zeros(4, np.uint32)])
+        self._chk(self.L.rb_host_swap(self.ctx, C.c_uint64(n), _p(src), _p(op_off), _p(s), _p(out)), "rb_host_swap")
+        return out[:len(ops)]
+
+
+def synth_n_ops(seed, first_record, n_rec, lo, hi):
+    L = lib()
+    return np.array([L.rb_synth_n_ops(seed, first_record + i, lo, hi) for i in range(n_rec)], dtype=np.uint64)
+
+
+def synth_fill_ops_host(seed, first_record, op_off):
+    L = lib()
+    op_off = _arr(op_off, np.uint64)
+    ops = np.zeros(int(op_off[-1]), np.uint32)
+    L.rb_synth_fill_ops_host(C.c_uint64(seed), C.c_uint64(first_record), C.c_uint64(len(op_off) - 1), _p(op_off),
+                             _p(ops))
+    return ops

@@ -1,0 +1,662 @@
+// capi.hip -- implementation of include/rustybam_amd.h (host side, HIP runtime).
+//
+// No CPU fallback lives here: every compute entry point needs a gfx950 device and fails with
+// RB_E_NO_DEVICE otherwise.  Nothing in this file (or this library) touches oracle/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/rustybam_amd.h"
+
+// ---- kernel-side parameter blocks (must match the .hip files) ----------------------------------
+struct rb_scan_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint64_t *t_st, *t_en, *q_st, *q_en;
+    const uint8_t *strand;
+    rb_reduce_row *reduce_rows;
+    rb_norm_row *norm_rows;
+};
+struct rb_lift_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint32_t *contig;
+    const uint8_t *strand;
+    const rb_norm_row *norm;
+    const uint32_t *sched;
+    const uint32_t *canon_pos;
+    const uint64_t *w_st, *w_en;
+    const uint32_t *w_orig;
+    const uint64_t *wo_st, *wo_en;
+    const uint64_t *cw_off;
+    const uint8_t *cw_mono;
+    uint32_t n_contig;
+    const uint64_t *x_st, *x_en;
+    uint64_t *hit_off;
+    rb_hit_row *rows;
+    uint64_t rows_cap;
+    uint32_t *out_ops;
+    uint64_t out_cap;
+    unsigned long long *arena_cur;
+    uint64_t arena_size;
+    uint32_t n_arena;
+    uint32_t *gen_list;
+    rb_counters *counters;
+    int policy;
+    int early_exit;
+};
+struct rb_break_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const rb_norm_row *norm;
+    const uint32_t *sched;
+    uint64_t *hit_off; // indexed by record (break-paf order is record order)
+    uint64_t *x_st, *x_en;
+    uint64_t rows_cap;
+    uint32_t max_size;
+    int fill;
+};
+struct rb_swap_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint8_t *strand;
+    uint32_t *out_ops;
+};
+
+extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream);
+extern "C" hipError_t rb_launch_liftover(const rb_lift_params *p, hipStream_t stream);
+extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec);
+extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops, hipStream_t stream);
+
+#define RB_ARENA_STRIDE 16
+#define RB_MAX_ARENA 256
+
+struct rb_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+};
+
+struct rb_plan {
+    rb_ctx *ctx = nullptr;
+    uint64_t n_rec = 0, n_win = 0;
+    uint32_t n_contig = 0;
+    // device arrays
+    uint32_t *sched = nullptr, *canon_pos = nullptr, *w_orig = nullptr, *ident = nullptr;
+    uint64_t *w_st = nullptr, *w_en = nullptr, *wo_st = nullptr, *wo_en = nullptr, *cw_off = nullptr;
+    uint8_t *cw_mono = nullptr;
+};
+
+static int fail(rb_ctx *ctx, int code, const char *fmt, ...) {
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        ctx->err = buf;
+    }
+    return code;
+}
+#define HIPCHK(ctx, call)                                                                             \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return fail((ctx), RB_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" int rb_abi_version(void) { return RB_ABI_VERSION; }
+
+extern "C" int rb_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int rb_ctx_create(int device, void *hip_stream, rb_ctx **out) {
+    if (!out) return RB_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return RB_E_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RB_E_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        fprintf(stderr, "rustybam_amd: device %d is %s; this library only carries gfx950 (MI355X) code objects\n", device, prop.gcnArchName);
+        return RB_E_NO_DEVICE;
+    }
+    if (hipSetDevice(device) != hipSuccess) return RB_E_NO_DEVICE;
+    rb_ctx *c = new rb_ctx();
+    c->device = device;
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete c;
+            return RB_E_HIP;
+        }
+        c->own_stream = true;
+    }
+    *out = c;
+    return RB_OK;
+}
+extern "C" void rb_ctx_destroy(rb_ctx *ctx) {
+    if (!ctx) return;
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+extern "C" const char *rb_ctx_last_error(const rb_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+extern "C" int rb_ctx_sync(rb_ctx *ctx) {
+    if (!ctx) return RB_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RB_OK;
+}
+extern "C" void *rb_ctx_stream(rb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
+    if (!ctx || !dev_ptr) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dev_ptr, bytes ? ((bytes + 255) & ~(size_t)255) : 256);
+    if (e != hipSuccess) return fail(ctx, RB_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return RB_OK;
+}
+extern "C" int rb_dev_free(rb_ctx *ctx, void *dev_ptr) {
+    if (!ctx) return RB_E_INVALID;
+    if (dev_ptr) HIPCHK(ctx, hipFree(dev_ptr));
+    return RB_OK;
+}
+extern "C" int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
+    if (!ctx) return RB_E_INVALID;
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return RB_OK;
+}
+extern "C" int rb_dev_download(rb_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
+    if (!ctx) return RB_E_INVALID;
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return RB_OK;
+}
+extern "C" int rb_dev_memset(rb_ctx *ctx, void *dev_dst, int value, size_t bytes) {
+    if (!ctx) return RB_E_INVALID;
+    if (bytes) HIPCHK(ctx, hipMemsetAsync(dev_dst, value, bytes, ctx->stream));
+    return RB_OK;
+}
+
+// ---- K1 ----------------------------------------------------------------------------------------
+extern "C" int rb_dev_scan_records(rb_ctx *ctx, const rb_batch_view *b, rb_reduce_row *reduce_rows, rb_norm_row *norm_rows) {
+    if (!ctx || !b) return RB_E_INVALID;
+    if (((uintptr_t)b->ops & 15u) != 0) return fail(ctx, RB_E_INVALID, "ops must be 16-byte aligned");
+    rb_scan_params p;
+    p.n_rec = b->n_rec;
+    p.ops = b->ops;
+    p.op_off = b->op_off;
+    p.t_st = b->t_st;
+    p.t_en = b->t_en;
+    p.q_st = b->q_st;
+    p.q_en = b->q_en;
+    p.strand = b->strand;
+    p.reduce_rows = reduce_rows;
+    p.norm_rows = norm_rows;
+    HIPCHK(ctx, rb_launch_scan_records(&p, ctx->stream));
+    return RB_OK;
+}
+
+// ---- plan ----------------------------------------------------------------------------------------
+template <typename T>
+static int upload_vec(rb_ctx *ctx, const std::vector<T> &v, T **dev) {
+    int rc = rb_dev_alloc(ctx, v.size() * sizeof(T) + 16, (void **)dev);
+    if (rc) return rc;
+    if (!v.empty()) {
+        hipError_t e = hipMemcpy(*dev, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(ctx, RB_E_HIP, "plan upload: %s", hipGetErrorString(e));
+    }
+    return RB_OK;
+}
+
+extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_off, const uint32_t *contig, uint64_t n_win,
+                              const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en, rb_plan **out) {
+    if (!ctx || !out || (n_rec && (!op_off || !contig))) return RB_E_INVALID;
+    if (n_rec >= 0xFFFFFFFFull || n_win >= 0xFFFFFFFFull) return fail(ctx, RB_E_INVALID, "too many records/windows for one batch");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rb_plan *pl = new rb_plan();
+    pl->ctx = ctx;
+    pl->n_rec = n_rec;
+    pl->n_win = n_win;
+    uint32_t maxc = 0;
+    for (uint64_t i = 0; i < n_rec; i++) maxc = std::max(maxc, contig[i]);
+    for (uint64_t i = 0; i < n_win; i++) maxc = std::max(maxc, w_contig[i]);
+    const uint32_t n_contig = (n_rec || n_win) ? maxc + 1 : 0;
+    pl->n_contig = n_contig;
+    // canonical order: contigs by first appearance among the records (liftover.rs:151), then record order
+    std::vector<uint32_t> canon_pos(n_rec);
+    {
+        std::vector<uint64_t> rank(n_contig, UINT64_MAX);
+        uint64_t nr = 0;
+        for (uint64_t i = 0; i < n_rec; i++)
+            if (rank[contig[i]] == UINT64_MAX) rank[contig[i]] = nr++;
+        std::vector<uint64_t> start(nr + 1, 0);
+        for (uint64_t i = 0; i < n_rec; i++) start[rank[contig[i]] + 1]++;
+        for (uint64_t k = 0; k < nr; k++) start[k + 1] += start[k];
+        for (uint64_t i = 0; i < n_rec; i++) canon_pos[i] = (uint32_t)start[rank[contig[i]]]++;
+    }
+    // launch order: longest record first (pure load balancing)
+    std::vector<uint32_t> sched(n_rec), ident(n_rec);
+    std::iota(sched.begin(), sched.end(), 0u);
+    std::iota(ident.begin(), ident.end(), 0u);
+    std::stable_sort(sched.begin(), sched.end(), [&](uint32_t a, uint32_t b) {
+        return (op_off[a + 1] - op_off[a]) > (op_off[b + 1] - op_off[b]);
+    });
+    // windows grouped by contig, BED order kept inside a contig
+    std::vector<uint64_t> cw_off(n_contig + 1, 0), g_st(n_win), g_en(n_win), o_st(n_win), o_en(n_win);
+    std::vector<uint32_t> g_orig(n_win);
+    std::vector<uint8_t> mono(n_contig ? n_contig : 1, 1);
+    for (uint64_t i = 0; i < n_win; i++) cw_off[w_contig[i] + 1]++;
+    for (uint32_t c = 0; c < n_contig; c++) cw_off[c + 1] += cw_off[c];
+    {
+        std::vector<uint64_t> cur(cw_off.begin(), cw_off.end() - (n_contig ? 1 : 0));
+        for (uint64_t i = 0; i < n_win; i++) {
+            const uint64_t d = cur[w_contig[i]]++;
+            g_st[d] = w_st[i];
+            g_en[d] = w_en[i];
+            g_orig[d] = (uint32_t)i;
+            o_st[i] = w_st[i];
+            o_en[i] = w_en[i];
+        }
+    }
+    for (uint32_t c = 0; c < n_contig; c++)
+        for (uint64_t i = cw_off[c] + 1; i < cw_off[c + 1]; i++)
+            if (g_st[i] < g_st[i - 1] || g_en[i] < g_en[i - 1]) mono[c] = 0;
+    int rc = RB_OK;
+    if (!rc) rc = upload_vec(ctx, sched, &pl->sched);
+    if (!rc) rc = upload_vec(ctx, ident, &pl->ident);
+    if (!rc) rc = upload_vec(ctx, canon_pos, &pl->canon_pos);
+    if (!rc) rc = upload_vec(ctx, g_st, &pl->w_st);
+    if (!rc) rc = upload_vec(ctx, g_en, &pl->w_en);
+    if (!rc) rc = upload_vec(ctx, g_orig, &pl->w_orig);
+    if (!rc) rc = upload_vec(ctx, o_st, &pl->wo_st);
+    if (!rc) rc = upload_vec(ctx, o_en, &pl->wo_en);
+    if (!rc) rc = upload_vec(ctx, cw_off, &pl->cw_off);
+    if (!rc) rc = upload_vec(ctx, mono, &pl->cw_mono);
+    if (rc) {
+        rb_plan_destroy(pl);
+        return rc;
+    }
+    *out = pl;
+    return RB_OK;
+}
+extern "C" void rb_plan_destroy(rb_plan *pl) {
+    if (!pl) return;
+    void *ptrs[] = {pl->sched, pl->ident, pl->canon_pos, pl->w_st, pl->w_en, pl->w_orig, pl->wo_st, pl->wo_en, pl->cw_off, pl->cw_mono};
+    for (void *q : ptrs)
+        if (q) hipFree(q);
+    delete pl;
+}
+
+// workspace layout: [hit_off (n_rec+1) u64][block sums][arena cursors][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
+struct ws_layout {
+    size_t hit_off, block_sums, arena, gen_list, x_st, x_en, total;
+};
+static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
+    ws_layout w;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t at = o;
+        o += (bytes + 255) & ~(size_t)255;
+        return at;
+    };
+    w.hit_off = take((n_rec + 2) * 8);
+    w.block_sums = take(rb_scan_block_sums_count(n_rec) * 8);
+    w.arena = take((size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8);
+    w.gen_list = take((rows_cap + 1) * 4);
+    w.x_st = take((rows_cap + 1) * 8);
+    w.x_en = take((rows_cap + 1) * 8);
+    w.total = o;
+    return w;
+}
+extern "C" size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap) {
+    if (!plan) return 0;
+    return ws_of(plan->n_rec, rows_cap).total;
+}
+
+static uint32_t pick_arenas(uint64_t n_rec) {
+    uint64_t a = n_rec / 256;
+    if (a < 1) a = 1;
+    if (a > RB_MAX_ARENA) a = RB_MAX_ARENA;
+    return (uint32_t)a;
+}
+
+static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b, const rb_norm_row *norm, int policy,
+                       void *workspace, rb_hit_row *rows, uint64_t rows_cap, uint32_t *out_ops, uint64_t out_cap,
+                       rb_counters *counters, bool is_break, uint32_t max_size) {
+    if (!ctx || !plan || !b || !norm || !workspace || !counters) return RB_E_INVALID;
+    if (b->n_rec != plan->n_rec) return fail(ctx, RB_E_INVALID, "plan was built for %llu records, batch has %llu", (unsigned long long)plan->n_rec, (unsigned long long)b->n_rec);
+    if (((uintptr_t)b->ops & 15u) || ((uintptr_t)out_ops & 15u)) return fail(ctx, RB_E_INVALID, "ops/out_ops must be 16-byte aligned");
+    if (rows_cap >= 0xFFFFFFFFull) return fail(ctx, RB_E_INVALID, "rows_cap too large");
+    const ws_layout w = ws_of(plan->n_rec, rows_cap);
+    char *ws = (char *)workspace;
+    rb_lift_params p;
+    memset(&p, 0, sizeof p);
+    p.n_rec = b->n_rec;
+    p.ops = b->ops;
+    p.op_off = b->op_off;
+    p.contig = b->contig;
+    p.strand = b->strand;
+    p.norm = norm;
+    p.sched = plan->sched;
+    p.canon_pos = is_break ? plan->ident : plan->canon_pos;
+    p.w_st = plan->w_st;
+    p.w_en = plan->w_en;
+    p.w_orig = plan->w_orig;
+    p.wo_st = plan->wo_st;
+    p.wo_en = plan->wo_en;
+    p.cw_off = plan->cw_off;
+    p.cw_mono = plan->cw_mono;
+    p.n_contig = plan->n_contig;
+    p.hit_off = (uint64_t *)(ws + w.hit_off);
+    p.rows = rows;
+    p.rows_cap = rows_cap;
+    p.out_ops = out_ops;
+    p.out_cap = out_cap;
+    p.arena_cur = (unsigned long long *)(ws + w.arena);
+    p.n_arena = pick_arenas(b->n_rec);
+    p.arena_size = (out_cap / p.n_arena) & ~(uint64_t)3;
+    p.gen_list = (uint32_t *)(ws + w.gen_list);
+    p.counters = counters;
+    p.policy = policy & 1;
+    p.early_exit = (policy & RB_LIFT_EARLY_EXIT) ? 1 : 0;
+    uint64_t *block_sums = (uint64_t *)(ws + w.block_sums);
+    HIPCHK(ctx, hipMemsetAsync(counters, 0, sizeof(rb_counters), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(p.arena_cur, 0, (size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8, ctx->stream));
+    if (b->n_rec == 0) return RB_OK;
+    if (is_break) {
+        rb_break_params bp;
+        bp.n_rec = b->n_rec;
+        bp.ops = b->ops;
+        bp.op_off = b->op_off;
+        bp.norm = norm;
+        bp.sched = plan->sched;
+        bp.hit_off = p.hit_off;
+        bp.x_st = (uint64_t *)(ws + w.x_st);
+        bp.x_en = (uint64_t *)(ws + w.x_en);
+        bp.rows_cap = rows_cap;
+        bp.max_size = max_size;
+        bp.fill = 0;
+        HIPCHK(ctx, rb_launch_break_pieces(&bp, ctx->stream));
+        HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, false, ctx->stream));
+        bp.fill = 1;
+        HIPCHK(ctx, rb_launch_break_pieces(&bp, ctx->stream));
+        p.x_st = bp.x_st;
+        p.x_en = bp.x_en;
+    } else {
+        HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, true, ctx->stream));
+    }
+    HIPCHK(ctx, rb_launch_liftover(&p, ctx->stream));
+    return RB_OK;
+}
+
+extern "C" int rb_dev_liftover(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *batch, const rb_norm_row *norm_rows,
+                               int bsearch_policy, void *workspace, rb_hit_row *rows, uint64_t rows_cap, uint32_t *out_ops,
+                               uint64_t out_cap, rb_counters *counters) {
+    return lift_common(ctx, plan, batch, norm_rows, bsearch_policy, workspace, rows, rows_cap, out_ops, out_cap, counters, false, 0);
+}
+extern "C" int rb_dev_break(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *batch, const rb_norm_row *norm_rows,
+                            uint32_t max_size, int bsearch_policy, void *workspace, rb_hit_row *rows, uint64_t rows_cap,
+                            uint32_t *out_ops, uint64_t out_cap, rb_counters *counters) {
+    return lift_common(ctx, plan, batch, norm_rows, bsearch_policy, workspace, rows, rows_cap, out_ops, out_cap, counters, true, max_size);
+}
+
+extern "C" int rb_dev_swap(rb_ctx *ctx, const rb_batch_view *b, uint32_t *out_ops) {
+    if (!ctx || !b || !out_ops) return RB_E_INVALID;
+    rb_swap_params p;
+    p.n_rec = b->n_rec;
+    p.ops = b->ops;
+    p.op_off = b->op_off;
+    p.strand = b->strand;
+    p.out_ops = out_ops;
+    HIPCHK(ctx, rb_launch_swap(&p, ctx->stream));
+    return RB_OK;
+}
+
+// ---- host-buffer wrappers ----------------------------------------------------------------------
+namespace {
+struct DevBatch {
+    rb_ctx *ctx;
+    rb_batch_view v{};
+    std::vector<void *> owned;
+    explicit DevBatch(rb_ctx *c) : ctx(c) {}
+    ~DevBatch() {
+        for (void *q : owned) hipFree(q);
+    }
+    template <typename T>
+    int up(const T *host, size_t n, const T **dev) {
+        void *d = nullptr;
+        int rc = rb_dev_alloc(ctx, n * sizeof(T) + 64, &d);
+        if (rc) return rc;
+        owned.push_back(d);
+        if (host && n) rc = rb_dev_upload(ctx, d, host, n * sizeof(T));
+        *dev = (const T *)d;
+        return rc;
+    }
+    template <typename T>
+    int alloc(size_t n, T **dev) {
+        void *d = nullptr;
+        int rc = rb_dev_alloc(ctx, n * sizeof(T) + 64, &d);
+        if (rc) return rc;
+        owned.push_back(d);
+        *dev = (T *)d;
+        return RB_OK;
+    }
+    int load(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st, const uint64_t *t_en,
+             const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand, const uint32_t *contig) {
+        v.n_rec = n_rec;
+        v.n_ops = n_rec ? op_off[n_rec] : 0;
+        int rc = RB_OK;
+        std::vector<uint32_t> zc;
+        std::vector<uint8_t> zs;
+        if (!contig) {
+            zc.assign(n_rec, 0);
+            contig = zc.data();
+        }
+        if (!strand) {
+            zs.assign(n_rec, (uint8_t)'+');
+            strand = zs.data();
+        }
+        if (!rc) rc = up(ops, (size_t)v.n_ops + 4, &v.ops);
+        if (!rc) rc = up(op_off, (size_t)n_rec + 1, &v.op_off);
+        if (!rc) rc = up(t_st, (size_t)n_rec, &v.t_st);
+        if (!rc) rc = up(t_en, (size_t)n_rec, &v.t_en);
+        if (!rc) rc = up(q_st, (size_t)n_rec, &v.q_st);
+        if (!rc) rc = up(q_en, (size_t)n_rec, &v.q_en);
+        if (!rc) rc = up(strand, (size_t)n_rec, &v.strand);
+        if (!rc) rc = up(contig, (size_t)n_rec, &v.contig);
+        if (!rc) rc = rb_ctx_sync(ctx); // the temporaries above must outlive the copies
+        return rc;
+    }
+};
+} // namespace
+
+extern "C" void rb_host_free(void *p) { free(p); }
+
+extern "C" int rb_host_scan_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                                    const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                                    rb_reduce_row *reduce_rows, rb_norm_row *norm_rows) {
+    if (!ctx) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBatch b(ctx);
+    int rc = b.load(n_rec, ops, op_off, t_st, t_en, q_st, q_en, strand, nullptr);
+    if (rc) return rc;
+    rb_reduce_row *d_red = nullptr;
+    rb_norm_row *d_norm = nullptr;
+    if (reduce_rows && (rc = b.alloc(n_rec, &d_red))) return rc;
+    if (norm_rows && (rc = b.alloc(n_rec, &d_norm))) return rc;
+    if ((rc = rb_dev_scan_records(ctx, &b.v, d_red, d_norm))) return rc;
+    if (reduce_rows && (rc = rb_dev_download(ctx, reduce_rows, d_red, n_rec * sizeof(rb_reduce_row)))) return rc;
+    if (norm_rows && (rc = rb_dev_download(ctx, norm_rows, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;
+    return rb_ctx_sync(ctx);
+}
+
+static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off,
+                     const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                     const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en,
+                     int policy, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows, uint32_t **out_ops, uint64_t *n_out,
+                     rb_counters *counters) {
+    if (!ctx || !rows || !n_rows || !out_ops || !n_out) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *rows = nullptr;
+    *out_ops = nullptr;
+    *n_rows = *n_out = 0;
+    DevBatch b(ctx);
+    std::vector<uint32_t> zc;
+    if (!contig) {
+        zc.assign(n_rec, 0);
+        contig = zc.data();
+    }
+    int rc = b.load(n_rec, ops, op_off, t_st, t_en, q_st, q_en, strand, contig);
+    if (rc) return rc;
+    rb_norm_row *d_norm = nullptr;
+    if ((rc = b.alloc(n_rec, &d_norm))) return rc;
+    if ((rc = rb_dev_scan_records(ctx, &b.v, nullptr, d_norm))) return rc;
+    if (norm_out && (rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;
+    rb_plan *plan = nullptr;
+    if ((rc = rb_plan_create(ctx, n_rec, op_off, contig, n_win, w_contig, w_st, w_en, &plan))) return rc;
+    rb_counters *d_cnt = nullptr;
+    if ((rc = b.alloc(1, &d_cnt))) {
+        rb_plan_destroy(plan);
+        return rc;
+    }
+    const uint64_t n_ops = n_rec ? op_off[n_rec] : 0;
+    uint64_t rows_cap = n_rec + n_win + 1024;
+    uint64_t out_cap = 2 * n_ops + 16 * rows_cap + 4096;
+    rb_counters hc;
+    memset(&hc, 0, sizeof hc);
+    void *ws = nullptr;
+    rb_hit_row *d_rows = nullptr;
+    uint32_t *d_out = nullptr;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (ws) hipFree(ws);
+        if (d_rows) hipFree(d_rows);
+        if (d_out) hipFree(d_out);
+        ws = nullptr;
+        d_rows = nullptr;
+        d_out = nullptr;
+        rc = rb_dev_alloc(ctx, rb_plan_workspace_bytes(plan, rows_cap), &ws);
+        if (!rc) rc = rb_dev_alloc(ctx, (rows_cap + 1) * sizeof(rb_hit_row), (void **)&d_rows);
+        if (!rc) rc = rb_dev_alloc(ctx, (out_cap + 4) * 4, (void **)&d_out);
+        if (rc) break;
+        rc = is_break ? rb_dev_break(ctx, plan, &b.v, d_norm, max_size, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt)
+                      : rb_dev_liftover(ctx, plan, &b.v, d_norm, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt);
+        if (rc) break;
+        rc = rb_dev_download(ctx, &hc, d_cnt, sizeof hc);
+        if (rc) break;
+        if (!hc.overflow) break;
+        rows_cap = std::max<uint64_t>(rows_cap, hc.n_hits + 16);
+        out_cap = std::max<uint64_t>(out_cap * 2, hc.out_ops_needed + hc.out_ops_needed / 4 + 4096);
+        rc = RB_E_CAPACITY;
+    }
+    if (!rc && hc.overflow) rc = RB_E_CAPACITY;
+    if (!rc) {
+        *n_rows = hc.n_hits;
+        *rows = (rb_hit_row *)malloc((size_t)(hc.n_hits + 1) * sizeof(rb_hit_row));
+        // compact the clipped cigars to a dense host array in row order
+        std::vector<rb_hit_row> hr((size_t)hc.n_hits);
+        if (hc.n_hits) rc = rb_dev_download(ctx, hr.data(), d_rows, (size_t)hc.n_hits * sizeof(rb_hit_row));
+        uint64_t total = 0;
+        for (auto &h : hr) total += h.status == RB_ST_OK ? h.out_n : 0;
+        *out_ops = (uint32_t *)malloc((size_t)(total + 1) * 4);
+        std::vector<uint32_t> dev_out;
+        if (!rc && hc.n_hits) {
+            uint64_t hi = 0;
+            for (auto &h : hr)
+                if (h.status == RB_ST_OK) hi = std::max<uint64_t>(hi, h.out_off + h.out_n);
+            dev_out.resize((size_t)hi + 4);
+            if (hi) rc = rb_dev_download(ctx, dev_out.data(), d_out, (size_t)hi * 4);
+        }
+        uint64_t o = 0;
+        for (size_t i = 0; i < hr.size() && !rc; i++) {
+            rb_hit_row h = hr[i];
+            if (h.status == RB_ST_OK) {
+                memcpy(*out_ops + o, dev_out.data() + h.out_off, (size_t)h.out_n * 4);
+                h.out_off = o;
+                o += h.out_n;
+            } else {
+                h.out_off = 0;
+                h.out_n = 0;
+            }
+            (*rows)[i] = h;
+        }
+        *n_out = o;
+        if (counters) *counters = hc;
+    }
+    if (ws) hipFree(ws);
+    if (d_rows) hipFree(d_rows);
+    if (d_out) hipFree(d_out);
+    rb_plan_destroy(plan);
+    if (rc) {
+        free(*rows);
+        free(*out_ops);
+        *rows = nullptr;
+        *out_ops = nullptr;
+        *n_rows = *n_out = 0;
+    }
+    return rc;
+}
+
+extern "C" int rb_host_liftover(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                                const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                                const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
+                                const uint64_t *w_en, int policy, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows,
+                                uint32_t **out_ops, uint64_t *n_out, rb_counters *counters) {
+    return host_lift(ctx, false, 0, n_rec, ops, op_off, t_st, t_en, q_st, q_en, strand, contig, n_win, w_contig, w_st, w_en, policy,
+                     norm_out, rows, n_rows, out_ops, n_out, counters);
+}
+extern "C" int rb_host_break(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                             const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand, uint32_t max_size,
+                             int policy, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows, uint32_t **out_ops,
+                             uint64_t *n_out, rb_counters *counters) {
+    return host_lift(ctx, true, max_size, n_rec, ops, op_off, t_st, t_en, q_st, q_en, strand, nullptr, 0, nullptr, nullptr, nullptr,
+                     policy, norm_out, rows, n_rows, out_ops, n_out, counters);
+}
+
+extern "C" int rb_host_swap(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint8_t *strand,
+                            uint32_t *out_ops) {
+    if (!ctx) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    DevBatch b(ctx);
+    std::vector<uint64_t> z(n_rec, 0);
+    int rc = b.load(n_rec, ops, op_off, z.data(), z.data(), z.data(), z.data(), strand, nullptr);
+    if (rc) return rc;
+    uint32_t *d_out = nullptr;
+    const uint64_t n_ops = n_rec ? op_off[n_rec] : 0;
+    if ((rc = b.alloc((size_t)n_ops + 4, &d_out))) return rc;
+    if ((rc = rb_dev_swap(ctx, &b.v, d_out))) return rc;
+    return rb_dev_download(ctx, out_ops, d_out, (size_t)n_ops * 4);
+}
+
+// ---- synthetic workload --------------------------------------------------------------------------
+#include "synth.h"
+extern "C" uint32_t rb_synth_n_ops(uint64_t seed, uint64_t record, uint32_t lo, uint32_t hi) { return rb_synth_n_ops_impl(seed, record, lo, hi); }
+extern "C" void rb_synth_fill_ops_host(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops) {
+    for (uint64_t r = 0; r < n_rec; r++) {
+        const uint64_t n = op_off[r + 1] - op_off[r];
+        for (uint64_t j = 0; j < n; j++) ops[op_off[r] + j] = rb_synth_op(seed, first_record + r, j);
+    }
+}
+extern "C" int rb_dev_synth_fill_ops(rb_ctx *ctx, uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off_dev,
+                                     uint32_t *ops_dev) {
+    if (!ctx) return RB_E_INVALID;
+    HIPCHK(ctx, rb_launch_synth(seed, first_record, n_rec, op_off_dev, ops_dev, ctx->stream));
+    return RB_OK;
+}

@@ -1,0 +1,181 @@
+// k_misc.hip -- break-paf piece enumeration, invert (swap), synthetic workload fill (gfx950).
+#include "rb_device.h"
+#include "synth.h"
+
+// ------------------------------------------------------------------------------------------------
+// break-paf (liftover.rs:182-226): every I/D longer than max_size closes the window [pre, cur) on
+// the target and opens the next one after it.  In op space, with Rx the reference offset of op i:
+//   big(i)   = indel(i) && len(i) > max_size
+//   pre(i)   = max over big j < i of (Rx(j) + reflen(j))          (0 if none; Rx is monotone)
+//   piece(i) = big(i) && Rx(i) > pre(i)  ->  window [t_st + pre(i), t_st + Rx(i))
+//   and a final window [t_st + pre(n), t_st + Rtot) if Rtot > pre(n).
+// One wavefront per record, streaming; a prefix-sum (ref offsets, piece ordinals) and a prefix-max
+// (pre) per 256-op step.  Run twice: count, then fill after the exclusive scan of the counts.
+// ------------------------------------------------------------------------------------------------
+struct rb_break_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const rb_norm_row *norm;
+    const uint32_t *sched;
+    uint64_t *hit_off;
+    uint64_t *x_st, *x_en;
+    uint64_t rows_cap;
+    uint32_t max_size;
+    int fill;
+};
+
+__device__ __forceinline__ uint32_t rb_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t rb_wave_scan_incl_max(uint32_t v) {
+    v = rb_umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v = rb_umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v = rb_umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v = rb_umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(8), 0xf, 0xf, false));
+    v = rb_umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_BCAST15, 0xa, 0xf, false));
+    v = rb_umax(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_BCAST31, 0xc, 0xf, false));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave >= p.n_rec) return;
+    const int lane = rb_lane();
+    const uint32_t r = rb_first(p.sched[wave]);
+    const rb_norm_row *nr = &p.norm[r];
+    if (nr->status != RB_ST_OK) {
+        if (!p.fill && lane == 0) p.hit_off[r] = 0;
+        return;
+    }
+    const uint32_t n = nr->n_ops;
+    const uint64_t t_st = nr->t_st;
+    const uint64_t rec0 = p.op_off[r] + nr->first_op;
+    const uint64_t h0 = p.fill ? rb_first64(p.hit_off[r]) : 0;
+    const uint64_t g0 = rec0 & ~3ull, gend = rec0 + n;
+    const uint64_t n_steps = (gend - g0 + 255u) >> 8;
+    uint32_t Rb = 0, pre = 0, cnt = 0; // ref bases so far, end of the last big indel, pieces so far
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    {
+        const uint64_t gi = g0 + (uint64_t)lane * 4u;
+        if (gi < gend) cur = *reinterpret_cast<const uint4 *>(p.ops + gi);
+    }
+    for (uint64_t st = 0; st < n_steps; st++) {
+        const uint64_t gi = g0 + (st << 8) + (uint64_t)lane * 4u;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (gi + 256u < gend) nxt = *reinterpret_cast<const uint4 *>(p.ops + gi + 256u);
+        const int32_t idx0 = (int32_t)((int64_t)gi - (int64_t)rec0);
+        const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t rl[4], Rx[4];
+        bool big[4];
+        uint32_t sr = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool valid = (uint32_t)(idx0 + q) < n;
+            const uint32_t opc = valid ? rb_opc(raw[q]) : RB_NULL_OP, len = valid ? rb_len(raw[q]) : 0u;
+            rl[q] = (opc <= 8u && rb_in(RB_REF_MASK, opc)) ? len : 0u;
+            big[q] = valid && (opc == RB_OP_I || opc == RB_OP_D) && len > p.max_size;
+            Rx[q] = sr;
+            sr += rl[q];
+        }
+        const uint32_t ir = rb_wave_scan_incl(sr);
+        const uint32_t er = Rb + ir - sr;
+        // lane-local: end of the last big indel inside the lane (absolute offsets are monotone)
+        uint32_t lane_end = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            Rx[q] += er;
+            if (big[q]) lane_end = Rx[q] + rl[q];
+        }
+        const uint32_t im = rb_wave_scan_incl_max(lane_end);
+        uint32_t run_pre = rb_umax(pre, rb_prev_lane(im, 0u)); // end of the last big indel before this lane
+        uint32_t pc[4], pst[4];
+        uint32_t lane_cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const bool piece = big[q] && Rx[q] > run_pre;
+            pc[q] = piece ? 1u : 0u;
+            pst[q] = run_pre;
+            lane_cnt += pc[q];
+            if (big[q]) run_pre = Rx[q] + rl[q];
+        }
+        const uint32_t ic = rb_wave_scan_incl(lane_cnt);
+        if (p.fill) {
+            uint32_t ord = cnt + ic - lane_cnt;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (pc[q]) {
+                    const uint64_t h = h0 + ord;
+                    if (h < p.rows_cap) {
+                        p.x_st[h] = t_st + pst[q];
+                        p.x_en[h] = t_st + Rx[q];
+                    }
+                    ord++;
+                }
+            }
+        }
+        cnt += rb_readlane<uint32_t>(ic, 63);
+        pre = rb_umax(pre, rb_readlane<uint32_t>(im, 63));
+        Rb += rb_readlane<uint32_t>(ir, 63);
+        cur = nxt;
+    }
+    const bool last = Rb > pre; // liftover.rs:213-224
+    if (lane == 0) {
+        if (p.fill) {
+            if (last && h0 + cnt < p.rows_cap) {
+                p.x_st[h0 + cnt] = t_st + pre;
+                p.x_en[h0 + cnt] = t_st + Rb;
+            }
+        } else {
+            p.hit_off[r] = (uint64_t)cnt + (last ? 1u : 0u);
+        }
+    }
+}
+
+extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_break_pieces, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// invert: cigar_swap_target_query (paf.rs:1050-1065): I <-> D, reversed when the strand is '-'
+// ------------------------------------------------------------------------------------------------
+struct rb_swap_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint8_t *strand;
+    uint32_t *out_ops;
+};
+__global__ __launch_bounds__(256) void rb_k_swap(rb_swap_params p) {
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave >= p.n_rec) return;
+    const uint64_t o0 = p.op_off[wave], n = p.op_off[wave + 1] - o0;
+    const bool minus = p.strand[wave] == (uint8_t)'-';
+    for (uint64_t j = rb_lane(); j < n; j += 64) {
+        uint32_t v = p.ops[o0 + (minus ? n - 1 - j : j)];
+        const uint32_t opc = rb_opc(v);
+        if (opc == RB_OP_I) v = (v & ~15u) | RB_OP_D;
+        else if (opc == RB_OP_D) v = (v & ~15u) | RB_OP_I;
+        p.out_ops[o0 + j] = v;
+    }
+}
+extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_swap, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// synthetic workload
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rb_k_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops) {
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave >= n_rec) return;
+    const uint64_t o0 = op_off[wave], n = op_off[wave + 1] - o0;
+    for (uint64_t j = rb_lane(); j < n; j += 64) ops[o0 + j] = rb_synth_op(seed, first_record + wave, j);
+}
+extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops, hipStream_t stream) {
+    if (n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_synth, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, stream, seed, first_record, n_rec, op_off, ops);
+    return hipGetLastError();
+}

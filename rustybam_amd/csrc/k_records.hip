@@ -1,0 +1,231 @@
+// k_records.hip -- K1: one streaming pass over every record's CIGAR (gfx950, wave64).
+//
+// One wavefront per record.  Each lane loads 4 packed ops (16 B, coalesced 1 KiB per wave
+// instruction) per step, accumulates per-class length sums, the bamstats counters and the
+// "regular" flags; a single cross-lane reduction at the end of the record produces
+//   rb_reduce_row  = infer_n_bases + check_integrity (paf.rs:631-654, :825-857) on the record as
+//                    loaded (Paf::from_file, paf.rs:70) + add_stats_from_cigar (bamstats.rs:107-142)
+//   rb_norm_row    = remove_trailing_indels (paf.rs:656-783): kept op range, shifted coordinates
+//                    (including the quirks at :668-701 and the strand swap :764-769) and the
+//                    check_integrity().unwrap() outcome at :782.
+// Roofline: HBM read, 4 B per op + 48 B header per record; 128 B of rows written per record.
+#include "rb_device.h"
+
+struct rb_scan_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint64_t *t_st, *t_en, *q_st, *q_en;
+    const uint8_t *strand;
+    rb_reduce_row *reduce_rows;
+    rb_norm_row *norm_rows;
+};
+
+struct rb_acc {
+    uint64_t len[9]; // per op code length sums
+    uint32_t ins_events, del_events;
+    uint32_t bad; // bit0: op outside M I D = X, bit1: zero length, bit2: adjacent ops of one type, bit3: code > 8
+};
+
+__device__ __forceinline__ void rb_acc_op(rb_acc &a, uint32_t v, bool valid, uint32_t prev_opc) {
+    uint32_t opc = valid ? rb_opc(v) : RB_NULL_OP;
+    uint32_t len = valid ? rb_len(v) : 0u;
+#pragma unroll
+    for (uint32_t t = 0; t < 9; t++) a.len[t] += (opc == t) ? len : 0u;
+    a.ins_events += (opc == RB_OP_I) ? 1u : 0u;
+    a.del_events += (opc == RB_OP_D) ? 1u : 0u;
+    if (valid) {
+        if (!rb_in(RB_REGULAR_MASK, opc)) a.bad |= 1u;
+        if (len == 0) a.bad |= 2u;
+        if (opc == prev_opc) a.bad |= 4u;
+        if (opc > 8u) a.bad |= 8u;
+    }
+}
+
+__global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave >= p.n_rec) return;
+    const uint64_t r = rb_first64(wave);
+    const int lane = rb_lane();
+    const uint64_t o0 = p.op_off[r], o1 = p.op_off[r + 1];
+    const uint64_t n = o1 - o0;
+
+    rb_acc a;
+#pragma unroll
+    for (int t = 0; t < 9; t++) a.len[t] = 0;
+    a.ins_events = a.del_events = 0;
+    a.bad = 0;
+
+    // ---- streaming pass: aligned 16-byte loads, 256 ops per wave step ----
+    const uint64_t g0 = o0 & ~3ull;
+    const uint64_t n_steps = (o1 - g0 + 255u) >> 8;
+    uint32_t carry_opc = RB_NULL_OP; // op code of the last op of the previous step
+    uint4 cur = make_uint4(0, 0, 0, 0);
+    {
+        uint64_t gi = g0 + (uint64_t)lane * 4u;
+        if (n_steps > 0 && gi < o1) cur = *reinterpret_cast<const uint4 *>(p.ops + gi);
+    }
+    for (uint64_t s = 0; s < n_steps; s++) {
+        const uint64_t gi = g0 + (s << 8) + (uint64_t)lane * 4u;
+        uint4 nxt = make_uint4(0, 0, 0, 0);
+        if (s + 1 < n_steps && gi + 256u < o1) nxt = *reinterpret_cast<const uint4 *>(p.ops + gi + 256u);
+        const bool v0 = gi + 0 >= o0 && gi + 0 < o1;
+        const bool v1 = gi + 1 >= o0 && gi + 1 < o1;
+        const bool v2 = gi + 2 >= o0 && gi + 2 < o1;
+        const bool v3 = gi + 3 >= o0 && gi + 3 < o1;
+        const uint32_t c0 = v0 ? rb_opc(cur.x) : RB_NULL_OP;
+        const uint32_t c1 = v1 ? rb_opc(cur.y) : RB_NULL_OP;
+        const uint32_t c2 = v2 ? rb_opc(cur.z) : RB_NULL_OP;
+        const uint32_t c3 = v3 ? rb_opc(cur.w) : RB_NULL_OP;
+        const uint32_t pl = rb_prev_lane(c3, carry_opc);
+        rb_acc_op(a, cur.x, v0, pl);
+        rb_acc_op(a, cur.y, v1, c0);
+        rb_acc_op(a, cur.z, v2, c1);
+        rb_acc_op(a, cur.w, v3, c2);
+        carry_opc = rb_readlane<uint32_t>(c3, 63);
+        cur = nxt;
+    }
+
+    // ---- cross-lane reduction ----
+    uint64_t L[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) L[t] = rb_wave_sum_u64(a.len[t]);
+    const uint32_t ins_events = rb_wave_sum_u32(a.ins_events);
+    const uint32_t del_events = rb_wave_sum_u32(a.del_events);
+    const uint32_t bad = rb_wave_or_u32(a.bad);
+    if (lane != 0) return;
+
+    const uint64_t R = L[RB_OP_M] + L[RB_OP_D] + L[RB_OP_N] + L[RB_OP_EQ] + L[RB_OP_X];
+    const uint64_t Q = L[RB_OP_M] + L[RB_OP_I] + L[RB_OP_S] + L[RB_OP_EQ] + L[RB_OP_X];
+    const uint64_t M = L[RB_OP_M] + L[RB_OP_EQ] + L[RB_OP_X];
+    uint64_t U = 0;
+#pragma unroll
+    for (int t = 0; t < 9; t++) U += L[t];
+    const uint64_t t_st = p.t_st[r], t_en = p.t_en[r], q_st = p.q_st[r], q_en = p.q_en[r];
+    const bool minus = p.strand && p.strand[r] == (uint8_t)'-';
+    uint32_t flags = 0;
+    if (bad == 0 && U <= 0xFFFFFFFFull) flags |= RB_F_REGULAR;
+    if (L[RB_OP_M] != 0) flags |= RB_F_HAS_M;
+
+    if (p.reduce_rows) {
+        rb_reduce_row w;
+        w.t_bases = R;
+        w.q_bases = Q;
+        w.nmatch = (uint32_t)M;
+        w.aln_len = (uint32_t)U;
+        // bamstats.rs:107-127, u32 counters
+        w.equal = (uint32_t)L[RB_OP_EQ];
+        w.diff = (uint32_t)(L[RB_OP_X] + L[RB_OP_M]);
+        w.ins = (uint32_t)L[RB_OP_I];
+        w.del = (uint32_t)L[RB_OP_D];
+        w.matches = (uint32_t)L[RB_OP_M];
+        w.ins_events = ins_events;
+        w.del_events = del_events;
+        // bamstats.rs:138-142: (100.0 * equal as f32) / (u32 sum) as f32
+        const float num = 100.0f * (float)w.equal;
+        w.id_by_all = num / (float)(uint32_t)(w.equal + w.diff + w.del + w.ins);
+        w.id_by_events = num / (float)(uint32_t)(w.equal + w.diff + w.del_events + w.ins_events);
+        w.id_by_matches = num / (float)(uint32_t)(w.equal + w.diff);
+        uint32_t st = RB_ST_OK;
+        if (U > 0xFFFFFFFFull)
+            st = RB_ST_PANIC_OVERFLOW;
+        else if (t_en < t_st || t_en - t_st != R)
+            st = RB_ST_PANIC_INTEGRITY_T;
+        else if (q_en < q_st || q_en - q_st != Q)
+            st = RB_ST_PANIC_INTEGRITY_Q;
+        w.status = st;
+        w.flags = flags;
+        p.reduce_rows[r] = w;
+    }
+
+    if (p.norm_rows) {
+        rb_norm_row w;
+        w.t_st = w.t_en = w.q_st = w.q_en = 0;
+        w.first_op = w.n_ops = w.lead_ops = w.trail_ops = w.nmatch = w.aln_len = 0;
+        w.flags = flags;
+        uint32_t st = RB_ST_OK;
+        if (n == 0) {
+            st = RB_ST_PANIC_EMPTY_CIGAR; // paf.rs:663
+        } else {
+            // paf.rs:663-701 leading run (serial: almost always zero iterations)
+            const uint32_t *ops = p.ops + o0;
+            uint64_t lead = 0, rm_st_t = 0, rm_st_q = 0;
+            uint32_t prev = RB_NULL_OP;
+            uint64_t lead_len = 0;
+            while (lead < n && rb_in(RB_INDEL_MASK, rb_opc(ops[lead]))) {
+                const uint32_t opc = rb_opc(ops[lead]), len = rb_len(ops[lead]);
+                if (opc == RB_OP_D) {
+                    rm_st_t += len;
+                    rm_st_q += 1; // :673
+                } else {
+                    rm_st_q += len;
+                }
+                if (prev != RB_NULL_OP && prev != opc) { // :690-701 D/I or I/D neighbours
+                    rm_st_t += 1;
+                    rm_st_q -= 1;
+                }
+                prev = opc;
+                lead_len += len;
+                lead++;
+            }
+            uint64_t trail = 0, rm_en_t = 0, rm_en_q = 0, trail_len = 0;
+            while (trail < n && rb_in(RB_INDEL_MASK, rb_opc(ops[n - 1 - trail]))) { // :704-723
+                const uint32_t opc = rb_opc(ops[n - 1 - trail]), len = rb_len(ops[n - 1 - trail]);
+                if (opc == RB_OP_D)
+                    rm_en_t += len;
+                else
+                    rm_en_q += len;
+                trail_len += len;
+                trail++;
+            }
+            w.lead_ops = (uint32_t)lead;
+            w.trail_ops = (uint32_t)trail;
+            if (lead || trail) w.flags |= RB_F_STRIPPED;
+            if (lead + trail > n) {
+                st = RB_ST_PANIC_ALL_INDEL; // :757
+            } else {
+                // stripped ops are I/D: D lengths leave R, I lengths leave Q
+                uint64_t dR = 0, dQ = 0;
+                for (uint64_t i = 0; i < lead; i++) {
+                    if (rb_opc(ops[i]) == RB_OP_D) dR += rb_len(ops[i]); else dQ += rb_len(ops[i]);
+                }
+                for (uint64_t i = 0; i < trail; i++) {
+                    if (rb_opc(ops[n - 1 - i]) == RB_OP_D) dR += rb_len(ops[n - 1 - i]); else dQ += rb_len(ops[n - 1 - i]);
+                }
+                const uint64_t Rn = R - dR, Qn = Q - dQ, Un = U - lead_len - trail_len;
+                uint64_t nt_st = t_st + rm_st_t, nt_en = t_en - rm_en_t; // :760-761
+                if (minus) { // :764-766
+                    const uint64_t t = rm_st_q;
+                    rm_st_q = rm_en_q;
+                    rm_en_q = t;
+                }
+                uint64_t nq_st = q_st + rm_st_q, nq_en = q_en - rm_en_q; // :768-769
+                if (Un > 0xFFFFFFFFull)
+                    st = RB_ST_PANIC_OVERFLOW;
+                else if (nt_en < nt_st || nt_en - nt_st != Rn)
+                    st = RB_ST_PANIC_INTEGRITY_T; // :782
+                else if (nq_en < nq_st || nq_en - nq_st != Qn)
+                    st = RB_ST_PANIC_INTEGRITY_Q;
+                if (st == RB_ST_OK) {
+                    w.t_st = nt_st;
+                    w.t_en = nt_en;
+                    w.q_st = nq_st;
+                    w.q_en = nq_en;
+                    w.first_op = (uint32_t)lead;
+                    w.n_ops = (uint32_t)(n - lead - trail);
+                    w.nmatch = (uint32_t)M;
+                    w.aln_len = (uint32_t)Un;
+                }
+            }
+        }
+        w.status = st;
+        p.norm_rows[r] = w;
+    }
+}
+
+extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    const uint64_t blocks = (p->n_rec + 3) / 4;
+    hipLaunchKernelGGL(rb_k_scan_records, dim3((unsigned)blocks), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}

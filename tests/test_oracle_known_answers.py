@@ -1,0 +1,175 @@
+"""Pins the CPU oracle against the reference's own known-answer tests (tests/golden/known_answers.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from rbtest_util import pack, recs_from_lines, unpack
+
+
+@pytest.fixture(scope="module")
+def ka(golden):
+    return json.load(open(os.path.join(golden, "known_answers.json")))
+
+
+def _paf(tmp_path, lines, name="in.paf"):
+    p = tmp_path / name
+    p.write_text("".join(ln + "\n" for ln in lines))
+    return str(p)
+
+
+def _parse_out(out):
+    rows = []
+    for ln in out.decode().splitlines():
+        t = ln.split("\t")
+        rows.append(dict(q_st=int(t[2]), q_en=int(t[3]), strand=t[4], t_st=int(t[7]), t_en=int(t[8]),
+                         nmatch=int(t[9]), aln_len=int(t[10]), id=t[12][5:], cigar=t[13][5:]))
+    return rows
+
+
+@pytest.mark.parametrize("policy", ["modern", "legacy"])
+def test_ka1_liftover_cli(oracle, ka, tmp_path, policy):
+    k = ka["KA1_liftover"]
+    paf = _paf(tmp_path, k["records"])
+    bed = tmp_path / "w.bed"
+    bed.write_text("".join(f"{c}\t{s}\t{e}\tw{i}\n" for i, (c, s, e) in enumerate(k["windows"])))
+    rc, out = oracle.cli("--bsearch", policy, "liftover", "--bed", bed, paf)
+    assert rc == 0
+    rows = _parse_out(out)
+    nw = len(k["windows"])
+    assert len(rows) == 2 * nw  # record-major: forward record x windows, then reverse record x windows
+    for w in range(nw):
+        for s in range(2):
+            got = rows[s * nw + w]
+            assert (got["q_st"], got["q_en"]) == (k["q_st"][2 * w + s], k["q_en"][2 * w + s]), (w, s, got)
+    # quirk 9.3.3: the window strictly containing the record returns it with its OWN (empty) id
+    assert rows[5]["id"] == "" and rows[2]["id"] == "w2"
+
+
+def test_ka1_liftover_arrays(oracle, ka):
+    k = ka["KA1_liftover"]
+    r = recs_from_lines(k["records"])
+    b = oracle.Batch(*r.arrays(), r.contig)
+    wc = np.zeros(len(k["windows"]), np.uint32)
+    ws = np.array([w[1] for w in k["windows"]], np.uint64)
+    we = np.array([w[2] for w in k["windows"]], np.uint64)
+    for pol in (oracle.MODERN, oracle.LEGACY):
+        rows, ops = oracle.liftover(b, wc, ws, we, pol)
+        assert len(rows) == 12 and (rows["status"] == 0).all()
+        for i, row in enumerate(rows):
+            rec, win = int(row["rec"]), int(row["win"])
+            assert (int(row["q_st"]), int(row["q_en"])) == (k["q_st"][2 * win + rec], k["q_en"][2 * win + rec])
+        assert rows["flags"][5] & 1 and not rows["flags"][2] & 1
+
+
+@pytest.mark.parametrize("policy", ["modern", "legacy"])
+def test_ka2_break(oracle, ka, tmp_path, policy):
+    k = ka["KA2_break"]
+    rc, out = oracle.cli("--bsearch", policy, "break-paf", "--max-size", k["break_length"], _paf(tmp_path, [k["record"]]))
+    assert rc == 0
+    rows = _parse_out(out)
+    assert len(rows) == k["expect_n_pieces"]
+    for r in rows:
+        assert r["t_en"] - r["t_st"] == k["expect_piece_t_span"]
+
+
+def test_ka3_trim_pair(oracle, ka):
+    k = ka["KA3_trim_pair"]
+    r = recs_from_lines([k["left"], k["right"]])
+    b = oracle.Batch(*r.arrays(), r.contig)
+    rows, ops = oracle.overlap_split(b, [0], [1], tuple(k["scores"]))
+    assert rows["status"][0] == 0
+    got = [unpack(ops[int(rows["out_off"][0][s]):int(rows["out_off"][0][s]) + int(rows["out_n"][0][s])]) for s in (0, 1)]
+    assert got == [k["left_cigar"], k["right_cigar"]]
+    assert int(rows["split_idx"][0]) == 2 and int(rows["split_score"][0]) == 5
+
+
+@pytest.mark.parametrize("policy", ["modern", "legacy"])
+def test_ka4_trim_paf(oracle, ka, tmp_path, policy):
+    k = ka["KA4_trim_paf"]
+    rc, out = oracle.cli("--bsearch", policy, "trim-paf", _paf(tmp_path, k["records"]))
+    assert rc == 0
+    assert [r["cigar"] for r in _parse_out(out)] == k["cigars"]
+
+
+def test_ka5_stats(oracle, ka):
+    k = ka["KA5_stats"]
+    ops = pack(k["cigar"])
+    b = oracle.Batch(ops, [0, len(ops)], [0], [20], [0], [20], [ord("+")])
+    row = oracle.reduce(b)[0]
+    assert abs(float(row["id_by_all"]) - k["id_by_all"]) < 1e-10
+    assert row["status"] == 0
+
+
+def test_ka7_fixture_loads(oracle, ka, golden):
+    rc, out = oracle.cli("stats", "--paf", os.path.join(golden, ka["KA7_fixture"]["file"]))
+    assert rc == 0
+    assert out.count(b"\n") == ka["KA7_fixture"]["n_records"] + 1  # 249 records pass check_integrity + header
+
+
+def test_ka8_ka10_cigar_text(oracle, ka, tmp_path):
+    rc, out = oracle.cli("invert", _paf(tmp_path, [ka["KA8_fake_rec"]["line"]]))
+    assert rc == 0  # 4M1I1D3= on '-': I<->D then reversed
+    assert _parse_out(out)[0]["cigar"] == "3=1I1D4M"
+    for cg in ka["KA10_cigar_parse"]["cigars"] + [ka["KA8_fake_rec"]["cigar"]]:
+        assert unpack(pack(cg)) == cg
+        r, q = 0, 0
+        line = f"Q 1000000 0 {sum(int(v) >> 4 for v in pack(cg) if (int(v) & 15) in (0, 1, 4, 7, 8))} + T 1000000 0 " \
+               f"{sum(int(v) >> 4 for v in pack(cg) if (int(v) & 15) in (0, 2, 3, 7, 8))} 0 0 60 cg:Z:{cg}"
+        rc, out = oracle.cli("trim-paf", _paf(tmp_path, [line], "one.paf"))
+        assert rc == 0 and _parse_out(out)[0]["cigar"] == cg
+
+
+def test_ka9_predicates(oracle):
+    L = oracle.lib()
+    X, M, EQ, I, D = 8, 0, 7, 1, 2
+    assert L.rbo_consumes_query(X) and L.rbo_is_match(M) and L.rbo_is_match(X) and L.rbo_is_match(EQ)
+    assert not L.rbo_is_match(I) and not L.rbo_consumes_reference(I) and not L.rbo_consumes_query(D)
+
+
+def test_ka11_bed(oracle, ka, golden, tmp_path):
+    # 10 regions from the 11-line fixture: `liftover` with every record must see exactly 10 windows;
+    # checked through the default id rule as well
+    paf = os.path.join(golden, "asm_small.paf")
+    rc, out = oracle.cli("liftover", "--bed", os.path.join(golden, ka["KA11_bed"]["file"]), paf)
+    assert rc == 0 and out.count(b"\n") == 12
+    bed = tmp_path / "d.bed"
+    bed.write_text("T\t13\t18\n")
+    rc, out = oracle.cli("liftover", "--bed", bed, _paf(tmp_path, ["Q 10 2 10 + T 40 12 20 3 9 60 cg:Z:4M1I1=1D2="]))
+    assert _parse_out(out)[0]["id"] == "T:14-18"  # bed.rs:150-153 default id = name:st+1-en
+
+
+def test_ka12_gz_same_as_plain(oracle, golden):
+    a = oracle.cli("stats", "--paf", os.path.join(golden, "asm_small.paf"))
+    b = oracle.cli("stats", "--paf", os.path.join(golden, "asm_small.paf.gz"))
+    assert a == b and a[0] == 0
+
+
+def test_f32_display(oracle):
+    # Rust `{}` on f32: shortest round trip, positional, "NaN"; checked here against numpy's shortest repr
+    rng = np.random.default_rng(7)
+    assert oracle.f32_display(100.0) == "100" and oracle.f32_display(float("nan")) == "NaN"
+    assert oracle.f32_display(99.89702) == "99.89702" and oracle.f32_display(0.0) == "0"
+    e = rng.integers(0, 2 ** 31 - 1, 3000, dtype=np.int64)
+    s = e + rng.integers(0, 2 ** 20, 3000)
+    vals = (np.float32(100.0) * e.astype(np.float32)) / s.astype(np.float32)
+    for v in vals:
+        want = np.format_float_positional(np.float32(v), unique=True, trim="-")
+        assert oracle.f32_display(float(v)) == want, (v, want)
+
+
+def test_remove_trailing_indels_quirks(oracle):
+    """leading I shifts the query (end on '-'), leading D makes the reference panic."""
+    rows = oracle.normalize(oracle.Batch(pack("2I5=3D"), [0, 3], [100], [108], [10], [17], [ord("+")]))
+    r = rows[0]
+    assert r["status"] == 0 and (r["t_st"], r["t_en"], r["q_st"], r["q_en"]) == (100, 105, 12, 17)
+    assert (r["first_op"], r["n_ops"], r["lead_ops"], r["trail_ops"]) == (1, 1, 1, 1)
+    r = oracle.normalize(oracle.Batch(pack("2I5=3D"), [0, 3], [100], [108], [10], [17], [ord("-")]))[0]
+    assert r["status"] == 0 and (r["q_st"], r["q_en"]) == (10, 15)
+    r = oracle.normalize(oracle.Batch(pack("2D5="), [0, 2], [100], [107], [10], [15], [ord("+")]))[0]
+    assert r["status"] == oracle.PANIC_INTEGRITY_Q
+    r = oracle.normalize(oracle.Batch(pack("2D3I"), [0, 2], [100], [102], [10], [13], [ord("+")]))[0]
+    assert r["status"] == oracle.PANIC_ALL_INDEL
+    r = oracle.normalize(oracle.Batch(np.zeros(0, np.uint32), [0, 0], [1], [1], [1], [1], [ord("+")]))[0]
+    assert r["status"] == oracle.PANIC_EMPTY_CIGAR
