@@ -168,6 +168,11 @@ void rb_ctx_destroy(rb_ctx *ctx);
 const char *rb_ctx_last_error(const rb_ctx *ctx);
 int rb_ctx_sync(rb_ctx *ctx);
 void *rb_ctx_stream(rb_ctx *ctx);
+/* Measurement aid: when enabled, every rb_dev_liftover / rb_dev_break call brackets its dominant
+ * (streaming clip) kernel with HIP events on the context's stream.  rb_ctx_get_timing synchronises
+ * and returns the per-call durations in milliseconds, oldest first (ring of the last 256 calls). */
+int rb_ctx_set_timing(rb_ctx *ctx, int enabled);
+int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_out);
 
 /* device memory helpers for hosts without their own allocator (the C++ host and ctypes tests) */
 int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr);

@@ -118,6 +118,59 @@ class Engine:
     def sync(self):
         self._chk(self.L.rb_ctx_sync(self.ctx), "rb_ctx_sync")
 
+    # ---- device-pointer level (bench.py: buffers are torch tensors already resident in HBM) ----
+    def set_timing(self, on=True):
+        self._chk(self.L.rb_ctx_set_timing(self.ctx, C.c_int(1 if on else 0)), "rb_ctx_set_timing")
+
+    def get_timing(self):
+        buf = (C.c_double * 256)()
+        n = C.c_int()
+        self._chk(self.L.rb_ctx_get_timing(self.ctx, buf, C.c_int(256), C.byref(n)), "rb_ctx_get_timing")
+        return [buf[i] for i in range(n.value)]
+
+    @staticmethod
+    def batch_view(n_rec, n_ops, ops, op_off, t_st, t_en, q_st, q_en, strand, contig):
+        """All arguments after n_ops are raw device addresses (ints)."""
+        return BatchView(n_rec, n_ops, ops, op_off, t_st, t_en, q_st, q_en, strand, contig)
+
+    def dev_synth_fill_ops(self, seed, first_record, n_rec, op_off_ptr, ops_ptr):
+        self._chk(self.L.rb_dev_synth_fill_ops(self.ctx, C.c_uint64(seed), C.c_uint64(first_record), C.c_uint64(n_rec),
+                                               C.c_void_p(op_off_ptr), C.c_void_p(ops_ptr)), "rb_dev_synth_fill_ops")
+
+    def dev_scan_records(self, view, reduce_ptr, norm_ptr):
+        self._chk(self.L.rb_dev_scan_records(self.ctx, C.byref(view), C.c_void_p(reduce_ptr or 0),
+                                             C.c_void_p(norm_ptr or 0)), "rb_dev_scan_records")
+
+    def plan_create(self, op_off, contig, w_contig=None, w_st=None, w_en=None):
+        op_off, contig = _arr(op_off, np.uint64), _arr(contig, np.uint32)
+        nw = 0 if w_st is None else len(w_st)
+        wc = _arr(w_contig if nw else np.zeros(0), np.uint32)
+        ws = _arr(w_st if nw else np.zeros(0), np.uint64)
+        we = _arr(w_en if nw else np.zeros(0), np.uint64)
+        plan = C.c_void_p()
+        self._chk(self.L.rb_plan_create(self.ctx, C.c_uint64(len(contig)), _p(op_off), _p(contig), C.c_uint64(nw),
+                                        _p(wc), _p(ws), _p(we), C.byref(plan)), "rb_plan_create")
+        return plan
+
+    def plan_destroy(self, plan):
+        self.L.rb_plan_destroy(plan)
+
+    def plan_workspace_bytes(self, plan, rows_cap):
+        return int(self.L.rb_plan_workspace_bytes(plan, C.c_uint64(rows_cap)))
+
+    def dev_liftover(self, plan, view, norm_ptr, policy, ws_ptr, rows_ptr, rows_cap, out_ptr, out_cap, counters_ptr):
+        self._chk(self.L.rb_dev_liftover(self.ctx, plan, C.byref(view), C.c_void_p(norm_ptr), C.c_int(policy),
+                                         C.c_void_p(ws_ptr), C.c_void_p(rows_ptr), C.c_uint64(rows_cap),
+                                         C.c_void_p(out_ptr), C.c_uint64(out_cap), C.c_void_p(counters_ptr)),
+                  "rb_dev_liftover")
+
+    def dev_break(self, plan, view, norm_ptr, max_size, policy, ws_ptr, rows_ptr, rows_cap, out_ptr, out_cap,
+                  counters_ptr):
+        self._chk(self.L.rb_dev_break(self.ctx, plan, C.byref(view), C.c_void_p(norm_ptr), C.c_uint32(max_size),
+                                      C.c_int(policy), C.c_void_p(ws_ptr), C.c_void_p(rows_ptr), C.c_uint64(rows_cap),
+                                      C.c_void_p(out_ptr), C.c_uint64(out_cap), C.c_void_p(counters_ptr)),
+                  "rb_dev_break")
+
     # ---- host-buffer wrappers ----
     def scan_records(self, ops, op_off, t_st, t_en, q_st, q_en, strand):
         ops, op_off = _arr(ops, np.uint32), _arr(op_off, np.uint64)

@@ -76,7 +76,8 @@ struct rb_swap_params {
 
 extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream);
-extern "C" hipError_t rb_launch_liftover(const rb_lift_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream);
 extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec);
 extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream);
@@ -85,11 +86,16 @@ extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint
 #define RB_ARENA_STRIDE 16
 #define RB_MAX_ARENA 256
 
+#define RB_TIMING_RING 256
 struct rb_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     std::string err;
+    // optional HIP-event timing of the dominant (streaming) kernel of each liftover/break call
+    bool timing = false;
+    std::vector<hipEvent_t> ev_a, ev_b;
+    uint64_t timed_calls = 0;
 };
 
 struct rb_plan {
@@ -155,6 +161,8 @@ extern "C" int rb_ctx_create(int device, void *hip_stream, rb_ctx **out) {
 }
 extern "C" void rb_ctx_destroy(rb_ctx *ctx) {
     if (!ctx) return;
+    for (auto e : ctx->ev_a) hipEventDestroy(e);
+    for (auto e : ctx->ev_b) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -165,6 +173,36 @@ extern "C" int rb_ctx_sync(rb_ctx *ctx) {
     return RB_OK;
 }
 extern "C" void *rb_ctx_stream(rb_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int rb_ctx_set_timing(rb_ctx *ctx, int enabled) {
+    if (!ctx) return RB_E_INVALID;
+    if (enabled && ctx->ev_a.empty()) {
+        ctx->ev_a.resize(RB_TIMING_RING);
+        ctx->ev_b.resize(RB_TIMING_RING);
+        for (int i = 0; i < RB_TIMING_RING; i++) {
+            HIPCHK(ctx, hipEventCreate(&ctx->ev_a[i]));
+            HIPCHK(ctx, hipEventCreate(&ctx->ev_b[i]));
+        }
+    }
+    ctx->timing = enabled != 0;
+    ctx->timed_calls = 0;
+    return RB_OK;
+}
+extern "C" int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_out) {
+    if (!ctx || !ms_out || !n_out) return RB_E_INVALID;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint64_t have = ctx->timed_calls < RB_TIMING_RING ? ctx->timed_calls : RB_TIMING_RING;
+    int n = 0;
+    for (uint64_t k = 0; k < have && n < cap; k++) {
+        const uint64_t call = ctx->timed_calls - have + k;
+        const size_t slot = (size_t)(call % RB_TIMING_RING);
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev_a[slot], ctx->ev_b[slot]));
+        ms_out[n++] = ms;
+    }
+    *n_out = n;
+    return RB_OK;
+}
 
 extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
     if (!ctx || !dev_ptr) return RB_E_INVALID;
@@ -403,7 +441,16 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     } else {
         HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, true, ctx->stream));
     }
-    HIPCHK(ctx, rb_launch_liftover(&p, ctx->stream));
+    if (ctx->timing) {
+        const size_t slot = (size_t)(ctx->timed_calls % RB_TIMING_RING);
+        HIPCHK(ctx, hipEventRecord(ctx->ev_a[slot], ctx->stream));
+        HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->ev_b[slot], ctx->stream));
+        ctx->timed_calls++;
+    } else {
+        HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
+    }
+    HIPCHK(ctx, rb_launch_liftover_tail(&p, ctx->stream));
     return RB_OK;
 }
 

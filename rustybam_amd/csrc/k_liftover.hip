@@ -957,10 +957,14 @@ extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t
     return hipGetLastError();
 }
 
-extern "C" hipError_t rb_launch_liftover(const rb_lift_params *p, hipStream_t stream) {
+extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((p->n_rec + 3) / 4);
     hipLaunchKernelGGL(rb_k_liftover_stream, dim3(blocks), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_liftover_generic, dim3(1024), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
     return hipGetLastError();
