@@ -42,6 +42,7 @@ struct rb_lift_params {
     uint32_t n_contig;
     const uint64_t *x_st, *x_en;
     uint64_t *hit_off;
+    uint32_t *win_lo;
     rb_hit_row *rows;
     uint64_t rows_cap;
     uint32_t *out_ops;
@@ -345,7 +346,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][block sums][arena cursors][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, block_sums, arena, gen_list, x_st, x_en, total;
+    size_t hit_off, win_lo, block_sums, arena, gen_list, x_st, x_en, total;
 };
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     ws_layout w;
@@ -356,6 +357,7 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
         return at;
     };
     w.hit_off = take((n_rec + 2) * 8);
+    w.win_lo = take((n_rec + 2) * 4);
     w.block_sums = take(rb_scan_block_sums_count(n_rec) * 8);
     w.arena = take((size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8);
     w.gen_list = take((rows_cap + 1) * 4);
@@ -404,6 +406,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.cw_mono = plan->cw_mono;
     p.n_contig = plan->n_contig;
     p.hit_off = (uint64_t *)(ws + w.hit_off);
+    p.win_lo = (uint32_t *)(ws + w.win_lo);
     p.rows = rows;
     p.rows_cap = rows_cap;
     p.out_ops = out_ops;

@@ -48,6 +48,7 @@ struct rb_lift_params {
     const uint64_t *x_st, *x_en;
     // rows
     uint64_t *hit_off; // [n_rec + 1], canonical order; holds counts before the scan
+    uint32_t *win_lo;  // [n_rec] first overlapping window of a monotone slice (grouped index), by record
     rb_hit_row *rows;
     uint64_t rows_cap;
     uint32_t *out_ops;
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(256) void rb_k_count_hits(rb_lift_params p) {
             const uint64_t lo = rb_lower_en_gt(p.w_en, ws, we, t_st);
             const uint64_t hi = rb_lower_st_ge(p.w_st, ws, we, t_en);
             cnt = hi > lo ? hi - lo : 0;
+            p.win_lo[r] = (uint32_t)lo;
         } else {
             for (uint64_t i = ws; i < we; i++) cnt += (t_en > p.w_st[i] && t_st < p.w_en[i]) ? 1 : 0;
         }
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
     const bool minus = p.strand[r] == (uint8_t)'-';
     const uint64_t rec0 = p.op_off[r] + nr->first_op; // global index of the record's first kept op
     const uint32_t *rec_ops = p.ops + rec0;
-    const uint64_t lo = explicit_w ? 0 : rb_lower_en_gt(p.w_en, ws, we, t_st);
+    const uint64_t lo = explicit_w ? 0 : p.win_lo[r];
     const uint32_t arena = (uint32_t)(wave % p.n_arena);
 
     for (uint64_t jb = 0; jb < nh; jb += RB_HMAX) {
@@ -416,15 +418,20 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
             const uint64_t g0 = rec0 & ~3ull;
             const uint64_t gend = rec0 + n;
             const uint64_t n_steps = (gend - g0 + 255u) >> 8;
-            uint4 cur = make_uint4(0, 0, 0, 0);
-            {
-                const uint64_t gi = g0 + (uint64_t)lane * 4u;
-                if (gi < gend) cur = *reinterpret_cast<const uint4 *>(p.ops + gi);
-            }
+            // 4 steps (4 KiB per wave) of loads stay in flight ahead of the step being processed
+            const uint64_t glane = g0 + (uint64_t)lane * 4u;
+            auto load_step = [&](uint64_t stp) -> uint4 {
+                const uint64_t gi = glane + (stp << 8);
+                return gi < gend ? *reinterpret_cast<const uint4 *>(p.ops + gi) : make_uint4(0, 0, 0, 0);
+            };
+            uint4 pf0 = load_step(0), pf1 = load_step(1), pf2 = load_step(2), pf3 = load_step(3);
             for (uint64_t st = 0; st < n_steps; st++) {
-                const uint64_t gi = g0 + (st << 8) + (uint64_t)lane * 4u;
-                uint4 nxt = make_uint4(0, 0, 0, 0);
-                if (gi + 256u < gend) nxt = *reinterpret_cast<const uint4 *>(p.ops + gi + 256u);
+                const uint64_t gi = glane + (st << 8);
+                const uint4 cur = pf0;
+                pf0 = pf1;
+                pf1 = pf2;
+                pf2 = pf3;
+                pf3 = load_step(st + 4);
                 rb_step s;
                 s.idx0 = (int32_t)((int64_t)gi - (int64_t)rec0);
                 const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
@@ -537,10 +544,24 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                             if (first_idx <= 0) {
                                 // nothing before: walk-left stops at unit 0 (paf.rs:556), which is before any start
                                 rb_set_end(h, lane, 0, 0, 0, 0, 0, RB_S_NONE);
-                            } else if (Y >= first_idx - 1 && rb_in(RB_MATCH_MASK, rb_opc(carry_tail))) {
-                                rb_set_end(h, lane, (uint32_t)(first_idx - 1), rb_len(carry_tail), Rb, Qb, Ub, RB_S_OK);
                             } else {
-                                rb_set_end(h, lane, 0, 0, 0, 0, 0, RB_S_DEFER);
+                                // the op we want sits in an earlier step: walk back over the (L2-resident)
+                                // ops just streamed; Rb/Qb/Ub are the prefixes at the end of op first_idx-1
+                                int32_t jb2 = first_idx - 1;
+                                uint32_t wr = Rb, wq = Qb, wu = Ub, st_end = RB_S_DEFER;
+                                for (int t = 0; t < 32 && jb2 >= 0; t++, jb2--) {
+                                    const uint32_t v = rec_ops[jb2];
+                                    const uint32_t vo = rb_opc(v), vl = rb_len(v);
+                                    if (jb2 <= Y && rb_in(RB_MATCH_MASK, vo)) {
+                                        rb_set_end(h, lane, (uint32_t)jb2, vl, wr, wq, wu, RB_S_OK);
+                                        st_end = RB_S_OK;
+                                        break;
+                                    }
+                                    wr -= (vo == RB_OP_I) ? 0u : vl;
+                                    wq -= (vo == RB_OP_D) ? 0u : vl;
+                                    wu -= vl;
+                                }
+                                if (st_end != RB_S_OK) rb_set_end(h, lane, 0, 0, 0, 0, 0, jb2 < 0 ? RB_S_NONE : RB_S_DEFER);
                             }
                         }
                     }
@@ -564,7 +585,6 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 Rb = Rend;
                 Qb = Qend;
                 Ub = Uend;
-                cur = nxt;
                 // optional: nothing downstream depends on the rest of the record once every boundary
                 // of the pass is resolved (boundaries on the last base are by construction pending)
                 if (p.early_exit && !(need_s | need_e | pend)) break;
@@ -685,30 +705,39 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 const uint32_t e_blast = rb_readlane<uint32_t>(b_last, j);
                 const bool e_inside = (inside_mask >> j) & 1ull;
                 const uint64_t e_off = rb_readlane<uint64_t>(my_off, j);
-                const uint32_t *src = rec_ops + e_aop;
-                uint32_t *dst = p.out_ops + e_off;
-                for (uint32_t i = (uint32_t)lane * 4u; i < e_n; i += 256u) {
-                    uint4 v;
-                    if (i + 4u <= e_n) {
-                        v = rb_load4_unaligned(src + i);
-                    } else {
-                        v.x = src[i];
-                        v.y = i + 1 < e_n ? src[i + 1] : 0u;
-                        v.z = i + 2 < e_n ? src[i + 2] : 0u;
-                        v.w = 0u;
+                const uint32_t *__restrict__ src = rec_ops + e_aop;
+                uint32_t *__restrict__ dst = p.out_ops + e_off;
+                // 1024 ops per round: the 4 loads of a lane are issued back to back (the ops array is
+                // padded, so reading up to 3 ops past the clip is safe; they are zeroed below)
+                for (uint32_t i0 = 0; i0 < e_n; i0 += 1024u) {
+                    uint4 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
+                        v[u] = i < e_n ? rb_load4_unaligned(src + i) : make_uint4(0, 0, 0, 0);
                     }
-                    if (!e_inside) {
-                        if (i == 0) { // first op keeps its tail, or the middle if the clip is a single op
-                            const uint32_t l0 = e_n == 1 ? (e_afirst + e_blast - rb_len(v.x)) : e_afirst;
-                            v.x = (l0 << 4) | rb_opc(v.x);
-                        }
-                        if (e_n > 1 && i <= e_n - 1 && e_n - 1 < i + 4u) { // last op keeps its head
-                            const uint32_t q = e_n - 1 - i;
-                            uint32_t *c = q == 0 ? &v.x : (q == 1 ? &v.y : (q == 2 ? &v.z : &v.w));
-                            *c = (e_blast << 4) | rb_opc(*c);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
+                        if (i < e_n) {
+                            if (i + 1 >= e_n) v[u].y = 0u;
+                            if (i + 2 >= e_n) v[u].z = 0u;
+                            if (i + 3 >= e_n) v[u].w = 0u;
+                            if (!e_inside) {
+                                if (i == 0) { // first op keeps its tail, or the middle if the clip is a single op
+                                    const uint32_t l0 = e_n == 1 ? (e_afirst + e_blast - rb_len(v[u].x)) : e_afirst;
+                                    v[u].x = (l0 << 4) | rb_opc(v[u].x);
+                                }
+                                if (e_n > 1 && e_n - 1 - i < 4u) { // last op keeps its head
+                                    const uint32_t q = e_n - 1 - i;
+                                    const uint32_t lastv = q == 0 ? v[u].x : (q == 1 ? v[u].y : (q == 2 ? v[u].z : v[u].w));
+                                    const uint32_t nv = (e_blast << 4) | rb_opc(lastv);
+                                    if (q == 0) v[u].x = nv; else if (q == 1) v[u].y = nv; else if (q == 2) v[u].z = nv; else v[u].w = nv;
+                                }
+                            }
+                            *reinterpret_cast<uint4 *>(dst + i) = v[u];
                         }
                     }
-                    *reinterpret_cast<uint4 *>(dst + i) = v;
                 }
             }
         }
@@ -931,14 +960,19 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
 }
 
 // out_ops_used / out_ops_needed from the arena cursors
-__global__ void rb_k_finish(rb_lift_params p) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(64) void rb_k_finish(rb_lift_params p) {
     unsigned long long mx = 0, sum = 0;
-    for (uint32_t a = 0; a < p.n_arena; a++) {
+    for (uint32_t a = threadIdx.x; a < p.n_arena; a += 64) {
         const unsigned long long c = p.arena_cur[(uint64_t)a * RB_ARENA_STRIDE];
         mx = c > mx ? c : mx;
         sum += c;
     }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(mx, off, 64);
+        mx = o > mx ? o : mx;
+        sum += __shfl_xor(sum, off, 64);
+    }
+    if (threadIdx.x != 0) return;
     p.counters->out_ops_used = sum;
     p.counters->out_ops_needed = (mx + 3ull) / 4ull * 4ull * p.n_arena;
     if (p.counters->n_hits > p.rows_cap) p.counters->overflow = 1;
