@@ -24,7 +24,7 @@
 #include "rb_device.h"
 
 #define RB_HMAX 64            // hits resolved per streaming pass of one record
-#define RB_LDS_PER_HIT 12     // dwords of per-hit state in LDS
+#define RB_LDS_PER_HIT 6      // dwords of per-hit (start) state in LDS
 #define RB_ARENA_STRIDE 16    // u64 words between arena cursors (128 B)
 
 struct rb_lift_params {
@@ -183,124 +183,9 @@ __global__ __launch_bounds__(256) void rb_k_scan_apply(uint64_t *v, uint64_t n, 
 // streaming kernel
 // ------------------------------------------------------------------------------------------------
 enum { RB_S_UNRES = 0, RB_S_OK = 1, RB_S_NONE = 2, RB_S_DEFER = 3 };
-// LDS slots per hit
-enum { H_AOP = 0, H_AFIRST = 1, H_RA = 2, H_QA = 3, H_UA = 4, H_BOP = 5, H_BLAST = 6, H_NRB = 7, H_NQB = 8, H_NUB = 9, H_AST = 10, H_BST = 11 };
-
-struct rb_step { // one 256-op step, per lane: 4 ops with exclusive prefixes (record relative)
-    uint32_t opc[4], len[4];
-    uint32_t Rx[4], Qx[4], Ux[4];
-    int32_t idx0; // record-relative op index of slot 0 (may be < 0 in the aligned head)
-};
 
 // first/last set helpers on 64-bit masks
 __device__ __forceinline__ int rb_ffs64(unsigned long long m) { return __ffsll((long long)m) - 1; }
-__device__ __forceinline__ int rb_fls64(unsigned long long m) { return 63 - __clzll((long long)m); }
-
-// select slot value by (per-lane) slot index
-__device__ __forceinline__ uint32_t rb_sel(const uint32_t v[4], int s) {
-    return s == 0 ? v[0] : (s == 1 ? v[1] : (s == 2 ? v[2] : v[3]));
-}
-
-struct rb_found { // wave-uniform description of one op
-    int32_t idx;  // record-relative op index
-    uint32_t opc, len, Rx, Qx, Ux;
-    uint32_t prev_opc, prev_len; // op idx-1 (RB_NULL_OP if none)
-    bool ok;
-};
-
-// op that contains reference offset D (the ref-consuming op with Rx <= D < Rx + len)
-__device__ __forceinline__ rb_found rb_find_ref(const rb_step &s, uint32_t D, uint32_t carry_tail) {
-    bool m[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) m[r] = rb_in(RB_REF_MASK, s.opc[r]) && (uint32_t)(D - s.Rx[r]) < s.len[r];
-    const bool any = m[0] || m[1] || m[2] || m[3];
-    const unsigned long long ball = __ballot(any);
-    rb_found f;
-    f.ok = ball != 0;
-    if (!f.ok) return f;
-    const int L = rb_ffs64(ball);
-    const int sl = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
-    // previous op: slot sl-1 of this lane, or slot 3 of the previous lane (lane 0: carry)
-    const uint32_t pl3 = rb_prev_lane((s.len[3] << 4) | s.opc[3], carry_tail);
-    const uint32_t prevp = sl == 0 ? pl3 : ((rb_sel(s.len, sl - 1) << 4) | rb_sel(s.opc, sl - 1));
-    f.idx = rb_readlane<int>(s.idx0 + sl, L);
-    f.opc = rb_readlane<uint32_t>(rb_sel(s.opc, sl), L);
-    f.len = rb_readlane<uint32_t>(rb_sel(s.len, sl), L);
-    f.Rx = rb_readlane<uint32_t>(rb_sel(s.Rx, sl), L);
-    f.Qx = rb_readlane<uint32_t>(rb_sel(s.Qx, sl), L);
-    f.Ux = rb_readlane<uint32_t>(rb_sel(s.Ux, sl), L);
-    const uint32_t pp = rb_readlane<uint32_t>(prevp, L);
-    f.prev_opc = f.idx > 0 ? rb_opc(pp) : RB_NULL_OP;
-    f.prev_len = rb_len(pp);
-    return f;
-}
-
-// first match-type op with record index >= X inside this step
-__device__ __forceinline__ rb_found rb_find_match_fwd(const rb_step &s, int32_t X) {
-    bool m[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) m[r] = rb_in(RB_MATCH_MASK, s.opc[r]) && (s.idx0 + r) >= X;
-    const bool any = m[0] || m[1] || m[2] || m[3];
-    const unsigned long long ball = __ballot(any);
-    rb_found f;
-    f.ok = ball != 0;
-    if (!f.ok) return f;
-    const int L = rb_ffs64(ball);
-    const int sl = m[0] ? 0 : (m[1] ? 1 : (m[2] ? 2 : 3));
-    f.idx = rb_readlane<int>(s.idx0 + sl, L);
-    f.opc = rb_readlane<uint32_t>(rb_sel(s.opc, sl), L);
-    f.len = rb_readlane<uint32_t>(rb_sel(s.len, sl), L);
-    f.Rx = rb_readlane<uint32_t>(rb_sel(s.Rx, sl), L);
-    f.Qx = rb_readlane<uint32_t>(rb_sel(s.Qx, sl), L);
-    f.Ux = rb_readlane<uint32_t>(rb_sel(s.Ux, sl), L);
-    f.prev_opc = RB_NULL_OP;
-    f.prev_len = 0;
-    return f;
-}
-
-// last match-type op with record index <= Y inside this step
-__device__ __forceinline__ rb_found rb_find_match_bwd(const rb_step &s, int32_t Y) {
-    bool m[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) m[r] = rb_in(RB_MATCH_MASK, s.opc[r]) && (s.idx0 + r) <= Y;
-    const bool any = m[0] || m[1] || m[2] || m[3];
-    const unsigned long long ball = __ballot(any);
-    rb_found f;
-    f.ok = ball != 0;
-    if (!f.ok) return f;
-    const int L = rb_fls64(ball);
-    const int sl = m[3] ? 3 : (m[2] ? 2 : (m[1] ? 1 : 0));
-    f.idx = rb_readlane<int>(s.idx0 + sl, L);
-    f.opc = rb_readlane<uint32_t>(rb_sel(s.opc, sl), L);
-    f.len = rb_readlane<uint32_t>(rb_sel(s.len, sl), L);
-    f.Rx = rb_readlane<uint32_t>(rb_sel(s.Rx, sl), L);
-    f.Qx = rb_readlane<uint32_t>(rb_sel(s.Qx, sl), L);
-    f.Ux = rb_readlane<uint32_t>(rb_sel(s.Ux, sl), L);
-    f.prev_opc = RB_NULL_OP;
-    f.prev_len = 0;
-    return f;
-}
-
-__device__ __forceinline__ void rb_set_start(uint32_t *h, int lane, uint32_t aop, uint32_t afirst, uint32_t Ra, uint32_t Qa, uint32_t Ua, uint32_t st) {
-    if (lane == 0) {
-        h[H_AOP] = aop;
-        h[H_AFIRST] = afirst;
-        h[H_RA] = Ra;
-        h[H_QA] = Qa;
-        h[H_UA] = Ua;
-        h[H_AST] = st;
-    }
-}
-__device__ __forceinline__ void rb_set_end(uint32_t *h, int lane, uint32_t bop, uint32_t blast, uint32_t nR, uint32_t nQ, uint32_t nU, uint32_t st) {
-    if (lane == 0) {
-        h[H_BOP] = bop;
-        h[H_BLAST] = blast;
-        h[H_NRB] = nR;
-        h[H_NQB] = nQ;
-        h[H_NUB] = nU;
-        h[H_BST] = st;
-    }
-}
 
 // append every hit of a record to the generic list (record not eligible for the streaming path)
 __device__ void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_norm_row *nr, uint64_t h0, uint64_t nh,
@@ -343,12 +228,191 @@ __device__ void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_no
     }
 }
 
+// copy ops [a_op, a_op + e_n) of the record to out_ops + off, patching the two clipped ends.
+// 1024 ops per round: the 4 loads of a lane are issued back to back.  (The ops array is padded, so
+// reading up to 3 ops past the clip is safe; they are zeroed.)  All arguments are wave-uniform.
+__device__ __forceinline__ void rb_emit(uint32_t *out_ops, const uint32_t *rec_ops, int lane, uint32_t a_op, uint32_t e_n,
+                                        uint32_t afirst, uint32_t blast, bool verbatim, uint64_t off) {
+    const uint32_t *__restrict__ src = rec_ops + a_op;
+    uint32_t *__restrict__ dst = out_ops + off;
+    for (uint32_t i0 = 0; i0 < e_n; i0 += 1024u) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
+            v[u] = i < e_n ? rb_load4_unaligned(src + i) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
+            if (i < e_n) {
+                if (i + 1 >= e_n) v[u].y = 0u;
+                if (i + 2 >= e_n) v[u].z = 0u;
+                if (i + 3 >= e_n) v[u].w = 0u;
+                if (!verbatim) {
+                    if (i == 0) { // first op keeps its tail, or the middle if the clip is a single op
+                        const uint32_t l0 = e_n == 1 ? (afirst + blast - rb_len(v[u].x)) : afirst;
+                        v[u].x = (l0 << 4) | rb_opc(v[u].x);
+                    }
+                    if (e_n > 1 && e_n - 1 - i < 4u) { // last op keeps its head
+                        const uint32_t q = e_n - 1 - i;
+                        const uint32_t lastv = q == 0 ? v[u].x : (q == 1 ? v[u].y : (q == 2 ? v[u].z : v[u].w));
+                        const uint32_t nv = (blast << 4) | rb_opc(lastv);
+                        if (q == 0) v[u].x = nv; else if (q == 1) v[u].y = nv; else if (q == 2) v[u].z = nv; else v[u].w = nv;
+                    }
+                }
+                *reinterpret_cast<uint4 *>(dst + i) = v[u];
+            }
+        }
+    }
+}
+
+// ---- lane-local boundary resolution --------------------------------------------------------------
+// One lane resolves one window boundary.  It starts from a checkpoint (exclusive prefixes R,Q,U at an
+// op index that is a multiple of 16, written to LDS by the streaming pass), walks at most 16 ops held
+// in registers to the reference-consuming op that contains offset D, then applies the reference's
+// tpos_to_idx + walk-to-match rules (paf.rs:541-561) with short look-ahead / look-back loads.
+struct rb_bres {
+    uint32_t st;            // RB_S_OK / NONE / DEFER
+    uint32_t op, part;      // op index; start: ops' remaining length (len - off), end: used length (off + 1)
+    uint32_t R, Q, U;       // start: exclusive counts at the unit; end: inclusive counts
+};
+
+#define RB_WALK_MAX 24
+
+// regular records only (M I D = X): ref = not I, query = not D
+__device__ __forceinline__ uint32_t rb_rl(uint32_t v) { return rb_opc(v) == RB_OP_I ? 0u : rb_len(v); }
+__device__ __forceinline__ uint32_t rb_ql(uint32_t v) { return rb_opc(v) == RB_OP_D ? 0u : rb_len(v); }
+__device__ __forceinline__ bool rb_ism(uint32_t v) { return rb_in(RB_MATCH_MASK, rb_opc(v)); }
+
+// ops[] = the record's kept ops, n of them.  (cR,cQ,cU) = prefixes at op index cidx (checkpoint).
+// D in [cR, next checkpoint's R) and D < Rtot.  is_start selects search-right (true) / search-left.
+__device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, uint32_t n, int32_t cidx, uint32_t cR, uint32_t cQ,
+                                              uint32_t cU, uint32_t D, bool is_start, int policy) {
+    rb_bres o;
+    o.st = RB_S_DEFER;
+    o.op = o.part = o.R = o.Q = o.U = 0;
+    // 16 ops of the checkpoint group (cidx may be negative by up to 3 in the aligned head: masked)
+    uint32_t g[16];
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(ops + cidx); // 16-byte aligned by construction
+        const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+        g[0] = a0.x; g[1] = a0.y; g[2] = a0.z; g[3] = a0.w; g[4] = a1.x; g[5] = a1.y; g[6] = a1.z; g[7] = a1.w;
+        g[8] = a2.x; g[9] = a2.y; g[10] = a2.z; g[11] = a2.w; g[12] = a3.x; g[13] = a3.y; g[14] = a3.z; g[15] = a3.w;
+    }
+    // find the ref-consuming op f with Rx <= D < Rx + len
+    int32_t fi = -1;
+    uint32_t fv = 0, fR = 0, fQ = 0, fU = 0, pv = (RB_NULL_OP);
+    {
+        uint32_t R = cR, Q = cQ, U = cU, prev = RB_NULL_OP;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int32_t idx = cidx + k;
+            const bool valid = (uint32_t)idx < n;
+            const uint32_t v = valid ? g[k] : RB_NULL_OP;
+            const uint32_t rl = valid ? rb_rl(v) : 0u;
+            if (fi < 0 && rl != 0 && (uint32_t)(D - R) < rl) {
+                fi = idx;
+                fv = v;
+                fR = R;
+                fQ = Q;
+                fU = U;
+                pv = prev;
+            }
+            R += rl;
+            Q += valid ? rb_ql(v) : 0u;
+            U += valid ? rb_len(v) : 0u;
+            if (valid) prev = v;
+        }
+    }
+    if (fi < 0) return o; // should not happen; the generic kernel sorts it out
+    if (fi > 0 && pv == RB_NULL_OP) pv = ops[fi - 1]; // previous op lives in the group before
+    const uint32_t off = D - fR;
+    if (is_start) {
+        int32_t X; // first match-type op with index >= X
+        if (off > 0) { // the boundary base and the next base share op f
+            if (rb_ism(fv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = rb_len(fv) - (off - 1), o.R = fR + off - 1, o.Q = fQ + off - 1, o.U = fU + off - 1;
+                return o;
+            }
+            X = fi + 1;
+        } else { // boundary base is the last unit before op f: the last equal element is the unit before f
+            if (fi > 0 && rb_ism(pv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = 1u, o.R = fR - 1, o.Q = fQ - 1, o.U = fU - 1;
+                return o;
+            }
+            // duplicates in tpos_aln (units of an insertion share the boundary's tpos): which one
+            // binary_search returns depends on the Rust std generation -> generic kernel decides
+            if (policy == RB_BSEARCH_LEGACY && fi > 0 && rb_opc(pv) == RB_OP_I) return o;
+            X = fi;
+        }
+        // walk right (paf.rs:551-553) from op fi
+        uint32_t R = fR, Q = fQ, U = fU;
+        uint32_t v = fv;
+        int32_t i = fi;
+        for (int t = 0; t < RB_WALK_MAX; t++) {
+            if (i >= X && rb_ism(v)) {
+                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
+                return o;
+            }
+            R += rb_rl(v);
+            Q += rb_ql(v);
+            U += rb_len(v);
+            i++;
+            if ((uint32_t)i >= n) {
+                o.st = RB_S_NONE; // ran off the end: start_idx == N (liftover.rs:52)
+                return o;
+            }
+            v = ops[i];
+        }
+        return o; // too far: generic
+    } else {
+        int32_t Y; // last match-type op with index <= Y
+        if (off > 0) {
+            if (rb_ism(fv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = off, o.R = D, o.Q = fQ + off, o.U = fU + off;
+                return o;
+            }
+            Y = fi - 1;
+        } else {
+            if (fi > 0 && rb_ism(pv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = rb_len(pv), o.R = fR, o.Q = fQ, o.U = fU;
+                return o;
+            }
+            Y = fi - 2;
+        }
+        // walk left (paf.rs:555-557): (R,Q,U) are the prefixes at the END of op i
+        uint32_t R = fR, Q = fQ, U = fU;
+        int32_t i = fi - 1;
+        for (int t = 0; t < RB_WALK_MAX; t++) {
+            if (i < 0) {
+                o.st = RB_S_NONE; // stops at unit 0, which lies before any start
+                return o;
+            }
+            const uint32_t v = ops[i];
+            if (i <= Y && rb_ism(v)) {
+                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
+                return o;
+            }
+            R -= rb_rl(v);
+            Q -= rb_ql(v);
+            U -= rb_len(v);
+            i--;
+        }
+        return o;
+    }
+}
+
+#define RB_SMAX 40 // steps (of 256 ops) whose checkpoints fit in LDS at once
+#define RB_CP_PER_STEP 16
+
 __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
-    __shared__ uint32_t lds_all[4][RB_HMAX * RB_LDS_PER_HIT];
+    // checkpoints: exclusive (R,Q,U) prefixes every 16 ops, SoA so that R can be binary-searched
+    __shared__ uint32_t cp_all[4][3][RB_SMAX * RB_CP_PER_STEP];
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (wave >= p.n_rec) return;
     const int lane = rb_lane();
-    uint32_t *lds = lds_all[threadIdx.x >> 6];
+    uint32_t *cpR = cp_all[threadIdx.x >> 6][0], *cpQ = cp_all[threadIdx.x >> 6][1], *cpU = cp_all[threadIdx.x >> 6][2];
     const uint32_t r = rb_first(p.sched[wave]);
     const rb_norm_row *nr = &p.norm[r];
     if (nr->status != RB_ST_OK) return;
@@ -361,13 +425,13 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
         return;
     }
     const bool explicit_w = p.x_st != nullptr;
-    const uint32_t c = p.contig[r];
+    const uint32_t cg = p.contig[r];
     uint64_t ws = 0, we = 0;
     bool mono = true;
     if (!explicit_w) {
-        ws = p.cw_off[c];
-        we = p.cw_off[c + 1];
-        mono = p.cw_mono[c] != 0;
+        ws = p.cw_off[cg];
+        we = p.cw_off[cg + 1];
+        mono = p.cw_mono[cg] != 0;
     }
     const bool fast = (nr->flags & RB_F_REGULAR) && (explicit_w || mono);
     if (!fast) {
@@ -381,13 +445,17 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
     const uint32_t *rec_ops = p.ops + rec0;
     const uint64_t lo = explicit_w ? 0 : p.win_lo[r];
     const uint32_t arena = (uint32_t)(wave % p.n_arena);
+    const uint64_t g0 = rec0 & ~3ull, gend = rec0 + n;
+    const uint32_t n_steps = (uint32_t)((gend - g0 + 255u) >> 8);
+    const int32_t head = (int32_t)(rec0 - g0); // 0..3 padding ops in front of the record in step 0
+    const uint64_t glane = g0 + (uint64_t)lane * 4u;
 
     for (uint64_t jb = 0; jb < nh; jb += RB_HMAX) {
         const uint32_t nb = (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX);
-        // ---- per-hit setup: lane j owns hit jb + j ----
+        // ---- per-hit setup: lane j owns window jb + j ----
         uint64_t wst = 0, wen = 0;
         uint32_t win = 0;
-        bool mine = (uint32_t)lane < nb;
+        const bool mine = (uint32_t)lane < nb;
         if (mine) {
             if (explicit_w) {
                 wst = p.x_st[h0 + jb + lane];
@@ -403,255 +471,112 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
         // D = (relative ref offset of the boundary base) + 1
         const uint32_t Ds = (uint32_t)((wst > t_st ? wst : t_st) - t_st) + 1u; // liftover.rs:28
         const uint32_t De = (uint32_t)((wen < t_en ? wen : t_en) - t_st);       // (min(en,t_en) - 1 - t_st) + 1, :38-40
-        for (int i = lane; i < (int)(nb * RB_LDS_PER_HIT); i += 64) lds[i] = 0;
-        unsigned long long need_s = __ballot(mine && !inside);
-        unsigned long long need_e = need_s;
-        uint32_t nextDs = need_s ? rb_readlane<uint32_t>(Ds, rb_ffs64(need_s)) : 0xFFFFFFFFu;
-        uint32_t nextDe = need_e ? rb_readlane<uint32_t>(De, rb_ffs64(need_e)) : 0xFFFFFFFFu;
-        unsigned long long pend = 0; // starts waiting for the next match-type op
+        bool need_s = mine && !inside, need_e = need_s;
+        rb_bres A, B;
+        A.st = B.st = RB_S_UNRES;
+        A.op = A.part = A.R = A.Q = A.U = 0;
+        B.op = B.part = B.R = B.Q = B.U = 0;
 
-        // ---- stream the record ----
-        uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals before this step
-        uint32_t carry_tail = (RB_NULL_OP); // packed last op of the previous step
-        uint32_t tail_len = 0;
-        if (need_s | need_e) {
-            const uint64_t g0 = rec0 & ~3ull;
-            const uint64_t gend = rec0 + n;
-            const uint64_t n_steps = (gend - g0 + 255u) >> 8;
-            // 4 steps (4 KiB per wave) of loads stay in flight ahead of the step being processed
-            const uint64_t glane = g0 + (uint64_t)lane * 4u;
-            auto load_step = [&](uint64_t stp) -> uint4 {
-                const uint64_t gi = glane + (stp << 8);
+        // ---- stream the record, RB_SMAX steps per segment; resolve after each segment ----
+        uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
+        if (__ballot(need_s) != 0) {
+            auto load_step = [&](uint32_t stp) -> uint4 {
+                const uint64_t gi = glane + ((uint64_t)stp << 8);
                 return gi < gend ? *reinterpret_cast<const uint4 *>(p.ops + gi) : make_uint4(0, 0, 0, 0);
             };
             uint4 pf0 = load_step(0), pf1 = load_step(1), pf2 = load_step(2), pf3 = load_step(3);
-            for (uint64_t st = 0; st < n_steps; st++) {
-                const uint64_t gi = glane + (st << 8);
-                const uint4 cur = pf0;
-                pf0 = pf1;
-                pf1 = pf2;
-                pf2 = pf3;
-                pf3 = load_step(st + 4);
-                rb_step s;
-                s.idx0 = (int32_t)((int64_t)gi - (int64_t)rec0);
-                const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
-                uint32_t rl[4], ql[4];
-                uint32_t sr = 0, sq = 0, su = 0;
+            for (uint32_t seg0 = 0; seg0 < n_steps; seg0 += RB_SMAX) {
+                const uint32_t seg1 = (seg0 + RB_SMAX < n_steps) ? seg0 + RB_SMAX : n_steps;
+                const uint32_t Rseg = Rb;
+                for (uint32_t st = seg0; st < seg1; st++) {
+                    const uint4 cur = pf0;
+                    pf0 = pf1;
+                    pf1 = pf2;
+                    pf2 = pf3;
+                    pf3 = load_step(st + 4);
+                    const int32_t idx0 = (int32_t)(st << 8) + lane * 4 - head;
+                    const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
+                    uint32_t sr = 0, sq = 0, su = 0;
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const bool valid = (uint32_t)(s.idx0 + q) < n; // also rejects negative indices
-                    s.opc[q] = valid ? rb_opc(raw[q]) : RB_NULL_OP;
-                    s.len[q] = valid ? rb_len(raw[q]) : 0u;
-                    // regular records: only M I D = X, so ref = not I, query = not D
-                    rl[q] = (s.opc[q] == RB_OP_I) ? 0u : s.len[q];
-                    ql[q] = (s.opc[q] == RB_OP_D) ? 0u : s.len[q];
-                    s.Rx[q] = sr;
-                    s.Qx[q] = sq;
-                    s.Ux[q] = su;
-                    sr += rl[q];
-                    sq += ql[q];
-                    su += s.len[q];
-                }
-                const uint32_t ir = rb_wave_scan_incl(sr), iq = rb_wave_scan_incl(sq), iu = rb_wave_scan_incl(su);
-                const uint32_t er = Rb + ir - sr, eq = Qb + iq - sq, eu = Ub + iu - su;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    s.Rx[q] += er;
-                    s.Qx[q] += eq;
-                    s.Ux[q] += eu;
-                }
-                const uint32_t Rend = Rb + rb_readlane<uint32_t>(ir, 63);
-                const uint32_t Qend = Qb + rb_readlane<uint32_t>(iq, 63);
-                const uint32_t Uend = Ub + rb_readlane<uint32_t>(iu, 63);
-
-                // (1) starts waiting for the first match-type op at or after this step
-                if (pend) {
-                    rb_found f = rb_find_match_fwd(s, 0); // every op of this step lies after the boundary
-                    if (f.ok) {
-                        while (pend) {
-                            const int j = rb_ffs64(pend);
-                            pend &= pend - 1;
-                            rb_set_start(lds + j * RB_LDS_PER_HIT, lane, (uint32_t)f.idx, f.len, f.Rx, f.Qx, f.Ux, RB_S_OK);
-                        }
+                    for (int q = 0; q < 4; q++) {
+                        const bool valid = (uint32_t)(idx0 + q) < n; // also rejects the negative head indices
+                        const uint32_t len = valid ? rb_len(raw[q]) : 0u;
+                        const uint32_t opc = rb_opc(raw[q]);
+                        sr += (opc == RB_OP_I) ? 0u : len;
+                        sq += (opc == RB_OP_D) ? 0u : len;
+                        su += len;
                     }
+                    const uint32_t ir = rb_wave_scan_incl(sr), iq = rb_wave_scan_incl(sq), iu = rb_wave_scan_incl(su);
+                    if ((lane & 3) == 0) { // checkpoint every 16 ops
+                        const uint32_t t = (st - seg0) * RB_CP_PER_STEP + ((uint32_t)lane >> 2);
+                        cpR[t] = Rb + ir - sr;
+                        cpQ[t] = Qb + iq - sq;
+                        cpU[t] = Ub + iu - su;
+                    }
+                    Rb += rb_readlane<uint32_t>(ir, 63);
+                    Qb += rb_readlane<uint32_t>(iq, 63);
+                    Ub += rb_readlane<uint32_t>(iu, 63);
                 }
-                // (2) window starts whose boundary op lies in this step (liftover.rs:29, search right)
-                while (nextDs < Rend) {
-                    const int j = rb_ffs64(need_s);
-                    need_s &= need_s - 1;
-                    uint32_t *h = lds + j * RB_LDS_PER_HIT;
-                    rb_found f = rb_find_ref(s, nextDs, carry_tail);
-                    const uint32_t off = nextDs - f.Rx;
-                    bool want_fwd = false;
-                    int32_t X = 0;
-                    if (off > 0) { // the boundary base and the next base share op f
-                        if (rb_in(RB_MATCH_MASK, f.opc)) {
-                            rb_set_start(h, lane, (uint32_t)f.idx, f.len - (off - 1), f.Rx + off - 1, f.Qx + off - 1, f.Ux + off - 1, RB_S_OK);
+                // ---- lane-parallel resolution of the boundaries that fall in this segment ----
+                const bool last_seg = seg1 == n_steps;
+                const uint32_t n_cp = (seg1 - seg0) * RB_CP_PER_STEP;
+                const int32_t cp_idx0 = (int32_t)(seg0 << 8) - head; // op index of checkpoint 0
+#pragma unroll 1
+                for (int which = 0; which < 2; which++) {
+                    const bool is_start = which == 0;
+                    const uint32_t D = is_start ? Ds : De;
+                    const bool todo = (is_start ? need_s : need_e) && D >= Rseg && (D < Rb || (last_seg && D == Rb));
+                    if (todo) {
+                        rb_bres o;
+                        if (D == Rb) { // boundary on the record's last base; the last op is match-type
+                            const uint32_t lv = rec_ops[n - 1];
+                            o.st = RB_S_OK, o.op = n - 1;
+                            if (is_start) o.part = 1u, o.R = Rb - 1, o.Q = Qb - 1, o.U = Ub - 1;
+                            else o.part = rb_len(lv), o.R = Rb, o.Q = Qb, o.U = Ub;
                         } else {
-                            want_fwd = true;
-                            X = f.idx + 1;
-                        }
-                    } else { // boundary base is the last unit before op f: last equal element is the unit before f
-                        if (rb_in(RB_MATCH_MASK, f.prev_opc)) {
-                            rb_set_start(h, lane, (uint32_t)(f.idx - 1), 1u, f.Rx - 1, f.Qx - 1, f.Ux - 1, RB_S_OK);
-                        } else if (p.policy == RB_BSEARCH_LEGACY && !rb_in(RB_REF_MASK, f.prev_opc)) {
-                            // duplicates in tpos_aln: which one binary_search returns is version dependent
-                            rb_set_start(h, lane, 0, 0, 0, 0, 0, RB_S_DEFER);
-                        } else {
-                            want_fwd = true;
-                            X = f.idx;
-                        }
-                    }
-                    if (want_fwd) {
-                        rb_found g = rb_find_match_fwd(s, X);
-                        if (g.ok)
-                            rb_set_start(h, lane, (uint32_t)g.idx, g.len, g.Rx, g.Qx, g.Ux, RB_S_OK);
-                        else
-                            pend |= 1ull << j;
-                    }
-                    nextDs = need_s ? rb_readlane<uint32_t>(Ds, rb_ffs64(need_s)) : 0xFFFFFFFFu;
-                }
-                // (3) window ends (liftover.rs:40, search left)
-                while (nextDe < Rend) {
-                    const int j = rb_ffs64(need_e);
-                    need_e &= need_e - 1;
-                    uint32_t *h = lds + j * RB_LDS_PER_HIT;
-                    rb_found f = rb_find_ref(s, nextDe, carry_tail);
-                    const uint32_t off = nextDe - f.Rx;
-                    bool want_bwd = false;
-                    int32_t Y = 0;
-                    if (off > 0) {
-                        if (rb_in(RB_MATCH_MASK, f.opc))
-                            rb_set_end(h, lane, (uint32_t)f.idx, off, nextDe, f.Qx + off, f.Ux + off, RB_S_OK);
-                        else {
-                            want_bwd = true;
-                            Y = f.idx - 1;
-                        }
-                    } else {
-                        if (rb_in(RB_MATCH_MASK, f.prev_opc))
-                            rb_set_end(h, lane, (uint32_t)(f.idx - 1), f.prev_len, f.Rx, f.Qx, f.Ux, RB_S_OK);
-                        else {
-                            want_bwd = true;
-                            Y = f.idx - 2;
-                        }
-                    }
-                    if (want_bwd) {
-                        rb_found g = rb_find_match_bwd(s, Y);
-                        if (g.ok) {
-                            rb_set_end(h, lane, (uint32_t)g.idx, g.len, g.Rx + g.len, g.Qx + g.len, g.Ux + g.len, RB_S_OK);
-                        } else {
-                            const int32_t first_idx = rb_readlane<int>(s.idx0, 0);
-                            if (first_idx <= 0) {
-                                // nothing before: walk-left stops at unit 0 (paf.rs:556), which is before any start
-                                rb_set_end(h, lane, 0, 0, 0, 0, 0, RB_S_NONE);
-                            } else {
-                                // the op we want sits in an earlier step: walk back over the (L2-resident)
-                                // ops just streamed; Rb/Qb/Ub are the prefixes at the end of op first_idx-1
-                                int32_t jb2 = first_idx - 1;
-                                uint32_t wr = Rb, wq = Qb, wu = Ub, st_end = RB_S_DEFER;
-                                for (int t = 0; t < 32 && jb2 >= 0; t++, jb2--) {
-                                    const uint32_t v = rec_ops[jb2];
-                                    const uint32_t vo = rb_opc(v), vl = rb_len(v);
-                                    if (jb2 <= Y && rb_in(RB_MATCH_MASK, vo)) {
-                                        rb_set_end(h, lane, (uint32_t)jb2, vl, wr, wq, wu, RB_S_OK);
-                                        st_end = RB_S_OK;
-                                        break;
-                                    }
-                                    wr -= (vo == RB_OP_I) ? 0u : vl;
-                                    wq -= (vo == RB_OP_D) ? 0u : vl;
-                                    wu -= vl;
-                                }
-                                if (st_end != RB_S_OK) rb_set_end(h, lane, 0, 0, 0, 0, 0, jb2 < 0 ? RB_S_NONE : RB_S_DEFER);
+                            // last checkpoint with R <= D (R is non-decreasing)
+                            uint32_t lo_t = 0, hi_t = n_cp;
+                            while (hi_t - lo_t > 1) {
+                                const uint32_t mid = (lo_t + hi_t) >> 1;
+                                if (cpR[mid] <= D) lo_t = mid; else hi_t = mid;
                             }
+                            o = rb_resolve(rec_ops, n, cp_idx0 + (int32_t)lo_t * 16, cpR[lo_t], cpQ[lo_t], cpU[lo_t], D, is_start, p.policy);
                         }
+                        if (is_start) A = o, need_s = false; else B = o, need_e = false;
                     }
-                    nextDe = need_e ? rb_readlane<uint32_t>(De, rb_ffs64(need_e)) : 0xFFFFFFFFu;
                 }
-                // carry to the next step
-                {
-                    const uint32_t packed3 = (s.len[3] << 4) | s.opc[3];
-                    // last VALID op of the step: lane 63 slot 3 unless the record ends inside the step
-                    const int32_t last_idx = (int32_t)n - 1;
-                    const int32_t rel = last_idx - rb_readlane<int>(s.idx0, 0);
-                    if (rel >= 255) {
-                        carry_tail = rb_readlane<uint32_t>(packed3, 63);
-                    } else {
-                        const int L = rel >> 2, sl = rel & 3;
-                        const uint32_t pk[4] = {(s.len[0] << 4) | s.opc[0], (s.len[1] << 4) | s.opc[1], (s.len[2] << 4) | s.opc[2], packed3};
-                        carry_tail = rb_readlane<uint32_t>(rb_sel(pk, sl), L);
-                    }
-                    tail_len = rb_len(carry_tail);
-                }
-                Rb = Rend;
-                Qb = Qend;
-                Ub = Uend;
-                // optional: nothing downstream depends on the rest of the record once every boundary
-                // of the pass is resolved (boundaries on the last base are by construction pending)
-                if (p.early_exit && !(need_s | need_e | pend)) break;
-            }
-            // ---- boundaries on the record's last base (D == total ref bases); last op is match-type ----
-            while (need_s) {
-                const int j = rb_ffs64(need_s);
-                need_s &= need_s - 1;
-                rb_set_start(lds + j * RB_LDS_PER_HIT, lane, n - 1, 1u, Rb - 1, Qb - 1, Ub - 1, RB_S_OK);
-            }
-            while (need_e) {
-                const int j = rb_ffs64(need_e);
-                need_e &= need_e - 1;
-                rb_set_end(lds + j * RB_LDS_PER_HIT, lane, n - 1, tail_len, Rb, Qb, Ub, RB_S_OK);
-            }
-            while (pend) { // no match-type op after the boundary: start_idx == N > end_idx
-                const int j = rb_ffs64(pend);
-                pend &= pend - 1;
-                rb_set_start(lds + j * RB_LDS_PER_HIT, lane, 0, 0, 0, 0, 0, RB_S_NONE);
+                if (p.early_exit && __ballot(need_s || need_e) == 0) break;
             }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of lane 0 visible to the wave
-        __builtin_amdgcn_wave_barrier();
 
         // ---- finalize: lane j computes the row of hit jb + j ----
-        uint32_t status = RB_ST_OK, out_n = 0, a_op = 0, a_first = 0, b_op = 0, b_last = 0;
+        uint32_t status = RB_ST_OK, out_n = 0, a_op = 0;
         uint64_t o_tst = 0, o_ten = 0, o_qst = 0, o_qen = 0;
         uint32_t o_nm = 0, o_al = 0;
         bool defer = false;
         if (mine) {
             if (inside) {
                 out_n = n;
-                o_tst = t_st;
-                o_ten = t_en;
-                o_qst = q_st;
-                o_qen = q_en;
-                o_nm = nr->nmatch;
-                o_al = nr->aln_len;
-                a_op = 0;
-                b_op = n - 1;
+                o_tst = t_st, o_ten = t_en, o_qst = q_st, o_qen = q_en;
+                o_nm = nr->nmatch, o_al = nr->aln_len;
+            } else if (A.st == RB_S_DEFER || B.st == RB_S_DEFER || A.st == RB_S_UNRES || B.st == RB_S_UNRES) {
+                defer = true;
+            } else if (A.st == RB_S_NONE || B.st == RB_S_NONE || A.U >= B.U) {
+                status = RB_ST_NONE_INDEL; // liftover.rs:52-54
             } else {
-                const uint32_t *h = lds + lane * RB_LDS_PER_HIT;
-                const uint32_t as = h[H_AST], bs = h[H_BST];
-                if (as == RB_S_DEFER || bs == RB_S_DEFER || as == RB_S_UNRES || bs == RB_S_UNRES) {
-                    defer = true;
-                } else if (as == RB_S_NONE || bs == RB_S_NONE || h[H_UA] >= h[H_NUB]) {
-                    status = RB_ST_NONE_INDEL; // liftover.rs:52-54
+                a_op = A.op;
+                o_tst = t_st + A.R; // liftover.rs:57-60, :77-82
+                o_ten = t_st + B.R;
+                if (!minus) {
+                    o_qst = q_st + A.Q;
+                    o_qen = q_st + B.Q;
                 } else {
-                    a_op = h[H_AOP];
-                    a_first = h[H_AFIRST];
-                    b_op = h[H_BOP];
-                    b_last = h[H_BLAST];
-                    const uint32_t Ra = h[H_RA], Qa = h[H_QA], Ua = h[H_UA];
-                    const uint32_t nR = h[H_NRB], nQ = h[H_NQB], nU = h[H_NUB];
-                    o_tst = t_st + Ra; // liftover.rs:57-60, :77-82
-                    o_ten = t_st + nR;
-                    if (!minus) {
-                        o_qst = q_st + Qa;
-                        o_qen = q_st + nQ;
-                    } else {
-                        o_qst = q_en - nQ;
-                        o_qen = q_en - Qa;
-                    }
-                    o_al = nU - Ua;
-                    o_nm = (nR + nQ - nU) - (Ra + Qa - Ua); // match units = ref + query - all (M I D = X only)
-                    out_n = b_op - a_op + 1;
+                    o_qst = q_en - B.Q;
+                    o_qen = q_en - A.Q;
                 }
+                o_al = B.U - A.U;
+                o_nm = (B.R + B.Q - B.U) - (A.R + A.Q - A.U); // match units = ref + query - all (M I D = X only)
+                out_n = B.op - A.op + 1;
             }
         }
         // space for the clipped cigars: one atomic per pass, each hit padded to 4 ops
@@ -692,53 +617,14 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 *row = w;
             }
         }
-        // ---- emit: copy ops[a_op .. b_op] (L2-resident), patch the two clipped ends ----
+        // ---- emit: copy ops[a_op .. b_op], patch the two clipped ends ----
         if (fits) {
-            unsigned long long todo = __ballot(padded != 0);
             const unsigned long long inside_mask = __ballot(inside);
-            while (todo) {
+            for (unsigned long long todo = __ballot(padded != 0); todo; todo &= todo - 1) {
                 const int j = rb_ffs64(todo);
-                todo &= todo - 1;
-                const uint32_t e_aop = rb_readlane<uint32_t>(a_op, j);
-                const uint32_t e_n = rb_readlane<uint32_t>(out_n, j);
-                const uint32_t e_afirst = rb_readlane<uint32_t>(a_first, j);
-                const uint32_t e_blast = rb_readlane<uint32_t>(b_last, j);
-                const bool e_inside = (inside_mask >> j) & 1ull;
-                const uint64_t e_off = rb_readlane<uint64_t>(my_off, j);
-                const uint32_t *__restrict__ src = rec_ops + e_aop;
-                uint32_t *__restrict__ dst = p.out_ops + e_off;
-                // 1024 ops per round: the 4 loads of a lane are issued back to back (the ops array is
-                // padded, so reading up to 3 ops past the clip is safe; they are zeroed below)
-                for (uint32_t i0 = 0; i0 < e_n; i0 += 1024u) {
-                    uint4 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
-                        v[u] = i < e_n ? rb_load4_unaligned(src + i) : make_uint4(0, 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
-                        if (i < e_n) {
-                            if (i + 1 >= e_n) v[u].y = 0u;
-                            if (i + 2 >= e_n) v[u].z = 0u;
-                            if (i + 3 >= e_n) v[u].w = 0u;
-                            if (!e_inside) {
-                                if (i == 0) { // first op keeps its tail, or the middle if the clip is a single op
-                                    const uint32_t l0 = e_n == 1 ? (e_afirst + e_blast - rb_len(v[u].x)) : e_afirst;
-                                    v[u].x = (l0 << 4) | rb_opc(v[u].x);
-                                }
-                                if (e_n > 1 && e_n - 1 - i < 4u) { // last op keeps its head
-                                    const uint32_t q = e_n - 1 - i;
-                                    const uint32_t lastv = q == 0 ? v[u].x : (q == 1 ? v[u].y : (q == 2 ? v[u].z : v[u].w));
-                                    const uint32_t nv = (e_blast << 4) | rb_opc(lastv);
-                                    if (q == 0) v[u].x = nv; else if (q == 1) v[u].y = nv; else if (q == 2) v[u].z = nv; else v[u].w = nv;
-                                }
-                            }
-                            *reinterpret_cast<uint4 *>(dst + i) = v[u];
-                        }
-                    }
-                }
+                rb_emit(p.out_ops, rec_ops, lane, rb_readlane<uint32_t>(a_op, j), rb_readlane<uint32_t>(out_n, j),
+                        rb_readlane<uint32_t>(A.part, j), rb_readlane<uint32_t>(B.part, j), (inside_mask >> j) & 1ull,
+                        rb_readlane<uint64_t>(my_off, j));
             }
         }
     }
