@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--early-exit", action="store_true", help="allow the kernel to stop a record early (off: full walk)")
+    ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: skip kernel phases (invalid results)")
     return ap.parse_args()
 
 
@@ -104,7 +105,7 @@ def main():
     gen_s = time.time() - t0
 
     # ---- size the outputs (first call tells what is needed) ----
-    policy = rustybam_amd.BSEARCH_MODERN | (rustybam_amd.LIFT_EARLY_EXIT if args.early_exit else 0)
+    policy = rustybam_amd.BSEARCH_MODERN | (rustybam_amd.LIFT_EARLY_EXIT if args.early_exit else 0) | (args.debug_skip << 8)
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
     rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, total_ops // 4)
     for _ in range(6):

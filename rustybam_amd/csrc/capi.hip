@@ -54,6 +54,7 @@ struct rb_lift_params {
     rb_counters *counters;
     int policy;
     int early_exit;
+    int debug_skip;
 };
 struct rb_break_params {
     uint64_t n_rec;
@@ -418,6 +419,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.counters = counters;
     p.policy = policy & 1;
     p.early_exit = (policy & RB_LIFT_EARLY_EXIT) ? 1 : 0;
+    p.debug_skip = (policy >> 8) & 7; // diagnostics only, undocumented on purpose
     uint64_t *block_sums = (uint64_t *)(ws + w.block_sums);
     HIPCHK(ctx, hipMemsetAsync(counters, 0, sizeof(rb_counters), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(p.arena_cur, 0, (size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8, ctx->stream));

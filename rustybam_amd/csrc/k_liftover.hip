@@ -62,6 +62,7 @@ struct rb_lift_params {
     rb_counters *counters;
     int policy;
     int early_exit; // stop streaming a record once every boundary of the pass is resolved
+    int debug_skip; // diagnostics only (wrong results): 1 = no emission, 2 = no resolution, 4 = no streaming
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -228,43 +229,30 @@ __device__ void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_no
     }
 }
 
-// copy ops [a_op, a_op + e_n) of the record to out_ops + off, patching the two clipped ends.
-// 1024 ops per round: the 4 loads of a lane are issued back to back.  (The ops array is padded, so
-// reading up to 3 ops past the clip is safe; they are zeroed.)  All arguments are wave-uniform.
-__device__ __forceinline__ void rb_emit(uint32_t *out_ops, const uint32_t *rec_ops, int lane, uint32_t a_op, uint32_t e_n,
-                                        uint32_t afirst, uint32_t blast, bool verbatim, uint64_t off) {
-    const uint32_t *__restrict__ src = rec_ops + a_op;
-    uint32_t *__restrict__ dst = out_ops + off;
-    for (uint32_t i0 = 0; i0 < e_n; i0 += 1024u) {
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
-            v[u] = i < e_n ? rb_load4_unaligned(src + i) : make_uint4(0, 0, 0, 0);
+// ---- emission helpers: one lane moves 4 ops (16 B) of its team's clip --------------------------------
+// i = op position inside the clip (multiple of 4), e_n = ops in the clip.  The ops array is padded, so
+// the load may read up to 3 ops past the clip; they are zeroed before the store.
+__device__ __forceinline__ uint4 rb_emit_load(const uint32_t *src, uint32_t i, uint32_t e_n) {
+    return i < e_n ? rb_load4_unaligned(src + i) : make_uint4(0, 0, 0, 0);
+}
+__device__ __forceinline__ void rb_emit_store(uint32_t *dst, uint32_t i, uint32_t e_n, uint32_t afirst, uint32_t blast, bool verbatim, uint4 v) {
+    if (i >= e_n) return;
+    if (i + 1 >= e_n) v.y = 0u;
+    if (i + 2 >= e_n) v.z = 0u;
+    if (i + 3 >= e_n) v.w = 0u;
+    if (!verbatim) {
+        if (i == 0) { // first op keeps its tail, or the middle if the clip is a single op
+            const uint32_t l0 = e_n == 1 ? (afirst + blast - rb_len(v.x)) : afirst;
+            v.x = (l0 << 4) | rb_opc(v.x);
         }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t i = i0 + (uint32_t)u * 256u + (uint32_t)lane * 4u;
-            if (i < e_n) {
-                if (i + 1 >= e_n) v[u].y = 0u;
-                if (i + 2 >= e_n) v[u].z = 0u;
-                if (i + 3 >= e_n) v[u].w = 0u;
-                if (!verbatim) {
-                    if (i == 0) { // first op keeps its tail, or the middle if the clip is a single op
-                        const uint32_t l0 = e_n == 1 ? (afirst + blast - rb_len(v[u].x)) : afirst;
-                        v[u].x = (l0 << 4) | rb_opc(v[u].x);
-                    }
-                    if (e_n > 1 && e_n - 1 - i < 4u) { // last op keeps its head
-                        const uint32_t q = e_n - 1 - i;
-                        const uint32_t lastv = q == 0 ? v[u].x : (q == 1 ? v[u].y : (q == 2 ? v[u].z : v[u].w));
-                        const uint32_t nv = (blast << 4) | rb_opc(lastv);
-                        if (q == 0) v[u].x = nv; else if (q == 1) v[u].y = nv; else if (q == 2) v[u].z = nv; else v[u].w = nv;
-                    }
-                }
-                *reinterpret_cast<uint4 *>(dst + i) = v[u];
-            }
+        if (e_n > 1 && e_n - 1 - i < 4u) { // last op keeps its head
+            const uint32_t q = e_n - 1 - i;
+            const uint32_t lastv = q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
+            const uint32_t nv = (blast << 4) | rb_opc(lastv);
+            if (q == 0) v.x = nv; else if (q == 1) v.y = nv; else if (q == 2) v.z = nv; else v.w = nv;
         }
     }
+    *reinterpret_cast<uint4 *>(dst + i) = v;
 }
 
 // ---- lane-local boundary resolution --------------------------------------------------------------
@@ -479,7 +467,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
 
         // ---- stream the record, RB_SMAX steps per segment; resolve after each segment ----
         uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
-        if (__ballot(need_s) != 0) {
+        if (__ballot(need_s) != 0 && !(p.debug_skip & 4)) {
             auto load_step = [&](uint32_t stp) -> uint4 {
                 const uint64_t gi = glane + ((uint64_t)stp << 8);
                 return gi < gend ? *reinterpret_cast<const uint4 *>(p.ops + gi) : make_uint4(0, 0, 0, 0);
@@ -526,7 +514,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                     const bool is_start = which == 0;
                     const uint32_t D = is_start ? Ds : De;
                     const bool todo = (is_start ? need_s : need_e) && D >= Rseg && (D < Rb || (last_seg && D == Rb));
-                    if (todo) {
+                    if (todo && !(p.debug_skip & 2)) {
                         rb_bres o;
                         if (D == Rb) { // boundary on the record's last base; the last op is match-type
                             const uint32_t lv = rec_ops[n - 1];
@@ -617,14 +605,41 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 *row = w;
             }
         }
-        // ---- emit: copy ops[a_op .. b_op], patch the two clipped ends ----
-        if (fits) {
-            const unsigned long long inside_mask = __ballot(inside);
-            for (unsigned long long todo = __ballot(padded != 0); todo; todo &= todo - 1) {
-                const int j = rb_ffs64(todo);
-                rb_emit(p.out_ops, rec_ops, lane, rb_readlane<uint32_t>(a_op, j), rb_readlane<uint32_t>(out_n, j),
-                        rb_readlane<uint32_t>(A.part, j), rb_readlane<uint32_t>(B.part, j), (inside_mask >> j) & 1ull,
-                        rb_readlane<uint64_t>(my_off, j));
+        // ---- emit: four 16-lane teams copy four hits at a time; per team 256 ops (4 x 16 B per lane) per
+        //      round, the loads of round k+1 in flight while round k is patched and stored ----
+        if (fits && !(p.debug_skip & 1)) {
+            const int team = lane >> 4, tl = lane & 15;
+            const uint32_t n_emit = padded != 0 ? out_n : 0u;
+            for (uint32_t gb = 0; gb < nb; gb += 4) {
+                const int hj = (int)gb + team;
+                const uint32_t e_n = __shfl(n_emit, hj & 63, 64);
+                const uint32_t e_aop = __shfl(a_op, hj & 63, 64);
+                const uint32_t e_af = __shfl(A.part, hj & 63, 64);
+                const uint32_t e_bl = __shfl(B.part, hj & 63, 64);
+                const uint64_t e_off = __shfl(my_off, hj & 63, 64);
+                const bool e_verb = __shfl((int)inside, hj & 63, 64) != 0;
+                const uint32_t *__restrict__ src = rec_ops + e_aop;
+                uint32_t *__restrict__ dst = p.out_ops + e_off;
+                uint32_t mx = e_n; // rounds needed by the longest clip of the four
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, 16, 64));
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32, 64));
+                const uint32_t rounds = (rb_first(mx) + 255u) >> 8;
+                const uint32_t li = (uint32_t)tl * 4u;
+                uint4 va[4], vb[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, li + (uint32_t)u * 64u, e_n);
+                for (uint32_t k = 0; k < rounds; k += 2) {
+                    const uint32_t i0 = k << 8;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) vb[u] = rb_emit_load(src, i0 + 256u + li + (uint32_t)u * 64u, e_n);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, va[u]);
+                    if (k + 1 >= rounds) break;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, i0 + 512u + li + (uint32_t)u * 64u, e_n);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + 256u + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, vb[u]);
+                }
             }
         }
     }
