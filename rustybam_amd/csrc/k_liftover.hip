@@ -23,7 +23,7 @@
 // emitted op.  No MFMA: integer / index work only.
 #include "rb_device.h"
 
-#define RB_HMAX 64            // hits resolved per streaming pass of one record
+#define RB_HMAX 32            // hits resolved per streaming pass of one record (lanes 0-31 starts, 32-63 ends)
 #define RB_LDS_PER_HIT 6      // dwords of per-hit (start) state in LDS
 #define RB_ARENA_STRIDE 16    // u64 words between arena cursors (128 B)
 
@@ -232,11 +232,13 @@ __device__ void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_no
 // ---- emission helpers: one lane moves 4 ops (16 B) of its team's clip --------------------------------
 // i = op position inside the clip (multiple of 4), e_n = ops in the clip.  The ops array is padded, so
 // the load may read up to 3 ops past the clip; they are zeroed before the store.
-__device__ __forceinline__ uint4 rb_emit_load(const uint32_t *src, uint32_t i, uint32_t e_n) {
+__device__ __forceinline__ uint4 rb_emit_load(const uint32_t *src, uint32_t i, uint32_t e_n, int dbg = 0) {
+    if (dbg & 16) return make_uint4(i, 0, 0, 0);
     return i < e_n ? rb_load4_unaligned(src + i) : make_uint4(0, 0, 0, 0);
 }
-__device__ __forceinline__ void rb_emit_store(uint32_t *dst, uint32_t i, uint32_t e_n, uint32_t afirst, uint32_t blast, bool verbatim, uint4 v) {
+__device__ __forceinline__ void rb_emit_store(uint32_t *dst, uint32_t i, uint32_t e_n, uint32_t afirst, uint32_t blast, bool verbatim, uint4 v, int dbg = 0) {
     if (i >= e_n) return;
+    if (dbg & 8) { if (v.x == 0xFFFFFFF1u) dst[0] = v.y; return; }
     if (i + 1 >= e_n) v.y = 0u;
     if (i + 2 >= e_n) v.z = 0u;
     if (i + 3 >= e_n) v.w = 0u;
@@ -391,7 +393,7 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
     }
 }
 
-#define RB_SMAX 40 // steps (of 256 ops) whose checkpoints fit in LDS at once
+#define RB_SMAX 20 // steps (of 256 ops) whose checkpoints fit in LDS at once
 #define RB_CP_PER_STEP 16
 
 __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
@@ -440,34 +442,37 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
 
     for (uint64_t jb = 0; jb < nh; jb += RB_HMAX) {
         const uint32_t nb = (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX);
-        // ---- per-hit setup: lane j owns window jb + j ----
+        // ---- per-hit setup: lanes j and j + 32 both look at window jb + j; lane j resolves its start
+        //      boundary, lane j + 32 its end boundary; lane j then owns the row ----
         uint64_t wst = 0, wen = 0;
         uint32_t win = 0;
-        const bool mine = (uint32_t)lane < nb;
-        if (mine) {
+        const uint32_t hl = (uint32_t)lane & 31u;
+        const bool own = hl < nb;
+        const bool mine = own && lane < 32;
+        const bool is_start = lane < 32;
+        if (own) {
             if (explicit_w) {
-                wst = p.x_st[h0 + jb + lane];
-                wen = p.x_en[h0 + jb + lane];
-                win = (uint32_t)(jb + lane);
+                wst = p.x_st[h0 + jb + hl];
+                wen = p.x_en[h0 + jb + hl];
+                win = (uint32_t)(jb + hl);
             } else {
-                wst = p.w_st[lo + jb + lane];
-                wen = p.w_en[lo + jb + lane];
-                win = p.w_orig[lo + jb + lane];
+                wst = p.w_st[lo + jb + hl];
+                wen = p.w_en[lo + jb + hl];
+                win = p.w_orig[lo + jb + hl];
             }
         }
-        const bool inside = mine && (t_st > wst && t_en < wen); // liftover.rs:23-25
+        const bool inside = own && (t_st > wst && t_en < wen); // liftover.rs:23-25
         // D = (relative ref offset of the boundary base) + 1
-        const uint32_t Ds = (uint32_t)((wst > t_st ? wst : t_st) - t_st) + 1u; // liftover.rs:28
-        const uint32_t De = (uint32_t)((wen < t_en ? wen : t_en) - t_st);       // (min(en,t_en) - 1 - t_st) + 1, :38-40
-        bool need_s = mine && !inside, need_e = need_s;
-        rb_bres A, B;
-        A.st = B.st = RB_S_UNRES;
-        A.op = A.part = A.R = A.Q = A.U = 0;
-        B.op = B.part = B.R = B.Q = B.U = 0;
+        const uint32_t D = is_start ? (uint32_t)((wst > t_st ? wst : t_st) - t_st) + 1u // liftover.rs:28
+                                    : (uint32_t)((wen < t_en ? wen : t_en) - t_st);     // (min(en,t_en) - 1 - t_st) + 1, :38-40
+        bool need = own && !inside;
+        rb_bres O;
+        O.st = RB_S_UNRES;
+        O.op = O.part = O.R = O.Q = O.U = 0;
 
         // ---- stream the record, RB_SMAX steps per segment; resolve after each segment ----
         uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
-        if (__ballot(need_s) != 0 && !(p.debug_skip & 4)) {
+        if (__ballot(need) != 0 && !(p.debug_skip & 4)) {
             auto load_step = [&](uint32_t stp) -> uint4 {
                 const uint64_t gi = glane + ((uint64_t)stp << 8);
                 return gi < gend ? *reinterpret_cast<const uint4 *>(p.ops + gi) : make_uint4(0, 0, 0, 0);
@@ -509,18 +514,14 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 const bool last_seg = seg1 == n_steps;
                 const uint32_t n_cp = (seg1 - seg0) * RB_CP_PER_STEP;
                 const int32_t cp_idx0 = (int32_t)(seg0 << 8) - head; // op index of checkpoint 0
-#pragma unroll 1
-                for (int which = 0; which < 2; which++) {
-                    const bool is_start = which == 0;
-                    const uint32_t D = is_start ? Ds : De;
-                    const bool todo = (is_start ? need_s : need_e) && D >= Rseg && (D < Rb || (last_seg && D == Rb));
+                {
+                    const bool todo = need && D >= Rseg && (D < Rb || (last_seg && D == Rb));
                     if (todo && !(p.debug_skip & 2)) {
-                        rb_bres o;
                         if (D == Rb) { // boundary on the record's last base; the last op is match-type
                             const uint32_t lv = rec_ops[n - 1];
-                            o.st = RB_S_OK, o.op = n - 1;
-                            if (is_start) o.part = 1u, o.R = Rb - 1, o.Q = Qb - 1, o.U = Ub - 1;
-                            else o.part = rb_len(lv), o.R = Rb, o.Q = Qb, o.U = Ub;
+                            O.st = RB_S_OK, O.op = n - 1;
+                            if (is_start) O.part = 1u, O.R = Rb - 1, O.Q = Qb - 1, O.U = Ub - 1;
+                            else O.part = rb_len(lv), O.R = Rb, O.Q = Qb, O.U = Ub;
                         } else {
                             // last checkpoint with R <= D (R is non-decreasing)
                             uint32_t lo_t = 0, hi_t = n_cp;
@@ -528,16 +529,24 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                                 const uint32_t mid = (lo_t + hi_t) >> 1;
                                 if (cpR[mid] <= D) lo_t = mid; else hi_t = mid;
                             }
-                            o = rb_resolve(rec_ops, n, cp_idx0 + (int32_t)lo_t * 16, cpR[lo_t], cpQ[lo_t], cpU[lo_t], D, is_start, p.policy);
+                            O = rb_resolve(rec_ops, n, cp_idx0 + (int32_t)lo_t * 16, cpR[lo_t], cpQ[lo_t], cpU[lo_t], D, is_start, p.policy);
                         }
-                        if (is_start) A = o, need_s = false; else B = o, need_e = false;
+                        need = false;
                     }
                 }
-                if (p.early_exit && __ballot(need_s || need_e) == 0) break;
+                if (p.early_exit && __ballot(need) == 0) break;
             }
         }
 
-        // ---- finalize: lane j computes the row of hit jb + j ----
+        // ---- finalize: lane j (< 32) computes the row of hit jb + j; the end comes from lane j + 32 ----
+        const rb_bres A = O;
+        rb_bres B;
+        B.st = (uint32_t)__shfl((int)O.st, lane + 32, 64);
+        B.op = (uint32_t)__shfl((int)O.op, lane + 32, 64);
+        B.part = (uint32_t)__shfl((int)O.part, lane + 32, 64);
+        B.R = (uint32_t)__shfl((int)O.R, lane + 32, 64);
+        B.Q = (uint32_t)__shfl((int)O.Q, lane + 32, 64);
+        B.U = (uint32_t)__shfl((int)O.U, lane + 32, 64);
         uint32_t status = RB_ST_OK, out_n = 0, a_op = 0;
         uint64_t o_tst = 0, o_ten = 0, o_qst = 0, o_qen = 0;
         uint32_t o_nm = 0, o_al = 0;
@@ -627,18 +636,18 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 const uint32_t li = (uint32_t)tl * 4u;
                 uint4 va[4], vb[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, li + (uint32_t)u * 64u, e_n);
+                for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, li + (uint32_t)u * 64u, e_n, p.debug_skip);
                 for (uint32_t k = 0; k < rounds; k += 2) {
                     const uint32_t i0 = k << 8;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) vb[u] = rb_emit_load(src, i0 + 256u + li + (uint32_t)u * 64u, e_n);
+                    for (int u = 0; u < 4; u++) vb[u] = rb_emit_load(src, i0 + 256u + li + (uint32_t)u * 64u, e_n, p.debug_skip);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, va[u]);
+                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, va[u], p.debug_skip);
                     if (k + 1 >= rounds) break;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, i0 + 512u + li + (uint32_t)u * 64u, e_n);
+                    for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, i0 + 512u + li + (uint32_t)u * 64u, e_n, p.debug_skip);
 #pragma unroll
-                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + 256u + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, vb[u]);
+                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + 256u + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, vb[u], p.debug_skip);
                 }
             }
         }
