@@ -22,6 +22,7 @@
 // Roofline: HBM.  Algorithmic bytes: 4 B per input op + 48 B per record + 88 B per hit + 4 B per
 // emitted op.  No MFMA: integer / index work only.
 #include "rb_device.h"
+#include <cstdlib>
 
 #define RB_HMAX 32            // hits resolved per streaming pass of one record (lanes 0-31 starts, 32-63 ends)
 #define RB_LDS_PER_HIT 6      // dwords of per-hit (start) state in LDS
@@ -254,7 +255,11 @@ __device__ __forceinline__ void rb_emit_store(uint32_t *dst, uint32_t i, uint32_
             if (q == 0) v.x = nv; else if (q == 1) v.y = nv; else if (q == 2) v.z = nv; else v.w = nv;
         }
     }
-    *reinterpret_cast<uint4 *>(dst + i) = v;
+    // streaming (non-temporal) store: the clipped cigars are written once and never re-read here, so they
+    // should not displace the record's ops from L2
+    typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
+    rb_u32x4 nv4 = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(nv4, reinterpret_cast<rb_u32x4 *>(dst + i));
 }
 
 // ---- lane-local boundary resolution --------------------------------------------------------------
@@ -395,10 +400,14 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
 
 #define RB_SMAX 20 // steps (of 256 ops) whose checkpoints fit in LDS at once
 #define RB_CP_PER_STEP 16
+#ifndef RB_EB
+#define RB_EB 4 // output groups (16 B) per lane and emission batch
+#endif
 
 __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
     // checkpoints: exclusive (R,Q,U) prefixes every 16 ops, SoA so that R can be binary-searched
     __shared__ uint32_t cp_all[4][3][RB_SMAX * RB_CP_PER_STEP];
+    __shared__ uint32_t et_all[4][5][RB_HMAX]; // per clip: first output op, a_op, out_n, first len, last len | verbatim
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (wave >= p.n_rec) return;
     const int lane = rb_lane();
@@ -614,40 +623,47 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 *row = w;
             }
         }
-        // ---- emit: four 16-lane teams copy four hits at a time; per team 256 ops (4 x 16 B per lane) per
-        //      round, the loads of round k+1 in flight while round k is patched and stored ----
-        if (fits && !(p.debug_skip & 1)) {
-            const int team = lane >> 4, tl = lane & 15;
-            const uint32_t n_emit = padded != 0 ? out_n : 0u;
-            for (uint32_t gb = 0; gb < nb; gb += 4) {
-                const int hj = (int)gb + team;
-                const uint32_t e_n = __shfl(n_emit, hj & 63, 64);
-                const uint32_t e_aop = __shfl(a_op, hj & 63, 64);
-                const uint32_t e_af = __shfl(A.part, hj & 63, 64);
-                const uint32_t e_bl = __shfl(B.part, hj & 63, 64);
-                const uint64_t e_off = __shfl(my_off, hj & 63, 64);
-                const bool e_verb = __shfl((int)inside, hj & 63, 64) != 0;
-                const uint32_t *__restrict__ src = rec_ops + e_aop;
-                uint32_t *__restrict__ dst = p.out_ops + e_off;
-                uint32_t mx = e_n; // rounds needed by the longest clip of the four
-                mx = max(mx, (uint32_t)__shfl_xor((int)mx, 16, 64));
-                mx = max(mx, (uint32_t)__shfl_xor((int)mx, 32, 64));
-                const uint32_t rounds = (rb_first(mx) + 255u) >> 8;
-                const uint32_t li = (uint32_t)tl * 4u;
-                uint4 va[4], vb[4];
+        // ---- emit: the clips of this pass occupy one contiguous output region [base, base + total).
+        //      Lane l moves output groups (4 ops, 16 B aligned) l, l + 64, ...; the clip a group belongs to is
+        //      found by a 5-step search of the clips' output offsets in LDS (offsets are non-decreasing; the
+        //      last clip starting at or before the group is the one that contains it).  8 independent 16 B
+        //      loads per lane are in flight per batch. ----
+        if (fits && total && !(p.debug_skip & 1)) {
+            uint32_t *et = &et_all[threadIdx.x >> 6][0][0];
+            if (mine) {
+                et[0 * RB_HMAX + lane] = incl - padded; // first output op of the clip
+                et[1 * RB_HMAX + lane] = a_op;
+                et[2 * RB_HMAX + lane] = padded ? out_n : 0u;
+                et[3 * RB_HMAX + lane] = A.part;
+                et[4 * RB_HMAX + lane] = B.part | (inside ? 0x80000000u : 0u);
+            }
+            uint32_t *__restrict__ dst = p.out_ops + ((uint64_t)arena * p.arena_size + base);
+            for (uint32_t gb = 0; gb * 4u < total; gb += RB_EB * 64u) {
+                uint4 v[RB_EB];
+                uint32_t cj[RB_EB], cpos[RB_EB];
 #pragma unroll
-                for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, li + (uint32_t)u * 64u, e_n, p.debug_skip);
-                for (uint32_t k = 0; k < rounds; k += 2) {
-                    const uint32_t i0 = k << 8;
+                for (int u = 0; u < RB_EB; u++) {
+                    const uint32_t o = (gb + (uint32_t)u * 64u + (uint32_t)lane) * 4u; // output op of this group
+                    uint32_t lo_j = 0, hi_j = nb;
+                    while (hi_j - lo_j > 1) { // last clip with first output op <= o
+                        const uint32_t mid = (lo_j + hi_j) >> 1;
+                        if (et[mid] <= o) lo_j = mid; else hi_j = mid;
+                    }
+                    cj[u] = lo_j;
+                    const uint32_t pos = o - et[lo_j];
+                    const uint32_t e_n = et[2 * RB_HMAX + lo_j];
+                    const bool live = o < total && pos < e_n;
+                    cpos[u] = live ? pos : 0xFFFFFFFFu;
+                    v[u] = live ? rb_emit_load(rec_ops + et[1 * RB_HMAX + lo_j], pos, e_n, p.debug_skip) : make_uint4(0, 0, 0, 0);
+                }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) vb[u] = rb_emit_load(src, i0 + 256u + li + (uint32_t)u * 64u, e_n, p.debug_skip);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, va[u], p.debug_skip);
-                    if (k + 1 >= rounds) break;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) va[u] = rb_emit_load(src, i0 + 512u + li + (uint32_t)u * 64u, e_n, p.debug_skip);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) rb_emit_store(dst, i0 + 256u + li + (uint32_t)u * 64u, e_n, e_af, e_bl, e_verb, vb[u], p.debug_skip);
+                for (int u = 0; u < RB_EB; u++) {
+                    if (cpos[u] != 0xFFFFFFFFu) {
+                        const uint32_t o = (gb + (uint32_t)u * 64u + (uint32_t)lane) * 4u;
+                        const uint32_t j = cj[u];
+                        const uint32_t bl = et[4 * RB_HMAX + j];
+                        rb_emit_store(dst + (o - cpos[u]), cpos[u], et[2 * RB_HMAX + j], et[3 * RB_HMAX + j], bl & 0x7FFFFFFFu, (bl >> 31) != 0, v[u], p.debug_skip);
+                    }
                 }
             }
         }
@@ -904,7 +920,9 @@ extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t
 extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((p->n_rec + 3) / 4);
-    hipLaunchKernelGGL(rb_k_liftover_stream, dim3(blocks), dim3(256), 0, stream, *p);
+    // diagnostics: RB_DEBUG_DYN_LDS=<bytes> adds unused dynamic LDS to lower the occupancy
+    static const unsigned dyn = getenv("RB_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("RB_DEBUG_DYN_LDS")) : 0u;
+    hipLaunchKernelGGL(rb_k_liftover_stream, dim3(blocks), dim3(256), dyn, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream) {
