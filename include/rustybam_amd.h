@@ -15,6 +15,9 @@
  *                             subset_cigar/collapse_long_cigar :593-620, paf_overlaps_rgn :622-627)
  *   rb_dev_break          <- liftover::break_paf_on_indels                liftover.rs:182-226
  *   rb_dev_swap           <- paf::paf_swap_query_and_target               paf.rs:1050-1094
+ *   rb_dev_overlap_split  <- trim_overlap::trim_overlapping_pafs          trim_overlap.rs:36-86
+ *                            + PafRecord::truncate_record_by_query        paf.rs:785-823
+ *                            (the pass / recursion driver Paf::overlapping_paf_recs, paf.rs:210-305, stays on the host)
  *
  * Conventions
  *   - Plain C types only.  Every `rb_dev_*` pointer argument is a DEVICE pointer (HBM) owned by
@@ -220,6 +223,16 @@ int rb_dev_break(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *batch, c
  * (The header swap t<->q is a host-side field swap.) */
 int rb_dev_swap(rb_ctx *ctx, const rb_batch_view *batch, uint32_t *out_ops);
 
+/* ---- trim-paf: one pass of independent (left, right) overlap pairs ------------------------------ *
+ * left[i] / right[i] index records of the batch (left = smaller q_st, paf.rs:252-256).  For each pair:
+ * split point = first arg-max of prefix(left scores) + suffix(right scores) over the overlapped query
+ * bases (trim_overlap.rs:50-76), then both records are clipped by query range.  pair_out_off[i] = first
+ * op of pair i's output in out_ops; the pair needs room for n_ops(left) + n_ops(right) ops.  norm_rows
+ * come from rb_dev_scan_records on the same batch. */
+int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *batch, const rb_norm_row *norm_rows, uint64_t n_pairs,
+                         const uint32_t *left, const uint32_t *right, const uint64_t *pair_out_off, int match_score,
+                         int diff_score, int indel_score, int bsearch_policy, rb_pair_row *rows, uint32_t *out_ops);
+
 /* ---- host-buffer wrappers (H2D, kernels, D2H; results malloc'ed, free with rb_host_free) ------ */
 int rb_host_scan_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off,
                          const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
@@ -235,6 +248,11 @@ int rb_host_break(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64
                   uint64_t *n_rows, uint32_t **out_ops, uint64_t *n_out, rb_counters *counters);
 int rb_host_swap(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint8_t *strand,
                  uint32_t *out_ops);
+/* rows [n_pairs] caller-allocated; out_ops malloc'ed (dense, rows' out_off rebased onto it) */
+int rb_host_overlap_split(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                          const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                          uint64_t n_pairs, const uint32_t *left, const uint32_t *right, int match_score, int diff_score,
+                          int indel_score, int bsearch_policy, rb_pair_row *rows, uint32_t **out_ops, uint64_t *n_out);
 void rb_host_free(void *p);
 
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *

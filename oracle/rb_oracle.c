@@ -942,7 +942,6 @@ int rbo_break_paf_on_indels(const rbo_rec *paf, uint32_t break_length, int polic
 
 /* ------------------------------------------------------------------ paf.rs:785-823 */
 int rbo_truncate_record_by_query(rbo_rec *r, uint64_t new_q_st, uint64_t new_q_en, int policy) {
-    if (getenv("RBO_DEBUG")) fprintf(stderr, "trunc q=%llu..%llu new=%llu..%llu %c\n", (unsigned long long)r->q_st, (unsigned long long)r->q_en, (unsigned long long)new_q_st, (unsigned long long)new_q_en, r->strand);
     if (!(new_q_st >= r->q_st)) return RBO_PANIC_ASSERT;
     if (!(new_q_en <= r->q_en)) return RBO_PANIC_ASSERT;
     if (new_q_en == 0) return RBO_PANIC_ASSERT; /* new_q_en - 1 underflows */
@@ -950,6 +949,8 @@ int rbo_truncate_record_by_query(rbo_rec *r, uint64_t new_q_st, uint64_t new_q_e
     size_t aln_st, aln_en;
     if (rbo_qpos_to_idx_match(r, new_q_st, 1, policy, &aln_st)) return RBO_PANIC_NOTFOUND;
     if (rbo_qpos_to_idx_match(r, new_q_en - 1, 0, policy, &aln_en)) return RBO_PANIC_NOTFOUND;
+    /* the walk to a match may run off the end (idx == len): self.qpos_aln[idx] then panics (paf.rs:795-796) */
+    if (aln_st >= r->n_aln || aln_en >= r->n_aln) return RBO_PANIC_NOTFOUND;
     uint64_t nn_q_st = r->qpos_aln[aln_st];
     uint64_t nn_q_en = r->qpos_aln[aln_en] + 1;
     if (aln_st > aln_en) {
@@ -994,7 +995,6 @@ int rbo_trim_overlapping_pafs(rbo_rec *left, rbo_rec *right, int ms, int ds, int
     uint64_t st_ovl = left->q_st > right->q_st ? left->q_st : right->q_st;
     uint64_t en_ovl = left->q_en < right->q_en ? left->q_en : right->q_en;
     size_t n = en_ovl > st_ovl ? (size_t)(en_ovl - st_ovl) : 0;
-    if (getenv("RBO_DEBUG")) fprintf(stderr, "pair L q=%llu..%llu %c  R q=%llu..%llu %c ovl=%llu..%llu\n", (unsigned long long)left->q_st, (unsigned long long)left->q_en, left->strand, (unsigned long long)right->q_st, (unsigned long long)right->q_en, right->strand, (unsigned long long)st_ovl, (unsigned long long)en_ovl);
     int32_t *l_score = (int32_t *)xmalloc((n + 1) * sizeof(int32_t));
     int32_t *r_score = (int32_t *)xmalloc((n + 1) * sizeof(int32_t));
     l_score[0] = 0;

@@ -5,5 +5,5 @@ The product is the C-ABI shared library ``librustybam_amd.so`` (include/rustybam
 it never falls back to a CPU implementation: if the library or a gfx950 device is missing, calls
 raise.
 """
-from .capi import (Engine, RbError, lib, lib_path, HIT_DT, NORM_DT, REDUCE_DT, COUNTERS_DT,  # noqa: F401
+from .capi import (Engine, RbError, lib, lib_path, HIT_DT, NORM_DT, REDUCE_DT, COUNTERS_DT, PAIR_DT,  # noqa: F401
                    BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, exported_symbols, declared_symbols)

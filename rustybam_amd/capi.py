@@ -23,10 +23,15 @@ NORM_DT = np.dtype(
 HIT_DT = np.dtype(
     [("rec", "<u4"), ("win", "<u4"), ("status", "<u2"), ("flags", "<u2"), ("out_n", "<u4"), ("t_st", "<u8"),
      ("t_en", "<u8"), ("q_st", "<u8"), ("q_en", "<u8"), ("nmatch", "<u4"), ("aln_len", "<u4"), ("out_off", "<u8")])
+PAIR_DT = np.dtype(
+    [("split_idx", "<u8"), ("split_score", "<i4"), ("status", "<u4"), ("t_st", "<u8", 2), ("t_en", "<u8", 2),
+     ("q_st", "<u8", 2), ("q_en", "<u8", 2), ("nmatch", "<u4", 2), ("aln_len", "<u4", 2), ("out_off", "<u8", 2),
+     ("out_n", "<u4", 2), ("_pad", "<u8")])
 COUNTERS_DT = np.dtype(
     [("n_hits", "<u8"), ("out_ops_needed", "<u8"), ("out_ops_used", "<u8"), ("n_generic", "<u8"),
      ("overflow", "<u4"), ("_pad", "<u4", 7)])
 assert REDUCE_DT.itemsize == 72 and NORM_DT.itemsize == 64 and HIT_DT.itemsize == 64 and COUNTERS_DT.itemsize == 64
+assert PAIR_DT.itemsize == 128
 
 
 class RbError(RuntimeError):
@@ -220,6 +225,28 @@ class Engine:
         s = _arr(strand, np.uint8)
         args = [C.c_uint64(n), _p(ops), _p(op_off), *map(_p, a), _p(s), C.c_uint32(max_size), C.c_int(policy)]
         return self._lift(self.L.rb_host_break, "rb_host_break", n, args)
+
+    def overlap_split(self, ops, op_off, t_st, t_en, q_st, q_en, strand, left, right, scores=(1, 1, 1),
+                      policy=BSEARCH_MODERN):
+        ops, op_off = _arr(ops, np.uint32), _arr(op_off, np.uint64)
+        n = len(op_off) - 1
+        ops = np.concatenate([ops, np.zeros(4, np.uint32)])
+        a = [_arr(x, np.uint64) for x in (t_st, t_en, q_st, q_en)]
+        s = _arr(strand, np.uint8)
+        left, right = _arr(left, np.uint32), _arr(right, np.uint32)
+        rows = np.zeros(len(left), PAIR_DT)
+        out, no = C.c_void_p(), C.c_uint64()
+        self._chk(self.L.rb_host_overlap_split(self.ctx, C.c_uint64(n), _p(ops), _p(op_off), *map(_p, a), _p(s),
+                                               C.c_uint64(len(left)), _p(left), _p(right), C.c_int(scores[0]),
+                                               C.c_int(scores[1]), C.c_int(scores[2]), C.c_int(policy), _p(rows),
+                                               C.byref(out), C.byref(no)), "rb_host_overlap_split")
+        if no.value:
+            buf = (C.c_char * (no.value * 4)).from_address(out.value)
+            o = np.frombuffer(buf, dtype=np.uint32).copy()
+        else:
+            o = np.zeros(0, np.uint32)
+        self.L.rb_host_free(out)
+        return rows, o
 
     def swap(self, ops, op_off, strand):
         ops, op_off, s = _arr(ops, np.uint32), _arr(op_off, np.uint64), _arr(strand, np.uint8)

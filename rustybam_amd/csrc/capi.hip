@@ -68,6 +68,19 @@ struct rb_break_params {
     uint32_t max_size;
     int fill;
 };
+struct rb_trim_params {
+    uint64_t n_pairs;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint8_t *strand;
+    const rb_norm_row *norm;
+    const uint32_t *left, *right;
+    const uint64_t *pair_out_off;
+    int match_score, diff_score, indel_score;
+    int policy;
+    rb_pair_row *rows;
+    uint32_t *out_ops;
+};
 struct rb_swap_params {
     uint64_t n_rec;
     const uint32_t *ops;
@@ -83,6 +96,7 @@ extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream
 extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec);
 extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops, hipStream_t stream);
 
 #define RB_ARENA_STRIDE 16
@@ -482,6 +496,29 @@ extern "C" int rb_dev_swap(rb_ctx *ctx, const rb_batch_view *b, uint32_t *out_op
     return RB_OK;
 }
 
+extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const rb_norm_row *norm, uint64_t n_pairs, const uint32_t *left,
+                                    const uint32_t *right, const uint64_t *pair_out_off, int match_score, int diff_score,
+                                    int indel_score, int policy, rb_pair_row *rows, uint32_t *out_ops) {
+    if (!ctx || !b || !norm || (n_pairs && (!left || !right || !pair_out_off || !rows || !out_ops))) return RB_E_INVALID;
+    rb_trim_params p;
+    p.n_pairs = n_pairs;
+    p.ops = b->ops;
+    p.op_off = b->op_off;
+    p.strand = b->strand;
+    p.norm = norm;
+    p.left = left;
+    p.right = right;
+    p.pair_out_off = pair_out_off;
+    p.match_score = match_score;
+    p.diff_score = diff_score;
+    p.indel_score = indel_score;
+    p.policy = policy & 1;
+    p.rows = rows;
+    p.out_ops = out_ops;
+    HIPCHK(ctx, rb_launch_overlap_split(&p, ctx->stream));
+    return RB_OK;
+}
+
 // ---- host-buffer wrappers ----------------------------------------------------------------------
 namespace {
 struct DevBatch {
@@ -695,6 +732,61 @@ extern "C" int rb_host_swap(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, co
     if ((rc = b.alloc((size_t)n_ops + 4, &d_out))) return rc;
     if ((rc = rb_dev_swap(ctx, &b.v, d_out))) return rc;
     return rb_dev_download(ctx, out_ops, d_out, (size_t)n_ops * 4);
+}
+
+extern "C" int rb_host_overlap_split(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                                     const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                                     uint64_t n_pairs, const uint32_t *left, const uint32_t *right, int match_score, int diff_score,
+                                     int indel_score, int policy, rb_pair_row *rows, uint32_t **out_ops, uint64_t *n_out) {
+    if (!ctx || !out_ops || !n_out || (n_pairs && !rows)) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *out_ops = nullptr;
+    *n_out = 0;
+    DevBatch b(ctx);
+    int rc = b.load(n_rec, ops, op_off, t_st, t_en, q_st, q_en, strand, nullptr);
+    if (rc) return rc;
+    rb_norm_row *d_norm = nullptr;
+    if ((rc = b.alloc(n_rec, &d_norm))) return rc;
+    if ((rc = rb_dev_scan_records(ctx, &b.v, nullptr, d_norm))) return rc;
+    std::vector<uint64_t> poff(n_pairs + 1, 0);
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        if (left[i] >= n_rec || right[i] >= n_rec) return fail(ctx, RB_E_INVALID, "pair %llu references a record outside the batch", (unsigned long long)i);
+        poff[i + 1] = poff[i] + (op_off[left[i] + 1] - op_off[left[i]]) + (op_off[right[i] + 1] - op_off[right[i]]);
+    }
+    const uint32_t *d_left = nullptr, *d_right = nullptr;
+    const uint64_t *d_poff = nullptr;
+    rb_pair_row *d_rows = nullptr;
+    uint32_t *d_out = nullptr;
+    if ((rc = b.up(left, (size_t)n_pairs, &d_left))) return rc;
+    if ((rc = b.up(right, (size_t)n_pairs, &d_right))) return rc;
+    if ((rc = b.up(poff.data(), (size_t)n_pairs + 1, &d_poff))) return rc;
+    if ((rc = b.alloc((size_t)n_pairs + 1, &d_rows))) return rc;
+    if ((rc = b.alloc((size_t)poff[n_pairs] + 4, &d_out))) return rc;
+    if ((rc = rb_dev_overlap_split(ctx, &b.v, d_norm, n_pairs, d_left, d_right, d_poff, match_score, diff_score, indel_score, policy,
+                                   d_rows, d_out)))
+        return rc;
+    if (n_pairs && (rc = rb_dev_download(ctx, rows, d_rows, (size_t)n_pairs * sizeof(rb_pair_row)))) return rc;
+    std::vector<uint32_t> raw((size_t)poff[n_pairs] + 4);
+    if (poff[n_pairs] && (rc = rb_dev_download(ctx, raw.data(), d_out, (size_t)poff[n_pairs] * 4))) return rc;
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n_pairs; i++)
+        if (rows[i].status == RB_ST_OK) total += rows[i].out_n[0] + rows[i].out_n[1];
+    *out_ops = (uint32_t *)malloc((size_t)(total + 1) * 4);
+    uint64_t o = 0;
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        for (int s = 0; s < 2; s++) {
+            if (rows[i].status == RB_ST_OK) {
+                memcpy(*out_ops + o, raw.data() + rows[i].out_off[s], (size_t)rows[i].out_n[s] * 4);
+                rows[i].out_off[s] = o;
+                o += rows[i].out_n[s];
+            } else {
+                rows[i].out_off[s] = 0;
+                rows[i].out_n[s] = 0;
+            }
+        }
+    }
+    *n_out = o;
+    return rb_ctx_sync(ctx);
 }
 
 // ---- synthetic workload --------------------------------------------------------------------------

@@ -1,0 +1,98 @@
+"""trim-paf on the device (pair kernel through the C ABI) vs the CPU oracle; bit-exact."""
+import hashlib
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import rustybam_amd
+from rustybam_amd import trim_driver
+from rbtest_util import random_cigar, read_paf, recs_from_lines, sums, unpack
+
+pytestmark = pytest.mark.gpu
+
+
+def _pairs_batch(rng, n_pairs, mode):
+    cig, t_st, t_en, q_st, q_en, strand = [], [], [], [], [], []
+    left, right = [], []
+    for _ in range(n_pairs):
+        ca = random_cigar(rng, int(rng.integers(3, 60)), mode)
+        cb = random_cigar(rng, int(rng.integers(3, 60)), mode)
+        (ra, qa), (rb, qb) = sums(ca), sums(cb)
+        if min(qa, qb) < 2:
+            continue
+        a0 = int(rng.integers(0, 1000))
+        o = int(rng.integers(1, min(qa, qb)))  # 1 <= overlap < both lengths: neither is contained
+        b0 = a0 + qa - o
+        for c, r, q, s0 in ((ca, ra, qa, a0), (cb, rb, qb, b0)):
+            ts = int(rng.integers(0, 5000))
+            cig.append(c); t_st.append(ts); t_en.append(ts + r); q_st.append(s0); q_en.append(s0 + q)
+            strand.append(ord("+") if rng.random() < .5 else ord("-"))
+        left.append(len(cig) - 2); right.append(len(cig) - 1)
+    off = np.zeros(len(cig) + 1, np.uint64)
+    off[1:] = np.cumsum([len(c) for c in cig])
+    return dict(ops=np.concatenate(cig), op_off=off, t_st=np.array(t_st, np.uint64), t_en=np.array(t_en, np.uint64),
+                q_st=np.array(q_st, np.uint64), q_en=np.array(q_en, np.uint64), strand=np.array(strand, np.uint8)), \
+        np.array(left, np.uint32), np.array(right, np.uint32)
+
+
+def _compare(rows, out, orows, oout, what):
+    assert len(rows) == len(orows)
+    bad = np.nonzero(rows["status"] != orows["status"])[0]
+    assert len(bad) == 0, f"{what}: status differs at {bad[:5]}: gpu {rows['status'][bad[:5]]} oracle {orows['status'][bad[:5]]}"
+    ok = orows["status"] == 0
+    for k in ("split_idx", "split_score"):
+        bad = np.nonzero(ok & (rows[k] != orows[k]))[0]
+        assert len(bad) == 0, f"{what}: {k} differs at {bad[:5]}: gpu {rows[k][bad[:5]]} oracle {orows[k][bad[:5]]}"
+    for k in ("t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
+        bad = np.nonzero(ok[:, None] & (rows[k] != orows[k]))[0]
+        assert len(bad) == 0, f"{what}: {k} differs at pairs {bad[:5]}: gpu {rows[k][bad[:3]]} oracle {orows[k][bad[:3]]}"
+    for i in np.nonzero(ok)[0]:
+        for s in (0, 1):
+            a = out[int(rows["out_off"][i][s]):int(rows["out_off"][i][s]) + int(rows["out_n"][i][s])]
+            b = oout[int(orows["out_off"][i][s]):int(orows["out_off"][i][s]) + int(orows["out_n"][i][s])]
+            assert np.array_equal(a, b), f"{what}: cigar of pair {i} side {s}: gpu {unpack(a[:10])} oracle {unpack(b[:10])}"
+
+
+def test_known_answer_ka3(engine, oracle, golden):
+    k = json.load(open(os.path.join(golden, "known_answers.json")))["KA3_trim_pair"]
+    r = recs_from_lines([k["left"], k["right"]])
+    rows, out = engine.overlap_split(*r.arrays(), [0], [1], tuple(k["scores"]))
+    assert rows["status"][0] == 0 and int(rows["split_idx"][0]) == 2 and int(rows["split_score"][0]) == 5
+    got = [unpack(out[int(rows["out_off"][0][s]):int(rows["out_off"][0][s]) + int(rows["out_n"][0][s])]) for s in (0, 1)]
+    assert got == [k["left_cigar"], k["right_cigar"]]
+
+
+@pytest.mark.parametrize("mode", ["regular", "indel_ends", "wild"])
+@pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
+@pytest.mark.parametrize("scores", [(1, 1, 1), (2, 3, 5)])
+def test_pairs_random(engine, oracle, mode, policy, scores):
+    rng = np.random.default_rng(zlib.crc32(f"{mode}{policy}{scores}".encode()))
+    b, left, right = _pairs_batch(rng, 300, mode)
+    rows, out = engine.overlap_split(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"],
+                                     left, right, scores, policy)
+    ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
+    orows, oout = oracle.overlap_split(ob, left, right, scores, policy)
+    _compare(rows, out, orows, oout, f"{mode} policy={policy}")
+
+
+@pytest.mark.parametrize("policy,key", [(rustybam_amd.BSEARCH_MODERN, "trim_paf_modern"),
+                                        (rustybam_amd.BSEARCH_LEGACY, "trim_paf_legacy")])
+def test_trim_paf_fixture_end_to_end(engine, golden, policy, key):
+    """full `rb trim-paf` on the reference fixture through the device pair kernel: the printed PAF must
+    have the digest the oracle CLI produces (tests/golden/digests.json)."""
+    r = read_paf(os.path.join(golden, "asm_small.paf"))
+    recs = [dict(q_name=r.q_name[i], q_len=r.q_len[i], t_name=r.t_name[i], t_len=r.t_len[i], mapq=r.mapq[i],
+                 q_st=int(r.q_st[i]), q_en=int(r.q_en[i]), t_st=int(r.t_st[i]), t_en=int(r.t_en[i]),
+                 strand=int(r.strand[i]), cigar=r.cigars[i], id="") for i in range(r.n)]
+    out = trim_driver.overlapping_paf_recs(engine, recs, (1, 1, 1), False, policy)
+    lines = []
+    for x in out:
+        lines.append("\t".join(map(str, [x["q_name"], x["q_len"], x["q_st"], x["q_en"], chr(x["strand"]), x["t_name"],
+                                          x["t_len"], x["t_st"], x["t_en"], x["nmatch"], x["aln_len"], x["mapq"],
+                                          "id:Z:" + x["id"], "cg:Z:" + unpack(x["cigar"])])) + "\n")
+    dig = json.load(open(os.path.join(golden, "digests.json")))[key]["md5"]
+    assert len(lines) == 249
+    assert hashlib.md5("".join(lines).encode()).hexdigest() == dig
