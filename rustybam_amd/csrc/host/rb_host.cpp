@@ -1,0 +1,467 @@
+// rb_host.cpp -- see rb_host.hpp.  No CIGAR is walked on the CPU here: counting, clipping, splitting and
+// swapping all go through the C ABI to the device.
+#include "rb_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <unordered_map>
+#include <unordered_set>
+
+namespace rb {
+
+static const char OPCH[] = "MIDNSHP=X";
+
+Engine::Engine(int device) {
+    int rc = rb_ctx_create(device, nullptr, &ctx_);
+    if (rc != RB_OK) throw std::runtime_error("rustybam_amd: no usable MI355X (gfx950) device (rb_ctx_create = " + std::to_string(rc) + "); there is no CPU fallback");
+}
+Engine::~Engine() { rb_ctx_destroy(ctx_); }
+void Engine::check(int rc, const char *what) const {
+    if (rc != RB_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + rb_ctx_last_error(ctx_));
+}
+
+std::string cigar_to_string(const std::vector<uint32_t> &cigar) {
+    std::string s;
+    s.reserve(cigar.size() * 5);
+    char buf[16];
+    for (uint32_t v : cigar) {
+        auto r = std::to_chars(buf, buf + sizeof buf, v >> 4);
+        s.append(buf, r.ptr);
+        s.push_back(OPCH[v & 15u]);
+    }
+    return s;
+}
+
+std::string PafRecord::to_string() const {
+    std::string s;
+    s.reserve(128 + cigar.size() * 5);
+    s += q_name; s += '\t'; s += std::to_string(q_len); s += '\t'; s += std::to_string(q_st); s += '\t';
+    s += std::to_string(q_en); s += '\t'; s += strand; s += '\t'; s += t_name; s += '\t'; s += std::to_string(t_len);
+    s += '\t'; s += std::to_string(t_st); s += '\t'; s += std::to_string(t_en); s += '\t'; s += std::to_string(nmatch);
+    s += '\t'; s += std::to_string(aln_len); s += '\t'; s += std::to_string(mapq); s += "\tid:Z:"; s += id; s += "\tcg:Z:";
+    s += cigar_to_string(cigar);
+    return s;
+}
+
+static bool parse_u64(const char *s, size_t n, uint64_t &out) { // Rust u64::from_str
+    size_t i = 0;
+    if (n == 0) return false;
+    if (s[0] == '+') {
+        i = 1;
+        if (n == 1) return false;
+    }
+    uint64_t v = 0;
+    for (; i < n; i++) {
+        if (s[i] < '0' || s[i] > '9') return false;
+        const uint64_t d = (uint64_t)(s[i] - '0');
+        if (v > (UINT64_MAX - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    out = v;
+    return true;
+}
+
+// rust-htslib CigarString::try_from as used at paf.rs:398-399; any violation is the .expect() panic
+static void parse_cigar(const char *s, size_t n, std::vector<uint32_t> &out) {
+    out.clear();
+    size_t i = 0;
+    while (i < n) {
+        size_t j = i;
+        uint64_t len = 0;
+        while (j < n && s[j] >= '0' && s[j] <= '9') {
+            len = len * 10 + (uint64_t)(s[j] - '0');
+            if (len > 0xFFFFFFFFull) throw Panic("Unable to parse cigar string.");
+            j++;
+        }
+        if (j == i || j >= n) throw Panic("Unable to parse cigar string.");
+        const char *p = (const char *)memchr(OPCH, s[j], 9);
+        if (!p) throw Panic("Unable to parse cigar string.");
+        if (len >= (1ull << 28)) throw Panic("cigar length does not fit the packed form (>= 2^28)");
+        out.push_back(((uint32_t)len << 4) | (uint32_t)(p - OPCH));
+        i = j + 1;
+    }
+}
+
+int paf_record_new(const std::string &line, PafRecord &out) {
+    std::vector<std::pair<const char *, size_t>> t;
+    const char *p = line.c_str();
+    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f'; };
+    while (*p) {
+        while (*p && ws(*p)) p++;
+        if (!*p) break;
+        const char *q = p;
+        while (*q && !ws(*q)) q++;
+        t.emplace_back(p, (size_t)(q - p));
+        p = q;
+    }
+    if (t.size() < 12) throw Panic("assertion failed: t.len() >= 12"); // paf.rs:381
+    std::vector<uint32_t> cigar;
+    for (size_t k = 12; k < t.size(); k++) { // PAF_TAG "(..):(.):(.*)", leftmost match (paf.rs:21, :387-390)
+        const char *s = t[k].first;
+        const size_t n = t[k].second;
+        size_t m = (size_t)-1;
+        for (size_t i = 0; i + 5 <= n; i++)
+            if (s[i + 2] == ':' && s[i + 4] == ':') {
+                m = i;
+                break;
+            }
+        if (m == (size_t)-1) throw Panic("assertion failed: PAF_TAG.is_match(token)");
+        if (s[m] == 'c' && s[m + 1] == 'g' && cigar.empty()) parse_cigar(s + m + 5, n - (m + 5), cigar); // paf.rs:395
+    }
+    uint64_t v[12] = {0};
+    static const int numeric[] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
+    for (int c : numeric)
+        if (!parse_u64(t[c].first, t[c].second, v[c])) return 1;
+    if (t[4].second != 1) return 1;
+    out = PafRecord();
+    out.q_name.assign(t[0].first, t[0].second);
+    out.q_len = v[1], out.q_st = v[2], out.q_en = v[3];
+    out.strand = t[4].first[0];
+    out.t_name.assign(t[5].first, t[5].second);
+    out.t_len = v[6], out.t_st = v[7], out.t_en = v[8], out.nmatch = v[9], out.aln_len = v[10], out.mapq = v[11];
+    out.cigar.swap(cigar);
+    return 0;
+}
+
+static bool gz_getline(gzFile f, std::string &line) {
+    line.clear();
+    char buf[1 << 16];
+    for (;;) {
+        if (!gzgets(f, buf, sizeof buf)) return !line.empty();
+        line += buf;
+        if (!line.empty() && line.back() == '\n') break;
+    }
+    if (!line.empty() && line.back() == '\n') line.pop_back();
+    if (!line.empty() && line.back() == '\r') line.pop_back();
+    return true;
+}
+
+std::vector<Region> parse_bed(const std::string &filename) {
+    gzFile f = gzopen(filename.c_str(), "rb");
+    if (!f) throw Panic("unable to open bam file."); // bed.rs:175 (sic)
+    std::vector<Region> out;
+    std::string line;
+    while (gz_getline(f, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::vector<std::string> c;
+        size_t a = 0;
+        for (;;) {
+            size_t b = line.find('\t', a);
+            c.push_back(line.substr(a, b == std::string::npos ? std::string::npos : b - a));
+            if (b == std::string::npos) break;
+            a = b + 1;
+        }
+        uint64_t st, en;
+        if (c.size() < 3 || !parse_u64(c[1].c_str(), c[1].size(), st) || !parse_u64(c[2].c_str(), c[2].size(), en)) continue; // warn + skip
+        Region r;
+        r.name = c[0], r.st = st, r.en = en;
+        r.id = c.size() > 3 ? c[3] : (c[0] + ":" + std::to_string(st + 1) + "-" + std::to_string(en)); // bed.rs:150-153
+        out.push_back(std::move(r));
+    }
+    gzclose(f);
+    return out;
+}
+
+std::string f32_display(float v) {
+    if (std::isnan(v)) return "NaN";
+    if (std::isinf(v)) return v < 0 ? "-inf" : "inf";
+    char buf[128];
+    auto r = std::to_chars(buf, buf + sizeof buf, v, std::chars_format::fixed); // shortest round trip, positional
+    return std::string(buf, r.ptr);
+}
+
+// ---- batches ------------------------------------------------------------------------------------------
+struct HostBatch {
+    std::vector<uint32_t> ops, contig;
+    std::vector<uint64_t> op_off, t_st, t_en, q_st, q_en;
+    std::vector<uint8_t> strand;
+    std::vector<std::string> contig_names;
+    std::unordered_map<std::string, uint32_t> contig_id;
+    explicit HostBatch(const std::vector<PafRecord> &recs) {
+        const size_t n = recs.size();
+        op_off.assign(n + 1, 0);
+        size_t total = 0;
+        for (size_t i = 0; i < n; i++) {
+            total += recs[i].cigar.size();
+            op_off[i + 1] = total;
+        }
+        ops.resize(total + 4, 0);
+        t_st.resize(n), t_en.resize(n), q_st.resize(n), q_en.resize(n), strand.resize(n), contig.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const PafRecord &r = recs[i];
+            if (!r.cigar.empty()) memcpy(&ops[op_off[i]], r.cigar.data(), r.cigar.size() * 4);
+            t_st[i] = r.t_st, t_en[i] = r.t_en, q_st[i] = r.q_st, q_en[i] = r.q_en;
+            strand[i] = (uint8_t)r.strand;
+            auto it = contig_id.find(r.t_name);
+            if (it == contig_id.end()) { // dense ids in order of first appearance = canonical contig order
+                it = contig_id.emplace(r.t_name, (uint32_t)contig_names.size()).first;
+                contig_names.push_back(r.t_name);
+            }
+            contig[i] = it->second;
+        }
+    }
+    uint64_t n() const { return t_st.size(); }
+};
+
+static void panic_on(uint32_t status, const char *what, size_t i) {
+    if (status >= RB_ST_PANIC_NOTFOUND) throw Panic(std::string(what) + ": record " + std::to_string(i + 1) + " has status " + std::to_string(status));
+}
+
+// the record after remove_trailing_indels: id gains _TO.<lead>.<trail> (paf.rs:726-732)
+static std::string stripped_id(const PafRecord &r, const rb_norm_row &nr) {
+    if (!(nr.flags & RB_F_STRIPPED)) return r.id;
+    std::vector<uint32_t> lead(r.cigar.begin(), r.cigar.begin() + nr.lead_ops), trail;
+    for (uint32_t k = 0; k < nr.trail_ops; k++) trail.push_back(r.cigar[r.cigar.size() - 1 - k]);
+    return r.id + "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
+}
+
+Paf Paf::from_file(Engine &eng, const std::string &file_name) {
+    gzFile f = file_name == "-" ? gzdopen(0, "rb") : gzopen(file_name.c_str(), "rb");
+    if (!f) throw Panic("Failed to open " + file_name);
+    gzbuffer(f, 1 << 20);
+    Paf paf;
+    std::string line;
+    size_t index = 0;
+    while (gz_getline(f, line)) {
+        PafRecord rec;
+        if (paf_record_new(line, rec) == 0)
+            paf.records.push_back(std::move(rec));
+        else
+            fprintf(stderr, "\nUnable to parse PAF record. Skipping line %zu\n", index + 1);
+        index++;
+    }
+    gzclose(f);
+    // check_integrity().unwrap() (paf.rs:70) for the whole file in one device pass; overwrites nmatch / aln_len
+    HostBatch b(paf.records);
+    std::vector<rb_reduce_row> red(b.n());
+    eng.check(rb_host_scan_records(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(),
+                                   b.q_en.data(), b.strand.data(), red.data(), nullptr),
+              "rb_host_scan_records");
+    for (size_t i = 0; i < paf.records.size(); i++) {
+        if (red[i].status != RB_ST_OK) throw Panic("check_integrity: record " + std::to_string(i + 1) + " status " + std::to_string(red[i].status));
+        paf.records[i].nmatch = red[i].nmatch;
+        paf.records[i].aln_len = red[i].aln_len;
+    }
+    return paf;
+}
+
+std::vector<PafRecord> paf_swap_query_and_target(Engine &eng, const std::vector<PafRecord> &recs) {
+    HostBatch b(recs);
+    std::vector<uint32_t> out(b.ops.size());
+    eng.check(rb_host_swap(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.strand.data(), out.data()), "rb_host_swap");
+    std::vector<PafRecord> fl(recs);
+    for (size_t i = 0; i < recs.size(); i++) {
+        fl[i].t_name = recs[i].q_name, fl[i].t_len = recs[i].q_len, fl[i].t_st = recs[i].q_st, fl[i].t_en = recs[i].q_en;
+        fl[i].q_name = recs[i].t_name, fl[i].q_len = recs[i].t_len, fl[i].q_st = recs[i].t_st, fl[i].q_en = recs[i].t_en;
+        fl[i].cigar.assign(out.begin() + b.op_off[i], out.begin() + b.op_off[i + 1]);
+    }
+    return fl;
+}
+
+static std::vector<PafRecord> rows_to_records(const std::vector<PafRecord> &src, const std::vector<rb_norm_row> &norm, const rb_hit_row *rows,
+                                              uint64_t n_rows, const uint32_t *out, const std::vector<Region> *rgns) {
+    std::vector<PafRecord> res;
+    for (uint64_t k = 0; k < n_rows; k++) {
+        const rb_hit_row &h = rows[k];
+        if (h.status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(h.rec + 1));
+        if (h.status != RB_ST_OK) continue; // trim_paf_rec_to_rgn returned None
+        const PafRecord &s = src[h.rec];
+        PafRecord r;
+        r.q_name = s.q_name, r.q_len = s.q_len, r.strand = s.strand, r.t_name = s.t_name, r.t_len = s.t_len, r.mapq = s.mapq;
+        r.t_st = h.t_st, r.t_en = h.t_en, r.q_st = h.q_st, r.q_en = h.q_en, r.nmatch = h.nmatch, r.aln_len = h.aln_len;
+        r.id = (rgns && !(h.flags & RB_HIT_INSIDE)) ? (*rgns)[h.win].id : stripped_id(s, norm[h.rec]);
+        r.cigar.assign(out + h.out_off, out + h.out_off + h.out_n);
+        res.push_back(std::move(r));
+    }
+    return res;
+}
+
+std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query) {
+    std::vector<PafRecord> swapped;
+    if (invert_query) swapped = paf_swap_query_and_target(eng, paf_recs);
+    const std::vector<PafRecord> &recs = invert_query ? swapped : paf_recs;
+    HostBatch b(recs);
+    std::vector<uint32_t> w_contig(rgns.size());
+    std::vector<uint64_t> w_st(rgns.size()), w_en(rgns.size());
+    for (size_t i = 0; i < rgns.size(); i++) {
+        auto it = b.contig_id.find(rgns[i].name);
+        if (it == b.contig_id.end()) it = b.contig_id.emplace(rgns[i].name, (uint32_t)b.contig_id.size()).first; // no record there
+        w_contig[i] = it->second, w_st[i] = rgns[i].st, w_en[i] = rgns[i].en;
+    }
+    std::vector<rb_norm_row> norm(b.n());
+    rb_hit_row *rows = nullptr;
+    uint32_t *out = nullptr;
+    uint64_t n_rows = 0, n_out = 0;
+    rb_counters cnt;
+    eng.check(rb_host_liftover(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
+                               b.strand.data(), b.contig.data(), rgns.size(), w_contig.data(), w_st.data(), w_en.data(),
+                               eng.bsearch_policy, norm.data(), &rows, &n_rows, &out, &n_out, &cnt),
+              "rb_host_liftover");
+    for (size_t i = 0; i < norm.size(); i++) panic_on(norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
+    std::vector<PafRecord> res = rows_to_records(recs, norm, rows, n_rows, out, &rgns);
+    rb_host_free(rows);
+    rb_host_free(out);
+    return res;
+}
+
+std::vector<PafRecord> break_paf_on_indels(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length) {
+    HostBatch b(paf_recs);
+    std::vector<rb_norm_row> norm(b.n());
+    rb_hit_row *rows = nullptr;
+    uint32_t *out = nullptr;
+    uint64_t n_rows = 0, n_out = 0;
+    rb_counters cnt;
+    eng.check(rb_host_break(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
+                            b.strand.data(), break_length, eng.bsearch_policy, norm.data(), &rows, &n_rows, &out, &n_out, &cnt),
+              "rb_host_break");
+    for (size_t i = 0; i < norm.size(); i++) panic_on(norm[i].status, "aligned_pairs", i); // main.rs:275
+    std::vector<PafRecord> res = rows_to_records(paf_recs, norm, rows, n_rows, out, nullptr); // id = paf.id (liftover.rs:194)
+    rb_host_free(rows);
+    rb_host_free(out);
+    return res;
+}
+
+std::vector<Stats> stats_from_paf(Engine &eng, const std::vector<PafRecord> &recs) {
+    HostBatch b(recs);
+    std::vector<rb_reduce_row> red(b.n());
+    eng.check(rb_host_scan_records(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
+                                   b.strand.data(), red.data(), nullptr),
+              "rb_host_scan_records");
+    std::vector<Stats> out(recs.size());
+    bool warned = false;
+    for (size_t i = 0; i < recs.size(); i++) {
+        const PafRecord &r = recs[i];
+        Stats &s = out[i];
+        s.r_nm = r.t_name, s.r_len = (int64_t)r.t_len, s.r_st = (int64_t)r.t_st, s.r_en = (int64_t)r.t_en;
+        s.q_nm = r.q_name, s.q_len = (int64_t)r.q_len, s.q_st = (int64_t)r.q_st, s.q_en = (int64_t)r.q_en;
+        s.strand = r.strand;
+        s.equal = red[i].equal, s.diff = red[i].diff, s.ins = red[i].ins, s.del = red[i].del, s.matches = red[i].matches;
+        s.ins_events = red[i].ins_events, s.del_events = red[i].del_events;
+        s.id_by_all = red[i].id_by_all, s.id_by_events = red[i].id_by_events, s.id_by_matches = red[i].id_by_matches;
+        if ((red[i].flags & RB_F_HAS_M) && !warned) { // bamstats.rs:145-153
+            fprintf(stderr, "\r⚠ warning: cigar string contains 'M', assuming mismatch since there is no MD tag.");
+            warned = true;
+        }
+    }
+    return out;
+}
+
+std::string cigar_stats_header(bool qbed) {
+    std::string s;
+    if (qbed)
+        s = "#query_name\tquery_start\tquery_end\tquery_length\tstrand\treference_name\treference_start\treference_end\treference_length\t";
+    else
+        s = "#reference_name\treference_start\treference_end\treference_length\tstrand\tquery_name\tquery_start\tquery_end\tquery_length\t";
+    s += "perID_by_matches\tperID_by_events\tperID_by_all\tmatches\tmismatches\tdeletion_events\tinsertion_events\tdeletions\tinsertions\n";
+    return s;
+}
+std::string cigar_stats_line(const Stats &s, bool qbed) {
+    std::string o;
+    auto four = [&](const std::string &nm, int64_t a, int64_t b, int64_t c) {
+        o += nm; o += '\t'; o += std::to_string(a); o += '\t'; o += std::to_string(b); o += '\t'; o += std::to_string(c); o += '\t';
+    };
+    if (qbed) four(s.q_nm, s.q_st, s.q_en, s.q_len); else four(s.r_nm, s.r_st, s.r_en, s.r_len);
+    o += s.strand; o += '\t';
+    if (qbed) four(s.r_nm, s.r_st, s.r_en, s.r_len); else four(s.q_nm, s.q_st, s.q_en, s.q_len);
+    o += f32_display(s.id_by_matches); o += '\t'; o += f32_display(s.id_by_events); o += '\t'; o += f32_display(s.id_by_all); o += '\t';
+    o += std::to_string(s.equal); o += '\t'; o += std::to_string(s.diff); o += '\t'; o += std::to_string(s.del_events); o += '\t';
+    o += std::to_string(s.ins_events); o += '\t'; o += std::to_string(s.del); o += '\t'; o += std::to_string(s.ins); o += '\n';
+    return o;
+}
+
+// ---- trim-paf driver (paf.rs:210-305); the recursion is a loop -----------------------------------------
+void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int indel_score, bool remove_contained) {
+    for (int pass = 0; pass < 100000; pass++) {
+        { // remove_trailing_indels on every record (:218-220)
+            HostBatch b(records);
+            std::vector<rb_norm_row> norm(b.n());
+            eng.check(rb_host_scan_records(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(),
+                                           b.q_en.data(), b.strand.data(), nullptr, norm.data()),
+                      "rb_host_scan_records");
+            for (size_t i = 0; i < records.size(); i++) {
+                panic_on(norm[i].status, "remove_trailing_indels", i);
+                PafRecord &r = records[i];
+                if (norm[i].flags & RB_F_STRIPPED) {
+                    r.id = stripped_id(r, norm[i]);
+                    r.cigar.assign(r.cigar.begin() + norm[i].first_op, r.cigar.begin() + norm[i].first_op + norm[i].n_ops);
+                }
+                r.t_st = norm[i].t_st, r.t_en = norm[i].t_en, r.q_st = norm[i].q_st, r.q_en = norm[i].q_en;
+                r.nmatch = norm[i].nmatch, r.aln_len = norm[i].aln_len;
+            }
+        }
+        std::stable_sort(records.begin(), records.end(), [](const PafRecord &a, const PafRecord &b) { return a.q_name < b.q_name; }); // :223
+        const size_t n = records.size();
+        std::vector<char> contained(n, 0);
+        if (n < 2) return; // :227-229
+        struct Pair { uint64_t overlap; uint32_t i, j; };
+        std::vector<Pair> pairs;
+        for (size_t i = 0; i + 1 < n; i++) { // :231-261
+            const PafRecord &r1 = records[i];
+            for (size_t j = i + 1; j < n && r1.q_name == records[j].q_name; j++) {
+                const PafRecord &r2 = records[j];
+                const uint64_t mn = std::min(r1.q_en, r2.q_en), mx = std::max(r1.q_st, r2.q_st);
+                const uint64_t ov = mn < mx ? 0 : mn - mx;
+                if (ov < 1) continue;
+                if (ov == r2.q_en - r2.q_st)
+                    contained[j] = 1;
+                else if (ov == r1.q_en - r1.q_st)
+                    contained[i] = 1;
+                else if (r1.q_st <= r2.q_st)
+                    pairs.push_back({ov, (uint32_t)i, (uint32_t)j});
+                else
+                    pairs.push_back({ov, (uint32_t)j, (uint32_t)i});
+            }
+        }
+        std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &b) { return a.overlap > b.overlap; }); // :262
+        std::unordered_set<std::string> q_seen;
+        std::vector<uint32_t> left, right;
+        size_t unseen = 0;
+        for (const Pair &pr : pairs) { // :266-284: one pair per query name per pass
+            if (q_seen.insert(records[pr.i].q_name).second) {
+                left.push_back(pr.i);
+                right.push_back(pr.j);
+            } else {
+                unseen++;
+            }
+        }
+        if (!left.empty()) {
+            HostBatch b(records);
+            std::vector<rb_pair_row> rows(left.size());
+            uint32_t *out = nullptr;
+            uint64_t n_out = 0;
+            eng.check(rb_host_overlap_split(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(),
+                                            b.q_en.data(), b.strand.data(), left.size(), left.data(), right.data(), match_score, diff_score,
+                                            indel_score, eng.bsearch_policy, rows.data(), &out, &n_out),
+                      "rb_host_overlap_split");
+            for (size_t k = 0; k < left.size(); k++) {
+                if (rows[k].status != RB_ST_OK) throw Panic("trim_overlapping_pafs: pair " + std::to_string(k) + " status " + std::to_string(rows[k].status));
+                const uint32_t idx[2] = {left[k], right[k]};
+                for (int s = 0; s < 2; s++) {
+                    PafRecord &r = records[idx[s]];
+                    r.t_st = rows[k].t_st[s], r.t_en = rows[k].t_en[s], r.q_st = rows[k].q_st[s], r.q_en = rows[k].q_en[s];
+                    r.nmatch = rows[k].nmatch[s], r.aln_len = rows[k].aln_len[s];
+                    r.cigar.assign(out + rows[k].out_off[s], out + rows[k].out_off[s] + rows[k].out_n[s]);
+                }
+            }
+            rb_host_free(out);
+        }
+        if (unseen > 0) continue; // :286-288
+        if (remove_contained) {   // :289-301
+            std::vector<PafRecord> keep;
+            for (size_t i = 0; i < n; i++)
+                if (!contained[i]) keep.push_back(std::move(records[i]));
+            records.swap(keep);
+        }
+        return;
+    }
+    throw Panic("trim-paf did not converge");
+}
+
+} // namespace rb

@@ -1,0 +1,84 @@
+// rb_host.hpp -- C++ host mirror of the reference's interface for the CIGAR-walk path, over the C ABI
+// (include/rustybam_amd.h).  Same names, argument meaning and error behaviour as the Rust functions it
+// stands in for; where the reference panics this layer throws rb::Panic (the rb binary then exits 101,
+// Rust's panic exit code).  Text decode/encode stays on the CPU; every CIGAR walk goes to the device.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/rustybam_amd.h"
+
+namespace rb {
+
+struct Panic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+// paf::PafRecord (paf.rs:346-368); cigar is packed len << 4 | op
+struct PafRecord {
+    std::string q_name;
+    uint64_t q_len = 0, q_st = 0, q_en = 0;
+    char strand = '+';
+    std::string t_name;
+    uint64_t t_len = 0, t_st = 0, t_en = 0, nmatch = 0, aln_len = 0, mapq = 0;
+    std::vector<uint32_t> cigar;
+    std::string id;
+    std::string to_string() const; // impl Display (paf.rs:923-944)
+};
+
+// bed::Region (bed.rs:15-21)
+struct Region {
+    std::string name;
+    uint64_t st = 0, en = 0;
+    std::string id;
+};
+
+// bamstats::Stats (bamstats.rs:16-36)
+struct Stats {
+    std::string q_nm, r_nm;
+    int64_t q_len = 0, q_st = 0, q_en = 0, r_len = 0, r_st = 0, r_en = 0;
+    char strand = '+';
+    uint32_t equal = 0, diff = 0, ins = 0, del = 0, matches = 0, ins_events = 0, del_events = 0;
+    float id_by_all = 0, id_by_events = 0, id_by_matches = 0;
+};
+
+class Engine { // one rb_ctx
+  public:
+    explicit Engine(int device = 0);
+    ~Engine();
+    rb_ctx *ctx() const { return ctx_; }
+    int bsearch_policy = RB_BSEARCH_MODERN;
+    void check(int rc, const char *what) const;
+
+  private:
+    rb_ctx *ctx_ = nullptr;
+};
+
+struct Paf { // paf::Paf (paf.rs:34-37)
+    std::vector<PafRecord> records;
+    // Paf::from_file (paf.rs:62-78): decode + check_integrity().unwrap() on every record (on the device)
+    static Paf from_file(Engine &eng, const std::string &file_name);
+    // Paf::overlapping_paf_recs (paf.rs:210-305)
+    void overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int indel_score, bool remove_contained);
+};
+
+std::string cigar_to_string(const std::vector<uint32_t> &cigar);
+// PafRecord::new (paf.rs:379-430): 0 = ok, 1 = Err(ParsePafColumn) (caller skips the line); throws Panic
+int paf_record_new(const std::string &line, PafRecord &out);
+std::vector<Region> parse_bed(const std::string &filename);                    // bed.rs:172-194
+std::string f32_display(float v);                                              // Rust `{}` for f32
+
+// paf_swap_query_and_target for a whole record set (paf.rs:1068-1094)
+std::vector<PafRecord> paf_swap_query_and_target(Engine &eng, const std::vector<PafRecord> &recs);
+// liftover::trim_paf_by_rgns (liftover.rs:134-167), single-thread output order
+std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query);
+// main.rs:274-280: aligned_pairs + liftover::break_paf_on_indels (liftover.rs:182-226) for every record, record order
+std::vector<PafRecord> break_paf_on_indels(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length);
+// bamstats::stats_from_paf (bamstats.rs:91-154) for every record
+std::vector<Stats> stats_from_paf(Engine &eng, const std::vector<PafRecord> &paf_recs);
+std::string cigar_stats_header(bool qbed);              // bamstats.rs:225-236
+std::string cigar_stats_line(const Stats &s, bool qbed); // bamstats.rs:239-270
+
+} // namespace rb
