@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
         we = p.cw_off[cg + 1];
         mono = p.cw_mono[cg] != 0;
     }
-    const bool fast = (nr->flags & RB_F_REGULAR) && (explicit_w || mono);
+    const bool fast = (nr->flags & RB_F_REGULAR) != 0; // window order does not matter: resolution is per lane
     if (!fast) {
         rb_defer_record(p, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
         return;
@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
     const bool minus = p.strand[r] == (uint8_t)'-';
     const uint64_t rec0 = p.op_off[r] + nr->first_op; // global index of the record's first kept op
     const uint32_t *rec_ops = p.ops + rec0;
-    const uint64_t lo = explicit_w ? 0 : p.win_lo[r];
+    const uint64_t lo = (explicit_w || !mono) ? 0 : p.win_lo[r];
+    uint64_t scan_pos = ws; // non-monotone window lists: next window of the slice to test
     const uint32_t arena = (uint32_t)(wave % p.n_arena);
     const uint64_t g0 = rec0 & ~3ull, gend = rec0 + n;
     const uint32_t n_steps = (uint32_t)((gend - g0 + 255u) >> 8);
@@ -459,7 +460,35 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
         const bool own = hl < nb;
         const bool mine = own && lane < 32;
         const bool is_start = lane < 32;
-        if (own) {
+        if (!explicit_w && !mono) {
+            // windows of this contig are not sorted: collect the next nb overlapping ones in BED order, 64
+            // candidates per ballot (same test as rb_k_count_hits, so the counts agree)
+            uint32_t *widx = &et_all[threadIdx.x >> 6][0][0];
+            uint32_t filled = 0;
+            while (filled < nb && scan_pos < we) {
+                const uint64_t i = scan_pos + (uint64_t)lane;
+                const bool hit = i < we && t_en > p.w_st[i] && t_st < p.w_en[i];
+                const unsigned long long ball = __ballot(hit);
+                const uint32_t room = nb - filled, cnt = (uint32_t)__popcll(ball);
+                const uint32_t rank = (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+                if (hit && rank < room) widx[filled + rank] = (uint32_t)(i - ws);
+                if (cnt <= room) {
+                    filled += cnt;
+                    scan_pos += 64;
+                } else { // the pass is full: resume after the room-th hit next time
+                    unsigned long long m = ball;
+                    for (uint32_t q = 1; q < room; q++) m &= m - 1;
+                    scan_pos += (uint64_t)rb_ffs64(m) + 1u;
+                    filled += room;
+                }
+            }
+            if (own) {
+                const uint64_t idx = ws + widx[hl];
+                wst = p.w_st[idx];
+                wen = p.w_en[idx];
+                win = p.w_orig[idx];
+            }
+        } else if (own) {
             if (explicit_w) {
                 wst = p.x_st[h0 + jb + hl];
                 wen = p.x_en[h0 + jb + hl];
