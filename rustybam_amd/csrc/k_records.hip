@@ -21,78 +21,82 @@ struct rb_scan_params {
     rb_norm_row *norm_rows;
 };
 
-struct rb_acc {
-    uint64_t len[9]; // per op code length sums
-    uint32_t ins_events, del_events;
-    uint32_t bad; // bit0: op outside M I D = X, bit1: zero length, bit2: adjacent ops of one type, bit3: code > 8
-};
-
-__device__ __forceinline__ void rb_acc_op(rb_acc &a, uint32_t v, bool valid, uint32_t prev_opc) {
-    uint32_t opc = valid ? rb_opc(v) : RB_NULL_OP;
-    uint32_t len = valid ? rb_len(v) : 0u;
-#pragma unroll
-    for (uint32_t t = 0; t < 9; t++) a.len[t] += (opc == t) ? len : 0u;
-    a.ins_events += (opc == RB_OP_I) ? 1u : 0u;
-    a.del_events += (opc == RB_OP_D) ? 1u : 0u;
-    if (valid) {
-        if (!rb_in(RB_REGULAR_MASK, opc)) a.bad |= 1u;
-        if (len == 0) a.bad |= 2u;
-        if (opc == prev_opc) a.bad |= 4u;
-        if (opc > 8u) a.bad |= 8u;
-    }
-}
+// Per-class accumulation goes through LDS: every lane owns one 64-bit counter per op code
+// (hist[code][lane], conflict-free: consecutive lanes hit consecutive banks) and adds
+// len | 1 << 40 to it with one ds_add_u64 per op, so the low 40 bits sum the lengths and the high
+// 24 bits count the ops (the ins/del "events" of bamstats.rs:112-117).  That replaces nine
+// compare/select/64-bit-add chains per op in registers and keeps the kernel HBM-bound.
+#define RB_LEN_BITS 40
 
 __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
+    __shared__ unsigned long long hist_all[4][9][64];
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (wave >= p.n_rec) return;
     const uint64_t r = rb_first64(wave);
     const int lane = rb_lane();
+    unsigned long long(*hist)[64] = hist_all[threadIdx.x >> 6];
     const uint64_t o0 = p.op_off[r], o1 = p.op_off[r + 1];
     const uint64_t n = o1 - o0;
-
-    rb_acc a;
 #pragma unroll
-    for (int t = 0; t < 9; t++) a.len[t] = 0;
-    a.ins_events = a.del_events = 0;
-    a.bad = 0;
+    for (int t = 0; t < 9; t++) hist[t][lane] = 0ull;
+    uint32_t bad = 0; // bit0: op outside M I D = X, bit1: zero length, bit2: adjacent ops of one type, bit3: code > 8
 
-    // ---- streaming pass: aligned 16-byte loads, 256 ops per wave step ----
+    // ---- streaming pass: aligned 16-byte loads, 256 ops per wave step, next step prefetched ----
     const uint64_t g0 = o0 & ~3ull;
     const uint64_t n_steps = (o1 - g0 + 255u) >> 8;
-    uint32_t carry_opc = RB_NULL_OP; // op code of the last op of the previous step
-    uint4 cur = make_uint4(0, 0, 0, 0);
+    uint32_t carry_opc = 16u; // op code of the last op of the previous step (16 = none)
+    uint4 cur = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
     {
-        uint64_t gi = g0 + (uint64_t)lane * 4u;
+        const uint64_t gi = g0 + (uint64_t)lane * 4u;
         if (n_steps > 0 && gi < o1) cur = *reinterpret_cast<const uint4 *>(p.ops + gi);
+        if (n_steps > 1 && gi + 256u < o1) nx1 = *reinterpret_cast<const uint4 *>(p.ops + gi + 256u);
     }
     for (uint64_t s = 0; s < n_steps; s++) {
         const uint64_t gi = g0 + (s << 8) + (uint64_t)lane * 4u;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (s + 1 < n_steps && gi + 256u < o1) nxt = *reinterpret_cast<const uint4 *>(p.ops + gi + 256u);
-        const bool v0 = gi + 0 >= o0 && gi + 0 < o1;
-        const bool v1 = gi + 1 >= o0 && gi + 1 < o1;
-        const bool v2 = gi + 2 >= o0 && gi + 2 < o1;
-        const bool v3 = gi + 3 >= o0 && gi + 3 < o1;
-        const uint32_t c0 = v0 ? rb_opc(cur.x) : RB_NULL_OP;
-        const uint32_t c1 = v1 ? rb_opc(cur.y) : RB_NULL_OP;
-        const uint32_t c2 = v2 ? rb_opc(cur.z) : RB_NULL_OP;
-        const uint32_t c3 = v3 ? rb_opc(cur.w) : RB_NULL_OP;
-        const uint32_t pl = rb_prev_lane(c3, carry_opc);
-        rb_acc_op(a, cur.x, v0, pl);
-        rb_acc_op(a, cur.y, v1, c0);
-        rb_acc_op(a, cur.z, v2, c1);
-        rb_acc_op(a, cur.w, v3, c2);
-        carry_opc = rb_readlane<uint32_t>(c3, 63);
-        cur = nxt;
+        uint4 nx2 = make_uint4(0, 0, 0, 0);
+        if (s + 2 < n_steps && gi + 512u < o1) nx2 = *reinterpret_cast<const uint4 *>(p.ops + gi + 512u);
+        const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
+        uint32_t code[4]; // 16 = not an op of this record (head / tail padding)
+        bool valid[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            valid[q] = gi + q >= o0 && gi + q < o1;
+            code[q] = valid[q] ? rb_opc(raw[q]) : 16u;
+        }
+        uint32_t prev = rb_prev_lane(code[3], carry_opc);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t opc = code[q], len = rb_len(raw[q]);
+            if (valid[q]) {
+                if (opc <= 8u) {
+                    __hip_atomic_fetch_add(&hist[opc][lane], (unsigned long long)len | (1ull << RB_LEN_BITS), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    bad |= 8u;
+                }
+                if (!rb_in(RB_REGULAR_MASK, opc)) bad |= 1u;
+                if (len == 0) bad |= 2u;
+                if (opc == prev) bad |= 4u;
+            }
+            prev = opc;
+        }
+        carry_opc = rb_readlane<uint32_t>(code[3], 63);
+        cur = nx1;
+        nx1 = nx2;
     }
 
     // ---- cross-lane reduction ----
     uint64_t L[9];
+    uint32_t C[9];
 #pragma unroll
-    for (int t = 0; t < 9; t++) L[t] = rb_wave_sum_u64(a.len[t]);
-    const uint32_t ins_events = rb_wave_sum_u32(a.ins_events);
-    const uint32_t del_events = rb_wave_sum_u32(a.del_events);
-    const uint32_t bad = rb_wave_or_u32(a.bad);
+    for (int t = 0; t < 9; t++) {
+        const unsigned long long v = hist[t][lane];
+        L[t] = rb_wave_sum_u64(v & ((1ull << RB_LEN_BITS) - 1ull));
+        C[t] = rb_wave_sum_u32((uint32_t)(v >> RB_LEN_BITS));
+    }
+    const uint32_t ins_events = C[RB_OP_I];
+    const uint32_t del_events = C[RB_OP_D];
+    bad = rb_wave_or_u32(bad);
     if (lane != 0) return;
 
     const uint64_t R = L[RB_OP_M] + L[RB_OP_D] + L[RB_OP_N] + L[RB_OP_EQ] + L[RB_OP_X];
