@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--early-exit", action="store_true", help="allow the kernel to stop a record early (off: full walk)")
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: skip kernel phases (invalid results)")
+    ap.add_argument("--descriptors", action="store_true",
+                    help="RB_LIFT_DESCRIPTORS: return which ops each clip keeps instead of copying them (not the headline mode)")
     return ap.parse_args()
 
 
@@ -50,7 +52,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RB_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL path on one GPU
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
@@ -106,8 +109,13 @@ def main():
 
     # ---- size the outputs (first call tells what is needed) ----
     policy = rustybam_amd.BSEARCH_MODERN | (rustybam_amd.LIFT_EARLY_EXIT if args.early_exit else 0) | (args.debug_skip << 8)
+    if args.descriptors:
+        policy |= rustybam_amd.LIFT_DESCRIPTORS
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
     rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, total_ops // 4)
+    if args.descriptors:
+        rows_cap = max(rows_cap, 16 * n_rec)
+        out_cap = 4 * rows_cap + total_ops // 8 + 65536
     for _ in range(6):
         d_ws = torch.empty(eng.plan_workspace_bytes(plan, rows_cap), dtype=torch.uint8, device=dev)
         d_rows = torch.empty((rows_cap + 1) * 64, dtype=torch.uint8, device=dev)
@@ -129,7 +137,7 @@ def main():
                          d_out.data_ptr(), out_cap, d_cnt.data_ptr())
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -146,7 +154,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = eng.get_timing()
     eng.set_timing(False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -164,12 +172,14 @@ def main():
     n_ok = int((status == 0).sum().item())
     n_out_ops = int((out_n * (status == 0)).sum().item())
     algo_bytes = wl.algorithmic_bytes(total_ops, n_rec, n_hits, n_out_ops)
+    if args.descriptors:  # nothing is copied: 4 B/op + 48 B/record + (88 + 16) B per hit
+        algo_bytes = wl.algorithmic_bytes(total_ops, n_rec, n_hits, 0) + 16 * n_hits
     k_ms = float(np.mean(kern_ms[-args.steps:])) if kern_ms else float("nan")
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     traffic = None  # HBM-side bytes per launch from the committed PMC run of this same workload (bench.py is not run under --pmc)
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-        if tj["workload"] == {"records_per_gpu": n_rec, "windows": int(len(w_st)), "workload": args.workload}:
+        if tj["workload"] == {"records_per_gpu": n_rec, "windows": int(len(w_st)), "workload": args.workload} and not args.descriptors:
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         pass
@@ -194,7 +204,7 @@ def main():
         "config": {"workload": f"BASELINE.json {args.workload}: {n_rec} records/GPU (uniform 1000-9000 ops, "
                                f"{total_ops} ops on rank 0) x {len(w_st)} windows, seed {seed:#x}",
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world}",
-                   "full_walk": not args.early_exit},
+                   "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops"},
         "paf_records_per_s": job_recs * args.steps / elapsed,
         "hits_per_gpu": n_hits, "ok_hits_per_gpu": n_ok, "out_ops_per_gpu": n_out_ops,
         "generic_hits_per_gpu": int(cnt["n_generic"]),
@@ -203,7 +213,7 @@ def main():
     }
 
     # ---- CPU baseline + sample parity (rank 0, N = 1 only) ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.descriptors:
         from oracle import pyoracle  # checker / baseline only; never on the product path
         from rustybam_amd import capi
         threads = os.cpu_count() or 1
@@ -247,7 +257,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     eng.plan_destroy(plan)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

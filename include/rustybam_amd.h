@@ -80,7 +80,14 @@ typedef enum rb_status {
 /* Rust slice::binary_search duplicate policy, low bit of `bsearch_policy`.
  * RB_LIFT_EARLY_EXIT may be OR-ed in: stop walking a record once all its windows are resolved
  * (same results; the reference always walks every record, so benchmarks leave it off). */
-enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY = 1 /* 1.52 .. 1.81 */, RB_LIFT_EARLY_EXIT = 16 };
+enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY = 1 /* 1.52 .. 1.81 */, RB_LIFT_EARLY_EXIT = 16,
+       /* RB_LIFT_DESCRIPTORS: do not copy the clipped cigars.  A host that still holds each record's cigar (the
+        * reference does) only needs to know WHICH ops a clip keeps: for a row with RB_HIT_DESCRIPTOR set,
+        * out_ops[out_off .. out_off + 4) = { first kept op (index into the record's ORIGINAL cigar), op count,
+        * length of the first kept op, length of the last kept op }; every op in between is unchanged; a one-op clip
+        * has length aln_len; RB_HIT_INSIDE rows keep all lengths.  Rows resolved by the generic kernel (irregular
+        * cigars whose adjacent ops may merge) still carry real ops.  out_cap must be >= 4 * rows_cap + room for those. */
+       RB_LIFT_DESCRIPTORS = 32 };
 
 /* rb_norm_row.flags / rb_reduce_row.flags */
 enum {
@@ -91,7 +98,8 @@ enum {
 /* rb_hit_row.flags */
 enum {
     RB_HIT_INSIDE = 1u << 0,  /* liftover.rs:23-25: record returned unchanged and keeps its OWN id */
-    RB_HIT_GENERIC = 1u << 1  /* resolved by the generic (serial) kernel, informational             */
+    RB_HIT_GENERIC = 1u << 1, /* resolved by the generic (serial) kernel, informational             */
+    RB_HIT_DESCRIPTOR = 1u << 2 /* out_ops holds a 4-word clip descriptor, not ops (RB_LIFT_DESCRIPTORS) */
 };
 
 /* ---- result rows (written by the device; 72 / 64 / 64 bytes) ---------------------------------- */

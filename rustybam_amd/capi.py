@@ -9,7 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "rustybam_amd.h")
 
-BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT = 0, 1, 16
+BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, LIFT_DESCRIPTORS = 0, 1, 16, 32
+HIT_INSIDE, HIT_GENERIC, HIT_DESCRIPTOR = 1, 2, 4
 
 REDUCE_DT = np.dtype(
     [("t_bases", "<u8"), ("q_bases", "<u8"), ("nmatch", "<u4"), ("aln_len", "<u4"), ("equal", "<u4"),

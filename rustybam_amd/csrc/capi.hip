@@ -54,6 +54,8 @@ struct rb_lift_params {
     rb_counters *counters;
     int policy;
     int early_exit;
+    int desc_mode;
+    uint64_t arena_origin;
     int debug_skip;
 };
 struct rb_break_params {
@@ -428,7 +430,10 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.out_cap = out_cap;
     p.arena_cur = (unsigned long long *)(ws + w.arena);
     p.n_arena = pick_arenas(b->n_rec);
-    p.arena_size = (out_cap / p.n_arena) & ~(uint64_t)3;
+    p.desc_mode = (policy & RB_LIFT_DESCRIPTORS) ? 1 : 0;
+    p.arena_origin = p.desc_mode ? 4 * rows_cap : 0;
+    if (p.desc_mode && out_cap < p.arena_origin + 1024) return fail(ctx, RB_E_CAPACITY, "descriptor mode needs out_cap >= 4 * rows_cap + 1024");
+    p.arena_size = ((out_cap - p.arena_origin) / p.n_arena) & ~(uint64_t)3;
     p.gen_list = (uint32_t *)(ws + w.gen_list);
     p.counters = counters;
     p.policy = policy & 1;
@@ -628,7 +633,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     }
     const uint64_t n_ops = n_rec ? op_off[n_rec] : 0;
     uint64_t rows_cap = n_rec + n_win + 1024;
-    uint64_t out_cap = 2 * n_ops + 16 * rows_cap + 4096;
+    uint64_t out_cap = ((policy & RB_LIFT_DESCRIPTORS) ? n_ops / 4 : 2 * n_ops) + 16 * rows_cap + 4096;
     rb_counters hc;
     memset(&hc, 0, sizeof hc);
     void *ws = nullptr;
@@ -652,7 +657,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         if (rc) break;
         if (!hc.overflow) break;
         rows_cap = std::max<uint64_t>(rows_cap, hc.n_hits + 16);
-        out_cap = std::max<uint64_t>(out_cap * 2, hc.out_ops_needed + hc.out_ops_needed / 4 + 4096);
+        out_cap = std::max<uint64_t>(out_cap * 2, hc.out_ops_needed + hc.out_ops_needed / 4 + 4096 + 4 * rows_cap);
         rc = RB_E_CAPACITY;
     }
     if (!rc && hc.overflow) rc = RB_E_CAPACITY;
@@ -663,13 +668,14 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         std::vector<rb_hit_row> hr((size_t)hc.n_hits);
         if (hc.n_hits) rc = rb_dev_download(ctx, hr.data(), d_rows, (size_t)hc.n_hits * sizeof(rb_hit_row));
         uint64_t total = 0;
-        for (auto &h : hr) total += h.status == RB_ST_OK ? h.out_n : 0;
+        auto words = [](const rb_hit_row &h) -> uint64_t { return h.status != RB_ST_OK ? 0 : ((h.flags & RB_HIT_DESCRIPTOR) ? 4 : h.out_n); };
+        for (auto &h : hr) total += words(h);
         *out_ops = (uint32_t *)malloc((size_t)(total + 1) * 4);
         std::vector<uint32_t> dev_out;
         if (!rc && hc.n_hits) {
             uint64_t hi = 0;
             for (auto &h : hr)
-                if (h.status == RB_ST_OK) hi = std::max<uint64_t>(hi, h.out_off + h.out_n);
+                if (h.status == RB_ST_OK) hi = std::max<uint64_t>(hi, h.out_off + words(h));
             dev_out.resize((size_t)hi + 4);
             if (hi) rc = rb_dev_download(ctx, dev_out.data(), d_out, (size_t)hi * 4);
         }
@@ -677,9 +683,9 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         for (size_t i = 0; i < hr.size() && !rc; i++) {
             rb_hit_row h = hr[i];
             if (h.status == RB_ST_OK) {
-                memcpy(*out_ops + o, dev_out.data() + h.out_off, (size_t)h.out_n * 4);
+                memcpy(*out_ops + o, dev_out.data() + h.out_off, (size_t)words(h) * 4);
                 h.out_off = o;
-                o += h.out_n;
+                o += words(h);
             } else {
                 h.out_off = 0;
                 h.out_n = 0;

@@ -63,6 +63,8 @@ struct rb_lift_params {
     rb_counters *counters;
     int policy;
     int early_exit; // stop streaming a record once every boundary of the pass is resolved
+    int desc_mode;  // RB_LIFT_DESCRIPTORS: 4-word clip descriptors at out_ops[4 * row] instead of copied ops
+    uint64_t arena_origin; // first op of the arena area inside out_ops (descriptor mode: after the descriptors)
     int debug_skip; // diagnostics only (wrong results): 1 = no emission, 2 = no resolution, 4 = no streaming
 };
 
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
             }
         }
         // space for the clipped cigars: one atomic per pass, each hit padded to 4 ops
-        const uint32_t padded = (mine && !defer && status == RB_ST_OK) ? ((out_n + 3u) & ~3u) : 0u;
+        const uint32_t padded = (mine && !defer && status == RB_ST_OK && !p.desc_mode) ? ((out_n + 3u) & ~3u) : 0u;
         const uint32_t incl = rb_wave_scan_incl(padded);
         const uint32_t total = rb_readlane<uint32_t>(incl, 63);
         uint64_t base = 0;
@@ -626,7 +628,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
         }
         const bool fits = base + total <= p.arena_size;
         if (!fits && lane == 0) p.counters->overflow = 1;
-        const uint64_t my_off = (uint64_t)arena * p.arena_size + base + (incl - padded);
+        const uint64_t my_off = p.arena_origin + (uint64_t)arena * p.arena_size + base + (incl - padded);
         if (mine) {
             rb_hit_row *row = &p.rows[h0 + jb + lane];
             if (defer) {
@@ -640,7 +642,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 w.rec = r;
                 w.win = win;
                 w.status = (uint16_t)status;
-                w.flags = inside ? RB_HIT_INSIDE : 0;
+                w.flags = (inside ? RB_HIT_INSIDE : 0) | ((p.desc_mode && status == RB_ST_OK) ? RB_HIT_DESCRIPTOR : 0);
                 w.out_n = status == RB_ST_OK ? out_n : 0;
                 w.t_st = o_tst;
                 w.t_en = o_ten;
@@ -648,8 +650,11 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 w.q_en = o_qen;
                 w.nmatch = o_nm;
                 w.aln_len = o_al;
-                w.out_off = status == RB_ST_OK ? my_off : 0;
+                w.out_off = status == RB_ST_OK ? (p.desc_mode ? 4ull * (h0 + jb + lane) : my_off) : 0;
                 *row = w;
+                if (p.desc_mode && status == RB_ST_OK) // which ops of the ORIGINAL cigar the clip keeps
+                    *reinterpret_cast<uint4 *>(p.out_ops + 4ull * (h0 + jb + lane)) =
+                        make_uint4(nr->first_op + a_op, out_n, inside ? 0u : A.part, inside ? 0u : B.part);
             }
         }
         // ---- emit: the clips of this pass occupy one contiguous output region [base, base + total).
@@ -666,7 +671,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 et[3 * RB_HMAX + lane] = A.part;
                 et[4 * RB_HMAX + lane] = B.part | (inside ? 0x80000000u : 0u);
             }
-            uint32_t *__restrict__ dst = p.out_ops + ((uint64_t)arena * p.arena_size + base);
+            uint32_t *__restrict__ dst = p.out_ops + (p.arena_origin + (uint64_t)arena * p.arena_size + base);
             for (uint32_t gb = 0; gb * 4u < total; gb += RB_EB * 64u) {
                 uint4 v[RB_EB];
                 uint32_t cj[RB_EB], cpos[RB_EB];
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
             const uint32_t padded = (n + 3u) & ~3u;
             const unsigned long long b0 = atomicAdd(&p.arena_cur[(uint64_t)arena * RB_ARENA_STRIDE], (unsigned long long)padded);
             if (b0 + padded <= p.arena_size) {
-                w.out_off = (uint64_t)arena * p.arena_size + b0;
+                w.out_off = p.arena_origin + (uint64_t)arena * p.arena_size + b0;
                 for (uint32_t i = 0; i < n; i++) p.out_ops[w.out_off + i] = ops[i];
             } else {
                 p.counters->overflow = 1;
@@ -886,7 +891,7 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
             *row = w;
             continue;
         }
-        w.out_off = (uint64_t)arena * p.arena_size + b0;
+        w.out_off = p.arena_origin + (uint64_t)arena * p.arena_size + b0;
         { // pass 4: emit
             uint64_t U = 0;
             uint32_t prev = RB_NULL_OP, run = 0;

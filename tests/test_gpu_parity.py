@@ -206,3 +206,72 @@ def test_synth_device_matches_host(engine):
     assert L.rb_dev_download(engine.ctx, C.c_void_p(dev.ctypes.data), d_ops, C.c_size_t(host.nbytes)) == 0
     L.rb_dev_free(engine.ctx, d_off); L.rb_dev_free(engine.ctx, d_ops)
     assert np.array_equal(dev, host)
+
+
+def _rebuild_from_descriptor(b, row, desc):
+    """clip descriptor -> packed ops, the way a host that still holds the record's cigar would"""
+    first, n, flen, llen = (int(x) for x in desc)
+    o0 = int(b["op_off"][int(row["rec"])])
+    ops = b["ops"][o0 + first:o0 + first + n].copy()
+    if not (int(row["flags"]) & rustybam_amd.HIT_INSIDE):
+        if n == 1:
+            ops[0] = (int(row["aln_len"]) << 4) | (int(ops[0]) & 15)
+        else:
+            ops[0] = (flen << 4) | (int(ops[0]) & 15)
+            ops[-1] = (llen << 4) | (int(ops[-1]) & 15)
+    return ops
+
+
+@pytest.mark.parametrize("mode", ["regular", "indel_ends", "mixed"])
+def test_liftover_descriptor_mode_and_early_exit(engine, oracle, mode):
+    """RB_LIFT_DESCRIPTORS returns which ops each clip keeps instead of copying them; RB_LIFT_EARLY_EXIT stops
+    walking a record after its last window.  Both must describe exactly the clips of the default mode."""
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(("desc" + mode).encode()))
+    b = random_batch(rng, 400, mode, n_contig=2, long_frac=0.3)
+    w = random_windows(rng, b, 150, True)
+    base_rows, base_ops, _, _ = engine.liftover(*batch_args(b), b["contig"], *w)
+    for pol in (rustybam_amd.LIFT_EARLY_EXIT, rustybam_amd.LIFT_DESCRIPTORS,
+                rustybam_amd.LIFT_DESCRIPTORS | rustybam_amd.LIFT_EARLY_EXIT):
+        rows, ops, _, cnt = engine.liftover(*batch_args(b), b["contig"], *w, policy=pol)
+        assert len(rows) == len(base_rows)
+        for k in ("rec", "win", "status", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
+            assert np.array_equal(rows[k], base_rows[k]), (pol, k)
+        n_desc = 0
+        for g, o in zip(rows, base_rows):
+            if int(o["status"]) != 0:
+                continue
+            want = base_ops[int(o["out_off"]):int(o["out_off"]) + int(o["out_n"])]
+            if int(g["flags"]) & rustybam_amd.HIT_DESCRIPTOR:
+                got = _rebuild_from_descriptor(b, g, ops[int(g["out_off"]):int(g["out_off"]) + 4])
+                n_desc += 1
+            else:
+                got = ops[int(g["out_off"]):int(g["out_off"]) + int(g["out_n"])]
+            assert np.array_equal(got, want), (pol, int(g["rec"]), int(g["win"]))
+        if pol & rustybam_amd.LIFT_DESCRIPTORS:
+            assert n_desc > 0
+            if mode == "regular":
+                assert n_desc == int((base_rows["status"] == 0).sum())
+
+
+def test_liftover_long_records_many_segments(engine, oracle):
+    """records far longer than one LDS checkpoint segment (20 steps x 256 ops), windows of every size"""
+    rng = np.random.default_rng(77)
+    b = random_batch(rng, 6, "regular", n_contig=1, max_ops=40, long_frac=0.0)
+    from rbtest_util import random_cigar, sums
+    cig = [random_cigar(rng, n, "regular") for n in (6000, 12000, 23000)]
+    for c in cig:
+        R, Q = sums(c)
+        ts, qs = int(rng.integers(0, 500)), int(rng.integers(0, 500))
+        b["ops"] = np.concatenate([b["ops"], c])
+        b["op_off"] = np.append(b["op_off"], b["op_off"][-1] + np.uint64(len(c)))
+        for k, v in (("t_st", ts), ("t_en", ts + R), ("q_st", qs), ("q_en", qs + Q), ("strand", ord("-") if len(c) % 2 else ord("+")),
+                     ("contig", 0)):
+            b[k] = np.append(b[k], np.array([v], b[k].dtype))
+    hi = int(b["t_en"].max())
+    st = np.sort(rng.integers(0, hi, 200)).astype(np.uint64)
+    ln = rng.choice([1, 50, 3000, 200000], 200).astype(np.uint64)
+    en = np.maximum.accumulate(st + ln)
+    w = (np.zeros(200, np.uint32), st, en)
+    rows, cnt = _check_liftover(engine, oracle, b, w, rustybam_amd.BSEARCH_MODERN, "long records")
+    assert cnt["n_generic"] == 0
