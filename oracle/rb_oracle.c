@@ -1353,6 +1353,265 @@ void rbo_print_stats(const rbo_rec *r, const rbo_stats *s, int qbed, FILE *f) {
 }
 
 /* ==================================================================================
+ * BAM input of `rb stats` (main.rs:60-77, bamstats.rs:156-222).  BGZF is read through zlib (a BGZF file is a
+ * multi-member gzip file).  CigarStringView::{end_pos, read_pos, leading/trailing clips} are restated from
+ * rust-htslib 0.44.1's published algorithm (only a smoke test exists in the reference: parity unpinned).
+ * ================================================================================== */
+/* bamstats.rs:48-79: regex (\d+)|([A-Z])|(\^[A-Z]+) scanned left to right */
+void rbo_parse_md_for_stats(const char *md, uint32_t out[4]) {
+    uint32_t match_count = 0, mismatch_count = 0, insertion_count = 0, insertion_bases = 0;
+    const char *p = md;
+    while (*p) {
+        if (*p >= '0' && *p <= '9') {
+            uint64_t v = 0;
+            while (*p >= '0' && *p <= '9') v = v * 10 + (uint64_t)(*p++ - '0');
+            match_count += (uint32_t)v;
+        } else if (*p >= 'A' && *p <= 'Z') {
+            mismatch_count += 1;
+            p++;
+        } else if (*p == '^' && p[1] >= 'A' && p[1] <= 'Z') {
+            const char *q = p + 1;
+            while (*q >= 'A' && *q <= 'Z') q++;
+            insertion_bases += (uint32_t)(q - p) - 1;
+            insertion_count += 1;
+            p = q;
+        } else {
+            p++; /* not matched by the regex: skipped */
+        }
+    }
+    out[0] = match_count;
+    out[1] = mismatch_count;
+    out[2] = insertion_count;
+    out[3] = insertion_bases;
+}
+
+/* rust-htslib CigarStringView::read_pos(ref_pos, include_softclips = false, include_dels = false).
+ * returns 0 = Ok(Some(*qpos)), 1 = Ok(None), -1 = Err */
+static int hts_read_pos(const uint32_t *cig, size_t n, int64_t pos, uint32_t ref_pos, uint32_t *qpos_out) {
+    uint32_t rpos = (uint32_t)pos, qpos = 0;
+    size_t j = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t op = cig[i] & 15;
+        if (op == RBO_M || op == RBO_X || op == RBO_EQ || op == RBO_I || op == RBO_S) {
+            j = i;
+            break;
+        }
+        if (op == RBO_D || op == RBO_N) return -1;
+        if (op == RBO_H && i > 0 && i + 1 < n) return -1;
+        if ((op == RBO_P || op == RBO_H) && i + 1 == n) return 1;
+        /* leading H / P: skipped */
+    }
+    while (rpos <= ref_pos && j < n) {
+        uint32_t op = cig[j] & 15, l = cig[j] >> 4;
+        if (op == RBO_M || op == RBO_X || op == RBO_EQ) {
+            if (rpos <= ref_pos && rpos + l > ref_pos) {
+                *qpos_out = qpos + (ref_pos - rpos);
+                return 0;
+            }
+            rpos += l;
+            qpos += l;
+            j++;
+        } else if (op == RBO_S || op == RBO_I) {
+            qpos += l;
+            j++;
+        } else if (op == RBO_N || op == RBO_D) {
+            rpos += l;
+            j++;
+        } else if (op == RBO_P) {
+            j++;
+        } else { /* H */
+            if (j + 1 < n) return -1;
+            return 1;
+        }
+    }
+    return 1;
+}
+
+typedef struct {
+    gzFile f;
+} bam_reader;
+static int bam_read_exact(gzFile f, void *buf, size_t n) {
+    size_t got = 0;
+    while (got < n) {
+        int r = gzread(f, (char *)buf + got, (unsigned)((n - got) > (1u << 30) ? (1u << 30) : (n - got)));
+        if (r <= 0) return 0;
+        got += (size_t)r;
+    }
+    return 1;
+}
+static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+/* walk the aux area: find the MD:Z string and a CG:B,I long cigar */
+static void bam_aux_scan(const uint8_t *a, size_t n, const char **md, const uint8_t **cg, uint32_t *cg_n) {
+    size_t p = 0;
+    *md = NULL;
+    *cg = NULL;
+    *cg_n = 0;
+    while (p + 3 <= n) {
+        const uint8_t *tag = a + p;
+        char ty = (char)a[p + 2];
+        p += 3;
+        size_t sz = 0;
+        if (ty == 'A' || ty == 'c' || ty == 'C') sz = 1;
+        else if (ty == 's' || ty == 'S') sz = 2;
+        else if (ty == 'i' || ty == 'I' || ty == 'f') sz = 4;
+        else if (ty == 'Z' || ty == 'H') {
+            size_t q = p;
+            while (q < n && a[q]) q++;
+            if (tag[0] == 'M' && tag[1] == 'D' && ty == 'Z') *md = (const char *)(a + p);
+            p = q + 1;
+            continue;
+        } else if (ty == 'B') {
+            if (p + 5 > n) return;
+            char sub = (char)a[p];
+            uint32_t cnt = rd_u32(a + p + 1);
+            size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+            if (tag[0] == 'C' && tag[1] == 'G' && sub == 'I') {
+                *cg = a + p + 5;
+                *cg_n = cnt;
+            }
+            p += 5 + es * (size_t)cnt;
+            continue;
+        } else {
+            return;
+        }
+        p += sz;
+    }
+}
+
+/* `rb stats <bam>`: header line + one line per mapped record.  returns 0, or <0 where the reference panics */
+int rbo_bam_stats(const char *path, int qbed, FILE *out) {
+    gzFile f = strcmp(path, "-") == 0 ? gzdopen(0, "rb") : gzopen(path, "rb");
+    if (!f) return -2;
+    gzbuffer(f, 1 << 20);
+    uint8_t h8[8];
+    if (!bam_read_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) {
+        gzclose(f);
+        return -3;
+    }
+    uint32_t l_text = rd_u32(h8 + 4);
+    char *text = (char *)xmalloc(l_text + 1);
+    bam_read_exact(f, text, l_text);
+    free(text);
+    uint8_t b4[4];
+    bam_read_exact(f, b4, 4);
+    uint32_t n_ref = rd_u32(b4);
+    char **ref_nm = (char **)xmalloc((n_ref + 1) * sizeof(char *));
+    uint32_t *ref_len = (uint32_t *)xmalloc((n_ref + 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n_ref; i++) {
+        bam_read_exact(f, b4, 4);
+        uint32_t l = rd_u32(b4);
+        ref_nm[i] = (char *)xmalloc(l + 1);
+        bam_read_exact(f, ref_nm[i], l);
+        ref_nm[i][l] = 0;
+        bam_read_exact(f, b4, 4);
+        ref_len[i] = rd_u32(b4);
+    }
+    rbo_print_stats_header(qbed, out);
+    int rc = 0;
+    uint8_t *rec = NULL;
+    size_t cap = 0;
+    while (bam_read_exact(f, b4, 4)) {
+        uint32_t bs = rd_u32(b4);
+        if (bs > cap) {
+            cap = bs * 2;
+            rec = (uint8_t *)xrealloc(rec, cap);
+        }
+        if (!bam_read_exact(f, rec, bs)) break;
+        int32_t refID = (int32_t)rd_u32(rec);
+        int64_t pos = (int32_t)rd_u32(rec + 4);
+        uint32_t l_rn = rec[8];
+        uint32_t n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
+        uint32_t flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8);
+        uint32_t l_seq = rd_u32(rec + 16);
+        if (flag & 4) continue; /* main.rs:73 */
+        const char *qname = (const char *)(rec + 32);
+        const uint8_t *cg_raw = rec + 32 + l_rn;
+        size_t aux_off = 32 + l_rn + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+        const char *md = NULL;
+        const uint8_t *cg_tag = NULL;
+        uint32_t cg_n = 0;
+        if (aux_off <= bs) bam_aux_scan(rec + aux_off, bs - aux_off, &md, &cg_tag, &cg_n);
+        uint32_t *cig;
+        size_t n;
+        if (cg_tag && n_cig >= 1 && (rd_u32(cg_raw) & 15) == RBO_S && (rd_u32(cg_raw) >> 4) == l_seq) { /* htslib: real cigar in CG */
+            n = cg_n;
+            cig = (uint32_t *)xmalloc((n + 1) * sizeof(uint32_t));
+            for (size_t i = 0; i < n; i++) cig[i] = rd_u32(cg_tag + 4 * i);
+        } else {
+            n = n_cig;
+            cig = (uint32_t *)xmalloc((n + 1) * sizeof(uint32_t));
+            for (size_t i = 0; i < n; i++) cig[i] = rd_u32(cg_raw + 4 * i);
+        }
+        /* bamstats.rs:156-207 */
+        int64_t r_st = pos, r_en = pos;
+        for (size_t i = 0; i < n; i++)
+            if (rbo_consumes_reference(cig[i])) r_en += cig[i] >> 4;
+        int64_t lead_h = (n && (cig[0] & 15) == RBO_H) ? (cig[0] >> 4) : 0;
+        int64_t lead_s = 0;
+        if (n && (cig[0] & 15) == RBO_S) lead_s = cig[0] >> 4;
+        else if (n > 1 && (cig[0] & 15) == RBO_H && (cig[1] & 15) == RBO_S) lead_s = cig[1] >> 4;
+        int64_t trail_h = (n && (cig[n - 1] & 15) == RBO_H) ? (cig[n - 1] >> 4) : 0;
+        uint32_t qp = 0;
+        int rp = hts_read_pos(cig, n, pos, (uint32_t)r_en - 1, &qp);
+        if (rp != 0) { /* .unwrap().unwrap() */
+            fprintf(stderr, "rb_oracle: read_pos failed for %s: the reference panics\n", qname);
+            free(cig);
+            rc = -RBO_PANIC_NOTFOUND;
+            break;
+        }
+        int64_t q_st = lead_h + lead_s;
+        int64_t q_en = lead_h + 1 + (int64_t)qp;
+        int64_t q_len = lead_h + (int64_t)l_seq + trail_h;
+        if (flag & 16) {
+            int64_t t = q_st;
+            q_st = q_len - q_en;
+            q_en = q_len - t;
+        }
+        rbo_stats s;
+        rbo_stats_from_cigar(cig, n, &s);
+        if (s.equal == 0 && s.matches > 0 && md) { /* bamstats.rs:129-135 */
+            uint32_t m4[4];
+            rbo_parse_md_for_stats(md, m4);
+            if (m4[0] + m4[1] != s.diff) {
+                free(cig);
+                rc = -RBO_PANIC_ASSERT;
+                break;
+            }
+            s.equal = m4[0];
+            s.diff = m4[1];
+            volatile float e = (float)s.equal;
+            volatile float num = 100.0f * e;
+            s.id_by_all = num / (float)(uint32_t)(s.equal + s.diff + s.del + s.ins);
+            s.id_by_events = num / (float)(uint32_t)(s.equal + s.diff + s.del_events + s.ins_events);
+            s.id_by_matches = num / (float)(uint32_t)(s.equal + s.diff);
+        }
+        rbo_rec r;
+        rbo_rec_init(&r);
+        free(r.q_name);
+        free(r.t_name);
+        r.q_name = xstrdup(qname);
+        r.t_name = xstrdup((refID >= 0 && (uint32_t)refID < n_ref) ? ref_nm[refID] : "*");
+        r.t_len = (refID >= 0 && (uint32_t)refID < n_ref) ? ref_len[refID] : 0;
+        r.t_st = (uint64_t)r_st;
+        r.t_en = (uint64_t)r_en;
+        r.q_st = (uint64_t)q_st;
+        r.q_en = (uint64_t)q_en;
+        r.q_len = (uint64_t)q_len;
+        r.strand = (flag & 16) ? '-' : '+';
+        rbo_print_stats(&r, &s, qbed, out);
+        rbo_rec_free(&r);
+        free(cig);
+    }
+    free(rec);
+    for (uint32_t i = 0; i < n_ref; i++) free(ref_nm[i]);
+    free(ref_nm);
+    free(ref_len);
+    gzclose(f);
+    return rc;
+}
+
+/* ==================================================================================
  * Flat-array API
  * ================================================================================== */
 static void rec_from_arrays(rbo_rec *r, uint64_t i, const uint32_t *ops, const uint64_t *op_off,

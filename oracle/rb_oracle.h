@@ -22,7 +22,9 @@
  *   - the text of Rust's f32 Display (shortest round-trip, positional) in `rb stats`;
  *   - rust-htslib 0.44.1 CIGAR text parser corner cases (missing digits, overflow);
  *   - bio 1.6.0 BED reader corner cases (ragged columns);
- *   - rayon par_bridge output order (we use the single-thread order).
+ *   - rayon par_bridge output order (we use the single-thread order);
+ *   - rust-htslib CigarStringView::read_pos / end_pos / clip accessors behind `rb stats <bam>` (restated from
+ *     the published algorithm; supported by asm_small.bam vs asm_small.paf: all 70 stats lines coincide).
  */
 #ifndef RB_ORACLE_H
 #define RB_ORACLE_H
@@ -147,6 +149,8 @@ void rbo_stats_from_cigar(const uint32_t *ops, size_t n, rbo_stats *s);
 size_t rbo_f32_display(float v, char *buf, size_t cap); /* Rust `{}` for f32 */
 void rbo_print_stats_header(int qbed, FILE *f);
 void rbo_print_stats(const rbo_rec *r, const rbo_stats *s, int qbed, FILE *f);
+void rbo_parse_md_for_stats(const char *md, uint32_t out[4]); /* bamstats.rs:48-79 */
+int rbo_bam_stats(const char *path, int qbed, FILE *out);       /* main.rs:60-77 + bamstats.rs:156-222 */
 
 /* ------------------------------------------------------------------------------------------
  * Flat-array API (what tests/bench compare the HIP path with).  Same data model as

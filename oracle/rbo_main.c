@@ -38,11 +38,11 @@ int main(int argc, char **argv) {
     if (a >= argc) return usage();
     const char *cmd = argv[a++];
     const char *paf_path = NULL, *bed_path = NULL;
-    int qbed = 0, largest = 0, remove_contained = 0;
+    int qbed = 0, largest = 0, remove_contained = 0, is_paf = 0;
     int ms = 1, ds = 1, is = 1;
     uint32_t max_size = 100;
     for (; a < argc; a++) {
-        if (!strcmp(argv[a], "--paf")) continue;
+        if (!strcmp(argv[a], "--paf") || !strcmp(argv[a], "-p")) { is_paf = 1; continue; }
         else if (!strcmp(argv[a], "--qbed") || !strcmp(argv[a], "-q")) qbed = 1;
         else if (!strcmp(argv[a], "--largest") || !strcmp(argv[a], "-l")) largest = 1;
         else if (!strcmp(argv[a], "--remove-contained") || !strcmp(argv[a], "-r")) remove_contained = 1;
@@ -54,6 +54,10 @@ int main(int argc, char **argv) {
         else paf_path = argv[a];
     }
     if (!paf_path) paf_path = "-";
+    if (!strcmp(cmd, "stats") && !is_paf) { /* BAM input, main.rs:60-77 */
+        int brc = rbo_bam_stats(paf_path, qbed, stdout);
+        return brc ? 101 : 0;
+    }
     rbo_paf paf;
     int rc = rbo_paf_from_file(paf_path, &paf);
     if (rc) {

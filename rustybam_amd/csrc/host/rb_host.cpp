@@ -353,6 +353,216 @@ std::vector<Stats> stats_from_paf(Engine &eng, const std::vector<PafRecord> &rec
     return out;
 }
 
+void parse_md_for_stats(const std::string &md, uint32_t out[4]) { // regex (\d+)|([A-Z])|(\^[A-Z]+), left to right
+    uint32_t m = 0, mm = 0, ic = 0, ib = 0;
+    size_t p = 0;
+    const size_t n = md.size();
+    while (p < n) {
+        const char c = md[p];
+        if (c >= '0' && c <= '9') {
+            uint64_t v = 0;
+            while (p < n && md[p] >= '0' && md[p] <= '9') v = v * 10 + (uint64_t)(md[p++] - '0');
+            m += (uint32_t)v;
+        } else if (c >= 'A' && c <= 'Z') {
+            mm++;
+            p++;
+        } else if (c == '^' && p + 1 < n && md[p + 1] >= 'A' && md[p + 1] <= 'Z') {
+            size_t q = p + 1;
+            while (q < n && md[q] >= 'A' && md[q] <= 'Z') q++;
+            ib += (uint32_t)(q - p) - 1;
+            ic++;
+            p = q;
+        } else {
+            p++;
+        }
+    }
+    out[0] = m, out[1] = mm, out[2] = ic, out[3] = ib;
+}
+
+namespace {
+struct BamRec {
+    std::string qname, md;
+    bool has_md = false;
+    int32_t ref_id = -1;
+    int64_t pos = 0;
+    uint32_t flag = 0, l_seq = 0;
+    size_t cig0 = 0, ncig = 0; // slice of the shared ops array
+};
+bool gz_exact(gzFile f, void *buf, size_t n) {
+    size_t got = 0;
+    while (got < n) {
+        const int r = gzread(f, (char *)buf + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
+        if (r <= 0) return false;
+        got += (size_t)r;
+    }
+    return true;
+}
+uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+} // namespace
+
+std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path) {
+    gzFile f = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+    if (!f) throw Panic("Failed to open " + path); // main.rs:63
+    gzbuffer(f, 1 << 20);
+    uint8_t h8[8], b4[4];
+    if (!gz_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw Panic(path + " is not a BAM file");
+    std::vector<char> text(le32(h8 + 4) + 1);
+    gz_exact(f, text.data(), text.size() - 1);
+    gz_exact(f, b4, 4);
+    const uint32_t n_ref = le32(b4);
+    std::vector<std::string> ref_nm(n_ref);
+    std::vector<uint32_t> ref_len(n_ref);
+    for (uint32_t i = 0; i < n_ref; i++) {
+        gz_exact(f, b4, 4);
+        std::vector<char> nm(le32(b4) + 1, 0);
+        gz_exact(f, nm.data(), nm.size() - 1);
+        ref_nm[i] = nm.data();
+        gz_exact(f, b4, 4);
+        ref_len[i] = le32(b4);
+    }
+    // decode every mapped record; cigars go straight into one packed array (BAM's encoding IS the ABI's)
+    std::vector<BamRec> recs;
+    std::vector<uint32_t> ops;
+    std::vector<uint8_t> rec;
+    while (gz_exact(f, b4, 4)) {
+        const uint32_t bs = le32(b4);
+        rec.resize(bs);
+        if (!gz_exact(f, rec.data(), bs)) break;
+        BamRec r;
+        r.ref_id = (int32_t)le32(rec.data());
+        r.pos = (int32_t)le32(rec.data() + 4);
+        const uint32_t l_rn = rec[8];
+        uint32_t n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
+        r.flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8);
+        r.l_seq = le32(rec.data() + 16);
+        if (r.flag & 4) continue; // main.rs:73 is_unmapped
+        r.qname = (const char *)(rec.data() + 32);
+        const uint8_t *cg = rec.data() + 32 + l_rn;
+        const size_t aux0 = 32 + l_rn + 4 * (size_t)n_cig + (r.l_seq + 1) / 2 + r.l_seq;
+        const uint8_t *cg_tag = nullptr;
+        uint32_t cg_n = 0;
+        for (size_t p = aux0; p + 3 <= bs;) { // aux fields: MD:Z and the CG:B,I long-cigar convention
+            const uint8_t *tag = rec.data() + p;
+            const char ty = (char)rec[p + 2];
+            p += 3;
+            if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
+            else if (ty == 's' || ty == 'S') p += 2;
+            else if (ty == 'i' || ty == 'I' || ty == 'f') p += 4;
+            else if (ty == 'Z' || ty == 'H') {
+                size_t q = p;
+                while (q < bs && rec[q]) q++;
+                if (tag[0] == 'M' && tag[1] == 'D' && ty == 'Z') {
+                    r.md.assign((const char *)rec.data() + p, q - p);
+                    r.has_md = true;
+                }
+                p = q + 1;
+            } else if (ty == 'B') {
+                if (p + 5 > bs) break;
+                const char sub = (char)rec[p];
+                const uint32_t cnt = le32(rec.data() + p + 1);
+                const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+                if (tag[0] == 'C' && tag[1] == 'G' && sub == 'I') {
+                    cg_tag = rec.data() + p + 5;
+                    cg_n = cnt;
+                }
+                p += 5 + es * (size_t)cnt;
+            } else {
+                break;
+            }
+        }
+        if (cg_tag && n_cig >= 1 && (le32(cg) & 15u) == RB_OP_S && (le32(cg) >> 4) == r.l_seq) {
+            cg = cg_tag;
+            n_cig = cg_n;
+        }
+        r.cig0 = ops.size();
+        r.ncig = n_cig;
+        for (uint32_t i = 0; i < n_cig; i++) ops.push_back(le32(cg + 4 * (size_t)i));
+        recs.push_back(std::move(r));
+    }
+    gzclose(f);
+    const size_t n = recs.size();
+    std::vector<uint64_t> op_off(n + 1, 0), zero(n, 0);
+    std::vector<uint8_t> strand(n, (uint8_t)'+');
+    for (size_t i = 0; i < n; i++) op_off[i + 1] = op_off[i] + recs[i].ncig;
+    ops.resize(ops.size() + 4, 0);
+    std::vector<rb_reduce_row> red(n);
+    eng.check(rb_host_scan_records(eng.ctx(), n, ops.data(), op_off.data(), zero.data(), zero.data(), zero.data(), zero.data(), strand.data(),
+                                   red.data(), nullptr),
+              "rb_host_scan_records");
+    std::vector<Stats> out(n);
+    bool warned = false;
+    for (size_t i = 0; i < n; i++) {
+        const BamRec &r = recs[i];
+        const uint32_t *cg = ops.data() + r.cig0;
+        const size_t nc = r.ncig;
+        auto opc = [&](size_t k) { return cg[k] & 15u; };
+        auto len = [&](size_t k) { return (int64_t)(cg[k] >> 4); };
+        Stats &s = out[i];
+        s.r_nm = (r.ref_id >= 0 && (uint32_t)r.ref_id < n_ref) ? ref_nm[r.ref_id] : "*";
+        s.r_len = (r.ref_id >= 0 && (uint32_t)r.ref_id < n_ref) ? ref_len[r.ref_id] : 0;
+        s.r_st = r.pos;
+        s.r_en = r.pos + (int64_t)red[i].t_bases; // CigarStringView::end_pos = pos + reference-consuming lengths
+        s.q_nm = r.qname;
+        const int64_t lead_h = (nc && opc(0) == RB_OP_H) ? len(0) : 0;
+        int64_t lead_s = 0;
+        if (nc && opc(0) == RB_OP_S) lead_s = len(0);
+        else if (nc > 1 && opc(0) == RB_OP_H && opc(1) == RB_OP_S) lead_s = len(1);
+        const int64_t trail_h = (nc && opc(nc - 1) == RB_OP_H) ? len(nc - 1) : 0;
+        // read_pos(r_en - 1): position in the read of the last reference base = read bases consumed through the last
+        // M/=/X op, minus one; anything else at the end of the reference span makes the reference's unwrap() panic
+        int64_t q_after = 0;
+        size_t k = nc;
+        bool ok = false;
+        for (size_t j = 0; j < nc; j++) { // rust-htslib read_pos: D / N before any op that describes read sequence is an Err
+            const uint32_t o = opc(j);
+            if (o == RB_OP_D || o == RB_OP_N) throw Panic("read_pos: 'deletion' found before any operation describing read sequence (" + r.qname + ")");
+            if (o == RB_OP_H && j > 0 && j + 1 < nc) throw Panic("read_pos: hard clip between operations (" + r.qname + ")");
+            if (o != RB_OP_H && o != RB_OP_P) break;
+        }
+        while (k > 0) {
+            const uint32_t o = opc(k - 1);
+            if (o == RB_OP_M || o == RB_OP_EQ || o == RB_OP_X) {
+                ok = true;
+                break;
+            }
+            if (o == RB_OP_D || o == RB_OP_N) break;
+            if (o == RB_OP_H && !(k == nc || k == 1)) break;
+            if (o == RB_OP_S || o == RB_OP_I) q_after += len(k - 1);
+            k--;
+        }
+        if (!ok || red[i].t_bases == 0) throw Panic("called `Option::unwrap()` on a `None` value (read_pos) for " + r.qname);
+        const int64_t qpos = (int64_t)red[i].q_bases - q_after - 1; // S and I count as read bases, H does not
+        s.q_st = lead_h + lead_s;
+        s.q_en = lead_h + 1 + qpos;
+        s.q_len = lead_h + (int64_t)r.l_seq + trail_h;
+        s.strand = (r.flag & 16) ? '-' : '+';
+        if (r.flag & 16) { // bamstats.rs:203-207
+            const int64_t t = s.q_st;
+            s.q_st = s.q_len - s.q_en;
+            s.q_en = s.q_len - t;
+        }
+        s.equal = red[i].equal, s.diff = red[i].diff, s.ins = red[i].ins, s.del = red[i].del, s.matches = red[i].matches;
+        s.ins_events = red[i].ins_events, s.del_events = red[i].del_events;
+        s.id_by_all = red[i].id_by_all, s.id_by_events = red[i].id_by_events, s.id_by_matches = red[i].id_by_matches;
+        if (s.equal == 0 && s.matches > 0 && r.has_md) { // bamstats.rs:129-142
+            uint32_t m4[4];
+            parse_md_for_stats(r.md, m4);
+            if (m4[0] + m4[1] != s.diff) throw Panic("assertion failed: m_count + mm_count == stats.diff");
+            s.equal = m4[0];
+            s.diff = m4[1];
+            const volatile float e = (float)s.equal;
+            const volatile float num = 100.0f * e;
+            s.id_by_all = num / (float)(uint32_t)(s.equal + s.diff + s.del + s.ins);
+            s.id_by_events = num / (float)(uint32_t)(s.equal + s.diff + s.del_events + s.ins_events);
+            s.id_by_matches = num / (float)(uint32_t)(s.equal + s.diff);
+        } else if (s.matches > 0 && !r.has_md && !warned) { // bamstats.rs:145-153
+            fprintf(stderr, "\r⚠ warning: cigar string contains 'M', assuming mismatch since there is no MD tag.");
+            warned = true;
+        }
+    }
+    return out;
+}
+
 std::string cigar_stats_header(bool qbed) {
     std::string s;
     if (qbed)

@@ -78,6 +78,11 @@ std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &
 std::vector<PafRecord> break_paf_on_indels(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length);
 // bamstats::stats_from_paf (bamstats.rs:91-154) for every record
 std::vector<Stats> stats_from_paf(Engine &eng, const std::vector<PafRecord> &paf_recs);
+// bamstats::parse_md_for_stats (bamstats.rs:48-79): (match_count, mismatch_count, insertion_count, insertion_bases)
+void parse_md_for_stats(const std::string &md, uint32_t out[4]);
+// main.rs:60-77 + bamstats::cigar_stats (bamstats.rs:156-222): every mapped record of a BAM file (BGZF through zlib);
+// the CIGAR counters come from the device record-scan kernel (BAM cigars are already the packed u32 form)
+std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &bam_path);
 std::string cigar_stats_header(bool qbed);              // bamstats.rs:225-236
 std::string cigar_stats_line(const Stats &s, bool qbed); // bamstats.rs:239-270
 

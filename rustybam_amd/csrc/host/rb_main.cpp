@@ -12,12 +12,12 @@
 static int usage() {
     fprintf(stderr,
             "usage: rb [--bsearch modern|legacy] [--device N] <subcommand> ...\n"
-            "  stats [-q|--qbed] -p|--paf <PAF>\n"
+            "  stats [-q|--qbed] [-p|--paf] <PAF or BAM>\n"
             "  liftover -b|--bed <BED> [-q|--qbed] [-l|--largest] [PAF]\n"
             "  break-paf [-m|--max-size 100] [PAF]\n"
             "  trim-paf [-m|--match-score 1] [-d|--diff-score 1] [-i|--indel-score 1] [-r|--remove-contained] [PAF]\n"
             "  invert [PAF]\n"
-            "BAM input and every other rustybam subcommand are outside this engine's scope.\n");
+            "Every other rustybam subcommand is outside this engine's scope.\n");
     return 2;
 }
 
@@ -59,13 +59,13 @@ int main(int argc, char **argv) {
         std::vector<char> obuf(1 << 22);
         setvbuf(stdout, obuf.data(), _IOFBF, obuf.size());
         if (cmd == "stats") {
-            if (!is_paf) {
-                fprintf(stderr, "rb stats: BAM input is outside this engine's scope (use --paf)\n");
-                return 2;
-            }
             put(rb::cigar_stats_header(qbed));
-            rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-            for (const rb::Stats &s : rb::stats_from_paf(eng, paf.records)) put(rb::cigar_stats_line(s, qbed));
+            if (!is_paf) { // BAM input (main.rs:60-77)
+                for (const rb::Stats &s : rb::cigar_stats_bam(eng, paf_path)) put(rb::cigar_stats_line(s, qbed));
+            } else {
+                rb::Paf paf = rb::Paf::from_file(eng, paf_path);
+                for (const rb::Stats &s : rb::stats_from_paf(eng, paf.records)) put(rb::cigar_stats_line(s, qbed));
+            }
         } else if (cmd == "invert") {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             for (const rb::PafRecord &r : rb::paf_swap_query_and_target(eng, paf.records)) put(r.to_string() + "\n");

@@ -77,3 +77,82 @@ def test_panics_like_the_reference(tmp_path):
     skip.write_text("Q x 0 5 + T 10 0 5 0 0 60 cg:Z:5=\nQ 10 0 5 + T 10 0 5 0 0 60 cg:Z:5=\n")
     rc, out = rb("invert", skip)
     assert rc == 0 and out.count(b"\n") == 1  # unparsable numeric column: the line is skipped (paf.rs:73)
+
+
+# ---- BAM input of `rb stats`: BGZF/BAM decode on the host, CIGAR counters on the device ----
+def _write_bam(path, refs, recs):
+    """minimal BAM writer (one gzip member per BGZF-less stream is fine for zlib readers)"""
+    import gzip
+    import struct
+    out = bytearray(b"BAM\x01")
+    text = b"@HD\tVN:1.6\n"
+    out += struct.pack("<i", len(text)) + text + struct.pack("<i", len(refs))
+    for nm, ln in refs:
+        out += struct.pack("<i", len(nm) + 1) + nm.encode() + b"\0" + struct.pack("<i", ln)
+    for r in recs:
+        name = r["name"].encode() + b"\0"
+        cig = b"".join(struct.pack("<I", (l << 4) | "MIDNSHP=X".index(c)) for l, c in r["cigar"])
+        l_seq = r["l_seq"]
+        body = struct.pack("<iiBBHHHiiii", r["ref"], r["pos"], len(name), 60, 0, len(r["cigar"]), r["flag"], l_seq, -1, -1, 0)
+        body += name + cig + b"\x11" * ((l_seq + 1) // 2) + b"\xff" * l_seq + r.get("aux", b"")
+        out += struct.pack("<i", len(body)) + body
+    with gzip.open(path, "wb") as f:
+        f.write(bytes(out))
+
+
+@pytest.mark.parametrize("bam", ["asm_small.bam", "test.bam", "stats.bam"])
+@pytest.mark.parametrize("qbed", [False, True])
+def test_stats_bam_fixtures(oracle, golden, bam, qbed):
+    a = ["stats"] + (["--qbed"] if qbed else []) + [f"{golden}/{bam}"]
+    rc, out = rb(*a)
+    orc, oout = oracle.cli(*a)
+    assert (rc, orc) == (0, 0)
+    assert out == oout and out.count(b"\n") > 5
+
+
+def test_stats_bam_equals_stats_paf_of_the_same_alignments(golden):
+    """asm_small.bam and asm_small.paf hold the same alignments: every BAM stats line appears among the PAF stats lines
+    (an independent check of the hard-clip / reverse-strand query coordinates of bamstats.rs:190-207)"""
+    rc1, b = rb("stats", f"{golden}/asm_small.bam")
+    rc2, p = rb("stats", "--paf", f"{golden}/asm_small.paf")
+    assert (rc1, rc2) == (0, 0)
+    plines = set(p.splitlines()[1:])
+    blines = b.splitlines()[1:]
+    assert len(blines) == 70 and all(x in plines for x in blines)
+
+
+def test_stats_bam_md_tag_cg_tag_and_panics(oracle, tmp_path):
+    import struct
+    refs = [("chrA", 100000)]
+    md = b"MDZ" + b"10A3T0T10^ACGT5" + b"\0"  # KA6 string + 5 more matches; 23+5 matches, 3 mismatches
+    recs = [
+        dict(name="md_refines_M", ref=0, pos=100, flag=0, l_seq=31, cigar=[(14, "M"), (4, "D"), (17, "M")], aux=md),   # 31 M bases = 28 + 3
+        dict(name="no_md", ref=0, pos=200, flag=16, l_seq=40, cigar=[(5, "S"), (20, "M"), (3, "I"), (12, "M")], aux=b"NMC\x03"),
+        dict(name="hard_soft", ref=0, pos=300, flag=16, l_seq=25, cigar=[(7, "H"), (5, "S"), (20, "="), (9, "H")]),
+        dict(name="unmapped", ref=-1, pos=-1, flag=4, l_seq=10, cigar=[]),
+    ]
+    real = [(30, "="), (2, "X"), (8, "=")]
+    cg = b"CGBI" + struct.pack("<i", len(real)) + b"".join(struct.pack("<I", (l << 4) | "MIDNSHP=X".index(c)) for l, c in real)
+    recs.append(dict(name="long_cigar_in_CG", ref=0, pos=500, flag=0, l_seq=40, cigar=[(40, "S"), (40, "N")], aux=cg))
+    bam = tmp_path / "synth.bam"
+    _write_bam(bam, refs, recs)
+    rc, out = rb("stats", bam)
+    orc, oout = oracle.cli("stats", bam)
+    assert (rc, orc) == (0, 0) and out == oout
+    lines = [ln.split(b"\t") for ln in out.splitlines()[1:]]
+    assert len(lines) == 4  # the unmapped record is skipped (main.rs:73)
+    assert lines[0][5] == b"md_refines_M" and (lines[0][12], lines[0][13]) == (b"28", b"3")  # equal / diff from the MD tag
+    assert lines[2][5:9] == [b"hard_soft", b"9", b"29", b"41"]  # reverse strand: q_len 41, q_st = 41 - 32, q_en = 41 - 12
+    assert lines[3][5] == b"long_cigar_in_CG" and lines[3][12] == b"38"
+    # KA6 (bamstats.rs:41-46)
+    import ctypes as C
+    m4 = (C.c_uint32 * 4)()
+    oracle.lib().rbo_parse_md_for_stats(b"10A3T0T10^ACGT", m4)
+    assert list(m4) == [23, 3, 1, 4]
+    # alignment whose reference span ends in a deletion: read_pos(...).unwrap().unwrap() panics
+    bad = tmp_path / "bad.bam"
+    _write_bam(bad, refs, [dict(name="ends_in_D", ref=0, pos=10, flag=0, l_seq=10, cigar=[(10, "="), (5, "D")])])
+    assert rb("stats", bad)[0] == 101 and oracle.cli("stats", bad)[0] == 101
+    bad2 = tmp_path / "bad2.bam"
+    _write_bam(bad2, refs, [dict(name="starts_with_D", ref=0, pos=10, flag=0, l_seq=10, cigar=[(5, "D"), (10, "=")])])
+    assert rb("stats", bad2)[0] == 101 and oracle.cli("stats", bad2)[0] == 101

@@ -173,3 +173,27 @@ def test_remove_trailing_indels_quirks(oracle):
     assert r["status"] == oracle.PANIC_ALL_INDEL
     r = oracle.normalize(oracle.Batch(np.zeros(0, np.uint32), [0, 0], [1], [1], [1], [1], [ord("+")]))[0]
     assert r["status"] == oracle.PANIC_EMPTY_CIGAR
+
+
+def test_ka6_md_parse(oracle, ka):
+    import ctypes as C
+    m4 = (C.c_uint32 * 4)()
+    oracle.lib().rbo_parse_md_for_stats(ka["KA6_md"]["md"].encode(), m4)
+    assert list(m4) == ka["KA6_md"]["expect"]
+
+
+def test_bam_stats_oracle(oracle, golden):
+    """`rb stats <bam>` (bamstats.rs:156-222): the 70 alignments of asm_small.bam are also in asm_small.paf, so every
+    BAM stats line must appear verbatim among the PAF stats lines -- pins the q-coordinate logic (hard clips,
+    reverse-strand flip, end_pos / read_pos) independently of this restatement of rust-htslib."""
+    import hashlib
+    import json
+    rc, b = oracle.cli("stats", f"{golden}/asm_small.bam")
+    rc2, p = oracle.cli("stats", "--paf", f"{golden}/asm_small.paf")
+    assert (rc, rc2) == (0, 0)
+    blines, plines = b.splitlines()[1:], set(p.splitlines()[1:])
+    assert len(blines) == 70 and all(x in plines for x in blines)
+    dig = json.load(open(f"{golden}/digests.json"))
+    for key, f in (("stats_bam_asm_small", "asm_small.bam"), ("stats_bam_test", "test.bam"), ("stats_bam_stats", "stats.bam")):
+        rc, out = oracle.cli("stats", f"{golden}/{f}")
+        assert rc == 0 and hashlib.md5(out).hexdigest() == dig[key]["md5"] and out.count(b"\n") == dig[key]["lines"]
