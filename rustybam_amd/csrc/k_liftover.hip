@@ -402,6 +402,9 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
 
 #define RB_SMAX 20 // steps (of 256 ops) whose checkpoints fit in LDS at once
 #define RB_CP_PER_STEP 16
+#ifndef RB_PF
+#define RB_PF 4 // steps (1 KiB each) of stream loads in flight per wave
+#endif
 #ifndef RB_EB
 #define RB_EB 4 // output groups (16 B) per lane and emission batch
 #endif
@@ -517,16 +520,17 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 const uint64_t gi = glane + ((uint64_t)stp << 8);
                 return gi < gend ? *reinterpret_cast<const uint4 *>(p.ops + gi) : make_uint4(0, 0, 0, 0);
             };
-            uint4 pf0 = load_step(0), pf1 = load_step(1), pf2 = load_step(2), pf3 = load_step(3);
+            uint4 pf[RB_PF];
+#pragma unroll
+            for (int q = 0; q < RB_PF; q++) pf[q] = load_step((uint32_t)q);
             for (uint32_t seg0 = 0; seg0 < n_steps; seg0 += RB_SMAX) {
                 const uint32_t seg1 = (seg0 + RB_SMAX < n_steps) ? seg0 + RB_SMAX : n_steps;
                 const uint32_t Rseg = Rb;
                 for (uint32_t st = seg0; st < seg1; st++) {
-                    const uint4 cur = pf0;
-                    pf0 = pf1;
-                    pf1 = pf2;
-                    pf2 = pf3;
-                    pf3 = load_step(st + 4);
+                    const uint4 cur = pf[0];
+#pragma unroll
+                    for (int q = 0; q + 1 < RB_PF; q++) pf[q] = pf[q + 1];
+                    pf[RB_PF - 1] = load_step(st + RB_PF);
                     const int32_t idx0 = (int32_t)(st << 8) + lane * 4 - head;
                     const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
                     uint32_t sr = 0, sq = 0, su = 0;
