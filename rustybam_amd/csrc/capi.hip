@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -602,6 +603,17 @@ extern "C" int rb_host_scan_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t 
     return rb_ctx_sync(ctx);
 }
 
+static double rb_now_s() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+static void rb_lap(const char *what, double &t) {
+    static const bool on = getenv("RB_TIMING") != nullptr;
+    const double n = rb_now_s();
+    if (on) fprintf(stderr, "[rb timing]     %-24s %.3f s\n", what, n - t);
+    t = n;
+}
 static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off,
                      const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
                      const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en,
@@ -618,21 +630,25 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         zc.assign(n_rec, 0);
         contig = zc.data();
     }
+    double tl = rb_now_s();
     int rc = b.load(n_rec, ops, op_off, t_st, t_en, q_st, q_en, strand, contig);
     if (rc) return rc;
+    rb_lap("H2D batch", tl);
     rb_norm_row *d_norm = nullptr;
     if ((rc = b.alloc(n_rec, &d_norm))) return rc;
     if ((rc = rb_dev_scan_records(ctx, &b.v, nullptr, d_norm))) return rc;
     if (norm_out && (rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;
+    rb_lap("scan_records + norm D2H", tl);
     rb_plan *plan = nullptr;
     if ((rc = rb_plan_create(ctx, n_rec, op_off, contig, n_win, w_contig, w_st, w_en, &plan))) return rc;
+    rb_lap("plan", tl);
     rb_counters *d_cnt = nullptr;
     if ((rc = b.alloc(1, &d_cnt))) {
         rb_plan_destroy(plan);
         return rc;
     }
     const uint64_t n_ops = n_rec ? op_off[n_rec] : 0;
-    uint64_t rows_cap = n_rec + n_win + 1024;
+    uint64_t rows_cap = 16 * n_rec + n_win + 1024; // a first guess; the counters say what is needed if it is short
     uint64_t out_cap = ((policy & RB_LIFT_DESCRIPTORS) ? n_ops / 4 : 2 * n_ops) + 16 * rows_cap + 4096;
     rb_counters hc;
     memset(&hc, 0, sizeof hc);
@@ -661,6 +677,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         rc = RB_E_CAPACITY;
     }
     if (!rc && hc.overflow) rc = RB_E_CAPACITY;
+    rb_lap("alloc + kernels", tl);
     if (!rc) {
         *n_rows = hc.n_hits;
         *rows = (rb_hit_row *)malloc((size_t)(hc.n_hits + 1) * sizeof(rb_hit_row));
@@ -694,6 +711,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         }
         *n_out = o;
         if (counters) *counters = hc;
+        rb_lap("D2H + compact", tl);
     }
     if (ws) hipFree(ws);
     if (d_rows) hipFree(d_rows);

@@ -6,15 +6,59 @@
 
 #include <algorithm>
 #include <charconv>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <numeric>
 #include <unordered_map>
 #include <unordered_set>
+#include <thread>
 
 namespace rb {
+
+// static chunking over host threads: text decode / encode is what bounds end-to-end throughput
+static unsigned host_threads() {
+    static const unsigned n = [] {
+        const char *e = getenv("RB_THREADS");
+        unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+        return v < 1 ? 1u : (v > 64 ? 64u : v);
+    }();
+    return n;
+}
+template <typename F>
+static void parallel_chunks(size_t n, F fn) { // fn(chunk_index, lo, hi)
+    const unsigned T = (unsigned)std::min<size_t>(host_threads(), n ? n : 1);
+    if (T <= 1) {
+        fn(0u, (size_t)0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(T);
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            try {
+                fn(t, n * t / T, n * (t + 1) / T);
+            } catch (...) {
+                err[t] = std::current_exception();
+            }
+        });
+    for (auto &x : th) x.join();
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e); // the first chunk's failure = the first failing line in file order
+}
+// RB_TIMING=1: wall time of host phases on stderr
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void lap(const char *what, double &t) {
+    static const bool on = getenv("RB_TIMING") != nullptr;
+    const double n = now_s();
+    if (on) fprintf(stderr, "[rb timing]   %-26s %.3f s\n", what, n - t);
+    t = n;
+}
+unsigned parallel_chunk_count(size_t n) { return (unsigned)std::min<size_t>(host_threads(), n ? n : 1); }
 
 static const char OPCH[] = "MIDNSHP=X";
 
@@ -194,9 +238,12 @@ struct HostBatch {
         }
         ops.resize(total + 4, 0);
         t_st.resize(n), t_en.resize(n), q_st.resize(n), q_en.resize(n), strand.resize(n), contig.resize(n);
+        parallel_chunks(n, [&](unsigned, size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++)
+                if (!recs[i].cigar.empty()) memcpy(&ops[op_off[i]], recs[i].cigar.data(), recs[i].cigar.size() * 4);
+        });
         for (size_t i = 0; i < n; i++) {
             const PafRecord &r = recs[i];
-            if (!r.cigar.empty()) memcpy(&ops[op_off[i]], r.cigar.data(), r.cigar.size() * 4);
             t_st[i] = r.t_st, t_en[i] = r.t_en, q_st[i] = r.q_st, q_en[i] = r.q_en;
             strand[i] = (uint8_t)r.strand;
             auto it = contig_id.find(r.t_name);
@@ -223,21 +270,64 @@ static std::string stripped_id(const PafRecord &r, const rb_norm_row &nr) {
 }
 
 Paf Paf::from_file(Engine &eng, const std::string &file_name) {
-    gzFile f = file_name == "-" ? gzdopen(0, "rb") : gzopen(file_name.c_str(), "rb");
-    if (!f) throw Panic("Failed to open " + file_name);
-    gzbuffer(f, 1 << 20);
-    Paf paf;
-    std::string line;
-    size_t index = 0;
-    while (gz_getline(f, line)) {
-        PafRecord rec;
-        if (paf_record_new(line, rec) == 0)
-            paf.records.push_back(std::move(rec));
-        else
-            fprintf(stderr, "\nUnable to parse PAF record. Skipping line %zu\n", index + 1);
-        index++;
+    std::string all; // the whole (decompressed) text; lines are parsed in parallel below
+    bool plain = false;
+    if (file_name != "-") { // uncompressed regular file: read it directly (zlib's pass-through mode is 3x slower)
+        FILE *fp = fopen(file_name.c_str(), "rb");
+        if (!fp) throw Panic("Failed to open " + file_name);
+        unsigned char magic[2] = {0, 0};
+        const size_t got = fread(magic, 1, 2, fp);
+        if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(fp, 0, SEEK_END) == 0) {
+            const long sz = ftell(fp);
+            if (sz >= 0) {
+                rewind(fp);
+                all.resize((size_t)sz);
+                if (fread(&all[0], 1, (size_t)sz, fp) == (size_t)sz) plain = true;
+            }
+        }
+        fclose(fp);
     }
-    gzclose(f);
+    if (!plain) {
+        gzFile f = file_name == "-" ? gzdopen(0, "rb") : gzopen(file_name.c_str(), "rb");
+        if (!f) throw Panic("Failed to open " + file_name);
+        gzbuffer(f, 1 << 20);
+        all.clear();
+        std::vector<char> buf(1 << 24);
+        int r;
+        while ((r = gzread(f, buf.data(), (unsigned)buf.size())) > 0) all.append(buf.data(), (size_t)r);
+        gzclose(f);
+    }
+    std::vector<std::pair<size_t, size_t>> lines; // BufRead::lines: split on \n, strip one trailing \r
+    for (size_t a = 0; a < all.size();) {
+        size_t b = all.find('\n', a);
+        if (b == std::string::npos) b = all.size();
+        size_t e = b;
+        if (e > a && all[e - 1] == '\r') e--;
+        lines.emplace_back(a, e - a);
+        a = b + 1;
+    }
+    const unsigned T = parallel_chunk_count(lines.size());
+    std::vector<std::vector<PafRecord>> part(T);
+    std::vector<std::vector<size_t>> skipped(T);
+    parallel_chunks(lines.size(), [&](unsigned t, size_t lo, size_t hi) {
+        part[t].reserve(hi - lo);
+        std::string line;
+        for (size_t i = lo; i < hi; i++) {
+            line.assign(all, lines[i].first, lines[i].second);
+            PafRecord rec;
+            if (paf_record_new(line, rec) == 0)
+                part[t].push_back(std::move(rec));
+            else
+                skipped[t].push_back(i);
+        }
+    });
+    Paf paf;
+    for (unsigned t = 0; t < T; t++) {
+        for (size_t i : skipped[t]) fprintf(stderr, "\nUnable to parse PAF record. Skipping line %zu\n", i + 1);
+        for (auto &r : part[t]) paf.records.push_back(std::move(r));
+    }
+    all.clear();
+    all.shrink_to_fit();
     // check_integrity().unwrap() (paf.rs:70) for the whole file in one device pass; overwrites nmatch / aln_len
     HostBatch b(paf.records);
     std::vector<rb_reduce_row> red(b.n());
@@ -267,27 +357,135 @@ std::vector<PafRecord> paf_swap_query_and_target(Engine &eng, const std::vector<
 
 static std::vector<PafRecord> rows_to_records(const std::vector<PafRecord> &src, const std::vector<rb_norm_row> &norm, const rb_hit_row *rows,
                                               uint64_t n_rows, const uint32_t *out, const std::vector<Region> *rgns) {
+    for (uint64_t k = 0; k < n_rows; k++)
+        if (rows[k].status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(rows[k].rec + 1));
+    const unsigned T = parallel_chunk_count((size_t)n_rows);
+    std::vector<std::vector<PafRecord>> part(T);
+    parallel_chunks((size_t)n_rows, [&](unsigned t, size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; k++) {
+            const rb_hit_row &h = rows[k];
+            if (h.status != RB_ST_OK) continue; // trim_paf_rec_to_rgn returned None
+            const PafRecord &s = src[h.rec];
+            PafRecord r;
+            r.q_name = s.q_name, r.q_len = s.q_len, r.strand = s.strand, r.t_name = s.t_name, r.t_len = s.t_len, r.mapq = s.mapq;
+            r.t_st = h.t_st, r.t_en = h.t_en, r.q_st = h.q_st, r.q_en = h.q_en, r.nmatch = h.nmatch, r.aln_len = h.aln_len;
+            r.id = (rgns && !(h.flags & RB_HIT_INSIDE)) ? (*rgns)[h.win].id : stripped_id(s, norm[h.rec]);
+            if (h.flags & RB_HIT_DESCRIPTOR) {
+                // the clip is described, not copied: {first op of the record's own cigar, count, first length, last length}
+                const uint32_t *d = out + h.out_off;
+                r.cigar.assign(s.cigar.begin() + d[0], s.cigar.begin() + d[0] + d[1]);
+                if (!(h.flags & RB_HIT_INSIDE)) {
+                    if (d[1] == 1) {
+                        r.cigar[0] = (h.aln_len << 4) | (r.cigar[0] & 15u);
+                    } else {
+                        r.cigar[0] = (d[2] << 4) | (r.cigar[0] & 15u);
+                        r.cigar.back() = (d[3] << 4) | (r.cigar.back() & 15u);
+                    }
+                }
+            } else {
+                r.cigar.assign(out + h.out_off, out + h.out_off + h.out_n);
+            }
+            part[t].push_back(std::move(r));
+        }
+    });
     std::vector<PafRecord> res;
-    for (uint64_t k = 0; k < n_rows; k++) {
-        const rb_hit_row &h = rows[k];
-        if (h.status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(h.rec + 1));
-        if (h.status != RB_ST_OK) continue; // trim_paf_rec_to_rgn returned None
-        const PafRecord &s = src[h.rec];
-        PafRecord r;
-        r.q_name = s.q_name, r.q_len = s.q_len, r.strand = s.strand, r.t_name = s.t_name, r.t_len = s.t_len, r.mapq = s.mapq;
-        r.t_st = h.t_st, r.t_en = h.t_en, r.q_st = h.q_st, r.q_en = h.q_en, r.nmatch = h.nmatch, r.aln_len = h.aln_len;
-        r.id = (rgns && !(h.flags & RB_HIT_INSIDE)) ? (*rgns)[h.win].id : stripped_id(s, norm[h.rec]);
-        r.cigar.assign(out + h.out_off, out + h.out_off + h.out_n);
-        res.push_back(std::move(r));
-    }
+    size_t total = 0;
+    for (auto &p : part) total += p.size();
+    res.reserve(total);
+    for (auto &p : part)
+        for (auto &r : p) res.push_back(std::move(r));
     return res;
 }
 
-std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query) {
+// `println!("{}", rec)` for every Some(rec) of a liftover / break-paf result, straight from the hit rows: no
+// intermediate PafRecord is built (1.3 M of them cost more than the whole device pass), text is encoded on all
+// host cores and returned in the reference's output order.
+static std::vector<std::string> rows_to_text(const std::vector<PafRecord> &src, const std::vector<rb_norm_row> &norm, const rb_hit_row *rows, uint64_t n_rows,
+                                const uint32_t *out, const std::vector<Region> *rgns) {
+    for (uint64_t k = 0; k < n_rows; k++)
+        if (rows[k].status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(rows[k].rec + 1));
+    const unsigned T = parallel_chunk_count((size_t)n_rows);
+    std::vector<std::string> part(T);
+    parallel_chunks((size_t)n_rows, [&](unsigned t, size_t lo, size_t hi) {
+        std::string &o = part[t];
+        size_t est = 0; // ~2.7 text bytes per op on alignment cigars; one allocation instead of a dozen doublings
+        for (size_t k = lo; k < hi; k++) est += rows[k].status == RB_ST_OK ? 160 + (size_t)rows[k].out_n * 3 : 0;
+        o.reserve(est);
+        char nb[24];
+        auto num = [&](uint64_t v) {
+            auto r = std::to_chars(nb, nb + sizeof nb, v);
+            o.append(nb, r.ptr);
+        };
+        auto op = [&](uint32_t v) {
+            auto r = std::to_chars(nb, nb + sizeof nb, v >> 4);
+            o.append(nb, r.ptr);
+            o.push_back(OPCH[v & 15u]);
+        };
+        for (size_t k = lo; k < hi; k++) {
+            const rb_hit_row &h = rows[k];
+            if (h.status != RB_ST_OK) continue;
+            const PafRecord &s = src[h.rec];
+            o += s.q_name; o += '\t'; num(s.q_len); o += '\t'; num(h.q_st); o += '\t'; num(h.q_en); o += '\t'; o += s.strand; o += '\t';
+            o += s.t_name; o += '\t'; num(s.t_len); o += '\t'; num(h.t_st); o += '\t'; num(h.t_en); o += '\t'; num(h.nmatch); o += '\t';
+            num(h.aln_len); o += '\t'; num(s.mapq); o += "\tid:Z:";
+            o += (rgns && !(h.flags & RB_HIT_INSIDE)) ? (*rgns)[h.win].id : stripped_id(s, norm[h.rec]);
+            o += "\tcg:Z:";
+            if (h.flags & RB_HIT_DESCRIPTOR) {
+                const uint32_t *d = out + h.out_off;
+                const uint32_t *c = s.cigar.data() + d[0];
+                const uint32_t n = d[1];
+                if (h.flags & RB_HIT_INSIDE) {
+                    for (uint32_t i = 0; i < n; i++) op(c[i]);
+                } else if (n == 1) {
+                    op((h.aln_len << 4) | (c[0] & 15u));
+                } else {
+                    op((d[2] << 4) | (c[0] & 15u));
+                    for (uint32_t i = 1; i + 1 < n; i++) op(c[i]);
+                    op((d[3] << 4) | (c[n - 1] & 15u));
+                }
+            } else {
+                for (uint32_t i = 0; i < h.out_n; i++) op(out[h.out_off + i]);
+            }
+            o += '\n';
+        }
+    });
+    return part; // chunks in output order (concatenating 3 GB of text would cost as much as encoding it)
+}
+
+// Display of many records at once (text encode in parallel, written in order)
+std::vector<std::string> records_to_text(const std::vector<PafRecord> &recs) {
+    const unsigned T = parallel_chunk_count(recs.size());
+    std::vector<std::string> part(T);
+    parallel_chunks(recs.size(), [&](unsigned t, size_t lo, size_t hi) {
+        std::string &o = part[t];
+        for (size_t i = lo; i < hi; i++) {
+            o += recs[i].to_string();
+            o += '\n';
+        }
+    });
+    return part;
+}
+
+namespace {
+struct LiftResult { // rows + clip descriptors of one liftover / break-paf call (freed on destruction)
     std::vector<PafRecord> swapped;
-    if (invert_query) swapped = paf_swap_query_and_target(eng, paf_recs);
-    const std::vector<PafRecord> &recs = invert_query ? swapped : paf_recs;
+    const std::vector<PafRecord> *recs = nullptr;
+    std::vector<rb_norm_row> norm;
+    rb_hit_row *rows = nullptr;
+    uint32_t *out = nullptr;
+    uint64_t n_rows = 0, n_out = 0;
+    ~LiftResult() {
+        rb_host_free(rows);
+        rb_host_free(out);
+    }
+};
+void run_liftover(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query, LiftResult &L) {
+    if (invert_query) L.swapped = paf_swap_query_and_target(eng, paf_recs);
+    L.recs = invert_query ? &L.swapped : &paf_recs;
+    const std::vector<PafRecord> &recs = *L.recs;
+    double tl = now_s();
     HostBatch b(recs);
+    lap("pack batch", tl);
     std::vector<uint32_t> w_contig(rgns.size());
     std::vector<uint64_t> w_st(rgns.size()), w_en(rgns.size());
     for (size_t i = 0; i < rgns.size(); i++) {
@@ -295,37 +493,51 @@ std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &
         if (it == b.contig_id.end()) it = b.contig_id.emplace(rgns[i].name, (uint32_t)b.contig_id.size()).first; // no record there
         w_contig[i] = it->second, w_st[i] = rgns[i].st, w_en[i] = rgns[i].en;
     }
-    std::vector<rb_norm_row> norm(b.n());
-    rb_hit_row *rows = nullptr;
-    uint32_t *out = nullptr;
-    uint64_t n_rows = 0, n_out = 0;
+    L.norm.resize(b.n());
     rb_counters cnt;
     eng.check(rb_host_liftover(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
                                b.strand.data(), b.contig.data(), rgns.size(), w_contig.data(), w_st.data(), w_en.data(),
-                               eng.bsearch_policy, norm.data(), &rows, &n_rows, &out, &n_out, &cnt),
+                               eng.bsearch_policy | RB_LIFT_DESCRIPTORS, L.norm.data(), &L.rows, &L.n_rows, &L.out, &L.n_out, &cnt),
               "rb_host_liftover");
-    for (size_t i = 0; i < norm.size(); i++) panic_on(norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
-    std::vector<PafRecord> res = rows_to_records(recs, norm, rows, n_rows, out, &rgns);
-    rb_host_free(rows);
-    rb_host_free(out);
-    return res;
+    lap("rb_host_liftover", tl);
+    for (size_t i = 0; i < L.norm.size(); i++) panic_on(L.norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
+}
+void run_break(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length, LiftResult &L) {
+    L.recs = &paf_recs;
+    HostBatch b(paf_recs);
+    L.norm.resize(b.n());
+    rb_counters cnt;
+    eng.check(rb_host_break(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
+                            b.strand.data(), break_length, eng.bsearch_policy | RB_LIFT_DESCRIPTORS, L.norm.data(), &L.rows, &L.n_rows, &L.out,
+                            &L.n_out, &cnt),
+              "rb_host_break");
+    for (size_t i = 0; i < L.norm.size(); i++) panic_on(L.norm[i].status, "aligned_pairs", i); // main.rs:275
+}
+} // namespace
+
+std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query) {
+    LiftResult L;
+    run_liftover(eng, rgns, paf_recs, invert_query, L);
+    return rows_to_records(*L.recs, L.norm, L.rows, L.n_rows, L.out, &rgns);
+}
+std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query) {
+    LiftResult L;
+    run_liftover(eng, rgns, paf_recs, invert_query, L);
+    double tl = now_s();
+    std::vector<std::string> text = rows_to_text(*L.recs, L.norm, L.rows, L.n_rows, L.out, &rgns);
+    lap("rows -> text", tl);
+    return text;
 }
 
 std::vector<PafRecord> break_paf_on_indels(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length) {
-    HostBatch b(paf_recs);
-    std::vector<rb_norm_row> norm(b.n());
-    rb_hit_row *rows = nullptr;
-    uint32_t *out = nullptr;
-    uint64_t n_rows = 0, n_out = 0;
-    rb_counters cnt;
-    eng.check(rb_host_break(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
-                            b.strand.data(), break_length, eng.bsearch_policy, norm.data(), &rows, &n_rows, &out, &n_out, &cnt),
-              "rb_host_break");
-    for (size_t i = 0; i < norm.size(); i++) panic_on(norm[i].status, "aligned_pairs", i); // main.rs:275
-    std::vector<PafRecord> res = rows_to_records(paf_recs, norm, rows, n_rows, out, nullptr); // id = paf.id (liftover.rs:194)
-    rb_host_free(rows);
-    rb_host_free(out);
-    return res;
+    LiftResult L;
+    run_break(eng, paf_recs, break_length, L);
+    return rows_to_records(paf_recs, L.norm, L.rows, L.n_rows, L.out, nullptr); // id = paf.id (liftover.rs:194)
+}
+std::vector<std::string> break_paf_on_indels_text(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length) {
+    LiftResult L;
+    run_break(eng, paf_recs, break_length, L);
+    return rows_to_text(paf_recs, L.norm, L.rows, L.n_rows, L.out, nullptr);
 }
 
 std::vector<Stats> stats_from_paf(Engine &eng, const std::vector<PafRecord> &recs) {

@@ -65,6 +65,7 @@ struct Paf { // paf::Paf (paf.rs:34-37)
 };
 
 std::string cigar_to_string(const std::vector<uint32_t> &cigar);
+std::vector<std::string> records_to_text(const std::vector<PafRecord> &recs); // `println!("{}", rec)` for every record, encoded on all host cores; chunks in output order
 // PafRecord::new (paf.rs:379-430): 0 = ok, 1 = Err(ParsePafColumn) (caller skips the line); throws Panic
 int paf_record_new(const std::string &line, PafRecord &out);
 std::vector<Region> parse_bed(const std::string &filename);                    // bed.rs:172-194
@@ -74,6 +75,9 @@ std::string f32_display(float v);                                              /
 std::vector<PafRecord> paf_swap_query_and_target(Engine &eng, const std::vector<PafRecord> &recs);
 // liftover::trim_paf_by_rgns (liftover.rs:134-167), single-thread output order
 std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query);
+// the same, printed: every Some(rec) as `println!("{}", rec)` would, without materialising the records
+std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query);
+std::vector<std::string> break_paf_on_indels_text(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length);
 // main.rs:274-280: aligned_pairs + liftover::break_paf_on_indels (liftover.rs:182-226) for every record, record order
 std::vector<PafRecord> break_paf_on_indels(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length);
 // bamstats::stats_from_paf (bamstats.rs:91-154) for every record

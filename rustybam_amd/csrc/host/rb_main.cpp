@@ -6,8 +6,21 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
+
+#include <chrono>
 
 #include "rb_host.hpp"
+#include "../synth.h"
+
+// RB_TIMING=1: wall time of the host phases on stderr (decode / device + gather / encode / write)
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void lap(const char *what, double &t) {
+    static const bool on = getenv("RB_TIMING") != nullptr;
+    const double n = now_s();
+    if (on) fprintf(stderr, "[rb timing] %-28s %.3f s\n", what, n - t);
+    t = n;
+}
 
 static int usage() {
     fprintf(stderr,
@@ -22,6 +35,53 @@ static int usage() {
 }
 
 static void put(const std::string &s) { fwrite(s.data(), 1, s.size(), stdout); }
+static void put(const std::vector<std::string> &chunks) {
+    for (const std::string &s : chunks) fwrite(s.data(), 1, s.size(), stdout);
+}
+
+// `rb synth-paf` / `rb synth-bed`: the bench workload of SURVEY.md 8(d) as text (not a reference subcommand).
+// Same counter-based generator as the device one (csrc/synth.h) and the same header rule as rustybam_amd/workload.py.
+static int synth_paf(uint64_t seed, uint64_t first, uint64_t n_rec, bool overlap_window) {
+    const uint64_t T_LEN = 248387497ull;
+    std::vector<char> obuf(1 << 22);
+    setvbuf(stdout, obuf.data(), _IOFBF, obuf.size());
+    std::string cg;
+    for (uint64_t r = first; r < first + n_rec; r++) {
+        const uint32_t n = rb_synth_n_ops_impl(seed, r, 1000, 9000);
+        uint64_t R = 0, Q = 0;
+        cg.clear();
+        char buf[24];
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t v = rb_synth_op(seed, r, j), op = v & 15u, len = v >> 4;
+            if (op != 1) R += len;
+            if (op != 2) Q += len;
+            const int k = snprintf(buf, sizeof buf, "%u%c", len, "MIDNSHP=X"[op]);
+            cg.append(buf, (size_t)k);
+        }
+        const uint64_t h1 = rb_splitmix64(seed ^ rb_splitmix64(r ^ 0x1111111111111111ull)), h2 = rb_splitmix64(h1), h3 = rb_splitmix64(h2);
+        uint64_t t_st;
+        if (!overlap_window) {
+            t_st = h1 % (T_LEN - (R < T_LEN ? R : T_LEN) + 1);
+        } else {
+            const uint64_t w0 = 12000000ull, w1 = 13000000ull, lo = R > w0 ? 0 : w0 - R + 1, hi = w1 - 1;
+            t_st = lo + h1 % (hi - lo + 1);
+        }
+        const char strand = (h2 & 1ull) == 0 ? '+' : '-';
+        const uint64_t q_st = h3 % 100001ull, q_en = q_st + Q;
+        printf("q%llu\t%llu\t%llu\t%llu\t%c\tchr1\t%llu\t%llu\t%llu\t0\t0\t60\ttp:A:P\tcg:Z:%s\n", (unsigned long long)r,
+               (unsigned long long)(q_en + 1000), (unsigned long long)q_st, (unsigned long long)q_en, strand, (unsigned long long)T_LEN,
+               (unsigned long long)t_st, (unsigned long long)(t_st + R), cg.c_str());
+    }
+    fflush(stdout);
+    return 0;
+}
+static int synth_bed(uint64_t n_win) {
+    for (uint64_t i = 0; i < n_win; i++) {
+        const uint64_t st = i * 82796ull, en = st + 100000ull < 248387497ull ? st + 100000ull : 248387497ull;
+        printf("chr1\t%llu\t%llu\n", (unsigned long long)st, (unsigned long long)en);
+    }
+    return 0;
+}
 
 int main(int argc, char **argv) {
     int a = 1, device = 0, policy = RB_BSEARCH_MODERN;
@@ -34,6 +94,12 @@ int main(int argc, char **argv) {
     }
     if (a >= argc) return usage();
     const std::string cmd = argv[a++];
+    if (cmd == "synth-paf" || cmd == "synth-bed") { // rb synth-paf <seed> <first_record> <n_records> [overlap] | rb synth-bed <n_windows>
+        if (cmd == "synth-bed") return synth_bed(a < argc ? strtoull(argv[a], nullptr, 0) : 3000);
+        if (a + 2 >= argc) return usage();
+        return synth_paf(strtoull(argv[a], nullptr, 0), strtoull(argv[a + 1], nullptr, 0), strtoull(argv[a + 2], nullptr, 0),
+                         a + 3 < argc && !strcmp(argv[a + 3], "overlap"));
+    }
     std::string paf_path = "-", bed_path;
     bool qbed = false, largest = false, remove_contained = false, is_paf = false;
     int ms = 1, ds = 1, is = 1;
@@ -54,7 +120,9 @@ int main(int argc, char **argv) {
         else paf_path = s;
     }
     try {
+        double tl = now_s();
         rb::Engine eng(device);
+        lap("device context", tl);
         eng.bsearch_policy = policy;
         std::vector<char> obuf(1 << 22);
         setvbuf(stdout, obuf.data(), _IOFBF, obuf.size());
@@ -68,13 +136,14 @@ int main(int argc, char **argv) {
             }
         } else if (cmd == "invert") {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-            for (const rb::PafRecord &r : rb::paf_swap_query_and_target(eng, paf.records)) put(r.to_string() + "\n");
+            put(rb::records_to_text(rb::paf_swap_query_and_target(eng, paf.records)));
         } else if (cmd == "liftover" || cmd == "lo") {
             if (bed_path.empty()) return usage();
             std::vector<rb::Region> rgns = rb::parse_bed(bed_path);
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-            std::vector<rb::PafRecord> out = rb::trim_paf_by_rgns(eng, rgns, paf.records, qbed);
+            lap("decode + check_integrity", tl);
             if (largest) { // main.rs:200-208: stable sort by id, keep the LAST record with maximal target span per id
+                std::vector<rb::PafRecord> out = rb::trim_paf_by_rgns(eng, rgns, paf.records, qbed);
                 std::stable_sort(out.begin(), out.end(), [](const rb::PafRecord &x, const rb::PafRecord &y) { return x.id < y.id; });
                 for (size_t i = 0; i < out.size();) {
                     size_t j = i, best = i;
@@ -84,15 +153,19 @@ int main(int argc, char **argv) {
                     i = j;
                 }
             } else {
-                for (const rb::PafRecord &r : out) put(r.to_string() + "\n");
+                const std::vector<std::string> text = rb::trim_paf_by_rgns_text(eng, rgns, paf.records, qbed);
+                lap("liftover (device + encode)", tl);
+                put(text);
+                fflush(stdout);
+                lap("write", tl);
             }
         } else if (cmd == "break-paf" || cmd == "breakpaf" || cmd == "bp") {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-            for (const rb::PafRecord &r : rb::break_paf_on_indels(eng, paf.records, max_size)) put(r.to_string() + "\n");
+            put(rb::break_paf_on_indels_text(eng, paf.records, max_size));
         } else if (trim) {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             paf.overlapping_paf_recs(eng, ms, ds, is, remove_contained);
-            for (const rb::PafRecord &r : paf.records) put(r.to_string() + "\n");
+            put(rb::records_to_text(paf.records));
         } else {
             return usage();
         }
