@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--early-exit", action="store_true", help="allow the kernel to stop a record early (off: full walk)")
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: skip kernel phases (invalid results)")
+    ap.add_argument("--op", default="liftover", choices=["liftover", "break"],
+                    help="liftover (headline) or break-paf --max-size 100 on the same records (secondary measurement)")
     ap.add_argument("--descriptors", action="store_true",
                     help="RB_LIFT_DESCRIPTORS: return which ops each clip keeps instead of copying them (not the headline mode)")
     return ap.parse_args()
@@ -113,6 +115,14 @@ def main():
         policy |= rustybam_amd.LIFT_DESCRIPTORS
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
     rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, total_ops // 4)
+
+    def run_op(ws, rows, out):
+        if args.op == "break":
+            eng.dev_break(plan, view, d_norm.data_ptr(), 100, policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(),
+                          out_cap, d_cnt.data_ptr())
+        else:
+            eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(),
+                             out_cap, d_cnt.data_ptr())
     if args.descriptors:
         rows_cap = max(rows_cap, 16 * n_rec)
         out_cap = 4 * rows_cap + total_ops // 8 + 65536
@@ -120,8 +130,7 @@ def main():
         d_ws = torch.empty(eng.plan_workspace_bytes(plan, rows_cap), dtype=torch.uint8, device=dev)
         d_rows = torch.empty((rows_cap + 1) * 64, dtype=torch.uint8, device=dev)
         d_out = torch.empty(out_cap + 64, dtype=torch.int32, device=dev)
-        eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, d_ws.data_ptr(), d_rows.data_ptr(), rows_cap,
-                         d_out.data_ptr(), out_cap, d_cnt.data_ptr())
+        run_op(d_ws, d_rows, d_out)
         torch.cuda.synchronize()
         cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
         if not cnt["overflow"]:
@@ -133,8 +142,7 @@ def main():
     n_hits = int(cnt["n_hits"])
 
     def step():
-        eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, d_ws.data_ptr(), d_rows.data_ptr(), rows_cap,
-                         d_out.data_ptr(), out_cap, d_cnt.data_ptr())
+        run_op(d_ws, d_rows, d_out)
 
     def barrier():
         if use_dist:
@@ -172,24 +180,29 @@ def main():
     n_ok = int((status == 0).sum().item())
     n_out_ops = int((out_n * (status == 0)).sum().item())
     algo_bytes = wl.algorithmic_bytes(total_ops, n_rec, n_hits, n_out_ops)
+    # (break-paf is priced with the same single-pass formula although this build walks the ops three times:
+    #  count pieces, fill pieces, clip; its rate is taken over the whole step, not one kernel)
     if args.descriptors:  # nothing is copied: 4 B/op + 48 B/record + (88 + 16) B per hit
         algo_bytes = wl.algorithmic_bytes(total_ops, n_rec, n_hits, 0) + 16 * n_hits
     k_ms = float(np.mean(kern_ms[-args.steps:])) if kern_ms else float("nan")
+    if args.op == "break":
+        k_ms = elapsed / args.steps * 1e3
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     traffic = None  # HBM-side bytes per launch from the committed PMC run of this same workload (bench.py is not run under --pmc)
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r01.json")))
-        if tj["workload"] == {"records_per_gpu": n_rec, "windows": int(len(w_st)), "workload": args.workload} and not args.descriptors:
+        if tj["workload"] == {"records_per_gpu": n_rec, "windows": int(len(w_st)), "workload": args.workload} and not args.descriptors and args.op == "liftover":
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "rb_k_liftover_stream", "achieved": round(achieved, 1), "peak": 8000.0,
+    roofline = {"bound": "hbm", "kernel": "rb_k_liftover_stream" if args.op == "liftover" else "rb_dev_break (rb_k_break_pieces x2 + rb_k_liftover_stream)", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)}
 
     result = {
-        "metric": "CIGAR-ops/s, liftover over 100 kb sliding windows (whole pass, inputs resident in HBM)",
+        "metric": ("CIGAR-ops/s, liftover over 100 kb sliding windows (whole pass, inputs resident in HBM)" if args.op == "liftover"
+                   else "CIGAR-ops/s, break-paf --max-size 100 (whole pass, inputs resident in HBM)"),
         "value": job_ops * args.steps / elapsed,
         "unit": "CIGAR-ops/s",
         "n_gpus": world,
@@ -213,7 +226,7 @@ def main():
     }
 
     # ---- CPU baseline + sample parity (rank 0, N = 1 only) ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.descriptors:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.descriptors and args.op == "liftover":
         from oracle import pyoracle  # checker / baseline only; never on the product path
         from rustybam_amd import capi
         threads = os.cpu_count() or 1
