@@ -1197,6 +1197,187 @@ int rbo_overlapping_paf_recs(rbo_paf *paf, int ms, int ds, int is, int remove_co
     return -RBO_PANIC_ASSERT;
 }
 
+/* ------------------------------------------------------------------ header-only commands (paf.rs:91-207) */
+typedef struct {
+    const char *t, *q;
+    int64_t orient;
+    uint64_t total_bp, order, aln_bp;
+} tq_entry;
+static tq_entry *tq_find(tq_entry **tab, size_t *n, size_t *cap, const char *t, const char *q) {
+    for (size_t i = 0; i < *n; i++)
+        if (strcmp((*tab)[i].t, t) == 0 && strcmp((*tab)[i].q, q) == 0) return &(*tab)[i];
+    if (*n == *cap) {
+        *cap = *cap ? *cap * 2 : 64;
+        *tab = (tq_entry *)xrealloc(*tab, *cap * sizeof(tq_entry));
+    }
+    tq_entry *e = &(*tab)[(*n)++];
+    memset(e, 0, sizeof(*e));
+    e->t = t;
+    e->q = q;
+    return e;
+}
+/* paf.rs:91-111 in the order main.rs:242-244 applies them */
+void rbo_paf_filter(rbo_paf *paf, uint64_t paired_len, uint64_t min_aln, uint64_t min_query) {
+    size_t w = 0;
+    for (size_t i = 0; i < paf->n; i++) { /* filter_query_len */
+        if (paf->recs[i].q_len > min_query) paf->recs[w++] = paf->recs[i];
+        else rbo_rec_free(&paf->recs[i]);
+    }
+    paf->n = w;
+    w = 0;
+    for (size_t i = 0; i < paf->n; i++) { /* filter_aln_len */
+        if (paf->recs[i].t_en - paf->recs[i].t_st > min_aln) paf->recs[w++] = paf->recs[i];
+        else rbo_rec_free(&paf->recs[i]);
+    }
+    paf->n = w;
+    tq_entry *tab = NULL;
+    size_t n = 0, cap = 0;
+    for (size_t i = 0; i < paf->n; i++) /* filter_aln_pairs */
+        tq_find(&tab, &n, &cap, paf->recs[i].t_name, paf->recs[i].q_name)->aln_bp += paf->recs[i].t_en - paf->recs[i].t_st;
+    uint8_t *keep = (uint8_t *)xmalloc(paf->n + 1);
+    for (size_t i = 0; i < paf->n; i++) keep[i] = paired_len < tq_find(&tab, &n, &cap, paf->recs[i].t_name, paf->recs[i].q_name)->aln_bp;
+    free(tab);
+    w = 0;
+    for (size_t i = 0; i < paf->n; i++) {
+        if (keep[i]) paf->recs[w++] = paf->recs[i];
+        else rbo_rec_free(&paf->recs[i]);
+    }
+    paf->n = w;
+    free(keep);
+}
+/* paf.rs:114-157; `order` of every record is returned through orders[] for scaffold */
+int rbo_paf_orient(rbo_paf *paf, uint64_t *orders) {
+    tq_entry *tab = NULL;
+    size_t n = 0, cap = 0;
+    for (size_t i = 0; i < paf->n; i++) {
+        rbo_rec *r = &paf->recs[i];
+        tq_entry *e = tq_find(&tab, &n, &cap, r->t_name, r->q_name);
+        if (r->strand == '-') e->orient -= (int64_t)(r->q_en - r->q_st); else e->orient += (int64_t)(r->q_en - r->q_st);
+        uint64_t weight = r->t_en - r->t_st;
+        e->total_bp += weight;
+        e->order += weight * (r->t_st + r->t_en) / 2;
+    }
+    /* the table keys point into the records' own strings, which the second loop replaces: resolve all lookups first */
+    tq_entry **ent = (tq_entry **)xmalloc((paf->n + 1) * sizeof(tq_entry *));
+    for (size_t i = 0; i < paf->n; i++) ent[i] = tq_find(&tab, &n, &cap, paf->recs[i].t_name, paf->recs[i].q_name);
+    int rc = 0;
+    for (size_t i = 0; i < paf->n && rc == 0; i++) {
+        rbo_rec *r = &paf->recs[i];
+        tq_entry *e = ent[i];
+        if (e->total_bp == 0) { /* attempt to divide by zero */
+            rc = -RBO_PANIC_ASSERT;
+            break;
+        }
+        if (orders) orders[i] = e->order / e->total_bp;
+        size_t L = strlen(r->q_name);
+        char *nn = (char *)xmalloc(L + 2);
+        memcpy(nn, r->q_name, L);
+        nn[L + 1] = 0;
+        if (e->orient < 0) {
+            nn[L] = '-';
+            uint64_t ns = r->q_len - r->q_en, ne = r->q_len - r->q_st;
+            r->q_st = ns;
+            r->q_en = ne;
+            r->strand = r->strand == '+' ? '-' : '+';
+        } else {
+            nn[L] = '+';
+        }
+        /* keep the old name alive until every lookup that points at it is done (they all are: ent[] is resolved) */
+        char *old = r->q_name;
+        r->q_name = nn;
+        for (size_t k = 0; k < n; k++)
+            if (tab[k].q == old) tab[k].q = "";
+        free(old);
+    }
+    free(ent);
+    free(tab);
+    return rc;
+}
+/* paf.rs:160-207 */
+typedef struct {
+    const rbo_rec *recs;
+    const uint64_t *orders;
+} scaf_ctx;
+static int cmp_scaf(const void *ctx, size_t a, size_t b) {
+    const scaf_ctx *c = (const scaf_ctx *)ctx;
+    int t = strcmp(c->recs[a].t_name, c->recs[b].t_name);
+    if (t) return t;
+    if (c->orders[a] != c->orders[b]) return c->orders[a] < c->orders[b] ? -1 : 1;
+    if (c->recs[a].q_st != c->recs[b].q_st) return c->recs[a].q_st < c->recs[b].q_st ? -1 : 1;
+    return 0;
+}
+void rbo_paf_scaffold(rbo_paf *paf, uint64_t *orders, uint64_t spacer) {
+    size_t n = paf->n;
+    size_t *ix = (size_t *)xmalloc((n + 1) * sizeof(size_t)), *tmp = (size_t *)xmalloc((n + 1) * sizeof(size_t));
+    for (size_t i = 0; i < n; i++) ix[i] = i;
+    scaf_ctx c = {paf->recs, orders};
+    msort(ix, tmp, n, cmp_scaf, &c);
+    rbo_rec *nr = (rbo_rec *)xmalloc((paf->cap ? paf->cap : 1) * sizeof(rbo_rec));
+    uint64_t *no = (uint64_t *)xmalloc((n + 1) * sizeof(uint64_t));
+    for (size_t i = 0; i < n; i++) {
+        nr[i] = paf->recs[ix[i]];
+        no[i] = orders[ix[i]];
+    }
+    free(paf->recs);
+    paf->recs = nr;
+    memcpy(orders, no, n * sizeof(uint64_t));
+    free(no);
+    free(ix);
+    free(tmp);
+    for (size_t g0 = 0; g0 < n;) { /* group_by t_name (consecutive) */
+        size_t g1 = g0;
+        while (g1 < n && strcmp(paf->recs[g1].t_name, paf->recs[g0].t_name) == 0) g1++;
+        /* (already sorted by order, q_st inside the group; the second sort at :173-177 is a no-op) */
+        size_t cap = 64, len = 0;
+        char *name = (char *)xmalloc(cap);
+        name[0] = 0;
+        for (size_t i = g0; i < g1; i++) { /* unique q_names in order of first appearance, joined by "::" */
+            int seen = 0;
+            for (size_t k = g0; k < i; k++)
+                if (strcmp(paf->recs[k].q_name, paf->recs[i].q_name) == 0) {
+                    seen = 1;
+                    break;
+                }
+            if (seen) continue;
+            size_t L = strlen(paf->recs[i].q_name);
+            while (len + L + 3 > cap) {
+                cap *= 2;
+                name = (char *)xrealloc(name, cap);
+            }
+            if (len) {
+                memcpy(name + len, "::", 2);
+                len += 2;
+            }
+            memcpy(name + len, paf->recs[i].q_name, L + 1);
+            len += L;
+        }
+        uint64_t scaffold_len = 0;
+        for (size_t q0 = g0; q0 < g1;) { /* group_by q_name (consecutive) */
+            size_t q1 = q0;
+            while (q1 < g1 && strcmp(paf->recs[q1].q_name, paf->recs[q0].q_name) == 0) q1++;
+            uint64_t q_min = UINT64_MAX, q_max = 0;
+            for (size_t i = q0; i < q1; i++) {
+                if (paf->recs[i].q_st < q_min) q_min = paf->recs[i].q_st;
+                if (paf->recs[i].q_en > q_max) q_max = paf->recs[i].q_en;
+            }
+            for (size_t i = q0; i < q1; i++) {
+                paf->recs[i].q_st = paf->recs[i].q_st - q_min + scaffold_len;
+                paf->recs[i].q_en = paf->recs[i].q_en - q_min + scaffold_len;
+            }
+            scaffold_len += (q_max - q_min) + spacer;
+            q0 = q1;
+        }
+        scaffold_len -= spacer;
+        for (size_t i = g0; i < g1; i++) {
+            free(paf->recs[i].q_name);
+            paf->recs[i].q_name = xstrdup(name);
+            paf->recs[i].q_len = scaffold_len;
+        }
+        free(name);
+        g0 = g1;
+    }
+}
+
 /* ------------------------------------------------------------------ bamstats.rs:107-154 (md = None) */
 void rbo_stats_from_cigar(const uint32_t *ops, size_t n, rbo_stats *s) {
     memset(s, 0, sizeof(*s));

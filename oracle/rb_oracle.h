@@ -137,6 +137,11 @@ int rbo_trim_overlapping_pafs(rbo_rec *left, rbo_rec *right, int match_score, in
 int rbo_overlapping_paf_recs(rbo_paf *paf, int match_score, int diff_score, int indel_score,
                              int remove_contained, int policy);
 
+/* --- header-only commands that bracket the hot path in pipelines (paf.rs:91-207) --- */
+void rbo_paf_filter(rbo_paf *paf, uint64_t paired_len, uint64_t min_aln, uint64_t min_query);
+int rbo_paf_orient(rbo_paf *paf, uint64_t *orders);
+void rbo_paf_scaffold(rbo_paf *paf, uint64_t *orders, uint64_t spacer);
+
 /* --- invert (paf.rs:1050-1094) --- */
 void rbo_paf_swap_query_and_target(const rbo_rec *in, rbo_rec *out);
 

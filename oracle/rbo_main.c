@@ -39,16 +39,23 @@ int main(int argc, char **argv) {
     const char *cmd = argv[a++];
     const char *paf_path = NULL, *bed_path = NULL;
     int qbed = 0, largest = 0, remove_contained = 0, is_paf = 0;
-    int ms = 1, ds = 1, is = 1;
+    int ms = 1, ds = 1, is = 1, scaffold = 0;
     uint32_t max_size = 100;
+    uint64_t paired_len = 0, min_aln = 0, min_query = 0, insert = 1000000;
     for (; a < argc; a++) {
-        if (!strcmp(argv[a], "--paf") || !strcmp(argv[a], "-p")) { is_paf = 1; continue; }
-        else if (!strcmp(argv[a], "--qbed") || !strcmp(argv[a], "-q")) qbed = 1;
+        const int is_filter = !strcmp(cmd, "filter");
+        if (!strcmp(argv[a], "--paf") || (!strcmp(argv[a], "-p") && !is_filter)) { is_paf = 1; continue; }
+        else if (!strcmp(argv[a], "--qbed") || (!strcmp(argv[a], "-q") && !is_filter)) qbed = 1;
         else if (!strcmp(argv[a], "--largest") || !strcmp(argv[a], "-l")) largest = 1;
         else if (!strcmp(argv[a], "--remove-contained") || !strcmp(argv[a], "-r")) remove_contained = 1;
         else if ((!strcmp(argv[a], "--bed") || !strcmp(argv[a], "-b")) && a + 1 < argc) bed_path = argv[++a];
         else if ((!strcmp(argv[a], "--max-size") || !strcmp(argv[a], "-m")) && a + 1 < argc) max_size = (uint32_t)strtoul(argv[++a], NULL, 10);
         else if (!strcmp(argv[a], "--match-score") && a + 1 < argc) ms = atoi(argv[++a]);
+        else if ((!strcmp(argv[a], "--paired-len") || (!strcmp(argv[a], "-p") && !strcmp(cmd, "filter"))) && a + 1 < argc) paired_len = strtoull(argv[++a], NULL, 10);
+        else if ((!strcmp(argv[a], "--aln") || !strcmp(argv[a], "-a")) && a + 1 < argc) min_aln = strtoull(argv[++a], NULL, 10);
+        else if ((!strcmp(argv[a], "--query") || (!strcmp(argv[a], "-q") && !strcmp(cmd, "filter"))) && a + 1 < argc) min_query = strtoull(argv[++a], NULL, 10);
+        else if ((!strcmp(argv[a], "--insert") || !strcmp(argv[a], "-i")) && a + 1 < argc && !strcmp(cmd, "orient")) insert = strtoull(argv[++a], NULL, 10);
+        else if ((!strcmp(argv[a], "--scaffold") || !strcmp(argv[a], "-s")) && !strcmp(cmd, "orient")) scaffold = 1;
         else if (!strcmp(argv[a], "--diff-score") && a + 1 < argc) ds = atoi(argv[++a]);
         else if (!strcmp(argv[a], "--indel-score") && a + 1 < argc) is = atoi(argv[++a]);
         else paf_path = argv[a];
@@ -119,6 +126,15 @@ int main(int argc, char **argv) {
             rbo_paf_free(&out);
             rbo_rec_drop_aln(&paf.recs[i]);
         }
+    } else if (!strcmp(cmd, "filter")) { /* main.rs:234-249 */
+        rbo_paf_filter(&paf, paired_len, min_aln, min_query);
+        for (size_t i = 0; i < paf.n; i++) rbo_rec_print(&paf.recs[i], stdout);
+    } else if (!strcmp(cmd, "orient")) { /* main.rs:253-267 */
+        uint64_t *orders = (uint64_t *)malloc((paf.n + 1) * sizeof(uint64_t));
+        if (rbo_paf_orient(&paf, orders)) return 101;
+        if (scaffold) rbo_paf_scaffold(&paf, orders, insert);
+        for (size_t i = 0; i < paf.n; i++) rbo_rec_print(&paf.recs[i], stdout);
+        free(orders);
     } else if (!strcmp(cmd, "trim-paf")) {
         rc = rbo_overlapping_paf_recs(&paf, ms, ds, is, remove_contained, policy);
         if (rc) return 101;

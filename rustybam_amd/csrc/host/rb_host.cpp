@@ -886,4 +886,104 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
     throw Panic("trim-paf did not converge");
 }
 
+
+// ---------------------------------------------------------------- header-only commands (paf.rs:91-207)
+namespace {
+struct TqKey {
+    std::string t, q;
+    bool operator==(const TqKey &o) const { return t == o.t && q == o.q; }
+};
+struct TqHash {
+    size_t operator()(const TqKey &k) const { return std::hash<std::string>()(k.t) * 1000003u ^ std::hash<std::string>()(k.q); }
+};
+} // namespace
+
+void Paf::filter_aln_pairs(uint64_t paired_len) {
+    std::unordered_map<TqKey, uint64_t, TqHash> dict;
+    for (const PafRecord &rec : records) dict[TqKey{rec.t_name, rec.q_name}] += rec.t_en - rec.t_st;
+    records.erase(std::remove_if(records.begin(), records.end(),
+                                 [&](const PafRecord &rec) { return !(paired_len < dict[TqKey{rec.t_name, rec.q_name}]); }),
+                  records.end());
+}
+void Paf::filter_query_len(uint64_t min_query_len) {
+    records.erase(std::remove_if(records.begin(), records.end(), [&](const PafRecord &rec) { return !(rec.q_len > min_query_len); }), records.end());
+}
+void Paf::filter_aln_len(uint64_t min_aln_len) {
+    records.erase(std::remove_if(records.begin(), records.end(), [&](const PafRecord &rec) { return !(rec.t_en - rec.t_st > min_aln_len); }),
+                  records.end());
+}
+void Paf::orient() {
+    struct Acc {
+        int64_t orient = 0;
+        uint64_t total_bp = 0, order = 0;
+    };
+    std::unordered_map<TqKey, Acc, TqHash> dict;
+    for (const PafRecord &rec : records) {
+        Acc &a = dict[TqKey{rec.t_name, rec.q_name}];
+        if (rec.strand == '-') a.orient -= (int64_t)(rec.q_en - rec.q_st);
+        else a.orient += (int64_t)(rec.q_en - rec.q_st);
+        const uint64_t weight = rec.t_en - rec.t_st;
+        a.total_bp += weight;
+        a.order += weight * (rec.t_st + rec.t_en) / 2;
+    }
+    for (PafRecord &rec : records) {
+        const Acc &a = dict[TqKey{rec.t_name, rec.q_name}];
+        if (a.total_bp == 0) throw Panic("attempt to divide by zero");
+        rec.order = a.order / a.total_bp;
+        if (a.orient < 0) {
+            rec.q_name += "-";
+            const uint64_t new_st = rec.q_len - rec.q_en, new_en = rec.q_len - rec.q_st;
+            rec.q_st = new_st;
+            rec.q_en = new_en;
+            rec.strand = rec.strand == '+' ? '-' : '+';
+        } else {
+            rec.q_name += "+";
+        }
+    }
+}
+void Paf::scaffold(uint64_t spacer_size) {
+    std::stable_sort(records.begin(), records.end(), [](const PafRecord &a, const PafRecord &b) {
+        const int t = a.t_name.compare(b.t_name);
+        if (t) return t < 0;
+        if (a.order != b.order) return a.order < b.order;
+        return a.q_st < b.q_st;
+    });
+    for (size_t g0 = 0; g0 < records.size();) {
+        size_t g1 = g0;
+        while (g1 < records.size() && records[g1].t_name == records[g0].t_name) g1++;
+        // within one target the records are already in (order, q_st) order, so the reference's second sort (:173-177) keeps them
+        std::string scaffold_name;
+        {
+            std::unordered_map<std::string, char> seen;
+            for (size_t i = g0; i < g1; i++)
+                if (seen.emplace(records[i].q_name, 1).second) {
+                    if (!scaffold_name.empty()) scaffold_name += "::";
+                    scaffold_name += records[i].q_name;
+                }
+        }
+        uint64_t scaffold_len = 0;
+        for (size_t q0 = g0; q0 < g1;) {
+            size_t q1 = q0;
+            uint64_t q_min = UINT64_MAX, q_max = 0;
+            while (q1 < g1 && records[q1].q_name == records[q0].q_name) {
+                q_min = std::min(q_min, records[q1].q_st);
+                q_max = std::max(q_max, records[q1].q_en);
+                q1++;
+            }
+            for (size_t i = q0; i < q1; i++) {
+                records[i].q_st = records[i].q_st - q_min + scaffold_len;
+                records[i].q_en = records[i].q_en - q_min + scaffold_len;
+            }
+            scaffold_len += (q_max - q_min) + spacer_size;
+            q0 = q1;
+        }
+        scaffold_len -= spacer_size;
+        for (size_t i = g0; i < g1; i++) {
+            records[i].q_name = scaffold_name;
+            records[i].q_len = scaffold_len;
+        }
+        g0 = g1;
+    }
+}
+
 } // namespace rb

@@ -25,6 +25,7 @@ struct PafRecord {
     uint64_t t_len = 0, t_st = 0, t_en = 0, nmatch = 0, aln_len = 0, mapq = 0;
     std::vector<uint32_t> cigar;
     std::string id;
+    uint64_t order = 0;            // set by Paf::orient (paf.rs:143)
     std::string to_string() const; // impl Display (paf.rs:923-944)
 };
 
@@ -62,6 +63,12 @@ struct Paf { // paf::Paf (paf.rs:34-37)
     static Paf from_file(Engine &eng, const std::string &file_name);
     // Paf::overlapping_paf_recs (paf.rs:210-305)
     void overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int indel_score, bool remove_contained);
+    // header-only commands that sit between the CIGAR-walk stages of a pipeline (no device work: they never touch a CIGAR)
+    void filter_aln_pairs(uint64_t paired_len);  // paf.rs:91-102
+    void filter_query_len(uint64_t min_query_len); // paf.rs:104-106
+    void filter_aln_len(uint64_t min_aln_len);   // paf.rs:109-111
+    void orient();                               // paf.rs:114-157 (panics on a zero-bp (target, query) pair: divide by zero)
+    void scaffold(uint64_t spacer_size);         // paf.rs:160-207
 };
 
 std::string cigar_to_string(const std::vector<uint32_t> &cigar);

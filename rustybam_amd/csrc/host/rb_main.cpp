@@ -1,5 +1,6 @@
 // rb_main.cpp -- `rb`-compatible front end for the hot-path subcommands (dispatcher arms main.rs:50-58 stats --paf,
-// :176-182 invert, :186-214 liftover, :218-230 trim-paf, :271-281 break-paf) over the MI355X engine.
+// :176-182 invert, :186-214 liftover, :218-230 trim-paf, :271-281 break-paf) over the MI355X engine, plus the two
+// header-only commands that sit between them in the reference's pipelines (:234-249 filter, :253-267 orient).
 // Same flag names and defaults as src/cli.rs; exits with 101 where the reference panics.
 #include <algorithm>
 #include <cstdio>
@@ -30,6 +31,8 @@ static int usage() {
             "  break-paf [-m|--max-size 100] [PAF]\n"
             "  trim-paf [-m|--match-score 1] [-d|--diff-score 1] [-i|--indel-score 1] [-r|--remove-contained] [PAF]\n"
             "  invert [PAF]\n"
+            "  orient [-s|--scaffold] [-i|--insert 1000000] [PAF]\n"
+            "  filter [-p|--paired-len 0] [-a|--aln 0] [-q|--query 0] [PAF]\n"
             "Every other rustybam subcommand is outside this engine's scope.\n");
     return 2;
 }
@@ -104,11 +107,19 @@ int main(int argc, char **argv) {
     bool qbed = false, largest = false, remove_contained = false, is_paf = false;
     int ms = 1, ds = 1, is = 1;
     uint32_t max_size = 100;
+    uint64_t paired_len = 0, min_aln = 0, min_query = 0, insert = 1000000;
+    bool do_scaffold = false;
     const bool trim = cmd == "trim-paf" || cmd == "trim" || cmd == "tp";
+    const bool filter = cmd == "filter", orient = cmd == "orient";
     for (; a < argc; a++) {
         const std::string s = argv[a];
         auto next = [&]() -> const char * { return a + 1 < argc ? argv[++a] : ""; };
-        if (s == "-p" || s == "--paf") is_paf = true;
+        if (s == "--paired-len" || (s == "-p" && filter)) paired_len = strtoull(next(), nullptr, 10);
+        else if (s == "--query" || (s == "-q" && filter)) min_query = strtoull(next(), nullptr, 10);
+        else if (s == "--aln" || (s == "-a" && filter)) min_aln = strtoull(next(), nullptr, 10);
+        else if (s == "--insert" || (s == "-i" && orient)) insert = strtoull(next(), nullptr, 10);
+        else if (s == "--scaffold" || (s == "-s" && orient)) do_scaffold = true;
+        else if (s == "-p" || s == "--paf") is_paf = true;
         else if (s == "-q" || s == "--qbed") qbed = true;
         else if (s == "-l" || s == "--largest") largest = true;
         else if (s == "-r" || s == "--remove-contained") remove_contained = true;
@@ -162,6 +173,17 @@ int main(int argc, char **argv) {
         } else if (cmd == "break-paf" || cmd == "breakpaf" || cmd == "bp") {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             put(rb::break_paf_on_indels_text(eng, paf.records, max_size));
+        } else if (filter) { // main.rs:234-249
+            rb::Paf paf = rb::Paf::from_file(eng, paf_path);
+            paf.filter_query_len(min_query);
+            paf.filter_aln_len(min_aln);
+            paf.filter_aln_pairs(paired_len);
+            put(rb::records_to_text(paf.records));
+        } else if (orient) { // main.rs:253-267
+            rb::Paf paf = rb::Paf::from_file(eng, paf_path);
+            paf.orient();
+            if (do_scaffold) paf.scaffold(insert);
+            put(rb::records_to_text(paf.records));
         } else if (trim) {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             paf.overlapping_paf_recs(eng, ms, ds, is, remove_contained);

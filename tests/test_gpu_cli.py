@@ -56,6 +56,11 @@ def test_tiled_windows_and_gz_input(dig, golden, tmp_path):
     ["trim-paf", "--match-score", "2", "--diff-score", "3", "--indel-score", "5", "{paf}"],
     ["break-paf", "--max-size", "0", "{paf}"],
     ["stats", "--qbed", "--paf", "{paf}"],
+    ["orient", "{paf}"],
+    ["orient", "--scaffold", "{paf}"],
+    ["orient", "-s", "-i", "500", "{paf}"],
+    ["filter", "--paired-len", "100000", "{paf}"],
+    ["filter", "-a", "20000", "-q", "60000000", "-p", "50000", "{paf}"],
 ])
 def test_matches_oracle_cli(oracle, golden, args):
     a = [x.format(paf=f"{golden}/asm_small.paf", bed=f"{golden}/asm_small.bed", trimbed=f"{golden}/trim_asm_small.bed") for x in args]
@@ -156,3 +161,30 @@ def test_stats_bam_md_tag_cg_tag_and_panics(oracle, tmp_path):
     bad2 = tmp_path / "bad2.bam"
     _write_bam(bad2, refs, [dict(name="starts_with_D", ref=0, pos=10, flag=0, l_seq=10, cigar=[(5, "D"), (10, "=")])])
     assert rb("stats", bad2)[0] == 101 and oracle.cli("stats", bad2)[0] == 101
+
+
+def test_readme_pipeline(oracle, golden, tmp_path):
+    """The reference README's showcase chain (trim-paf | break-paf | orient | liftover | filter | stats), every stage through
+    `rb`, against the same chain through the oracle CLI; each intermediate file must be byte-identical too."""
+    bed = tmp_path / "rgn.bed"
+    bed.write_text("chr22\t12000000\t13000000\n")
+    stages = [
+        ["trim-paf", "{inp}"],
+        ["break-paf", "--max-size", "100", "{inp}"],
+        ["orient", "{inp}"],
+        ["liftover", "--bed", str(bed), "{inp}"],
+        ["filter", "--paired-len", "10000", "{inp}"],
+        ["stats", "--paf", "{inp}"],
+    ]
+    inp = f"{golden}/asm_small.paf"
+    for i, st in enumerate(stages):
+        a = [x.format(inp=inp) for x in st]
+        rc, out = rb(*a)
+        orc, oout = oracle.cli(*a)
+        assert (rc, orc) == (0, 0), st
+        assert out == oout, st
+        assert out.count(b"\n") > 0, st
+        nxt = tmp_path / f"stage{i}.paf"
+        nxt.write_bytes(out)
+        inp = str(nxt)
+    assert hashlib.md5(out).hexdigest() == "c4e325dd79f7e580f63a388e1636ca97"

@@ -197,3 +197,31 @@ def test_bam_stats_oracle(oracle, golden):
     for key, f in (("stats_bam_asm_small", "asm_small.bam"), ("stats_bam_test", "test.bam"), ("stats_bam_stats", "stats.bam")):
         rc, out = oracle.cli("stats", f"{golden}/{f}")
         assert rc == 0 and hashlib.md5(out).hexdigest() == dig[key]["md5"] and out.count(b"\n") == dig[key]["lines"]
+
+
+def test_ka13_orient_scaffold_filter(oracle, tmp_path):
+    """Hand-derived from paf.rs:91-207.  (T,A): orient = +10 - 30 < 0 -> "A-", query coordinates flipped against q_len 100,
+    strands swapped; order = (10*10/2 + 30*230/2) / 40 = 87 for both A records, (T,B): 502.  Scaffold: sort by (order, q_st)
+    puts the flipped 50..80 record first; A- spans 50..100 -> 0..30 and 40..50, spacer 7, B+ 0..5 -> 57..62, length 62.
+    filter --paired-len 5: (T,A) sums 40 > 5 kept, (T,B) sums 5, 5 < 5 false -> dropped."""
+    p = tmp_path / "o.paf"
+    p.write_text("A\t100\t0\t10\t+\tT\t1000\t0\t10\t10\t10\t60\tcg:Z:10=\n"
+                 "A\t100\t20\t50\t-\tT\t1000\t100\t130\t30\t30\t60\tcg:Z:30=\n"
+                 "B\t100\t0\t5\t+\tT\t1000\t500\t505\t5\t5\t60\tcg:Z:5=\n")
+
+    def cols(out):
+        return [ln.split("\t")[:9] for ln in out.decode().splitlines()]
+    rc, out = oracle.cli("orient", p)
+    assert rc == 0 and cols(out) == [
+        ["A-", "100", "90", "100", "-", "T", "1000", "0", "10"],
+        ["A-", "100", "50", "80", "+", "T", "1000", "100", "130"],
+        ["B+", "100", "0", "5", "+", "T", "1000", "500", "505"]]
+    rc, out = oracle.cli("orient", "--scaffold", "--insert", "7", p)
+    assert rc == 0 and cols(out) == [
+        ["A-::B+", "62", "0", "30", "+", "T", "1000", "100", "130"],
+        ["A-::B+", "62", "40", "50", "-", "T", "1000", "0", "10"],
+        ["A-::B+", "62", "57", "62", "+", "T", "1000", "500", "505"]]
+    rc, out = oracle.cli("filter", "--paired-len", "5", p)
+    assert rc == 0 and [c[0] for c in cols(out)] == ["A", "A"]
+    rc, out = oracle.cli("filter", "--aln", "9", "--query", "99", p)
+    assert rc == 0 and [c[2] for c in cols(out)] == ["0", "20"]
