@@ -185,6 +185,9 @@ def main():
     if args.descriptors:  # nothing is copied: 4 B/op + 48 B/record + (88 + 16) B per hit
         algo_bytes = wl.algorithmic_bytes(total_ops, n_rec, n_hits, 0) + 16 * n_hits
     k_ms = float(np.mean(kern_ms[-args.steps:])) if kern_ms else float("nan")
+    if kern_ms and os.environ.get("RB_BENCH_VERBOSE"):  # experiments: the spread of the per-step clip-kernel times
+        ks = np.sort(np.asarray(kern_ms[-args.steps:]))
+        print(f"[kernel ms] min {ks[0]:.3f}  median {ks[len(ks) // 2]:.3f}  mean {ks.mean():.3f}  max {ks[-1]:.3f}", file=sys.stderr)
     if args.op == "break":
         k_ms = elapsed / args.steps * 1e3
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9

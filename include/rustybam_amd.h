@@ -206,7 +206,8 @@ int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_off_host, con
                    uint64_t n_win, const uint32_t *w_contig_host, const uint64_t *w_st_host, const uint64_t *w_en_host,
                    rb_plan **out);
 void rb_plan_destroy(rb_plan *plan);
-/* bytes of device workspace rb_dev_liftover / rb_dev_break need for this plan and row capacity */
+/* bytes of device workspace rb_dev_liftover / rb_dev_break need for this plan and row capacity (the workspace must be
+ * 256-byte aligned, as rb_dev_alloc returns it) */
 size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap);
 
 /* ---- liftover --------------------------------------------------------------------------------- *

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/rustybam_amd.h"
+#include "rb_lift.h" // rb_lift_params (the device helpers in it are unused here)
 
 // ---- kernel-side parameter blocks (must match the .hip files) ----------------------------------
 struct rb_scan_params {
@@ -25,39 +26,6 @@ struct rb_scan_params {
     const uint8_t *strand;
     rb_reduce_row *reduce_rows;
     rb_norm_row *norm_rows;
-};
-struct rb_lift_params {
-    uint64_t n_rec;
-    const uint32_t *ops;
-    const uint64_t *op_off;
-    const uint32_t *contig;
-    const uint8_t *strand;
-    const rb_norm_row *norm;
-    const uint32_t *sched;
-    const uint32_t *canon_pos;
-    const uint64_t *w_st, *w_en;
-    const uint32_t *w_orig;
-    const uint64_t *wo_st, *wo_en;
-    const uint64_t *cw_off;
-    const uint8_t *cw_mono;
-    uint32_t n_contig;
-    const uint64_t *x_st, *x_en;
-    uint64_t *hit_off;
-    uint32_t *win_lo;
-    rb_hit_row *rows;
-    uint64_t rows_cap;
-    uint32_t *out_ops;
-    uint64_t out_cap;
-    unsigned long long *arena_cur;
-    uint64_t arena_size;
-    uint32_t n_arena;
-    uint32_t *gen_list;
-    rb_counters *counters;
-    int policy;
-    int early_exit;
-    int desc_mode;
-    uint64_t arena_origin;
-    int debug_skip;
 };
 struct rb_break_params {
     uint64_t n_rec;
@@ -94,6 +62,7 @@ struct rb_swap_params {
 
 extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream);
+extern "C" hipError_t rb_launch_make_jobs(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream);
 extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec);
@@ -102,7 +71,6 @@ extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops, hipStream_t stream);
 
-#define RB_ARENA_STRIDE 16
 #define RB_MAX_ARENA 256
 
 #define RB_TIMING_RING 256
@@ -362,9 +330,9 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
     delete pl;
 }
 
-// workspace layout: [hit_off (n_rec+1) u64][block sums][arena cursors][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
+// workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, gen_list, x_st, x_en, total;
+    size_t hit_off, win_lo, block_sums, arena, jobs, gen_list, x_st, x_en, total;
 };
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     ws_layout w;
@@ -378,6 +346,7 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     w.win_lo = take((n_rec + 2) * 4);
     w.block_sums = take(rb_scan_block_sums_count(n_rec) * 8);
     w.arena = take((size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8);
+    w.jobs = take((n_rec + 1) * sizeof(rb_job));
     w.gen_list = take((rows_cap + 1) * 4);
     w.x_st = take((rows_cap + 1) * 8);
     w.x_en = take((rows_cap + 1) * 8);
@@ -403,6 +372,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     if (b->n_rec != plan->n_rec) return fail(ctx, RB_E_INVALID, "plan was built for %llu records, batch has %llu", (unsigned long long)plan->n_rec, (unsigned long long)b->n_rec);
     if (((uintptr_t)b->ops & 15u) || ((uintptr_t)out_ops & 15u)) return fail(ctx, RB_E_INVALID, "ops/out_ops must be 16-byte aligned");
     if (rows_cap >= 0xFFFFFFFFull) return fail(ctx, RB_E_INVALID, "rows_cap too large");
+    if ((uintptr_t)workspace & 255u) return fail(ctx, RB_E_INVALID, "workspace must be 256-byte aligned");
     const ws_layout w = ws_of(plan->n_rec, rows_cap);
     char *ws = (char *)workspace;
     rb_lift_params p;
@@ -436,10 +406,11 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     if (p.desc_mode && out_cap < p.arena_origin + 1024) return fail(ctx, RB_E_CAPACITY, "descriptor mode needs out_cap >= 4 * rows_cap + 1024");
     p.arena_size = ((out_cap - p.arena_origin) / p.n_arena) & ~(uint64_t)3;
     p.gen_list = (uint32_t *)(ws + w.gen_list);
+    p.jobs = (rb_job *)(ws + w.jobs);
     p.counters = counters;
     p.policy = policy & 1;
     p.early_exit = (policy & RB_LIFT_EARLY_EXIT) ? 1 : 0;
-    p.debug_skip = (policy >> 8) & 7; // diagnostics only, undocumented on purpose
+    p.debug_skip = (policy >> 8) & 0xFFF; // diagnostics only, undocumented on purpose
     uint64_t *block_sums = (uint64_t *)(ws + w.block_sums);
     HIPCHK(ctx, hipMemsetAsync(counters, 0, sizeof(rb_counters), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(p.arena_cur, 0, (size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8, ctx->stream));
@@ -466,14 +437,15 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     } else {
         HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, true, ctx->stream));
     }
+    HIPCHK(ctx, rb_launch_make_jobs(&p, ctx->stream));
+    const size_t slot = (size_t)(ctx->timed_calls % RB_TIMING_RING);
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_a[slot], ctx->stream));
+    p.wave0 = 0;
+    p.wave_end = (uint32_t)b->n_rec;
+    HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
     if (ctx->timing) {
-        const size_t slot = (size_t)(ctx->timed_calls % RB_TIMING_RING);
-        HIPCHK(ctx, hipEventRecord(ctx->ev_a[slot], ctx->stream));
-        HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
         HIPCHK(ctx, hipEventRecord(ctx->ev_b[slot], ctx->stream));
         ctx->timed_calls++;
-    } else {
-        HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
     }
     HIPCHK(ctx, rb_launch_liftover_tail(&p, ctx->stream));
     return RB_OK;

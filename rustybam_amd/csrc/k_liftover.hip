@@ -7,85 +7,26 @@
 //
 //   rb_k_count_hits     one thread per record: number of overlapping windows (paf.rs:622-627)
 //   rb_k_scan_*         exclusive scan of the counts -> first row of every record (canonical order)
-//   rb_k_liftover_stream  ONE WAVEFRONT PER RECORD.  The record's packed ops stream from HBM once
-//                       (16 B per lane, 1 KiB per wave instruction); a 6-step DPP prefix scan
-//                       gives the running (ref, query, unit) offsets of every op in registers; window
-//                       boundaries are resolved on the fly with a ballot + readlane, up to 64 windows
-//                       per pass, their state kept in LDS.  The clipped CIGARs are then copied out
-//                       of L2 (the record has just been streamed) into space the wave reserves with
-//                       one atomic per record.
+//   rb_k_make_jobs      one thread per schedule slot: a 64-byte job descriptor, so that a wave starts on its record
+//                       after ONE load instead of a chain of dependent ones
+//   rb_k_liftover_stream  ONE WAVEFRONT PER RECORD.  The record's packed ops stream from HBM once (32 contiguous
+//                       bytes per lane, 2 KiB per step, two steps in flight); per lane the reference / query /
+//                       unit lengths of 8 ops are summed (op class -> mask with one v_bfe_i32), three 6-step DPP
+//                       prefix scans give the running offsets, every second lane leaves a 16-op checkpoint in
+//                       LDS; window boundaries are resolved lane-parallel against the checkpoints (lane j: start
+//                       of window j, lane j + 32: its end).  One atomic per pass reserves the output; every clip
+//                       is placed so that it keeps the 16-byte phase of its ops in the input, hence its interior
+//                       is copied (out of L2 / Infinity Cache: the record has just been streamed) with aligned
+//                       16-byte loads and stores through a hand-pipelined 4-buffer ring, and only the two end
+//                       groups of a clip are patched.
 //   rb_k_liftover_generic  one thread per hit, serial walk: every case the streaming kernel declines
 //                       (irregular CIGARs: N/S/H/P, zero lengths, adjacent ops of one type that must
-//                       merge (paf.rs:602-620); non-monotone window lists; the legacy binary-search
-//                       policy when the duplicate choice matters; lookbacks across a 256-op step).
+//                       merge (paf.rs:602-620); the legacy binary-search policy when the duplicate
+//                       choice matters; look-aheads / look-backs longer than RB_WALK_MAX ops).
 //
 // Roofline: HBM.  Algorithmic bytes: 4 B per input op + 48 B per record + 88 B per hit + 4 B per
 // emitted op.  No MFMA: integer / index work only.
-#include "rb_device.h"
-#include <cstdlib>
-
-#define RB_HMAX 32            // hits resolved per streaming pass of one record (lanes 0-31 starts, 32-63 ends)
-#define RB_LDS_PER_HIT 6      // dwords of per-hit (start) state in LDS
-#define RB_ARENA_STRIDE 16    // u64 words between arena cursors (128 B)
-
-struct rb_lift_params {
-    uint64_t n_rec;
-    const uint32_t *ops;
-    const uint64_t *op_off;
-    const uint32_t *contig;
-    const uint8_t *strand;
-    const rb_norm_row *norm;
-    // schedule
-    const uint32_t *sched;     // [n_rec] record handled by wave w (longest first)
-    const uint32_t *canon_pos; // [n_rec] position of record r in canonical order
-    // windows grouped by contig (BED order kept inside a contig) + original order
-    const uint64_t *w_st, *w_en; // grouped
-    const uint32_t *w_orig;      // grouped -> BED index
-    const uint64_t *wo_st, *wo_en; // BED order
-    const uint64_t *cw_off;    // [n_contig + 1]
-    const uint8_t *cw_mono;    // [n_contig]
-    uint32_t n_contig;
-    // explicit per-hit windows (break-paf); NULL for BED windows
-    const uint64_t *x_st, *x_en;
-    // rows
-    uint64_t *hit_off; // [n_rec + 1], canonical order; holds counts before the scan
-    uint32_t *win_lo;  // [n_rec] first overlapping window of a monotone slice (grouped index), by record
-    rb_hit_row *rows;
-    uint64_t rows_cap;
-    uint32_t *out_ops;
-    uint64_t out_cap;
-    // output arenas
-    unsigned long long *arena_cur; // [n_arena * RB_ARENA_STRIDE]
-    uint64_t arena_size;           // ops per arena (multiple of 4)
-    uint32_t n_arena;
-    // generic list
-    uint32_t *gen_list; // [rows_cap]
-    rb_counters *counters;
-    int policy;
-    int early_exit; // stop streaming a record once every boundary of the pass is resolved
-    int desc_mode;  // RB_LIFT_DESCRIPTORS: 4-word clip descriptors at out_ops[4 * row] instead of copied ops
-    uint64_t arena_origin; // first op of the arena area inside out_ops (descriptor mode: after the descriptors)
-    int debug_skip; // diagnostics only (wrong results): 1 = no emission, 2 = no resolution, 4 = no streaming
-};
-
-// ------------------------------------------------------------------------------------------------
-// hit counting: paf_overlaps_rgn (paf.rs:622-627) on the NORMALISED record (trim_helper runs
-// aligned_pairs, hence remove_trailing_indels, before the filter: liftover.rs:119-127)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t rb_lower_en_gt(const uint64_t *w_en, uint64_t lo, uint64_t hi, uint64_t t_st) {
-    while (lo < hi) { // first idx with en > t_st (en non-decreasing)
-        uint64_t mid = lo + ((hi - lo) >> 1);
-        if (w_en[mid] > t_st) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
-__device__ __forceinline__ uint64_t rb_lower_st_ge(const uint64_t *w_st, uint64_t lo, uint64_t hi, uint64_t t_en) {
-    while (lo < hi) { // first idx with st >= t_en (st non-decreasing)
-        uint64_t mid = lo + ((hi - lo) >> 1);
-        if (w_st[mid] >= t_en) hi = mid; else lo = mid + 1;
-    }
-    return lo;
-}
+#include "rb_lift.h"
 
 __global__ __launch_bounds__(256) void rb_k_count_hits(rb_lift_params p) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,326 +125,125 @@ __global__ __launch_bounds__(256) void rb_k_scan_apply(uint64_t *v, uint64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// clip jobs: one thread per schedule slot gathers what the clip kernels need about the slot's record
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= p.n_rec) return;
+    const uint32_t r = p.sched[w];
+    const rb_norm_row *nr = &p.norm[r];
+    rb_job j;
+    j.r = r;
+    j.n = nr->n_ops;
+    j.rec0 = p.op_off[r] + nr->first_op;
+    j.t_st = nr->t_st, j.t_en = nr->t_en, j.q_st = nr->q_st, j.q_en = nr->q_en;
+    const uint64_t k = p.canon_pos[r];
+    const uint64_t h0 = p.hit_off[k], nh = p.hit_off[k + 1] - h0;
+    const bool explicit_w = p.x_st != nullptr;
+    const uint32_t cg = p.contig[r];
+    const bool mono = explicit_w || (cg < p.n_contig && p.cw_mono[cg] != 0);
+    uint32_t f = 0;
+    if (nr->status == RB_ST_OK && nh != 0) {
+        if (h0 + nh > p.rows_cap) f |= RB_JOB_ROWS_OVERFLOW;
+        else f |= RB_JOB_VALID;
+    }
+    if (nr->flags & RB_F_REGULAR) f |= RB_JOB_REGULAR;
+    if (p.strand[r] == (uint8_t)'-') f |= RB_JOB_MINUS;
+    if (mono) f |= RB_JOB_MONO;
+    j.flags = f;
+    j.h0 = (uint32_t)h0;
+    j.nh = (uint32_t)nh;
+    j.lo = (explicit_w || !mono || !(f & RB_JOB_VALID)) ? 0u : p.win_lo[r];
+    p.jobs[w] = j;
+}
+
+// ------------------------------------------------------------------------------------------------
 // streaming kernel
 // ------------------------------------------------------------------------------------------------
-enum { RB_S_UNRES = 0, RB_S_OK = 1, RB_S_NONE = 2, RB_S_DEFER = 3 };
-
-// first/last set helpers on 64-bit masks
-__device__ __forceinline__ int rb_ffs64(unsigned long long m) { return __ffsll((long long)m) - 1; }
-
-// append every hit of a record to the generic list (record not eligible for the streaming path)
-__device__ void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_norm_row *nr, uint64_t h0, uint64_t nh,
-                                bool explicit_w, bool mono, uint64_t ws, uint64_t we, int lane) {
-    if (explicit_w || mono) {
-        uint64_t lo = 0;
-        if (!explicit_w) lo = rb_lower_en_gt(p.w_en, ws, we, nr->t_st);
-        for (uint64_t j = lane; j < nh; j += 64) {
-            const uint64_t h = h0 + j;
-            if (h < p.rows_cap) {
-                rb_hit_row *row = &p.rows[h];
-                row->rec = r;
-                row->win = explicit_w ? (uint32_t)j : p.w_orig[lo + j];
-                row->flags = RB_HIT_GENERIC;
-                const unsigned long long g = atomicAdd((unsigned long long *)&p.counters->n_generic, 1ull);
-                p.gen_list[g] = (uint32_t)h;
-            }
-        }
-    } else {
-        // non-monotone window list: enumerate in BED order, 64 windows per step
-        uint64_t done = 0;
-        for (uint64_t b = ws; b < we; b += 64) {
-            const uint64_t i = b + lane;
-            const bool hit = i < we && nr->t_en > p.w_st[i] && nr->t_st < p.w_en[i];
-            const unsigned long long ball = __ballot(hit);
-            if (hit) {
-                const uint64_t j = done + __popcll(ball & ((1ull << lane) - 1ull));
-                const uint64_t h = h0 + j;
-                if (h < p.rows_cap) {
-                    rb_hit_row *row = &p.rows[h];
-                    row->rec = r;
-                    row->win = p.w_orig[i];
-                    row->flags = RB_HIT_GENERIC;
-                    const unsigned long long g = atomicAdd((unsigned long long *)&p.counters->n_generic, 1ull);
-                    p.gen_list[g] = (uint32_t)h;
-                }
-            }
-            done += __popcll(ball);
-        }
-    }
-}
-
-// ---- emission helpers: one lane moves 4 ops (16 B) of its team's clip --------------------------------
-// i = op position inside the clip (multiple of 4), e_n = ops in the clip.  The ops array is padded, so
-// the load may read up to 3 ops past the clip; they are zeroed before the store.
-__device__ __forceinline__ uint4 rb_emit_load(const uint32_t *src, uint32_t i, uint32_t e_n, int dbg = 0) {
-    if (dbg & 16) return make_uint4(i, 0, 0, 0);
-    return i < e_n ? rb_load4_unaligned(src + i) : make_uint4(0, 0, 0, 0);
-}
-__device__ __forceinline__ void rb_emit_store(uint32_t *dst, uint32_t i, uint32_t e_n, uint32_t afirst, uint32_t blast, bool verbatim, uint4 v, int dbg = 0) {
-    if (i >= e_n) return;
-    if (dbg & 8) { if (v.x == 0xFFFFFFF1u) dst[0] = v.y; return; }
-    if (i + 1 >= e_n) v.y = 0u;
-    if (i + 2 >= e_n) v.z = 0u;
-    if (i + 3 >= e_n) v.w = 0u;
-    if (!verbatim) {
-        if (i == 0) { // first op keeps its tail, or the middle if the clip is a single op
-            const uint32_t l0 = e_n == 1 ? (afirst + blast - rb_len(v.x)) : afirst;
-            v.x = (l0 << 4) | rb_opc(v.x);
-        }
-        if (e_n > 1 && e_n - 1 - i < 4u) { // last op keeps its head
-            const uint32_t q = e_n - 1 - i;
-            const uint32_t lastv = q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
-            const uint32_t nv = (blast << 4) | rb_opc(lastv);
-            if (q == 0) v.x = nv; else if (q == 1) v.y = nv; else if (q == 2) v.z = nv; else v.w = nv;
-        }
-    }
-    // streaming (non-temporal) store: the clipped cigars are written once and never re-read here, so they
-    // should not displace the record's ops from L2
-    typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
-    rb_u32x4 nv4 = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(nv4, reinterpret_cast<rb_u32x4 *>(dst + i));
-}
-
-// ---- lane-local boundary resolution --------------------------------------------------------------
-// One lane resolves one window boundary.  It starts from a checkpoint (exclusive prefixes R,Q,U at an
-// op index that is a multiple of 16, written to LDS by the streaming pass), walks at most 16 ops held
-// in registers to the reference-consuming op that contains offset D, then applies the reference's
-// tpos_to_idx + walk-to-match rules (paf.rs:541-561) with short look-ahead / look-back loads.
-struct rb_bres {
-    uint32_t st;            // RB_S_OK / NONE / DEFER
-    uint32_t op, part;      // op index; start: ops' remaining length (len - off), end: used length (off + 1)
-    uint32_t R, Q, U;       // start: exclusive counts at the unit; end: inclusive counts
-};
-
-#define RB_WALK_MAX 24
-
-// regular records only (M I D = X): ref = not I, query = not D
-__device__ __forceinline__ uint32_t rb_rl(uint32_t v) { return rb_opc(v) == RB_OP_I ? 0u : rb_len(v); }
-__device__ __forceinline__ uint32_t rb_ql(uint32_t v) { return rb_opc(v) == RB_OP_D ? 0u : rb_len(v); }
-__device__ __forceinline__ bool rb_ism(uint32_t v) { return rb_in(RB_MATCH_MASK, rb_opc(v)); }
-
-// ops[] = the record's kept ops, n of them.  (cR,cQ,cU) = prefixes at op index cidx (checkpoint).
-// D in [cR, next checkpoint's R) and D < Rtot.  is_start selects search-right (true) / search-left.
-__device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, uint32_t n, int32_t cidx, uint32_t cR, uint32_t cQ,
-                                              uint32_t cU, uint32_t D, bool is_start, int policy) {
-    rb_bres o;
-    o.st = RB_S_DEFER;
-    o.op = o.part = o.R = o.Q = o.U = 0;
-    // 16 ops of the checkpoint group (cidx may be negative by up to 3 in the aligned head: masked)
-    uint32_t g[16];
-    {
-        const uint4 *q = reinterpret_cast<const uint4 *>(ops + cidx); // 16-byte aligned by construction
-        const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
-        g[0] = a0.x; g[1] = a0.y; g[2] = a0.z; g[3] = a0.w; g[4] = a1.x; g[5] = a1.y; g[6] = a1.z; g[7] = a1.w;
-        g[8] = a2.x; g[9] = a2.y; g[10] = a2.z; g[11] = a2.w; g[12] = a3.x; g[13] = a3.y; g[14] = a3.z; g[15] = a3.w;
-    }
-    // find the ref-consuming op f with Rx <= D < Rx + len
-    int32_t fi = -1;
-    uint32_t fv = 0, fR = 0, fQ = 0, fU = 0, pv = (RB_NULL_OP);
-    {
-        uint32_t R = cR, Q = cQ, U = cU, prev = RB_NULL_OP;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int32_t idx = cidx + k;
-            const bool valid = (uint32_t)idx < n;
-            const uint32_t v = valid ? g[k] : RB_NULL_OP;
-            const uint32_t rl = valid ? rb_rl(v) : 0u;
-            if (fi < 0 && rl != 0 && (uint32_t)(D - R) < rl) {
-                fi = idx;
-                fv = v;
-                fR = R;
-                fQ = Q;
-                fU = U;
-                pv = prev;
-            }
-            R += rl;
-            Q += valid ? rb_ql(v) : 0u;
-            U += valid ? rb_len(v) : 0u;
-            if (valid) prev = v;
-        }
-    }
-    if (fi < 0) return o; // should not happen; the generic kernel sorts it out
-    if (fi > 0 && pv == RB_NULL_OP) pv = ops[fi - 1]; // previous op lives in the group before
-    const uint32_t off = D - fR;
-    if (is_start) {
-        int32_t X; // first match-type op with index >= X
-        if (off > 0) { // the boundary base and the next base share op f
-            if (rb_ism(fv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = rb_len(fv) - (off - 1), o.R = fR + off - 1, o.Q = fQ + off - 1, o.U = fU + off - 1;
-                return o;
-            }
-            X = fi + 1;
-        } else { // boundary base is the last unit before op f: the last equal element is the unit before f
-            if (fi > 0 && rb_ism(pv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = 1u, o.R = fR - 1, o.Q = fQ - 1, o.U = fU - 1;
-                return o;
-            }
-            // duplicates in tpos_aln (units of an insertion share the boundary's tpos): which one
-            // binary_search returns depends on the Rust std generation -> generic kernel decides
-            if (policy == RB_BSEARCH_LEGACY && fi > 0 && rb_opc(pv) == RB_OP_I) return o;
-            X = fi;
-        }
-        // walk right (paf.rs:551-553) from op fi
-        uint32_t R = fR, Q = fQ, U = fU;
-        uint32_t v = fv;
-        int32_t i = fi;
-        for (int t = 0; t < RB_WALK_MAX; t++) {
-            if (i >= X && rb_ism(v)) {
-                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
-                return o;
-            }
-            R += rb_rl(v);
-            Q += rb_ql(v);
-            U += rb_len(v);
-            i++;
-            if ((uint32_t)i >= n) {
-                o.st = RB_S_NONE; // ran off the end: start_idx == N (liftover.rs:52)
-                return o;
-            }
-            v = ops[i];
-        }
-        return o; // too far: generic
-    } else {
-        int32_t Y; // last match-type op with index <= Y
-        if (off > 0) {
-            if (rb_ism(fv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = off, o.R = D, o.Q = fQ + off, o.U = fU + off;
-                return o;
-            }
-            Y = fi - 1;
-        } else {
-            if (fi > 0 && rb_ism(pv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = rb_len(pv), o.R = fR, o.Q = fQ, o.U = fU;
-                return o;
-            }
-            Y = fi - 2;
-        }
-        // walk left (paf.rs:555-557): (R,Q,U) are the prefixes at the END of op i
-        uint32_t R = fR, Q = fQ, U = fU;
-        int32_t i = fi - 1;
-        for (int t = 0; t < RB_WALK_MAX; t++) {
-            if (i < 0) {
-                o.st = RB_S_NONE; // stops at unit 0, which lies before any start
-                return o;
-            }
-            const uint32_t v = ops[i];
-            if (i <= Y && rb_ism(v)) {
-                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
-                return o;
-            }
-            R -= rb_rl(v);
-            Q -= rb_ql(v);
-            U -= rb_len(v);
-            i--;
-        }
-        return o;
-    }
-}
-
-#define RB_SMAX 20 // steps (of 256 ops) whose checkpoints fit in LDS at once
-#define RB_CP_PER_STEP 16
+#define RB_STEP_SHIFT 9  // a step is 512 ops: 8 ops (two 16-byte loads, 32 contiguous bytes) per lane
+#define RB_CP_PER_STEP 32 // one checkpoint per 16 ops (every second lane)
 #ifndef RB_PF
-#define RB_PF 4 // steps (1 KiB each) of stream loads in flight per wave
+#define RB_PF 2 // steps (2 KiB each) of stream loads in flight per wave
+#endif
+#define RB_ET (RB_HMAX + 1) // slots per column of the clip table (one sentinel)
+#define RB_SMAX ((10 / RB_PF) * RB_PF) // steps whose checkpoints fit in LDS at once; whole turns of the load ring
+#ifndef RB_WPE
+#define RB_WPE 5, 6 // waves per SIMD the register budget is cut for
+#endif
+#ifdef RB_NO_NT
+#define RB_ST_NT ""
+#endif
+#ifndef RB_ST_NT
+#define RB_ST_NT " nt" // clip stores are non-temporal: written once, never re-read by this kernel
 #endif
 #ifndef RB_EB
-#define RB_EB 4 // output groups (16 B) per lane and emission batch
+#define RB_EB 4 // emission buffers (one 16-byte group per lane each) in rotation
 #endif
 
-__global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) void rb_k_liftover_stream(rb_lift_params p) {
     // checkpoints: exclusive (R,Q,U) prefixes every 16 ops, SoA so that R can be binary-searched
     __shared__ uint32_t cp_all[4][3][RB_SMAX * RB_CP_PER_STEP];
-    __shared__ uint32_t et_all[4][5][RB_HMAX]; // per clip: first output op, a_op, out_n, first len, last len | verbatim
-    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (wave >= p.n_rec) return;
+    __shared__ uint32_t et_all[4][3][RB_HMAX + 1]; // per clip of a pass: region offset, first group, last group (+ sentinel)
+    const uint32_t wib = rb_first(threadIdx.x >> 6); // wave in block (told to the compiler as the wave-uniform value it is)
+    const uint64_t wave = (uint64_t)p.wave0 + (uint64_t)blockIdx.x * 4u + wib;
+    if (wave >= p.wave_end) return;
     const int lane = rb_lane();
-    uint32_t *cpR = cp_all[threadIdx.x >> 6][0], *cpQ = cp_all[threadIdx.x >> 6][1], *cpU = cp_all[threadIdx.x >> 6][2];
-    const uint32_t r = rb_first(p.sched[wave]);
-    const rb_norm_row *nr = &p.norm[r];
-    if (nr->status != RB_ST_OK) return;
-    const uint64_t k = p.canon_pos[r];
-    const uint64_t h0 = rb_first64(p.hit_off[k]);
-    const uint64_t nh = rb_first64(p.hit_off[k + 1]) - h0;
-    if (nh == 0) return;
-    if (h0 + nh > p.rows_cap) { // rows do not fit: flag and leave (host retries with more room)
+    uint32_t *cpR = cp_all[wib][0], *cpQ = cp_all[wib][1], *cpU = cp_all[wib][2];
+    const rb_job jb_ = p.jobs[wave]; // (uniform address: one 64-byte request)
+    const uint32_t jflags = rb_first(jb_.flags);
+    if (jflags & RB_JOB_ROWS_OVERFLOW) { // rows do not fit: flag and leave (host retries with more room)
         if (lane == 0) p.counters->overflow = 1;
         return;
     }
+    if (!(jflags & RB_JOB_VALID)) return;
+    const uint32_t r = rb_first(jb_.r);
+    const rb_norm_row *nr = &p.norm[r];
+    const uint64_t h0 = rb_first(jb_.h0);
+    const uint64_t nh = rb_first(jb_.nh);
     const bool explicit_w = p.x_st != nullptr;
-    const uint32_t cg = p.contig[r];
+    const bool mono = (jflags & RB_JOB_MONO) != 0;
     uint64_t ws = 0, we = 0;
-    bool mono = true;
-    if (!explicit_w) {
+    if (!explicit_w && (!mono || !(jflags & RB_JOB_REGULAR))) { // the contig's window slice: only the rare paths need it
+        const uint32_t cg = p.contig[r];
         ws = p.cw_off[cg];
         we = p.cw_off[cg + 1];
-        mono = p.cw_mono[cg] != 0;
     }
-    const bool fast = (nr->flags & RB_F_REGULAR) != 0; // window order does not matter: resolution is per lane
-    if (!fast) {
+    if (!(jflags & RB_JOB_REGULAR)) { // window order does not matter on the fast path: resolution is per lane
         rb_defer_record(p, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
         return;
     }
-    const uint64_t t_st = nr->t_st, t_en = nr->t_en, q_st = nr->q_st, q_en = nr->q_en;
-    const uint32_t n = nr->n_ops;
-    const bool minus = p.strand[r] == (uint8_t)'-';
-    const uint64_t rec0 = p.op_off[r] + nr->first_op; // global index of the record's first kept op
+    // wave-uniform coordinates: pinned to scalar registers (left alone, the compiler keeps vector copies alive through the
+    // whole record and spills them)
+    auto sgpr64 = [](uint64_t v) -> uint64_t {
+        uint32_t lo = rb_first((uint32_t)v), hi = rb_first((uint32_t)(v >> 32));
+        asm volatile("" : "+s"(lo), "+s"(hi));
+        return ((uint64_t)hi << 32) | lo;
+    };
+    const uint64_t t_st = sgpr64(jb_.t_st), t_en = sgpr64(jb_.t_en), q_st = sgpr64(jb_.q_st), q_en = sgpr64(jb_.q_en);
+    const uint32_t n = rb_first(jb_.n);
+    const bool minus = (jflags & RB_JOB_MINUS) != 0;
+    const uint64_t rec0 = rb_first64(jb_.rec0); // global index of the record's first kept op
     const uint32_t *rec_ops = p.ops + rec0;
-    const uint64_t lo = (explicit_w || !mono) ? 0 : p.win_lo[r];
+    const uint64_t lo = rb_first(jb_.lo);
     uint64_t scan_pos = ws; // non-monotone window lists: next window of the slice to test
     const uint32_t arena = (uint32_t)(wave % p.n_arena);
     const uint64_t g0 = rec0 & ~3ull, gend = rec0 + n;
-    const uint32_t n_steps = (uint32_t)((gend - g0 + 255u) >> 8);
+    const uint32_t n_steps = (uint32_t)((gend - g0 + (1u << RB_STEP_SHIFT) - 1u) >> RB_STEP_SHIFT);
     const int32_t head = (int32_t)(rec0 - g0); // 0..3 padding ops in front of the record in step 0
-    const uint64_t glane = g0 + (uint64_t)lane * 4u;
+    const uint32_t *__restrict__ gbase0 = p.ops + g0;                 // the record's first (aligned) 16-byte group
+    const uint32_t last_off = (uint32_t)(((gend - 1u) & ~3ull) - g0); // last 16-byte group that holds an op of this record
 
     for (uint64_t jb = 0; jb < nh; jb += RB_HMAX) {
         const uint32_t nb = (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX);
         // ---- per-hit setup: lanes j and j + 32 both look at window jb + j; lane j resolves its start
         //      boundary, lane j + 32 its end boundary; lane j then owns the row ----
-        uint64_t wst = 0, wen = 0;
-        uint32_t win = 0;
         const uint32_t hl = (uint32_t)lane & 31u;
         const bool own = hl < nb;
         const bool mine = own && lane < 32;
         const bool is_start = lane < 32;
-        if (!explicit_w && !mono) {
-            // windows of this contig are not sorted: collect the next nb overlapping ones in BED order, 64
-            // candidates per ballot (same test as rb_k_count_hits, so the counts agree)
-            uint32_t *widx = &et_all[threadIdx.x >> 6][0][0];
-            uint32_t filled = 0;
-            while (filled < nb && scan_pos < we) {
-                const uint64_t i = scan_pos + (uint64_t)lane;
-                const bool hit = i < we && t_en > p.w_st[i] && t_st < p.w_en[i];
-                const unsigned long long ball = __ballot(hit);
-                const uint32_t room = nb - filled, cnt = (uint32_t)__popcll(ball);
-                const uint32_t rank = (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
-                if (hit && rank < room) widx[filled + rank] = (uint32_t)(i - ws);
-                if (cnt <= room) {
-                    filled += cnt;
-                    scan_pos += 64;
-                } else { // the pass is full: resume after the room-th hit next time
-                    unsigned long long m = ball;
-                    for (uint32_t q = 1; q < room; q++) m &= m - 1;
-                    scan_pos += (uint64_t)rb_ffs64(m) + 1u;
-                    filled += room;
-                }
-            }
-            if (own) {
-                const uint64_t idx = ws + widx[hl];
-                wst = p.w_st[idx];
-                wen = p.w_en[idx];
-                win = p.w_orig[idx];
-            }
-        } else if (own) {
-            if (explicit_w) {
-                wst = p.x_st[h0 + jb + hl];
-                wen = p.x_en[h0 + jb + hl];
-                win = (uint32_t)(jb + hl);
-            } else {
-                wst = p.w_st[lo + jb + hl];
-                wen = p.w_en[lo + jb + hl];
-                win = p.w_orig[lo + jb + hl];
-            }
-        }
+        const rb_pass_win pw = rb_pass_windows(p, &et_all[wib][0][0], explicit_w, mono, ws, we, lo, h0, jb, nb, t_st, t_en, scan_pos, lane);
+        const uint64_t wst = pw.wst, wen = pw.wen;
+        const uint32_t win = pw.win;
         const bool inside = own && (t_st > wst && t_en < wen); // liftover.rs:23-25
         // D = (relative ref offset of the boundary base) + 1
         const uint32_t D = is_start ? (uint32_t)((wst > t_st ? wst : t_st) - t_st) + 1u // liftover.rs:28
@@ -516,48 +256,70 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
         // ---- stream the record, RB_SMAX steps per segment; resolve after each segment ----
         uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
         if (__ballot(need) != 0 && !(p.debug_skip & 4)) {
-            auto load_step = [&](uint32_t stp) -> uint4 {
-                const uint64_t gi = glane + ((uint64_t)stp << 8);
-                return gi < gend ? *reinterpret_cast<const uint4 *>(p.ops + gi) : make_uint4(0, 0, 0, 0);
+            auto load_half = [&](uint32_t stp, uint32_t half) -> uint4 {
+                // unconditional (an exec-masked load makes the compiler drain the whole ring at the loop edge):
+                // groups past the record's end re-read its last group; the tail step masks them out
+                uint32_t off = (stp << RB_STEP_SHIFT) + half * 4u + (uint32_t)lane * 8u; // (uniform base + 32-bit lane offset)
+                off = off < last_off ? off : last_off;
+                return *reinterpret_cast<const uint4 *>(gbase0 + off);
             };
-            uint4 pf[RB_PF];
+            uint4 pf[RB_PF][2];
 #pragma unroll
-            for (int q = 0; q < RB_PF; q++) pf[q] = load_step((uint32_t)q);
+            for (int q = 0; q < RB_PF; q++) {
+                pf[q][0] = load_half((uint32_t)q, 0u);
+                pf[q][1] = load_half((uint32_t)q, 1u);
+                __builtin_amdgcn_sched_barrier(0); // keep issue order = consumption order, so that vmcnt counts stay exact
+            }
             for (uint32_t seg0 = 0; seg0 < n_steps; seg0 += RB_SMAX) {
                 const uint32_t seg1 = (seg0 + RB_SMAX < n_steps) ? seg0 + RB_SMAX : n_steps;
                 const uint32_t Rseg = Rb;
-                for (uint32_t st = seg0; st < seg1; st++) {
-                    const uint4 cur = pf[0];
+                // the ring is indexed statically (unrolled by RB_PF): rotating it with register moves would make
+                // every step wait for ALL loads in flight (the moves read their destination registers)
+                for (uint32_t st0 = seg0; st0 < seg1; st0 += RB_PF) {
 #pragma unroll
-                    for (int q = 0; q + 1 < RB_PF; q++) pf[q] = pf[q + 1];
-                    pf[RB_PF - 1] = load_step(st + RB_PF);
-                    const int32_t idx0 = (int32_t)(st << 8) + lane * 4 - head;
-                    const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
-                    uint32_t sr = 0, sq = 0, su = 0;
+                    for (int ring = 0; ring < RB_PF; ring++) {
+                        const uint32_t st = st0 + (uint32_t)ring;
+                        if (st < seg1) { // (no break: the ring must be in the same state on every path)
+                            uint32_t raw[8] = {pf[ring][0].x, pf[ring][0].y, pf[ring][0].z, pf[ring][0].w,
+                                               pf[ring][1].x, pf[ring][1].y, pf[ring][1].z, pf[ring][1].w};
+                            if (st == 0 || st + 1 == n_steps) { // only the first / last step can hold ops of the neighbours
+                                const int32_t idx0 = (int32_t)(st << RB_STEP_SHIFT) + lane * 8 - head;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const bool valid = (uint32_t)(idx0 + q) < n; // also rejects the negative head indices
-                        const uint32_t len = valid ? rb_len(raw[q]) : 0u;
-                        const uint32_t opc = rb_opc(raw[q]);
-                        sr += (opc == RB_OP_I) ? 0u : len;
-                        sq += (opc == RB_OP_D) ? 0u : len;
-                        su += len;
+                                for (int q = 0; q < 8; q++)
+                                    if ((uint32_t)(idx0 + q) >= n) raw[q] = 0u; // (also the negative head indices); 0 = a 0-length M
+                            }
+                            // per-lane sums of the reference / query / unit lengths of 8 ops; regular records hold only
+                            // M I D = X, so "consumes the reference" = not I and "consumes the query" = not D: one
+                            // v_bfe_i32 per class turns the op code (low bits of the word) into an all-ones / zero mask
+                            uint32_t sr = 0, sq = 0, su = 0;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const uint32_t len = rb_len(raw[q]);
+                                sr += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFDFFFDu, raw[q], 1u);
+                                sq += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFBFFFBu, raw[q], 1u);
+                                su += len;
+                            }
+                            const uint32_t ir = rb_wave_scan_incl(sr), iq = rb_wave_scan_incl(sq), iu = rb_wave_scan_incl(su);
+                            if ((lane & 1) == 0) { // checkpoint every 16 ops
+                                const uint32_t t = (st - seg0) * RB_CP_PER_STEP + ((uint32_t)lane >> 1);
+                                cpR[t] = Rb + ir - sr;
+                                cpQ[t] = Qb + iq - sq;
+                                cpU[t] = Ub + iu - su;
+                            }
+                            Rb += rb_readlane<uint32_t>(ir, 63);
+                            Qb += rb_readlane<uint32_t>(iq, 63);
+                            Ub += rb_readlane<uint32_t>(iu, 63);
+                        }
+                        // reload the slot only after its ops are consumed: the load then targets the same registers
+                        // and the compiler needs no copy (which would wait for every load in flight)
+                        pf[ring][0] = load_half(st + RB_PF, 0u);
+                        pf[ring][1] = load_half(st + RB_PF, 1u);
                     }
-                    const uint32_t ir = rb_wave_scan_incl(sr), iq = rb_wave_scan_incl(sq), iu = rb_wave_scan_incl(su);
-                    if ((lane & 3) == 0) { // checkpoint every 16 ops
-                        const uint32_t t = (st - seg0) * RB_CP_PER_STEP + ((uint32_t)lane >> 2);
-                        cpR[t] = Rb + ir - sr;
-                        cpQ[t] = Qb + iq - sq;
-                        cpU[t] = Ub + iu - su;
-                    }
-                    Rb += rb_readlane<uint32_t>(ir, 63);
-                    Qb += rb_readlane<uint32_t>(iq, 63);
-                    Ub += rb_readlane<uint32_t>(iu, 63);
                 }
                 // ---- lane-parallel resolution of the boundaries that fall in this segment ----
                 const bool last_seg = seg1 == n_steps;
                 const uint32_t n_cp = (seg1 - seg0) * RB_CP_PER_STEP;
-                const int32_t cp_idx0 = (int32_t)(seg0 << 8) - head; // op index of checkpoint 0
+                const int32_t cp_idx0 = (int32_t)(seg0 << RB_STEP_SHIFT) - head; // op index of checkpoint 0
                 {
                     const bool todo = need && D >= Rseg && (D < Rb || (last_seg && D == Rb));
                     if (todo && !(p.debug_skip & 2)) {
@@ -620,8 +382,23 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 out_n = B.op - A.op + 1;
             }
         }
-        // space for the clipped cigars: one atomic per pass, each hit padded to 4 ops
-        const uint32_t padded = (mine && !defer && status == RB_ST_OK && !p.desc_mode) ? ((out_n + 3u) & ~3u) : 0u;
+        // space for the clipped cigars: one atomic per pass.  A clip starts `lead` ops into its region so that it keeps the
+        // 16-byte phase its ops have in the input: interior 16-byte groups are then copied with aligned loads AND aligned
+        // stores and need no patching; only the group(s) holding a clip's first and last op are rewritten op by op.
+        const bool emits = mine && !defer && status == RB_ST_OK && !p.desc_mode;
+        const uint32_t e_first = (uint32_t)head + a_op; // coordinate (op index + head, counted from the aligned g0) of the first op
+        const uint32_t e_cnt = emits ? out_n : 0u;
+        const uint32_t eg_last = e_first + e_cnt - 1u;
+        const uint32_t eg_f = e_first & ~3u, eg_l = e_cnt ? (eg_last & ~3u) : eg_f;
+        // the two end groups are re-read here, BEFORE any store of this pass: vmcnt retires in order on gfx9, a load issued
+        // after stores would wait for every one of them; this way the latency hides behind the reservation atomic.
+        // (unconditional: a conditional load is sunk to its use; the ops array is padded, a quad may reach past the record)
+        const uint32_t *__restrict__ gsrc = rec_ops - head; // coordinate c -> gsrc[c]; 16-byte aligned at c % 4 == 0
+        uint4 eg_q0 = *reinterpret_cast<const uint4 *>(gsrc + eg_f);
+        uint4 eg_q1 = *reinterpret_cast<const uint4 *>(gsrc + eg_l);
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t lead = e_first & 3u;
+        const uint32_t padded = emits ? ((lead + out_n + 3u) & ~3u) : 0u;
         const uint32_t incl = rb_wave_scan_incl(padded);
         const uint32_t total = rb_readlane<uint32_t>(incl, 63);
         uint64_t base = 0;
@@ -632,15 +409,22 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
         }
         const bool fits = base + total <= p.arena_size;
         if (!fits && lane == 0) p.counters->overflow = 1;
-        const uint64_t my_off = p.arena_origin + (uint64_t)arena * p.arena_size + base + (incl - padded);
+        const uint64_t region0 = p.arena_origin + (uint64_t)arena * p.arena_size + base; // multiple of 4 ops
+        const uint32_t my_rel = (incl - padded) + lead;                                   // first op of my clip inside the region
+        const uint64_t my_off = region0 + my_rel;
+        // (the row index is formed from an opaque copy of the lane id: otherwise the compiler hoists the row addresses above
+        //  the streaming loop and carries -- or spills -- them through it)
+        uint32_t lane_late = (uint32_t)lane;
+        asm volatile("" : "+v"(lane_late));
+        const uint64_t my_row = h0 + jb + lane_late;
         if (mine) {
-            rb_hit_row *row = &p.rows[h0 + jb + lane];
+            rb_hit_row *row = &p.rows[my_row];
             if (defer) {
                 row->rec = r;
                 row->win = win;
                 row->flags = RB_HIT_GENERIC;
                 const unsigned long long g = atomicAdd((unsigned long long *)&p.counters->n_generic, 1ull);
-                p.gen_list[g] = (uint32_t)(h0 + jb + lane);
+                p.gen_list[g] = (uint32_t)my_row;
             } else {
                 rb_hit_row w;
                 w.rec = r;
@@ -654,55 +438,98 @@ __global__ __launch_bounds__(256) void rb_k_liftover_stream(rb_lift_params p) {
                 w.q_en = o_qen;
                 w.nmatch = o_nm;
                 w.aln_len = o_al;
-                w.out_off = status == RB_ST_OK ? (p.desc_mode ? 4ull * (h0 + jb + lane) : my_off) : 0;
+                w.out_off = status == RB_ST_OK ? (p.desc_mode ? 4ull * my_row : my_off) : 0;
                 *row = w;
                 if (p.desc_mode && status == RB_ST_OK) // which ops of the ORIGINAL cigar the clip keeps
-                    *reinterpret_cast<uint4 *>(p.out_ops + 4ull * (h0 + jb + lane)) =
+                    *reinterpret_cast<uint4 *>(p.out_ops + 4ull * my_row) =
                         make_uint4(nr->first_op + a_op, out_n, inside ? 0u : A.part, inside ? 0u : B.part);
             }
         }
-        // ---- emit: the clips of this pass occupy one contiguous output region [base, base + total).
-        //      Lane l moves output groups (4 ops, 16 B aligned) l, l + 64, ...; the clip a group belongs to is
-        //      found by a 5-step search of the clips' output offsets in LDS (offsets are non-decreasing; the
-        //      last clip starting at or before the group is the one that contains it).  8 independent 16 B
-        //      loads per lane are in flight per batch. ----
+        // ---- emit.  (1) end groups: the lane that owns a clip writes the group(s) holding its first and last op, op by op,
+        //      with the clipped lengths patched in.  (2) interior groups: the pass's clips occupy one contiguous region
+        //      [0, total); lane l copies its 16-byte groups l, l + 64, ... (aligned load from the input, aligned store).
+        //      The clip a group belongs to only moves forward as the group index grows, so each lane keeps a cursor into the
+        //      clip table in LDS instead of searching it per group. ----
         if (fits && total && !(p.debug_skip & 1)) {
-            uint32_t *et = &et_all[threadIdx.x >> 6][0][0];
-            if (mine) {
-                et[0 * RB_HMAX + lane] = incl - padded; // first output op of the clip
-                et[1 * RB_HMAX + lane] = a_op;
-                et[2 * RB_HMAX + lane] = padded ? out_n : 0u;
-                et[3 * RB_HMAX + lane] = A.part;
-                et[4 * RB_HMAX + lane] = B.part | (inside ? 0x80000000u : 0u);
+            uint32_t *region = p.out_ops + region0;
+            if (e_cnt) { // slots of my region before the first / behind the last op are padding: written as zeros
+                uint32_t *__restrict__ dst = region + (incl - padded); // my region; its first group holds coordinate eg_f
+                uint32_t q0[4] = {eg_q0.x, eg_q0.y, eg_q0.z, eg_q0.w}, q1[4] = {eg_q1.x, eg_q1.y, eg_q1.z, eg_q1.w};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t c0 = eg_f + (uint32_t)q, c1 = eg_l + (uint32_t)q;
+                    uint32_t w0 = q0[q], w1 = q1[q];
+                    if (!inside) {
+                        if (e_cnt == 1u) { // the middle of one op
+                            if (c0 == e_first) w0 = ((A.part + B.part - rb_len(w0)) << 4) | rb_opc(w0);
+                        } else {
+                            if (c0 == e_first) w0 = (A.part << 4) | rb_opc(w0); // first op keeps its tail
+                            if (c0 == eg_last) w0 = (B.part << 4) | rb_opc(w0); // (clips of 2..4 ops inside one group)
+                            if (c1 == eg_last) w1 = (B.part << 4) | rb_opc(w1); // last op keeps its head
+                        }
+                    }
+                    q0[q] = (c0 < e_first || c0 > eg_last) ? 0u : w0;
+                    q1[q] = (c1 > eg_last) ? 0u : w1;
+                }
+                typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
+                const rb_u32x4 s0 = {q0[0], q0[1], q0[2], q0[3]}, s1 = {q1[0], q1[1], q1[2], q1[3]};
+                __builtin_nontemporal_store(s0, reinterpret_cast<rb_u32x4 *>(dst));
+                if (eg_l != eg_f) __builtin_nontemporal_store(s1, reinterpret_cast<rb_u32x4 *>(dst + (eg_l - eg_f)));
             }
-            uint32_t *__restrict__ dst = p.out_ops + (p.arena_origin + (uint64_t)arena * p.arena_size + base);
-            for (uint32_t gb = 0; gb * 4u < total; gb += RB_EB * 64u) {
-                uint4 v[RB_EB];
-                uint32_t cj[RB_EB], cpos[RB_EB];
-#pragma unroll
-                for (int u = 0; u < RB_EB; u++) {
-                    const uint32_t o = (gb + (uint32_t)u * 64u + (uint32_t)lane) * 4u; // output op of this group
-                    uint32_t lo_j = 0, hi_j = nb;
-                    while (hi_j - lo_j > 1) { // last clip with first output op <= o
-                        const uint32_t mid = (lo_j + hi_j) >> 1;
-                        if (et[mid] <= o) lo_j = mid; else hi_j = mid;
-                    }
-                    cj[u] = lo_j;
-                    const uint32_t pos = o - et[lo_j];
-                    const uint32_t e_n = et[2 * RB_HMAX + lo_j];
-                    const bool live = o < total && pos < e_n;
-                    cpos[u] = live ? pos : 0xFFFFFFFFu;
-                    v[u] = live ? rb_emit_load(rec_ops + et[1 * RB_HMAX + lo_j], pos, e_n, p.debug_skip) : make_uint4(0, 0, 0, 0);
+            // clip table: region offset of the clip's first group, coordinates of its first and last group
+            uint32_t *et = &et_all[wib][0][0];
+            if (mine) {
+                et[0 * RB_ET + lane] = incl - padded;
+                et[1 * RB_ET + lane] = eg_f;
+                et[2 * RB_ET + lane] = e_cnt ? eg_l : eg_f; // (no ops: no interior group either)
+            }
+            if (lane == 0) et[0 * RB_ET + nb] = 0xFFFFFFFFu; // sentinel (the table has RB_HMAX + 1 slots)
+            uint32_t cj = 0, c_start = et[0], c_fg = et[1 * RB_ET], c_lg = et[2 * RB_ET], n_start = et[1];
+            // Four buffers of one group per lane rotate: turn t loads the group of turn t into buffer t % 4 and stores the
+            // group loaded two turns earlier.  The load / wait / store triple is written by hand: vmcnt retires in order on
+            // gfx9, and left to the compiler every load of this loop waits for every store before it (it falls back to
+            // vmcnt(0) around the predicated accesses).  s_waitcnt vmcnt(2) here leaves the newest load and the newest store
+            // in flight and is satisfied once the load issued two turns ago has landed, whether or not a fully masked store
+            // counts; store data is read when the store issues, so a buffer may be reloaded right after.
+            typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
+            rb_u32x4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
+            uint32_t d0 = 0xFFFFFFFFu, d1 = d0, d2 = d0, d3 = d0; // byte offset of the buffer's group in the region, or dead
+            const uint32_t n_turns = ((total >> 2) + 63u) >> 6;   // 64 groups per turn
+            auto turn = [&](uint32_t t, rb_u32x4 &bl, uint32_t &dl, rb_u32x4 &bs, uint32_t ds, rb_u32x4 &bx, rb_u32x4 &by) {
+                const uint32_t o = (t * 64u + (uint32_t)lane) * 4u; // region offset of this lane's group in turn t
+                while (o >= n_start) {                             // next clip (offsets are increasing)
+                    cj++;
+                    c_start = n_start;
+                    c_fg = et[1 * RB_ET + cj];
+                    c_lg = et[2 * RB_ET + cj];
+                    n_start = et[cj + 1];
                 }
-#pragma unroll
-                for (int u = 0; u < RB_EB; u++) {
-                    if (cpos[u] != 0xFFFFFFFFu) {
-                        const uint32_t o = (gb + (uint32_t)u * 64u + (uint32_t)lane) * 4u;
-                        const uint32_t j = cj[u];
-                        const uint32_t bl = et[4 * RB_HMAX + j];
-                        rb_emit_store(dst + (o - cpos[u]), cpos[u], et[2 * RB_HMAX + j], et[3 * RB_HMAX + j], bl & 0x7FFFFFFFu, (bl >> 31) != 0, v[u], p.debug_skip);
-                    }
-                }
+                const uint32_t c = c_fg + (o - c_start); // coordinate of the group's first op
+                const bool live = t < n_turns && o < total && c > c_fg && c < c_lg;
+                dl = live ? o * 4u : 0xFFFFFFFFu;
+                uint32_t src = (live ? c : c_fg) * 4u;
+                // (dead lanes re-read their clip's first group, which is in L2, and store nothing)
+                // (one asm body for every turn, the drain turns load with an empty exec mask: two variants would make the
+                //  compiler copy buffers between them while their loads are still in flight)
+                const unsigned long long lmask = rb_first64(t < n_turns ? ~0ull : 0ull); // (scalar register operand)
+                unsigned long long sv;
+                asm volatile("s_mov_b64 %[sv], exec\n\t"
+                             "s_and_b64 exec, %[sv], %[lmask]\n\t"
+                             "global_load_dwordx4 %[bl], %[src], %[sbase]\n\t"
+                             "s_mov_b64 exec, %[sv]\n\t"
+                             "s_waitcnt vmcnt(2)\n\t"
+                             "v_cmpx_ne_u32_e32 vcc, -1, %[ds]\n\t"
+                             "global_store_dwordx4 %[ds], %[bs], %[dbase]" RB_ST_NT "\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [bl] "+v"(bl), [sv] "=&s"(sv), [bs] "+v"(bs), [bx] "+v"(bx), [by] "+v"(by)
+                             : [src] "v"(src), [sbase] "s"(gsrc), [ds] "v"(ds), [dbase] "s"(region), [lmask] "s"(lmask)
+                             : "vcc", "memory");
+            };
+            for (uint32_t t0 = 0; t0 < n_turns + 2u; t0 += 4u) { // two extra turns drain the pipeline
+                turn(t0 + 0u, b0, d0, b2, d2, b1, b3);
+                turn(t0 + 1u, b1, d1, b3, d3, b0, b2);
+                turn(t0 + 2u, b2, d2, b0, d0, b1, b3);
+                turn(t0 + 3u, b3, d3, b1, d1, b0, b2);
             }
         }
     }
@@ -954,10 +781,15 @@ extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t
     hipLaunchKernelGGL(rb_k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, p->hit_off, p->n_rec, (const uint64_t *)block_sums, p->counters);
     return hipGetLastError();
 }
+extern "C" hipError_t rb_launch_make_jobs(const rb_lift_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_make_jobs, dim3((unsigned)((p->n_rec + 255) / 256)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
 
 extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream) {
-    if (p->n_rec == 0) return hipSuccess;
-    const unsigned blocks = (unsigned)((p->n_rec + 3) / 4);
+    if (p->n_rec == 0 || p->wave_end <= p->wave0) return hipSuccess;
+    const unsigned blocks = (unsigned)(((uint64_t)(p->wave_end - p->wave0) + 3) / 4);
     // diagnostics: RB_DEBUG_DYN_LDS=<bytes> adds unused dynamic LDS to lower the occupancy
     static const unsigned dyn = getenv("RB_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("RB_DEBUG_DYN_LDS")) : 0u;
     hipLaunchKernelGGL(rb_k_liftover_stream, dim3(blocks), dim3(256), dyn, stream, *p);

@@ -1,0 +1,328 @@
+// rb_lift.h -- parameters and device helpers of the liftover / break-paf clip kernels (k_liftover.hip; also included by
+// capi.hip for the launch parameters): window search, per-boundary resolution, the per-pass window setup.
+#pragma once
+#include "rb_device.h"
+#include <cstdlib>
+
+
+#define RB_HMAX 32            // hits resolved per streaming pass of one record (lanes 0-31 starts, 32-63 ends)
+#define RB_LDS_PER_HIT 6      // dwords of per-hit (start) state in LDS
+#define RB_ARENA_STRIDE 16    // u64 words between arena cursors (128 B)
+
+// One clip job per schedule slot, 64 bytes, written by rb_k_make_jobs after the hit scan: everything a wave needs to
+// start streaming its record arrives with one load instead of a chain of dependent ones (schedule -> record row ->
+// hit offsets -> window bounds).
+struct __attribute__((aligned(64))) rb_job {
+    uint64_t rec0;  // global index of the record's first kept op
+    uint32_t n;     // kept ops
+    uint32_t r;     // record
+    uint32_t h0;    // first hit row of the record (rows_cap < 2^32)
+    uint32_t flags; // RB_JOB_*
+    uint32_t nh;    // hits
+    uint32_t lo;    // first overlapping window (grouped index) of a monotone window list
+    uint64_t t_st, t_en, q_st, q_en; // normalised coordinates
+};
+enum { RB_JOB_VALID = 1, RB_JOB_REGULAR = 2, RB_JOB_MINUS = 4, RB_JOB_MONO = 8, RB_JOB_ROWS_OVERFLOW = 16 };
+
+struct rb_lift_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint32_t *contig;
+    const uint8_t *strand;
+    const rb_norm_row *norm;
+    // schedule
+    const uint32_t *sched;     // [n_rec] record handled by wave w (longest first)
+    const uint32_t *canon_pos; // [n_rec] position of record r in canonical order
+    // windows grouped by contig (BED order kept inside a contig) + original order
+    const uint64_t *w_st, *w_en; // grouped
+    const uint32_t *w_orig;      // grouped -> BED index
+    const uint64_t *wo_st, *wo_en; // BED order
+    const uint64_t *cw_off;    // [n_contig + 1]
+    const uint8_t *cw_mono;    // [n_contig]
+    uint32_t n_contig;
+    // explicit per-hit windows (break-paf); NULL for BED windows
+    const uint64_t *x_st, *x_en;
+    // rows
+    uint64_t *hit_off; // [n_rec + 1], canonical order; holds counts before the scan
+    uint32_t *win_lo;  // [n_rec] first overlapping window of a monotone slice (grouped index), by record
+    rb_hit_row *rows;
+    uint64_t rows_cap;
+    uint32_t *out_ops;
+    uint64_t out_cap;
+    // output arenas
+    unsigned long long *arena_cur; // [n_arena * RB_ARENA_STRIDE]
+    uint64_t arena_size;           // ops per arena (multiple of 4)
+    uint32_t n_arena;
+    // generic list
+    uint32_t *gen_list; // [rows_cap]
+    rb_counters *counters;
+    int policy;
+    int early_exit; // stop streaming a record once every boundary of the pass is resolved
+    int desc_mode;  // RB_LIFT_DESCRIPTORS: 4-word clip descriptors at out_ops[4 * row] instead of copied ops
+    uint64_t arena_origin; // first op of the arena area inside out_ops (descriptor mode: after the descriptors)
+    int debug_skip; // diagnostics only (wrong results): 1 = no emission, 2 = no resolution, 4 = no streaming
+    uint32_t wave0, wave_end; // slice of the schedule this launch covers (records are classed by length)
+    rb_job *jobs;             // [n_rec], schedule order
+};
+
+// ------------------------------------------------------------------------------------------------
+// hit counting: paf_overlaps_rgn (paf.rs:622-627) on the NORMALISED record (trim_helper runs
+// aligned_pairs, hence remove_trailing_indels, before the filter: liftover.rs:119-127)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rb_lower_en_gt(const uint64_t *w_en, uint64_t lo, uint64_t hi, uint64_t t_st) {
+    while (lo < hi) { // first idx with en > t_st (en non-decreasing)
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (w_en[mid] > t_st) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint64_t rb_lower_st_ge(const uint64_t *w_st, uint64_t lo, uint64_t hi, uint64_t t_en) {
+    while (lo < hi) { // first idx with st >= t_en (st non-decreasing)
+        uint64_t mid = lo + ((hi - lo) >> 1);
+        if (w_st[mid] >= t_en) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming kernel
+// ------------------------------------------------------------------------------------------------
+enum { RB_S_UNRES = 0, RB_S_OK = 1, RB_S_NONE = 2, RB_S_DEFER = 3 };
+
+// first/last set helpers on 64-bit masks
+__device__ __forceinline__ int rb_ffs64(unsigned long long m) { return __ffsll((long long)m) - 1; }
+
+// append every hit of a record to the generic list (record not eligible for the streaming path)
+__device__ inline void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_norm_row *nr, uint64_t h0, uint64_t nh,
+                                bool explicit_w, bool mono, uint64_t ws, uint64_t we, int lane) {
+    if (explicit_w || mono) {
+        uint64_t lo = 0;
+        if (!explicit_w) lo = rb_lower_en_gt(p.w_en, ws, we, nr->t_st);
+        for (uint64_t j = lane; j < nh; j += 64) {
+            const uint64_t h = h0 + j;
+            if (h < p.rows_cap) {
+                rb_hit_row *row = &p.rows[h];
+                row->rec = r;
+                row->win = explicit_w ? (uint32_t)j : p.w_orig[lo + j];
+                row->flags = RB_HIT_GENERIC;
+                const unsigned long long g = atomicAdd((unsigned long long *)&p.counters->n_generic, 1ull);
+                p.gen_list[g] = (uint32_t)h;
+            }
+        }
+    } else {
+        // non-monotone window list: enumerate in BED order, 64 windows per step
+        uint64_t done = 0;
+        for (uint64_t b = ws; b < we; b += 64) {
+            const uint64_t i = b + lane;
+            const bool hit = i < we && nr->t_en > p.w_st[i] && nr->t_st < p.w_en[i];
+            const unsigned long long ball = __ballot(hit);
+            if (hit) {
+                const uint64_t j = done + __popcll(ball & ((1ull << lane) - 1ull));
+                const uint64_t h = h0 + j;
+                if (h < p.rows_cap) {
+                    rb_hit_row *row = &p.rows[h];
+                    row->rec = r;
+                    row->win = p.w_orig[i];
+                    row->flags = RB_HIT_GENERIC;
+                    const unsigned long long g = atomicAdd((unsigned long long *)&p.counters->n_generic, 1ull);
+                    p.gen_list[g] = (uint32_t)h;
+                }
+            }
+            done += __popcll(ball);
+        }
+    }
+}
+
+// ---- lane-local boundary resolution --------------------------------------------------------------
+// One lane resolves one window boundary.  It starts from a checkpoint (exclusive prefixes R,Q,U at an
+// op index that is a multiple of 16, written to LDS by the streaming pass), walks at most 16 ops held
+// in registers to the reference-consuming op that contains offset D, then applies the reference's
+// tpos_to_idx + walk-to-match rules (paf.rs:541-561) with short look-ahead / look-back loads.
+struct rb_bres {
+    uint32_t st;            // RB_S_OK / NONE / DEFER
+    uint32_t op, part;      // op index; start: ops' remaining length (len - off), end: used length (off + 1)
+    uint32_t R, Q, U;       // start: exclusive counts at the unit; end: inclusive counts
+};
+
+#define RB_WALK_MAX 24
+
+// regular records only (M I D = X): ref = not I, query = not D
+__device__ __forceinline__ uint32_t rb_rl(uint32_t v) { return rb_opc(v) == RB_OP_I ? 0u : rb_len(v); }
+__device__ __forceinline__ uint32_t rb_ql(uint32_t v) { return rb_opc(v) == RB_OP_D ? 0u : rb_len(v); }
+__device__ __forceinline__ bool rb_ism(uint32_t v) { return rb_in(RB_MATCH_MASK, rb_opc(v)); }
+
+// ops[] = the record's kept ops, n of them.  (cR,cQ,cU) = prefixes at op index cidx (checkpoint).
+// D in [cR, next checkpoint's R) and D < Rtot.  is_start selects search-right (true) / search-left.
+__device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, uint32_t n, int32_t cidx, uint32_t cR, uint32_t cQ,
+                                              uint32_t cU, uint32_t D, bool is_start, int policy) {
+    rb_bres o;
+    o.st = RB_S_DEFER;
+    o.op = o.part = o.R = o.Q = o.U = 0;
+    // 16 ops of the checkpoint group (cidx may be negative by up to 3 in the aligned head: masked)
+    uint32_t g[16];
+    {
+        const uint4 *q = reinterpret_cast<const uint4 *>(ops + cidx); // 16-byte aligned by construction
+        const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+        g[0] = a0.x; g[1] = a0.y; g[2] = a0.z; g[3] = a0.w; g[4] = a1.x; g[5] = a1.y; g[6] = a1.z; g[7] = a1.w;
+        g[8] = a2.x; g[9] = a2.y; g[10] = a2.z; g[11] = a2.w; g[12] = a3.x; g[13] = a3.y; g[14] = a3.z; g[15] = a3.w;
+    }
+    // find the ref-consuming op f with Rx <= D < Rx + len
+    int32_t fi = -1;
+    uint32_t fv = 0, fR = 0, fQ = 0, fU = 0, pv = (RB_NULL_OP);
+    {
+        uint32_t R = cR, Q = cQ, U = cU, prev = RB_NULL_OP;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int32_t idx = cidx + k;
+            const bool valid = (uint32_t)idx < n;
+            const uint32_t v = valid ? g[k] : RB_NULL_OP;
+            const uint32_t rl = valid ? rb_rl(v) : 0u;
+            if (fi < 0 && rl != 0 && (uint32_t)(D - R) < rl) {
+                fi = idx;
+                fv = v;
+                fR = R;
+                fQ = Q;
+                fU = U;
+                pv = prev;
+            }
+            R += rl;
+            Q += valid ? rb_ql(v) : 0u;
+            U += valid ? rb_len(v) : 0u;
+            if (valid) prev = v;
+        }
+    }
+    if (fi < 0) return o; // should not happen; the generic kernel sorts it out
+    if (fi > 0 && pv == RB_NULL_OP) pv = ops[fi - 1]; // previous op lives in the group before
+    const uint32_t off = D - fR;
+    if (is_start) {
+        int32_t X; // first match-type op with index >= X
+        if (off > 0) { // the boundary base and the next base share op f
+            if (rb_ism(fv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = rb_len(fv) - (off - 1), o.R = fR + off - 1, o.Q = fQ + off - 1, o.U = fU + off - 1;
+                return o;
+            }
+            X = fi + 1;
+        } else { // boundary base is the last unit before op f: the last equal element is the unit before f
+            if (fi > 0 && rb_ism(pv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = 1u, o.R = fR - 1, o.Q = fQ - 1, o.U = fU - 1;
+                return o;
+            }
+            // duplicates in tpos_aln (units of an insertion share the boundary's tpos): which one
+            // binary_search returns depends on the Rust std generation -> generic kernel decides
+            if (policy == RB_BSEARCH_LEGACY && fi > 0 && rb_opc(pv) == RB_OP_I) return o;
+            X = fi;
+        }
+        // walk right (paf.rs:551-553) from op fi
+        uint32_t R = fR, Q = fQ, U = fU;
+        uint32_t v = fv;
+        int32_t i = fi;
+        for (int t = 0; t < RB_WALK_MAX; t++) {
+            if (i >= X && rb_ism(v)) {
+                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
+                return o;
+            }
+            R += rb_rl(v);
+            Q += rb_ql(v);
+            U += rb_len(v);
+            i++;
+            if ((uint32_t)i >= n) {
+                o.st = RB_S_NONE; // ran off the end: start_idx == N (liftover.rs:52)
+                return o;
+            }
+            v = ops[i];
+        }
+        return o; // too far: generic
+    } else {
+        int32_t Y; // last match-type op with index <= Y
+        if (off > 0) {
+            if (rb_ism(fv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = off, o.R = D, o.Q = fQ + off, o.U = fU + off;
+                return o;
+            }
+            Y = fi - 1;
+        } else {
+            if (fi > 0 && rb_ism(pv)) {
+                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = rb_len(pv), o.R = fR, o.Q = fQ, o.U = fU;
+                return o;
+            }
+            Y = fi - 2;
+        }
+        // walk left (paf.rs:555-557): (R,Q,U) are the prefixes at the END of op i
+        uint32_t R = fR, Q = fQ, U = fU;
+        int32_t i = fi - 1;
+        for (int t = 0; t < RB_WALK_MAX; t++) {
+            if (i < 0) {
+                o.st = RB_S_NONE; // stops at unit 0, which lies before any start
+                return o;
+            }
+            const uint32_t v = ops[i];
+            if (i <= Y && rb_ism(v)) {
+                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
+                return o;
+            }
+            R -= rb_rl(v);
+            Q -= rb_ql(v);
+            U -= rb_len(v);
+            i--;
+        }
+        return o;
+    }
+}
+
+
+// ---- windows of one pass ---------------------------------------------------------------------------
+// Lanes j and j + 32 both receive window jb + j of the record (lane j resolves its start boundary, lane
+// j + 32 its end boundary).  Monotone window lists and explicit (break-paf) windows are indexed directly;
+// windows of a contig that are not sorted are collected in BED order, 64 candidates per ballot, with the
+// same test as rb_k_count_hits so the counts agree.  widx = RB_HMAX words of LDS scratch of this wave.
+struct rb_pass_win {
+    uint64_t wst, wen;
+    uint32_t win;
+};
+__device__ __forceinline__ rb_pass_win rb_pass_windows(const rb_lift_params &p, uint32_t *widx, bool explicit_w, bool mono, uint64_t ws,
+                                                       uint64_t we, uint64_t lo, uint64_t h0, uint64_t jb, uint32_t nb, uint64_t t_st,
+                                                       uint64_t t_en, uint64_t &scan_pos, int lane) {
+    rb_pass_win o;
+    o.wst = o.wen = 0;
+    o.win = 0;
+    const uint32_t hl = (uint32_t)lane & 31u;
+    const bool own = hl < nb;
+    if (!explicit_w && !mono) {
+        uint32_t filled = 0;
+        while (filled < nb && scan_pos < we) {
+            const uint64_t i = scan_pos + (uint64_t)lane;
+            const bool hit = i < we && t_en > p.w_st[i] && t_st < p.w_en[i];
+            const unsigned long long ball = __ballot(hit);
+            const uint32_t room = nb - filled, cnt = (uint32_t)__popcll(ball);
+            const uint32_t rank = (uint32_t)__popcll(ball & ((1ull << lane) - 1ull));
+            if (hit && rank < room) widx[filled + rank] = (uint32_t)(i - ws);
+            if (cnt <= room) {
+                filled += cnt;
+                scan_pos += 64;
+            } else { // the pass is full: resume after the room-th hit next time
+                unsigned long long m = ball;
+                for (uint32_t q = 1; q < room; q++) m &= m - 1;
+                scan_pos += (uint64_t)rb_ffs64(m) + 1u;
+                filled += room;
+            }
+        }
+        if (own) {
+            const uint64_t idx = ws + widx[hl];
+            o.wst = p.w_st[idx];
+            o.wen = p.w_en[idx];
+            o.win = p.w_orig[idx];
+        }
+    } else if (own) {
+        if (explicit_w) {
+            o.wst = p.x_st[h0 + jb + hl];
+            o.wen = p.x_en[h0 + jb + hl];
+            o.win = (uint32_t)(jb + hl);
+        } else {
+            o.wst = p.w_st[lo + jb + hl];
+            o.wen = p.w_en[lo + jb + hl];
+            o.win = p.w_orig[lo + jb + hl];
+        }
+    }
+    return o;
+}
