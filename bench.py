@@ -187,7 +187,8 @@ def main():
     k_ms = float(np.mean(kern_ms[-args.steps:])) if kern_ms else float("nan")
     if kern_ms and os.environ.get("RB_BENCH_VERBOSE"):  # experiments: the spread of the per-step clip-kernel times
         ks = np.sort(np.asarray(kern_ms[-args.steps:]))
-        print(f"[kernel ms] min {ks[0]:.3f}  median {ks[len(ks) // 2]:.3f}  mean {ks.mean():.3f}  max {ks[-1]:.3f}", file=sys.stderr)
+        print(f"[kernel ms] min {ks[0]:.3f}  median {ks[len(ks) // 2]:.3f}  mean {ks.mean():.3f}  max {ks[-1]:.3f}"
+              f"  | out_cap {out_cap} rows_cap {rows_cap} d_out 0x{d_out.data_ptr():x} d_ops 0x{d_ops.data_ptr():x}", file=sys.stderr)
     if args.op == "break":
         k_ms = elapsed / args.steps * 1e3
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9

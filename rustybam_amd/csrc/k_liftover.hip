@@ -485,17 +485,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
             }
             if (lane == 0) et[0 * RB_ET + nb] = 0xFFFFFFFFu; // sentinel (the table has RB_HMAX + 1 slots)
             uint32_t cj = 0, c_start = et[0], c_fg = et[1 * RB_ET], c_lg = et[2 * RB_ET], n_start = et[1];
-            // Four buffers of one group per lane rotate: turn t loads the group of turn t into buffer t % 4 and stores the
-            // group loaded two turns earlier.  The load / wait / store triple is written by hand: vmcnt retires in order on
-            // gfx9, and left to the compiler every load of this loop waits for every store before it (it falls back to
-            // vmcnt(0) around the predicated accesses).  s_waitcnt vmcnt(2) here leaves the newest load and the newest store
-            // in flight and is satisfied once the load issued two turns ago has landed, whether or not a fully masked store
-            // counts; store data is read when the store issues, so a buffer may be reloaded right after.
+            // RB_EB buffers of one group per lane rotate: turn t loads the group of turn t into buffer t % RB_EB and stores
+            // the group loaded RB_EB - 1 turns earlier.  The load / wait / store triple is written by hand: vmcnt retires in
+            // order on gfx9, and left to the compiler every load of this loop waits for every store before it (it falls back
+            // to vmcnt(0) around the predicated accesses).  Between the load of turn t - K (K = RB_EB - 1) and the wait of
+            // turn t exactly 2K vector-memory instructions are issued (K loads, K stores; instructions issued with an empty
+            // exec mask count too, tools/vmcnt_probe.hip), so s_waitcnt vmcnt(2K) is satisfied exactly when that load has
+            // landed and leaves K loads and K stores in flight.  Store data is read when the store issues, so a buffer may be
+            // reloaded right after.
             typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
-            rb_u32x4 b0 = {0, 0, 0, 0}, b1 = b0, b2 = b0, b3 = b0;
+            const rb_u32x4 z4 = {0, 0, 0, 0};
+            rb_u32x4 b0 = z4, b1 = z4, b2 = z4, b3 = z4;
             uint32_t d0 = 0xFFFFFFFFu, d1 = d0, d2 = d0, d3 = d0; // byte offset of the buffer's group in the region, or dead
-            const uint32_t n_turns = ((total >> 2) + 63u) >> 6;   // 64 groups per turn
-            auto turn = [&](uint32_t t, rb_u32x4 &bl, uint32_t &dl, rb_u32x4 &bs, uint32_t ds, rb_u32x4 &bx, rb_u32x4 &by) {
+#if RB_EB == 6
+            rb_u32x4 b4 = z4, b5 = z4;
+            uint32_t d4 = d0, d5 = d0;
+#define RB_PIN_BUFS [p0] "+v"(b0), [p1] "+v"(b1), [p2] "+v"(b2), [p3] "+v"(b3), [p4] "+v"(b4), [p5] "+v"(b5)
+#define RB_EMIT_WAIT "s_waitcnt vmcnt(10)\n\t"
+#elif RB_EB == 4
+#define RB_PIN_BUFS [p0] "+v"(b0), [p1] "+v"(b1), [p2] "+v"(b2), [p3] "+v"(b3)
+#define RB_EMIT_WAIT "s_waitcnt vmcnt(6)\n\t"
+#else
+#error "RB_EB must be 4 or 6"
+#endif
+            const uint32_t n_turns = ((total >> 2) + 63u) >> 6; // 64 groups per turn
+            // address work of turn t: the group this lane loads, and where it goes
+            auto plan = [&](uint32_t t, uint32_t &dl) -> uint32_t {
                 const uint32_t o = (t * 64u + (uint32_t)lane) * 4u; // region offset of this lane's group in turn t
                 while (o >= n_start) {                             // next clip (offsets are increasing)
                     cj++;
@@ -507,30 +522,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                 const uint32_t c = c_fg + (o - c_start); // coordinate of the group's first op
                 const bool live = t < n_turns && o < total && c > c_fg && c < c_lg;
                 dl = live ? o * 4u : 0xFFFFFFFFu;
-                uint32_t src = (live ? c : c_fg) * 4u;
-                // (dead lanes re-read their clip's first group, which is in L2, and store nothing)
-                // (one asm body for every turn, the drain turns load with an empty exec mask: two variants would make the
-                //  compiler copy buffers between them while their loads are still in flight)
-                const unsigned long long lmask = rb_first64(t < n_turns ? ~0ull : 0ull); // (scalar register operand)
-                unsigned long long sv;
-                asm volatile("s_mov_b64 %[sv], exec\n\t"
-                             "s_and_b64 exec, %[sv], %[lmask]\n\t"
-                             "global_load_dwordx4 %[bl], %[src], %[sbase]\n\t"
-                             "s_mov_b64 exec, %[sv]\n\t"
-                             "s_waitcnt vmcnt(2)\n\t"
-                             "v_cmpx_ne_u32_e32 vcc, -1, %[ds]\n\t"
-                             "global_store_dwordx4 %[ds], %[bs], %[dbase]" RB_ST_NT "\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [bl] "+v"(bl), [sv] "=&s"(sv), [bs] "+v"(bs), [bx] "+v"(bx), [by] "+v"(by)
-                             : [src] "v"(src), [sbase] "s"(gsrc), [ds] "v"(ds), [dbase] "s"(region), [lmask] "s"(lmask)
-                             : "vcc", "memory");
+                return (live ? c : c_fg) * 4u; // (dead lanes re-read their clip's first group, which is in L2, and store nothing)
             };
-            for (uint32_t t0 = 0; t0 < n_turns + 2u; t0 += 4u) { // two extra turns drain the pipeline
-                turn(t0 + 0u, b0, d0, b2, d2, b1, b3);
-                turn(t0 + 1u, b1, d1, b3, d3, b0, b2);
-                turn(t0 + 2u, b2, d2, b0, d0, b1, b3);
-                turn(t0 + 3u, b3, d3, b1, d1, b0, b2);
+            // (one asm body for every turn, the drain turns load with an empty exec mask: two variants would make the
+            //  compiler copy buffers between them while their loads are still in flight)
+#define RB_EMIT_TURN(T, L, DL, S, DS)                                                                                          \
+    {                                                                                                                          \
+        const uint32_t t_ = (T);                                                                                               \
+        const uint32_t src_ = plan(t_, DL);                                                                                    \
+        const unsigned long long lmask_ = rb_first64(t_ < n_turns ? ~0ull : 0ull); /* (scalar register operand) */             \
+        unsigned long long sv_;                                                                                                \
+        asm volatile("s_mov_b64 %[sv], exec\n\t"                                                                               \
+                     "s_and_b64 exec, %[sv], %[lmask]\n\t"                                                                     \
+                     "global_load_dwordx4 %[p" #L "], %[src], %[sbase]\n\t"                                                     \
+                     "s_mov_b64 exec, %[sv]\n\t" RB_EMIT_WAIT "v_cmpx_ne_u32_e32 vcc, -1, %[ds]\n\t"                           \
+                     "global_store_dwordx4 %[ds], %[p" #S "], %[dbase]" RB_ST_NT "\n\t"                                          \
+                     "s_mov_b64 exec, %[sv]"                                                                                   \
+                     : [sv] "=&s"(sv_), RB_PIN_BUFS                                                                            \
+                     : [src] "v"(src_), [sbase] "s"(gsrc), [ds] "v"(DS), [dbase] "s"(region), [lmask] "s"(lmask_)              \
+                     : "vcc", "memory");                                                                                       \
+    }
+            for (uint32_t t0 = 0; t0 < n_turns + (RB_EB - 1); t0 += RB_EB) { // RB_EB - 1 extra turns drain the pipeline
+#if RB_EB == 6
+                RB_EMIT_TURN(t0 + 0u, 0, d0, 1, d1)
+                RB_EMIT_TURN(t0 + 1u, 1, d1, 2, d2)
+                RB_EMIT_TURN(t0 + 2u, 2, d2, 3, d3)
+                RB_EMIT_TURN(t0 + 3u, 3, d3, 4, d4)
+                RB_EMIT_TURN(t0 + 4u, 4, d4, 5, d5)
+                RB_EMIT_TURN(t0 + 5u, 5, d5, 0, d0)
+#else
+                RB_EMIT_TURN(t0 + 0u, 0, d0, 1, d1)
+                RB_EMIT_TURN(t0 + 1u, 1, d1, 2, d2)
+                RB_EMIT_TURN(t0 + 2u, 2, d2, 3, d3)
+                RB_EMIT_TURN(t0 + 3u, 3, d3, 0, d0)
+#endif
             }
+#undef RB_EMIT_TURN
+#undef RB_PIN_BUFS
+#undef RB_EMIT_WAIT
         }
     }
 }
