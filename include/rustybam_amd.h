@@ -151,6 +151,9 @@ typedef struct rb_counters { /* device-written job summary, 64 bytes */
     uint32_t _pad[7];
 } rb_counters;
 
+/* per-record outcome of rb_dev_parse_cigars */
+enum { RB_TEXT_OK = 0, RB_TEXT_BAD = 1 /* the reference's "Unable to parse cigar string." panic */, RB_TEXT_TOO_LONG = 2 /* a length >= 2^28 */ };
+
 /* ---- views over caller-owned device memory ---------------------------------------------------- */
 typedef struct rb_batch_view {
     uint64_t n_rec, n_ops;
@@ -263,6 +266,48 @@ int rb_host_overlap_split(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, cons
                           uint64_t n_pairs, const uint32_t *left, const uint32_t *right, int match_score, int diff_score,
                           int indel_score, int bsearch_policy, rb_pair_row *rows, uint32_t **out_ops, uint64_t *n_out);
 void rb_host_free(void *p);
+
+/* ---- CIGAR text <-> packed ops on the device (the data format either side of the path) ----------
+ *
+ * rb_dev_parse_cigars   <- CigarString::try_from(value.as_bytes()).expect(..)       paf.rs:398-399
+ *     text      device bytes holding the CIGAR strings of n_rec records (the `cg:Z:` values, without the tag);
+ *               16-byte aligned, readable up to the next multiple of 16 past the last string
+ *     text_off  [n_rec + 1] start of every string;  text_end [n_rec] or NULL (NULL: strings are back to back)
+ *     op_off    [n_rec + 1] OUT  exclusive prefix of ops per record (op_off[n_rec] = total)
+ *     ops       OUT, capacity ops_cap (total text bytes / 2 is always enough: an op is at least two characters)
+ *     status    [n_rec] OUT  RB_TEXT_OK / RB_TEXT_BAD (the reference panics: "Unable to parse cigar string.") /
+ *               RB_TEXT_TOO_LONG (a length >= 2^28 cannot be packed; the reference would go on)
+ *     scratch   rb_text_scratch_bytes(n_rec) bytes
+ * rb_dev_format_cigars  <- impl Display for CigarString inside impl Display for PafRecord   paf.rs:923-944
+ *     item i prints ops[first[i] .. first[i] + count[i]) as <len><op>...; first_len / last_len (arrays or NULL,
+ *     0 = keep) replace the length of the first / last op -- the clip descriptors of RB_LIFT_DESCRIPTORS:
+ *     {first kept op, op count, first length, last length}; a one-op item with both prints first + last - len.
+ *     ops_alt   optional second source array: an item whose first[] has bit 63 set takes its ops from ops_alt[]
+ *               (clips the generic kernel copied out live in out_ops[], descriptor clips point into the batch)
+ *     text_off  [n_items + 1] OUT exclusive prefix of bytes;  text OUT (NULL: sizes only), capacity text_cap
+ *               (11 bytes per op suffice)
+ * rb_host_liftover_text: liftover from CIGAR text to CIGAR text.  text holds the records' `cg:Z:` values at
+ *     [cig_off[r], cig_end[r]); they are parsed on the device (cig_status[r] = RB_TEXT_*; if any is not OK nothing else
+ *     is computed), scanned (reduce_out / norm_out, either may be NULL), lifted over the windows in descriptor mode, and the
+ *     clipped CIGAR of every hit row is printed on the device: row k's text is row_text[row_text_off[k] .. [k + 1]) (empty
+ *     for rows whose status is not RB_ST_OK).  rows / row_text_off / row_text are malloc'ed (rb_host_free).
+ */
+size_t rb_text_scratch_bytes(uint64_t n);
+int rb_dev_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_end, uint64_t n_rec,
+                        uint64_t *op_off, uint32_t *ops, uint64_t ops_cap, uint8_t *status, void *scratch);
+int rb_dev_format_cigars(rb_ctx *ctx, const uint32_t *ops, const uint32_t *ops_alt, uint64_t n_items, const uint64_t *first,
+                         const uint32_t *count, const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off, uint8_t *text,
+                         uint64_t text_cap, void *scratch);
+/* host-buffer forms: H2D, kernels, D2H.  *ops / *text are malloc'ed (rb_host_free) */
+int rb_host_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_end, uint64_t n_rec,
+                         uint64_t *op_off, uint32_t **ops, uint8_t *status);
+int rb_host_format_cigars(rb_ctx *ctx, const uint32_t *ops, uint64_t n_ops, uint64_t n_items, const uint64_t *first, const uint32_t *count,
+                          const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off, uint8_t **text);
+int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off,
+                          const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
+                          const uint8_t *strand, const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
+                          const uint64_t *w_en, int bsearch_policy, uint8_t *cig_status, rb_reduce_row *reduce_out, rb_norm_row *norm_out,
+                          rb_hit_row **rows, uint64_t *n_rows, uint64_t **row_text_off, uint8_t **row_text, rb_counters *counters);
 
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and

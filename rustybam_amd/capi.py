@@ -257,6 +257,50 @@ class Engine:
         self._chk(self.L.rb_host_swap(self.ctx, C.c_uint64(n), _p(src), _p(op_off), _p(s), _p(out)), "rb_host_swap")
         return out[:len(ops)]
 
+    # ---- CIGAR text <-> packed ops (k_text.hip) ----
+    def parse_cigars(self, cigars):
+        """cigars: list of bytes / str (the cg:Z: values).  Returns (op_off, ops, status)."""
+        bs = [c.encode() if isinstance(c, str) else bytes(c) for c in cigars]
+        off = np.zeros(len(bs) + 1, np.uint64)
+        if bs:
+            off[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+        text = np.frombuffer(b"".join(bs) + b"\0" * 32, dtype=np.uint8).copy()
+        return self.parse_cigar_text(text, off, None)
+
+    def parse_cigar_text(self, text, text_off, text_end=None):
+        text, text_off = _arr(text, np.uint8), _arr(text_off, np.uint64)
+        n = len(text_off) - 1
+        end = None if text_end is None else _arr(text_end, np.uint64)
+        op_off = np.zeros(n + 1, np.uint64)
+        status = np.zeros(max(n, 1), np.uint8)
+        out = C.c_void_p()
+        self._chk(self.L.rb_host_parse_cigars(self.ctx, _p(text), _p(text_off), _p(end) if end is not None else None,
+                                              C.c_uint64(n), _p(op_off), C.byref(out), _p(status)), "rb_host_parse_cigars")
+        n_ops = int(op_off[n])
+        if n_ops:
+            ops = np.frombuffer((C.c_char * (n_ops * 4)).from_address(out.value), dtype=np.uint32).copy()
+        else:
+            ops = np.zeros(0, np.uint32)
+        self.L.rb_host_free(out)
+        return op_off, ops, status[:n]
+
+    def format_cigars(self, ops, first, count, first_len=None, last_len=None):
+        """Items = runs ops[first[i] : first[i] + count[i]] with optional clipped first / last lengths.  Returns (text_off, text)."""
+        ops, first, count = _arr(ops, np.uint32), _arr(first, np.uint64), _arr(count, np.uint32)
+        n = len(first)
+        fl = None if first_len is None else _arr(first_len, np.uint32)
+        ll = None if last_len is None else _arr(last_len, np.uint32)
+        toff = np.zeros(n + 1, np.uint64)
+        out = C.c_void_p()
+        src = np.concatenate([ops, np.zeros(4, np.uint32)])
+        self._chk(self.L.rb_host_format_cigars(self.ctx, _p(src), C.c_uint64(len(ops)), C.c_uint64(n), _p(first), _p(count),
+                                               _p(fl) if fl is not None else None, _p(ll) if ll is not None else None, _p(toff),
+                                               C.byref(out)), "rb_host_format_cigars")
+        nb = int(toff[n])
+        text = bytes((C.c_char * nb).from_address(out.value)) if nb else b""
+        self.L.rb_host_free(out)
+        return toff, text
+
 
 def synth_n_ops(seed, first_record, n_rec, lo, hi):
     L = lib()

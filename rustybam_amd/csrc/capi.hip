@@ -62,6 +62,31 @@ struct rb_swap_params {
 
 extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream);
+struct rb_parse_params {
+    uint64_t n_rec;
+    const uint8_t *text;
+    const uint64_t *text_off;
+    const uint64_t *text_end;
+    uint64_t *op_off;
+    uint32_t *ops;
+    uint64_t ops_cap;
+    uint8_t *status;
+};
+struct rb_format_params {
+    uint64_t n_items;
+    const uint32_t *ops;
+    const uint32_t *ops_alt;
+    const uint64_t *first;
+    const uint32_t *count;
+    const uint32_t *first_len;
+    const uint32_t *last_len;
+    uint64_t *text_off;
+    uint8_t *text;
+    uint64_t text_cap;
+};
+extern "C" hipError_t rb_launch_parse_cigars(const rb_parse_params *p, bool fill, hipStream_t stream);
+extern "C" hipError_t rb_launch_format_cigars(const rb_format_params *p, bool fill, hipStream_t stream);
+extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t *block_sums, uint64_t *total_out, hipStream_t stream);
 extern "C" hipError_t rb_launch_make_jobs(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream);
@@ -497,6 +522,51 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     return RB_OK;
 }
 
+// ---- CIGAR text ----------------------------------------------------------------------------------
+extern "C" size_t rb_text_scratch_bytes(uint64_t n) { return (rb_scan_block_sums_count(n) + 4) * 8; }
+extern "C" int rb_dev_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_end, uint64_t n_rec,
+                                   uint64_t *op_off, uint32_t *ops, uint64_t ops_cap, uint8_t *status, void *scratch) {
+    if (!ctx || !text_off || !op_off || !status || !scratch || (n_rec && !text)) return RB_E_INVALID;
+    if (((uintptr_t)text & 15u) != 0) return fail(ctx, RB_E_INVALID, "text must be 16-byte aligned");
+    rb_parse_params p;
+    p.n_rec = n_rec;
+    p.text = text;
+    p.text_off = text_off;
+    p.text_end = text_end;
+    p.op_off = op_off;
+    p.ops = ops;
+    p.ops_cap = ops_cap;
+    p.status = status;
+    HIPCHK(ctx, hipMemsetAsync(op_off + n_rec, 0, 8, ctx->stream));
+    if (n_rec == 0) return RB_OK;
+    HIPCHK(ctx, rb_launch_parse_cigars(&p, false, ctx->stream));
+    HIPCHK(ctx, rb_launch_exclusive_scan(op_off, n_rec, (uint64_t *)scratch, nullptr, ctx->stream));
+    HIPCHK(ctx, rb_launch_parse_cigars(&p, true, ctx->stream));
+    return RB_OK;
+}
+extern "C" int rb_dev_format_cigars(rb_ctx *ctx, const uint32_t *ops, const uint32_t *ops_alt, uint64_t n_items, const uint64_t *first,
+                                    const uint32_t *count, const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off,
+                                    uint8_t *text, uint64_t text_cap, void *scratch) {
+    if (!ctx || !text_off || !scratch || (n_items && (!ops || !first || !count))) return RB_E_INVALID;
+    rb_format_params p;
+    p.n_items = n_items;
+    p.ops = ops;
+    p.ops_alt = ops_alt;
+    p.first = first;
+    p.count = count;
+    p.first_len = first_len;
+    p.last_len = last_len;
+    p.text_off = text_off;
+    p.text = text;
+    p.text_cap = text_cap;
+    HIPCHK(ctx, hipMemsetAsync(text_off + n_items, 0, 8, ctx->stream));
+    if (n_items == 0) return RB_OK;
+    HIPCHK(ctx, rb_launch_format_cigars(&p, false, ctx->stream));
+    HIPCHK(ctx, rb_launch_exclusive_scan(text_off, n_items, (uint64_t *)scratch, nullptr, ctx->stream));
+    if (text) HIPCHK(ctx, rb_launch_format_cigars(&p, true, ctx->stream));
+    return RB_OK;
+}
+
 // ---- host-buffer wrappers ----------------------------------------------------------------------
 namespace {
 struct DevBatch {
@@ -713,6 +783,248 @@ extern "C" int rb_host_break(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, c
                              uint64_t *n_out, rb_counters *counters) {
     return host_lift(ctx, true, max_size, n_rec, ops, op_off, t_st, t_en, q_st, q_en, strand, nullptr, 0, nullptr, nullptr, nullptr,
                      policy, norm_out, rows, n_rows, out_ops, n_out, counters);
+}
+
+extern "C" int rb_host_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_end, uint64_t n_rec,
+                                    uint64_t *op_off, uint32_t **ops, uint8_t *status) {
+    if (!ctx || !text_off || !op_off || !ops || !status) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *ops = nullptr;
+    uint64_t text_bytes = 0;
+    for (uint64_t r = 0; r < n_rec; r++) text_bytes = std::max(text_bytes, text_end ? text_end[r] : text_off[r + 1]);
+    DevBatch b(ctx);
+    const uint8_t *d_text = nullptr;
+    const uint64_t *d_off = nullptr, *d_end = nullptr;
+    uint64_t *d_opoff = nullptr;
+    uint32_t *d_ops = nullptr;
+    uint8_t *d_status = nullptr;
+    void *d_scr = nullptr;
+    int rc;
+    {
+        uint8_t *t = nullptr;
+        if ((rc = b.alloc((size_t)text_bytes + 32, &t))) return rc;
+        if (text_bytes && (rc = rb_dev_upload(ctx, t, text, (size_t)text_bytes))) return rc;
+        d_text = t;
+    }
+    if ((rc = b.up(text_off, (size_t)n_rec + 1, &d_off))) return rc;
+    if (text_end && (rc = b.up(text_end, (size_t)n_rec, &d_end))) return rc;
+    const uint64_t ops_cap = text_bytes / 2 + 4;
+    if ((rc = b.alloc((size_t)n_rec + 2, &d_opoff))) return rc;
+    if ((rc = b.alloc((size_t)ops_cap, &d_ops))) return rc;
+    if ((rc = b.alloc((size_t)n_rec + 1, &d_status))) return rc;
+    if ((rc = b.alloc(rb_text_scratch_bytes(n_rec), (uint8_t **)&d_scr))) return rc;
+    if ((rc = rb_dev_parse_cigars(ctx, d_text, d_off, d_end, n_rec, d_opoff, d_ops, ops_cap, d_status, d_scr))) return rc;
+    if ((rc = rb_dev_download(ctx, op_off, d_opoff, ((size_t)n_rec + 1) * 8))) return rc;
+    if (n_rec && (rc = rb_dev_download(ctx, status, d_status, (size_t)n_rec))) return rc;
+    const uint64_t n_ops = op_off[n_rec];
+    *ops = (uint32_t *)malloc(((size_t)n_ops + 4) * 4);
+    if (!*ops) return fail(ctx, RB_E_NOMEM, "malloc(%llu ops)", (unsigned long long)n_ops);
+    if (n_ops) return rb_dev_download(ctx, *ops, d_ops, (size_t)n_ops * 4);
+    return RB_OK;
+}
+extern "C" int rb_host_format_cigars(rb_ctx *ctx, const uint32_t *ops, uint64_t n_ops, uint64_t n_items, const uint64_t *first,
+                                     const uint32_t *count, const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off,
+                                     uint8_t **text) {
+    if (!ctx || !text_off || !text || (n_items && (!first || !count))) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *text = nullptr;
+    for (uint64_t i = 0; i < n_items; i++)
+        if (first[i] + count[i] > n_ops) return fail(ctx, RB_E_INVALID, "item %llu reaches past the ops", (unsigned long long)i);
+    DevBatch b(ctx);
+    const uint32_t *d_ops = nullptr, *d_count = nullptr, *d_fl = nullptr, *d_ll = nullptr;
+    const uint64_t *d_first = nullptr;
+    uint64_t *d_toff = nullptr;
+    uint8_t *d_text = nullptr;
+    void *d_scr = nullptr;
+    int rc;
+    if ((rc = b.up(ops, (size_t)n_ops, &d_ops))) return rc;
+    if ((rc = b.up(first, (size_t)n_items, &d_first))) return rc;
+    if ((rc = b.up(count, (size_t)n_items, &d_count))) return rc;
+    if (first_len && (rc = b.up(first_len, (size_t)n_items, &d_fl))) return rc;
+    if (last_len && (rc = b.up(last_len, (size_t)n_items, &d_ll))) return rc;
+    if ((rc = b.alloc((size_t)n_items + 2, &d_toff))) return rc;
+    if ((rc = b.alloc(rb_text_scratch_bytes(n_items), (uint8_t **)&d_scr))) return rc;
+    if ((rc = rb_dev_format_cigars(ctx, d_ops, nullptr, n_items, d_first, d_count, d_fl, d_ll, d_toff, nullptr, 0, d_scr))) return rc; // sizes
+    if ((rc = rb_dev_download(ctx, text_off, d_toff, ((size_t)n_items + 1) * 8))) return rc;
+    const uint64_t bytes = text_off[n_items];
+    if ((rc = b.alloc((size_t)bytes + 16, &d_text))) return rc;
+    if ((rc = rb_dev_format_cigars(ctx, d_ops, nullptr, n_items, d_first, d_count, d_fl, d_ll, d_toff, d_text, bytes, d_scr))) return rc;
+    *text = (uint8_t *)malloc((size_t)bytes + 16);
+    if (!*text) return fail(ctx, RB_E_NOMEM, "malloc(%llu text bytes)", (unsigned long long)bytes);
+    if (bytes) return rb_dev_download(ctx, *text, d_text, (size_t)bytes);
+    return RB_OK;
+}
+
+extern "C" int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off,
+                                     const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st,
+                                     const uint64_t *q_en, const uint8_t *strand, const uint32_t *contig, uint64_t n_win,
+                                     const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en, int policy, uint8_t *cig_status,
+                                     rb_reduce_row *reduce_out, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows,
+                                     uint64_t **row_text_off, uint8_t **row_text, rb_counters *counters) {
+    if (!ctx || !cig_off || !cig_end || !cig_status || !rows || !n_rows || !row_text_off || !row_text) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    *rows = nullptr;
+    *row_text_off = nullptr;
+    *row_text = nullptr;
+    *n_rows = 0;
+    DevBatch b(ctx);
+    int rc;
+    double tl = rb_now_s();
+    // ---- text -> ops on the device ----
+    uint8_t *d_text = nullptr, *d_status = nullptr;
+    const uint64_t *d_coff = nullptr, *d_cend = nullptr;
+    uint64_t *d_opoff = nullptr;
+    uint32_t *d_ops = nullptr;
+    void *d_scr = nullptr;
+    if ((rc = b.alloc((size_t)text_bytes + 32, &d_text))) return rc;
+    if (text_bytes && (rc = rb_dev_upload(ctx, d_text, text, (size_t)text_bytes))) return rc;
+    if ((rc = b.up(cig_off, (size_t)n_rec, &d_coff))) return rc;
+    if ((rc = b.up(cig_end, (size_t)n_rec, &d_cend))) return rc;
+    uint64_t cig_bytes = 0;
+    for (uint64_t r = 0; r < n_rec; r++) {
+        if (cig_end[r] < cig_off[r] || cig_end[r] > text_bytes) return fail(ctx, RB_E_INVALID, "record %llu: CIGAR range outside the text", (unsigned long long)r);
+        cig_bytes += cig_end[r] - cig_off[r];
+    }
+    const uint64_t ops_cap = cig_bytes / 2 + 8;
+    if ((rc = b.alloc((size_t)n_rec + 2, &d_opoff))) return rc;
+    if ((rc = b.alloc((size_t)ops_cap + 4, &d_ops))) return rc;
+    if ((rc = b.alloc((size_t)n_rec + 1, &d_status))) return rc;
+    if ((rc = b.alloc(rb_text_scratch_bytes(n_rec), (uint8_t **)&d_scr))) return rc;
+    rb_lap("H2D text", tl);
+    if ((rc = rb_dev_parse_cigars(ctx, d_text, d_coff, d_cend, n_rec, d_opoff, d_ops, ops_cap, d_status, d_scr))) return rc;
+    if (n_rec && (rc = rb_dev_download(ctx, cig_status, d_status, (size_t)n_rec))) return rc;
+    for (uint64_t r = 0; r < n_rec; r++)
+        if (cig_status[r] != RB_TEXT_OK) return RB_OK; // the caller reports it (the reference panics at paf.rs:399)
+    std::vector<uint64_t> op_off((size_t)n_rec + 1, 0);
+    if ((rc = rb_dev_download(ctx, op_off.data(), d_opoff, ((size_t)n_rec + 1) * 8))) return rc;
+    rb_lap("parse cigars + op_off D2H", tl);
+    // ---- the batch, device-resident ----
+    std::vector<uint32_t> zc;
+    if (!contig) {
+        zc.assign(n_rec, 0);
+        contig = zc.data();
+    }
+    b.v.n_rec = n_rec;
+    b.v.n_ops = op_off[n_rec];
+    b.v.ops = d_ops;
+    b.v.op_off = d_opoff;
+    if ((rc = b.up(t_st, (size_t)n_rec, &b.v.t_st))) return rc;
+    if ((rc = b.up(t_en, (size_t)n_rec, &b.v.t_en))) return rc;
+    if ((rc = b.up(q_st, (size_t)n_rec, &b.v.q_st))) return rc;
+    if ((rc = b.up(q_en, (size_t)n_rec, &b.v.q_en))) return rc;
+    if ((rc = b.up(strand, (size_t)n_rec, &b.v.strand))) return rc;
+    if ((rc = b.up(contig, (size_t)n_rec, &b.v.contig))) return rc;
+    rb_norm_row *d_norm = nullptr;
+    rb_reduce_row *d_red = nullptr;
+    if ((rc = b.alloc(n_rec, &d_norm))) return rc;
+    if (reduce_out && (rc = b.alloc(n_rec, &d_red))) return rc;
+    if ((rc = rb_dev_scan_records(ctx, &b.v, d_red, d_norm))) return rc;
+    if (norm_out && (rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;
+    if (reduce_out && (rc = rb_dev_download(ctx, reduce_out, d_red, n_rec * sizeof(rb_reduce_row)))) return rc;
+    rb_lap("scan_records + rows D2H", tl);
+    rb_plan *plan = nullptr;
+    if ((rc = rb_plan_create(ctx, n_rec, op_off.data(), contig, n_win, w_contig, w_st, w_en, &plan))) return rc;
+    rb_counters *d_cnt = nullptr;
+    if ((rc = b.alloc(1, &d_cnt))) {
+        rb_plan_destroy(plan);
+        return rc;
+    }
+    policy |= RB_LIFT_DESCRIPTORS;
+    uint64_t rows_cap = 16 * n_rec + n_win + 1024;
+    uint64_t out_cap = b.v.n_ops / 4 + 16 * rows_cap + 4096;
+    rb_counters hc;
+    memset(&hc, 0, sizeof hc);
+    void *ws = nullptr;
+    rb_hit_row *d_rows = nullptr;
+    uint32_t *d_out = nullptr;
+    for (int attempt = 0; attempt < 6; attempt++) {
+        if (ws) hipFree(ws);
+        if (d_rows) hipFree(d_rows);
+        if (d_out) hipFree(d_out);
+        ws = nullptr, d_rows = nullptr, d_out = nullptr;
+        rc = rb_dev_alloc(ctx, rb_plan_workspace_bytes(plan, rows_cap), &ws);
+        if (!rc) rc = rb_dev_alloc(ctx, (rows_cap + 1) * sizeof(rb_hit_row), (void **)&d_rows);
+        if (!rc) rc = rb_dev_alloc(ctx, (out_cap + 4) * 4, (void **)&d_out);
+        if (rc) break;
+        rc = rb_dev_liftover(ctx, plan, &b.v, d_norm, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt);
+        if (rc) break;
+        rc = rb_dev_download(ctx, &hc, d_cnt, sizeof hc);
+        if (rc) break;
+        if (!hc.overflow) break;
+        rows_cap = std::max<uint64_t>(rows_cap, hc.n_hits + 16);
+        out_cap = std::max<uint64_t>(out_cap * 2, hc.out_ops_needed + hc.out_ops_needed / 4 + 4096 + 4 * rows_cap);
+        rc = RB_E_CAPACITY;
+    }
+    if (!rc && hc.overflow) rc = RB_E_CAPACITY;
+    rb_lap("plan + clip kernels", tl);
+    // ---- rows to the host, clip items back to the device, text out ----
+    const uint64_t nr = hc.n_hits;
+    std::vector<uint32_t> desc;
+    uint64_t *d_first = nullptr, *d_toff = nullptr;
+    uint32_t *d_cnt3 = nullptr; // count | first_len | last_len, three arrays of nr
+    uint8_t *d_rtext = nullptr;
+    if (!rc) {
+        *rows = (rb_hit_row *)malloc((size_t)(nr + 1) * sizeof(rb_hit_row));
+        *row_text_off = (uint64_t *)malloc((size_t)(nr + 2) * 8);
+        if (!*rows || !*row_text_off) rc = fail(ctx, RB_E_NOMEM, "malloc(rows)");
+    }
+    if (!rc && nr) rc = rb_dev_download(ctx, *rows, d_rows, (size_t)nr * sizeof(rb_hit_row));
+    if (!rc && nr) {
+        desc.resize((size_t)nr * 4);
+        rc = rb_dev_download(ctx, desc.data(), d_out, (size_t)nr * 16); // descriptor of row k at out_ops[4k]
+    }
+    rb_lap("rows D2H", tl);
+    if (!rc) {
+        std::vector<uint64_t> first((size_t)nr + 1, 0);
+        std::vector<uint32_t> c3((size_t)nr * 3 + 1, 0);
+        for (uint64_t k = 0; k < nr; k++) {
+            const rb_hit_row &h = (*rows)[k];
+            if (h.status != RB_ST_OK) continue;
+            if (h.flags & RB_HIT_DESCRIPTOR) {
+                const uint32_t *d = &desc[(size_t)k * 4];
+                first[k] = op_off[h.rec] + d[0];
+                c3[k] = d[1];
+                c3[nr + k] = d[2];
+                c3[2 * nr + k] = d[3];
+            } else { // copied by the generic kernel
+                first[k] = h.out_off | (1ull << 63);
+                c3[k] = h.out_n;
+            }
+        }
+        rc = b.alloc((size_t)nr + 1, &d_first);
+        if (!rc) rc = b.alloc((size_t)nr * 3 + 1, &d_cnt3);
+        if (!rc) rc = b.alloc((size_t)nr + 2, &d_toff);
+        void *d_scr2 = nullptr;
+        if (!rc) rc = b.alloc(rb_text_scratch_bytes(nr), (uint8_t **)&d_scr2);
+        if (!rc && nr) rc = rb_dev_upload(ctx, d_first, first.data(), (size_t)nr * 8);
+        if (!rc && nr) rc = rb_dev_upload(ctx, d_cnt3, c3.data(), (size_t)nr * 12);
+        if (!rc) rc = rb_ctx_sync(ctx);
+        if (!rc) rc = rb_dev_format_cigars(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, nullptr, 0, d_scr2);
+        if (!rc) rc = rb_dev_download(ctx, *row_text_off, d_toff, ((size_t)nr + 1) * 8);
+        const uint64_t bytes = rc ? 0 : (*row_text_off)[nr];
+        if (!rc) rc = b.alloc((size_t)bytes + 16, &d_rtext);
+        if (!rc) rc = rb_dev_format_cigars(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, d_rtext, bytes, d_scr2);
+        if (!rc) {
+            *row_text = (uint8_t *)malloc((size_t)bytes + 16);
+            if (!*row_text) rc = fail(ctx, RB_E_NOMEM, "malloc(%llu text bytes)", (unsigned long long)bytes);
+        }
+        if (!rc && bytes) rc = rb_dev_download(ctx, *row_text, d_rtext, (size_t)bytes);
+        rb_lap("format cigars + text D2H", tl);
+    }
+    if (!rc) {
+        *n_rows = nr;
+        if (counters) *counters = hc;
+    } else {
+        free(*rows);
+        free(*row_text_off);
+        free(*row_text);
+        *rows = nullptr, *row_text_off = nullptr, *row_text = nullptr;
+    }
+    if (ws) hipFree(ws);
+    if (d_rows) hipFree(d_rows);
+    if (d_out) hipFree(d_out);
+    rb_plan_destroy(plan);
+    return rc;
 }
 
 extern "C" int rb_host_swap(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint8_t *strand,

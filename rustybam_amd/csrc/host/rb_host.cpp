@@ -269,8 +269,9 @@ static std::string stripped_id(const PafRecord &r, const rb_norm_row &nr) {
     return r.id + "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
 }
 
-Paf Paf::from_file(Engine &eng, const std::string &file_name) {
-    std::string all; // the whole (decompressed) text; lines are parsed in parallel below
+// the whole (decompressed) text of a PAF file or stdin
+static std::string read_all(const std::string &file_name) {
+    std::string all;
     bool plain = false;
     if (file_name != "-") { // uncompressed regular file: read it directly (zlib's pass-through mode is 3x slower)
         FILE *fp = fopen(file_name.c_str(), "rb");
@@ -297,15 +298,25 @@ Paf Paf::from_file(Engine &eng, const std::string &file_name) {
         while ((r = gzread(f, buf.data(), (unsigned)buf.size())) > 0) all.append(buf.data(), (size_t)r);
         gzclose(f);
     }
-    std::vector<std::pair<size_t, size_t>> lines; // BufRead::lines: split on \n, strip one trailing \r
+    return all;
+}
+// BufRead::lines: split on \n, strip one trailing \r
+static std::vector<std::pair<size_t, size_t>> split_lines(std::string_view all) {
+    std::vector<std::pair<size_t, size_t>> lines;
     for (size_t a = 0; a < all.size();) {
-        size_t b = all.find('\n', a);
-        if (b == std::string::npos) b = all.size();
+        const void *nl = memchr(all.data() + a, '\n', all.size() - a);
+        const size_t b = nl ? (size_t)((const char *)nl - all.data()) : all.size();
         size_t e = b;
         if (e > a && all[e - 1] == '\r') e--;
         lines.emplace_back(a, e - a);
         a = b + 1;
     }
+    return lines;
+}
+
+Paf Paf::from_file(Engine &eng, const std::string &file_name) {
+    std::string all = read_all(file_name); // lines are parsed in parallel below
+    const std::vector<std::pair<size_t, size_t>> lines = split_lines(all);
     const unsigned T = parallel_chunk_count(lines.size());
     std::vector<std::vector<PafRecord>> part(T);
     std::vector<std::vector<size_t>> skipped(T);
@@ -527,6 +538,186 @@ std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Re
     std::vector<std::string> text = rows_to_text(*L.recs, L.norm, L.rows, L.n_rows, L.out, &rgns);
     lap("rows -> text", tl);
     return text;
+}
+
+// ---- liftover, text in -> text out ------------------------------------------------------------------------------------
+// main.rs:186-214 without --qbed / --largest: Paf::from_file + trim_paf_by_rgns + println! of every record.  The CIGAR text
+// (95 % of a PAF's bytes) never becomes host data structures: the `cg:Z:` values are parsed on the device, the clipped CIGARs
+// are printed on the device from the clip descriptors, and the host only handles the twelve header columns.
+namespace {
+struct HeaderOnly { // PafRecord::new (paf.rs:379-430) minus the CIGAR: token ranges inside the file text
+    size_t q_name, q_name_n, t_name, t_name_n, cg, cg_n;
+    uint64_t q_len, q_st, q_en, t_len, t_st, t_en, mapq;
+    char strand;
+};
+// 0 = ok, 1 = Err(ParsePafColumn) (the line is skipped), 2 = needs the general parser (two cg tags); throws Panic
+int paf_header_new(const char *base, size_t a, size_t n, HeaderOnly &h) {
+    std::pair<size_t, size_t> t[64];
+    size_t nt = 0, cg_tags = 0;
+    const char *p = base + a, *end = p + n;
+    auto ws = [](char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f'; };
+    h.cg = h.cg_n = 0;
+    while (p < end) {
+        while (p < end && ws(*p)) p++;
+        if (p >= end) break;
+        const char *q = p;
+        while (q < end && !ws(*q)) q++;
+        if (nt < 12) {
+            t[nt] = {(size_t)(p - base), (size_t)(q - p)};
+        } else { // PAF_TAG "(..):(.):(.*)", leftmost match (paf.rs:21, :387-390)
+            const size_t len = (size_t)(q - p);
+            size_t m = (size_t)-1;
+            for (size_t i = 0; i + 5 <= len; i++)
+                if (p[i + 2] == ':' && p[i + 4] == ':') {
+                    m = i;
+                    break;
+                }
+            if (m == (size_t)-1) throw Panic("assertion failed: PAF_TAG.is_match(token)");
+            if (p[m] == 'c' && p[m + 1] == 'g') {
+                if (cg_tags++ == 0) h.cg = (size_t)(p - base) + m + 5, h.cg_n = len - (m + 5);
+            }
+        }
+        nt++;
+        p = q;
+    }
+    if (nt < 12) throw Panic("assertion failed: t.len() >= 12"); // paf.rs:381
+    if (cg_tags > 1) return 2; // (a second cg tag is parsed when the first one is empty, paf.rs:395: left to the general path)
+    uint64_t v[12] = {0};
+    static const int numeric[] = {1, 2, 3, 6, 7, 8, 9, 10, 11};
+    for (int c : numeric)
+        if (!parse_u64(base + t[c].first, t[c].second, v[c])) return 1;
+    if (t[4].second != 1) return 1;
+    h.q_name = t[0].first, h.q_name_n = t[0].second, h.t_name = t[5].first, h.t_name_n = t[5].second;
+    h.q_len = v[1], h.q_st = v[2], h.q_en = v[3], h.t_len = v[6], h.t_st = v[7], h.t_en = v[8], h.mapq = v[11];
+    h.strand = base[t[4].first];
+    return 0;
+}
+} // namespace
+
+bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text) {
+    double tl = now_s();
+    std::string all = read_all(paf_path);
+    const size_t text_bytes = all.size();
+    all.append(32, '\0'); // the device reads whole 16-byte groups
+    const std::vector<std::pair<size_t, size_t>> lines = split_lines(std::string_view(all.data(), text_bytes));
+    lap("read + split lines", tl);
+    const unsigned T = parallel_chunk_count(lines.size());
+    std::vector<std::vector<HeaderOnly>> part(T);
+    std::vector<std::vector<size_t>> skipped(T);
+    std::vector<int> general(T, 0);
+    std::vector<std::string> panics(T);
+    parallel_chunks(lines.size(), [&](unsigned t, size_t lo, size_t hi) {
+        part[t].reserve(hi - lo);
+        try {
+            for (size_t i = lo; i < hi; i++) {
+                HeaderOnly h;
+                const int rc = paf_header_new(all.data(), lines[i].first, lines[i].second, h);
+                if (rc == 0) part[t].push_back(h);
+                else if (rc == 1) skipped[t].push_back(i);
+                else general[t] = 1;
+            }
+        } catch (const Panic &e) {
+            panics[t] = e.what();
+        }
+    });
+    for (unsigned t = 0; t < T; t++)
+        if (!panics[t].empty()) throw Panic(panics[t]);
+    for (unsigned t = 0; t < T; t++)
+        if (general[t]) return false; // the caller takes the general path
+    std::vector<HeaderOnly> recs;
+    for (unsigned t = 0; t < T; t++) {
+        for (size_t i : skipped[t]) fprintf(stderr, "\nUnable to parse PAF record. Skipping line %zu\n", i + 1);
+        recs.insert(recs.end(), part[t].begin(), part[t].end());
+    }
+    const size_t n = recs.size();
+    lap("header columns", tl);
+    // dense contig ids in order of first appearance (canonical contig order), windows mapped onto them
+    std::vector<uint64_t> cig_off(n), cig_end(n), t_st(n), t_en(n), q_st(n), q_en(n);
+    std::vector<uint8_t> strand(n);
+    std::vector<uint32_t> contig(n);
+    std::unordered_map<std::string_view, uint32_t> contig_id;
+    for (size_t i = 0; i < n; i++) {
+        const HeaderOnly &h = recs[i];
+        cig_off[i] = h.cg, cig_end[i] = h.cg + h.cg_n;
+        t_st[i] = h.t_st, t_en[i] = h.t_en, q_st[i] = h.q_st, q_en[i] = h.q_en, strand[i] = (uint8_t)h.strand;
+        const std::string_view name(all.data() + h.t_name, h.t_name_n);
+        auto it = contig_id.find(name);
+        if (it == contig_id.end()) it = contig_id.emplace(name, (uint32_t)contig_id.size()).first;
+        contig[i] = it->second;
+    }
+    std::vector<uint32_t> w_contig(rgns.size());
+    std::vector<uint64_t> w_st(rgns.size()), w_en(rgns.size());
+    for (size_t i = 0; i < rgns.size(); i++) {
+        auto it = contig_id.find(std::string_view(rgns[i].name));
+        if (it == contig_id.end()) it = contig_id.emplace(std::string_view(rgns[i].name), (uint32_t)contig_id.size()).first; // no record there
+        w_contig[i] = it->second, w_st[i] = rgns[i].st, w_en[i] = rgns[i].en;
+    }
+    std::vector<uint8_t> cig_status(n ? n : 1);
+    std::vector<rb_reduce_row> red(n);
+    std::vector<rb_norm_row> norm(n);
+    rb_hit_row *rows = nullptr;
+    uint64_t n_rows = 0, *toff = nullptr;
+    uint8_t *rtext = nullptr;
+    rb_counters cnt;
+    eng.check(rb_host_liftover_text(eng.ctx(), n, (const uint8_t *)all.data(), text_bytes, cig_off.data(), cig_end.data(), t_st.data(),
+                                    t_en.data(), q_st.data(), q_en.data(), strand.data(), contig.data(), rgns.size(), w_contig.data(),
+                                    w_st.data(), w_en.data(), eng.bsearch_policy, cig_status.data(), red.data(), norm.data(), &rows, &n_rows,
+                                    &toff, &rtext, &cnt),
+              "rb_host_liftover_text");
+    struct Free {
+        rb_hit_row *r;
+        uint64_t *o;
+        uint8_t *t;
+        ~Free() { rb_host_free(r), rb_host_free(o), rb_host_free(t); }
+    } guard{rows, toff, rtext};
+    lap("rb_host_liftover_text", tl);
+    for (size_t i = 0; i < n; i++) {
+        if (cig_status[i] == RB_TEXT_TOO_LONG) throw Panic("cigar length does not fit the packed form (>= 2^28)");
+        if (cig_status[i] != RB_TEXT_OK) throw Panic("Unable to parse cigar string.");
+    }
+    for (size_t i = 0; i < n; i++) // check_integrity().unwrap() (paf.rs:70), then aligned_pairs (liftover.rs:119-121)
+        if (red[i].status != RB_ST_OK) throw Panic("check_integrity: record " + std::to_string(i + 1) + " status " + std::to_string(red[i].status));
+    for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i);
+    for (uint64_t k = 0; k < n_rows; k++)
+        if (rows[k].status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(rows[k].rec + 1));
+    // id of a record whose end indels were stripped (paf.rs:726-732): its lead / trail ops, parsed from its own text (rare)
+    auto stripped = [&](uint32_t r) -> std::string {
+        const rb_norm_row &nr = norm[r];
+        if (!(nr.flags & RB_F_STRIPPED)) return std::string();
+        std::vector<uint32_t> cig;
+        parse_cigar(all.data() + recs[r].cg, recs[r].cg_n, cig);
+        std::vector<uint32_t> lead(cig.begin(), cig.begin() + nr.lead_ops), trail;
+        for (uint32_t k = 0; k < nr.trail_ops; k++) trail.push_back(cig[cig.size() - 1 - k]);
+        return "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
+    };
+    const unsigned TO = parallel_chunk_count((size_t)n_rows);
+    out_text.assign(TO, std::string());
+    parallel_chunks((size_t)n_rows, [&](unsigned t, size_t lo, size_t hi) {
+        std::string &o = out_text[t];
+        size_t est = 0;
+        for (size_t k = lo; k < hi; k++) est += rows[k].status == RB_ST_OK ? 160 + (size_t)(toff[k + 1] - toff[k]) : 0;
+        o.reserve(est);
+        char nb[24];
+        auto num = [&](uint64_t v) {
+            auto r = std::to_chars(nb, nb + sizeof nb, v);
+            o.append(nb, r.ptr);
+        };
+        for (size_t k = lo; k < hi; k++) {
+            const rb_hit_row &h = rows[k];
+            if (h.status != RB_ST_OK) continue;
+            const HeaderOnly &s = recs[h.rec];
+            o.append(all.data() + s.q_name, s.q_name_n); o += '\t'; num(s.q_len); o += '\t'; num(h.q_st); o += '\t'; num(h.q_en); o += '\t';
+            o += s.strand; o += '\t'; o.append(all.data() + s.t_name, s.t_name_n); o += '\t'; num(s.t_len); o += '\t'; num(h.t_st); o += '\t';
+            num(h.t_en); o += '\t'; num(h.nmatch); o += '\t'; num(h.aln_len); o += '\t'; num(s.mapq); o += "\tid:Z:";
+            if (!(h.flags & RB_HIT_INSIDE)) o += rgns[h.win].id;
+            else o += stripped(h.rec); // (a record read from a file has an empty id of its own)
+            o += "\tcg:Z:";
+            o.append((const char *)rtext + toff[k], (size_t)(toff[k + 1] - toff[k]));
+            o += '\n';
+        }
+    });
+    lap("assemble lines", tl);
+    return true;
 }
 
 std::vector<PafRecord> break_paf_on_indels(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length) {

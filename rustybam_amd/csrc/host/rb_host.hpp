@@ -84,6 +84,9 @@ std::vector<PafRecord> paf_swap_query_and_target(Engine &eng, const std::vector<
 std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query);
 // the same, printed: every Some(rec) as `println!("{}", rec)` would, without materialising the records
 std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query);
+// main.rs:186-214 without --qbed / --largest, text in -> text out: the CIGAR text is parsed and printed on the device
+// (rb_host_liftover_text); false = the file needs the general path (a line with two cg tags), nothing was produced
+bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text);
 std::vector<std::string> break_paf_on_indels_text(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length);
 // main.rs:274-280: aligned_pairs + liftover::break_paf_on_indels (liftover.rs:182-226) for every record, record order
 std::vector<PafRecord> break_paf_on_indels(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length);

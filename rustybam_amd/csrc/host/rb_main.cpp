@@ -151,6 +151,16 @@ int main(int argc, char **argv) {
         } else if (cmd == "liftover" || cmd == "lo") {
             if (bed_path.empty()) return usage();
             std::vector<rb::Region> rgns = rb::parse_bed(bed_path);
+            if (!largest && !qbed && !getenv("RB_GENERAL_PATH")) { // text in -> text out, CIGAR text handled on the device
+                std::vector<std::string> text;
+                if (rb::liftover_file_text(eng, paf_path, rgns, text)) {
+                    lap("liftover (text to text)", tl);
+                    put(text);
+                    fflush(stdout);
+                    lap("write", tl);
+                    return 0;
+                }
+            }
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             lap("decode + check_integrity", tl);
             if (largest) { // main.rs:200-208: stable sort by id, keep the LAST record with maximal target span per id

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void rb_k_scan_top(uint64_t *block_sums, uint6
     }
     if (threadIdx.x == 0) block_sums[n_blocks] = carry;
 }
-__global__ __launch_bounds__(256) void rb_k_scan_apply(uint64_t *v, uint64_t n, const uint64_t *block_sums, rb_counters *counters) {
+__global__ __launch_bounds__(256) void rb_k_scan_apply(uint64_t *v, uint64_t n, const uint64_t *block_sums, uint64_t *total_out) {
     __shared__ uint64_t sh[256];
     const uint64_t base = (uint64_t)blockIdx.x * RB_SCAN_PER_BLOCK;
     // each thread owns 8 consecutive elements
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void rb_k_scan_apply(uint64_t *v, uint64_t n, 
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 255) {
         const uint64_t total = block_sums[gridDim.x];
         v[n] = total;
-        counters->n_hits = total;
+        if (total_out) *total_out = total;
     }
 }
 
@@ -798,16 +798,22 @@ __global__ __launch_bounds__(64) void rb_k_finish(rb_lift_params p) {
     if (p.counters->n_hits > p.rows_cap) p.counters->overflow = 1;
 }
 
+extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t *block_sums, uint64_t *total_out, hipStream_t stream);
 extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     if (do_count) {
         const unsigned blocks = (unsigned)((p->n_rec + 255) / 256);
         hipLaunchKernelGGL(rb_k_count_hits, dim3(blocks), dim3(256), 0, stream, *p);
     }
-    const uint64_t nb = (p->n_rec + RB_SCAN_PER_BLOCK - 1) / RB_SCAN_PER_BLOCK;
-    hipLaunchKernelGGL(rb_k_scan_partial, dim3((unsigned)nb), dim3(256), 0, stream, (const uint64_t *)p->hit_off, p->n_rec, block_sums);
+    return rb_launch_exclusive_scan(p->hit_off, p->n_rec, block_sums, &p->counters->n_hits, stream);
+}
+// in-place exclusive scan of n u64 counts (n + 1 outputs); block_sums: rb_scan_block_sums_count(n) words of scratch
+extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t *block_sums, uint64_t *total_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint64_t nb = (n + RB_SCAN_PER_BLOCK - 1) / RB_SCAN_PER_BLOCK;
+    hipLaunchKernelGGL(rb_k_scan_partial, dim3((unsigned)nb), dim3(256), 0, stream, (const uint64_t *)v, n, block_sums);
     hipLaunchKernelGGL(rb_k_scan_top, dim3(1), dim3(256), 0, stream, block_sums, nb);
-    hipLaunchKernelGGL(rb_k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, p->hit_off, p->n_rec, (const uint64_t *)block_sums, p->counters);
+    hipLaunchKernelGGL(rb_k_scan_apply, dim3((unsigned)nb), dim3(256), 0, stream, v, n, (const uint64_t *)block_sums, total_out);
     return hipGetLastError();
 }
 extern "C" hipError_t rb_launch_make_jobs(const rb_lift_params *p, hipStream_t stream) {

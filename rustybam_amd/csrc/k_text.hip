@@ -1,0 +1,245 @@
+// k_text.hip -- CIGAR text <-> packed ops on the device, gfx950 (wave64, CDNA4).
+//
+// The data format either side of the CIGAR walk: a PAF line carries its CIGAR as text
+// (`cg:Z:12=1X3I...`, 95 % of the bytes of an assembly PAF), and every output line prints one again.
+//
+//   rb_k_parse_cigars   replaces CigarString::try_from(value.as_bytes()) at paf.rs:398-399 (rust-htslib 0.44.1:
+//                       decimal u32 length, then one op character of MIDNSHP=X; anything else is the
+//                       `.expect("Unable to parse cigar string.")` panic -> per-record status here).
+//                       One wavefront per record, 16 text bytes per lane and step; a lane walks its bytes as a
+//                       tiny state machine, a number that straddles two lanes is completed with the previous lane's
+//                       unfinished digits (DPP wave_shr:1); a wave scan of the per-lane op counts places the ops.
+//                       Run twice: count (ops per record -> exclusive scan -> op_off), then fill.
+//   rb_k_format_cigars  replaces `impl Display for CigarString` as used by `impl Display for PafRecord`
+//                       (paf.rs:923-944): items = runs of ops with an optional clipped first / last length
+//                       (exactly what the clip descriptors of rb_dev_liftover describe), so clipped CIGARs are
+//                       printed straight from the record's original ops.  One wavefront per item, 4 ops per lane
+//                       and step; count (bytes per item -> scan -> text_off), then fill.
+//
+// Roofline: HBM (byte work, no MFMA).  Algorithmic bytes: parse = text bytes read twice + 4 B per op written;
+// format = 4 B per op read twice + text bytes written.
+#include "rb_device.h"
+
+struct rb_parse_params {
+    uint64_t n_rec;
+    const uint8_t *text;      // all CIGAR strings, any layout
+    const uint64_t *text_off; // [n_rec + 1] record r's string is text[text_off[r] .. text_end[r])
+    const uint64_t *text_end; // [n_rec] (NULL: strings are back to back, end = text_off[r + 1])
+    uint64_t *op_off;         // [n_rec + 1] counts (count pass) / offsets (fill pass)
+    uint32_t *ops;
+    uint64_t ops_cap;
+    uint8_t *status;          // [n_rec] RB_TEXT_*
+};
+struct rb_format_params {
+    uint64_t n_items;
+    const uint32_t *ops;
+    const uint32_t *ops_alt;   // second source: items whose first[] has bit 63 set index this array (NULL if unused)
+    const uint64_t *first;     // [n_items] index of the item's first op in ops[] (bit 63: in ops_alt[])
+    const uint32_t *count;     // [n_items] ops in the item (0 = empty text)
+    const uint32_t *first_len; // [n_items] or NULL: != 0 replaces the length of the first op
+    const uint32_t *last_len;  // [n_items] or NULL: != 0 replaces the length of the last op; a one-op item with both keeps first + last - len
+    uint64_t *text_off;        // [n_items + 1] counts / offsets
+    uint8_t *text;
+    uint64_t text_cap;
+};
+
+// op character -> code (MIDNSHP=X -> 0..8), 255 = not an op
+__device__ __forceinline__ uint32_t rb_op_code_of(uint32_t c) {
+    // 'M'77 'I'73 'D'68 'N'78 'S'83 'H'72 'P'80 '='61 'X'88
+    switch (c) {
+    case 'M': return 0u;
+    case 'I': return 1u;
+    case 'D': return 2u;
+    case 'N': return 3u;
+    case 'S': return 4u;
+    case 'H': return 5u;
+    case 'P': return 6u;
+    case '=': return 7u;
+    case 'X': return 8u;
+    default: return 255u;
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
+    const uint32_t wib = rb_first(threadIdx.x >> 6);
+    const uint64_t r = (uint64_t)blockIdx.x * 4u + wib;
+    if (r >= p.n_rec) return;
+    const int lane = rb_lane();
+    const uint64_t b0 = rb_first64(p.text_off[r]);
+    const uint64_t b1 = rb_first64(p.text_end ? p.text_end[r] : p.text_off[r + 1]);
+    const uint64_t a0 = b0 & ~15ull;                  // aligned start: bytes before b0 are masked
+    const uint64_t n_steps = (b1 - a0 + 1023u) >> 10; // 1 KiB of text per step
+    uint64_t out_base = FILL ? rb_first64(p.op_off[r]) : 0; // next op slot of this record
+    uint32_t total = 0;                               // ops found
+    uint32_t err = 0;                                 // RB_TEXT_* of this lane
+    // unfinished number at the end of lane 63 of the previous step
+    uint32_t carry_val = 0, carry_nd = 0;
+    for (uint64_t st = 0; st < n_steps; st++) {
+        const uint64_t la = a0 + (st << 10) + (uint64_t)lane * 16u;
+        uint4 q = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
+        if (la < b1) q = *reinterpret_cast<const uint4 *>(p.text + la); // (the buffer is padded to 16 bytes)
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        // lane-local walk: ops that end in this chunk.  An op takes at least two bytes, so the op whose character sits
+        // in byte pair k / 2 gets slot k / 2 (statically indexed registers); the first one may have begun in the
+        // previous lane.
+        uint32_t slen[8], sinfo[8]; // length so far; code | digits << 8 | overflow << 16 | present << 24
+#pragma unroll
+        for (int j = 0; j < 8; j++) slen[j] = 0u, sinfo[j] = 0u;
+        uint32_t cnt = 0;
+        uint64_t acc = 0;
+        uint32_t nd = 0;      // digits of the number being read
+        uint32_t lead_nd = 0; // digits before the first op character of the chunk (to combine with the carry)
+        bool seen = false, any_valid = false;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint64_t pos = la + (uint64_t)k;
+            const bool valid = pos >= b0 && pos < b1;
+            const uint32_t c = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
+            const uint32_t d = c - 48u;
+            if (valid) {
+                any_valid = true;
+                if (d < 10u) {
+                    acc = acc * 10u + d;
+                    nd++;
+                    if (nd > 10u) err = RB_TEXT_BAD; // more digits than a u32 has
+                } else {
+                    const uint32_t code = rb_op_code_of(c);
+                    if (code == 255u) err = RB_TEXT_BAD;
+                    if (!seen) lead_nd = nd;
+                    else if (nd == 0u || acc > 0xFFFFFFFFull) err = RB_TEXT_BAD;        // no length / overflow of u32
+                    else if (acc >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;   // not representable in the packed form
+                    if (sinfo[k >> 1] != 0u) err = RB_TEXT_BAD;                        // two op characters in one byte pair
+                    slen[k >> 1] = (uint32_t)acc;                                       // (completed below for the first op)
+                    sinfo[k >> 1] = (code & 15u) | (acc > 0xFFFFFFFFull ? 0x10000u : 0u) | (seen ? 0u : 0x20000u) | 0x1000000u;
+                    cnt++;
+                    seen = true;
+                    acc = 0;
+                    nd = 0;
+                }
+            }
+        }
+        // the string must end with an op character
+        if (la + 16u >= b1 && la < b1 && nd != 0u) err = RB_TEXT_BAD;
+        // my unfinished tail -> the next lane; lane 0 takes the previous step's lane 63
+        const uint32_t tail_val = (uint32_t)acc, tail_nd = nd | (acc > 0xFFFFFFFFull ? 0x100u : 0u);
+        const uint32_t in_val = rb_prev_lane(tail_val, carry_val), in_nd = rb_prev_lane(tail_nd, carry_nd);
+        // a chunk of digits only is legal as the (short) head of the string; it cannot continue a number
+        if (!seen && any_valid && (in_nd & 0xFFu) != 0u) err = RB_TEXT_BAD;
+        carry_val = rb_readlane<uint32_t>(tail_val, 63);
+        carry_nd = rb_readlane<uint32_t>(tail_nd, 63);
+        const uint32_t incl = rb_wave_scan_incl(cnt);
+        const uint32_t step_total = rb_readlane<uint32_t>(incl, 63);
+        if (FILL) {
+            uint64_t o = out_base + (incl - cnt);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                if (sinfo[j] & 0x1000000u) {
+                    uint32_t l = slen[j];
+                    if (sinfo[j] & 0x20000u) { // the first op of the chunk: incoming digits are more significant
+                        const uint32_t ind = in_nd & 0xFFu;
+                        const uint32_t tnd = ind + lead_nd;
+                        uint64_t full = l;
+                        if (ind) {
+                            uint64_t pw = 1;
+                            for (uint32_t e = 0; e < lead_nd; e++) pw *= 10u;
+                            full = (uint64_t)in_val * pw + l;
+                            if (in_nd & 0x100u) full = ~0ull;
+                        }
+                        if (sinfo[j] & 0x10000u) full = ~0ull;
+                        if (tnd == 0u || tnd > 10u || full > 0xFFFFFFFFull) err = RB_TEXT_BAD;
+                        else if (full >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;
+                        l = (uint32_t)full;
+                    }
+                    if (o < p.ops_cap) p.ops[o] = (l << 4) | (sinfo[j] & 15u);
+                    o++;
+                }
+            }
+            out_base += step_total;
+        }
+        total += step_total;
+    }
+    // (an empty string is an empty CIGAR)
+    const uint32_t any_err = rb_wave_or_u32(err == RB_TEXT_BAD ? 1u : (err == RB_TEXT_TOO_LONG ? 2u : 0u));
+    if (lane == 0) {
+        if (!FILL) p.op_off[r] = total;
+        else p.status[r] = (uint8_t)((any_err & 1u) ? RB_TEXT_BAD : ((any_err & 2u) ? RB_TEXT_TOO_LONG : RB_TEXT_OK));
+    }
+}
+
+// decimal digits of v (v < 2^28: at most 9)
+__device__ __forceinline__ uint32_t rb_ndigits(uint32_t v) {
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
+    const uint32_t wib = rb_first(threadIdx.x >> 6);
+    const uint64_t it = (uint64_t)blockIdx.x * 4u + wib;
+    if (it >= p.n_items) return;
+    const int lane = rb_lane();
+    const uint64_t f_raw = rb_first64(p.first[it]);
+    const uint32_t *__restrict__ src = (f_raw >> 63) ? p.ops_alt : p.ops;
+    const uint64_t f0 = f_raw & ~(1ull << 63);
+    const uint32_t n = rb_first(p.count[it]);
+    const uint32_t fl = p.first_len ? rb_first(p.first_len[it]) : 0u;
+    const uint32_t ll = p.last_len ? rb_first(p.last_len[it]) : 0u;
+    uint64_t out = FILL ? rb_first64(p.text_off[it]) : 0;
+    uint64_t bytes = 0;
+    for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
+        uint32_t len[4], opc[4], nb[4];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint32_t i = i0 + (uint32_t)lane * 4u + (uint32_t)q;
+            uint32_t v = i < n ? src[f0 + i] : 0u;
+            uint32_t l = v >> 4;
+            if (n == 1u && fl && ll) l = fl + ll - l; // the middle of one op (liftover.rs via subset_cigar, paf.rs:593-620)
+            else if (i == 0u && fl) l = fl;             // first op keeps its tail
+            else if (i + 1u == n && ll) l = ll;         // last op keeps its head
+            len[q] = l;
+            opc[q] = v & 15u;
+            nb[q] = i < n ? rb_ndigits(l) + 1u : 0u;
+            mine += nb[q];
+        }
+        const uint32_t incl = rb_wave_scan_incl(mine);
+        const uint32_t step_bytes = rb_readlane<uint32_t>(incl, 63);
+        if (FILL) {
+            uint64_t o = out + (incl - mine);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (nb[q]) {
+                    const uint32_t nd = nb[q] - 1u;
+                    uint32_t l = len[q];
+                    if (o + nb[q] <= p.text_cap) {
+                        p.text[o + nd] = (uint8_t)("MIDNSHP=X??????"[opc[q] < 9u ? opc[q] : 9u]);
+                        for (uint32_t k = nd; k-- > 0u;) {
+                            const uint32_t t = l / 10u;
+                            p.text[o + k] = (uint8_t)(48u + (l - t * 10u));
+                            l = t;
+                        }
+                    }
+                    o += nb[q];
+                }
+            }
+            out += step_bytes;
+        }
+        bytes += step_bytes;
+    }
+    if (!FILL && lane == 0) p.text_off[it] = bytes;
+}
+
+extern "C" hipError_t rb_launch_parse_cigars(const rb_parse_params *p, bool fill, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((p->n_rec + 3) / 4);
+    if (fill) hipLaunchKernelGGL(rb_k_parse_cigars<true>, dim3(blocks), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(rb_k_parse_cigars<false>, dim3(blocks), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t rb_launch_format_cigars(const rb_format_params *p, bool fill, hipStream_t stream) {
+    if (p->n_items == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((p->n_items + 3) / 4);
+    if (fill) hipLaunchKernelGGL(rb_k_format_cigars<true>, dim3(blocks), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(rb_k_format_cigars<false>, dim3(blocks), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}

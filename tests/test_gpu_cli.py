@@ -14,9 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RB = os.path.join(ROOT, "rustybam_amd", "rb")
 
 
-def rb(*args):
+def rb(*args, env=None):
     assert os.path.exists(RB), "rustybam_amd/rb missing: run __graft_entry__.build()"
-    r = subprocess.run([RB, *map(str, args)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    r = subprocess.run([RB, *map(str, args)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=None if env is None else {**os.environ, **env})
     return r.returncode, r.stdout
 
 
@@ -188,3 +188,31 @@ def test_readme_pipeline(oracle, golden, tmp_path):
         nxt.write_bytes(out)
         inp = str(nxt)
     assert hashlib.md5(out).hexdigest() == "c4e325dd79f7e580f63a388e1636ca97"
+
+
+def test_liftover_general_path_still_agrees(dig, golden, tmp_path):
+    """`rb liftover` normally goes text -> text with the CIGAR text parsed / printed on the device; RB_GENERAL_PATH=1 keeps
+    the record-based path (the one --qbed / --largest use) under test on the same inputs."""
+    bed = str(tmp_path / "tile.bed")
+    tile_bed(bed)
+    for env in (None, {"RB_GENERAL_PATH": "1"}):
+        rc, out = rb("liftover", "--bed", bed, f"{golden}/asm_small.paf", env=env)
+        assert rc == 0 and hashlib.md5(out).hexdigest() == dig["liftover_tile_100kb"]["md5"], env
+
+
+def test_liftover_text_path_panics_and_skips(tmp_path):
+    bed = tmp_path / "r.bed"
+    bed.write_text("T\t0\t100\n")
+    bad = tmp_path / "bad.paf"
+    bad.write_text("Q 10 0 5 + T 10 0 5 0 0 60 cg:Z:5=\nQ 10 0 5 + T 10 0 5 0 0 60 cg:Z:5Q\n")
+    assert rb("liftover", "--bed", bed, bad)[0] == 101   # "Unable to parse cigar string." (paf.rs:399)
+    bad.write_text("Q 10 0 5 + T 10 0 6 0 0 60 cg:Z:5=\n")
+    assert rb("liftover", "--bed", bed, bad)[0] == 101   # check_integrity().unwrap() (paf.rs:70)
+    bad.write_text("Q 10 0 5 + T 10\n")
+    assert rb("liftover", "--bed", bed, bad)[0] == 101   # assert!(t.len() >= 12)
+    ok = tmp_path / "ok.paf"
+    ok.write_text("Q x 0 5 + T 10 0 5 0 0 60 cg:Z:5=\nQ 10 0 5 + T 10 0 5 0 0 60 cg:Z:5=\n")
+    rc, out = rb("liftover", "--bed", bed, ok)
+    assert rc == 0 and out.count(b"\n") == 1            # the unparsable line is skipped (paf.rs:73)
+    rc2, out2 = rb("liftover", "--bed", bed, ok, env={"RB_GENERAL_PATH": "1"})
+    assert (rc2, out2) == (rc, out)

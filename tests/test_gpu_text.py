@@ -1,0 +1,129 @@
+"""CIGAR text <-> packed ops on the device (k_text.hip) against the oracle's restatement of rust-htslib's
+CigarString::try_from / Display (oracle/rb_oracle.c: rbo_parse_cigar, rbo_cigar_to_string) and against the fixture."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+OPS = "MIDNSHP=X"
+
+
+def oracle_parse(oracle, s):
+    L = oracle.lib()
+    ops, n = C.POINTER(C.c_uint32)(), C.c_size_t()
+    b = s if isinstance(s, bytes) else s.encode()
+    rc = L.rbo_parse_cigar(b, C.c_size_t(len(b)), C.byref(ops), C.byref(n))
+    if rc != 0:
+        return None
+    out = np.ctypeslib.as_array(ops, shape=(n.value,)).copy() if n.value else np.zeros(0, np.uint32)
+    L.rbo_free(ops)
+    return out
+
+
+def oracle_format(oracle, ops):
+    L = oracle.lib()
+    out = C.c_char_p()
+    a = np.ascontiguousarray(ops, np.uint32)
+    L.rbo_cigar_to_string.restype = C.c_size_t
+    k = L.rbo_cigar_to_string(a.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_size_t(len(a)), C.byref(out))
+    s = C.string_at(out, k)
+    L.rbo_free(out)
+    return s
+
+
+def rand_cigar(rng, n_ops, big=False):
+    parts = []
+    for _ in range(n_ops):
+        r = rng.random()
+        if big and r < 0.02:
+            ln = int(rng.integers(1 << 20, (1 << 28) - 1))
+        elif r < 0.5:
+            ln = int(rng.integers(1, 10))
+        elif r < 0.9:
+            ln = int(rng.integers(10, 5000))
+        else:
+            ln = int(rng.integers(5000, 3_000_000))
+        parts.append(f"{ln}{OPS[int(rng.integers(0, 9))]}")
+    return "".join(parts)
+
+
+def test_parse_matches_oracle_random(engine, oracle):
+    rng = np.random.default_rng(zlib.crc32(b"text-parse"))
+    cigs = [rand_cigar(rng, int(n), big=True) for n in list(rng.integers(0, 40, 200)) + [1000, 5000, 257, 256, 255, 64, 63, 65]]
+    cigs += ["", "1M", "0M", "268435455=", "12=1X3I", "4294967295M"[:0] + "5M"]
+    op_off, ops, status = engine.parse_cigars(cigs)
+    assert status.tolist() == [0] * len(cigs)
+    for i, c in enumerate(cigs):
+        want = oracle_parse(oracle, c)
+        assert want is not None
+        assert np.array_equal(ops[int(op_off[i]):int(op_off[i + 1])], want), (i, c[:60])
+
+
+@pytest.mark.parametrize("shift", range(0, 17))
+def test_parse_every_alignment(engine, oracle, shift):
+    """strings that start at every byte phase of a 16-byte lane chunk, with numbers straddling lanes and 1 KiB steps"""
+    rng = np.random.default_rng(1000 + shift)
+    cigs = ["7M" * shift] + [rand_cigar(rng, int(n)) for n in (1, 3, 9, 130, 700, 2100)] + ["123456789=" * 120, "1M" * 1500]
+    op_off, ops, status = engine.parse_cigars(cigs)
+    assert not status.any()
+    for i, c in enumerate(cigs):
+        assert np.array_equal(ops[int(op_off[i]):int(op_off[i + 1])], oracle_parse(oracle, c)), (shift, i)
+
+
+@pytest.mark.parametrize("bad", [
+    "M", "1", "12", "1M2", "1MM", "MM", "1Q", "1m", "1M 2M", "-1M", "+1M", "1.5M", "4294967296M", "99999999999M", "1M\n",
+    "10=" * 40 + "X", "10=" * 700 + "5", "12345678901234567=", "1=" * 8 + "=",
+])
+def test_parse_errors_like_the_reference(engine, oracle, bad):
+    """everything CigarString::try_from rejects is the `.expect()` panic at paf.rs:399"""
+    assert oracle_parse(oracle, bad) is None
+    good = "5=2X"
+    _, _, status = engine.parse_cigars([good, bad, good])
+    assert status.tolist() == [0, 1, 0]
+
+
+def test_parse_too_long_for_the_packed_form(engine):
+    _, _, status = engine.parse_cigars(["268435456M", "3=268435456D1=", "268435455M"])
+    assert status.tolist() == [2, 2, 0]
+
+
+def test_parse_fixture_file(engine, oracle, golden):
+    cigs = []
+    for line in open(f"{golden}/asm_small.paf"):
+        for tok in line.rstrip("\n").split("\t")[12:]:
+            if tok.startswith("cg:Z:"):
+                cigs.append(tok[5:])
+    assert len(cigs) == 249
+    op_off, ops, status = engine.parse_cigars(cigs)
+    assert not status.any()
+    for i in range(0, len(cigs), 7):
+        assert np.array_equal(ops[int(op_off[i]):int(op_off[i + 1])], oracle_parse(oracle, cigs[i]))
+    # and back: the device prints what it parsed
+    first, count = op_off[:-1].copy(), np.diff(op_off).astype(np.uint32)
+    toff, text = engine.format_cigars(ops, first, count)
+    for i, c in enumerate(cigs):
+        assert text[int(toff[i]):int(toff[i + 1])] == c.encode(), i
+
+
+def test_format_matches_oracle_and_clips(engine, oracle):
+    rng = np.random.default_rng(zlib.crc32(b"text-format"))
+    lens = np.where(rng.random(6000) < 0.7, rng.integers(1, 300, 6000), rng.integers(1, 1 << 27, 6000)).astype(np.uint32)
+    ops = ((lens << 4) | rng.integers(0, 9, 6000).astype(np.uint32)).astype(np.uint32)
+    ops[10] = (9 << 4) | 7  # the one-op item below keeps 5 + 7 - 9 = 3 bases of it
+    first = np.array([0, 0, 10, 10, 5000, 17, 300, 301, 5999, 42], np.uint64)
+    count = np.array([6000, 1, 1, 700, 1000, 0, 257, 256, 1, 2], np.uint32)
+    fl = np.array([0, 0, 5, 3, 0, 0, 9, 0, 0, 4], np.uint32)
+    ll = np.array([0, 0, 7, 0, 8, 0, 2, 11, 0, 6], np.uint32)
+    toff, text = engine.format_cigars(ops, first, count, fl, ll)
+    for i in range(len(first)):
+        seg = ops[int(first[i]):int(first[i]) + int(count[i])].copy()
+        if len(seg) == 1 and fl[i] and ll[i]:
+            seg[0] = ((int(fl[i]) + int(ll[i]) - (int(seg[0]) >> 4)) << 4) | (int(seg[0]) & 15)
+        else:
+            if len(seg) and fl[i]:
+                seg[0] = (int(fl[i]) << 4) | (int(seg[0]) & 15)
+            if len(seg) and ll[i]:
+                seg[-1] = (int(ll[i]) << 4) | (int(seg[-1]) & 15)
+        assert text[int(toff[i]):int(toff[i + 1])] == oracle_format(oracle, seg), i
