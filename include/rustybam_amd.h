@@ -308,6 +308,15 @@ int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint
                           const uint8_t *strand, const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
                           const uint64_t *w_en, int bsearch_policy, uint8_t *cig_status, rb_reduce_row *reduce_out, rb_norm_row *norm_out,
                           rb_hit_row **rows, uint64_t *n_rows, uint64_t **row_text_off, uint8_t **row_text, rb_counters *counters);
+/* the same around rb_dev_break (break-paf, main.rs:271-281), and the record scan alone (stats --paf, main.rs:50-58) */
+int rb_host_break_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off,
+                       const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
+                       const uint8_t *strand, uint32_t max_size, int bsearch_policy, uint8_t *cig_status, rb_reduce_row *reduce_out,
+                       rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows, uint64_t **row_text_off, uint8_t **row_text,
+                       rb_counters *counters);
+int rb_host_scan_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off, const uint64_t *cig_end,
+                      const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                      uint8_t *cig_status, rb_reduce_row *reduce_out, rb_norm_row *norm_out);
 
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and

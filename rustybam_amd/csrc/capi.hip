@@ -855,13 +855,19 @@ extern "C" int rb_host_format_cigars(rb_ctx *ctx, const uint32_t *ops, uint64_t 
     return RB_OK;
 }
 
-extern "C" int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off,
-                                     const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st,
-                                     const uint64_t *q_en, const uint8_t *strand, const uint32_t *contig, uint64_t n_win,
-                                     const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en, int policy, uint8_t *cig_status,
-                                     rb_reduce_row *reduce_out, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows,
-                                     uint64_t **row_text_off, uint8_t **row_text, rb_counters *counters) {
-    if (!ctx || !cig_off || !cig_end || !cig_status || !rows || !n_rows || !row_text_off || !row_text) return RB_E_INVALID;
+// text in -> text out around the clip kernels; scan_only stops after the record scan (rb_host_scan_text)
+static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool scan_only, uint64_t n_rec, const uint8_t *text,
+                          uint64_t text_bytes, const uint64_t *cig_off, const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en,
+                          const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand, const uint32_t *contig, uint64_t n_win,
+                          const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en, int policy, uint8_t *cig_status,
+                          rb_reduce_row *reduce_out, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows, uint64_t **row_text_off,
+                          uint8_t **row_text, rb_counters *counters) {
+    if (!ctx || !cig_off || !cig_end || !cig_status) return RB_E_INVALID;
+    rb_hit_row *rows_dummy = nullptr;
+    uint64_t n_dummy = 0, *off_dummy = nullptr;
+    uint8_t *text_dummy = nullptr;
+    if (scan_only) rows = &rows_dummy, n_rows = &n_dummy, row_text_off = &off_dummy, row_text = &text_dummy;
+    if (!rows || !n_rows || !row_text_off || !row_text) return RB_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     *rows = nullptr;
     *row_text_off = nullptr;
@@ -922,6 +928,7 @@ extern "C" int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t 
     if (norm_out && (rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;
     if (reduce_out && (rc = rb_dev_download(ctx, reduce_out, d_red, n_rec * sizeof(rb_reduce_row)))) return rc;
     rb_lap("scan_records + rows D2H", tl);
+    if (scan_only) return RB_OK;
     rb_plan *plan = nullptr;
     if ((rc = rb_plan_create(ctx, n_rec, op_off.data(), contig, n_win, w_contig, w_st, w_en, &plan))) return rc;
     rb_counters *d_cnt = nullptr;
@@ -946,7 +953,8 @@ extern "C" int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t 
         if (!rc) rc = rb_dev_alloc(ctx, (rows_cap + 1) * sizeof(rb_hit_row), (void **)&d_rows);
         if (!rc) rc = rb_dev_alloc(ctx, (out_cap + 4) * 4, (void **)&d_out);
         if (rc) break;
-        rc = rb_dev_liftover(ctx, plan, &b.v, d_norm, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt);
+        rc = is_break ? rb_dev_break(ctx, plan, &b.v, d_norm, max_size, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt)
+                      : rb_dev_liftover(ctx, plan, &b.v, d_norm, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt);
         if (rc) break;
         rc = rb_dev_download(ctx, &hc, d_cnt, sizeof hc);
         if (rc) break;
@@ -1025,6 +1033,31 @@ extern "C" int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t 
     if (d_out) hipFree(d_out);
     rb_plan_destroy(plan);
     return rc;
+}
+
+extern "C" int rb_host_liftover_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off,
+                                     const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st,
+                                     const uint64_t *q_en, const uint8_t *strand, const uint32_t *contig, uint64_t n_win,
+                                     const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en, int policy, uint8_t *cig_status,
+                                     rb_reduce_row *reduce_out, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows,
+                                     uint64_t **row_text_off, uint8_t **row_text, rb_counters *counters) {
+    return host_lift_text(ctx, false, 0, false, n_rec, text, text_bytes, cig_off, cig_end, t_st, t_en, q_st, q_en, strand, contig, n_win,
+                          w_contig, w_st, w_en, policy, cig_status, reduce_out, norm_out, rows, n_rows, row_text_off, row_text, counters);
+}
+extern "C" int rb_host_break_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off,
+                                  const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st,
+                                  const uint64_t *q_en, const uint8_t *strand, uint32_t max_size, int policy, uint8_t *cig_status,
+                                  rb_reduce_row *reduce_out, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows,
+                                  uint64_t **row_text_off, uint8_t **row_text, rb_counters *counters) {
+    return host_lift_text(ctx, true, max_size, false, n_rec, text, text_bytes, cig_off, cig_end, t_st, t_en, q_st, q_en, strand, nullptr, 0,
+                          nullptr, nullptr, nullptr, policy, cig_status, reduce_out, norm_out, rows, n_rows, row_text_off, row_text, counters);
+}
+extern "C" int rb_host_scan_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off,
+                                 const uint64_t *cig_end, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st,
+                                 const uint64_t *q_en, const uint8_t *strand, uint8_t *cig_status, rb_reduce_row *reduce_out,
+                                 rb_norm_row *norm_out) {
+    return host_lift_text(ctx, false, 0, true, n_rec, text, text_bytes, cig_off, cig_end, t_st, t_en, q_st, q_en, strand, nullptr, 0, nullptr,
+                          nullptr, nullptr, 0, cig_status, reduce_out, norm_out, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int rb_host_swap(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint8_t *strand,

@@ -594,108 +594,101 @@ int paf_header_new(const char *base, size_t a, size_t n, HeaderOnly &h) {
 }
 } // namespace
 
-bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text) {
-    double tl = now_s();
-    std::string all = read_all(paf_path);
-    const size_t text_bytes = all.size();
-    all.append(32, '\0'); // the device reads whole 16-byte groups
-    const std::vector<std::pair<size_t, size_t>> lines = split_lines(std::string_view(all.data(), text_bytes));
-    lap("read + split lines", tl);
-    const unsigned T = parallel_chunk_count(lines.size());
-    std::vector<std::vector<HeaderOnly>> part(T);
-    std::vector<std::vector<size_t>> skipped(T);
-    std::vector<int> general(T, 0);
-    std::vector<std::string> panics(T);
-    parallel_chunks(lines.size(), [&](unsigned t, size_t lo, size_t hi) {
-        part[t].reserve(hi - lo);
-        try {
-            for (size_t i = lo; i < hi; i++) {
-                HeaderOnly h;
-                const int rc = paf_header_new(all.data(), lines[i].first, lines[i].second, h);
-                if (rc == 0) part[t].push_back(h);
-                else if (rc == 1) skipped[t].push_back(i);
-                else general[t] = 1;
-            }
-        } catch (const Panic &e) {
-            panics[t] = e.what();
-        }
-    });
-    for (unsigned t = 0; t < T; t++)
-        if (!panics[t].empty()) throw Panic(panics[t]);
-    for (unsigned t = 0; t < T; t++)
-        if (general[t]) return false; // the caller takes the general path
+namespace {
+// the file text, where every kept line's columns and cg:Z: value sit in it, and the arrays the ABI wants
+struct TextFile {
+    std::string all;
+    size_t text_bytes = 0;
     std::vector<HeaderOnly> recs;
-    for (unsigned t = 0; t < T; t++) {
-        for (size_t i : skipped[t]) fprintf(stderr, "\nUnable to parse PAF record. Skipping line %zu\n", i + 1);
-        recs.insert(recs.end(), part[t].begin(), part[t].end());
+    std::vector<uint64_t> cig_off, cig_end, t_st, t_en, q_st, q_en;
+    std::vector<uint8_t> strand;
+    std::vector<uint32_t> contig;
+    std::unordered_map<std::string_view, uint32_t> contig_id; // dense ids in order of first appearance (canonical contig order)
+    std::string_view name(size_t off, size_t n) const { return std::string_view(all.data() + off, n); }
+    // false = a line needs the general parser (two cg tags)
+    bool load(const std::string &paf_path) {
+        double tl = now_s();
+        all = read_all(paf_path);
+        text_bytes = all.size();
+        all.append(32, '\0'); // the device reads whole 16-byte groups
+        const std::vector<std::pair<size_t, size_t>> lines = split_lines(std::string_view(all.data(), text_bytes));
+        lap("read + split lines", tl);
+        const unsigned T = parallel_chunk_count(lines.size());
+        std::vector<std::vector<HeaderOnly>> part(T);
+        std::vector<std::vector<size_t>> skipped(T);
+        std::vector<int> general(T, 0);
+        std::vector<std::string> panics(T);
+        parallel_chunks(lines.size(), [&](unsigned t, size_t lo, size_t hi) {
+            part[t].reserve(hi - lo);
+            try {
+                for (size_t i = lo; i < hi; i++) {
+                    HeaderOnly h;
+                    const int rc = paf_header_new(all.data(), lines[i].first, lines[i].second, h);
+                    if (rc == 0) part[t].push_back(h);
+                    else if (rc == 1) skipped[t].push_back(i);
+                    else general[t] = 1;
+                }
+            } catch (const Panic &e) {
+                panics[t] = e.what();
+            }
+        });
+        for (unsigned t = 0; t < T; t++)
+            if (!panics[t].empty()) throw Panic(panics[t]);
+        for (unsigned t = 0; t < T; t++)
+            if (general[t]) return false;
+        for (unsigned t = 0; t < T; t++) {
+            for (size_t i : skipped[t]) fprintf(stderr, "\nUnable to parse PAF record. Skipping line %zu\n", i + 1);
+            recs.insert(recs.end(), part[t].begin(), part[t].end());
+        }
+        const size_t n = recs.size();
+        cig_off.resize(n), cig_end.resize(n), t_st.resize(n), t_en.resize(n), q_st.resize(n), q_en.resize(n), strand.resize(n), contig.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const HeaderOnly &h = recs[i];
+            cig_off[i] = h.cg, cig_end[i] = h.cg + h.cg_n;
+            t_st[i] = h.t_st, t_en[i] = h.t_en, q_st[i] = h.q_st, q_en[i] = h.q_en, strand[i] = (uint8_t)h.strand;
+            const std::string_view nm = name(h.t_name, h.t_name_n);
+            auto it = contig_id.find(nm);
+            if (it == contig_id.end()) it = contig_id.emplace(nm, (uint32_t)contig_id.size()).first;
+            contig[i] = it->second;
+        }
+        lap("header columns", tl);
+        return true;
     }
-    const size_t n = recs.size();
-    lap("header columns", tl);
-    // dense contig ids in order of first appearance (canonical contig order), windows mapped onto them
-    std::vector<uint64_t> cig_off(n), cig_end(n), t_st(n), t_en(n), q_st(n), q_en(n);
-    std::vector<uint8_t> strand(n);
-    std::vector<uint32_t> contig(n);
-    std::unordered_map<std::string_view, uint32_t> contig_id;
-    for (size_t i = 0; i < n; i++) {
-        const HeaderOnly &h = recs[i];
-        cig_off[i] = h.cg, cig_end[i] = h.cg + h.cg_n;
-        t_st[i] = h.t_st, t_en[i] = h.t_en, q_st[i] = h.q_st, q_en[i] = h.q_en, strand[i] = (uint8_t)h.strand;
-        const std::string_view name(all.data() + h.t_name, h.t_name_n);
-        auto it = contig_id.find(name);
-        if (it == contig_id.end()) it = contig_id.emplace(name, (uint32_t)contig_id.size()).first;
-        contig[i] = it->second;
+    // the panics of Paf::from_file (paf.rs:399, :70), in the reference's order of checks
+    void check_loaded(const std::vector<uint8_t> &cig_status, const std::vector<rb_reduce_row> &red) const {
+        for (size_t i = 0; i < recs.size(); i++) {
+            if (cig_status[i] == RB_TEXT_TOO_LONG) throw Panic("cigar length does not fit the packed form (>= 2^28)");
+            if (cig_status[i] != RB_TEXT_OK) throw Panic("Unable to parse cigar string.");
+        }
+        for (size_t i = 0; i < recs.size(); i++)
+            if (red[i].status != RB_ST_OK) throw Panic("check_integrity: record " + std::to_string(i + 1) + " status " + std::to_string(red[i].status));
     }
-    std::vector<uint32_t> w_contig(rgns.size());
-    std::vector<uint64_t> w_st(rgns.size()), w_en(rgns.size());
-    for (size_t i = 0; i < rgns.size(); i++) {
-        auto it = contig_id.find(std::string_view(rgns[i].name));
-        if (it == contig_id.end()) it = contig_id.emplace(std::string_view(rgns[i].name), (uint32_t)contig_id.size()).first; // no record there
-        w_contig[i] = it->second, w_st[i] = rgns[i].st, w_en[i] = rgns[i].en;
-    }
-    std::vector<uint8_t> cig_status(n ? n : 1);
-    std::vector<rb_reduce_row> red(n);
-    std::vector<rb_norm_row> norm(n);
-    rb_hit_row *rows = nullptr;
-    uint64_t n_rows = 0, *toff = nullptr;
-    uint8_t *rtext = nullptr;
-    rb_counters cnt;
-    eng.check(rb_host_liftover_text(eng.ctx(), n, (const uint8_t *)all.data(), text_bytes, cig_off.data(), cig_end.data(), t_st.data(),
-                                    t_en.data(), q_st.data(), q_en.data(), strand.data(), contig.data(), rgns.size(), w_contig.data(),
-                                    w_st.data(), w_en.data(), eng.bsearch_policy, cig_status.data(), red.data(), norm.data(), &rows, &n_rows,
-                                    &toff, &rtext, &cnt),
-              "rb_host_liftover_text");
-    struct Free {
-        rb_hit_row *r;
-        uint64_t *o;
-        uint8_t *t;
-        ~Free() { rb_host_free(r), rb_host_free(o), rb_host_free(t); }
-    } guard{rows, toff, rtext};
-    lap("rb_host_liftover_text", tl);
-    for (size_t i = 0; i < n; i++) {
-        if (cig_status[i] == RB_TEXT_TOO_LONG) throw Panic("cigar length does not fit the packed form (>= 2^28)");
-        if (cig_status[i] != RB_TEXT_OK) throw Panic("Unable to parse cigar string.");
-    }
-    for (size_t i = 0; i < n; i++) // check_integrity().unwrap() (paf.rs:70), then aligned_pairs (liftover.rs:119-121)
-        if (red[i].status != RB_ST_OK) throw Panic("check_integrity: record " + std::to_string(i + 1) + " status " + std::to_string(red[i].status));
-    for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i);
-    for (uint64_t k = 0; k < n_rows; k++)
-        if (rows[k].status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(rows[k].rec + 1));
-    // id of a record whose end indels were stripped (paf.rs:726-732): its lead / trail ops, parsed from its own text (rare)
-    auto stripped = [&](uint32_t r) -> std::string {
-        const rb_norm_row &nr = norm[r];
+    // "_TO.<lead>.<trail>" of a record whose end indels were stripped (paf.rs:726-732), parsed from its own text (rare)
+    std::string stripped_suffix(uint32_t r, const rb_norm_row &nr) const {
         if (!(nr.flags & RB_F_STRIPPED)) return std::string();
         std::vector<uint32_t> cig;
         parse_cigar(all.data() + recs[r].cg, recs[r].cg_n, cig);
         std::vector<uint32_t> lead(cig.begin(), cig.begin() + nr.lead_ops), trail;
         for (uint32_t k = 0; k < nr.trail_ops; k++) trail.push_back(cig[cig.size() - 1 - k]);
         return "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
-    };
-    const unsigned TO = parallel_chunk_count((size_t)n_rows);
-    out_text.assign(TO, std::string());
-    parallel_chunks((size_t)n_rows, [&](unsigned t, size_t lo, size_t hi) {
+    }
+};
+struct TextRows { // results of rb_host_liftover_text / rb_host_break_text (freed on destruction)
+    rb_hit_row *rows = nullptr;
+    uint64_t n_rows = 0, *toff = nullptr;
+    uint8_t *text = nullptr;
+    ~TextRows() { rb_host_free(rows), rb_host_free(toff), rb_host_free(text); }
+};
+// `println!("{}", rec)` for every Some(rec): header columns from the file text and the hit rows, CIGAR text from the device
+std::vector<std::string> assemble_lines(const TextFile &f, const std::vector<rb_norm_row> &norm, const TextRows &R, const std::vector<Region> *rgns) {
+    for (uint64_t k = 0; k < R.n_rows; k++)
+        if (R.rows[k].status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(R.rows[k].rec + 1));
+    const unsigned TO = parallel_chunk_count((size_t)R.n_rows);
+    std::vector<std::string> out_text(TO);
+    parallel_chunks((size_t)R.n_rows, [&](unsigned t, size_t lo, size_t hi) {
         std::string &o = out_text[t];
         size_t est = 0;
-        for (size_t k = lo; k < hi; k++) est += rows[k].status == RB_ST_OK ? 160 + (size_t)(toff[k + 1] - toff[k]) : 0;
+        for (size_t k = lo; k < hi; k++) est += R.rows[k].status == RB_ST_OK ? 160 + (size_t)(R.toff[k + 1] - R.toff[k]) : 0;
         o.reserve(est);
         char nb[24];
         auto num = [&](uint64_t v) {
@@ -703,20 +696,107 @@ bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vec
             o.append(nb, r.ptr);
         };
         for (size_t k = lo; k < hi; k++) {
-            const rb_hit_row &h = rows[k];
+            const rb_hit_row &h = R.rows[k];
             if (h.status != RB_ST_OK) continue;
-            const HeaderOnly &s = recs[h.rec];
-            o.append(all.data() + s.q_name, s.q_name_n); o += '\t'; num(s.q_len); o += '\t'; num(h.q_st); o += '\t'; num(h.q_en); o += '\t';
-            o += s.strand; o += '\t'; o.append(all.data() + s.t_name, s.t_name_n); o += '\t'; num(s.t_len); o += '\t'; num(h.t_st); o += '\t';
+            const HeaderOnly &s = f.recs[h.rec];
+            o.append(f.all.data() + s.q_name, s.q_name_n); o += '\t'; num(s.q_len); o += '\t'; num(h.q_st); o += '\t'; num(h.q_en); o += '\t';
+            o += s.strand; o += '\t'; o.append(f.all.data() + s.t_name, s.t_name_n); o += '\t'; num(s.t_len); o += '\t'; num(h.t_st); o += '\t';
             num(h.t_en); o += '\t'; num(h.nmatch); o += '\t'; num(h.aln_len); o += '\t'; num(s.mapq); o += "\tid:Z:";
-            if (!(h.flags & RB_HIT_INSIDE)) o += rgns[h.win].id;
-            else o += stripped(h.rec); // (a record read from a file has an empty id of its own)
+            if (rgns && !(h.flags & RB_HIT_INSIDE)) o += (*rgns)[h.win].id;
+            else o += f.stripped_suffix(h.rec, norm[h.rec]); // (a record read from a file has an empty id of its own)
             o += "\tcg:Z:";
-            o.append((const char *)rtext + toff[k], (size_t)(toff[k + 1] - toff[k]));
+            o.append((const char *)R.text + R.toff[k], (size_t)(R.toff[k + 1] - R.toff[k]));
             o += '\n';
         }
     });
+    return out_text;
+}
+} // namespace
+
+bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text) {
+    TextFile f;
+    if (!f.load(paf_path)) return false; // the caller takes the general path
+    double tl = now_s();
+    const size_t n = f.recs.size();
+    std::vector<uint32_t> w_contig(rgns.size());
+    std::vector<uint64_t> w_st(rgns.size()), w_en(rgns.size());
+    for (size_t i = 0; i < rgns.size(); i++) {
+        auto it = f.contig_id.find(std::string_view(rgns[i].name));
+        if (it == f.contig_id.end()) it = f.contig_id.emplace(std::string_view(rgns[i].name), (uint32_t)f.contig_id.size()).first; // no record there
+        w_contig[i] = it->second, w_st[i] = rgns[i].st, w_en[i] = rgns[i].en;
+    }
+    std::vector<uint8_t> cig_status(n ? n : 1);
+    std::vector<rb_reduce_row> red(n);
+    std::vector<rb_norm_row> norm(n);
+    TextRows R;
+    rb_counters cnt;
+    eng.check(rb_host_liftover_text(eng.ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(), f.cig_end.data(), f.t_st.data(),
+                                    f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(), f.contig.data(), rgns.size(), w_contig.data(),
+                                    w_st.data(), w_en.data(), eng.bsearch_policy, cig_status.data(), red.data(), norm.data(), &R.rows,
+                                    &R.n_rows, &R.toff, &R.text, &cnt),
+              "rb_host_liftover_text");
+    lap("rb_host_liftover_text", tl);
+    f.check_loaded(cig_status, red);
+    for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
+    out_text = assemble_lines(f, norm, R, &rgns);
     lap("assemble lines", tl);
+    return true;
+}
+
+// main.rs:271-281, text in -> text out
+bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_length, std::vector<std::string> &out_text) {
+    TextFile f;
+    if (!f.load(paf_path)) return false;
+    double tl = now_s();
+    const size_t n = f.recs.size();
+    std::vector<uint8_t> cig_status(n ? n : 1);
+    std::vector<rb_reduce_row> red(n);
+    std::vector<rb_norm_row> norm(n);
+    TextRows R;
+    rb_counters cnt;
+    eng.check(rb_host_break_text(eng.ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(), f.cig_end.data(), f.t_st.data(),
+                                 f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(), break_length, eng.bsearch_policy, cig_status.data(),
+                                 red.data(), norm.data(), &R.rows, &R.n_rows, &R.toff, &R.text, &cnt),
+              "rb_host_break_text");
+    lap("rb_host_break_text", tl);
+    f.check_loaded(cig_status, red);
+    for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i); // main.rs:275
+    out_text = assemble_lines(f, norm, R, nullptr);
+    lap("assemble lines", tl);
+    return true;
+}
+
+// main.rs:50-58 (stats --paf), text in -> stats lines
+bool stats_file_text(Engine &eng, const std::string &paf_path, bool qbed, std::vector<std::string> &out_text) {
+    TextFile f;
+    if (!f.load(paf_path)) return false;
+    const size_t n = f.recs.size();
+    std::vector<uint8_t> cig_status(n ? n : 1);
+    std::vector<rb_reduce_row> red(n);
+    eng.check(rb_host_scan_text(eng.ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(), f.cig_end.data(), f.t_st.data(),
+                                f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(), cig_status.data(), red.data(), nullptr),
+              "rb_host_scan_text");
+    f.check_loaded(cig_status, red);
+    for (size_t i = 0; i < n; i++)
+        if (red[i].flags & RB_F_HAS_M) { // bamstats.rs:145-153
+            fprintf(stderr, "\r⚠ warning: cigar string contains 'M', assuming mismatch since there is no MD tag.");
+            break;
+        }
+    const unsigned TO = parallel_chunk_count(n);
+    out_text.assign(TO, std::string());
+    parallel_chunks(n, [&](unsigned t, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const HeaderOnly &r = f.recs[i];
+            Stats s;
+            s.r_nm.assign(f.all.data() + r.t_name, r.t_name_n), s.r_len = (int64_t)r.t_len, s.r_st = (int64_t)r.t_st, s.r_en = (int64_t)r.t_en;
+            s.q_nm.assign(f.all.data() + r.q_name, r.q_name_n), s.q_len = (int64_t)r.q_len, s.q_st = (int64_t)r.q_st, s.q_en = (int64_t)r.q_en;
+            s.strand = r.strand;
+            s.equal = red[i].equal, s.diff = red[i].diff, s.ins = red[i].ins, s.del = red[i].del, s.matches = red[i].matches;
+            s.ins_events = red[i].ins_events, s.del_events = red[i].del_events;
+            s.id_by_all = red[i].id_by_all, s.id_by_events = red[i].id_by_events, s.id_by_matches = red[i].id_by_matches;
+            out_text[t] += cigar_stats_line(s, qbed);
+        }
+    });
     return true;
 }
 

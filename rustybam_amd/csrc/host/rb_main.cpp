@@ -132,6 +132,9 @@ int main(int argc, char **argv) {
     }
     try {
         double tl = now_s();
+        // text in -> text out (CIGAR text parsed / printed on the device) for regular files; stdin and RB_GENERAL_PATH=1 take the
+        // record-based path, which every other arm uses anyway
+        const bool text_path = paf_path != "-" && !getenv("RB_GENERAL_PATH");
         rb::Engine eng(device);
         lap("device context", tl);
         eng.bsearch_policy = policy;
@@ -142,8 +145,13 @@ int main(int argc, char **argv) {
             if (!is_paf) { // BAM input (main.rs:60-77)
                 for (const rb::Stats &s : rb::cigar_stats_bam(eng, paf_path)) put(rb::cigar_stats_line(s, qbed));
             } else {
-                rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-                for (const rb::Stats &s : rb::stats_from_paf(eng, paf.records)) put(rb::cigar_stats_line(s, qbed));
+                std::vector<std::string> text;
+                if (text_path && rb::stats_file_text(eng, paf_path, qbed, text)) {
+                    put(text);
+                } else {
+                    rb::Paf paf = rb::Paf::from_file(eng, paf_path);
+                    for (const rb::Stats &s : rb::stats_from_paf(eng, paf.records)) put(rb::cigar_stats_line(s, qbed));
+                }
             }
         } else if (cmd == "invert") {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
@@ -151,7 +159,7 @@ int main(int argc, char **argv) {
         } else if (cmd == "liftover" || cmd == "lo") {
             if (bed_path.empty()) return usage();
             std::vector<rb::Region> rgns = rb::parse_bed(bed_path);
-            if (!largest && !qbed && !getenv("RB_GENERAL_PATH")) { // text in -> text out, CIGAR text handled on the device
+            if (!largest && !qbed && text_path) { // text in -> text out, CIGAR text handled on the device
                 std::vector<std::string> text;
                 if (rb::liftover_file_text(eng, paf_path, rgns, text)) {
                     lap("liftover (text to text)", tl);
@@ -181,8 +189,13 @@ int main(int argc, char **argv) {
                 lap("write", tl);
             }
         } else if (cmd == "break-paf" || cmd == "breakpaf" || cmd == "bp") {
-            rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-            put(rb::break_paf_on_indels_text(eng, paf.records, max_size));
+            std::vector<std::string> text;
+            if (text_path && rb::break_file_text(eng, paf_path, max_size, text)) {
+                put(text);
+            } else {
+                rb::Paf paf = rb::Paf::from_file(eng, paf_path);
+                put(rb::break_paf_on_indels_text(eng, paf.records, max_size));
+            }
         } else if (filter) { // main.rs:234-249
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             paf.filter_query_len(min_query);

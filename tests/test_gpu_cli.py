@@ -200,6 +200,17 @@ def test_liftover_general_path_still_agrees(dig, golden, tmp_path):
         assert rc == 0 and hashlib.md5(out).hexdigest() == dig["liftover_tile_100kb"]["md5"], env
 
 
+@pytest.mark.parametrize("args", [["break-paf", "--max-size", "100", "{paf}"], ["break-paf", "--max-size", "7", "{paf}"],
+                                  ["stats", "--paf", "{paf}"], ["stats", "--qbed", "--paf", "{paf}"]])
+def test_text_and_general_paths_agree(oracle, golden, args):
+    a = [x.format(paf=f"{golden}/asm_small.paf") for x in args]
+    rc, out = rb(*a)
+    rc2, out2 = rb(*a, env={"RB_GENERAL_PATH": "1"})
+    orc, oout = oracle.cli(*a)
+    assert (rc, rc2, orc) == (0, 0, 0)
+    assert out == oout and out2 == oout
+
+
 def test_liftover_text_path_panics_and_skips(tmp_path):
     bed = tmp_path / "r.bed"
     bed.write_text("T\t0\t100\n")
