@@ -142,6 +142,9 @@ def main():
     n_hits = int(cnt["n_hits"])
 
     def step():
+        # the whole hot path from the packed ops: the record scan (remove_trailing_indels + check_integrity, which the reference's
+        # aligned_pairs runs inside trim_paf_by_rgns, liftover.rs:119-121) and then the clip kernels
+        eng.dev_scan_records(view, 0, d_norm.data_ptr())
         run_op(d_ws, d_rows, d_out)
 
     def barrier():

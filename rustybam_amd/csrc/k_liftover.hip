@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
 #define RB_PF 2 // steps (2 KiB each) of stream loads in flight per wave
 #endif
 #define RB_ET (RB_HMAX + 1) // slots per column of the clip table (one sentinel)
-#define RB_SMAX ((10 / RB_PF) * RB_PF) // steps whose checkpoints fit in LDS at once; whole turns of the load ring
+#ifndef RB_SEG
+#define RB_SEG 10
+#endif
+#define RB_SMAX ((RB_SEG / RB_PF) * RB_PF) // steps whose checkpoints fit in LDS at once; whole turns of the load ring
 #ifndef RB_WPE
 #define RB_WPE 5, 6 // waves per SIMD the register budget is cut for
 #endif
