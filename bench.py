@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--early-exit", action="store_true", help="allow the kernel to stop a record early (off: full walk)")
+    ap.add_argument("--unfused", action="store_true", help="run rb_dev_scan_records as its own pass inside the step instead of the fused scan")
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: skip kernel phases (invalid results)")
     ap.add_argument("--op", default="liftover", choices=["liftover", "break"],
                     help="liftover (headline) or break-paf --max-size 100 on the same records (secondary measurement)")
@@ -113,6 +114,8 @@ def main():
     policy = rustybam_amd.BSEARCH_MODERN | (rustybam_amd.LIFT_EARLY_EXIT if args.early_exit else 0) | (args.debug_skip << 8)
     if args.descriptors:
         policy |= rustybam_amd.LIFT_DESCRIPTORS
+    if args.op != "break" and not args.unfused:
+        policy |= rustybam_amd.LIFT_FUSED_SCAN
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
     rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, total_ops // 4)
 
@@ -142,9 +145,11 @@ def main():
     n_hits = int(cnt["n_hits"])
 
     def step():
-        # the whole hot path from the packed ops: the record scan (remove_trailing_indels + check_integrity, which the reference's
-        # aligned_pairs runs inside trim_paf_by_rgns, liftover.rs:119-121) and then the clip kernels
-        eng.dev_scan_records(view, 0, d_norm.data_ptr())
+        # the whole hot path from the packed ops.  liftover: one fused call -- remove_trailing_indels + check_integrity (which the
+        # reference's aligned_pairs runs inside trim_paf_by_rgns, liftover.rs:119-121) are done by the clip kernel while it streams
+        # each record (RB_LIFT_FUSED_SCAN: the normalised rows are an output of the step).  break-paf: record scan, then the kernels.
+        if args.op == "break" or args.unfused:
+            eng.dev_scan_records(view, 0, d_norm.data_ptr())
         run_op(d_ws, d_rows, d_out)
 
     def barrier():

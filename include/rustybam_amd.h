@@ -87,13 +87,19 @@ enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY
         * length of the first kept op, length of the last kept op }; every op in between is unchanged; a one-op clip
         * has length aln_len; RB_HIT_INSIDE rows keep all lengths.  Rows resolved by the generic kernel (irregular
         * cigars whose adjacent ops may merge) still carry real ops.  out_cap must be >= 4 * rows_cap + room for those. */
-       RB_LIFT_DESCRIPTORS = 32 };
+       RB_LIFT_DESCRIPTORS = 32,
+       /* RB_LIFT_FUSED_SCAN (rb_dev_liftover only): norm_rows is an OUTPUT.  rb_dev_scan_records need not have run: the call
+        * looks at the ends of every record (remove_trailing_indels), verifies integrity and regularity while the clip kernel
+        * streams the record, and runs the full record scan only for records that fail that check.  Rows of a record whose
+        * norm row ends up with status != RB_ST_OK carry that status. */
+       RB_LIFT_FUSED_SCAN = 64 };
 
 /* rb_norm_row.flags / rb_reduce_row.flags */
 enum {
     RB_F_REGULAR = 1u << 0,   /* only M I D = X ops, every len >= 1, no two adjacent ops of one type */
     RB_F_STRIPPED = 1u << 1,  /* leading/trailing indels were removed (host appends _TO.<..>.<..>) */
-    RB_F_HAS_M = 1u << 2      /* cigar contains 'M' (bamstats.rs:145 warning)                      */
+    RB_F_HAS_M = 1u << 2,     /* cigar contains 'M' (bamstats.rs:145 warning)                      */
+    RB_F_PROVISIONAL = 1u << 3 /* never visible to callers: row written from the record's ends only, not yet verified */
 };
 /* rb_hit_row.flags */
 enum {

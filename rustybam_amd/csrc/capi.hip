@@ -26,6 +26,8 @@ struct rb_scan_params {
     const uint8_t *strand;
     rb_reduce_row *reduce_rows;
     rb_norm_row *norm_rows;
+    const uint32_t *list;
+    const uint64_t *n_list;
 };
 struct rb_break_params {
     uint64_t n_rec;
@@ -61,6 +63,7 @@ struct rb_swap_params {
 };
 
 extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_peek_norm(const rb_scan_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream);
 struct rb_parse_params {
     uint64_t n_rec;
@@ -260,6 +263,8 @@ extern "C" int rb_dev_scan_records(rb_ctx *ctx, const rb_batch_view *b, rb_reduc
     p.strand = b->strand;
     p.reduce_rows = reduce_rows;
     p.norm_rows = norm_rows;
+    p.list = nullptr;
+    p.n_list = nullptr;
     HIPCHK(ctx, rb_launch_scan_records(&p, ctx->stream));
     return RB_OK;
 }
@@ -357,7 +362,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, jobs, gen_list, x_st, x_en, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, total;
 };
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     ws_layout w;
@@ -371,6 +376,8 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     w.win_lo = take((n_rec + 2) * 4);
     w.block_sums = take(rb_scan_block_sums_count(n_rec) * 8);
     w.arena = take((size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8);
+    w.pend_count = take(256);
+    w.pend_list = take((n_rec + 1) * 4);
     w.jobs = take((n_rec + 1) * sizeof(rb_job));
     w.gen_list = take((rows_cap + 1) * 4);
     w.x_st = take((rows_cap + 1) * 8);
@@ -432,6 +439,22 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.arena_size = ((out_cap - p.arena_origin) / p.n_arena) & ~(uint64_t)3;
     p.gen_list = (uint32_t *)(ws + w.gen_list);
     p.jobs = (rb_job *)(ws + w.jobs);
+    p.fused = (!is_break && (policy & RB_LIFT_FUSED_SCAN)) ? 1 : 0;
+    p.norm_w = const_cast<rb_norm_row *>(norm);
+    p.pend_list = (uint32_t *)(ws + w.pend_list);
+    p.pend_count = (unsigned long long *)(ws + w.pend_count);
+    rb_scan_params sp;
+    memset(&sp, 0, sizeof sp);
+    if (p.fused) {
+        sp.n_rec = b->n_rec;
+        sp.ops = b->ops;
+        sp.op_off = b->op_off;
+        sp.t_st = b->t_st, sp.t_en = b->t_en, sp.q_st = b->q_st, sp.q_en = b->q_en;
+        sp.strand = b->strand;
+        sp.norm_rows = p.norm_w;
+        HIPCHK(ctx, hipMemsetAsync(p.pend_count, 0, 8, ctx->stream));
+        HIPCHK(ctx, rb_launch_peek_norm(&sp, ctx->stream)); // provisional rows from the records' ends
+    }
     p.counters = counters;
     p.policy = policy & 1;
     p.early_exit = (policy & RB_LIFT_EARLY_EXIT) ? 1 : 0;
@@ -468,6 +491,11 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.wave0 = 0;
     p.wave_end = (uint32_t)b->n_rec;
     HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
+    if (p.fused) { // the full record scan for the records the clip kernel handed back (usually none)
+        sp.list = p.pend_list;
+        sp.n_list = (const uint64_t *)p.pend_count;
+        HIPCHK(ctx, rb_launch_scan_records(&sp, ctx->stream));
+    }
     if (ctx->timing) {
         HIPCHK(ctx, hipEventRecord(ctx->ev_b[slot], ctx->stream));
         ctx->timed_calls++;
@@ -678,9 +706,12 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     rb_lap("H2D batch", tl);
     rb_norm_row *d_norm = nullptr;
     if ((rc = b.alloc(n_rec, &d_norm))) return rc;
-    if ((rc = rb_dev_scan_records(ctx, &b.v, nullptr, d_norm))) return rc;
-    if (norm_out && (rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;
-    rb_lap("scan_records + norm D2H", tl);
+    const bool fused = !is_break && (policy & RB_LIFT_FUSED_SCAN); // the clip kernel verifies the records itself
+    if (!fused) {
+        if ((rc = rb_dev_scan_records(ctx, &b.v, nullptr, d_norm))) return rc;
+        if (norm_out && (rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;
+        rb_lap("scan_records + norm D2H", tl);
+    }
     rb_plan *plan = nullptr;
     if ((rc = rb_plan_create(ctx, n_rec, op_off, contig, n_win, w_contig, w_st, w_en, &plan))) return rc;
     rb_lap("plan", tl);
@@ -720,6 +751,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     }
     if (!rc && hc.overflow) rc = RB_E_CAPACITY;
     rb_lap("alloc + kernels", tl);
+    if (!rc && fused && norm_out) rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row));
     if (!rc) {
         *n_rows = hc.n_hits;
         *rows = (rb_hit_row *)malloc((size_t)(hc.n_hits + 1) * sizeof(rb_hit_row));

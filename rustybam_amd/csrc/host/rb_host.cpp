@@ -508,8 +508,9 @@ void run_liftover(Engine &eng, const std::vector<Region> &rgns, const std::vecto
     rb_counters cnt;
     eng.check(rb_host_liftover(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
                                b.strand.data(), b.contig.data(), rgns.size(), w_contig.data(), w_st.data(), w_en.data(),
-                               eng.bsearch_policy | RB_LIFT_DESCRIPTORS, L.norm.data(), &L.rows, &L.n_rows, &L.out, &L.n_out, &cnt),
-              "rb_host_liftover");
+                               eng.bsearch_policy | RB_LIFT_DESCRIPTORS | RB_LIFT_FUSED_SCAN, L.norm.data(), &L.rows, &L.n_rows, &L.out, &L.n_out,
+                               &cnt),
+              "rb_host_liftover"); // (fused scan: aligned_pairs' strip + integrity check happen inside the clip kernel)
     lap("rb_host_liftover", tl);
     for (size_t i = 0; i < L.norm.size(); i++) panic_on(L.norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
 }

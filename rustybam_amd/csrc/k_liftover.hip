@@ -27,6 +27,7 @@
 // Roofline: HBM.  Algorithmic bytes: 4 B per input op + 48 B per record + 88 B per hit + 4 B per
 // emitted op.  No MFMA: integer / index work only.
 #include "rb_lift.h"
+#include <type_traits>
 
 __global__ __launch_bounds__(256) void rb_k_count_hits(rb_lift_params p) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -143,17 +144,18 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
     const uint32_t cg = p.contig[r];
     const bool mono = explicit_w || (cg < p.n_contig && p.cw_mono[cg] != 0);
     uint32_t f = 0;
-    if (nr->status == RB_ST_OK && nh != 0) {
+    const bool provisional = (nr->flags & RB_F_PROVISIONAL) != 0; // fused scan: the clip kernel verifies the record itself,
+    if (nr->status == RB_ST_OK && (nh != 0 || provisional)) {     // also when no window overlaps it (liftover.rs:119-121)
         if (h0 + nh > p.rows_cap) f |= RB_JOB_ROWS_OVERFLOW;
         else f |= RB_JOB_VALID;
     }
-    if (nr->flags & RB_F_REGULAR) f |= RB_JOB_REGULAR;
+    if ((nr->flags & RB_F_REGULAR) || provisional) f |= RB_JOB_REGULAR;
     if (p.strand[r] == (uint8_t)'-') f |= RB_JOB_MINUS;
     if (mono) f |= RB_JOB_MONO;
     j.flags = f;
     j.h0 = (uint32_t)h0;
     j.nh = (uint32_t)nh;
-    j.lo = (explicit_w || !mono || !(f & RB_JOB_VALID)) ? 0u : p.win_lo[r];
+    j.lo = (explicit_w || !mono || !(f & RB_JOB_VALID) || nh == 0) ? 0u : p.win_lo[r];
     p.jobs[w] = j;
 }
 
@@ -236,8 +238,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
     const uint32_t *__restrict__ gbase0 = p.ops + g0;                 // the record's first (aligned) 16-byte group
     const uint32_t last_off = (uint32_t)(((gend - 1u) & ~3ull) - g0); // last 16-byte group that holds an op of this record
 
-    for (uint64_t jb = 0; jb < nh; jb += RB_HMAX) {
+    const bool fused = p.fused != 0;
+    uint32_t rec_nmatch = 0, rec_aln_len = 0; // of the whole (normalised) record: taken from its row, or from the fused verification
+    if (!fused) rec_nmatch = nr->nmatch, rec_aln_len = nr->aln_len;
+    const uint64_t n_items = (nh == 0 && fused) ? 1 : nh; // (a record no window overlaps is still streamed once, to verify it)
+    for (uint64_t jb = 0; jb < n_items; jb += RB_HMAX) {
         const uint32_t nb = (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX);
+        const bool validate = fused && jb == 0;
         // ---- per-hit setup: lanes j and j + 32 both look at window jb + j; lane j resolves its start
         //      boundary, lane j + 32 its end boundary; lane j then owns the row ----
         const uint32_t hl = (uint32_t)lane & 31u;
@@ -258,7 +265,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
 
         // ---- stream the record, RB_SMAX steps per segment; resolve after each segment ----
         uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
-        if (__ballot(need) != 0 && !(p.debug_skip & 4)) {
+        // fused verification (first pass): AND of the "regular op" masks, minimum length, minimum of code XOR previous code
+        // (0 = two adjacent ops of one type), minimum op code (0 = an M), sums too large for 32-bit scans
+        uint32_t v_reg = 0xFFFFFFFFu, v_minlen = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_mincode = 15u, v_big = 0u;
+        uint32_t v_carry = 0xFu;       // last op word of the previous step (code 15: equals nothing)
+        unsigned long long v_utot = 0; // 64-bit sum of all lengths
+        if ((__ballot(need) != 0 || validate) && !(p.debug_skip & 4)) {
             auto load_half = [&](uint32_t stp, uint32_t half) -> uint4 {
                 // unconditional (an exec-masked load makes the compiler drain the whole ring at the loop edge):
                 // groups past the record's end re-read its last group; the tail step masks them out
@@ -291,6 +303,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                                 for (int q = 0; q < 8; q++)
                                     if ((uint32_t)(idx0 + q) >= n) raw[q] = 0u; // (also the negative head indices); 0 = a 0-length M
                             }
+                            if (validate) {
+                                const int32_t idx0v = (int32_t)(st << RB_STEP_SHIFT) + lane * 8 - head;
+                                auto verify = [&](auto edge_c) {
+                                    constexpr bool edge = decltype(edge_c)::value; // first / last step: ops of the neighbours are skipped
+                                    uint32_t mylast = raw[7];                      // adjacency form: 0xF where there is no op
+                                    if (edge && (uint32_t)(idx0v + 7) >= n) mylast = 0xFu;
+                                    uint32_t prevw = rb_prev_lane(mylast, v_carry); // previous lane's last op; lane 0: previous step's
+                                    v_carry = rb_readlane<uint32_t>(mylast, 63);
+#pragma unroll
+                                    for (int q = 0; q < 8; q++) {
+                                        const bool ok = !edge || (uint32_t)(idx0v + q) < n;
+                                        const uint32_t w = raw[q];
+                                        if (ok) {
+                                            v_reg &= (uint32_t)__builtin_amdgcn_sbfe((int)0x01870187u, w, 1u); // M I D = X
+                                            v_minlen = v_minlen < rb_len(w) ? v_minlen : rb_len(w);
+                                            const uint32_t x = (w ^ prevw) & 15u;
+                                            v_adj = v_adj < x ? v_adj : x;
+                                            v_mincode = v_mincode < (w & 15u) ? v_mincode : (w & 15u);
+                                        }
+                                        prevw = ok ? w : 0xFu;
+                                    }
+                                };
+                                if (st == 0 || st + 1 == n_steps) verify(std::true_type{});
+                                else verify(std::false_type{});
+                            }
                             // per-lane sums of the reference / query / unit lengths of 8 ops; regular records hold only
                             // M I D = X, so "consumes the reference" = not I and "consumes the query" = not D: one
                             // v_bfe_i32 per class turns the op code (low bits of the word) into an all-ones / zero mask
@@ -312,6 +349,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                             Rb += rb_readlane<uint32_t>(ir, 63);
                             Qb += rb_readlane<uint32_t>(iq, 63);
                             Ub += rb_readlane<uint32_t>(iu, 63);
+                            if (validate) {
+                                v_big |= su >> 25; // per-lane sums below 2^25 keep the 64-lane scans inside 32 bits
+                                v_utot += rb_readlane<uint32_t>(iu, 63);
+                            }
                         }
                         // reload the slot only after its ops are consumed: the load then targets the same registers
                         // and the compiler needs no copy (which would wait for every load in flight)
@@ -343,10 +384,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                         need = false;
                     }
                 }
-                if (p.early_exit && __ballot(need) == 0) break;
+                if (p.early_exit && !validate && __ballot(need) == 0) break;
             }
         }
 
+        if (validate) {
+            // ---- the verdict of the fused scan: check_integrity (paf.rs:825-857) on the normalised record and the
+            //      conditions of the fast path.  A record that fails any of them is handed back: the full record scan
+            //      (list mode) decides its status, the generic kernel clips it if it is merely irregular ----
+            const bool lane_bad = v_reg != 0xFFFFFFFFu || v_minlen == 0u || v_adj == 0u || v_big != 0u;
+            const bool bad = __ballot(lane_bad) != 0 || rb_first64(v_utot) > 0xFFFFFFFFull || t_en < t_st || q_en < q_st ||
+                             (uint64_t)Rb != t_en - t_st || (uint64_t)Qb != q_en - q_st;
+            if (bad) {
+                if (lane == 0) {
+                    const unsigned long long i = atomicAdd(p.pend_count, 1ull);
+                    p.pend_list[i] = r;
+                }
+                if (nh) {
+                    if (!explicit_w) {
+                        const uint32_t cg = p.contig[r];
+                        ws = p.cw_off[cg];
+                        we = p.cw_off[cg + 1];
+                    }
+                    rb_defer_record(p, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
+                }
+                return;
+            }
+            rec_nmatch = Rb + Qb - Ub; // match units = ref + query - all (M I D = X only)
+            rec_aln_len = Ub;
+            const bool has_m = __ballot(v_mincode == 0u) != 0;
+            if (lane == 0) {
+                rb_norm_row *w = &p.norm_w[r];
+                w->nmatch = rec_nmatch;
+                w->aln_len = rec_aln_len;
+                w->flags = (nr->flags & RB_F_STRIPPED) | RB_F_REGULAR | (has_m ? RB_F_HAS_M : 0u);
+            }
+            if (nh == 0) return;
+        }
         // ---- finalize: lane j (< 32) computes the row of hit jb + j; the end comes from lane j + 32 ----
         const rb_bres A = O;
         rb_bres B;
@@ -364,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
             if (inside) {
                 out_n = n;
                 o_tst = t_st, o_ten = t_en, o_qst = q_st, o_qen = q_en;
-                o_nm = nr->nmatch, o_al = nr->aln_len;
+                o_nm = rec_nmatch, o_al = rec_aln_len;
             } else if (A.st == RB_S_DEFER || B.st == RB_S_DEFER || A.st == RB_S_UNRES || B.st == RB_S_UNRES) {
                 defer = true;
             } else if (A.st == RB_S_NONE || B.st == RB_S_NONE || A.U >= B.U) {
@@ -598,6 +672,14 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
         rb_hit_row *row = &p.rows[hrow];
         const uint32_t r = row->rec, win = row->win;
         const rb_norm_row *nr = &p.norm[r];
+        if (nr->status != RB_ST_OK) { // fused scan: the record was handed back and the full scan found the reference would panic on it
+            row->status = (uint16_t)nr->status;
+            row->out_n = 0;
+            row->out_off = 0;
+            row->t_st = row->t_en = row->q_st = row->q_en = 0;
+            row->nmatch = row->aln_len = 0;
+            continue;
+        }
         const uint64_t t_st = nr->t_st, t_en = nr->t_en, q_st = nr->q_st, q_en = nr->q_en;
         const bool minus = p.strand[r] == (uint8_t)'-';
         const uint32_t n = nr->n_ops;

@@ -19,7 +19,99 @@ struct rb_scan_params {
     const uint8_t *strand;
     rb_reduce_row *reduce_rows;
     rb_norm_row *norm_rows;
+    // list mode (fused liftover): only the records list[0 .. *n_list) are scanned
+    const uint32_t *list;
+    const uint64_t *n_list;
 };
+
+// remove_trailing_indels (paf.rs:656-783) needs only the runs of I/D ops at the two ends of a record: how many ops go,
+// how many reference / query bases they hold, and the shifted coordinates (with the quirks at :668-701 and the strand
+// swap :764-769).  Serial, almost always zero iterations.
+struct rb_strip {
+    uint32_t lead, trail;         // ops removed in front / behind
+    uint64_t dR, dQ;              // reference / query bases of the removed ops
+    uint64_t t_st, t_en, q_st, q_en; // coordinates after the shift
+};
+__device__ __forceinline__ rb_strip rb_strip_ends(const uint32_t *ops, uint64_t n, uint64_t t_st, uint64_t t_en, uint64_t q_st, uint64_t q_en,
+                                                  bool minus) {
+    rb_strip o;
+    uint64_t lead = 0, rm_st_t = 0, rm_st_q = 0;
+    uint32_t prev = RB_NULL_OP;
+    o.dR = o.dQ = 0;
+    while (lead < n && rb_in(RB_INDEL_MASK, rb_opc(ops[lead]))) { // paf.rs:663-701 leading run
+        const uint32_t opc = rb_opc(ops[lead]), len = rb_len(ops[lead]);
+        if (opc == RB_OP_D) {
+            rm_st_t += len;
+            rm_st_q += 1; // :673
+            o.dR += len;
+        } else {
+            rm_st_q += len;
+            o.dQ += len;
+        }
+        if (prev != RB_NULL_OP && prev != opc) { // :690-701 D/I or I/D neighbours
+            rm_st_t += 1;
+            rm_st_q -= 1;
+        }
+        prev = opc;
+        lead++;
+    }
+    uint64_t trail = 0, rm_en_t = 0, rm_en_q = 0;
+    while (trail < n && rb_in(RB_INDEL_MASK, rb_opc(ops[n - 1 - trail]))) { // :704-723
+        const uint32_t opc = rb_opc(ops[n - 1 - trail]), len = rb_len(ops[n - 1 - trail]);
+        if (opc == RB_OP_D) {
+            rm_en_t += len;
+            if (lead + trail < n) o.dR += len; // (an all-indel record is reported, its sums are not used)
+        } else {
+            rm_en_q += len;
+            if (lead + trail < n) o.dQ += len;
+        }
+        trail++;
+    }
+    o.lead = (uint32_t)lead;
+    o.trail = (uint32_t)trail;
+    o.t_st = t_st + rm_st_t, o.t_en = t_en - rm_en_t; // :760-761
+    if (minus) {                                      // :764-766
+        const uint64_t t = rm_st_q;
+        rm_st_q = rm_en_q;
+        rm_en_q = t;
+    }
+    o.q_st = q_st + rm_st_q, o.q_en = q_en - rm_en_q; // :768-769
+    return o;
+}
+
+// Fused liftover (RB_LIFT_FUSED_SCAN): the clip kernel itself verifies a record while it streams it, so up front only
+// the ends are looked at.  One thread per record writes a PROVISIONAL row: kept op range and shifted coordinates are
+// final; integrity, regularity, nmatch and aln_len are filled in by the clip kernel (or by the full scan in list mode
+// for the records it hands back).
+__global__ __launch_bounds__(256) void rb_k_peek_norm(rb_scan_params p) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n_rec) return;
+    const uint64_t o0 = p.op_off[r], n = p.op_off[r + 1] - o0;
+    rb_norm_row w;
+    w.t_st = w.t_en = w.q_st = w.q_en = 0;
+    w.first_op = w.n_ops = w.lead_ops = w.trail_ops = w.nmatch = w.aln_len = 0;
+    w.flags = RB_F_PROVISIONAL;
+    uint32_t st = RB_ST_OK;
+    if (n == 0) {
+        st = RB_ST_PANIC_EMPTY_CIGAR; // paf.rs:663
+    } else {
+        const bool minus = p.strand && p.strand[r] == (uint8_t)'-';
+        const rb_strip sp = rb_strip_ends(p.ops + o0, n, p.t_st[r], p.t_en[r], p.q_st[r], p.q_en[r], minus);
+        w.lead_ops = sp.lead;
+        w.trail_ops = sp.trail;
+        if (sp.lead || sp.trail) w.flags |= RB_F_STRIPPED;
+        if ((uint64_t)sp.lead + sp.trail > n) {
+            st = RB_ST_PANIC_ALL_INDEL; // :757
+        } else {
+            w.t_st = sp.t_st, w.t_en = sp.t_en, w.q_st = sp.q_st, w.q_en = sp.q_en;
+            w.first_op = sp.lead;
+            w.n_ops = (uint32_t)(n - sp.lead - sp.trail);
+        }
+    }
+    if (st != RB_ST_OK) w.flags &= ~(uint32_t)RB_F_PROVISIONAL; // nothing left to verify: the reference panics on this record
+    w.status = st;
+    p.norm_rows[r] = w;
+}
 
 // Per-class accumulation goes through LDS: every lane owns one 64-bit counter per op code
 // (hist[code][lane], conflict-free: consecutive lanes hit consecutive banks) and adds
@@ -32,7 +124,11 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
     __shared__ unsigned long long hist_all[4][9][64];
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (wave >= p.n_rec) return;
-    const uint64_t r = rb_first64(wave);
+    uint64_t r = rb_first64(wave);
+    if (p.list) {
+        if (wave >= rb_first64(*p.n_list)) return;
+        r = rb_first(p.list[wave]);
+    }
     const int lane = rb_lane();
     unsigned long long(*hist)[64] = hist_all[threadIdx.x >> 6];
     const uint64_t o0 = p.op_off[r], o1 = p.op_off[r + 1];
@@ -151,72 +247,27 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
         if (n == 0) {
             st = RB_ST_PANIC_EMPTY_CIGAR; // paf.rs:663
         } else {
-            // paf.rs:663-701 leading run (serial: almost always zero iterations)
-            const uint32_t *ops = p.ops + o0;
-            uint64_t lead = 0, rm_st_t = 0, rm_st_q = 0;
-            uint32_t prev = RB_NULL_OP;
-            uint64_t lead_len = 0;
-            while (lead < n && rb_in(RB_INDEL_MASK, rb_opc(ops[lead]))) {
-                const uint32_t opc = rb_opc(ops[lead]), len = rb_len(ops[lead]);
-                if (opc == RB_OP_D) {
-                    rm_st_t += len;
-                    rm_st_q += 1; // :673
-                } else {
-                    rm_st_q += len;
-                }
-                if (prev != RB_NULL_OP && prev != opc) { // :690-701 D/I or I/D neighbours
-                    rm_st_t += 1;
-                    rm_st_q -= 1;
-                }
-                prev = opc;
-                lead_len += len;
-                lead++;
-            }
-            uint64_t trail = 0, rm_en_t = 0, rm_en_q = 0, trail_len = 0;
-            while (trail < n && rb_in(RB_INDEL_MASK, rb_opc(ops[n - 1 - trail]))) { // :704-723
-                const uint32_t opc = rb_opc(ops[n - 1 - trail]), len = rb_len(ops[n - 1 - trail]);
-                if (opc == RB_OP_D)
-                    rm_en_t += len;
-                else
-                    rm_en_q += len;
-                trail_len += len;
-                trail++;
-            }
-            w.lead_ops = (uint32_t)lead;
-            w.trail_ops = (uint32_t)trail;
-            if (lead || trail) w.flags |= RB_F_STRIPPED;
-            if (lead + trail > n) {
+            const rb_strip sp = rb_strip_ends(p.ops + o0, n, t_st, t_en, q_st, q_en, minus);
+            w.lead_ops = sp.lead;
+            w.trail_ops = sp.trail;
+            if (sp.lead || sp.trail) w.flags |= RB_F_STRIPPED;
+            if ((uint64_t)sp.lead + sp.trail > n) {
                 st = RB_ST_PANIC_ALL_INDEL; // :757
             } else {
-                // stripped ops are I/D: D lengths leave R, I lengths leave Q
-                uint64_t dR = 0, dQ = 0;
-                for (uint64_t i = 0; i < lead; i++) {
-                    if (rb_opc(ops[i]) == RB_OP_D) dR += rb_len(ops[i]); else dQ += rb_len(ops[i]);
-                }
-                for (uint64_t i = 0; i < trail; i++) {
-                    if (rb_opc(ops[n - 1 - i]) == RB_OP_D) dR += rb_len(ops[n - 1 - i]); else dQ += rb_len(ops[n - 1 - i]);
-                }
-                const uint64_t Rn = R - dR, Qn = Q - dQ, Un = U - lead_len - trail_len;
-                uint64_t nt_st = t_st + rm_st_t, nt_en = t_en - rm_en_t; // :760-761
-                if (minus) { // :764-766
-                    const uint64_t t = rm_st_q;
-                    rm_st_q = rm_en_q;
-                    rm_en_q = t;
-                }
-                uint64_t nq_st = q_st + rm_st_q, nq_en = q_en - rm_en_q; // :768-769
+                const uint64_t Rn = R - sp.dR, Qn = Q - sp.dQ, Un = U - sp.dR - sp.dQ; // stripped ops are I/D
                 if (Un > 0xFFFFFFFFull)
                     st = RB_ST_PANIC_OVERFLOW;
-                else if (nt_en < nt_st || nt_en - nt_st != Rn)
+                else if (sp.t_en < sp.t_st || sp.t_en - sp.t_st != Rn)
                     st = RB_ST_PANIC_INTEGRITY_T; // :782
-                else if (nq_en < nq_st || nq_en - nq_st != Qn)
+                else if (sp.q_en < sp.q_st || sp.q_en - sp.q_st != Qn)
                     st = RB_ST_PANIC_INTEGRITY_Q;
                 if (st == RB_ST_OK) {
-                    w.t_st = nt_st;
-                    w.t_en = nt_en;
-                    w.q_st = nq_st;
-                    w.q_en = nq_en;
-                    w.first_op = (uint32_t)lead;
-                    w.n_ops = (uint32_t)(n - lead - trail);
+                    w.t_st = sp.t_st;
+                    w.t_en = sp.t_en;
+                    w.q_st = sp.q_st;
+                    w.q_en = sp.q_en;
+                    w.first_op = sp.lead;
+                    w.n_ops = (uint32_t)(n - sp.lead - sp.trail);
                     w.nmatch = (uint32_t)M;
                     w.aln_len = (uint32_t)Un;
                 }
@@ -227,6 +278,11 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
     }
 }
 
+extern "C" hipError_t rb_launch_peek_norm(const rb_scan_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_peek_norm, dim3((unsigned)((p->n_rec + 255) / 256)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
 extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     const uint64_t blocks = (p->n_rec + 3) / 4;

@@ -64,6 +64,12 @@ struct rb_lift_params {
     int debug_skip; // diagnostics only (wrong results): 1 = no emission, 2 = no resolution, 4 = no streaming
     uint32_t wave0, wave_end; // slice of the schedule this launch covers (records are classed by length)
     rb_job *jobs;             // [n_rec], schedule order
+    // RB_LIFT_FUSED_SCAN: norm[] holds provisional rows (rb_k_peek_norm); the clip kernel verifies every record while it
+    // streams it, completes the row, and hands records it cannot vouch for back through pend_list for the full scan
+    int fused;
+    rb_norm_row *norm_w;           // == norm, writable
+    uint32_t *pend_list;           // [n_rec]
+    unsigned long long *pend_count;
 };
 
 // ------------------------------------------------------------------------------------------------

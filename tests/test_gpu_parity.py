@@ -45,6 +45,24 @@ def _check_liftover(engine, oracle, b, w, policy, what):
     rows, ops, norm, cnt = engine.liftover(*batch_args(b), b["contig"], *w, policy=policy)
     orows, oops = oracle.liftover(_obatch(oracle, b), *w, policy=policy)
     compare_hits(rows, ops, orows, oops, what)
+    # the same call with the record scan fused into the clip kernel (RB_LIFT_FUSED_SCAN): identical normalised rows, and
+    # identical hit rows for every record the reference would not panic on (rows of the others only carry the status)
+    frows, fops, fnorm, fcnt = engine.liftover(*batch_args(b), b["contig"], *w, policy=policy | rustybam_amd.LIFT_FUSED_SCAN)
+    assert np.array_equal(fnorm["status"], norm["status"]), f"{what}: fused norm.status"
+    ok = norm["status"] == 0
+    for k in ("t_st", "t_en", "q_st", "q_en", "first_op", "n_ops", "nmatch", "aln_len", "lead_ops", "trail_ops"):
+        bad = np.nonzero(ok & (fnorm[k] != norm[k]))[0]
+        assert len(bad) == 0, f"{what}: fused norm.{k} differs at {bad[:5]}: {fnorm[k][bad[:5]]} vs {norm[k][bad[:5]]}"
+    # flags: the fused scan judges regularity on the KEPT ops only, the stand-alone scan on the whole record (stripped end
+    # indels included), so "regular" may be granted more often; the other bits agree, except HAS_M which the fused scan
+    # also derives from the kept ops
+    fl, nl = fnorm["flags"].astype(np.int64), norm["flags"].astype(np.int64)
+    assert ((fl & 8) == 0).all(), f"{what}: a provisional row leaked"
+    assert ((fl & 2) == (nl & 2))[ok].all(), f"{what}: fused norm.flags STRIPPED"
+    assert ((nl & 1) <= (fl & 1))[ok].all(), f"{what}: fused norm.flags REGULAR"
+    keep = ok[frows["rec"]] if len(frows) else np.zeros(0, bool)
+    assert (frows["status"][~keep] != 0).all(), f"{what}: fused rows of panicking records must carry a status"
+    compare_hits(frows[keep], fops, orows, oops, what + " (fused)")
     return rows, cnt
 
 
