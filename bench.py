@@ -114,7 +114,7 @@ def main():
     policy = rustybam_amd.BSEARCH_MODERN | (rustybam_amd.LIFT_EARLY_EXIT if args.early_exit else 0) | (args.debug_skip << 8)
     if args.descriptors:
         policy |= rustybam_amd.LIFT_DESCRIPTORS
-    if args.op != "break" and not args.unfused:
+    if not args.unfused:
         policy |= rustybam_amd.LIFT_FUSED_SCAN
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
     rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, total_ops // 4)
@@ -147,8 +147,8 @@ def main():
     def step():
         # the whole hot path from the packed ops.  liftover: one fused call -- remove_trailing_indels + check_integrity (which the
         # reference's aligned_pairs runs inside trim_paf_by_rgns, liftover.rs:119-121) are done by the clip kernel while it streams
-        # each record (RB_LIFT_FUSED_SCAN: the normalised rows are an output of the step).  break-paf: record scan, then the kernels.
-        if args.op == "break" or args.unfused:
+        # each record (RB_LIFT_FUSED_SCAN: the normalised rows are an output of the step).
+        if args.unfused:
             eng.dev_scan_records(view, 0, d_norm.data_ptr())
         run_op(d_ws, d_rows, d_out)
 

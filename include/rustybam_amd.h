@@ -88,7 +88,7 @@ enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY
         * has length aln_len; RB_HIT_INSIDE rows keep all lengths.  Rows resolved by the generic kernel (irregular
         * cigars whose adjacent ops may merge) still carry real ops.  out_cap must be >= 4 * rows_cap + room for those. */
        RB_LIFT_DESCRIPTORS = 32,
-       /* RB_LIFT_FUSED_SCAN (rb_dev_liftover only): norm_rows is an OUTPUT.  rb_dev_scan_records need not have run: the call
+       /* RB_LIFT_FUSED_SCAN (rb_dev_liftover, rb_dev_break): norm_rows is an OUTPUT.  rb_dev_scan_records need not have run: the call
         * looks at the ends of every record (remove_trailing_indels), verifies integrity and regularity while the clip kernel
         * streams the record, and runs the full record scan only for records that fail that check.  Rows of a record whose
         * norm row ends up with status != RB_ST_OK carry that status. */

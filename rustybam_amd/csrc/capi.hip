@@ -439,7 +439,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.arena_size = ((out_cap - p.arena_origin) / p.n_arena) & ~(uint64_t)3;
     p.gen_list = (uint32_t *)(ws + w.gen_list);
     p.jobs = (rb_job *)(ws + w.jobs);
-    p.fused = (!is_break && (policy & RB_LIFT_FUSED_SCAN)) ? 1 : 0;
+    p.fused = (policy & RB_LIFT_FUSED_SCAN) ? 1 : 0;
     p.norm_w = const_cast<rb_norm_row *>(norm);
     p.pend_list = (uint32_t *)(ws + w.pend_list);
     p.pend_count = (unsigned long long *)(ws + w.pend_count);
@@ -706,7 +706,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     rb_lap("H2D batch", tl);
     rb_norm_row *d_norm = nullptr;
     if ((rc = b.alloc(n_rec, &d_norm))) return rc;
-    const bool fused = !is_break && (policy & RB_LIFT_FUSED_SCAN); // the clip kernel verifies the records itself
+    const bool fused = (policy & RB_LIFT_FUSED_SCAN) != 0; // the clip kernel verifies the records itself
     if (!fused) {
         if ((rc = rb_dev_scan_records(ctx, &b.v, nullptr, d_norm))) return rc;
         if (norm_out && (rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row)))) return rc;

@@ -520,7 +520,8 @@ void run_break(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t bre
     L.norm.resize(b.n());
     rb_counters cnt;
     eng.check(rb_host_break(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(), b.q_en.data(),
-                            b.strand.data(), break_length, eng.bsearch_policy | RB_LIFT_DESCRIPTORS, L.norm.data(), &L.rows, &L.n_rows, &L.out,
+                            b.strand.data(), break_length, eng.bsearch_policy | RB_LIFT_DESCRIPTORS | RB_LIFT_FUSED_SCAN, L.norm.data(), &L.rows,
+                            &L.n_rows, &L.out,
                             &L.n_out, &cnt),
               "rb_host_break");
     for (size_t i = 0; i < L.norm.size(); i++) panic_on(L.norm[i].status, "aligned_pairs", i); // main.rs:275

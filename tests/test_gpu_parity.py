@@ -194,6 +194,11 @@ def test_break_paf_fixture_and_random(engine, oracle, golden, policy, max_size):
         rows, ops, norm, cnt = engine.break_paf(*batch_args(bb), max_size, policy=policy)
         orows, oops = oracle.break_paf(_obatch(oracle, bb), max_size, policy=policy)
         compare_hits(rows, ops, orows, oops, f"break {what} max={max_size}")
+        # the same with the record scan fused into the clip kernel
+        frows, fops, fnorm, _ = engine.break_paf(*batch_args(bb), max_size, policy=policy | rustybam_amd.LIFT_FUSED_SCAN)
+        assert np.array_equal(fnorm["status"], norm["status"]) and not (fnorm["flags"] & 8).any()
+        keep = (norm["status"] == 0)[frows["rec"]] if len(frows) else np.zeros(0, bool)
+        compare_hits(frows[keep], fops, orows, oops, f"break {what} max={max_size} (fused)")
         if what == "fixture" and max_size == 100 and policy == rustybam_amd.BSEARCH_MODERN:
             assert int((rows["status"] == 0).sum()) == 2447
 
