@@ -894,7 +894,18 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
                           const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en, int policy, uint8_t *cig_status,
                           rb_reduce_row *reduce_out, rb_norm_row *norm_out, rb_hit_row **rows, uint64_t *n_rows, uint64_t **row_text_off,
                           uint8_t **row_text, rb_counters *counters) {
-    if (!ctx || !cig_off || !cig_end || !cig_status) return RB_E_INVALID;
+    if (!ctx || (n_rec && (!cig_off || !cig_end || !cig_status))) return RB_E_INVALID;
+    if (n_rec == 0) { // an empty file: no rows, no text
+        if (rows) *rows = nullptr;
+        if (n_rows) *n_rows = 0;
+        if (row_text) *row_text = nullptr;
+        if (row_text_off) {
+            *row_text_off = (uint64_t *)calloc(2, 8);
+            if (!*row_text_off) return fail(ctx, RB_E_NOMEM, "malloc");
+        }
+        if (counters) memset(counters, 0, sizeof *counters);
+        return RB_OK;
+    }
     rb_hit_row *rows_dummy = nullptr;
     uint64_t n_dummy = 0, *off_dummy = nullptr;
     uint8_t *text_dummy = nullptr;

@@ -227,3 +227,20 @@ def test_liftover_text_path_panics_and_skips(tmp_path):
     assert rc == 0 and out.count(b"\n") == 1            # the unparsable line is skipped (paf.rs:73)
     rc2, out2 = rb("liftover", "--bed", bed, ok, env={"RB_GENERAL_PATH": "1"})
     assert (rc2, out2) == (rc, out)
+
+
+def test_empty_and_tagless_inputs(oracle, tmp_path):
+    bed = tmp_path / "r.bed"
+    bed.write_text("T\t0\t100\n")
+    empty = tmp_path / "empty.paf"
+    empty.write_text("")
+    for args in (["liftover", "--bed", bed, empty], ["break-paf", empty], ["stats", "--paf", empty]):
+        rc, out = rb(*args)
+        orc, oout = oracle.cli(*args)
+        assert (rc, out) == (orc, oout), args
+    nocg = tmp_path / "nocg.paf"  # a record without a cg tag has an empty CIGAR: whatever the reference path does with it,
+    nocg.write_text("Q 10 0 5 + T 10 0 5 0 0 60 tp:A:P\n")  # the text path and the record path must agree
+    for args in (["liftover", "--bed", bed, nocg], ["stats", "--paf", nocg]):
+        a = rb(*args)
+        b = rb(*args, env={"RB_GENERAL_PATH": "1"})
+        assert a == b, args
