@@ -118,7 +118,7 @@ struct rb_plan {
     uint64_t n_rec = 0, n_win = 0;
     uint32_t n_contig = 0;
     // device arrays
-    uint32_t *sched = nullptr, *canon_pos = nullptr, *w_orig = nullptr, *ident = nullptr;
+    uint32_t *sched = nullptr, *slot_of = nullptr, *canon_pos = nullptr, *w_orig = nullptr, *ident = nullptr;
     uint64_t *w_st = nullptr, *w_en = nullptr, *wo_st = nullptr, *wo_en = nullptr, *cw_off = nullptr;
     uint8_t *cw_mono = nullptr;
 };
@@ -335,7 +335,10 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
         for (uint64_t i = cw_off[c] + 1; i < cw_off[c + 1]; i++)
             if (g_st[i] < g_st[i - 1] || g_en[i] < g_en[i - 1]) mono[c] = 0;
     int rc = RB_OK;
+    std::vector<uint32_t> slot_of(n_rec);
+    for (uint64_t w = 0; w < n_rec; w++) slot_of[sched[w]] = (uint32_t)w;
     if (!rc) rc = upload_vec(ctx, sched, &pl->sched);
+    if (!rc) rc = upload_vec(ctx, slot_of, &pl->slot_of);
     if (!rc) rc = upload_vec(ctx, ident, &pl->ident);
     if (!rc) rc = upload_vec(ctx, canon_pos, &pl->canon_pos);
     if (!rc) rc = upload_vec(ctx, g_st, &pl->w_st);
@@ -354,7 +357,7 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
 }
 extern "C" void rb_plan_destroy(rb_plan *pl) {
     if (!pl) return;
-    void *ptrs[] = {pl->sched, pl->ident, pl->canon_pos, pl->w_st, pl->w_en, pl->w_orig, pl->wo_st, pl->wo_en, pl->cw_off, pl->cw_mono};
+    void *ptrs[] = {pl->sched, pl->slot_of, pl->ident, pl->canon_pos, pl->w_st, pl->w_en, pl->w_orig, pl->wo_st, pl->wo_en, pl->cw_off, pl->cw_mono};
     for (void *q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -416,6 +419,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.strand = b->strand;
     p.norm = norm;
     p.sched = plan->sched;
+    p.slot_of = plan->slot_of;
     p.canon_pos = is_break ? plan->ident : plan->canon_pos;
     p.w_st = plan->w_st;
     p.w_en = plan->w_en;

@@ -126,12 +126,14 @@ __global__ __launch_bounds__(256) void rb_k_scan_apply(uint64_t *v, uint64_t n, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// clip jobs: one thread per schedule slot gathers what the clip kernels need about the slot's record
+// clip jobs: what a wave needs about its record, gathered into the record's schedule slot
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= p.n_rec) return;
-    const uint32_t r = p.sched[w];
+    // one thread per RECORD (rows, offsets and hit counts are read in memory order), the job goes to the record's slot
+    const uint64_t r64 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r64 >= p.n_rec) return;
+    const uint32_t r = (uint32_t)r64;
+    const uint64_t w = p.slot_of[r];
     const rb_norm_row *nr = &p.norm[r];
     rb_job j;
     j.r = r;
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                      "s_mov_b64 exec, %[sv]"                                                                                   \
                      : [sv] "=&s"(sv_), RB_PIN_BUFS                                                                            \
                      : [src] "v"(src_), [sbase] "s"(gsrc), [ds] "v"(DS), [dbase] "s"(region), [lmask] "s"(lmask_)              \
-                     : "vcc", "memory");                                                                                       \
+                     : "vcc", "scc", "memory");                                                                                \
     }
             for (uint32_t t0 = 0; t0 < n_turns + (RB_EB - 1); t0 += RB_EB) { // RB_EB - 1 extra turns drain the pipeline
 #if RB_EB == 6

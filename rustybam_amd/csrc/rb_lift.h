@@ -33,6 +33,7 @@ struct rb_lift_params {
     const rb_norm_row *norm;
     // schedule
     const uint32_t *sched;     // [n_rec] record handled by wave w (longest first)
+    const uint32_t *slot_of;   // [n_rec] inverse of sched: the wave that handles record r
     const uint32_t *canon_pos; // [n_rec] position of record r in canonical order
     // windows grouped by contig (BED order kept inside a contig) + original order
     const uint64_t *w_st, *w_en; // grouped
