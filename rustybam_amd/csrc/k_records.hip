@@ -10,6 +10,7 @@
 //                    check_integrity().unwrap() outcome at :782.
 // Roofline: HBM read, 4 B per op + 48 B header per record; 128 B of rows written per record.
 #include "rb_device.h"
+#include <algorithm>
 
 struct rb_scan_params {
     uint64_t n_rec;
@@ -122,15 +123,14 @@ __global__ __launch_bounds__(256) void rb_k_peek_norm(rb_scan_params p) {
 
 __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
     __shared__ unsigned long long hist_all[4][9][64];
-    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (wave >= p.n_rec) return;
-    uint64_t r = rb_first64(wave);
-    if (p.list) {
-        if (wave >= rb_first64(*p.n_list)) return;
-        r = rb_first(p.list[wave]);
-    }
+    const uint64_t wave0 = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     const int lane = rb_lane();
     unsigned long long(*hist)[64] = hist_all[threadIdx.x >> 6];
+    // list mode: a small fixed grid strides over the (usually empty) list; otherwise one wave per record
+    const uint64_t n_work = p.list ? rb_first64(*p.n_list) : p.n_rec;
+    const uint64_t stride = p.list ? (uint64_t)gridDim.x * 4u : n_work + 1;
+  for (uint64_t wave = wave0; wave < n_work; wave += stride) {
+    const uint64_t r = p.list ? (uint64_t)rb_first(p.list[wave]) : rb_first64(wave);
     const uint64_t o0 = p.op_off[r], o1 = p.op_off[r + 1];
     const uint64_t n = o1 - o0;
 #pragma unroll
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
     const uint32_t ins_events = C[RB_OP_I];
     const uint32_t del_events = C[RB_OP_D];
     bad = rb_wave_or_u32(bad);
-    if (lane != 0) return;
+    if (lane != 0) continue;
 
     const uint64_t R = L[RB_OP_M] + L[RB_OP_D] + L[RB_OP_N] + L[RB_OP_EQ] + L[RB_OP_X];
     const uint64_t Q = L[RB_OP_M] + L[RB_OP_I] + L[RB_OP_S] + L[RB_OP_EQ] + L[RB_OP_X];
@@ -276,6 +276,7 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
         w.status = st;
         p.norm_rows[r] = w;
     }
+  }
 }
 
 extern "C" hipError_t rb_launch_peek_norm(const rb_scan_params *p, hipStream_t stream) {
@@ -285,7 +286,7 @@ extern "C" hipError_t rb_launch_peek_norm(const rb_scan_params *p, hipStream_t s
 }
 extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
-    const uint64_t blocks = (p->n_rec + 3) / 4;
+    const uint64_t blocks = p->list ? std::min<uint64_t>((p->n_rec + 3) / 4, 1024) : (p->n_rec + 3) / 4;
     hipLaunchKernelGGL(rb_k_scan_records, dim3((unsigned)blocks), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
