@@ -667,6 +667,54 @@ __device__ uint64_t rb_legacy_probe(uint64_t N, uint64_t klo, uint64_t khi) {
     return klo;
 }
 
+// tpos_aln of a record whose target start is 0 and whose first ops consume no reference begins with units at
+// t_pos = -1, i.e. u64::MAX (paf.rs:505, :531): the array is then NOT sorted and slice::binary_search returns whatever
+// its probe sequence leads to.  This reproduces that probe sequence on the virtual array (value of a unit = walk of the
+// ops), for both generations of the Rust standard library.  Returns true and the index on Ok, false on Err.
+__device__ uint64_t rb_unit_tpos(const uint32_t *ops, uint32_t n, uint64_t t_st, uint64_t unit) {
+    int64_t tpos = (int64_t)t_st - 1;
+    uint64_t U = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t opc = rb_opc(ops[i]), len = rb_len(ops[i]);
+        const bool isref = opc <= 8 && rb_in(RB_REF_MASK, opc);
+        if (unit < U + len) return (uint64_t)(isref ? tpos + (int64_t)(unit - U) + 1 : tpos); // (-1 wraps to u64::MAX)
+        U += len;
+        if (isref) tpos += len;
+    }
+    return ~0ull;
+}
+__device__ bool rb_bsearch_units(const uint32_t *ops, uint32_t n, uint64_t t_st, uint64_t N, uint64_t key, int policy, uint64_t *idx) {
+    auto cmp = [&](uint64_t mid) -> int {
+        const uint64_t v = rb_unit_tpos(ops, n, t_st, mid);
+        return v < key ? -1 : (v > key ? 1 : 0);
+    };
+    if (policy != RB_BSEARCH_LEGACY) { // rustc >= 1.82
+        uint64_t size = N;
+        if (size == 0) return false;
+        uint64_t base = 0;
+        while (size > 1) {
+            const uint64_t half = size / 2, mid = base + half;
+            base = cmp(mid) > 0 ? base : mid;
+            size -= half;
+        }
+        *idx = base;
+        return cmp(base) == 0;
+    }
+    uint64_t size = N, left = 0, right = N; // 1.52 .. 1.81
+    while (left < right) {
+        const uint64_t mid = left + size / 2;
+        const int c = cmp(mid);
+        if (c < 0) left = mid + 1;
+        else if (c > 0) right = mid;
+        else {
+            *idx = mid;
+            return true;
+        }
+        size = right - left;
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
     const uint64_t n_gen = p.counters->n_generic;
     for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_gen; g += (uint64_t)gridDim.x * blockDim.x) {
@@ -757,13 +805,34 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
                 N += len;
             }
         }
-        if (!s_found || !e_found) { // binary_search Err -> panic (liftover.rs:31, :42)
-            w.status = RB_ST_PANIC_NOTFOUND;
-            *row = w;
-            continue;
+        // units at t_pos = -1 in front of the first reference-consuming op (only possible with t_st == 0): the array is not
+        // sorted, so the equal ranges do not tell what binary_search returns; its probe sequence is replayed instead
+        bool wrapped = false;
+        if (t_st == 0)
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t opc = rb_opc(ops[i]);
+                if (opc <= 8 && rb_in(RB_REF_MASK, opc)) break;
+                if (rb_len(ops[i]) != 0) {
+                    wrapped = true;
+                    break;
+                }
+            }
+        uint64_t ks, ke;
+        if (wrapped) {
+            if (!rb_bsearch_units(ops, n, t_st, N, (uint64_t)ps, p.policy, &ks) || !rb_bsearch_units(ops, n, t_st, N, (uint64_t)pe, p.policy, &ke)) {
+                w.status = RB_ST_PANIC_NOTFOUND;
+                *row = w;
+                continue;
+            }
+        } else {
+            if (!s_found || !e_found) { // binary_search Err -> panic (liftover.rs:31, :42)
+                w.status = RB_ST_PANIC_NOTFOUND;
+                *row = w;
+                continue;
+            }
+            ks = p.policy == RB_BSEARCH_LEGACY ? rb_legacy_probe(N, s_lo, s_hi) : s_hi;
+            ke = p.policy == RB_BSEARCH_LEGACY ? rb_legacy_probe(N, e_lo, e_hi) : e_hi;
         }
-        const uint64_t ks = p.policy == RB_BSEARCH_LEGACY ? rb_legacy_probe(N, s_lo, s_hi) : s_hi;
-        const uint64_t ke = p.policy == RB_BSEARCH_LEGACY ? rb_legacy_probe(N, e_lo, e_hi) : e_hi;
         // pass 2: a = first match-type unit >= ks (else N); b = last match-type unit <= ke (else 0)
         uint64_t a = N, b = 0;
         uint64_t Ra = 0, Qa = 0, Ma = 0, nRb = 0, nQb = 0, nMb = 0;

@@ -147,11 +147,15 @@ struct rb_qstream {
 __device__ uint32_t rb_clip_by_query(const rb_sview &v, uint64_t N, uint64_t new_q_st, uint64_t new_q_en, int policy, uint32_t *out,
                                      rb_pair_row *row, int s, uint64_t out_base) {
     if (!(new_q_st >= v.q_st) || !(new_q_en <= v.q_en) || new_q_en == 0) return RB_ST_PANIC_ASSERT; // :787-788
-    uint64_t klo, khi;
-    if (!rb_s_qrange(v, new_q_st, &klo, &khi)) return RB_ST_PANIC_NOTFOUND;
-    const uint64_t ks = policy == RB_BSEARCH_LEGACY ? rb_s_legacy_probe(N, klo, khi) : khi;
-    if (!rb_s_qrange(v, new_q_en - 1, &klo, &khi)) return RB_ST_PANIC_NOTFOUND;
-    const uint64_t ke = policy == RB_BSEARCH_LEGACY ? rb_s_legacy_probe(N, klo, khi) : khi;
+    uint64_t klo, khi, ks, ke;
+    if (rb_s_wrapped_q(v)) { // qpos_aln is not sorted: replay the binary search itself
+        if (!rb_s_bsearch_q(v, N, new_q_st, policy, &ks) || !rb_s_bsearch_q(v, N, new_q_en - 1, policy, &ke)) return RB_ST_PANIC_NOTFOUND;
+    } else {
+        if (!rb_s_qrange(v, new_q_st, &klo, &khi)) return RB_ST_PANIC_NOTFOUND;
+        ks = policy == RB_BSEARCH_LEGACY ? rb_s_legacy_probe(N, klo, khi) : khi;
+        if (!rb_s_qrange(v, new_q_en - 1, &klo, &khi)) return RB_ST_PANIC_NOTFOUND;
+        ke = policy == RB_BSEARCH_LEGACY ? rb_s_legacy_probe(N, klo, khi) : khi;
+    }
     // qpos_to_idx_match (paf.rs:576-590): search_right flips on '-'
     uint64_t aln_st = !v.minus ? rb_s_match_ge(v, ks, N) : rb_s_match_le(v, ks);
     uint64_t aln_en = !v.minus ? rb_s_match_le(v, ke) : rb_s_match_ge(v, ke, N);
@@ -227,7 +231,46 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split(rb_trim_params p) {
     B.v = R, B.policy = p.policy, B.N = NR, B.ms = p.match_score, B.ds = p.diff_score, B.is = p.indel_score;
     int32_t best = 0;
     uint64_t best_idx = 0;
-    if (n > 0) {
+    if (n > 0 && (rb_s_wrapped_q(L) || rb_s_wrapped_q(R))) {
+        // a qpos_aln that is not sorted (see rb_s_wrapped_q): score_of_qpos (trim_overlap.rs:6-19) base by base with the
+        // binary search replayed; an Err is the .unwrap() panic.  Slow, and only for this corner.
+        auto score = [&](const rb_sview &v, uint64_t N, uint64_t pos, int32_t *out) -> bool {
+            uint64_t idx;
+            if (!rb_s_bsearch_q(v, N, pos, p.policy, &idx)) return false;
+            uint32_t oc;
+            uint64_t tp, qp;
+            rb_s_unit(v, idx, &oc, &tp, &qp);
+            *out = oc == RB_OP_EQ ? p.match_score : ((oc == RB_OP_I || oc == RB_OP_D) ? -p.indel_score : -p.diff_score);
+            return true;
+        };
+        bool ok = true;
+        int32_t rsum = 0;
+        for (uint64_t k = 0; k < n && ok; k++) {
+            int32_t ls, rs;
+            ok = score(L, NL, st_ovl + k, &ls) && score(R, NR, st_ovl + k, &rs); // (both are looked up, left first: :50-51)
+            if (ok) rsum += rs;
+        }
+        if (!ok) {
+            w.status = RB_ST_PANIC_NOTFOUND;
+            p.rows[pi] = w;
+            return;
+        }
+        int32_t lpre = 0, rpre = 0;
+        for (uint64_t k = 0; k <= n; k++) { // l_score[k] + r_score[k], first strict maximum (initial 0 at 0)
+            const int32_t val = lpre + (rsum - rpre);
+            if (val > best) {
+                best = val;
+                best_idx = k;
+            }
+            if (k < n) {
+                int32_t ls, rs;
+                score(L, NL, st_ovl + k, &ls);
+                score(R, NR, st_ovl + k, &rs);
+                lpre += ls;
+                rpre += rs;
+            }
+        }
+    } else if (n > 0) {
         // sum of the right record's scores over the overlap (r_score suffix sum at index 0)
         int32_t rsum = 0;
         B.seek(st_ovl);

@@ -103,6 +103,53 @@ __device__ inline void rb_s_unit(const rb_sview &v, uint64_t k, uint32_t *opc_ou
     *tpos_out = *qpos_out = 0;
 }
 
+// qpos_aln of a '+' record whose query start is 0 and whose first ops consume no query begins with units at
+// q_pos = -1, i.e. u64::MAX (paf.rs:506, :532): the array is then NOT sorted and what slice::binary_search_by returns is
+// whatever its probe sequence leads to.  rb_s_bsearch_q replays that sequence on the virtual array (paf.rs:564-573; the
+// comparator is reversed on '-'), for both generations of the Rust standard library.  false = Err.
+__device__ inline bool rb_s_wrapped_q(const rb_sview &v) {
+    if (v.minus || v.q_st != 0) return false;
+    for (uint32_t i = 0; i < v.n; i++) {
+        if (rb_len(v.ops[i]) == 0) continue;
+        return !rb_s_qry(rb_opc(v.ops[i]));
+    }
+    return false;
+}
+__device__ inline bool rb_s_bsearch_q(const rb_sview &v, uint64_t N, uint64_t key, int policy, uint64_t *idx) {
+    auto cmp = [&](uint64_t mid) -> int {
+        uint32_t oc;
+        uint64_t tp, qp;
+        rb_s_unit(v, mid, &oc, &tp, &qp);
+        const int c = qp < key ? -1 : (qp > key ? 1 : 0);
+        return v.minus ? -c : c;
+    };
+    if (policy != RB_BSEARCH_LEGACY) { // rustc >= 1.82
+        uint64_t size = N;
+        if (size == 0) return false;
+        uint64_t base = 0;
+        while (size > 1) {
+            const uint64_t half = size / 2, mid = base + half;
+            base = cmp(mid) > 0 ? base : mid;
+            size -= half;
+        }
+        *idx = base;
+        return cmp(base) == 0;
+    }
+    uint64_t size = N, left = 0, right = N; // 1.52 .. 1.81
+    while (left < right) {
+        const uint64_t mid = left + size / 2;
+        const int c = cmp(mid);
+        if (c < 0) left = mid + 1;
+        else if (c > 0) right = mid;
+        else {
+            *idx = mid;
+            return true;
+        }
+        size = right - left;
+    }
+    return false;
+}
+
 // first match-type unit >= k (N if none): the walk of paf.rs:551-553 / :581-583
 __device__ inline uint64_t rb_s_match_ge(const rb_sview &v, uint64_t k, uint64_t N) {
     uint64_t U = 0;

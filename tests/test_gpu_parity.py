@@ -298,3 +298,18 @@ def test_liftover_long_records_many_segments(engine, oracle):
     w = (np.zeros(200, np.uint32), st, en)
     rows, cnt = _check_liftover(engine, oracle, b, w, rustybam_amd.BSEARCH_MODERN, "long records")
     assert cnt["n_generic"] == 0
+
+
+def test_liftover_unsorted_tpos_array(engine, oracle):
+    """t_st == 0 and a leading op that consumes no reference: the reference's tpos_aln starts with units at t_pos = -1
+    (u64::MAX), is not sorted, and binary_search returns whatever its probe sequence leads to (found by tools/soak.py).
+    The generic kernel replays the probe sequence; both generations of the standard library."""
+    lines = ["Q 2000 1666 1766 + T 100 0 23 0 0 60 cg:Z:40S2=2N2I1=1D1N3I2=40I3=1=2=1I3D2=1=2N",
+             "Q 2000 0 12 + T 100 0 9 0 0 60 cg:Z:5H3=1X2N3=3S", "Q 2000 0 12 - T 100 0 9 0 0 60 cg:Z:3S3=1X2N3=5H"]
+    r = recs_from_lines(lines)
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand, contig=r.contig)
+    ws = np.array([2, 0, 1, 5, 0, 8], np.uint64)
+    we = np.array([88, 4, 9, 6, 23, 9], np.uint64)
+    w = (np.zeros(len(ws), np.uint32), ws, we)
+    for pol in (rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY):
+        _check_liftover(engine, oracle, b, w, pol, f"unsorted tpos policy {pol}")

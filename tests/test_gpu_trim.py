@@ -14,7 +14,7 @@ from rbtest_util import random_cigar, read_paf, recs_from_lines, sums, unpack
 pytestmark = pytest.mark.gpu
 
 
-def _pairs_batch(rng, n_pairs, mode):
+def _pairs_batch(rng, n_pairs, mode, zero_bias=False):
     cig, t_st, t_en, q_st, q_en, strand = [], [], [], [], [], []
     left, right = [], []
     for _ in range(n_pairs):
@@ -23,7 +23,7 @@ def _pairs_batch(rng, n_pairs, mode):
         (ra, qa), (rb, qb) = sums(ca), sums(cb)
         if min(qa, qb) < 2:
             continue
-        a0 = int(rng.integers(0, 1000))
+        a0 = 0 if (zero_bias and rng.random() < 0.5) else int(rng.integers(0, 1000))
         o = int(rng.integers(1, min(qa, qb)))  # 1 <= overlap < both lengths: neither is contained
         b0 = a0 + qa - o
         for c, r, q, s0 in ((ca, ra, qa, a0), (cb, rb, qb, b0)):
@@ -96,3 +96,16 @@ def test_trim_paf_fixture_end_to_end(engine, golden, policy, key):
     dig = json.load(open(os.path.join(golden, "digests.json")))[key]["md5"]
     assert len(lines) == 249
     assert hashlib.md5("".join(lines).encode()).hexdigest() == dig
+
+
+@pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
+def test_pairs_unsorted_qpos_array(engine, oracle, policy):
+    """q_st == 0 on '+' with a leading op that consumes no query: qpos_aln starts at q_pos = -1 (u64::MAX) and is not sorted;
+    the pair kernel replays the binary search base by base (found by tools/soak_trim.py)."""
+    rng = np.random.default_rng(7002)
+    b, left, right = _pairs_batch(rng, 200, "wild", zero_bias=True)
+    rows, out = engine.overlap_split(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], left, right, (1, 1, 1), policy)
+    ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], np.zeros(len(b["t_st"]), np.uint32))
+    orows, oout = oracle.overlap_split(ob, left, right, (1, 1, 1), policy)
+    assert (orows["status"] == 16).any() and (orows["status"] == 0).any()  # the corner is actually exercised
+    _compare(rows, out, orows, oout, f"unsorted qpos policy {policy}")
