@@ -810,12 +810,10 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
         bool wrapped = false;
         if (t_st == 0)
             for (uint32_t i = 0; i < n; i++) {
+                if (rb_len(ops[i]) == 0) continue; // (a zero-length op adds no unit)
                 const uint32_t opc = rb_opc(ops[i]);
-                if (opc <= 8 && rb_in(RB_REF_MASK, opc)) break;
-                if (rb_len(ops[i]) != 0) {
-                    wrapped = true;
-                    break;
-                }
+                wrapped = !(opc <= 8 && rb_in(RB_REF_MASK, opc));
+                break;
             }
         uint64_t ks, ke;
         if (wrapped) {

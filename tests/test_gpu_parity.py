@@ -305,7 +305,8 @@ def test_liftover_unsorted_tpos_array(engine, oracle):
     (u64::MAX), is not sorted, and binary_search returns whatever its probe sequence leads to (found by tools/soak.py).
     The generic kernel replays the probe sequence; both generations of the standard library."""
     lines = ["Q 2000 1666 1766 + T 100 0 23 0 0 60 cg:Z:40S2=2N2I1=1D1N3I2=40I3=1=2=1I3D2=1=2N",
-             "Q 2000 0 12 + T 100 0 9 0 0 60 cg:Z:5H3=1X2N3=3S", "Q 2000 0 12 - T 100 0 9 0 0 60 cg:Z:3S3=1X2N3=5H"]
+             "Q 2000 0 12 + T 100 0 9 0 0 60 cg:Z:5H3=1X2N3=3S", "Q 2000 0 12 - T 100 0 9 0 0 60 cg:Z:3S3=1X2N3=5H",
+             "Q 2000 0 65 + T 100 0 23 0 0 60 cg:Z:0=2S40I2D7X1I1D2I3=3=3X3I3D1X"]  # (a zero-length op adds no unit)
     r = recs_from_lines(lines)
     b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand, contig=r.contig)
     ws = np.array([2, 0, 1, 5, 0, 8], np.uint64)

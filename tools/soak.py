@@ -14,7 +14,21 @@ for seed in range(n_cases):
     rng = np.random.default_rng(1000 + seed)
     mode = ["regular", "indel_ends", "wild", "mixed"][seed % 4]
     b = random_batch(rng, int(rng.integers(1, 400)), mode, n_contig=int(rng.integers(1, 4)), long_frac=float(rng.random() * 0.3))
-    w = random_windows(rng, b, int(rng.integers(1, 200)), bool(seed % 3))
+    if seed % 5 == 0:  # coordinates that start at 0
+        z = rng.random(len(b["t_st"])) < 0.5
+        b["t_en"] = np.where(z, b["t_en"] - b["t_st"], b["t_en"]); b["t_st"] = np.where(z, 0, b["t_st"]).astype(np.uint64)
+        z = rng.random(len(b["q_st"])) < 0.5
+        b["q_en"] = np.where(z, b["q_en"] - b["q_st"], b["q_en"]); b["q_st"] = np.where(z, 0, b["q_st"]).astype(np.uint64)
+        b["t_en"], b["q_en"] = b["t_en"].astype(np.uint64), b["q_en"].astype(np.uint64)
+    w = random_windows(rng, b, int(rng.integers(1, 600 if seed % 7 == 0 else 200)), bool(seed % 3))
+    # scan rows as well
+    red, norm0 = eng.scan_records(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
+    ored, onorm = oracle.reduce(oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], b["contig"])), \
+        oracle.normalize(oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], b["contig"]))
+    assert np.array_equal(red["status"], ored["status"]) and np.array_equal(norm0["status"], onorm["status"]), (seed, "scan status")
+    okn = onorm["status"] == 0
+    for kk in ("t_st", "t_en", "q_st", "q_en", "first_op", "n_ops", "nmatch", "aln_len"):
+        assert np.array_equal(norm0[kk][okn], onorm[kk][okn]), (seed, "norm", kk)
     ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], b["contig"])
     for pol in (rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY):
         orows, oops = oracle.liftover(ob, *w, policy=pol)
