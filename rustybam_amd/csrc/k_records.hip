@@ -11,6 +11,7 @@
 // Roofline: HBM read, 4 B per op + 48 B header per record; 128 B of rows written per record.
 #include "rb_device.h"
 #include <algorithm>
+#include <type_traits>
 
 struct rb_scan_params {
     uint64_t n_rec;
@@ -137,49 +138,74 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
     for (int t = 0; t < 9; t++) hist[t][lane] = 0ull;
     uint32_t bad = 0; // bit0: op outside M I D = X, bit1: zero length, bit2: adjacent ops of one type, bit3: code > 8
 
-    // ---- streaming pass: aligned 16-byte loads, 256 ops per wave step, next step prefetched ----
+    // ---- streaming pass: 8 ops (32 contiguous bytes) per lane and step, two steps in flight in a statically indexed
+    //      ring (rotating it with moves, or predicating the loads, makes the compiler wait for every load in flight);
+    //      loads past the record's end re-read its last group and are masked on the last step ----
     const uint64_t g0 = o0 & ~3ull;
-    const uint64_t n_steps = (o1 - g0 + 255u) >> 8;
-    uint32_t carry_opc = 16u; // op code of the last op of the previous step (16 = none)
-    uint4 cur = make_uint4(0, 0, 0, 0), nx1 = make_uint4(0, 0, 0, 0);
-    {
-        const uint64_t gi = g0 + (uint64_t)lane * 4u;
-        if (n_steps > 0 && gi < o1) cur = *reinterpret_cast<const uint4 *>(p.ops + gi);
-        if (n_steps > 1 && gi + 256u < o1) nx1 = *reinterpret_cast<const uint4 *>(p.ops + gi + 256u);
-    }
-    for (uint64_t s = 0; s < n_steps; s++) {
-        const uint64_t gi = g0 + (s << 8) + (uint64_t)lane * 4u;
-        uint4 nx2 = make_uint4(0, 0, 0, 0);
-        if (s + 2 < n_steps && gi + 512u < o1) nx2 = *reinterpret_cast<const uint4 *>(p.ops + gi + 512u);
-        const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
-        uint32_t code[4]; // 16 = not an op of this record (head / tail padding)
-        bool valid[4];
+    const int32_t head = (int32_t)(o0 - g0);
+    const uint32_t n32 = (uint32_t)n; // (a record has fewer than 2^32 ops)
+    const uint32_t n_steps = n ? (uint32_t)((o1 - g0 + 511u) >> 9) : 0u;
+    const uint32_t *__restrict__ gbase = p.ops + g0;
+    const uint32_t last_off = n ? (uint32_t)(((o1 - 1u) & ~3ull) - g0) : 0u;
+    auto load_half = [&](uint32_t stp, uint32_t half) -> uint4 {
+        uint32_t off = (stp << 9) + half * 4u + (uint32_t)lane * 8u;
+        off = off < last_off ? off : last_off;
+        return *reinterpret_cast<const uint4 *>(gbase + off);
+    };
+    uint32_t carry_w = 0xFu; // last op word of the previous step in adjacency form (code 15 equals nothing)
+    uint32_t v_reg = 0xFFFFFFFFu, v_minlen = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_big = 0u;
+    uint4 pf[2][2];
+    if (n_steps) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            valid[q] = gi + q >= o0 && gi + q < o1;
-            code[q] = valid[q] ? rb_opc(raw[q]) : 16u;
+        for (int q = 0; q < 2; q++) {
+            pf[q][0] = load_half((uint32_t)q, 0u);
+            pf[q][1] = load_half((uint32_t)q, 1u);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        uint32_t prev = rb_prev_lane(code[3], carry_opc);
+    }
+    const uint32_t my_hist = (uint32_t)lane; // hist[code][lane]
+    for (uint32_t st0 = 0; st0 < n_steps; st0 += 2) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t opc = code[q], len = rb_len(raw[q]);
-            if (valid[q]) {
-                if (opc <= 8u) {
-                    __hip_atomic_fetch_add(&hist[opc][lane], (unsigned long long)len | (1ull << RB_LEN_BITS), __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
-                } else {
-                    bad |= 8u;
-                }
-                if (!rb_in(RB_REGULAR_MASK, opc)) bad |= 1u;
-                if (len == 0) bad |= 2u;
-                if (opc == prev) bad |= 4u;
+        for (int ring = 0; ring < 2; ring++) {
+            const uint32_t st = st0 + (uint32_t)ring;
+            if (st < n_steps) {
+                const uint32_t raw[8] = {pf[ring][0].x, pf[ring][0].y, pf[ring][0].z, pf[ring][0].w,
+                                         pf[ring][1].x, pf[ring][1].y, pf[ring][1].z, pf[ring][1].w};
+                const int32_t idx0 = (int32_t)(st << 9) + lane * 8 - head;
+                auto step = [&](auto edge_c) {
+                    constexpr bool edge = decltype(edge_c)::value; // first / last step: ops of the neighbours are skipped
+                    uint32_t mylast = raw[7];
+                    if (edge && (uint32_t)(idx0 + 7) >= n32) mylast = 0xFu;
+                    uint32_t prevw = rb_prev_lane(mylast, carry_w);
+                    carry_w = rb_readlane<uint32_t>(mylast, 63);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const bool ok = !edge || (uint32_t)(idx0 + q) < n32;
+                        const uint32_t w = raw[q], opc = w & 15u, len = w >> 4;
+                        if (ok) {
+                            if (opc <= 8u) {
+                                __hip_atomic_fetch_add(&hist[opc][my_hist], (unsigned long long)len | (1ull << RB_LEN_BITS), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+                            } else {
+                                v_big |= 8u;
+                            }
+                            v_reg &= (uint32_t)__builtin_amdgcn_sbfe((int)0x01870187u, w, 1u); // M I D = X
+                            v_minlen = v_minlen < len ? v_minlen : len;
+                            const uint32_t x = (w ^ prevw) & 15u;
+                            v_adj = v_adj < x ? v_adj : x;
+                        }
+                        prevw = ok ? w : 0xFu;
+                    }
+                };
+                if (st == 0 || st + 1 == n_steps) step(std::true_type{});
+                else step(std::false_type{});
             }
-            prev = opc;
+            pf[ring][0] = load_half(st + 2u, 0u);
+            pf[ring][1] = load_half(st + 2u, 1u);
         }
-        carry_opc = rb_readlane<uint32_t>(code[3], 63);
-        cur = nx1;
-        nx1 = nx2;
     }
+    // bit0: op outside M I D = X, bit1: zero length, bit2: adjacent ops of one type, bit3: code > 8
+    if (n_steps) bad = (v_reg != 0xFFFFFFFFu ? 1u : 0u) | (v_minlen == 0u ? 2u : 0u) | (v_adj == 0u ? 4u : 0u) | v_big;
 
     // ---- cross-lane reduction ----
     uint64_t L[9];
