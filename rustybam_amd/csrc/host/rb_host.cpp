@@ -656,14 +656,24 @@ struct TextFile {
         lap("header columns", tl);
         return true;
     }
-    // the panics of Paf::from_file (paf.rs:399, :70), in the reference's order of checks
-    void check_loaded(const std::vector<uint8_t> &cig_status, const std::vector<rb_reduce_row> &red) const {
+    // the panics of Paf::from_file (paf.rs:399, :70), in the reference's order of checks.  false = a CIGAR the device left to
+    // the host (zero-padded numbers longer than a lane) turned out to be valid: the caller takes the general path
+    bool check_loaded(const std::vector<uint8_t> &cig_status, const std::vector<rb_reduce_row> &red) const {
+        bool unusual = false;
         for (size_t i = 0; i < recs.size(); i++) {
+            if (cig_status[i] == RB_TEXT_UNUSUAL) {
+                std::vector<uint32_t> cig;
+                parse_cigar(all.data() + recs[i].cg, recs[i].cg_n, cig); // throws the reference's panic if it is malformed
+                unusual = true;
+                continue;
+            }
             if (cig_status[i] == RB_TEXT_TOO_LONG) throw Panic("cigar length does not fit the packed form (>= 2^28)");
             if (cig_status[i] != RB_TEXT_OK) throw Panic("Unable to parse cigar string.");
         }
+        if (unusual) return false;
         for (size_t i = 0; i < recs.size(); i++)
             if (red[i].status != RB_ST_OK) throw Panic("check_integrity: record " + std::to_string(i + 1) + " status " + std::to_string(red[i].status));
+        return true;
     }
     // "_TO.<lead>.<trail>" of a record whose end indels were stripped (paf.rs:726-732), parsed from its own text (rare)
     std::string stripped_suffix(uint32_t r, const rb_norm_row &nr) const {
@@ -738,7 +748,7 @@ bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vec
                                     &R.n_rows, &R.toff, &R.text, &cnt),
               "rb_host_liftover_text");
     lap("rb_host_liftover_text", tl);
-    f.check_loaded(cig_status, red);
+    if (!f.check_loaded(cig_status, red)) return false;
     for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
     out_text = assemble_lines(f, norm, R, &rgns);
     lap("assemble lines", tl);
@@ -761,7 +771,7 @@ bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_le
                                  red.data(), norm.data(), &R.rows, &R.n_rows, &R.toff, &R.text, &cnt),
               "rb_host_break_text");
     lap("rb_host_break_text", tl);
-    f.check_loaded(cig_status, red);
+    if (!f.check_loaded(cig_status, red)) return false;
     for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i); // main.rs:275
     out_text = assemble_lines(f, norm, R, nullptr);
     lap("assemble lines", tl);
@@ -778,7 +788,7 @@ bool stats_file_text(Engine &eng, const std::string &paf_path, bool qbed, std::v
     eng.check(rb_host_scan_text(eng.ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(), f.cig_end.data(), f.t_st.data(),
                                 f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(), cig_status.data(), red.data(), nullptr),
               "rb_host_scan_text");
-    f.check_loaded(cig_status, red);
+    if (!f.check_loaded(cig_status, red)) return false;
     for (size_t i = 0; i < n; i++)
         if (red[i].flags & RB_F_HAS_M) { // bamstats.rs:145-153
             fprintf(stderr, "\r⚠ warning: cigar string contains 'M', assuming mismatch since there is no MD tag.");

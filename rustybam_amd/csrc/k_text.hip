@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
 #pragma unroll
         for (int j = 0; j < 8; j++) slen[j] = 0u, sinfo[j] = 0u;
         uint32_t cnt = 0;
-        uint64_t acc = 0;
+        uint32_t acc = 0;     // value of the number being read (32-bit; `ovf` says it went past u32::MAX)
+        bool ovf = false;
         uint32_t nd = 0;      // digits of the number being read
         uint32_t lead_nd = 0; // digits before the first op character of the chunk (to combine with the carry)
         bool seen = false, any_valid = false;
@@ -100,21 +101,22 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
             if (valid) {
                 any_valid = true;
                 if (d < 10u) {
-                    acc = acc * 10u + d;
+                    if (acc > 429496729u || (acc == 429496729u && d > 5u)) ovf = true; // the value leaves u32 (leading zeros may run on)
+                    acc = ((acc << 3) + (acc << 1)) + d; // acc * 10 + d without the slow 32-bit multiply
                     nd++;
-                    if (nd > 10u) err = RB_TEXT_BAD; // more digits than a u32 has
                 } else {
                     const uint32_t code = rb_op_code_of(c);
                     if (code == 255u) err = RB_TEXT_BAD;
                     if (!seen) lead_nd = nd;
-                    else if (nd == 0u || acc > 0xFFFFFFFFull) err = RB_TEXT_BAD;        // no length / overflow of u32
-                    else if (acc >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;   // not representable in the packed form
+                    else if (nd == 0u || ovf) err = RB_TEXT_BAD;                        // no length / overflow of u32
+                    else if (acc >= (1u << 28) && err == 0) err = RB_TEXT_TOO_LONG;     // not representable in the packed form
                     if (sinfo[k >> 1] != 0u) err = RB_TEXT_BAD;                        // two op characters in one byte pair
-                    slen[k >> 1] = (uint32_t)acc;                                       // (completed below for the first op)
-                    sinfo[k >> 1] = (code & 15u) | (acc > 0xFFFFFFFFull ? 0x10000u : 0u) | (seen ? 0u : 0x20000u) | 0x1000000u;
+                    slen[k >> 1] = acc;                                                 // (completed below for the first op)
+                    sinfo[k >> 1] = (code & 15u) | (ovf ? 0x10000u : 0u) | (seen ? 0u : 0x20000u) | 0x1000000u;
                     cnt++;
                     seen = true;
                     acc = 0;
+                    ovf = false;
                     nd = 0;
                 }
             }
@@ -122,10 +124,11 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
         // the string must end with an op character
         if (la + 16u >= b1 && la < b1 && nd != 0u) err = RB_TEXT_BAD;
         // my unfinished tail -> the next lane; lane 0 takes the previous step's lane 63
-        const uint32_t tail_val = (uint32_t)acc, tail_nd = nd | (acc > 0xFFFFFFFFull ? 0x100u : 0u);
+        const uint32_t tail_val = acc, tail_nd = nd | (ovf ? 0x100u : 0u);
         const uint32_t in_val = rb_prev_lane(tail_val, carry_val), in_nd = rb_prev_lane(tail_nd, carry_nd);
-        // a chunk of digits only is legal as the (short) head of the string; it cannot continue a number
-        if (!seen && any_valid && (in_nd & 0xFFu) != 0u) err = RB_TEXT_BAD;
+        // a chunk of digits only is the (short) head of the string, or part of a number padded with zeros to more than a
+        // lane holds: legal for the reference (u32::from_str), not handled here -> the host decides (RB_TEXT_UNUSUAL)
+        if (!seen && any_valid && ((in_nd & 0xFFu) != 0u || nd >= 16u)) err = err ? err : RB_TEXT_UNUSUAL;
         carry_val = rb_readlane<uint32_t>(tail_val, 63);
         carry_nd = rb_readlane<uint32_t>(tail_nd, 63);
         const uint32_t incl = rb_wave_scan_incl(cnt);
@@ -140,14 +143,17 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
                         const uint32_t ind = in_nd & 0xFFu;
                         const uint32_t tnd = ind + lead_nd;
                         uint64_t full = l;
-                        if (ind) {
-                            uint64_t pw = 1;
-                            for (uint32_t e = 0; e < lead_nd; e++) pw *= 10u;
-                            full = (uint64_t)in_val * pw + l;
-                            if (in_nd & 0x100u) full = ~0ull;
+                        if (ind && in_val != 0u) { // (incoming zeros change nothing)
+                            if (lead_nd >= 10u) {
+                                full = ~0ull; // a non-zero value followed by ten more digits is past u32::MAX
+                            } else {
+                                uint64_t pw = 1;
+                                for (uint32_t e = 0; e < lead_nd; e++) pw *= 10u;
+                                full = (uint64_t)in_val * pw + l; // < 2^32 * 10^9
+                            }
                         }
-                        if (sinfo[j] & 0x10000u) full = ~0ull;
-                        if (tnd == 0u || tnd > 10u || full > 0xFFFFFFFFull) err = RB_TEXT_BAD;
+                        if ((in_nd & 0x100u) || (sinfo[j] & 0x10000u)) full = ~0ull;
+                        if (tnd == 0u || full > 0xFFFFFFFFull) err = (err == 0 || err == RB_TEXT_TOO_LONG) ? RB_TEXT_BAD : err;
                         else if (full >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;
                         l = (uint32_t)full;
                     }
@@ -160,10 +166,11 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
         total += step_total;
     }
     // (an empty string is an empty CIGAR)
-    const uint32_t any_err = rb_wave_or_u32(err == RB_TEXT_BAD ? 1u : (err == RB_TEXT_TOO_LONG ? 2u : 0u));
+    const uint32_t any_err = rb_wave_or_u32(err == RB_TEXT_BAD ? 1u : (err == RB_TEXT_TOO_LONG ? 2u : (err == RB_TEXT_UNUSUAL ? 4u : 0u)));
     if (lane == 0) {
         if (!FILL) p.op_off[r] = total;
-        else p.status[r] = (uint8_t)((any_err & 1u) ? RB_TEXT_BAD : ((any_err & 2u) ? RB_TEXT_TOO_LONG : RB_TEXT_OK));
+        else // (an unusual string may also be a bad one: the host's parser has the last word on it)
+            p.status[r] = (uint8_t)((any_err & 4u) ? RB_TEXT_UNUSUAL : ((any_err & 1u) ? RB_TEXT_BAD : ((any_err & 2u) ? RB_TEXT_TOO_LONG : RB_TEXT_OK)));
     }
 }
 

@@ -244,3 +244,15 @@ def test_empty_and_tagless_inputs(oracle, tmp_path):
         a = rb(*args)
         b = rb(*args, env={"RB_GENERAL_PATH": "1"})
         assert a == b, args
+
+
+def test_zero_padded_cigar_numbers(oracle, tmp_path):
+    """u32::from_str accepts leading zeros; a number longer than a 16-byte lane makes the text path step aside"""
+    bed = tmp_path / "r.bed"
+    bed.write_text("T\t1\t4\n")
+    paf = tmp_path / "z.paf"
+    paf.write_text("Q 10 0 5 + T 10 0 5 0 0 60 cg:Z:00000000000000000005=\nQ 10 0 5 + T 10 0 5 0 0 60 cg:Z:003=02X\n")
+    for args in (["liftover", "--bed", bed, paf], ["stats", "--paf", paf], ["break-paf", paf]):
+        rc, out = rb(*args)
+        orc, oout = oracle.cli(*args)
+        assert (rc, out) == (orc, oout) and rc == 0 and out, args

@@ -81,7 +81,8 @@ def test_parse_errors_like_the_reference(engine, oracle, bad):
     assert oracle_parse(oracle, bad) is None
     good = "5=2X"
     _, _, status = engine.parse_cigars([good, bad, good])
-    assert status.tolist() == [0, 1, 0]
+    # 1 = rejected on the device; 3 = "a number longer than a lane holds, ask the host's parser" (which rejects it)
+    assert status[0] == 0 and status[2] == 0 and status[1] in (1, 3)
 
 
 def test_parse_too_long_for_the_packed_form(engine):
@@ -127,3 +128,17 @@ def test_format_matches_oracle_and_clips(engine, oracle):
             if len(seg) and ll[i]:
                 seg[-1] = (int(ll[i]) << 4) | (int(seg[-1]) & 15)
         assert text[int(toff[i]):int(toff[i + 1])] == oracle_format(oracle, seg), i
+
+
+def test_parse_zero_padded_numbers(engine, oracle):
+    """u32::from_str accepts any number of leading zeros: short paddings are parsed on the device, a number longer than one
+    16-byte lane is handed to the host (status 3), never rejected"""
+    cigs = ["00000000005M", "0000000000000012=3X", "7=" + "0" * 9 + "4294967295D"[:0] + "000000000268435455D", "0" * 40 + "9M", "5=" + "0" * 20 + "1X"]
+    op_off, ops, status = engine.parse_cigars(cigs)
+    for i, c in enumerate(cigs):
+        want = oracle_parse(oracle, c)
+        assert want is not None
+        assert status[i] in (0, 3), (c, int(status[i]))
+        if status[i] == 0:
+            assert np.array_equal(ops[int(op_off[i]):int(op_off[i + 1])], want), c
+    assert status[0] == 0 and status[3] == 3

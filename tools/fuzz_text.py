@@ -22,7 +22,7 @@ for it in range(0, n_cases, 500):
     for _ in range(500):
         if rng.random() < 0.5:  # mostly valid, then damaged
             k = int(rng.integers(0, 400))
-            parts = [f"{int(rng.integers(0, 10 ** int(rng.integers(1, 9))))}{'MIDNSHP=X'[int(rng.integers(0, 9))]}" for _ in range(k)]
+            parts = [f"{'0' * int(rng.choice([0, 0, 0, 1, 3, 9]))}{int(rng.integers(0, 10 ** int(rng.integers(1, 9))))}{'MIDNSHP=X'[int(rng.integers(0, 9))]}" for _ in range(k)]
             s = bytearray("".join(parts).encode())
             for _ in range(int(rng.integers(0, 2))):
                 if s:
@@ -33,8 +33,9 @@ for it in range(0, n_cases, 500):
     op_off, ops, status = eng.parse_cigars(strs)
     for i, s in enumerate(strs):
         want = oparse(s)
+        if status[i] == 3:  # handed to the host's parser
+            continue
         if want is None:
-            big = False
             assert status[i] != 0, (s, "device accepted what the oracle rejects")
             bad += 1
         else:
