@@ -43,21 +43,15 @@ struct rb_format_params {
     uint64_t text_cap;
 };
 
-// op character -> code (MIDNSHP=X -> 0..8), 255 = not an op
+// op character -> code (MIDNSHP=X -> 0..8), 255 = not an op.  Branch-free: the nine characters lie in '=' (61) .. 'X' (88),
+// so the code is a nibble of a packed table indexed by c - 61 (15 = not an op).
 __device__ __forceinline__ uint32_t rb_op_code_of(uint32_t c) {
-    // 'M'77 'I'73 'D'68 'N'78 'S'83 'H'72 'P'80 '='61 'X'88
-    switch (c) {
-    case 'M': return 0u;
-    case 'I': return 1u;
-    case 'D': return 2u;
-    case 'N': return 3u;
-    case 'S': return 4u;
-    case 'H': return 5u;
-    case 'P': return 6u;
-    case '=': return 7u;
-    case 'X': return 8u;
-    default: return 255u;
-    }
+    const unsigned long long lo = 0xfff15fff2ffffff7ull; // offsets 0..15 from '=': '=' 0 -> 7, 'D' 7 -> 2, 'H' 11 -> 5, 'I' 12 -> 1
+    const unsigned long long hi = 0xffff8ffff4ff6f30ull; // offsets 16..31: 'M' 16 -> 0, 'N' 17 -> 3, 'P' 19 -> 6, 'S' 22 -> 4, 'X' 27 -> 8
+    const uint32_t o = c - 61u;
+    const unsigned long long t = (o & 16u) ? hi : lo;
+    const uint32_t nib = (uint32_t)(t >> ((o & 15u) * 4u)) & 15u;
+    return (o < 32u && nib != 15u) ? nib : 255u;
 }
 
 template <bool FILL>
@@ -92,35 +86,39 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
         uint32_t nd = 0;      // digits of the number being read
         uint32_t lead_nd = 0; // digits before the first op character of the chunk (to combine with the carry)
         bool seen = false, any_valid = false;
+        // (written with selects, not branches: sixteen divergent ifs per lane cost ~1600 scalar instructions of exec-mask
+        //  handling per step and made the kernel scalar-issue-bound)
+        const uint32_t first_valid = b0 > la ? (uint32_t)(b0 - la) : 0u;                     // bytes [first_valid, end_valid) of the
+        const uint32_t end_valid = b1 > la ? (b1 - la < 16u ? (uint32_t)(b1 - la) : 16u) : 0u; // chunk belong to the string
+        uint32_t errb = 0; // bit 0: malformed, bit 1: a length >= 2^28
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const uint64_t pos = la + (uint64_t)k;
-            const bool valid = pos >= b0 && pos < b1;
+            const bool valid = (uint32_t)k >= first_valid && (uint32_t)k < end_valid;
             const uint32_t c = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
             const uint32_t d = c - 48u;
-            if (valid) {
-                any_valid = true;
-                if (d < 10u) {
-                    if (acc > 429496729u || (acc == 429496729u && d > 5u)) ovf = true; // the value leaves u32 (leading zeros may run on)
-                    acc = ((acc << 3) + (acc << 1)) + d; // acc * 10 + d without the slow 32-bit multiply
-                    nd++;
-                } else {
-                    const uint32_t code = rb_op_code_of(c);
-                    if (code == 255u) err = RB_TEXT_BAD;
-                    if (!seen) lead_nd = nd;
-                    else if (nd == 0u || ovf) err = RB_TEXT_BAD;                        // no length / overflow of u32
-                    else if (acc >= (1u << 28) && err == 0) err = RB_TEXT_TOO_LONG;     // not representable in the packed form
-                    if (sinfo[k >> 1] != 0u) err = RB_TEXT_BAD;                        // two op characters in one byte pair
-                    slen[k >> 1] = acc;                                                 // (completed below for the first op)
-                    sinfo[k >> 1] = (code & 15u) | (ovf ? 0x10000u : 0u) | (seen ? 0u : 0x20000u) | 0x1000000u;
-                    cnt++;
-                    seen = true;
-                    acc = 0;
-                    ovf = false;
-                    nd = 0;
-                }
-            }
+            const bool isdig = valid & (d < 10u), islet = valid & !(d < 10u);
+            const uint32_t code = rb_op_code_of(c);
+            // digit: the value leaves u32 (leading zeros may run on), acc * 10 + d without the slow 32-bit multiply
+            ovf |= isdig & ((acc > 429496729u) | ((acc == 429496729u) & (d > 5u)));
+            const uint32_t acc10 = ((acc << 3) + (acc << 1)) + d;
+            // op character
+            const bool later = islet & seen; // (the first op of the chunk is completed below, with the incoming digits)
+            errb |= (islet & (code == 255u)) ? 1u : 0u;
+            errb |= (later & ((nd == 0u) | ovf)) ? 1u : 0u;                      // no length / overflow of u32
+            errb |= (later & !ovf & (acc >= (1u << 28))) ? 2u : 0u;              // not representable in the packed form
+            errb |= (islet & (sinfo[k >> 1] != 0u)) ? 1u : 0u;                   // two op characters in one byte pair
+            lead_nd = (islet & !seen) ? nd : lead_nd;
+            slen[k >> 1] = islet ? acc : slen[k >> 1];                           // (completed below for the first op)
+            sinfo[k >> 1] = islet ? ((code & 15u) | (ovf ? 0x10000u : 0u) | (seen ? 0u : 0x20000u) | 0x1000000u) : sinfo[k >> 1];
+            cnt += islet ? 1u : 0u;
+            seen |= islet;
+            any_valid |= valid;
+            acc = isdig ? acc10 : (islet ? 0u : acc);
+            nd = isdig ? nd + 1u : (islet ? 0u : nd);
+            ovf = ovf & !islet;
         }
+        if (errb & 1u) err = RB_TEXT_BAD;
+        else if ((errb & 2u) && err == 0) err = RB_TEXT_TOO_LONG;
         // the string must end with an op character
         if (la + 16u >= b1 && la < b1 && nd != 0u) err = RB_TEXT_BAD;
         // my unfinished tail -> the next lane; lane 0 takes the previous step's lane 63
