@@ -50,72 +50,90 @@ __global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
     const uint64_t t_st = nr->t_st;
     const uint64_t rec0 = p.op_off[r] + nr->first_op;
     const uint64_t h0 = p.fill ? rb_first64(p.hit_off[r]) : 0;
+    // 8 ops (32 contiguous bytes) per lane and step, two steps in flight in a statically indexed ring; loads past the
+    // record's end re-read its last group and are masked on the last step (see k_liftover.hip)
     const uint64_t g0 = rec0 & ~3ull, gend = rec0 + n;
-    const uint64_t n_steps = (gend - g0 + 255u) >> 8;
+    const int32_t head = (int32_t)(rec0 - g0);
+    const uint32_t n_steps = (uint32_t)((gend - g0 + 511u) >> 9);
+    const uint32_t *__restrict__ gbase = p.ops + g0;
+    const uint32_t last_off = (uint32_t)(((gend - 1u) & ~3ull) - g0);
+    auto load_half = [&](uint32_t stp, uint32_t half) -> uint4 {
+        uint32_t off = (stp << 9) + half * 4u + (uint32_t)lane * 8u;
+        off = off < last_off ? off : last_off;
+        return *reinterpret_cast<const uint4 *>(gbase + off);
+    };
     uint32_t Rb = 0, pre = 0, cnt = 0; // ref bases so far, end of the last big indel, pieces so far
-    uint4 cur = make_uint4(0, 0, 0, 0);
-    {
-        const uint64_t gi = g0 + (uint64_t)lane * 4u;
-        if (gi < gend) cur = *reinterpret_cast<const uint4 *>(p.ops + gi);
+    uint4 pf[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        pf[q][0] = load_half((uint32_t)q, 0u);
+        pf[q][1] = load_half((uint32_t)q, 1u);
+        __builtin_amdgcn_sched_barrier(0);
     }
-    for (uint64_t st = 0; st < n_steps; st++) {
-        const uint64_t gi = g0 + (st << 8) + (uint64_t)lane * 4u;
-        uint4 nxt = make_uint4(0, 0, 0, 0);
-        if (gi + 256u < gend) nxt = *reinterpret_cast<const uint4 *>(p.ops + gi + 256u);
-        const int32_t idx0 = (int32_t)((int64_t)gi - (int64_t)rec0);
-        const uint32_t raw[4] = {cur.x, cur.y, cur.z, cur.w};
-        uint32_t rl[4], Rx[4];
-        bool big[4];
-        uint32_t sr = 0;
+    for (uint32_t st0 = 0; st0 < n_steps; st0 += 2) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bool valid = (uint32_t)(idx0 + q) < n;
-            const uint32_t opc = valid ? rb_opc(raw[q]) : RB_NULL_OP, len = valid ? rb_len(raw[q]) : 0u;
-            rl[q] = (opc <= 8u && rb_in(RB_REF_MASK, opc)) ? len : 0u;
-            big[q] = valid && (opc == RB_OP_I || opc == RB_OP_D) && len > p.max_size;
-            Rx[q] = sr;
-            sr += rl[q];
-        }
-        const uint32_t ir = rb_wave_scan_incl(sr);
-        const uint32_t er = Rb + ir - sr;
-        // lane-local: end of the last big indel inside the lane (absolute offsets are monotone)
-        uint32_t lane_end = 0;
+        for (int ring = 0; ring < 2; ring++) {
+            const uint32_t st = st0 + (uint32_t)ring;
+            if (st < n_steps) {
+                const uint32_t raw[8] = {pf[ring][0].x, pf[ring][0].y, pf[ring][0].z, pf[ring][0].w,
+                                         pf[ring][1].x, pf[ring][1].y, pf[ring][1].z, pf[ring][1].w};
+                const int32_t idx0 = (int32_t)(st << 9) + lane * 8 - head;
+                const bool edge = st == 0 || st + 1 == n_steps;
+                uint32_t rl[8], Rx[8];
+                bool big[8];
+                uint32_t sr = 0;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            Rx[q] += er;
-            if (big[q]) lane_end = Rx[q] + rl[q];
-        }
-        const uint32_t im = rb_wave_scan_incl_max(lane_end);
-        uint32_t run_pre = rb_umax(pre, rb_prev_lane(im, 0u)); // end of the last big indel before this lane
-        uint32_t pc[4], pst[4];
-        uint32_t lane_cnt = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const bool piece = big[q] && Rx[q] > run_pre;
-            pc[q] = piece ? 1u : 0u;
-            pst[q] = run_pre;
-            lane_cnt += pc[q];
-            if (big[q]) run_pre = Rx[q] + rl[q];
-        }
-        const uint32_t ic = rb_wave_scan_incl(lane_cnt);
-        if (p.fill) {
-            uint32_t ord = cnt + ic - lane_cnt;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (pc[q]) {
-                    const uint64_t h = h0 + ord;
-                    if (h < p.rows_cap) {
-                        p.x_st[h] = t_st + pst[q];
-                        p.x_en[h] = t_st + Rx[q];
-                    }
-                    ord++;
+                for (int q = 0; q < 8; q++) {
+                    const bool valid = !edge || (uint32_t)(idx0 + q) < n;
+                    const uint32_t opc = valid ? rb_opc(raw[q]) : RB_NULL_OP, len = valid ? rb_len(raw[q]) : 0u;
+                    rl[q] = (opc <= 8u && rb_in(RB_REF_MASK, opc)) ? len : 0u;
+                    big[q] = valid && (opc == RB_OP_I || opc == RB_OP_D) && len > p.max_size;
+                    Rx[q] = sr;
+                    sr += rl[q];
                 }
+                const uint32_t ir = rb_wave_scan_incl(sr);
+                const uint32_t er = Rb + ir - sr;
+                // lane-local: end of the last big indel inside the lane (absolute offsets are monotone)
+                uint32_t lane_end = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    Rx[q] += er;
+                    if (big[q]) lane_end = Rx[q] + rl[q];
+                }
+                const uint32_t im = rb_wave_scan_incl_max(lane_end);
+                uint32_t run_pre = rb_umax(pre, rb_prev_lane(im, 0u)); // end of the last big indel before this lane
+                uint32_t pc[8], pst[8];
+                uint32_t lane_cnt = 0;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const bool piece = big[q] && Rx[q] > run_pre;
+                    pc[q] = piece ? 1u : 0u;
+                    pst[q] = run_pre;
+                    lane_cnt += pc[q];
+                    if (big[q]) run_pre = Rx[q] + rl[q];
+                }
+                const uint32_t ic = rb_wave_scan_incl(lane_cnt);
+                if (p.fill) {
+                    uint32_t ord = cnt + ic - lane_cnt;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (pc[q]) {
+                            const uint64_t h = h0 + ord;
+                            if (h < p.rows_cap) {
+                                p.x_st[h] = t_st + pst[q];
+                                p.x_en[h] = t_st + Rx[q];
+                            }
+                            ord++;
+                        }
+                    }
+                }
+                cnt += rb_readlane<uint32_t>(ic, 63);
+                pre = rb_umax(pre, rb_readlane<uint32_t>(im, 63));
+                Rb += rb_readlane<uint32_t>(ir, 63);
             }
+            pf[ring][0] = load_half(st + 2u, 0u);
+            pf[ring][1] = load_half(st + 2u, 1u);
         }
-        cnt += rb_readlane<uint32_t>(ic, 63);
-        pre = rb_umax(pre, rb_readlane<uint32_t>(im, 63));
-        Rb += rb_readlane<uint32_t>(ir, 63);
-        cur = nxt;
     }
     const bool last = Rb > pre; // liftover.rs:213-224
     if (lane == 0) {
