@@ -182,6 +182,12 @@ def main():
 
     # ---- post-run facts for the roofline (rank 0's shard) ----
     cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
+    if args.debug_skip & 32:  # diagnostics: per-phase shader-clock sums of the clip kernel (last step, every 16th record)
+        ph = [int(x) * 16 * 16 for x in cnt["_pad"]]
+        names = ["job+windows", "stream+resolve", "verdict+finalize", "reservation", "rows+end groups", "interior copy", "-"]
+        tot = sum(ph) or 1
+        print("[phases] " + "  ".join(f"{n_}={v / tot:.3f}" for n_, v in zip(names, ph)) + f"  | mean cycles/record {tot / max(1, n_rec):.0f}",
+              file=sys.stderr)
     rows_t = d_rows[: n_hits * 64].view(torch.int32).view(n_hits, 16)
     status = (rows_t[:, 2] & 0xFFFF)
     out_n = rows_t[:, 3].to(torch.int64)

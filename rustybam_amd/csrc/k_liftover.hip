@@ -29,6 +29,16 @@
 #include "rb_lift.h"
 #include <type_traits>
 
+// diagnostics (debug_skip & 32): shader-clock time of each phase of a record, every 16th record, summed in units of 16
+// cycles into counters->_pad[0..6]: job + windows, stream + resolve, verdict + finalize, reservation, rows + end groups,
+// interior copy, (unused)
+#define RB_PHASE(i)                                                                                                  \
+    if (p.debug_skip & 32) {                                                                                         \
+        const long long t_now = clock64();                                                                           \
+        if (lane == 0 && (wave & 15) == 0) atomicAdd(&p.counters->_pad[i], (uint32_t)((t_now - t_prev) >> 4));       \
+        t_prev = t_now;                                                                                              \
+    }
+
 __global__ __launch_bounds__(256) void rb_k_count_hits(rb_lift_params p) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.n_rec) return;
@@ -195,6 +205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
     const uint64_t wave = (uint64_t)p.wave0 + (uint64_t)blockIdx.x * 4u + wib;
     if (wave >= p.wave_end) return;
     const int lane = rb_lane();
+    long long t_prev = (p.debug_skip & 32) ? clock64() : 0;
     uint32_t *cpR = cp_all[wib][0], *cpQ = cp_all[wib][1], *cpU = cp_all[wib][2];
     const rb_job jb_ = p.jobs[wave]; // (uniform address: one 64-byte request)
     const uint32_t jflags = rb_first(jb_.flags);
@@ -264,6 +275,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
         rb_bres O;
         O.st = RB_S_UNRES;
         O.op = O.part = O.R = O.Q = O.U = 0;
+        if (p.debug_skip & 32) { // (the window values must have arrived for the phase boundary to mean anything)
+            asm volatile("s_waitcnt vmcnt(0)");
+        }
+        RB_PHASE(0)
 
         // ---- stream the record, RB_SMAX steps per segment; resolve after each segment ----
         uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
@@ -390,6 +405,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
             }
         }
 
+        RB_PHASE(1)
         if (validate) {
             // ---- the verdict of the fused scan: check_integrity (paf.rs:825-857) on the normalised record and the
             //      conditions of the fast path.  A record that fails any of them is handed back: the full record scan
@@ -476,6 +492,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
         uint4 eg_q0 = *reinterpret_cast<const uint4 *>(gsrc + eg_f);
         uint4 eg_q1 = *reinterpret_cast<const uint4 *>(gsrc + eg_l);
         __builtin_amdgcn_sched_barrier(0);
+        RB_PHASE(2)
         const uint32_t lead = e_first & 3u;
         const uint32_t padded = emits ? ((lead + out_n + 3u) & ~3u) : 0u;
         const uint32_t incl = rb_wave_scan_incl(padded);
@@ -486,6 +503,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
             if (lane == 0) b0 = atomicAdd(&p.arena_cur[(uint64_t)arena * RB_ARENA_STRIDE], (unsigned long long)total);
             base = rb_first64(b0);
         }
+        RB_PHASE(3)
         const bool fits = base + total <= p.arena_size;
         if (!fits && lane == 0) p.counters->overflow = 1;
         const uint64_t region0 = p.arena_origin + (uint64_t)arena * p.arena_size + base; // multiple of 4 ops
@@ -555,6 +573,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                 __builtin_nontemporal_store(s0, reinterpret_cast<rb_u32x4 *>(dst));
                 if (eg_l != eg_f) __builtin_nontemporal_store(s1, reinterpret_cast<rb_u32x4 *>(dst + (eg_l - eg_f)));
             }
+            RB_PHASE(4)
             // clip table: region offset of the clip's first group, coordinates of its first and last group
             uint32_t *et = &et_all[wib][0][0];
             if (mine) {
@@ -639,6 +658,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
 #undef RB_EMIT_TURN
 #undef RB_PIN_BUFS
 #undef RB_EMIT_WAIT
+            RB_PHASE(5)
         }
     }
 }
