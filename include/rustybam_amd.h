@@ -96,10 +96,11 @@ enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY
 
 /* rb_norm_row.flags / rb_reduce_row.flags */
 enum {
-    RB_F_REGULAR = 1u << 0,   /* only M I D = X ops, every len >= 1, no two adjacent ops of one type */
+    RB_F_REGULAR = 1u << 0,   /* only M I D N = X ops, every len >= 1, no two adjacent ops of one type, M / = / X at both ends */
     RB_F_STRIPPED = 1u << 1,  /* leading/trailing indels were removed (host appends _TO.<..>.<..>) */
     RB_F_HAS_M = 1u << 2,     /* cigar contains 'M' (bamstats.rs:145 warning)                      */
-    RB_F_PROVISIONAL = 1u << 3 /* never visible to callers: row written from the record's ends only, not yet verified */
+    RB_F_PROVISIONAL = 1u << 3, /* never visible to callers: row written from the record's ends only, not yet verified */
+    RB_F_ENDS_NOT_MATCH = 1u << 4 /* never visible to callers: provisional row whose kept range does not start and end on M / = / X */
 };
 /* rb_hit_row.flags */
 enum {

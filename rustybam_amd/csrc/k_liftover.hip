@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
         if (h0 + nh > p.rows_cap) f |= RB_JOB_ROWS_OVERFLOW;
         else f |= RB_JOB_VALID;
     }
-    if ((nr->flags & RB_F_REGULAR) || provisional) f |= RB_JOB_REGULAR;
+    if ((nr->flags & RB_F_REGULAR) || (provisional && !(nr->flags & RB_F_ENDS_NOT_MATCH))) f |= RB_JOB_REGULAR;
     if (p.strand[r] == (uint8_t)'-') f |= RB_JOB_MINUS;
     if (mono) f |= RB_JOB_MONO;
     j.flags = f;
@@ -227,6 +227,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
         we = p.cw_off[cg + 1];
     }
     if (!(jflags & RB_JOB_REGULAR)) { // window order does not matter on the fast path: resolution is per lane
+        if (p.fused && lane == 0) { // (a provisional row that cannot take the fast path: the full scan completes it)
+            const unsigned long long i = atomicAdd(p.pend_count, 1ull);
+            p.pend_list[i] = r;
+        }
         rb_defer_record(p, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
         return;
     }
@@ -333,7 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                                         const bool ok = !edge || (uint32_t)(idx0v + q) < n;
                                         const uint32_t w = raw[q];
                                         if (ok) {
-                                            v_reg &= (uint32_t)__builtin_amdgcn_sbfe((int)0x01870187u, w, 1u); // M I D = X
+                                            v_reg &= (uint32_t)__builtin_amdgcn_sbfe((int)0x018F018Fu, w, 1u); // M I D N = X
                                             v_minlen = v_minlen < rb_len(w) ? v_minlen : rb_len(w);
                                             const uint32_t x = (w ^ prevw) & 15u;
                                             v_adj = v_adj < x ? v_adj : x;
@@ -346,14 +350,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                                 else verify(std::false_type{});
                             }
                             // per-lane sums of the reference / query / unit lengths of 8 ops; regular records hold only
-                            // M I D = X, so "consumes the reference" = not I and "consumes the query" = not D: one
+                            // M I D N = X, so "consumes the reference" = not I and "consumes the query" = not D / N: one
                             // v_bfe_i32 per class turns the op code (low bits of the word) into an all-ones / zero mask
                             uint32_t sr = 0, sq = 0, su = 0;
 #pragma unroll
                             for (int q = 0; q < 8; q++) {
                                 const uint32_t len = rb_len(raw[q]);
                                 sr += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFDFFFDu, raw[q], 1u);
-                                sq += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFBFFFBu, raw[q], 1u);
+                                sq += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFF3FFF3u, raw[q], 1u); // not D, not N
                                 su += len;
                             }
                             const uint32_t ir = rb_wave_scan_incl(sr), iq = rb_wave_scan_incl(sq), iu = rb_wave_scan_incl(su);

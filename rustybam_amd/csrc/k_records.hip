@@ -108,6 +108,10 @@ __global__ __launch_bounds__(256) void rb_k_peek_norm(rb_scan_params p) {
             w.t_st = sp.t_st, w.t_en = sp.t_en, w.q_st = sp.q_st, w.q_en = sp.q_en;
             w.first_op = sp.lead;
             w.n_ops = (uint32_t)(n - sp.lead - sp.trail);
+            // the streaming kernel wants a match-type op at both ends of the kept range; otherwise the record goes straight to
+            // the full scan and the generic kernel
+            const uint32_t fo = rb_opc(p.ops[o0 + sp.lead]), lo_ = rb_opc(p.ops[o0 + n - 1 - sp.trail]);
+            if (fo > 8u || lo_ > 8u || !rb_in(RB_MATCH_MASK, fo) || !rb_in(RB_MATCH_MASK, lo_)) w.flags |= RB_F_ENDS_NOT_MATCH;
         }
     }
     if (st != RB_ST_OK) w.flags &= ~(uint32_t)RB_F_PROVISIONAL; // nothing left to verify: the reference panics on this record
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
                             } else {
                                 v_big |= 8u;
                             }
-                            v_reg &= (uint32_t)__builtin_amdgcn_sbfe((int)0x01870187u, w, 1u); // M I D = X
+                            v_reg &= (uint32_t)__builtin_amdgcn_sbfe((int)0x018F018Fu, w, 1u); // M I D N = X
                             v_minlen = v_minlen < len ? v_minlen : len;
                             const uint32_t x = (w ^ prevw) & 15u;
                             v_adj = v_adj < x ? v_adj : x;
@@ -296,6 +300,9 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
                     w.n_ops = (uint32_t)(n - sp.lead - sp.trail);
                     w.nmatch = (uint32_t)M;
                     w.aln_len = (uint32_t)Un;
+                    // the streaming kernel wants a match-type op at both ends of the kept range (N is never stripped)
+                    const uint32_t fo = rb_opc(p.ops[o0 + sp.lead]), lo_ = rb_opc(p.ops[o1 - 1 - sp.trail]);
+                    if (!rb_in(RB_MATCH_MASK, fo) || !rb_in(RB_MATCH_MASK, lo_)) w.flags &= ~(uint32_t)RB_F_REGULAR;
                 }
             }
         }

@@ -13,7 +13,7 @@
 #define RB_QRY_MASK 0x193u   /* M I S = X   */
 #define RB_MATCH_MASK 0x181u /* M = X       */
 #define RB_INDEL_MASK 0x006u /* I D         */
-#define RB_REGULAR_MASK 0x187u /* M I D = X */
+#define RB_REGULAR_MASK 0x18Fu /* M I D N = X: what the streaming clip kernel handles (N behaves like D, but is never stripped) */
 
 __device__ __forceinline__ uint32_t rb_opc(uint32_t v) { return v & 15u; }
 __device__ __forceinline__ uint32_t rb_len(uint32_t v) { return v >> 4; }

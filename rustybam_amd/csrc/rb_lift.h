@@ -154,9 +154,9 @@ struct rb_bres {
 
 #define RB_WALK_MAX 24
 
-// regular records only (M I D = X): ref = not I, query = not D
+// regular records only (M I D N = X): ref = not I, query = not D and not N
 __device__ __forceinline__ uint32_t rb_rl(uint32_t v) { return rb_opc(v) == RB_OP_I ? 0u : rb_len(v); }
-__device__ __forceinline__ uint32_t rb_ql(uint32_t v) { return rb_opc(v) == RB_OP_D ? 0u : rb_len(v); }
+__device__ __forceinline__ uint32_t rb_ql(uint32_t v) { return (rb_opc(v) == RB_OP_D || rb_opc(v) == RB_OP_N) ? 0u : rb_len(v); }
 __device__ __forceinline__ bool rb_ism(uint32_t v) { return rb_in(RB_MATCH_MASK, rb_opc(v)); }
 
 // ops[] = the record's kept ops, n of them.  (cR,cQ,cU) = prefixes at op index cidx (checkpoint).

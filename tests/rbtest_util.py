@@ -100,6 +100,7 @@ def sums(ops):
 def random_cigar(rng, n_ops, mode):
     """mode 'regular': = X M I D, no two adjacent of one type, starts/ends on a match op (like minimap2)
        mode 'indel_ends': regular body with leading/trailing I/D runs
+       mode 'spliced': regular plus N ops (introns), which the streaming kernel treats like D but which are never stripped
        mode 'wild': anything incl. N S H P, zero lengths, adjacent duplicates"""
     ops = []
     if mode == "wild":
@@ -111,8 +112,12 @@ def random_cigar(rng, n_ops, mode):
     prev = -1
     for i in range(n_ops):
         while True:
-            if i == 0 or i == n_ops - 1:
+            if mode == "spliced" and (i == 0 or i == n_ops - 1):
+                c = int(rng.choice([7, 8, 0, 3], p=[.75, .1, .1, .05]))  # an N at an end is never stripped
+            elif i == 0 or i == n_ops - 1:
                 c = int(rng.choice([7, 8, 0], p=[.8, .1, .1]))
+            elif mode == "spliced":
+                c = int(rng.choice([7, 8, 0, 1, 2, 3], p=[.42, .18, .05, .12, .12, .11]))
             else:
                 c = int(rng.choice([7, 8, 0, 1, 2], p=[.45, .2, .05, .15, .15]))
             if c != prev:
@@ -133,7 +138,7 @@ def random_batch(rng, n_rec, mode="regular", n_contig=2, max_ops=40, long_frac=0
         n_ops = int(rng.integers(1, max_ops))
         if rng.random() < long_frac:
             n_ops = int(rng.integers(200, 1500))
-        m = mode if mode != "mixed" else str(rng.choice(["regular", "indel_ends", "wild"]))
+        m = mode if mode != "mixed" else str(rng.choice(["regular", "indel_ends", "spliced", "wild"]))
         c = random_cigar(rng, n_ops, m)
         R, Q = sums(c)
         ts, qs = int(rng.integers(0, 3000)), int(rng.integers(0, 3000))

@@ -146,8 +146,8 @@ def test_liftover_fixture_tiled_100kb(engine, oracle, golden):
     assert cnt["n_generic"] < len(rows) // 50  # the streaming kernel did the work
 
 
-@pytest.mark.parametrize("mode,monotone", [("regular", True), ("regular", False), ("indel_ends", True),
-                                           ("wild", True), ("mixed", False), ("mixed", True)])
+@pytest.mark.parametrize("mode,monotone", [("regular", True), ("regular", False), ("indel_ends", True), ("spliced", True),
+                                           ("spliced", False), ("wild", True), ("mixed", False), ("mixed", True)])
 @pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
 def test_liftover_random(engine, oracle, mode, monotone, policy):
     import zlib
@@ -158,6 +158,8 @@ def test_liftover_random(engine, oracle, mode, monotone, policy):
         rows, cnt = _check_liftover(engine, oracle, b, w, policy, f"{mode} mono={monotone} rep={rep}")
         if mode == "regular" and policy == rustybam_amd.BSEARCH_MODERN:
             assert cnt["n_generic"] == 0  # sorted or not, regular records never leave the streaming kernel
+        if mode == "spliced":
+            assert cnt["n_generic"] < len(rows) // 4  # N ops stay on the fast path unless one sits at an end of the record
 
 
 def test_liftover_many_windows_per_record(engine, oracle):

@@ -12,9 +12,9 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 tot = 0
 for seed in range(n_cases):
     rng = np.random.default_rng(1000 + seed)
-    mode = ["regular", "indel_ends", "wild", "mixed"][seed % 4]
+    mode = ["regular", "indel_ends", "wild", "mixed", "spliced"][seed % 5]
     b = random_batch(rng, int(rng.integers(1, 400)), mode, n_contig=int(rng.integers(1, 4)), long_frac=float(rng.random() * 0.3))
-    if seed % 5 == 0:  # coordinates that start at 0
+    if seed % 7 == 0:  # coordinates that start at 0
         z = rng.random(len(b["t_st"])) < 0.5
         b["t_en"] = np.where(z, b["t_en"] - b["t_st"], b["t_en"]); b["t_st"] = np.where(z, 0, b["t_st"]).astype(np.uint64)
         z = rng.random(len(b["q_st"])) < 0.5

@@ -12,7 +12,7 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 tot = 0
 for seed in range(n_cases):
     rng = np.random.default_rng(5000 + seed)
-    mode = ["regular", "indel_ends", "regular", "mixed"][seed % 4]
+    mode = ["regular", "indel_ends", "spliced", "mixed"][seed % 4]
     cig, t_st, t_en, q_st, q_en, strand = [], [], [], [], [], []
     for _ in range(int(rng.integers(2, 14))):
         n_ops = int(rng.choice([511, 512, 513, 1023, 1025, 5119, 5120, 5121, 5125, int(rng.integers(3000, 16000))]))
