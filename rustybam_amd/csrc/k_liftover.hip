@@ -287,8 +287,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
         // ---- stream the record, RB_SMAX steps per segment; resolve after each segment ----
         uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
         // fused verification (first pass): AND of the "regular op" masks, minimum length, minimum of code XOR previous code
-        // (0 = two adjacent ops of one type), minimum op code (0 = an M), sums too large for 32-bit scans
-        uint32_t v_reg = 0xFFFFFFFFu, v_minlen = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_mincode = 15u, v_big = 0u;
+        // (0 = two adjacent ops of one type), minimum op code (0 = an M); sums too large for 32-bit scans zero the minimum length
+        uint32_t v_reg = 0xFFFFFFFFu, v_minlen = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_mincode = 15u;
         uint32_t v_carry = 0xFu;       // last op word of the previous step (code 15: equals nothing)
         unsigned long long v_utot = 0; // 64-bit sum of all lengths
         if ((__ballot(need) != 0 || validate) && !(p.debug_skip & 4)) {
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
                             Qb += rb_readlane<uint32_t>(iq, 63);
                             Ub += rb_readlane<uint32_t>(iu, 63);
                             if (validate) {
-                                v_big |= su >> 25; // per-lane sums below 2^25 keep the 64-lane scans inside 32 bits
+                                v_minlen = (su >> 25) ? 0u : v_minlen; // per-lane sums below 2^25 keep the 64-lane scans inside 32 bits (else: handed back like a zero length)
                                 v_utot += rb_readlane<uint32_t>(iu, 63);
                             }
                         }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE))) v
             // ---- the verdict of the fused scan: check_integrity (paf.rs:825-857) on the normalised record and the
             //      conditions of the fast path.  A record that fails any of them is handed back: the full record scan
             //      (list mode) decides its status, the generic kernel clips it if it is merely irregular ----
-            const bool lane_bad = v_reg != 0xFFFFFFFFu || v_minlen == 0u || v_adj == 0u || v_big != 0u;
+            const bool lane_bad = v_reg != 0xFFFFFFFFu || v_minlen == 0u || v_adj == 0u;
             const bool bad = __ballot(lane_bad) != 0 || rb_first64(v_utot) > 0xFFFFFFFFull || t_en < t_st || q_en < q_st ||
                              (uint64_t)Rb != t_en - t_st || (uint64_t)Qb != q_en - q_st;
             if (bad) {

@@ -103,6 +103,9 @@ __device__ __forceinline__ int rb_ffs64(unsigned long long m) { return __ffsll((
 // append every hit of a record to the generic list (record not eligible for the streaming path)
 __device__ inline void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_norm_row *nr, uint64_t h0, uint64_t nh,
                                 bool explicit_w, bool mono, uint64_t ws, uint64_t we, int lane) {
+    // (an opaque copy of the lane id: this rare path is inlined into the clip kernel's pass loop, and its row addresses
+    //  would otherwise be hoisted out of that loop and carried -- spilled -- through every record)
+    asm volatile("" : "+v"(lane));
     if (explicit_w || mono) {
         uint64_t lo = 0;
         if (!explicit_w) lo = rb_lower_en_gt(p.w_en, ws, we, nr->t_st);
@@ -293,6 +296,7 @@ __device__ __forceinline__ rb_pass_win rb_pass_windows(const rb_lift_params &p, 
     rb_pass_win o;
     o.wst = o.wen = 0;
     o.win = 0;
+    asm volatile("" : "+v"(lane)); // (opaque: keeps lo + lane from being hoisted out of the pass loop and spilled)
     const uint32_t hl = (uint32_t)lane & 31u;
     const bool own = hl < nb;
     if (!explicit_w && !mono) {
