@@ -1,7 +1,7 @@
 """Fuzz rb_k_parse_cigars against the oracle's parser: random byte strings over a CIGAR-like alphabet."""
 import os, sys, ctypes as C
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import rustybam_amd
 from oracle import pyoracle as oracle
 L = oracle.lib()

@@ -1,8 +1,8 @@
 """Randomised soak: many seeds x batch modes, liftover (fused and two-pass) and break-paf against the oracle."""
 import os, sys, zlib
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import rustybam_amd
 from oracle import pyoracle as oracle
 from rbtest_util import random_batch, random_windows, batch_args, compare_hits

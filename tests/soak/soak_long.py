@@ -1,8 +1,8 @@
 """Soak with long records (several 512-op steps and several checkpoint segments) and many windows per record."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import rustybam_amd
 from oracle import pyoracle as oracle
 from rbtest_util import random_cigar, sums, batch_args, compare_hits

@@ -1,8 +1,8 @@
 """Randomised soak of the trim-paf pair kernel against the oracle, biased towards coordinates that start at 0."""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import rustybam_amd
 from oracle import pyoracle as oracle
 from rbtest_util import random_cigar, sums

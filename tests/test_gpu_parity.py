@@ -304,7 +304,7 @@ def test_liftover_long_records_many_segments(engine, oracle):
 
 def test_liftover_unsorted_tpos_array(engine, oracle):
     """t_st == 0 and a leading op that consumes no reference: the reference's tpos_aln starts with units at t_pos = -1
-    (u64::MAX), is not sorted, and binary_search returns whatever its probe sequence leads to (found by tools/soak.py).
+    (u64::MAX), is not sorted, and binary_search returns whatever its probe sequence leads to (found by tests/soak/soak.py).
     The generic kernel replays the probe sequence; both generations of the standard library."""
     lines = ["Q 2000 1666 1766 + T 100 0 23 0 0 60 cg:Z:40S2=2N2I1=1D1N3I2=40I3=1=2=1I3D2=1=2N",
              "Q 2000 0 12 + T 100 0 9 0 0 60 cg:Z:5H3=1X2N3=3S", "Q 2000 0 12 - T 100 0 9 0 0 60 cg:Z:3S3=1X2N3=5H",

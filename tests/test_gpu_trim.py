@@ -101,7 +101,7 @@ def test_trim_paf_fixture_end_to_end(engine, golden, policy, key):
 @pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
 def test_pairs_unsorted_qpos_array(engine, oracle, policy):
     """q_st == 0 on '+' with a leading op that consumes no query: qpos_aln starts at q_pos = -1 (u64::MAX) and is not sorted;
-    the pair kernel replays the binary search base by base (found by tools/soak_trim.py)."""
+    the pair kernel replays the binary search base by base (found by tests/soak/soak_trim.py)."""
     rng = np.random.default_rng(7002)
     b, left, right = _pairs_batch(rng, 200, "wild", zero_bias=True)
     rows, out = engine.overlap_split(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], left, right, (1, 1, 1), policy)
