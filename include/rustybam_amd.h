@@ -18,6 +18,7 @@
  *   rb_dev_overlap_split  <- trim_overlap::trim_overlapping_pafs          trim_overlap.rs:36-86
  *                            + PafRecord::truncate_record_by_query        paf.rs:785-823
  *                            (the pass / recursion driver Paf::overlapping_paf_recs, paf.rs:210-305, stays on the host)
+ *   rb_dev_nucfreq        <- nucfreq::nucfreq / region_nucfreq            nucfreq.rs:61-95, :111-125
  *
  * Conventions
  *   - Plain C types only.  Every `rb_dev_*` pointer argument is a DEVICE pointer (HBM) owned by
@@ -325,6 +326,55 @@ int rb_host_break_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_
 int rb_host_scan_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t text_bytes, const uint64_t *cig_off, const uint64_t *cig_end,
                       const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
                       uint8_t *cig_status, rb_reduce_row *reduce_out, rb_norm_row *norm_out);
+
+/* ---- nucfreq: A/C/G/T counts at every covered reference position -----------------
+ *
+ * rb_dev_nucfreq  <- nucfreq::nucfreq (nucfreq.rs:61-95) over the reads nucfreq::region_nucfreq fetches (:111-125),
+ *                    for all the 10 kb pieces main.rs:100-110 cuts the regions into, in one call.
+ *   reads   BAM records in FILE ORDER (coordinate sorted: (tid, pos) non-decreasing, unplaced reads with tid -1 last):
+ *           ops / op_off  the CIGAR words (BAM's encoding is the packed encoding of this ABI; the host resolves the CG:B,I
+ *                         long-cigar convention as htslib does) and their exclusive prefix [n_reads + 1]
+ *           seq / seq_off 4-bit bases exactly as in the BAM record (=ACMGRSVTWYHKDBN, high nibble first), read i starting at
+ *                         byte seq_off[i];  l_seq bases per read;  tid, pos (0-based leftmost), flag per read
+ *   regions rg_tid / rg_st / rg_en [n_regions]  half-open, 0-based; out_off [n_regions + 1] = exclusive prefix of en - st
+ *           (n_positions = out_off[n_regions]); regions may overlap, each is computed on its own
+ *   counts  OUT [4 * n_positions] u32: A, C, G, T at position rg_st[r] + k -> counts[4 * (out_off[r] + k) ..].  Bit 31 of the A
+ *           word (RB_NF_COVERED) is set where the pileup reports the position at all (some read that passes the flag
+ *           filter covers it, deletions and reference skips included): the reference prints only those positions
+ *   read_status OUT [n_reads] rb_read_status.  FILTERED = tid < 0 or a flag of htslib's default pileup mask (UNMAP |
+ *           SECONDARY | QCFAIL | DUP).  BAD_CIGAR = htslib's cursor would assert (no reference-consuming op, a lone op that
+ *           is not M/=/X, a zero-length M/D/N/=/X) or the spans do not fit 31 bits.  SEQ_SHORT = a counted base lies past
+ *           l_seq (the reference panics on the index).  Reads that are not OK contribute nothing.
+ *   counters OUT: max_depth (reads covering one position, deletions included), n_covered, n_bad, unsorted.  htslib's pileup
+ *           stops admitting reads once 8000 are buffered; that cap is NOT restated (parity unpinned): a caller must treat
+ *           max_depth + 2 > 8000 as unsupported, rb_host_nucfreq returns RB_E_INVALID for it, and for unsorted input.
+ *   ws      rb_nucfreq_workspace_bytes(n_reads, n_regions, n_positions) bytes, 256-byte aligned
+ */
+typedef struct {
+    uint64_t n_reads;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint8_t *seq;
+    const uint64_t *seq_off;
+    const uint32_t *l_seq;
+    const int32_t *tid;
+    const int64_t *pos;
+    const uint32_t *flag;
+} rb_reads_view;
+enum rb_read_status { RB_RD_OK = 0, RB_RD_FILTERED = 1, RB_RD_BAD_CIGAR = 2, RB_RD_SEQ_SHORT = 3 };
+typedef struct {
+    uint64_t max_depth, n_covered, n_bad, unsorted;
+} rb_nucfreq_counters;
+#define RB_NF_COVERED 0x80000000u
+#define RB_NF_DEPTH_CAP 8000u /* htslib bam_plp_init: maxcnt */
+size_t rb_nucfreq_workspace_bytes(uint64_t n_reads, uint64_t n_regions, uint64_t n_positions);
+int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t n_regions, const int32_t *rg_tid, const uint64_t *rg_st,
+                   const uint64_t *rg_en, const uint64_t *out_off, uint64_t n_positions, uint32_t *counts, uint32_t *read_status,
+                   rb_nucfreq_counters *counters, void *ws, size_t ws_bytes);
+/* host-buffer form: uploads ops[op_off[0] .. op_off[n_reads]) and the sequence bytes the reads span, runs, downloads.
+ * counts [4 * sum(en - st)] and read_status [n_reads] are caller-allocated; read_status may be NULL */
+int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t n_regions, const int32_t *rg_tid, const uint64_t *rg_st,
+                    const uint64_t *rg_en, uint32_t *counts, uint32_t *read_status, rb_nucfreq_counters *counters);
 
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and

@@ -153,6 +153,23 @@ def swap(b):
     return out
 
 
+def nucfreq(tid, pos, flag, op_off, ops, l_seq, seq_off, seq, rtid, st, en):
+    """One fetch + pileup (nucfreq.rs:111-125, :61-95): (positions, counts [n, 4]) of the covered positions of [st, en)."""
+    tid, pos, flag = _arr(tid, np.int32), _arr(pos, np.int64), _arr(flag, np.uint32)
+    op_off, ops = _arr(op_off, np.uint64), _arr(ops, np.uint32)
+    l_seq, seq_off, seq = _arr(l_seq, np.uint32), _arr(seq_off, np.uint64), _arr(seq, np.uint8)
+    cap = max(int(en) - int(st), 1)
+    out_pos = np.zeros(cap, np.uint32)
+    out_cnt = np.zeros((cap, 4), np.uint64)
+    f = lib().rbo_nucfreq_arrays
+    f.restype = C.c_int64
+    n = f(C.c_uint64(len(tid)), _p(tid), _p(pos), _p(flag), _p(op_off), _p(ops), _p(l_seq), _p(seq_off), _p(seq), C.c_int32(rtid),
+          C.c_uint64(st), C.c_uint64(en), _p(out_pos), _p(out_cnt), C.c_uint64(cap))
+    if n < 0:
+        return int(n), None, None
+    return 0, out_pos[:n].copy(), out_cnt[:n].copy()
+
+
 def cli(*args, stdin=None):
     """Run the oracle CLI; returns (returncode, stdout bytes)."""
     build()

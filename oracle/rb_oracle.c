@@ -1793,6 +1793,386 @@ int rbo_bam_stats(const char *path, int qbed, FILE *out) {
 }
 
 /* ==================================================================================
+ * nucfreq (nucfreq.rs:61-95, :111-125; main.rs:82-121): A/C/G/T counts at every covered position of a region.
+ *
+ * The pileup engine is third-party: rust-htslib 0.44.1 `Read::pileup()` = htslib `bam_plp_init` / `bam_plp_auto` with
+ * the default mask (UNMAP | SECONDARY | QCFAIL | DUP) and maxcnt 8000.  It is absent from /root/reference; the
+ * published algorithm (htslib sam.c: bam_plp_push, bam_plp64_next, resolve_cigar2) is restated below, position by
+ * position with the same per-read cursor.  Only KA13 (nucfreq.rs:41-60) pins it: the depth cap and the behaviour on
+ * malformed cigars are "parity unpinned".
+ * ================================================================================== */
+#define PLP_MASK (0x4u | 0x100u | 0x200u | 0x400u)
+#define PLP_MAXCNT 8000
+
+/* bam_endpos: pos + reference length (0 for unmapped reads), at least pos + 1 */
+static int64_t plp_endpos(const rbo_read *b) {
+    int64_t rlen = 0;
+    if (!(b->flag & 4u))
+        for (uint32_t k = 0; k < b->n_cigar; k++)
+            if (rbo_consumes_reference(b->cigar[k])) rlen += b->cigar[k] >> 4;
+    if (rlen == 0) rlen = 1;
+    return b->pos + rlen;
+}
+
+typedef struct plp_node {
+    const rbo_read *b;
+    int64_t beg, end;
+    int k;        /* cstate: current op (-1 = never processed) */
+    int64_t x, y; /* reference position / query offset of the start of op k */
+    struct plp_node *next;
+} plp_node;
+
+static int plp_is_mdnex(uint32_t op) { return op == RBO_M || op == RBO_D || op == RBO_N || op == RBO_EQ || op == RBO_X; }
+static int plp_is_mex(uint32_t op) { return op == RBO_M || op == RBO_EQ || op == RBO_X; }
+
+/* resolve_cigar2: moves the cursor of one read to `pos`; *is_del / *qpos as bam_pileup1_t.  <0 where htslib asserts */
+static int plp_resolve(plp_node *s, int64_t pos, int *is_del, int64_t *qpos) {
+    const rbo_read *b = s->b;
+    const uint32_t *cg = b->cigar;
+    int n = (int)b->n_cigar, k;
+    if (s->k == -1) {
+        if (n == 1) {
+            if (plp_is_mex(cg[0] & 15u)) s->k = 0, s->x = b->pos, s->y = 0;
+        } else {
+            for (k = 0, s->x = b->pos, s->y = 0; k < n; ++k) {
+                uint32_t op = cg[k] & 15u, l = cg[k] >> 4;
+                if (plp_is_mdnex(op)) break;
+                else if (op == RBO_I || op == RBO_S) s->y += l;
+            }
+            if (k >= n) return -5;
+            s->k = k;
+        }
+        if (s->k < 0) return -5; /* (a lone non-match op: htslib reads cigar[-1]) */
+    } else {
+        int64_t l = cg[s->k] >> 4;
+        if (pos - s->x >= l) {
+            if (s->k + 1 >= n) return -5;
+            uint32_t op = cg[s->k + 1] & 15u;
+            if (plp_is_mdnex(op)) {
+                if (plp_is_mex(cg[s->k] & 15u)) s->y += l;
+                s->x += l;
+                ++s->k;
+            } else {
+                if (plp_is_mex(cg[s->k] & 15u)) s->y += l;
+                s->x += l;
+                for (k = s->k + 1; k < n; ++k) {
+                    uint32_t o = cg[k] & 15u, ll = cg[k] >> 4;
+                    if (plp_is_mdnex(o)) break;
+                    else if (o == RBO_I || o == RBO_S) s->y += ll;
+                }
+                s->k = k;
+            }
+            if (s->k >= n) return -5;
+        }
+    }
+    uint32_t op = cg[s->k] & 15u;
+    *is_del = 0;
+    if (plp_is_mex(op)) *qpos = s->y + (pos - s->x);
+    else {
+        *is_del = 1; /* D and N both set is_del; N also is_refskip: neither is counted (nucfreq.rs:79) */
+        *qpos = s->y;
+    }
+    return 0;
+}
+
+/* one fetch + pileup (nucfreq.rs:111-125 then :61-95): rows for the covered positions of [st, en) on tid.
+ * returns 0, -1 = unsorted input (the iterator errors, p.unwrap() panics), -4 = base index past the sequence (panic),
+ * -5 = htslib assertion */
+int rbo_nucfreq(const rbo_read *reads, size_t n_reads, int32_t rtid, uint64_t st, uint64_t en, rbo_nucfreq_row **rows_out, size_t *n_rows) {
+    size_t cap = 1024, nr = 0;
+    rbo_nucfreq_row *rows = (rbo_nucfreq_row *)xmalloc(cap * sizeof(*rows));
+    int rc = 0;
+    /* iterator state (bam_plp_init) */
+    plp_node *head = (plp_node *)xmalloc(sizeof(plp_node)), *tail = head;
+    memset(head, 0, sizeof(*head));
+    long mp_cnt = 1;
+    int32_t it_tid = 0, max_tid = -1;
+    int64_t it_pos = 0, max_pos = -1;
+    int is_eof = 0;
+    size_t next_read = 0;
+    for (;;) {
+        /* ---- bam_plp64_next ---- */
+        int have = 0, n_plp = 0;
+        int32_t o_tid = 0;
+        int64_t o_pos = 0;
+        uint64_t cnt[4] = {0, 0, 0, 0};
+        int finished = 0;
+        if (is_eof && head == tail) finished = 1;
+        while (!finished && !have && (is_eof || max_tid > it_tid || (max_tid == it_tid && max_pos > it_pos))) {
+            n_plp = 0;
+            cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+            plp_node **pptr = &head;
+            while (*pptr != tail) {
+                plp_node *p = *pptr;
+                if (p->b->tid < it_tid || (p->b->tid == it_tid && p->end <= it_pos)) {
+                    *pptr = p->next;
+                    free(p);
+                    --mp_cnt;
+                } else {
+                    if (p->b->tid == it_tid && p->beg <= it_pos) {
+                        int is_del = 0;
+                        int64_t qpos = 0;
+                        int r = plp_resolve(p, it_pos, &is_del, &qpos);
+                        if (r < 0) { rc = r; goto done; }
+                        ++n_plp;
+                        if (!is_del && (uint64_t)it_pos >= st && (uint64_t)it_pos < en && it_tid == rtid) { /* nucfreq.rs:65, :79-91 */
+                            if (qpos < 0 || (uint64_t)qpos >= p->b->l_seq) { rc = -4; goto done; }
+                            uint8_t nib = (p->b->seq[qpos >> 1] >> ((~qpos & 1) << 2)) & 15u;
+                            if (nib == 1) cnt[0]++;
+                            else if (nib == 2) cnt[1]++;
+                            else if (nib == 4) cnt[2]++;
+                            else if (nib == 8) cnt[3]++;
+                            /* N: silent; anything else: a warning on stderr, not counted */
+                        }
+                    }
+                    pptr = &(*pptr)->next;
+                }
+            }
+            o_tid = it_tid;
+            o_pos = it_pos;
+            if (head != tail && it_tid > head->b->tid) { rc = -1; goto done; }
+            if (head != tail && it_tid < head->b->tid) {
+                it_tid = head->b->tid;
+                it_pos = head->beg;
+            } else if (head != tail && it_pos < head->beg) {
+                it_pos = head->beg;
+            } else ++it_pos;
+            if (n_plp) have = 1;
+            else if (is_eof && head == tail) finished = 1;
+        }
+        if (have) {
+            if (o_tid == rtid && (uint64_t)o_pos >= st && (uint64_t)o_pos < en) {
+                if (nr == cap) {
+                    cap *= 2;
+                    rows = (rbo_nucfreq_row *)xrealloc(rows, cap * sizeof(*rows));
+                }
+                rows[nr].pos = (uint32_t)o_pos;
+                rows[nr].a = cnt[0], rows[nr].c = cnt[1], rows[nr].g = cnt[2], rows[nr].t = cnt[3];
+                nr++;
+            }
+            continue;
+        }
+        if (finished) break;
+        /* ---- bam_plp_auto: read the next record of the fetch and push it ---- */
+        const rbo_read *b = NULL;
+        while (next_read < n_reads) { /* hts_itr_next on (tid, st, en): same contig, pos < en, endpos > st */
+            const rbo_read *c = &reads[next_read++];
+            if (c->tid == rtid && c->pos < (int64_t)en && plp_endpos(c) > (int64_t)st) { b = c; break; }
+        }
+        if (!b) { is_eof = 1; continue; }
+        /* ---- bam_plp_push ---- */
+        if (b->tid < 0) continue;
+        if (b->flag & PLP_MASK) continue;
+        if (it_tid == b->tid && it_pos == b->pos && mp_cnt > PLP_MAXCNT) continue;
+        tail->b = b;
+        tail->beg = b->pos;
+        tail->end = plp_endpos(b);
+        tail->k = -1, tail->x = tail->y = 0;
+        if (b->tid < max_tid || (b->tid == max_tid && tail->beg < max_pos)) { rc = -1; goto done; }
+        max_tid = b->tid;
+        max_pos = tail->beg;
+        if (tail->end > it_pos || tail->b->tid > it_tid) {
+            plp_node *nn = (plp_node *)xmalloc(sizeof(plp_node));
+            memset(nn, 0, sizeof(*nn));
+            ++mp_cnt;
+            tail->next = nn;
+            tail = nn;
+        }
+    }
+done:
+    while (head) {
+        plp_node *nx = head == tail ? NULL : head->next;
+        free(head);
+        head = nx;
+    }
+    if (rc) {
+        free(rows);
+        rows = NULL;
+        nr = 0;
+    }
+    *rows_out = rows;
+    *n_rows = nr;
+    return rc;
+}
+
+/* flat-array form: one region; rows go to out_pos[cap] / out_cnt[4 * cap]; returns the row count or <0 */
+int64_t rbo_nucfreq_arrays(uint64_t n_reads, const int32_t *tid, const int64_t *pos, const uint32_t *flag, const uint64_t *op_off,
+                           const uint32_t *ops, const uint32_t *l_seq, const uint64_t *seq_off, const uint8_t *seq, int32_t rtid,
+                           uint64_t st, uint64_t en, uint32_t *out_pos, uint64_t *out_cnt, uint64_t cap) {
+    rbo_read *rd = (rbo_read *)xmalloc((n_reads + 1) * sizeof(*rd));
+    for (uint64_t i = 0; i < n_reads; i++) {
+        rd[i].tid = tid[i], rd[i].pos = pos[i], rd[i].flag = flag[i];
+        rd[i].n_cigar = (uint32_t)(op_off[i + 1] - op_off[i]);
+        rd[i].cigar = ops + op_off[i];
+        rd[i].l_seq = l_seq[i];
+        rd[i].seq = seq + seq_off[i];
+    }
+    rbo_nucfreq_row *rows = NULL;
+    size_t n = 0;
+    int rc = rbo_nucfreq(rd, n_reads, rtid, st, en, &rows, &n);
+    free(rd);
+    if (rc) return rc;
+    if (n > cap) {
+        free(rows);
+        return -100;
+    }
+    for (size_t i = 0; i < n; i++) {
+        out_pos[i] = rows[i].pos;
+        out_cnt[4 * i] = rows[i].a, out_cnt[4 * i + 1] = rows[i].c, out_cnt[4 * i + 2] = rows[i].g, out_cnt[4 * i + 3] = rows[i].t;
+    }
+    free(rows);
+    return (int64_t)n;
+}
+
+/* bed.rs:104-131 parse_region: regex (.+):([0-9]+)-([0-9]+), leftmost match, greedy name */
+int rbo_parse_region(const char *s, rbo_region *out) {
+    size_t n = strlen(s);
+    /* greedy (.+): the LAST position where ":digits-digits" starts, with at least one name character before it */
+    for (size_t c = n; c-- > 1;) {
+        if (s[c] != ':') continue;
+        size_t i = c + 1, a0 = i;
+        while (i < n && s[i] >= '0' && s[i] <= '9') i++;
+        if (i == a0 || i >= n || s[i] != '-') continue;
+        size_t b0 = ++i;
+        while (i < n && s[i] >= '0' && s[i] <= '9') i++;
+        if (i == b0) continue;
+        /* st: parse::<u64>().unwrap() - 1 */
+        uint64_t st = 0, en = 0;
+        int en_ok = 1;
+        for (size_t k = a0; k < b0 - 1; k++) {
+            if (st > (UINT64_MAX - (uint64_t)(s[k] - '0')) / 10) return -1;
+            st = st * 10 + (uint64_t)(s[k] - '0');
+        }
+        if (st == 0) return -1; /* 0 - 1 overflows */
+        st -= 1;
+        for (size_t k = b0; k < i; k++) {
+            if (en > (UINT64_MAX - (uint64_t)(s[k] - '0')) / 10) { en_ok = 0; break; }
+            en = en * 10 + (uint64_t)(s[k] - '0');
+        }
+        if (!en_ok) en = 4294967295ull; /* unwrap_or(2^32 - 1) */
+        if (st > en) return -1;         /* assert!(st <= en) */
+        out->name = (char *)xmalloc(c + 1);
+        memcpy(out->name, s, c);
+        out->name[c] = 0;
+        out->st = st, out->en = en;
+        out->id = NULL;
+        rbo_region_default_id(out); /* name:st+1-en */
+        return 0;
+    }
+    return -1;
+}
+
+/* `rb nucfreq [--region R] [--bed B] [--small] <bam>` (main.rs:82-121) */
+int rbo_bam_nucfreq(const char *path, const char *region, const char *bed_path, int small, FILE *out) {
+    gzFile f = strcmp(path, "-") == 0 ? gzdopen(0, "rb") : gzopen(path, "rb");
+    if (!f) return -2;
+    gzbuffer(f, 1 << 20);
+    uint8_t h8[8], b4[4];
+    if (!bam_read_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) {
+        gzclose(f);
+        return -3;
+    }
+    uint32_t l_text = rd_u32(h8 + 4);
+    char *text = (char *)xmalloc(l_text + 1);
+    bam_read_exact(f, text, l_text);
+    free(text);
+    bam_read_exact(f, b4, 4);
+    uint32_t n_ref = rd_u32(b4);
+    char **ref_nm = (char **)xmalloc((n_ref + 1) * sizeof(char *));
+    for (uint32_t i = 0; i < n_ref; i++) {
+        bam_read_exact(f, b4, 4);
+        uint32_t l = rd_u32(b4);
+        ref_nm[i] = (char *)xmalloc(l + 1);
+        bam_read_exact(f, ref_nm[i], l);
+        ref_nm[i][l] = 0;
+        bam_read_exact(f, b4, 4);
+    }
+    size_t n = 0, cap = 1024;
+    rbo_read *rd = (rbo_read *)xmalloc(cap * sizeof(*rd));
+    while (bam_read_exact(f, b4, 4)) {
+        uint32_t bs = rd_u32(b4);
+        uint8_t *rec = (uint8_t *)xmalloc(bs + 8);
+        if (!bam_read_exact(f, rec, bs)) { free(rec); break; }
+        if (n == cap) {
+            cap *= 2;
+            rd = (rbo_read *)xrealloc(rd, cap * sizeof(*rd));
+        }
+        rbo_read *r = &rd[n++];
+        r->tid = (int32_t)rd_u32(rec);
+        r->pos = (int32_t)rd_u32(rec + 4);
+        uint32_t l_rn = rec[8];
+        uint32_t n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
+        r->flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8);
+        r->l_seq = rd_u32(rec + 16);
+        const uint8_t *cg_raw = rec + 32 + l_rn;
+        r->seq = cg_raw + 4 * (size_t)n_cig;
+        size_t aux_off = 32 + l_rn + 4 * (size_t)n_cig + (r->l_seq + 1) / 2 + r->l_seq;
+        const char *md = NULL;
+        const uint8_t *cg_tag = NULL;
+        uint32_t cg_n = 0;
+        if (aux_off <= bs) bam_aux_scan(rec + aux_off, bs - aux_off, &md, &cg_tag, &cg_n);
+        const uint8_t *src = cg_raw;
+        uint32_t nn = n_cig;
+        if (cg_tag && n_cig >= 1 && (rd_u32(cg_raw) & 15) == RBO_S && (rd_u32(cg_raw) >> 4) == r->l_seq) src = cg_tag, nn = cg_n;
+        uint32_t *cig = (uint32_t *)xmalloc((nn + 1) * sizeof(uint32_t));
+        for (uint32_t i = 0; i < nn; i++) cig[i] = rd_u32(src + 4 * (size_t)i);
+        r->cigar = cig;
+        r->n_cigar = nn;
+        /* (rec and cig stay allocated for the life of the process: test tool) */
+    }
+    gzclose(f);
+    /* main.rs:90-98: --region first, then the bed file */
+    rbo_bed rg;
+    rg.r = NULL, rg.n = rg.cap = 0;
+    int rc = 0;
+    if (bed_path && rbo_bed_from_file(bed_path, &rg)) return -6;
+    size_t n_rg = rg.n + (region ? 1 : 0);
+    rbo_region *all = (rbo_region *)xmalloc((n_rg + 1) * sizeof(*all));
+    size_t w = 0;
+    if (region) {
+        if (rbo_parse_region(region, &all[w])) return -7;
+        w++;
+    }
+    for (size_t i = 0; i < rg.n; i++) all[w++] = rg.r[i];
+    for (size_t i = 0; i < n_rg && !rc; i++) {
+        const rbo_region *R = &all[i];
+        int32_t tid = -1;
+        for (uint32_t k = 0; k < n_ref; k++)
+            if (!strcmp(ref_nm[k], R->name)) { tid = (int32_t)k; break; }
+        for (uint64_t m0 = R->st; m0 < R->en && !rc; m0 += 1000000) { /* bed.rs:215-235 split_region(1 Mbp) */
+            uint64_t m1 = m0 + 1000000 < R->en ? m0 + 1000000 : R->en;
+            if (tid < 0) { rc = -8; break; } /* fetch fails: "Is this region in your reference/bam?" */
+            if (!small) fprintf(out, "#chr\tstart\tend\tA\tC\tG\tT\tregion_id\n"); /* nucfreq.rs:127-131 */
+            int first = 1;
+            for (uint64_t s0 = m0; s0 < m1 && !rc; s0 += 10000) { /* split_region(10 kbp), one fetch + pileup each */
+                uint64_t s1 = s0 + 10000 < m1 ? s0 + 10000 : m1;
+                rbo_nucfreq_row *rows = NULL;
+                size_t nr = 0;
+                rc = rbo_nucfreq(rd, n, tid, s0, s1, &rows, &nr);
+                if (rc) break;
+                for (size_t k = 0; k < nr; k++) {
+                    if (small) { /* nucfreq.rs:139-153 (name and id are constant inside one call) */
+                        if (first) fprintf(out, "#%s\t%u\t%s\n", R->name, rows[k].pos, R->id);
+                        first = 0;
+                        uint64_t mc[4] = {rows[k].a, rows[k].c, rows[k].g, rows[k].t};
+                        for (int x = 0; x < 4; x++)
+                            for (int y = x + 1; y < 4; y++)
+                                if (mc[y] < mc[x]) { uint64_t t = mc[x]; mc[x] = mc[y]; mc[y] = t; }
+                        fprintf(out, "%llu\t%llu\n", (unsigned long long)mc[3], (unsigned long long)mc[2]);
+                    } else {
+                        fprintf(out, "%s\t%u\t%u\t%llu\t%llu\t%llu\t%llu\t%s\n", R->name, rows[k].pos, rows[k].pos + 1,
+                                (unsigned long long)rows[k].a, (unsigned long long)rows[k].c, (unsigned long long)rows[k].g,
+                                (unsigned long long)rows[k].t, R->id);
+                    }
+                }
+                free(rows);
+            }
+        }
+    }
+    return rc;
+}
+
+/* ==================================================================================
  * Flat-array API
  * ================================================================================== */
 static void rec_from_arrays(rbo_rec *r, uint64_t i, const uint32_t *ops, const uint64_t *op_off,

@@ -145,6 +145,25 @@ void rbo_paf_scaffold(rbo_paf *paf, uint64_t *orders, uint64_t spacer);
 /* --- invert (paf.rs:1050-1094) --- */
 void rbo_paf_swap_query_and_target(const rbo_rec *in, rbo_rec *out);
 
+/* --- nucfreq (nucfreq.rs:61-95, :111-125, main.rs:82-121; htslib pileup restated, see rb_oracle.c) --- */
+typedef struct {
+    int32_t tid;
+    int64_t pos;
+    uint32_t flag, n_cigar, l_seq;
+    const uint32_t *cigar; /* BAM cigar words = packed len<<4|op */
+    const uint8_t *seq;    /* 4-bit bases, high nibble first */
+} rbo_read;
+typedef struct {
+    uint32_t pos;
+    uint64_t a, c, g, t;
+} rbo_nucfreq_row;
+int rbo_nucfreq(const rbo_read *reads, size_t n_reads, int32_t rtid, uint64_t st, uint64_t en, rbo_nucfreq_row **rows, size_t *n_rows);
+int64_t rbo_nucfreq_arrays(uint64_t n_reads, const int32_t *tid, const int64_t *pos, const uint32_t *flag, const uint64_t *op_off,
+                           const uint32_t *ops, const uint32_t *l_seq, const uint64_t *seq_off, const uint8_t *seq, int32_t rtid,
+                           uint64_t st, uint64_t en, uint32_t *out_pos, uint64_t *out_cnt, uint64_t cap);
+int rbo_parse_region(const char *s, rbo_region *out); /* bed.rs:104-131 */
+int rbo_bam_nucfreq(const char *path, const char *region, const char *bed_path, int small, FILE *out);
+
 /* --- stats (bamstats.rs:16-36, :107-154, :225-270) --- */
 typedef struct {
     uint32_t equal, diff, ins, del, matches, ins_events, del_events;

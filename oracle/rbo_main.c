@@ -25,7 +25,8 @@ static int usage(void) {
             "  liftover --bed <bed> [--qbed] [--largest] <paf>\n"
             "  break-paf [--max-size N] <paf>\n"
             "  trim-paf [--match-score 1] [--diff-score 1] [--indel-score 1] [--remove-contained] <paf>\n"
-            "  invert <paf>\n");
+            "  invert <paf>\n"
+            "  nucfreq [--region chr:st-en] [--bed <bed>] [--small] <bam>\n");
     return 2;
 }
 
@@ -42,8 +43,13 @@ int main(int argc, char **argv) {
     int ms = 1, ds = 1, is = 1, scaffold = 0;
     uint32_t max_size = 100;
     uint64_t paired_len = 0, min_aln = 0, min_query = 0, insert = 1000000;
+    const char *region = NULL;
+    int small = 0;
+    const int is_nucfreq = !strcmp(cmd, "nucfreq");
     for (; a < argc; a++) {
         const int is_filter = !strcmp(cmd, "filter");
+        if (is_nucfreq && (!strcmp(argv[a], "--region") || !strcmp(argv[a], "-r")) && a + 1 < argc) { region = argv[++a]; continue; }
+        if (is_nucfreq && (!strcmp(argv[a], "--small") || !strcmp(argv[a], "-s"))) { small = 1; continue; }
         if (!strcmp(argv[a], "--paf") || (!strcmp(argv[a], "-p") && !is_filter)) { is_paf = 1; continue; }
         else if (!strcmp(argv[a], "--qbed") || (!strcmp(argv[a], "-q") && !is_filter)) qbed = 1;
         else if (!strcmp(argv[a], "--largest") || !strcmp(argv[a], "-l")) largest = 1;
@@ -61,6 +67,10 @@ int main(int argc, char **argv) {
         else paf_path = argv[a];
     }
     if (!paf_path) paf_path = "-";
+    if (is_nucfreq) { /* main.rs:82-121 */
+        int nrc = rbo_bam_nucfreq(paf_path, region, bed_path, small, stdout);
+        return nrc ? 101 : 0;
+    }
     if (!strcmp(cmd, "stats") && !is_paf) { /* BAM input, main.rs:60-77 */
         int brc = rbo_bam_stats(paf_path, qbed, stdout);
         return brc ? 101 : 0;

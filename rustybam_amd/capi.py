@@ -11,6 +11,8 @@ HEADER = os.path.join(ROOT, "include", "rustybam_amd.h")
 
 BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, LIFT_DESCRIPTORS, LIFT_FUSED_SCAN = 0, 1, 16, 32, 64
 HIT_INSIDE, HIT_GENERIC, HIT_DESCRIPTOR = 1, 2, 4
+NF_COVERED = 0x80000000
+RD_OK, RD_FILTERED, RD_BAD_CIGAR, RD_SEQ_SHORT = 0, 1, 2, 3
 
 REDUCE_DT = np.dtype(
     [("t_bases", "<u8"), ("q_bases", "<u8"), ("nmatch", "<u4"), ("aln_len", "<u4"), ("equal", "<u4"),
@@ -300,6 +302,31 @@ class Engine:
         text = bytes((C.c_char * nb).from_address(out.value)) if nb else b""
         self.L.rb_host_free(out)
         return toff, text
+
+
+    # ---- nucfreq (k_nucfreq.hip) ----
+    def nucfreq(self, tid, pos, flag, op_off, ops, l_seq, seq_off, seq, rg_tid, rg_st, rg_en):
+        """Reads (BAM file order) x regions -> (counts [n_positions, 4] u32 with NF_COVERED in bit 31 of column 0,
+        read_status [n_reads], counters dict)."""
+        tid, pos, flag = _arr(tid, np.int32), _arr(pos, np.int64), _arr(flag, np.uint32)
+        op_off, ops = _arr(op_off, np.uint64), np.concatenate([_arr(ops, np.uint32), np.zeros(4, np.uint32)])
+        l_seq, seq_off = _arr(l_seq, np.uint32), _arr(seq_off, np.uint64)
+        seq = np.concatenate([_arr(seq, np.uint8), np.zeros(16, np.uint8)])
+        rg_tid, rg_st, rg_en = _arr(rg_tid, np.int32), _arr(rg_st, np.uint64), _arr(rg_en, np.uint64)
+        n, nr = len(tid), len(rg_tid)
+        n_pos = int((rg_en.astype(np.int64) - rg_st.astype(np.int64)).sum()) if nr else 0
+
+        class View(C.Structure):
+            _fields_ = [("n_reads", C.c_uint64), ("ops", C.c_void_p), ("op_off", C.c_void_p), ("seq", C.c_void_p), ("seq_off", C.c_void_p),
+                        ("l_seq", C.c_void_p), ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p)]
+        v = View(n, ops.ctypes.data, op_off.ctypes.data, seq.ctypes.data, seq_off.ctypes.data, l_seq.ctypes.data, tid.ctypes.data,
+                 pos.ctypes.data, flag.ctypes.data)
+        counts = np.zeros((max(n_pos, 1), 4), np.uint32)
+        status = np.zeros(max(n, 1), np.uint32)
+        ctr = np.zeros(4, np.uint64)
+        self._chk(self.L.rb_host_nucfreq(self.ctx, C.byref(v), C.c_uint64(nr), _p(rg_tid), _p(rg_st), _p(rg_en), _p(counts), _p(status),
+                                         _p(ctr)), "rb_host_nucfreq")
+        return counts[:n_pos], status[:n], dict(max_depth=int(ctr[0]), n_covered=int(ctr[1]), n_bad=int(ctr[2]), unsorted=int(ctr[3]))
 
 
 def synth_n_ops(seed, first_record, n_rec, lo, hi):

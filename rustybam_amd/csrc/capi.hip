@@ -99,6 +99,33 @@ extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops, hipStream_t stream);
 
+struct rb_nf_params {
+    uint64_t n_reads;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const uint8_t *seq;
+    const uint64_t *seq_off;
+    const uint32_t *l_seq;
+    const int32_t *tid;
+    const int64_t *pos;
+    const uint32_t *flag;
+    uint64_t n_regions;
+    const int32_t *rg_tid;
+    const uint64_t *rg_st, *rg_en, *out_off;
+    uint32_t *counts;
+    uint32_t *read_status;
+    rb_nucfreq_counters *counters;
+    uint64_t *end_key;
+    uint32_t *rd_end;
+    uint64_t *tile_off;
+    uint64_t *blk;
+    uint64_t *tile_lo, *tile_hi;
+    uint64_t max_tiles;
+};
+extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *p, hipStream_t stream);
+extern "C" size_t rb_nf_tile_positions(void);
+extern "C" size_t rb_nf_scan_blocks(uint64_t n);
+
 #define RB_MAX_ARENA 256
 
 #define RB_TIMING_RING 256
@@ -1190,5 +1217,119 @@ extern "C" int rb_dev_synth_fill_ops(rb_ctx *ctx, uint64_t seed, uint64_t first_
                                      uint32_t *ops_dev) {
     if (!ctx) return RB_E_INVALID;
     HIPCHK(ctx, rb_launch_synth(seed, first_record, n_rec, op_off_dev, ops_dev, ctx->stream));
+    return RB_OK;
+}
+
+// ---- nucfreq ----------------------------------------------------------------------------------------------------------
+namespace {
+struct nf_layout {
+    size_t end_key, rd_end, tile_off, blk, tile_lo, tile_hi, total;
+    uint64_t max_tiles;
+};
+nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_positions) {
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    nf_layout L;
+    L.max_tiles = n_positions / rb_nf_tile_positions() + n_regions;
+    size_t o = 0;
+    L.end_key = o, o = up(o + ((size_t)n_reads + 1) * 8);
+    L.rd_end = o, o = up(o + ((size_t)n_reads + 1) * 4);
+    L.tile_off = o, o = up(o + ((size_t)n_regions + 2) * 8);
+    L.blk = o, o = up(o + (std::max(rb_nf_scan_blocks(n_reads), rb_scan_block_sums_count(n_regions)) + 2) * 8);
+    L.tile_lo = o, o = up(o + ((size_t)L.max_tiles + 1) * 8);
+    L.tile_hi = o, o = up(o + ((size_t)L.max_tiles + 1) * 8);
+    L.total = o;
+    return L;
+}
+} // namespace
+
+extern "C" size_t rb_nucfreq_workspace_bytes(uint64_t n_reads, uint64_t n_regions, uint64_t n_positions) {
+    return nf_ws_layout(n_reads, n_regions, n_positions).total;
+}
+
+extern "C" int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t n_regions, const int32_t *rg_tid, const uint64_t *rg_st,
+                              const uint64_t *rg_en, const uint64_t *out_off, uint64_t n_positions, uint32_t *counts, uint32_t *read_status,
+                              rb_nucfreq_counters *counters, void *ws, size_t ws_bytes) {
+    if (!ctx || !reads || !counters || (n_regions && (!rg_tid || !rg_st || !rg_en || !out_off)) || (n_positions && !counts)) return RB_E_INVALID;
+    if (reads->n_reads && (!reads->ops || !reads->op_off || !reads->seq || !reads->seq_off || !reads->l_seq || !reads->tid || !reads->pos ||
+                           !reads->flag || !read_status))
+        return RB_E_INVALID;
+    const nf_layout L = nf_ws_layout(reads->n_reads, n_regions, n_positions);
+    if (!ws || ((uintptr_t)ws & 255) || ws_bytes < L.total) return fail(ctx, RB_E_INVALID, "nucfreq workspace: %zu bytes, 256-byte aligned, needed", L.total);
+    if (L.max_tiles >= 0x7FFFFFFFull) return fail(ctx, RB_E_INVALID, "nucfreq: too many positions for one call");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMemsetAsync(counters, 0, sizeof(rb_nucfreq_counters), ctx->stream));
+    uint8_t *w = (uint8_t *)ws;
+    rb_nf_params p{};
+    p.n_reads = reads->n_reads;
+    p.ops = reads->ops, p.op_off = reads->op_off, p.seq = reads->seq, p.seq_off = reads->seq_off, p.l_seq = reads->l_seq;
+    p.tid = reads->tid, p.pos = reads->pos, p.flag = reads->flag;
+    p.n_regions = n_regions;
+    p.rg_tid = rg_tid, p.rg_st = rg_st, p.rg_en = rg_en, p.out_off = out_off;
+    p.counts = counts, p.read_status = read_status, p.counters = counters;
+    p.end_key = (uint64_t *)(w + L.end_key), p.rd_end = (uint32_t *)(w + L.rd_end), p.tile_off = (uint64_t *)(w + L.tile_off);
+    p.blk = (uint64_t *)(w + L.blk), p.tile_lo = (uint64_t *)(w + L.tile_lo), p.tile_hi = (uint64_t *)(w + L.tile_hi);
+    p.max_tiles = L.max_tiles;
+    HIPCHK(ctx, rb_launch_nucfreq(&p, ctx->stream));
+    return RB_OK;
+}
+
+extern "C" int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t n_regions, const int32_t *rg_tid, const uint64_t *rg_st,
+                               const uint64_t *rg_en, uint32_t *counts, uint32_t *read_status, rb_nucfreq_counters *counters) {
+    if (!ctx || !reads || !counters || (n_regions && (!rg_tid || !rg_st || !rg_en))) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = reads->n_reads;
+    std::vector<uint64_t> out_off(n_regions + 1, 0);
+    for (uint64_t r = 0; r < n_regions; r++) {
+        if (rg_en[r] < rg_st[r]) return fail(ctx, RB_E_INVALID, "region %llu ends before it starts", (unsigned long long)r);
+        out_off[r + 1] = out_off[r] + (rg_en[r] - rg_st[r]);
+    }
+    const uint64_t n_pos = out_off[n_regions];
+    if (n_pos && !counts) return RB_E_INVALID;
+    DevBatch b(ctx);
+    rb_reads_view d{};
+    d.n_reads = n;
+    int rc;
+    if (n) {
+        // only the part of ops / seq these reads use goes up, offsets rebased
+        const uint64_t op0 = reads->op_off[0], op1 = reads->op_off[n];
+        uint64_t s0 = ~0ull, s1 = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t a = reads->seq_off[i], e = a + ((uint64_t)reads->l_seq[i] + 1) / 2;
+            s0 = std::min(s0, a), s1 = std::max(s1, e);
+        }
+        std::vector<uint64_t> opo(n + 1), sqo(n);
+        for (uint64_t i = 0; i <= n; i++) opo[i] = reads->op_off[i] - op0;
+        for (uint64_t i = 0; i < n; i++) sqo[i] = reads->seq_off[i] - s0;
+        if ((rc = b.up(reads->ops + op0, (size_t)(op1 - op0), &d.ops))) return rc;
+        if ((rc = b.up(opo.data(), (size_t)n + 1, &d.op_off))) return rc;
+        if ((rc = b.up(reads->seq + s0, (size_t)(s1 - s0), &d.seq))) return rc;
+        if ((rc = b.up(sqo.data(), (size_t)n, &d.seq_off))) return rc;
+        if ((rc = b.up(reads->l_seq, (size_t)n, &d.l_seq))) return rc;
+        if ((rc = b.up(reads->tid, (size_t)n, &d.tid))) return rc;
+        if ((rc = b.up(reads->pos, (size_t)n, &d.pos))) return rc;
+        if ((rc = b.up(reads->flag, (size_t)n, &d.flag))) return rc;
+    }
+    const int32_t *d_tid = nullptr;
+    const uint64_t *d_st = nullptr, *d_en = nullptr, *d_off = nullptr;
+    if ((rc = b.up(rg_tid, (size_t)n_regions, &d_tid))) return rc;
+    if ((rc = b.up(rg_st, (size_t)n_regions, &d_st))) return rc;
+    if ((rc = b.up(rg_en, (size_t)n_regions, &d_en))) return rc;
+    if ((rc = b.up(out_off.data(), (size_t)n_regions + 1, &d_off))) return rc;
+    uint32_t *d_counts = nullptr, *d_status = nullptr;
+    rb_nucfreq_counters *d_ctr = nullptr;
+    uint8_t *d_ws = nullptr;
+    if ((rc = b.alloc((size_t)n_pos * 4 + 4, &d_counts))) return rc;
+    if ((rc = b.alloc((size_t)n + 1, &d_status))) return rc;
+    if ((rc = b.alloc(1, &d_ctr))) return rc;
+    const size_t wsb = rb_nucfreq_workspace_bytes(n, n_regions, n_pos);
+    if ((rc = b.alloc(wsb, &d_ws))) return rc;
+    if ((rc = rb_dev_nucfreq(ctx, &d, n_regions, d_tid, d_st, d_en, d_off, n_pos, d_counts, d_status, d_ctr, d_ws, wsb))) return rc;
+    if ((rc = rb_dev_download(ctx, counters, d_ctr, sizeof(*counters)))) return rc;
+    if (read_status && n && (rc = rb_dev_download(ctx, read_status, d_status, (size_t)n * 4))) return rc;
+    if (n_pos && (rc = rb_dev_download(ctx, counts, d_counts, (size_t)n_pos * 16))) return rc;
+    if (counters->unsorted) return fail(ctx, RB_E_INVALID, "nucfreq: the reads are not sorted by (tid, pos)");
+    if (counters->max_depth + 2 > RB_NF_DEPTH_CAP)
+        return fail(ctx, RB_E_INVALID, "nucfreq: depth %llu reaches htslib's pileup cap of %u reads, which is not restated",
+                    (unsigned long long)counters->max_depth, RB_NF_DEPTH_CAP);
     return RB_OK;
 }

@@ -1,0 +1,95 @@
+"""GPU parity of rb_dev_nucfreq (k_nucfreq.hip) against the oracle's pileup restatement: bit-exact counts and coverage."""
+import os
+
+import numpy as np
+import pytest
+
+import rustybam_amd
+from nf_util import Reads, read_bam, random_reads, check_regions
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_ka13_fixture(engine, oracle):
+    names, lens, rd = read_bam(f"{GOLD}/test_nucfreq.bam")
+    counts, status, ctr = check_regions(engine, oracle, rd, [(0, 1, 102), (0, 0, lens[0] if lens[0] < 50000 else 50000)])
+    mx = (counts[:101] & 0x7FFFFFFF).max(axis=1)
+    assert set(mx.tolist()) <= {0, 2}          # nucfreq.rs:41-60
+    assert ctr["max_depth"] == 2 and ctr["unsorted"] == 0 and ctr["n_bad"] == 0
+
+
+@pytest.mark.parametrize("bam", ["asm_small.bam", "stats.bam"])
+def test_bam_fixtures(engine, oracle, bam):
+    """whole-contig alignments (40k-op cigars spanning megabases) and a read set: windows around the tile edges"""
+    names, lens, rd = read_bam(f"{GOLD}/{bam}")
+    ok = np.flatnonzero((rd.tid >= 0) & ((rd.flag & 0x704) == 0))
+    regions = []
+    rng = np.random.default_rng(5)
+    for i in rng.choice(ok, size=min(6, len(ok)), replace=False).tolist():
+        p = int(rd.pos[i])
+        regions.append((int(rd.tid[i]), max(p - 100, 0), p + 9000))
+    regions.append((int(rd.tid[ok[0]]), 0, 5000))
+    check_regions(engine, oracle, rd, regions)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_reads_all_op_types(engine, oracle, seed):
+    rng = np.random.default_rng(77 + seed)
+    rd = random_reads(rng, 300, n_contig=3, span=30000, long_frac=0.1)
+    regions = []
+    for _ in range(6):
+        t = int(rng.integers(0, 3))
+        st = int(rng.integers(0, 35000))
+        regions.append((t, st, st + int(rng.integers(1, 20000))))
+    regions += [(0, 4095, 4097), (1, 0, 4096), (2, 8192, 8193), (0, 60000, 60010)]   # tile edges, one position, beyond every read
+    counts, status, ctr = check_regions(engine, oracle, rd, regions)
+    filt = (rd.flag & 0x704) != 0
+    assert np.array_equal(status == rustybam_amd.RD_FILTERED, filt)
+    assert ctr["unsorted"] == 0
+
+
+def test_deep_pile_and_overlapping_regions(engine, oracle):
+    rng = np.random.default_rng(9)
+    rd = random_reads(rng, 3000, n_contig=1, span=2000, long_frac=0.0, odd_flags=False, max_ops=8)
+    counts, status, ctr = check_regions(engine, oracle, rd, [(0, 0, 6000), (0, 1000, 3000), (0, 1000, 3000)])
+    assert ctr["max_depth"] > 500
+
+
+def test_empty_inputs(engine):
+    rd = Reads([], [], [], [], [])
+    counts, status, ctr = engine.nucfreq(*rd.args(), [0], [10], [500])
+    assert counts.shape == (490, 4) and not counts.any() and ctr["n_covered"] == 0
+    rd = Reads([0], [5], [0], [[(10 << 4)]], [[1] * 10])
+    counts, status, ctr = engine.nucfreq(*rd.args(), [], [], [])
+    assert counts.shape[0] == 0 and status.tolist() == [rustybam_amd.RD_OK]
+    counts, status, ctr = engine.nucfreq(*rd.args(), [0, 0], [7, 9], [7, 12])   # an empty region among the regions
+    assert (counts[:, 0] & 0x7FFFFFFF).tolist() == [1, 1, 1] and ctr["n_covered"] == 3
+
+
+def test_bad_reads_are_flagged_not_counted(engine, oracle):
+    M, I, D, S = 0, 1, 2, 4
+    cig = lambda *x: [(l << 4) | o for l, o in x]
+    rd = Reads([0, 0, 0, 0, 0, 0], [10, 20, 30, 40, 50, 60], [0] * 6,
+               [cig((5, M)), cig((5, D)), cig((5, S), (3, I)), cig((3, M), (0, D), (3, M)), [], cig((8, M))],
+               [[1] * 5, [], [2] * 8, [4] * 6, [], [8] * 4])
+    counts, status, ctr = engine.nucfreq(*rd.args(), [0], [0], [100])
+    assert status.tolist() == [rustybam_amd.RD_OK, rustybam_amd.RD_BAD_CIGAR, rustybam_amd.RD_BAD_CIGAR, rustybam_amd.RD_BAD_CIGAR,
+                               rustybam_amd.RD_BAD_CIGAR, rustybam_amd.RD_SEQ_SHORT]
+    assert ctr["n_bad"] == 4
+    c = counts & 0x7FFFFFFF
+    assert c[10:15, 0].tolist() == [1] * 5 and c[60:64, 3].tolist() == [1] * 4 and c[64:68].sum() == 0
+    assert oracle.nucfreq(*rd.slice(5, 6).args(), 0, 0, 100)[0] == -4   # the reference panics on the same read
+
+
+def test_unsorted_and_depth_cap_are_refused(engine):
+    rd = Reads([0, 0], [50, 10], [0, 0], [[(10 << 4)], [(10 << 4)]], [[1] * 10, [1] * 10])
+    with pytest.raises(rustybam_amd.RbError):
+        engine.nucfreq(*rd.args(), [0], [0], [100])
+    n = 8000
+    rd = Reads([0] * n, [5] * n, [0] * n, [[(4 << 4)]] * n, [[1] * 4] * n)
+    with pytest.raises(rustybam_amd.RbError):
+        engine.nucfreq(*rd.args(), [0], [0], [100])
+    rd = rd.slice(0, 7000)
+    counts, status, ctr = engine.nucfreq(*rd.args(), [0], [0], [100])
+    assert ctr["max_depth"] == 7000 and (counts[5:9, 0] & 0x7FFFFFFF).tolist() == [7000] * 4
