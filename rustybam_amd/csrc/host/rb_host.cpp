@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <map>
 #include <numeric>
 #include <unordered_map>
@@ -1169,6 +1170,228 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
     throw Panic("trim-paf did not converge");
 }
 
+
+// ---------------------------------------------------------------- nucfreq (main.rs:82-121, nucfreq.rs, bed.rs:88-131, :215-235)
+Region parse_region(const std::string &region) {
+    // regex (.+):([0-9]+)-([0-9]+), leftmost match with a greedy name: the LAST ":digits-digits" that has a name before it
+    const size_t n = region.size();
+    for (size_t c = n; c-- > 1;) {
+        if (region[c] != ':') continue;
+        size_t i = c + 1;
+        const size_t a0 = i;
+        while (i < n && region[i] >= '0' && region[i] <= '9') i++;
+        if (i == a0 || i >= n || region[i] != '-') continue;
+        const size_t b0 = ++i;
+        while (i < n && region[i] >= '0' && region[i] <= '9') i++;
+        if (i == b0) continue;
+        uint64_t st = 0, en = 0;
+        auto [p1, e1] = std::from_chars(region.data() + a0, region.data() + b0 - 1, st);
+        if (e1 != std::errc() || st == 0) throw Panic("called `Result::unwrap()` on an `Err` value: region start " + region); // parse().unwrap() - 1
+        st -= 1;
+        auto [p2, e2] = std::from_chars(region.data() + b0, region.data() + i, en);
+        if (e2 != std::errc()) en = 4294967295ull; // unwrap_or(2^32 - 1)
+        (void)p1, (void)p2;
+        if (st > en) throw Panic("Region start must be less than end.\n" + region);
+        Region r;
+        r.name = region.substr(0, c);
+        r.st = st, r.en = en;
+        r.id = r.name + ":" + std::to_string(st + 1) + "-" + std::to_string(en);
+        return r;
+    }
+    throw Panic("Failed to parse region string.");
+}
+
+namespace {
+struct BamReads { // every record of the file, in file order: the arrays of rb_reads_view plus what the host needs to pick a slice
+    std::vector<std::string> ref_nm;
+    std::vector<uint32_t> ref_len;
+    std::vector<int32_t> tid;
+    std::vector<int64_t> pos;
+    std::vector<uint32_t> flag, l_seq, ops;
+    std::vector<uint64_t> op_off, seq_off, end_key_pmax; // prefix maximum of tid << 32 | endpos over the reads that enter the pileup
+    std::vector<uint8_t> seq;
+};
+uint64_t nf_key(int32_t tid, uint64_t p) { return ((uint64_t)(uint32_t)tid << 32) | std::min<uint64_t>(p, 0xFFFFFFFFull); }
+
+void load_bam_reads(const std::string &path, BamReads &B) {
+    gzFile f = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+    if (!f) throw Panic("Failed to open " + path); // nucfreq.rs:115
+    gzbuffer(f, 1 << 20);
+    uint8_t h8[8], b4[4];
+    if (!gz_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw Panic(path + " is not a BAM file");
+    std::vector<char> text(le32(h8 + 4) + 1);
+    gz_exact(f, text.data(), text.size() - 1);
+    gz_exact(f, b4, 4);
+    const uint32_t n_ref = le32(b4);
+    B.ref_nm.resize(n_ref), B.ref_len.resize(n_ref);
+    for (uint32_t i = 0; i < n_ref; i++) {
+        gz_exact(f, b4, 4);
+        std::vector<char> nm(le32(b4) + 1, 0);
+        gz_exact(f, nm.data(), nm.size() - 1);
+        B.ref_nm[i] = nm.data();
+        gz_exact(f, b4, 4);
+        B.ref_len[i] = le32(b4);
+    }
+    std::vector<uint8_t> rec;
+    B.op_off.push_back(0);
+    uint64_t run = 0;
+    while (gz_exact(f, b4, 4)) {
+        const uint32_t bs = le32(b4);
+        rec.resize(bs);
+        if (!gz_exact(f, rec.data(), bs)) break;
+        const int32_t tid = (int32_t)le32(rec.data());
+        const int64_t pos = (int32_t)le32(rec.data() + 4);
+        const uint32_t l_rn = rec[8];
+        uint32_t n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
+        const uint32_t flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8), l_seq = le32(rec.data() + 16);
+        const uint8_t *cg = rec.data() + 32 + l_rn;
+        const uint8_t *sq = cg + 4 * (size_t)n_cig;
+        // htslib resolves the CG:B,I long-cigar convention while reading (bam_tag2cigar): <l_seq>S<ref_len>N + CG tag
+        if (n_cig >= 1 && (le32(cg) & 15u) == RB_OP_S && (le32(cg) >> 4) == l_seq) {
+            const size_t aux0 = 32 + l_rn + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+            for (size_t p = aux0; p + 3 <= bs;) {
+                const uint8_t *tag = rec.data() + p;
+                const char ty = (char)rec[p + 2];
+                p += 3;
+                if (ty == 'A' || ty == 'c' || ty == 'C') p += 1;
+                else if (ty == 's' || ty == 'S') p += 2;
+                else if (ty == 'i' || ty == 'I' || ty == 'f') p += 4;
+                else if (ty == 'Z' || ty == 'H') {
+                    while (p < bs && rec[p]) p++;
+                    p++;
+                } else if (ty == 'B') {
+                    if (p + 5 > bs) break;
+                    const char sub = (char)rec[p];
+                    const uint32_t cnt = le32(rec.data() + p + 1);
+                    const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+                    if (tag[0] == 'C' && tag[1] == 'G' && sub == 'I') {
+                        cg = rec.data() + p + 5;
+                        n_cig = cnt;
+                        break;
+                    }
+                    p += 5 + es * (size_t)cnt;
+                } else break;
+            }
+        }
+        uint64_t ref = 0;
+        for (uint32_t i = 0; i < n_cig; i++) {
+            const uint32_t w = le32(cg + 4 * (size_t)i);
+            B.ops.push_back(w);
+            if ((0x18Du >> (w & 15u)) & 1u) ref += w >> 4;
+        }
+        B.op_off.push_back(B.ops.size());
+        B.tid.push_back(tid), B.pos.push_back(pos), B.flag.push_back(flag), B.l_seq.push_back(l_seq);
+        B.seq_off.push_back(B.seq.size());
+        B.seq.insert(B.seq.end(), sq, sq + (l_seq + 1) / 2);
+        // bam_endpos; reads the pileup never admits reach nothing
+        const bool enters = tid >= 0 && !(flag & (0x4u | 0x100u | 0x200u | 0x400u));
+        const uint64_t endpos = (uint64_t)std::max<int64_t>(pos, 0) + ((flag & 4u) || ref == 0 ? 1 : ref);
+        if (enters) run = std::max(run, nf_key(tid, endpos));
+        B.end_key_pmax.push_back(run);
+    }
+    gzclose(f);
+    B.ops.resize(B.ops.size() + 4, 0);
+    B.seq.resize(B.seq.size() + 16, 0);
+}
+
+void put_u64(std::string &o, uint64_t v) {
+    char b[24];
+    auto [p, e] = std::to_chars(b, b + sizeof b, v);
+    (void)e;
+    o.append(b, (size_t)(p - b));
+}
+} // namespace
+
+void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Region> &rgns, bool small,
+                 const std::function<void(const std::string &)> &put) {
+    BamReads B;
+    load_bam_reads(bam_path, B);
+    const uint64_t n_all = B.tid.size();
+    for (uint64_t i = 1; i < n_all; i++) // the pileup iterator refuses unsorted input ("the input is not sorted"), p.unwrap() panics
+        if (nf_key(B.tid[i], (uint64_t)B.pos[i]) < nf_key(B.tid[i - 1], (uint64_t)B.pos[i - 1]) && B.tid[i] >= 0 && B.pos[i] >= 0)
+            throw Panic("nucfreq: the BAM file is not coordinate sorted");
+    const uint64_t MED = 1000000, BATCH = 32; // main.rs:101 (one header per piece); pieces handed to the device per call
+    std::vector<uint32_t> counts, status;
+    std::string out;
+    for (const Region &R : rgns) {
+        int32_t tid = -1;
+        for (size_t k = 0; k < B.ref_nm.size(); k++)
+            if (B.ref_nm[k] == R.name) { tid = (int32_t)k; break; }
+        for (uint64_t b0 = R.st; b0 < R.en; b0 += MED * BATCH) {
+            if (tid < 0) // nucfreq.rs:121-122 (fetch fails)
+                throw Panic("Is this region (" + R.name + ":" + std::to_string(R.st + 1) + "-" + std::to_string(R.en) + ") in your reference/bam?");
+            const uint64_t b1 = std::min(b0 + MED * BATCH, R.en);
+            // positions past the last base any read of this contig reaches are never reported: the device gets [b0, c1)
+            const uint64_t c1 = std::min<uint64_t>(b1, std::max<uint64_t>(b0, std::min<uint64_t>(B.ref_len[tid], 0xFFFFFFFFull)));
+            // the slice of reads that can reach [b0, c1)
+            const uint64_t k_st = nf_key(tid, b0), k_en = nf_key(tid, c1);
+            const uint64_t i0 = (uint64_t)(std::upper_bound(B.end_key_pmax.begin(), B.end_key_pmax.end(), k_st) - B.end_key_pmax.begin());
+            uint64_t lo = i0, hi = n_all;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (nf_key(B.tid[mid], (uint64_t)B.pos[mid]) >= k_en) hi = mid; else lo = mid + 1;
+            }
+            const uint64_t i1 = std::max(lo, i0);
+            rb_nucfreq_counters ctr{};
+            const uint64_t n_pos = c1 - b0;
+            counts.assign((size_t)n_pos * 4 + 4, 0);
+            if (n_pos && i1 > i0) {
+                rb_reads_view v{};
+                v.n_reads = i1 - i0;
+                v.ops = B.ops.data(), v.op_off = B.op_off.data() + i0, v.seq = B.seq.data(), v.seq_off = B.seq_off.data() + i0;
+                v.l_seq = B.l_seq.data() + i0, v.tid = B.tid.data() + i0, v.pos = B.pos.data() + i0, v.flag = B.flag.data() + i0;
+                const int32_t rt = tid;
+                status.assign((size_t)v.n_reads, 0);
+                eng.check(rb_host_nucfreq(eng.ctx(), &v, 1, &rt, &b0, &c1, counts.data(), status.data(), &ctr), "rb_host_nucfreq");
+                for (uint64_t i = 0; i < v.n_reads; i++) {
+                    if (status[i] == RB_RD_SEQ_SHORT) throw Panic("index out of bounds: a base of read " + std::to_string(i0 + i) + " lies past its sequence");
+                    if (status[i] == RB_RD_BAD_CIGAR && B.pos[i0 + i] < (int64_t)c1) // (a read the fetch returns: htslib's cursor asserts on it)
+                        throw Panic("nucfreq: read " + std::to_string(i0 + i) + " has a cigar htslib's pileup cannot walk");
+                }
+            }
+            for (uint64_t m0 = b0; m0 < b1; m0 += MED) {
+                const uint64_t m1 = std::min(m0 + MED, b1);
+                out.clear();
+                if (!small) out += "#chr\tstart\tend\tA\tC\tG\tT\tregion_id\n"; // nucfreq.rs:127-131, once per piece
+                bool first = true;
+                for (uint64_t p = m0; p < std::min(m1, c1); p++) {
+                    const uint32_t *c = &counts[(size_t)(p - b0) * 4];
+                    if (!(c[0] & RB_NF_COVERED)) continue;
+                    const uint64_t a = c[0] & ~RB_NF_COVERED;
+                    if (small) { // nucfreq.rs:139-153
+                        if (first) {
+                            out += '#', out += R.name, out += '\t';
+                            put_u64(out, p);
+                            out += '\t', out += R.id, out += '\n';
+                        }
+                        first = false;
+                        uint64_t mc[4] = {a, c[1], c[2], c[3]};
+                        std::sort(mc, mc + 4);
+                        put_u64(out, mc[3]);
+                        out += '\t';
+                        put_u64(out, mc[2]);
+                        out += '\n';
+                    } else { // impl Display for Nucfreq, nucfreq.rs:17-33
+                        out += R.name, out += '\t';
+                        put_u64(out, p);
+                        out += '\t';
+                        put_u64(out, (uint32_t)(p + 1));
+                        out += '\t';
+                        put_u64(out, a);
+                        out += '\t';
+                        put_u64(out, c[1]);
+                        out += '\t';
+                        put_u64(out, c[2]);
+                        out += '\t';
+                        put_u64(out, c[3]);
+                        out += '\t', out += R.id, out += '\n';
+                    }
+                }
+                put(out);
+            }
+        }
+    }
+}
 
 // ---------------------------------------------------------------- header-only commands (paf.rs:91-207)
 namespace {

@@ -5,6 +5,7 @@
 #pragma once
 #include <cstdint>
 #include <stdexcept>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,12 @@ void parse_md_for_stats(const std::string &md, uint32_t out[4]);
 // the CIGAR counters come from the device record-scan kernel (BAM cigars are already the packed u32 form)
 std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &bam_path);
 std::string cigar_stats_header(bool qbed);              // bamstats.rs:225-236
+// bed::parse_region (bed.rs:88-131): "name:st-en", 1-based inclusive start -> 0-based half-open; id = the same text
+Region parse_region(const std::string &region);
+// main.rs:82-121 + nucfreq.rs: A/C/G/T counts at every covered position of every region, printed piece by piece (1 Mbp) through
+// `put`; BGZF/BAM decode on the host, the pileup on the device (rb_host_nucfreq)
+void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Region> &rgns, bool small,
+                 const std::function<void(const std::string &)> &put);
 std::string cigar_stats_line(const Stats &s, bool qbed); // bamstats.rs:239-270
 
 } // namespace rb

@@ -33,6 +33,7 @@ static int usage() {
             "  invert [PAF]\n"
             "  orient [-s|--scaffold] [-i|--insert 1000000] [PAF]\n"
             "  filter [-p|--paired-len 0] [-a|--aln 0] [-q|--query 0] [PAF]\n"
+            "  nucfreq [-r|--region chr:st-en] [-b|--bed <BED>] [-s|--small] <BAM>\n"
             "Every other rustybam subcommand is outside this engine's scope.\n");
     return 2;
 }
@@ -110,11 +111,15 @@ int main(int argc, char **argv) {
     uint64_t paired_len = 0, min_aln = 0, min_query = 0, insert = 1000000;
     bool do_scaffold = false;
     const bool trim = cmd == "trim-paf" || cmd == "trim" || cmd == "tp";
-    const bool filter = cmd == "filter", orient = cmd == "orient";
+    const bool filter = cmd == "filter", orient = cmd == "orient", nucfreq = cmd == "nucfreq";
+    std::string region;
+    bool small = false;
     for (; a < argc; a++) {
         const std::string s = argv[a];
         auto next = [&]() -> const char * { return a + 1 < argc ? argv[++a] : ""; };
-        if (s == "--paired-len" || (s == "-p" && filter)) paired_len = strtoull(next(), nullptr, 10);
+        if (nucfreq && (s == "-r" || s == "--region")) region = next();
+        else if (nucfreq && (s == "-s" || s == "--small")) small = true;
+        else if (s == "--paired-len" || (s == "-p" && filter)) paired_len = strtoull(next(), nullptr, 10);
         else if (s == "--query" || (s == "-q" && filter)) min_query = strtoull(next(), nullptr, 10);
         else if (s == "--aln" || (s == "-a" && filter)) min_aln = strtoull(next(), nullptr, 10);
         else if (s == "--insert" || (s == "-i" && orient)) insert = strtoull(next(), nullptr, 10);
@@ -140,7 +145,13 @@ int main(int argc, char **argv) {
         eng.bsearch_policy = policy;
         std::vector<char> obuf(1 << 22);
         setvbuf(stdout, obuf.data(), _IOFBF, obuf.size());
-        if (cmd == "stats") {
+        if (nucfreq) { // main.rs:82-121: --region first, then the bed file
+            std::vector<rb::Region> rgns;
+            if (!region.empty()) rgns.push_back(rb::parse_region(region));
+            if (!bed_path.empty())
+                for (rb::Region &r : rb::parse_bed(bed_path)) rgns.push_back(std::move(r));
+            rb::nucfreq_bam(eng, paf_path, rgns, small, [&](const std::string &t) { put(t); });
+        } else if (cmd == "stats") {
             put(rb::cigar_stats_header(qbed));
             if (!is_paf) { // BAM input (main.rs:60-77)
                 for (const rb::Stats &s : rb::cigar_stats_bam(eng, paf_path)) put(rb::cigar_stats_line(s, qbed));

@@ -256,3 +256,60 @@ def test_zero_padded_cigar_numbers(oracle, tmp_path):
         rc, out = rb(*args)
         orc, oout = oracle.cli(*args)
         assert (rc, out) == (orc, oout) and rc == 0 and out, args
+
+
+# ---- `rb nucfreq`: BAM decode on the host, the pileup on the device ----
+@pytest.mark.parametrize("small", [False, True])
+def test_nucfreq_ka13_fixture(oracle, golden, small):
+    a = ["nucfreq", "-r", "CHROMOSOME_I:2-102"] + (["-s"] if small else []) + [f"{golden}/test_nucfreq.bam"]
+    rc, out = rb(*a)
+    orc, oout = oracle.cli(*a)
+    assert (rc, orc) == (0, 0)
+    assert out == oout and out.count(b"\n") == 102
+
+
+def test_nucfreq_bed_regions_and_pieces(oracle, golden, tmp_path):
+    """regions from --region and a BED file (4th column = id), one of them longer than the 1 Mbp print piece"""
+    import subprocess
+    rc, st = rb("stats", f"{golden}/asm_small.bam")
+    f = st.splitlines()[1].split(b"\t")
+    name, r_st = f[0].decode(), int(f[1])
+    bed = tmp_path / "r.bed"
+    bed.write_text(f"{name}\t{r_st + 5000}\t{r_st + 5200}\tmy_id\n{name}\t{max(r_st - 300, 0)}\t{r_st + 300}\n{name}\t{r_st + 999000}\t{r_st + 2001500}\tlong\n")
+    for extra in ([], ["--small"]):
+        a = ["nucfreq", "--region", f"{name}:{r_st + 10001}-{r_st + 10050}", "--bed", str(bed)] + extra + [f"{golden}/asm_small.bam"]
+        rc, out = rb(*a)
+        orc, oout = oracle.cli(*a)
+        assert (rc, orc) == (0, 0)
+        assert out == oout
+        if not extra:
+            assert out.count(b"#chr\tstart") == 1 + 1 + 1 + 2 and out.count(b"\tmy_id\n") == 200
+
+
+def test_nucfreq_unknown_contig_panics(oracle, golden):
+    a = ["nucfreq", "-r", "nope:1-100", f"{golden}/test_nucfreq.bam"]
+    rc, out = rb(*a)
+    orc, oout = oracle.cli(*a)
+    assert rc == 101 and orc == 101 and out == oout == b""
+
+
+def test_nucfreq_synthetic_bam_flags_and_clips(oracle, tmp_path):
+    refs = [("chrA", 50000), ("chrB", 30000)]
+    recs = [
+        dict(name="r1", ref=0, pos=100, flag=0, l_seq=50, cigar=[(5, "S"), (20, "M"), (3, "I"), (4, "D"), (22, "M")]),
+        dict(name="r2", ref=0, pos=110, flag=16, l_seq=30, cigar=[(2, "H"), (10, "="), (1, "X"), (100, "N"), (19, "M"), (3, "H")]),
+        dict(name="dup", ref=0, pos=115, flag=1024, l_seq=10, cigar=[(10, "M")]),
+        dict(name="sec", ref=0, pos=118, flag=256, l_seq=10, cigar=[(10, "M")]),
+        dict(name="r3", ref=0, pos=4090, flag=0, l_seq=20, cigar=[(20, "M")]),
+        dict(name="r4", ref=1, pos=0, flag=0, l_seq=12, cigar=[(12, "M")]),
+        dict(name="un", ref=-1, pos=-1, flag=4, l_seq=5, cigar=[]),
+    ]
+    p = tmp_path / "s.bam"
+    _write_bam(str(p), refs, recs)
+    for a in (["-r", "chrA:1-50000"], ["-r", "chrA:105-125", "-s"], ["-r", "chrB:1-4294967295"], ["-r", "chrA:4097-4100"]):
+        rc, out = rb("nucfreq", *a, str(p))
+        orc, oout = oracle.cli("nucfreq", *a, str(p))
+        assert (rc, orc) == (0, 0), a
+        assert out == oout, a
+    rc, out = rb("nucfreq", "-r", "chrA:1-50000", str(p))
+    assert out.count(b"\n") == 1 + 140 + 20   # r1 [100,146) and r2 [110,240) merge; r3 [4090,4110); dup / secondary reads add nothing
