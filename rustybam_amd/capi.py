@@ -305,6 +305,22 @@ class Engine:
 
 
     # ---- nucfreq (k_nucfreq.hip) ----
+    def nucfreq_workspace_bytes(self, n_reads, n_regions, n_pos):
+        f = self.L.rb_nucfreq_workspace_bytes
+        f.restype = C.c_size_t
+        return int(f(C.c_uint64(n_reads), C.c_uint64(n_regions), C.c_uint64(n_pos)))
+
+    def dev_nucfreq(self, n_reads, ops, op_off, seq, seq_off, l_seq, tid, pos, flag, n_regions, rg_tid, rg_st, rg_en, out_off, n_pos,
+                    counts, status, counters, ws, ws_bytes):
+        """every pointer argument is a device address (int); enqueues on the context's stream"""
+        class View(C.Structure):
+            _fields_ = [("n_reads", C.c_uint64), ("ops", C.c_void_p), ("op_off", C.c_void_p), ("seq", C.c_void_p), ("seq_off", C.c_void_p),
+                        ("l_seq", C.c_void_p), ("tid", C.c_void_p), ("pos", C.c_void_p), ("flag", C.c_void_p)]
+        v = View(n_reads, ops, op_off, seq, seq_off, l_seq, tid, pos, flag)
+        self._chk(self.L.rb_dev_nucfreq(self.ctx, C.byref(v), C.c_uint64(n_regions), C.c_void_p(rg_tid), C.c_void_p(rg_st), C.c_void_p(rg_en),
+                                        C.c_void_p(out_off), C.c_uint64(n_pos), C.c_void_p(counts), C.c_void_p(status), C.c_void_p(counters),
+                                        C.c_void_p(ws), C.c_size_t(ws_bytes)), "rb_dev_nucfreq")
+
     def nucfreq(self, tid, pos, flag, op_off, ops, l_seq, seq_off, seq, rg_tid, rg_st, rg_en):
         """Reads (BAM file order) x regions -> (counts [n_positions, 4] u32 with NF_COVERED in bit 31 of column 0,
         read_status [n_reads], counters dict)."""

@@ -1,0 +1,121 @@
+"""per-position A/C/G/T counts, 30x coverage of one 250 Mbp contig by 15 kb reads.
+
+Prints one JSON line shaped like bench.py's.  A step is one rb_dev_nucfreq call over the whole contig with everything
+resident in HBM.  Parity of this workload is checked by tests/soak/soak_nucfreq.py; this script never touches the oracle.
+
+  python tools/bench_nucfreq.py [--contig 250000000] [--coverage 30] [--read-len 15000] [--steps 5] [--warmup 1]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+SEED = 0x5EED0005
+N_EVENTS = 15  # indel events per read: 16 M runs, 31 ops
+
+
+def make_reads(contig, coverage, read_len, seed=SEED):
+    """sorted starts; cigar = M (I|D) M ... M with query length read_len exactly"""
+    rng = np.random.default_rng(seed)
+    n = int(contig * coverage // read_len)
+    pos = np.sort(rng.integers(0, contig - 2 * read_len, n)).astype(np.int64)
+    is_ins = rng.random((n, N_EVENTS)) < 0.5
+    ev_len = np.where(rng.random((n, N_EVENTS)) < 0.7, 1, rng.integers(2, 30, (n, N_EVENTS))).astype(np.int64)
+    ins_total = (ev_len * is_ins).sum(axis=1)
+    m_total = read_len - ins_total                                     # query bases in M
+    cuts = np.sort(rng.integers(1, (m_total - 1)[:, None], (n, N_EVENTS)), axis=1)
+    cuts += np.arange(N_EVENTS)[None, :]                               # strictly increasing -> every M run >= 1
+    edges = np.concatenate([np.zeros((n, 1), np.int64), cuts, (m_total + N_EVENTS)[:, None]], axis=1)
+    m_len = np.diff(edges, axis=1) - np.concatenate([np.zeros((n, 1), np.int64), np.ones((n, N_EVENTS), np.int64)], axis=1)
+    m_len[:, 0] = edges[:, 1]
+    m_len = np.maximum(m_len, 1)
+    m_len[:, -1] += m_total - m_len.sum(axis=1)                        # fix the total
+    assert (m_len >= 1).all()
+    ops = np.zeros((n, 2 * N_EVENTS + 1), np.uint32)
+    ops[:, 0::2] = (m_len << 4).astype(np.uint32)                      # M = 0
+    ops[:, 1::2] = ((ev_len << 4) | np.where(is_ins, 1, 2)).astype(np.uint32)
+    op_off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(2 * N_EVENTS + 1))
+    return pos, ops.reshape(-1), op_off, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--contig", type=int, default=250_000_000)
+    ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--read-len", type=int, default=15000)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    a = ap.parse_args()
+    import torch
+    import rustybam_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    t0 = time.time()
+    pos, ops, op_off, n = make_reads(a.contig, a.coverage, a.read_len)
+    bytes_per_read = (a.read_len + 1) // 2
+    g = torch.Generator(device=dev)
+    g.manual_seed(SEED)
+    lut = torch.tensor([(1 << (k >> 2)) << 4 | (1 << (k & 3)) for k in range(16)], dtype=torch.uint8, device=dev)
+    d_seq = lut[torch.randint(0, 16, (n * bytes_per_read + 64,), dtype=torch.uint8, device=dev, generator=g).long()] if n * bytes_per_read < (1 << 28) else None
+    if d_seq is None:  # in pieces: the index tensor of a one-shot gather would be 8x the sequence
+        d_seq = torch.empty(n * bytes_per_read + 64, dtype=torch.uint8, device=dev)
+        step = 1 << 27
+        for o in range(0, d_seq.numel(), step):
+            m = min(step, d_seq.numel() - o)
+            d_seq[o:o + m] = lut[torch.randint(0, 16, (m,), dtype=torch.uint8, device=dev, generator=g).long()]
+    i64 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev)
+    d_pos, d_opoff = i64(pos), i64(op_off)
+    d_ops = torch.from_numpy(np.concatenate([ops, np.zeros(8, np.uint32)]).view(np.int32)).to(dev)
+    d_seqoff = i64(np.arange(n, dtype=np.uint64) * np.uint64(bytes_per_read))
+    d_lseq = torch.full((n,), a.read_len, dtype=torch.int32, device=dev)
+    d_tid = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_flag = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_rgtid = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_rgst = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_rgen = torch.full((1,), a.contig, dtype=torch.int64, device=dev)
+    d_outoff = torch.tensor([0, a.contig], dtype=torch.int64, device=dev)
+    d_counts = torch.empty(a.contig * 4 + 16, dtype=torch.int32, device=dev)
+    d_status = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_ctr = torch.zeros(4, dtype=torch.int64, device=dev)
+    wsb = eng.nucfreq_workspace_bytes(n, 1, a.contig)
+    d_ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+    ws_ptr = (d_ws.data_ptr() + 255) & ~255
+    setup = time.time() - t0
+
+    def step():
+        eng.dev_nucfreq(n, d_ops.data_ptr(), d_opoff.data_ptr(), d_seq.data_ptr(), d_seqoff.data_ptr(), d_lseq.data_ptr(), d_tid.data_ptr(),
+                        d_pos.data_ptr(), d_flag.data_ptr(), 1, d_rgtid.data_ptr(), d_rgst.data_ptr(), d_rgen.data_ptr(), d_outoff.data_ptr(),
+                        a.contig, d_counts.data_ptr(), d_status.data_ptr(), d_ctr.data_ptr(), ws_ptr, wsb)
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()          # (the engine runs on its own stream: device-wide synchronisation brackets the timed steps)
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / a.steps
+    ctr = d_ctr.cpu().numpy()
+    assert int((d_status[:n] != 0).sum()) == 0 and ctr[3] == 0
+    c = d_counts[:a.contig * 4].view(-1, 4)
+    tot = int((c[:, 0] & 0x7FFFFFFF).sum() + c[:, 1].sum() + c[:, 2].sum() + c[:, 3].sum())
+    m_bases = int(((ops >> 4) * ((ops & 15) == 0)).sum())
+    assert tot == m_bases, (tot, m_bases)   # every M base lands inside the contig and is A/C/G/T: a checksum of the whole pile
+    alg = n * bytes_per_read + 4 * len(ops) + 16 * a.contig + 44 * n
+    print(json.dumps({
+        "metric": "read bases piled up per second (A/C/G/T counts at every position, inputs resident in HBM)", "value": m_bases / (ms * 1e-3),
+        "unit": "bases/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "dtype": "u16 in LDS, u32 out",
+        "data": "synthetic", "config": {"workload": f"SURVEY 8d config5: {a.coverage}x of one {a.contig} bp contig, {n} reads of {a.read_len} bases, "
+                                        f"{2 * N_EVENTS + 1} ops each, seed 0x5eed0005"},
+        "positions_per_s": a.contig / (ms * 1e-3), "max_depth": int(ctr[0]), "covered": int(ctr[1]),
+        "roofline": {"bound": "hbm", "kernel": "rb_k_nf_tiles (whole call)", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": None, "algorithmic_bytes": alg},
+        "setup_s": round(setup, 2)}))
+
+
+if __name__ == "__main__":
+    main()
