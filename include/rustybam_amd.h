@@ -335,7 +335,8 @@ int rb_host_scan_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t
  *           ops / op_off  the CIGAR words (BAM's encoding is the packed encoding of this ABI; the host resolves the CG:B,I
  *                         long-cigar convention as htslib does) and their exclusive prefix [n_reads + 1]
  *           seq / seq_off 4-bit bases exactly as in the BAM record (=ACMGRSVTWYHKDBN, high nibble first), read i starting at
- *                         byte seq_off[i];  l_seq bases per read;  tid, pos (0-based leftmost), flag per read
+ *                         byte seq_off[i] (any byte); seq itself 4-byte aligned and readable for 32 bytes past the last read
+ *                         (the kernel fetches 16 bytes at a time);  l_seq bases per read;  tid, pos (0-based leftmost), flag
  *   regions rg_tid / rg_st / rg_en [n_regions]  half-open, 0-based; out_off [n_regions + 1] = exclusive prefix of en - st
  *           (n_positions = out_off[n_regions]); regions may overlap, each is computed on its own
  *   counts  OUT [4 * n_positions] u32: A, C, G, T at position rg_st[r] + k -> counts[4 * (out_off[r] + k) ..].  Bit 31 of the A

@@ -327,7 +327,7 @@ class Engine:
         tid, pos, flag = _arr(tid, np.int32), _arr(pos, np.int64), _arr(flag, np.uint32)
         op_off, ops = _arr(op_off, np.uint64), np.concatenate([_arr(ops, np.uint32), np.zeros(4, np.uint32)])
         l_seq, seq_off = _arr(l_seq, np.uint32), _arr(seq_off, np.uint64)
-        seq = np.concatenate([_arr(seq, np.uint8), np.zeros(16, np.uint8)])
+        seq = np.concatenate([_arr(seq, np.uint8), np.zeros(32, np.uint8)])
         rg_tid, rg_st, rg_en = _arr(rg_tid, np.int32), _arr(rg_st, np.uint64), _arr(rg_en, np.uint64)
         n, nr = len(tid), len(rg_tid)
         n_pos = int((rg_en.astype(np.int64) - rg_st.astype(np.int64)).sum()) if nr else 0

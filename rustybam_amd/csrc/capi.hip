@@ -116,7 +116,7 @@ struct rb_nf_params {
     uint32_t *read_status;
     rb_nucfreq_counters *counters;
     uint64_t *end_key;
-    uint32_t *rd_end;
+    void *hd;
     uint64_t *tile_off;
     uint64_t *blk;
     uint64_t *tile_lo, *tile_hi;
@@ -1232,7 +1232,7 @@ nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_position
     L.max_tiles = n_positions / rb_nf_tile_positions() + n_regions;
     size_t o = 0;
     L.end_key = o, o = up(o + ((size_t)n_reads + 1) * 8);
-    L.rd_end = o, o = up(o + ((size_t)n_reads + 1) * 4);
+    L.rd_end = o, o = up(o + ((size_t)n_reads + 1) * 48);
     L.tile_off = o, o = up(o + ((size_t)n_regions + 2) * 8);
     L.blk = o, o = up(o + (std::max(rb_nf_scan_blocks(n_reads), rb_scan_block_sums_count(n_regions)) + 2) * 8);
     L.tile_lo = o, o = up(o + ((size_t)L.max_tiles + 1) * 8);
@@ -1266,7 +1266,7 @@ extern "C" int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t 
     p.n_regions = n_regions;
     p.rg_tid = rg_tid, p.rg_st = rg_st, p.rg_en = rg_en, p.out_off = out_off;
     p.counts = counts, p.read_status = read_status, p.counters = counters;
-    p.end_key = (uint64_t *)(w + L.end_key), p.rd_end = (uint32_t *)(w + L.rd_end), p.tile_off = (uint64_t *)(w + L.tile_off);
+    p.end_key = (uint64_t *)(w + L.end_key), p.hd = (void *)(w + L.rd_end), p.tile_off = (uint64_t *)(w + L.tile_off);
     p.blk = (uint64_t *)(w + L.blk), p.tile_lo = (uint64_t *)(w + L.tile_lo), p.tile_hi = (uint64_t *)(w + L.tile_hi);
     p.max_tiles = L.max_tiles;
     HIPCHK(ctx, rb_launch_nucfreq(&p, ctx->stream));
@@ -1302,7 +1302,12 @@ extern "C" int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t
         for (uint64_t i = 0; i < n; i++) sqo[i] = reads->seq_off[i] - s0;
         if ((rc = b.up(reads->ops + op0, (size_t)(op1 - op0), &d.ops))) return rc;
         if ((rc = b.up(opo.data(), (size_t)n + 1, &d.op_off))) return rc;
-        if ((rc = b.up(reads->seq + s0, (size_t)(s1 - s0), &d.seq))) return rc;
+        {   // (32 readable bytes behind the last read, as the kernel asks)
+            uint8_t *dsq = nullptr;
+            if ((rc = b.alloc((size_t)(s1 - s0) + 32, &dsq))) return rc;
+            if (s1 > s0 && (rc = rb_dev_upload(ctx, dsq, reads->seq + s0, (size_t)(s1 - s0)))) return rc;
+            d.seq = dsq;
+        }
         if ((rc = b.up(sqo.data(), (size_t)n, &d.seq_off))) return rc;
         if ((rc = b.up(reads->l_seq, (size_t)n, &d.l_seq))) return rc;
         if ((rc = b.up(reads->tid, (size_t)n, &d.tid))) return rc;

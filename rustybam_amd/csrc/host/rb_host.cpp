@@ -1291,7 +1291,7 @@ void load_bam_reads(const std::string &path, BamReads &B) {
     }
     gzclose(f);
     B.ops.resize(B.ops.size() + 4, 0);
-    B.seq.resize(B.seq.size() + 16, 0);
+    B.seq.resize(B.seq.size() + 32, 0);
 }
 
 void put_u64(std::string &o, uint64_t v) {

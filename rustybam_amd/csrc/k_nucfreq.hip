@@ -11,17 +11,20 @@
 //   rb_k_nf_pmax_*      inclusive prefix MAXIMUM of the end keys in file order: the first read that can reach a position
 //                       is then one binary search away (reads are sorted by start, not by end)
 //   rb_k_nf_plan_tiles  thread per tile of NF_TILE positions: its region, and the range of reads that can overlap it
-//   rb_k_nf_tiles       workgroup per tile: the tile's counters live in LDS (4 x u16 per position + a coverage
+//   rb_k_nf_tiles       workgroup per tile: the tile's counters live in LDS (4 x u16 in one u64 per position + a coverage
 //                       difference array); each wave takes reads of the range in turn, walks the CIGAR 64 ops at a time
 //                       (wave scans give every op its reference / query start), and for every match-type op that
-//                       overlaps the tile the lanes stride over its bases: one byte load, one LDS atomic.  At the end
-//                       a block scan of the difference array gives the depth (coverage + the htslib depth-cap check),
-//                       and the tile is written out with 16-byte stores.
+//                       overlaps the tile each lane takes 8 consecutive positions: the read's bases over the tile are fetched
+//                       into LDS in one go (16 bytes per lane, all loads in flight), two dwords of it give a lane its 8 base
+//                       codes, a 16-entry table turns a code into what it adds, one ds_add_u32 per base (no branch on the
+//                       base: N and the IUPAC codes add 0).  At the end a block scan of the difference array gives the
+//                       depth (coverage + the htslib depth-cap check), and the tile is written out with 16-byte stores.
 // HBM traffic: each read's packed bases once per tile it overlaps (4 bits / base), its CIGAR likewise, 16 B written per
 // position.  Bound: HBM (the counters never leave LDS).
 #include "rb_device.h"
 
 #define NF_TILE 4096
+#define NF_STAGE_DW (NF_TILE / 8 + 256) // dwords of packed bases staged per read and tile: the tile itself + 2048 inserted bases
 #define NF_THREADS 512
 #define NF_WAVES (NF_THREADS / 64)
 #define NF_PLP_MASK (0x4u | 0x100u | 0x200u | 0x400u) // htslib BAM_DEF_MASK: UNMAP | SECONDARY | QCFAIL | DUP
@@ -44,11 +47,22 @@ struct rb_nf_params {
     rb_nucfreq_counters *counters;
     // workspace
     uint64_t *end_key;  // [n_reads] tid << 32 | end, then its inclusive prefix maximum
-    uint32_t *rd_end;   // [n_reads] end of each read (exclusive), 0 for reads that take no part
+    struct nf_read *hd; // [n_reads] what the tile kernel needs of a read, in one 48-byte record
     uint64_t *tile_off; // [n_regions + 1] exclusive prefix of tiles per region
     uint64_t *blk;      // block partials of the scans
     uint64_t *tile_lo, *tile_hi; // [max_tiles] reads that can overlap the tile
     uint64_t max_tiles;
+};
+
+// one read as the tile kernel sees it: a single 48-byte record (one scalar load) instead of eight arrays
+struct __attribute__((aligned(16))) nf_read {
+    uint32_t pos, end; // reference span [pos, end); end = 0 for reads that take no part (filtered, malformed)
+    int32_t tid;
+    uint32_t l_seq;
+    uint64_t op_off;
+    uint32_t n_ops, pad0;
+    uint64_t nib0; // index of the read's first base counted in 4-bit units from seq
+    uint64_t pad1;
 };
 
 __device__ __forceinline__ uint64_t nf_key(int32_t tid, uint64_t pos32) { return ((uint64_t)(uint32_t)tid << 32) | (pos32 & 0xFFFFFFFFull); }
@@ -81,13 +95,18 @@ __global__ __launch_bounds__(256) void rb_k_nf_read_spans(rb_nf_params p) {
     // op that is not M / = / X; plus what the 32-bit arithmetic of the tile kernel cannot hold
     if (o1 == o0 || !any_ref) bad = 1;
     if (o1 - o0 == 1 && !rb_in(RB_MATCH_MASK, rb_opc(p.ops[o0]))) bad = 1;
-    if (pos < 0 || pos > 0x7FFFFFFFll || ref > 0x7FFFFFFFull) bad = 1;
+    if (pos < 0 || pos > 0x7FFFFFFFll || ref > 0x7FFFFFFFull || o1 - o0 > 0x7FFFFFFFull) bad = 1;
     const uint32_t status = filtered ? RB_RD_FILTERED : (bad ? RB_RD_BAD_CIGAR : RB_RD_OK);
     if (lane == 0) {
         uint64_t end = (uint64_t)pos + ref;
         if (end > 0xFFFFFFFFull) end = 0xFFFFFFFFull;
         p.read_status[i] = status;
-        p.rd_end[i] = status == RB_RD_OK ? (uint32_t)end : 0u;
+        nf_read h;
+        h.pos = (uint32_t)pos, h.end = status == RB_RD_OK ? (uint32_t)end : 0u;
+        h.tid = tid, h.l_seq = p.l_seq[i];
+        h.op_off = o0, h.n_ops = (uint32_t)(o1 - o0 < 0xFFFFFFFFull ? o1 - o0 : 0xFFFFFFFFull), h.pad0 = 0;
+        h.nib0 = 2ull * p.seq_off[i], h.pad1 = 0;
+        p.hd[i] = h;
         p.end_key[i] = status == RB_RD_OK ? nf_key(tid, end) : 0ull;
         if (status == RB_RD_BAD_CIGAR) atomicAdd((unsigned long long *)&p.counters->n_bad, 1ull);
         if (i > 0 && nf_key(tid, (uint64_t)pos) < nf_key(p.tid[i - 1], (uint64_t)p.pos[i - 1])) p.counters->unsorted = 1;
@@ -215,42 +234,73 @@ __global__ __launch_bounds__(256) void rb_k_nf_plan_tiles(rb_nf_params p) {
     p.tile_hi[t] = hi;
 }
 
+// LDS place of tile position i: two dwords (A | C << 16, G | T << 16); 8 guard positions in front (a lane's group of 8 may start
+// before the tile), and one dword skipped after every 8 positions so that the lanes of an atomic -- lane l adds to position
+// 8 l + k -- are 17 dwords apart and fall on different banks
+#define NF_CNT_DW (17 * ((NF_TILE + 16) / 8))
+__device__ __forceinline__ uint32_t nf_slot(uint32_t i) { return 2u * (i + 8u) + ((i + 8u) >> 3); }
+__device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { return ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu); }
+
 __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
-    __shared__ uint32_t cnt[NF_TILE * 2]; // per position: A | C << 16, G | T << 16
-    __shared__ int32_t diff[NF_TILE + 8]; // +1 where a read starts covering, -1 where it stops; then the depth
+    __shared__ uint32_t cnt[NF_CNT_DW]; // per position: A | C << 16, G | T << 16
+    __shared__ uint32_t lut[16];        // what a base code adds to its word: 1 4 = A G: 1; 2 8 = C T: 1 << 16; everything else 0 (nucfreq.rs:83-90)
+    __shared__ int32_t diff[NF_TILE + 8];        // +1 where a read starts covering, -1 where it stops; then the depth
     __shared__ int32_t wsum[NF_WAVES];
     __shared__ uint32_t blk_max, blk_cov;
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[NF_WAVES][NF_STAGE_DW + 8]; // per wave: the bases one read lays over the tile (4 zero dwords in front)
     const uint64_t t = blockIdx.x;
     if (t >= p.tile_off[p.n_regions]) return;
     const nf_tile T = nf_tile_of(p, t);
     const uint32_t n_pos = (uint32_t)(T.en - T.st);
-    for (uint32_t k = threadIdx.x; k < NF_TILE * 2; k += NF_THREADS) cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < NF_CNT_DW; k += NF_THREADS) cnt[k] = 0;
+    if ((threadIdx.x & 63u) < 4u) stage_all[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
     for (uint32_t k = threadIdx.x; k < NF_TILE + 8; k += NF_THREADS) diff[k] = 0;
+    if (threadIdx.x < 16) {
+        const uint32_t n = threadIdx.x;
+        lut[n] = (n == 1 || n == 4) ? 1u : (n == 2 || n == 8) ? 0x10000u : 0u;
+    }
     if (threadIdx.x == 0) blk_max = 0, blk_cov = 0;
     __syncthreads();
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const int lane = rb_lane();
     const uint64_t lo = p.tile_lo[t], hi = p.tile_hi[t];
+    const uint32_t *__restrict__ sw32 = reinterpret_cast<const uint32_t *>(p.seq);
+    uint32_t *stage = stage_all[wib] + 4;
+    // the wave's reads, one after the other.  Two loads run ahead of the work: the record of the read after next, and the first 64
+    // ops of the next read (whose record arrived one turn earlier) -- a read then starts with its ops in registers instead of
+    // waiting for three dependent trips to memory
+    nf_read h_cur, h_nxt;
+    h_cur.end = 0, h_nxt.end = 0, h_cur.n_ops = 0, h_nxt.n_ops = 0, h_cur.op_off = 0, h_nxt.op_off = 0;
+    uint32_t w_cur = RB_NULL_OP;
+    if (lo + wib < hi) h_cur = p.hd[lo + wib];
+    if (lo + wib + NF_WAVES < hi) h_nxt = p.hd[lo + wib + NF_WAVES];
+    if ((uint32_t)lane < h_cur.n_ops) w_cur = p.ops[h_cur.op_off + (uint32_t)lane];
     for (uint64_t i = lo + wib; i < hi; i += NF_WAVES) {
-        const uint32_t rs = p.read_status[i];
-        if (rs == RB_RD_FILTERED || rs == RB_RD_BAD_CIGAR) continue;
-        const int64_t pos = p.pos[i];
-        const uint64_t rend = p.rd_end[i];
-        if (p.tid[i] != T.tid || (uint64_t)pos >= T.en || rend <= T.st) continue; // hts_itr_next: pos < en && endpos > st
+        nf_read h_nn;
+        h_nn.end = 0, h_nn.n_ops = 0, h_nn.op_off = 0;
+        if (i + 2 * NF_WAVES < hi) h_nn = p.hd[i + 2 * NF_WAVES];
+        uint32_t w_nxt = RB_NULL_OP;
+        if ((uint32_t)lane < h_nxt.n_ops) w_nxt = p.ops[h_nxt.op_off + (uint32_t)lane];
+        const nf_read h = h_cur;
+        const uint32_t w_first = w_cur;
+        h_cur = h_nxt, h_nxt = h_nn, w_cur = w_nxt;
+        const int64_t pos = h.pos;
+        const uint64_t rend = h.end;
+        if (h.tid != T.tid || (uint64_t)pos >= T.en || rend <= T.st) continue; // hts_itr_next: pos < en && endpos > st (end = 0: not in the pileup)
         const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = rend < T.en ? rend : T.en;
         if (lane == 0) {
             atomicAdd(&diff[(uint32_t)(c0 - T.st)], 1);
             atomicAdd(&diff[(uint32_t)(c1 - T.st)], -1);
         }
-        const uint64_t o0 = p.op_off[i], o1 = p.op_off[i + 1];
-        const uint8_t *__restrict__ sq = p.seq + p.seq_off[i];
-        const uint32_t lseq = p.l_seq[i];
+        const uint64_t o0 = h.op_off, o1 = h.op_off + h.n_ops;
+        const int64_t nib0 = (int64_t)h.nib0;
+        const int64_t lseq = (int64_t)h.l_seq;
         const int64_t rel_st = (int64_t)T.st - pos, rel_en = (int64_t)T.en - pos; // the tile in read-relative reference offsets
         const int64_t idx0 = pos - (int64_t)T.st;                                  // tile index of the read's first base
         uint32_t R = 0, Q = 0;
         bool seq_short = false;
         for (uint64_t o = o0; o < o1; o += 64) {
-            const uint32_t w = (o + (uint64_t)lane < o1) ? p.ops[o + (uint64_t)lane] : RB_NULL_OP;
+            const uint32_t w = o == o0 ? w_first : ((o + (uint64_t)lane < o1) ? p.ops[o + (uint64_t)lane] : RB_NULL_OP);
             const uint32_t c = rb_opc(w), len = rb_len(w);
             const uint32_t rl = rb_in(RB_REF_MASK, c) ? len : 0u, ql = rb_in(RB_QRY_MASK, c) ? len : 0u;
             const uint32_t ir = rb_wave_scan_incl(rl), iq = rb_wave_scan_incl(ql);
@@ -260,22 +310,77 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
             if ((int64_t)R <= rel_st) continue; // these 64 ops end before the tile
             const bool hit = rb_in(RB_MATCH_MASK, c) && (int64_t)r0 < rel_en && (int64_t)r0 + (int64_t)len > rel_st;
             uint64_t m = __ballot(hit);
+            // the bases these ops lay over the tile are one contiguous stretch of the read: fetch all of it now, 16 bytes per lane and
+            // every load in flight at once, and park it in LDS -- the per-op loops below then never wait for HBM.  (A stretch longer
+            // than the buffer -- a long insertion inside the tile -- is read from memory group by group instead.)
+            int64_t wd_lo = 0;
+            bool staged = false;
+            if (m) {
+                const int jf = __builtin_ctzll(m), jl = 63 - __builtin_clzll(m);
+                const int64_t fr0 = rb_readlane<uint32_t>(r0, jf), fq0 = rb_readlane<uint32_t>(q0, jf);
+                const int64_t lr0 = rb_readlane<uint32_t>(r0, jl), lq0 = rb_readlane<uint32_t>(q0, jl), llen = rb_readlane<uint32_t>(len, jl);
+                const int64_t q_lo = fq0 + ((fr0 > rel_st ? fr0 : rel_st) - fr0);
+                int64_t q_hi = lq0 + ((lr0 + llen < rel_en ? lr0 + llen : rel_en) - lr0);
+                q_hi = q_hi < lseq ? q_hi : lseq;
+                wd_lo = (nib0 + q_lo - 7) >> 3;
+                wd_lo = wd_lo > 0 ? wd_lo : 0;
+                const int64_t n_dw = ((nib0 + q_hi + 7) >> 3) + 2 - wd_lo; // (+ the second dword of the last group)
+                staged = n_dw <= NF_STAGE_DW && q_hi > q_lo;
+                if (staged) {
+                    uint4 v[NF_STAGE_DW / 256];
+#pragma unroll
+                    for (int r = 0; r < NF_STAGE_DW / 256; r++) {
+                        int64_t idx = 4 * lane + 256 * r;
+                        idx = idx < n_dw ? idx : (n_dw - 1 > 0 ? (n_dw - 1) & ~3ll : 0); // (past the stretch: re-read its last piece)
+                        v[r] = rb_load4_unaligned(sw32 + wd_lo + idx);
+                    }
+#pragma unroll
+                    for (int r = 0; r < NF_STAGE_DW / 256; r++)
+                        if (4 * lane + 256 * r < n_dw) // (kept in base order: BAM packs the first base of a byte into its high half)
+                            *reinterpret_cast<uint4 *>(stage + 4 * lane + 256 * r) =
+                                make_uint4(nf_swap_nibbles(v[r].x), nf_swap_nibbles(v[r].y), nf_swap_nibbles(v[r].z), nf_swap_nibbles(v[r].w));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
             while (m) {
                 const int j = __builtin_ctzll(m);
                 m &= m - 1;
-                const uint32_t jr0 = rb_readlane<uint32_t>(r0, j), jlen = rb_readlane<uint32_t>(len, j), jq0 = rb_readlane<uint32_t>(q0, j);
-                const int64_t a = (int64_t)jr0 > rel_st ? (int64_t)jr0 : rel_st;
-                const int64_t b = (int64_t)jr0 + (int64_t)jlen < rel_en ? (int64_t)jr0 + (int64_t)jlen : rel_en;
-                for (int64_t x = a + lane; x < b; x += 64) {
-                    const uint32_t q = jq0 + (uint32_t)(x - (int64_t)jr0); // bam_pileup1_t::qpos
-                    if (q >= lseq) { // record().seq()[qpos] is out of bounds: the reference panics
-                        seq_short = true;
-                        continue;
+                const int64_t jr0 = rb_readlane<uint32_t>(r0, j), jlen = rb_readlane<uint32_t>(len, j), jq0 = rb_readlane<uint32_t>(q0, j);
+                const int64_t a = jr0 > rel_st ? jr0 : rel_st, b = jr0 + jlen < rel_en ? jr0 + jlen : rel_en;
+                const int32_t ia = (int32_t)(idx0 + a); // tile indices [ia, ib) of this op's bases
+                int32_t ib = (int32_t)(idx0 + b);
+                const int64_t qa = jq0 + (a - jr0); // bam_pileup1_t::qpos of the base at ia
+                if (qa + (int64_t)(ib - ia) > lseq) { // record().seq()[qpos] would be out of bounds: the reference panics
+                    seq_short = true;
+                    ib = lseq > qa ? ia + (int32_t)(lseq - qa) : ia;
+                }
+                // lane l takes the 8 positions [P, P + 8) of an 8-aligned group (P = tile index + 8); their bases are 8 consecutive
+                // 4-bit codes of the read: two dwords (nibbles swapped into base order), funnel-shifted to the group's first base
+                auto add_group = [&](int32_t P, uint32_t d0, uint32_t d1, uint32_t shift4) {
+                    const int32_t j0 = ia + 8 - P > 0 ? ia + 8 - P : 0, j1 = ib + 8 - P < 8 ? ib + 8 - P : 8;
+                    uint32_t x = __builtin_amdgcn_alignbit(d1, d0, shift4); // (d0, d1: nibbles already in base order)
+                    const uint32_t width = (uint32_t)(j1 - j0) * 4u;
+                    x &= width >= 32u ? 0xFFFFFFFFu : (((1u << width) - 1u) << ((uint32_t)j0 * 4u)); // bases outside [ia, ib) become code 0: add nothing
+                    uint32_t *g = &cnt[17u * ((uint32_t)P >> 3)];
+                    uint32_t inc[8]; // (the table reads first, all eight in flight, then the atomics)
+#pragma unroll
+                    for (int k = 0; k < 8; k++) inc[k] = lut[(x >> (4 * k)) & 15u];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) atomicAdd(g + 2 * k + __builtin_amdgcn_ubfe(0x110u, (x >> (4 * k)) & 15u, 1u), inc[k]);
+                };
+                const int32_t P0 = ((ia + 8) & ~7) + 8 * lane;
+                if (staged) {
+                    const int32_t rel = (int32_t)(nib0 + qa - 8 * wd_lo) - (ia + 8); // 4-bit index of position P inside the staged stretch = rel + P
+                    for (int32_t P = P0; P < ib + 8; P += 512) {
+                        const int32_t an = rel + P, sd = an >> 3; // (sd = -1: only masked bases, in front of the buffer -- the zero guard)
+                        add_group(P, stage[sd], stage[sd + 1], (uint32_t)(an & 7) * 4u);
                     }
-                    const uint32_t nib = ((uint32_t)sq[q >> 1] >> ((~q & 1u) << 2)) & 15u;
-                    if (nib != 0u && (nib & (nib - 1u)) == 0u) { // 1 2 4 8 = A C G T (nucfreq.rs:83-90); N and the IUPAC codes count nothing
-                        const uint32_t bs = (uint32_t)__builtin_ctz(nib);
-                        atomicAdd(&cnt[(uint32_t)(idx0 + x) * 2u + (bs >> 1)], 1u << ((bs & 1u) << 4));
+                } else {
+                    for (int32_t P = P0; P < ib + 8; P += 512) {
+                        const int64_t An = nib0 + qa + (int64_t)(P - 8 - ia); // (>= -7: only masked bases can lie before the buffer)
+                        const int64_t wd = An >> 3;
+                        add_group(P, wd >= 0 ? nf_swap_nibbles(sw32[wd]) : 0u, nf_swap_nibbles(sw32[wd + 1]), (uint32_t)(An & 7) * 4u);
                     }
                 }
             }
@@ -319,8 +424,8 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     }
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(p.counts + 4ull * T.out);
     for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
-        const uint32_t c01 = cnt[2 * k], c23 = cnt[2 * k + 1];
-        out[k] = make_uint4((c01 & 0xFFFFu) | (diff[k] > 0 ? RB_NF_COVERED : 0u), c01 >> 16, c23 & 0xFFFFu, c23 >> 16);
+        const uint32_t ac = cnt[nf_slot(k)], gt = cnt[nf_slot(k) + 1];
+        out[k] = make_uint4((ac & 0xFFFFu) | (diff[k] > 0 ? RB_NF_COVERED : 0u), ac >> 16, gt & 0xFFFFu, gt >> 16);
     }
 }
 
