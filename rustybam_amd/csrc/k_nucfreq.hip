@@ -23,9 +23,14 @@
 // position.  Bound: HBM (the counters never leave LDS).
 #include "rb_device.h"
 
+#ifndef NF_TILE
 #define NF_TILE 4096
+#endif
 #define NF_STAGE_DW (NF_TILE / 8 + 256) // dwords of packed bases staged per read and tile: the tile itself + 2048 inserted bases
+#ifndef NF_THREADS
 #define NF_THREADS 512
+#endif
+#define NF_PER_THREAD (NF_TILE / NF_THREADS) // positions per thread in the depth scan
 #define NF_WAVES (NF_THREADS / 64)
 #define NF_PLP_MASK (0x4u | 0x100u | 0x200u | 0x400u) // htslib BAM_DEF_MASK: UNMAP | SECONDARY | QCFAIL | DUP
 
@@ -389,12 +394,12 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         if (__ballot(seq_short) != 0 && lane == 0) p.read_status[i] = RB_RD_SEQ_SHORT;
     }
     __syncthreads();
-    // depth = prefix sum of the difference array: 8 positions per thread
+    // depth = prefix sum of the difference array: NF_PER_THREAD positions per thread
     {
-        const uint32_t b0 = threadIdx.x * 8u;
-        int32_t d[8], s = 0;
+        const uint32_t b0 = threadIdx.x * NF_PER_THREAD;
+        int32_t d[NF_PER_THREAD], s = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < NF_PER_THREAD; k++) {
             s += diff[b0 + k];
             d[k] = s;
         }
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         int32_t mx = 0;
         uint32_t cov = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < NF_PER_THREAD; k++) {
             const int32_t dep = before + d[k];
             diff[b0 + k] = dep;
             if (b0 + k < n_pos) {
