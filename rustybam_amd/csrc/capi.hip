@@ -53,6 +53,7 @@ struct rb_trim_params {
     int policy;
     rb_pair_row *rows;
     uint32_t *out_ops;
+    int only_pending;
 };
 struct rb_swap_params {
     uint64_t n_rec;
@@ -577,6 +578,7 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     p.policy = policy & 1;
     p.rows = rows;
     p.out_ops = out_ops;
+    p.only_pending = 0;
     HIPCHK(ctx, rb_launch_overlap_split(&p, ctx->stream));
     return RB_OK;
 }
