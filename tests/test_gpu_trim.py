@@ -14,12 +14,12 @@ from rbtest_util import random_cigar, read_paf, recs_from_lines, sums, unpack
 pytestmark = pytest.mark.gpu
 
 
-def _pairs_batch(rng, n_pairs, mode, zero_bias=False):
+def _pairs_batch(rng, n_pairs, mode, zero_bias=False, ops_range=(3, 60)):
     cig, t_st, t_en, q_st, q_en, strand = [], [], [], [], [], []
     left, right = [], []
     for _ in range(n_pairs):
-        ca = random_cigar(rng, int(rng.integers(3, 60)), mode)
-        cb = random_cigar(rng, int(rng.integers(3, 60)), mode)
+        ca = random_cigar(rng, int(rng.integers(*ops_range)), mode)
+        cb = random_cigar(rng, int(rng.integers(*ops_range)), mode)
         (ra, qa), (rb, qb) = sums(ca), sums(cb)
         if min(qa, qb) < 2:
             continue
@@ -76,6 +76,19 @@ def test_pairs_random(engine, oracle, mode, policy, scores):
     ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
     orows, oout = oracle.overlap_split(ob, left, right, scores, policy)
     _compare(rows, out, orows, oout, f"{mode} policy={policy}")
+
+
+@pytest.mark.parametrize("ops_range", [(60, 200), (600, 900), (760, 776)])
+def test_pairs_long_regular_cigars(engine, oracle, ops_range):
+    """the wave-per-pair kernel stages a record 64 ops at a time and takes records of at most 768 ops; longer ones (and their
+    partners) go to the serial kernel: both sides of that limit, several staging steps, both strands"""
+    rng = np.random.default_rng(ops_range[0])
+    b, left, right = _pairs_batch(rng, 40, "regular", ops_range=ops_range)
+    for scores in ((1, 1, 1), (3, 1, 7)):
+        rows, out = engine.overlap_split(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], left, right, scores)
+        ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
+        orows, oout = oracle.overlap_split(ob, left, right, scores)
+        _compare(rows, out, orows, oout, f"long regular {ops_range} {scores}")
 
 
 @pytest.mark.parametrize("policy,key", [(rustybam_amd.BSEARCH_MODERN, "trim_paf_modern"),
