@@ -52,3 +52,56 @@ def canonical_sort(rows, contig_of_rec):
     rank = np.array([first[int(contig_of_rec[int(r)])] for r in rows["rec"]], dtype=np.int64)
     order = np.lexsort((np.arange(len(rows)), rows["rec"], rank))
     return rows[order]
+
+
+# ---- nucfreq: partition by POSITION range, reads that straddle a boundary go to both ranks ----
+def shard_regions(rg_tid, rg_st, rg_en, n_shards, tile=4096):
+    """Split the positions of the regions into n_shards contiguous pieces of (nearly) equal size, cut on multiples of `tile`
+    inside a region (whole tiles of the device kernel).  Returns per shard a list of (region index, st, en); concatenating the
+    shards' pieces in shard order gives every region back in order."""
+    rg_st, rg_en = np.asarray(rg_st, np.int64), np.asarray(rg_en, np.int64)
+    total = int((rg_en - rg_st).sum())
+    out = [[] for _ in range(n_shards)]
+    if total == 0:
+        return out
+    done = 0
+    for r, (st, en) in enumerate(zip(rg_st.tolist(), rg_en.tolist())):
+        p = st
+        while p < en:
+            s = min(n_shards - 1, done * n_shards // total)
+            limit = -(-(total * (s + 1)) // n_shards)            # first global position of the next shard
+            q = min(en, p + max(limit - done, 1))
+            if q < en:                                           # cut on a tile edge of this region
+                q = min(en, st + -(-(q - st) // tile) * tile)
+            out[s].append((r, p, q))
+            done += q - p
+            p = q
+    return out
+
+
+def shard_reads(tid, pos, end, pieces):
+    """The contiguous range [lo, hi) of sorted reads that can reach any of the pieces (rg_tid resolved by the caller:
+    pieces = [(tid, st, en)]); `end` = each read's reference end."""
+    tid, pos, end = np.asarray(tid, np.int64), np.asarray(pos, np.int64), np.asarray(end, np.int64)
+    key = tid * (1 << 32) + pos
+    lo, hi = len(tid), 0
+    pmax = np.maximum.accumulate(tid * (1 << 32) + end) if len(tid) else np.zeros(0, np.int64)
+    for t, st, en in pieces:
+        a = int(np.searchsorted(pmax, t * (1 << 32) + st, side="right"))
+        b = int(np.searchsorted(key, t * (1 << 32) + en, side="left"))
+        if b > a:
+            lo, hi = min(lo, a), max(hi, b)
+    return (lo, hi) if hi > lo else (0, 0)
+
+
+def gather_counts(parts, pieces_per_shard, rg_st, rg_en):
+    """Per-shard count arrays (positions of the shard's pieces, concatenated) back into one array per region list order."""
+    rg_st, rg_en = np.asarray(rg_st, np.int64), np.asarray(rg_en, np.int64)
+    off = np.concatenate([[0], np.cumsum(rg_en - rg_st)])
+    out = np.zeros((int(off[-1]), 4), np.uint32)
+    for counts, pieces in zip(parts, pieces_per_shard):
+        o = 0
+        for r, st, en in pieces:
+            out[off[r] + (st - rg_st[r]):off[r] + (en - rg_st[r])] = counts[o:o + (en - st)]
+            o += en - st
+    return out

@@ -89,3 +89,76 @@ def test_shard_bounds_properties():
         per = np.array([int(off[b[i + 1]]) - int(off[b[i]]) for i in range(k)])
         assert per.max() - per.min() <= 2 * n.max()
     assert list(shard.shard_bounds(np.zeros(1, np.uint64), 4)) == [0, 0, 0, 0, 0]
+
+
+NF_WORKER = r'''
+import os, sys, pickle
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+from rustybam_amd import shard
+from oracle import pyoracle
+from nf_util import random_reads
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+rng = np.random.default_rng(4321)           # every rank builds the same global input
+rd = random_reads(rng, 400, n_contig=2, span=30000, long_frac=0.1)
+rg = [(0, 100, 21000), (1, 5000, 5001), (1, 0, 30000), (0, 9000, 9100)]
+pieces = shard.shard_regions([r[0] for r in rg], [r[1] for r in rg], [r[2] for r in rg], 2)[rank]
+# reference end of every read (what rb_k_nf_read_spans computes on a GPU run)
+ref = np.array([sum(int(w) >> 4 for w in rd.ops[int(rd.op_off[i]):int(rd.op_off[i + 1])] if (0x18D >> (int(w) & 15)) & 1) for i in range(rd.n)])
+ok = (rd.tid >= 0) & ((rd.flag & 0x704) == 0)
+end = np.where(ok, rd.pos + np.maximum(ref, 1), 0)
+lo, hi = shard.shard_reads(rd.tid, rd.pos, end, [(rg[r][0], st, en) for r, st, en in pieces])
+sub = rd.slice(lo, hi)
+chunks = []
+for r, st, en in pieces:                    # the rank's compute stand-in: the oracle on its slice of reads
+    cnt = np.zeros((en - st, 4), np.uint32)
+    rc, p, c = pyoracle.nucfreq(*sub.args(), rg[r][0], st, en)
+    assert rc == 0
+    cnt[p.astype(np.int64) - st] = c
+    cnt[p.astype(np.int64) - st, 0] |= 0x80000000
+    chunks.append(cnt)
+mine = np.concatenate(chunks) if chunks else np.zeros((0, 4), np.uint32)
+parts = [None, None]
+dist.all_gather_object(parts, mine)
+dist.barrier()
+if rank == 0:
+    allp = shard.shard_regions([r[0] for r in rg], [r[1] for r in rg], [r[2] for r in rg], 2)
+    pickle.dump((shard.gather_counts(parts, allp, [r[1] for r in rg], [r[2] for r in rg]), allp), open({out!r}, "wb"))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_nucfreq_position_shards_match_single_process(oracle):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from nf_util import random_reads
+    import pickle
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "gathered.pkl")
+        script = os.path.join(d, "worker.py")
+        open(script, "w").write(NF_WORKER.format(root=ROOT, port=port, out=out))
+        procs = [subprocess.Popen([sys.executable, script, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+        outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        got, pieces = pickle.load(open(out, "rb"))
+    assert len(pieces[0]) >= 1 and len(pieces[1]) >= 1                 # both ranks had work
+    rg_st = [100, 5000, 0, 9000]
+    assert all((st - rg_st[r]) % 4096 == 0 for r, st, _e in pieces[0] + pieces[1])   # cuts fall on tile edges of the region
+    rng = np.random.default_rng(4321)
+    rd = random_reads(rng, 400, n_contig=2, span=30000, long_frac=0.1)
+    rg = [(0, 100, 21000), (1, 5000, 5001), (1, 0, 30000), (0, 9000, 9100)]
+    want = []
+    for t, st, en in rg:
+        cnt = np.zeros((en - st, 4), np.uint32)
+        rc, p, c = oracle.nucfreq(*rd.args(), t, st, en)
+        assert rc == 0
+        cnt[p.astype(np.int64) - st] = c
+        cnt[p.astype(np.int64) - st, 0] |= 0x80000000
+        want.append(cnt)
+    assert np.array_equal(got, np.concatenate(want))
