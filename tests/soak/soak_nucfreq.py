@@ -45,4 +45,15 @@ rd.seq_off, rd.seq, rd.n = np.arange(n, dtype=np.uint64) * np.uint64(bpr), seq, 
 regs = [(0, int(s), int(s) + 20000) for s in rng.integers(0, 2_950_000, 6)] + [(0, 0, 30000), (0, 2_960_000, 3_000_000)]
 check_regions(eng, oracle, rd, regs)
 pos_total += sum(e - s for _t, s, e in regs)
+# the oracle alone on the same regions (one core, per 10 kb fetch + pileup like the reference): the CPU figure quoted beside the
+# device number in profiles/r01_nf_summary.md
+import time
+from nf_util import oracle_region
+t0 = time.perf_counter()
+based = 0
+for t, s0, e0 in regs:
+    cov, cnt = oracle_region(oracle, rd, t, s0, e0)
+    based += int(cnt.sum())
+dt = time.perf_counter() - t0
+print(f"oracle pileup, 1 core: {based} bases over {sum(e - s for _t, s, e in regs)} positions in {dt:.2f} s = {based / dt:.3g} bases/s")
 print(f"nucfreq soak ok: {n_cases} random cases + 8 regions of the bench workload, {pos_total} positions compared")

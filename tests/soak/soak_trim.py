@@ -44,4 +44,36 @@ for seed in range(n):
             orows, oout = oracle.overlap_split(ob, left, right, scores, pol)
             _compare(rows, out, orows, oout, f"seed {seed} {mode} pol {pol} {scores}")
             tot += len(rows)
+# the shape of SURVEY 8d config 4 (tools/bench_config4.py): synthetic records of 300-700 ops, 4 per query, consecutive query spans
+# overlapping by U[100, 10000] bases; device against oracle, and the oracle alone timed (one core) for profiles/r01_c4_summary.md
+import time
+from rustybam_amd import workload as wl, capi
+SEED4, n4 = 0x5EED0004, 2400
+nops = wl.n_ops(SEED4, 0, n4, 300, 700)
+off4 = wl.op_offsets(nops)
+ops4 = capi.synth_fill_ops_host(SEED4, 0, off4)
+strand4 = np.where(np.arange(n4) % 3 == 0, ord("-"), ord("+")).astype(np.uint8)
+z = np.zeros(n4, np.uint64)
+red, _ = eng.scan_records(ops4, off4, z, z, z, z, strand4)
+tb, qb = red["t_bases"].astype(np.uint64), red["q_bases"].astype(np.uint64)
+rng = np.random.default_rng(SEED4)
+q_st = np.zeros(n4, np.uint64)
+ov = rng.integers(100, 10001, n4).astype(np.uint64)
+for j in range(1, 4):
+    prev_en = q_st[j - 1::4] + qb[j - 1::4]
+    q_st[j::4] = prev_en - np.minimum(ov[j::4], np.minimum(qb[j - 1::4], qb[j::4]) // np.uint64(2))
+q_en = q_st + qb
+t_st = rng.integers(0, 200_000_000, n4).astype(np.uint64)
+t_en = t_st + tb
+left4 = np.arange(n4, dtype=np.uint32)[np.arange(n4) % 4 != 3]
+right4 = left4 + 1
+rows, out = eng.overlap_split(ops4, off4, t_st, t_en, q_st, q_en, strand4, left4, right4)
+ob = oracle.Batch(ops4, off4, t_st, t_en, q_st, q_en, strand4, np.zeros(n4, np.uint32))
+t0 = time.perf_counter()
+orows, oout = oracle.overlap_split(ob, left4, right4, (1, 1, 1), 0)
+dt = time.perf_counter() - t0
+for k in ("split_idx", "split_score", "status", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
+    assert np.array_equal(rows[k], orows[k]), k
+assert np.array_equal(out, oout)
+print(f"config-4 shape: {len(left4)} pairs identical; oracle alone, 1 core: {dt:.2f} s = {len(left4) / dt:.3g} pairs/s")
 print(f"trim soak ok: {n} cases, {tot} pairs compared")

@@ -304,9 +304,13 @@ def test_nucfreq_synthetic_bam_flags_and_clips(oracle, tmp_path):
         dict(name="r4", ref=1, pos=0, flag=0, l_seq=12, cigar=[(12, "M")]),
         dict(name="un", ref=-1, pos=-1, flag=4, l_seq=5, cigar=[]),
     ]
+    import struct
+    real = [(10, "M"), (2, "I"), (6, "D"), (28, "M")]   # htslib's long-cigar convention: <l_seq>S<ref_len>N in the record, the real cigar in CG:B,I
+    cg = b"CGBI" + struct.pack("<i", len(real)) + b"".join(struct.pack("<I", (l << 4) | "MIDNSHP=X".index(c)) for l, c in real)
+    recs.insert(6, dict(name="long_cigar_in_CG", ref=1, pos=100, flag=0, l_seq=40, cigar=[(40, "S"), (44, "N")], aux=cg))
     p = tmp_path / "s.bam"
     _write_bam(str(p), refs, recs)
-    for a in (["-r", "chrA:1-50000"], ["-r", "chrA:105-125", "-s"], ["-r", "chrB:1-4294967295"], ["-r", "chrA:4097-4100"]):
+    for a in (["-r", "chrA:1-50000"], ["-r", "chrA:105-125", "-s"], ["-r", "chrB:1-4294967295"], ["-r", "chrA:4097-4100"], ["-r", "chrB:90-160"]):
         rc, out = rb("nucfreq", *a, str(p))
         orc, oout = oracle.cli("nucfreq", *a, str(p))
         assert (rc, orc) == (0, 0), a
