@@ -93,3 +93,19 @@ def test_unsorted_and_depth_cap_are_refused(engine):
     rd = rd.slice(0, 7000)
     counts, status, ctr = engine.nucfreq(*rd.args(), [0], [0], [100])
     assert ctr["max_depth"] == 7000 and (counts[5:9, 0] & 0x7FFFFFFF).tolist() == [7000] * 4
+
+
+def test_long_insertions_inside_a_tile(engine, oracle):
+    """the tile kernel stages the stretch of a read that lies over a tile (at most 6144 bases); a longer stretch -- a long insertion
+    between two matches of the same tile -- is read from memory group by group instead: both routes, next to each other"""
+    rng = np.random.default_rng(11)
+    M, I, D = 0, 1, 2
+    cigs, seqs, poss = [], [], []
+    for k, ins in enumerate([10, 3000, 5900, 6200, 9000, 20000, 7000]):
+        c = [(int(rng.integers(50, 300)) << 4) | M, (ins << 4) | I, (int(rng.integers(50, 300)) << 4) | M, (7 << 4) | D, (120 << 4) | M]
+        q = sum(w >> 4 for w in c if (w & 15) in (0, 1))
+        cigs.append(c)
+        seqs.append(rng.choice([1, 2, 4, 8, 15], size=q).tolist())
+        poss.append(100 + 37 * k)
+    rd = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, seqs)
+    check_regions(engine, oracle, rd, [(0, 0, 1200), (0, 300, 301), (0, 0, 5000)])
