@@ -91,6 +91,49 @@ def test_pairs_long_regular_cigars(engine, oracle, ops_range):
         _compare(rows, out, orows, oout, f"long regular {ops_range} {scores}")
 
 
+def test_pairs_odd_geometries(engine, oracle):
+    """regular records (the wave-per-pair kernel) whose query spans do not overlap, touch, coincide, or contain one another: the
+    split degenerates and truncate_record_by_query runs into its assertions / not-found panics exactly as in the oracle"""
+    rng = np.random.default_rng(99)
+    cig, t_st, t_en, q_st, q_en, strand, left, right = [], [], [], [], [], [], [], []
+    for rel in ("apart", "touch", "same", "contained", "contains", "one_base", "apart", "same", "contained"):
+        for sa in "+-":
+            for sb in "+-":
+                ca = random_cigar(rng, int(rng.integers(5, 90)), "regular")
+                cb = random_cigar(rng, int(rng.integers(5, 90)), "regular")
+                (ra, qa), (rb, qb) = sums(ca), sums(cb)
+                a0 = int(rng.integers(0, 3)) * 500
+                if rel == "apart":
+                    b0 = a0 + qa + 17
+                elif rel == "touch":
+                    b0 = a0 + qa
+                elif rel == "one_base":
+                    b0 = a0 + qa - 1
+                elif rel == "same":
+                    cb, rb, qb, b0 = ca, ra, qa, a0
+                elif rel == "contained":       # right inside left
+                    if qb >= qa:
+                        ca, cb, ra, rb, qa, qb = cb, ca, rb, ra, qb, qa
+                    b0 = a0 + (qa - qb) // 2
+                else:                          # left starts first but right ends later and left ends inside right: plain overlap from the left end
+                    b0 = a0 + max(qa // 3, 1)
+                for c, r, q, s0, sd in ((ca, ra, qa, a0, sa), (cb, rb, qb, b0, sb)):
+                    ts = int(rng.integers(0, 5000))
+                    cig.append(c); t_st.append(ts); t_en.append(ts + r); q_st.append(s0); q_en.append(s0 + q); strand.append(ord(sd))
+                left.append(len(cig) - 2); right.append(len(cig) - 1)
+    off = np.zeros(len(cig) + 1, np.uint64)
+    off[1:] = np.cumsum([len(c) for c in cig])
+    b = dict(ops=np.concatenate(cig), op_off=off, t_st=np.array(t_st, np.uint64), t_en=np.array(t_en, np.uint64),
+             q_st=np.array(q_st, np.uint64), q_en=np.array(q_en, np.uint64), strand=np.array(strand, np.uint8))
+    left, right = np.array(left, np.uint32), np.array(right, np.uint32)
+    for scores in ((1, 1, 1), (5, 1, 2)):
+        rows, out = engine.overlap_split(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], left, right, scores)
+        ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
+        orows, oout = oracle.overlap_split(ob, left, right, scores)
+        _compare(rows, out, orows, oout, f"odd geometries {scores}")
+    assert len(set(orows["status"].tolist())) >= 2          # some of these really are panics in the reference
+
+
 @pytest.mark.parametrize("policy,key", [(rustybam_amd.BSEARCH_MODERN, "trim_paf_modern"),
                                         (rustybam_amd.BSEARCH_LEGACY, "trim_paf_legacy")])
 def test_trim_paf_fixture_end_to_end(engine, golden, policy, key):
