@@ -40,6 +40,12 @@ struct rb_break_params {
     uint64_t rows_cap;
     uint32_t max_size;
     int fill;
+    int redo_only;
+    void *tmp;
+    uint64_t *tmp_off;
+    unsigned long long *tmp_cursor;
+    uint32_t n_arena;
+    uint64_t arena_cap;
 };
 struct rb_trim_params {
     uint64_t n_pairs;
@@ -96,6 +102,7 @@ extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStre
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream);
 extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec);
 extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_break_place(const rb_break_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops, hipStream_t stream);
@@ -393,7 +400,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, total;
 };
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     ws_layout w;
@@ -413,6 +420,9 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     w.gen_list = take((rows_cap + 1) * 4);
     w.x_st = take((rows_cap + 1) * 8);
     w.x_en = take((rows_cap + 1) * 8);
+    w.bp_tmp = take((rows_cap + 1) * 8); // break-paf: piece windows between the collect pass and their rows
+    w.bp_off = take((n_rec + 1) * 8);
+    w.bp_cur = take((size_t)RB_MAX_ARENA * 128);
     w.total = o;
     return w;
 }
@@ -507,10 +517,19 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
         bp.x_en = (uint64_t *)(ws + w.x_en);
         bp.rows_cap = rows_cap;
         bp.max_size = max_size;
-        bp.fill = 0;
+        // one walk of the ops: count the pieces of every record and keep their windows (tmp[]), scan the counts, move the
+        // windows to their rows; a second walk only for records with more pieces than the collect pass keeps
+        bp.tmp = ws + w.bp_tmp;
+        bp.tmp_off = (uint64_t *)(ws + w.bp_off);
+        bp.tmp_cursor = (unsigned long long *)(ws + w.bp_cur);
+        bp.n_arena = pick_arenas(b->n_rec);
+        bp.arena_cap = rows_cap / bp.n_arena;
+        HIPCHK(ctx, hipMemsetAsync(bp.tmp_cursor, 0, (size_t)RB_MAX_ARENA * 128, ctx->stream));
+        bp.fill = 2, bp.redo_only = 0;
         HIPCHK(ctx, rb_launch_break_pieces(&bp, ctx->stream));
         HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, false, ctx->stream));
-        bp.fill = 1;
+        HIPCHK(ctx, rb_launch_break_place(&bp, ctx->stream));
+        bp.fill = 1, bp.redo_only = 1;
         HIPCHK(ctx, rb_launch_break_pieces(&bp, ctx->stream));
         p.x_st = bp.x_st;
         p.x_en = bp.x_en;

@@ -22,8 +22,16 @@ struct rb_break_params {
     uint64_t *x_st, *x_en;
     uint64_t rows_cap;
     uint32_t max_size;
-    int fill;
+    int fill; // 0: count pieces; 1: write the windows of every record (or, with redo_only, of the records the collect pass gave up on);
+              // 2 (collect): count AND keep the windows, in LDS while the record streams, then in tmp[] at a slot from tmp_cursor
+    int redo_only;
+    uint2 *tmp;                    // [rows_cap] (start, end) of a piece relative to the record's t_st
+    uint64_t *tmp_off;             // [n_rec] where the record's pieces sit in tmp[]; ~0 = not kept (more than RB_BP_CAP pieces, or no room)
+    unsigned long long *tmp_cursor; // one bump cursor per arena, 128 bytes apart (a single cursor would serialise every record at one L2 line)
+    uint32_t n_arena;
+    uint64_t arena_cap;             // slots of tmp[] per arena
 };
+#define RB_BP_CAP 512 // pieces of one record kept in LDS by the collect pass
 
 __device__ __forceinline__ uint32_t rb_umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t rb_wave_scan_incl_max(uint32_t v) {
@@ -37,19 +45,26 @@ __device__ __forceinline__ uint32_t rb_wave_scan_incl_max(uint32_t v) {
 }
 
 __global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
+    __shared__ uint2 keep_all[4][RB_BP_CAP];
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
     if (wave >= p.n_rec) return;
     const int lane = rb_lane();
     const uint32_t r = rb_first(p.sched[wave]);
     const rb_norm_row *nr = &p.norm[r];
+    const bool collect = p.fill == 2;
+    uint2 *keep = keep_all[threadIdx.x >> 6];
+    if (p.redo_only && p.tmp_off[r] != ~0ull) return;
     if (nr->status != RB_ST_OK) {
-        if (!p.fill && lane == 0) p.hit_off[r] = 0;
+        if (p.fill != 1 && lane == 0) {
+            p.hit_off[r] = 0;
+            if (collect) p.tmp_off[r] = 0;
+        }
         return;
     }
     const uint32_t n = nr->n_ops;
     const uint64_t t_st = nr->t_st;
     const uint64_t rec0 = p.op_off[r] + nr->first_op;
-    const uint64_t h0 = p.fill ? rb_first64(p.hit_off[r]) : 0;
+    const uint64_t h0 = p.fill == 1 ? rb_first64(p.hit_off[r]) : 0;
     // 8 ops (32 contiguous bytes) per lane and step, two steps in flight in a statically indexed ring; loads past the
     // record's end re-read its last group and are masked on the last step (see k_liftover.hip)
     const uint64_t g0 = rec0 & ~3ull, gend = rec0 + n;
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
                     if (big[q]) run_pre = Rx[q] + rl[q];
                 }
                 const uint32_t ic = rb_wave_scan_incl(lane_cnt);
-                if (p.fill) {
+                if (p.fill == 1) {
                     uint32_t ord = cnt + ic - lane_cnt;
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -123,6 +138,15 @@ __global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
                                 p.x_st[h] = t_st + pst[q];
                                 p.x_en[h] = t_st + Rx[q];
                             }
+                            ord++;
+                        }
+                    }
+                } else if (collect && __ballot(lane_cnt != 0) != 0) {
+                    uint32_t ord = cnt + ic - lane_cnt;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (pc[q]) {
+                            if (ord < RB_BP_CAP) keep[ord] = make_uint2(pst[q], Rx[q]);
                             ord++;
                         }
                     }
@@ -136,14 +160,48 @@ __global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
         }
     }
     const bool last = Rb > pre; // liftover.rs:213-224
-    if (lane == 0) {
-        if (p.fill) {
-            if (last && h0 + cnt < p.rows_cap) {
-                p.x_st[h0 + cnt] = t_st + pre;
-                p.x_en[h0 + cnt] = t_st + Rb;
-            }
-        } else {
-            p.hit_off[r] = (uint64_t)cnt + (last ? 1u : 0u);
+    if (p.fill == 1) {
+        if (lane == 0 && last && h0 + cnt < p.rows_cap) {
+            p.x_st[h0 + cnt] = t_st + pre;
+            p.x_en[h0 + cnt] = t_st + Rb;
+        }
+        return;
+    }
+    const uint32_t total = cnt + (last ? 1u : 0u);
+    if (lane == 0) p.hit_off[r] = (uint64_t)total;
+    if (!collect) return;
+    // the record's windows leave LDS for one slot of tmp[]; rb_k_break_place moves them to their rows once the row offsets exist
+    uint64_t base = ~0ull;
+    if (total <= RB_BP_CAP) {
+        const uint32_t a = (uint32_t)(wave % p.n_arena);
+        unsigned long long b0 = 0;
+        if (lane == 0) b0 = atomicAdd(&p.tmp_cursor[(size_t)a * 16u], (unsigned long long)total);
+        base = rb_first64(b0);
+        base = base + total <= p.arena_cap ? (uint64_t)a * p.arena_cap + base : ~0ull; // (arena full: the second walk does this record)
+    }
+    if (base != ~0ull) {
+        if (last && lane == 0) keep[cnt] = make_uint2(pre, Rb);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j = (uint32_t)lane; j < total; j += 64) p.tmp[base + j] = keep[j];
+    }
+    if (lane == 0) p.tmp_off[r] = base;
+}
+
+// windows of the collect pass -> x_st / x_en at the record's row offset (thread per record: a record has a handful of pieces)
+__global__ __launch_bounds__(256) void rb_k_break_place(rb_break_params p) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= p.n_rec) return;
+    const uint64_t base = p.tmp_off[r];
+    if (base == ~0ull) return;
+    const rb_norm_row *nr = &p.norm[r];
+    if (nr->status != RB_ST_OK) return;
+    const uint64_t h0 = p.hit_off[r], n = p.hit_off[r + 1] - h0, t_st = nr->t_st;
+    for (uint64_t j = 0; j < n; j++) {
+        const uint2 w = p.tmp[base + j];
+        if (h0 + j < p.rows_cap) {
+            p.x_st[h0 + j] = t_st + w.x;
+            p.x_en[h0 + j] = t_st + w.y;
         }
     }
 }
@@ -151,6 +209,11 @@ __global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
 extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_break_pieces, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t rb_launch_break_place(const rb_break_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_break_place, dim3((unsigned)((p->n_rec + 255) / 256)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 
