@@ -11,7 +11,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <exception>
+#include <memory>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <functional>
 #include <map>
 #include <numeric>
@@ -301,17 +306,83 @@ static std::string read_all(const std::string &file_name) {
     }
     return all;
 }
+// the bytes of a text file in a buffer nobody zero-fills first (std::string::resize would touch 1.5 GB twice), 32 zero bytes behind
+// the text (the device reads whole 16-byte groups).  A plain file is read by all host threads at once, each its own slice.
+struct TextBuf {
+    std::unique_ptr<char[]> p;
+    size_t n = 0;
+    const char *data() const { return p.get(); }
+    size_t size() const { return n; }
+};
+static TextBuf read_text(const std::string &file_name) {
+    TextBuf b;
+    if (file_name != "-") {
+        const int fd = open(file_name.c_str(), O_RDONLY);
+        if (fd < 0) throw Panic("Failed to open " + file_name);
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        const bool plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+        if (plain) {
+            b.n = (size_t)st.st_size;
+            b.p.reset(new char[b.n + 32]);
+            memset(b.p.get() + b.n, 0, 32);
+            std::atomic<bool> ok{true};
+            parallel_chunks((b.n + (1u << 22) - 1) >> 22, [&](unsigned, size_t lo, size_t hi) { // 4 MiB pieces
+                size_t a = lo << 22;
+                const size_t e = std::min(b.n, hi << 22);
+                while (a < e) {
+                    const ssize_t r = pread(fd, b.p.get() + a, e - a, (off_t)a);
+                    if (r <= 0) {
+                        ok = false;
+                        return;
+                    }
+                    a += (size_t)r;
+                }
+            });
+            close(fd);
+            if (!ok) throw Panic("Failed to read " + file_name);
+            return b;
+        }
+        close(fd);
+    }
+    const std::string all = read_all(file_name); // gzip / stdin
+    b.n = all.size();
+    b.p.reset(new char[b.n + 32]);
+    memcpy(b.p.get(), all.data(), b.n);
+    memset(b.p.get() + b.n, 0, 32);
+    return b;
+}
 // BufRead::lines: split on \n, strip one trailing \r
 static std::vector<std::pair<size_t, size_t>> split_lines(std::string_view all) {
+    // newline positions, every thread its slice of the bytes; then the (start, length) pairs in file order
+    const unsigned T = parallel_chunk_count((all.size() >> 20) + 1);
+    std::vector<std::vector<size_t>> nl(T);
+    parallel_chunks(T, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; t++) {
+            const size_t a0 = all.size() * t / T, a1 = all.size() * (t + 1) / T;
+            for (size_t a = a0; a < a1;) {
+                const void *q = memchr(all.data() + a, '\n', a1 - a);
+                if (!q) break;
+                const size_t b = (size_t)((const char *)q - all.data());
+                nl[t].push_back(b);
+                a = b + 1;
+            }
+        }
+    });
+    size_t total = 0;
+    for (const auto &v : nl) total += v.size();
     std::vector<std::pair<size_t, size_t>> lines;
-    for (size_t a = 0; a < all.size();) {
-        const void *nl = memchr(all.data() + a, '\n', all.size() - a);
-        const size_t b = nl ? (size_t)((const char *)nl - all.data()) : all.size();
+    lines.reserve(total + 1);
+    size_t a = 0;
+    auto add = [&](size_t b) { // line [a, b), b = the newline or the end of the text
         size_t e = b;
         if (e > a && all[e - 1] == '\r') e--;
         lines.emplace_back(a, e - a);
         a = b + 1;
-    }
+    };
+    for (const auto &v : nl)
+        for (size_t b : v) add(b);
+    if (a < all.size()) add(all.size());
     return lines;
 }
 
@@ -600,7 +671,7 @@ int paf_header_new(const char *base, size_t a, size_t n, HeaderOnly &h) {
 namespace {
 // the file text, where every kept line's columns and cg:Z: value sit in it, and the arrays the ABI wants
 struct TextFile {
-    std::string all;
+    TextBuf all;
     size_t text_bytes = 0;
     std::vector<HeaderOnly> recs;
     std::vector<uint64_t> cig_off, cig_end, t_st, t_en, q_st, q_en;
@@ -611,9 +682,8 @@ struct TextFile {
     // false = a line needs the general parser (two cg tags)
     bool load(const std::string &paf_path) {
         double tl = now_s();
-        all = read_all(paf_path);
+        all = read_text(paf_path);
         text_bytes = all.size();
-        all.append(32, '\0'); // the device reads whole 16-byte groups
         const std::vector<std::pair<size_t, size_t>> lines = split_lines(std::string_view(all.data(), text_bytes));
         lap("read + split lines", tl);
         const unsigned T = parallel_chunk_count(lines.size());
@@ -727,7 +797,8 @@ std::vector<std::string> assemble_lines(const TextFile &f, const std::vector<rb_
 } // namespace
 
 bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text) {
-    TextFile f;
+    // (one-shot command: the gigabytes behind these two are left to the end of the process instead of being unmapped piece by piece)
+    TextFile &f = *new TextFile;
     if (!f.load(paf_path)) return false; // the caller takes the general path
     double tl = now_s();
     const size_t n = f.recs.size();
@@ -741,7 +812,7 @@ bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vec
     std::vector<uint8_t> cig_status(n ? n : 1);
     std::vector<rb_reduce_row> red(n);
     std::vector<rb_norm_row> norm(n);
-    TextRows R;
+    TextRows &R = *new TextRows;
     rb_counters cnt;
     eng.check(rb_host_liftover_text(eng.ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(), f.cig_end.data(), f.t_st.data(),
                                     f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(), f.contig.data(), rgns.size(), w_contig.data(),
@@ -758,14 +829,15 @@ bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vec
 
 // main.rs:271-281, text in -> text out
 bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_length, std::vector<std::string> &out_text) {
-    TextFile f;
+    // (one-shot command: the gigabytes behind these two are left to the end of the process instead of being unmapped piece by piece)
+    TextFile &f = *new TextFile;
     if (!f.load(paf_path)) return false;
     double tl = now_s();
     const size_t n = f.recs.size();
     std::vector<uint8_t> cig_status(n ? n : 1);
     std::vector<rb_reduce_row> red(n);
     std::vector<rb_norm_row> norm(n);
-    TextRows R;
+    TextRows &R = *new TextRows;
     rb_counters cnt;
     eng.check(rb_host_break_text(eng.ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(), f.cig_end.data(), f.t_st.data(),
                                  f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(), break_length, eng.bsearch_policy, cig_status.data(),
