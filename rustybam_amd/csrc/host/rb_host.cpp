@@ -234,22 +234,25 @@ struct HostBatch {
     std::vector<uint8_t> strand;
     std::vector<std::string> contig_names;
     std::unordered_map<std::string, uint32_t> contig_id;
-    explicit HostBatch(const std::vector<PafRecord> &recs) {
-        const size_t n = recs.size();
+    explicit HostBatch(const std::vector<PafRecord> &recs) { fill(recs, nullptr); }
+    HostBatch(const std::vector<PafRecord> &all, const std::vector<uint32_t> &idx) { fill(all, &idx); } // the records all[idx[k]], in that order
+    void fill(const std::vector<PafRecord> &all, const std::vector<uint32_t> *idx) {
+        const size_t n = idx ? idx->size() : all.size();
+        auto rec = [&](size_t i) -> const PafRecord & { return idx ? all[(*idx)[i]] : all[i]; };
         op_off.assign(n + 1, 0);
         size_t total = 0;
         for (size_t i = 0; i < n; i++) {
-            total += recs[i].cigar.size();
+            total += rec(i).cigar.size();
             op_off[i + 1] = total;
         }
         ops.resize(total + 4, 0);
         t_st.resize(n), t_en.resize(n), q_st.resize(n), q_en.resize(n), strand.resize(n), contig.resize(n);
         parallel_chunks(n, [&](unsigned, size_t lo, size_t hi) {
             for (size_t i = lo; i < hi; i++)
-                if (!recs[i].cigar.empty()) memcpy(&ops[op_off[i]], recs[i].cigar.data(), recs[i].cigar.size() * 4);
+                if (!rec(i).cigar.empty()) memcpy(&ops[op_off[i]], rec(i).cigar.data(), rec(i).cigar.size() * 4);
         });
         for (size_t i = 0; i < n; i++) {
-            const PafRecord &r = recs[i];
+            const PafRecord &r = rec(i);
             t_st[i] = r.t_st, t_en[i] = r.t_en, q_st[i] = r.q_st, q_en[i] = r.q_en;
             strand[i] = (uint8_t)r.strand;
             auto it = contig_id.find(r.t_name);
@@ -1156,25 +1159,32 @@ std::string cigar_stats_line(const Stats &s, bool qbed) {
 
 // ---- trim-paf driver (paf.rs:210-305); the recursion is a loop -----------------------------------------
 void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int indel_score, bool remove_contained) {
+    // remove_trailing_indels (:218-220) runs on every record in every pass of the reference; it changes nothing on a record it
+    // has already seen unless a trim rewrote that record in between, so only those ("dirty") go back to the device
+    std::vector<uint32_t> dirty(records.size());
+    std::iota(dirty.begin(), dirty.end(), 0u);
     for (int pass = 0; pass < 100000; pass++) {
-        { // remove_trailing_indels on every record (:218-220)
-            HostBatch b(records);
+        if (!dirty.empty()) {
+            HostBatch b(records, dirty);
             std::vector<rb_norm_row> norm(b.n());
             eng.check(rb_host_scan_records(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(),
                                            b.q_en.data(), b.strand.data(), nullptr, norm.data()),
                       "rb_host_scan_records");
-            for (size_t i = 0; i < records.size(); i++) {
-                panic_on(norm[i].status, "remove_trailing_indels", i);
+            for (size_t k = 0; k < dirty.size(); k++) {
+                const size_t i = dirty[k];
+                panic_on(norm[k].status, "remove_trailing_indels", i);
                 PafRecord &r = records[i];
-                if (norm[i].flags & RB_F_STRIPPED) {
-                    r.id = stripped_id(r, norm[i]);
-                    r.cigar.assign(r.cigar.begin() + norm[i].first_op, r.cigar.begin() + norm[i].first_op + norm[i].n_ops);
+                if (norm[k].flags & RB_F_STRIPPED) {
+                    r.id = stripped_id(r, norm[k]);
+                    r.cigar.assign(r.cigar.begin() + norm[k].first_op, r.cigar.begin() + norm[k].first_op + norm[k].n_ops);
                 }
-                r.t_st = norm[i].t_st, r.t_en = norm[i].t_en, r.q_st = norm[i].q_st, r.q_en = norm[i].q_en;
-                r.nmatch = norm[i].nmatch, r.aln_len = norm[i].aln_len;
+                r.t_st = norm[k].t_st, r.t_en = norm[k].t_en, r.q_st = norm[k].q_st, r.q_en = norm[k].q_en;
+                r.nmatch = norm[k].nmatch, r.aln_len = norm[k].aln_len;
             }
         }
-        std::stable_sort(records.begin(), records.end(), [](const PafRecord &a, const PafRecord &b) { return a.q_name < b.q_name; }); // :223
+        dirty.clear();
+        const auto by_q = [](const PafRecord &a, const PafRecord &b) { return a.q_name < b.q_name; };
+        if (!std::is_sorted(records.begin(), records.end(), by_q)) std::stable_sort(records.begin(), records.end(), by_q); // :223 (a no-op from the second pass on)
         const size_t n = records.size();
         std::vector<char> contained(n, 0);
         if (n < 2) return; // :227-229
@@ -1210,12 +1220,15 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
             }
         }
         if (!left.empty()) {
-            HostBatch b(records);
+            // only the records of this pass's pairs go to the device: sub-batch = left[0], right[0], left[1], right[1], ...
+            std::vector<uint32_t> sub(2 * left.size()), sl(left.size()), sr(left.size());
+            for (size_t k = 0; k < left.size(); k++) sub[2 * k] = left[k], sub[2 * k + 1] = right[k], sl[k] = (uint32_t)(2 * k), sr[k] = (uint32_t)(2 * k + 1);
+            HostBatch b(records, sub);
             std::vector<rb_pair_row> rows(left.size());
             uint32_t *out = nullptr;
             uint64_t n_out = 0;
             eng.check(rb_host_overlap_split(eng.ctx(), b.n(), b.ops.data(), b.op_off.data(), b.t_st.data(), b.t_en.data(), b.q_st.data(),
-                                            b.q_en.data(), b.strand.data(), left.size(), left.data(), right.data(), match_score, diff_score,
+                                            b.q_en.data(), b.strand.data(), left.size(), sl.data(), sr.data(), match_score, diff_score,
                                             indel_score, eng.bsearch_policy, rows.data(), &out, &n_out),
                       "rb_host_overlap_split");
             for (size_t k = 0; k < left.size(); k++) {
@@ -1226,6 +1239,7 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
                     r.t_st = rows[k].t_st[s], r.t_en = rows[k].t_en[s], r.q_st = rows[k].q_st[s], r.q_en = rows[k].q_en[s];
                     r.nmatch = rows[k].nmatch[s], r.aln_len = rows[k].aln_len[s];
                     r.cigar.assign(out + rows[k].out_off[s], out + rows[k].out_off[s] + rows[k].out_n[s]);
+                    dirty.push_back(idx[s]);
                 }
             }
             rb_host_free(out);

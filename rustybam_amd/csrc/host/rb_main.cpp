@@ -227,8 +227,14 @@ int main(int argc, char **argv) {
             put(rb::records_to_text(paf.records));
         } else if (trim) {
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
+            lap("decode + check_integrity", tl);
             paf.overlapping_paf_recs(eng, ms, ds, is, remove_contained);
-            put(rb::records_to_text(paf.records));
+            lap("overlapping_paf_recs (passes)", tl);
+            const std::vector<std::string> text = rb::records_to_text(paf.records);
+            lap("encode", tl);
+            put(text);
+            fflush(stdout);
+            lap("write", tl);
         } else {
             return usage();
         }
