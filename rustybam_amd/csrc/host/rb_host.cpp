@@ -1163,6 +1163,7 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
     // has already seen unless a trim rewrote that record in between, so only those ("dirty") go back to the device
     std::vector<uint32_t> dirty(records.size());
     std::iota(dirty.begin(), dirty.end(), 0u);
+    double tl = now_s();
     for (int pass = 0; pass < 100000; pass++) {
         if (!dirty.empty()) {
             HostBatch b(records, dirty);
@@ -1183,6 +1184,7 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
             }
         }
         dirty.clear();
+        lap("  pass: strip rewritten records", tl);
         const auto by_q = [](const PafRecord &a, const PafRecord &b) { return a.q_name < b.q_name; };
         if (!std::is_sorted(records.begin(), records.end(), by_q)) std::stable_sort(records.begin(), records.end(), by_q); // :223 (a no-op from the second pass on)
         const size_t n = records.size();
@@ -1219,6 +1221,7 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
                 unseen++;
             }
         }
+        lap("  pass: sort, pairs, one per query", tl);
         if (!left.empty()) {
             // only the records of this pass's pairs go to the device: sub-batch = left[0], right[0], left[1], right[1], ...
             std::vector<uint32_t> sub(2 * left.size()), sl(left.size()), sr(left.size());
@@ -1244,6 +1247,7 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
             }
             rb_host_free(out);
         }
+        lap("  pass: split + clip on the device", tl);
         if (unseen > 0) continue; // :286-288
         if (remove_contained) {   // :289-301
             std::vector<PafRecord> keep;
