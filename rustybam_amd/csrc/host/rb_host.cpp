@@ -389,7 +389,12 @@ static std::vector<std::pair<size_t, size_t>> split_lines(std::string_view all) 
     return lines;
 }
 
+static bool paf_from_text_file(Engine &eng, const std::string &file_name, Paf &paf);
 Paf Paf::from_file(Engine &eng, const std::string &file_name) {
+    if (file_name != "-" && !getenv("RB_GENERAL_PATH")) { // regular files: header columns on the host, the cg:Z: values parsed on the device
+        Paf fast;
+        if (paf_from_text_file(eng, file_name, fast)) return fast;
+    }
     std::string all = read_all(file_name); // lines are parsed in parallel below
     const std::vector<std::pair<size_t, size_t>> lines = split_lines(all);
     const unsigned T = parallel_chunk_count(lines.size());
@@ -759,6 +764,46 @@ struct TextFile {
         return "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
     }
 };
+} // namespace
+// Paf::from_file for a regular file: read by all host threads, the twelve header columns parsed on the host, every cg:Z: value parsed
+// by rb_k_parse_cigars, check_integrity (paf.rs:70) in the same device visit.  false = the file needs the line-by-line parser.
+static bool paf_from_text_file(Engine &eng, const std::string &file_name, Paf &paf) {
+    TextFile f;
+    if (!f.load(file_name)) return false;
+    const size_t n = f.recs.size();
+    std::vector<uint64_t> op_off(n + 1, 0);
+    std::vector<uint8_t> status(n ? n : 1, 0);
+    uint32_t *ops = nullptr;
+    eng.check(rb_host_parse_cigars(eng.ctx(), (const uint8_t *)f.all.data(), f.cig_off.data(), f.cig_end.data(), n, op_off.data(), &ops, status.data()),
+              "rb_host_parse_cigars");
+    struct Free {
+        uint32_t *p;
+        ~Free() { rb_host_free(p); }
+    } guard{ops};
+    std::vector<rb_reduce_row> red(n);
+    bool text_ok = true;
+    for (size_t i = 0; i < n; i++) text_ok = text_ok && status[i] == RB_TEXT_OK;
+    if (text_ok && n)
+        eng.check(rb_host_scan_records(eng.ctx(), n, ops, op_off.data(), f.t_st.data(), f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(),
+                                       red.data(), nullptr),
+                  "rb_host_scan_records");
+    if (!f.check_loaded(status, red)) return false; // (throws the reference's panics, in its order of checks)
+    paf.records.resize(n);
+    parallel_chunks(n, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; i++) {
+            const HeaderOnly &h = f.recs[i];
+            PafRecord &r = paf.records[i];
+            r.q_name.assign(f.all.data() + h.q_name, h.q_name_n);
+            r.q_len = h.q_len, r.q_st = h.q_st, r.q_en = h.q_en, r.strand = h.strand;
+            r.t_name.assign(f.all.data() + h.t_name, h.t_name_n);
+            r.t_len = h.t_len, r.t_st = h.t_st, r.t_en = h.t_en, r.mapq = h.mapq;
+            r.nmatch = red[i].nmatch, r.aln_len = red[i].aln_len; // check_integrity overwrites both
+            r.cigar.assign(ops + op_off[i], ops + op_off[i + 1]);
+        }
+    });
+    return true;
+}
+namespace {
 struct TextRows { // results of rb_host_liftover_text / rb_host_break_text (freed on destruction)
     rb_hit_row *rows = nullptr;
     uint64_t n_rows = 0, *toff = nullptr;
