@@ -317,14 +317,14 @@ struct TextBuf {
     const char *data() const { return p.get(); }
     size_t size() const { return n; }
 };
-static TextBuf read_text(const std::string &file_name) {
+static TextBuf read_text(const std::string &file_name, bool raw_bytes = false) { // raw_bytes: a gzip file is NOT inflated
     TextBuf b;
     if (file_name != "-") {
         const int fd = open(file_name.c_str(), O_RDONLY);
         if (fd < 0) throw Panic("Failed to open " + file_name);
         unsigned char magic[2] = {0, 0};
         struct stat st;
-        const bool plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+        const bool plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (raw_bytes || !(pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b));
         if (plain) {
             b.n = (size_t)st.st_size;
             b.p.reset(new char[b.n + 32]);
@@ -347,6 +347,7 @@ static TextBuf read_text(const std::string &file_name) {
             return b;
         }
         close(fd);
+        if (raw_bytes) throw Panic("Failed to read " + file_name);
     }
     const std::string all = read_all(file_name); // gzip / stdin
     b.n = all.size();
@@ -1004,23 +1005,89 @@ struct BamRec {
     uint32_t flag = 0, l_seq = 0;
     size_t cig0 = 0, ncig = 0; // slice of the shared ops array
 };
-bool gz_exact(gzFile f, void *buf, size_t n) {
-    size_t got = 0;
-    while (got < n) {
-        const int r = gzread(f, (char *)buf + got, (unsigned)std::min<size_t>(n - got, 1u << 30));
-        if (r <= 0) return false;
-        got += (size_t)r;
-    }
-    return true;
-}
 uint32_t le32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+// The decompressed bytes of a BAM file.  A BGZF file is a series of independent gzip members of at most 64 KiB, each carrying its
+// compressed size (BC subfield) and its uncompressed size (ISIZE): the file is read by all host threads, the members are found by
+// hopping from header to header, and every thread inflates its share straight into place.  Anything else (stdin, plain gzip)
+// streams through zlib.
+struct BamStream {
+    std::unique_ptr<uint8_t[]> buf;
+    size_t n = 0, pos = 0;
+    explicit BamStream(const std::string &path) {
+        if (path != "-" && inflate_bgzf(path)) return;
+        gzFile f = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
+        if (!f) throw Panic("Failed to open " + path); // main.rs:63, nucfreq.rs:115
+        gzbuffer(f, 1 << 20);
+        std::vector<uint8_t> all, chunk(1 << 24);
+        int r;
+        while ((r = gzread(f, chunk.data(), (unsigned)chunk.size())) > 0) all.insert(all.end(), chunk.begin(), chunk.begin() + r);
+        gzclose(f);
+        n = all.size();
+        buf.reset(new uint8_t[n + 1]);
+        if (n) memcpy(buf.get(), all.data(), n);
+    }
+    bool exact(void *dst, size_t k) {
+        if (k > n - pos) return false;
+        memcpy(dst, buf.get() + pos, k);
+        pos += k;
+        return true;
+    }
+    bool inflate_bgzf(const std::string &path) {
+        TextBuf raw;
+        try {
+            raw = read_text(path, true);
+        } catch (const Panic &) {
+            return false;
+        }
+        const uint8_t *d = (const uint8_t *)raw.data();
+        const size_t sz = raw.size();
+        struct Member { size_t off, data, clen, out, isize; };
+        std::vector<Member> mem;
+        size_t off = 0, out = 0;
+        while (off < sz) {
+            if (sz - off < 18 || d[off] != 0x1f || d[off + 1] != 0x8b || d[off + 2] != 8 || !(d[off + 3] & 4)) return false;
+            const size_t xlen = (size_t)d[off + 10] | ((size_t)d[off + 11] << 8);
+            if (sz - off < 12 + xlen) return false;
+            size_t bsize = 0;
+            for (size_t x = off + 12; x + 4 <= off + 12 + xlen;) { // extra subfields: SI1 SI2 SLEN data
+                const size_t slen = (size_t)d[x + 2] | ((size_t)d[x + 3] << 8);
+                if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= off + 12 + xlen) bsize = ((size_t)d[x + 4] | ((size_t)d[x + 5] << 8)) + 1;
+                x += 4 + slen;
+            }
+            if (bsize < 12 + xlen + 8 || bsize > sz - off) return false;
+            const size_t isize = le32(d + off + bsize - 4);
+            mem.push_back({off, off + 12 + xlen, bsize - xlen - 12 - 8, out, isize});
+            out += isize;
+            off += bsize;
+        }
+        buf.reset(new uint8_t[out + 1]);
+        n = out;
+        std::atomic<bool> ok{true};
+        parallel_chunks(mem.size(), [&](unsigned, size_t lo, size_t hi) {
+            z_stream zs;
+            for (size_t m = lo; m < hi && ok; m++) {
+                if (mem[m].isize == 0) continue; // (the empty end-of-file member)
+                memset(&zs, 0, sizeof zs);
+                if (inflateInit2(&zs, -15) != Z_OK) { ok = false; break; }
+                zs.next_in = const_cast<Bytef *>(d + mem[m].data);
+                zs.avail_in = (uInt)mem[m].clen;
+                zs.next_out = buf.get() + mem[m].out;
+                zs.avail_out = (uInt)mem[m].isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.avail_out != 0) ok = false;
+                inflateEnd(&zs);
+            }
+        });
+        return ok;
+    }
+};
+bool gz_exact(BamStream &f, void *buf, size_t n) { return f.exact(buf, n); }
 } // namespace
 
 std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path) {
-    gzFile f = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
-    if (!f) throw Panic("Failed to open " + path); // main.rs:63
-    gzbuffer(f, 1 << 20);
-    uint8_t h8[8], b4[4];
+    BamStream f(path);
+    uint8_t h8[8] = {0}, b4[4] = {0};
     if (!gz_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw Panic(path + " is not a BAM file");
     std::vector<char> text(le32(h8 + 4) + 1);
     gz_exact(f, text.data(), text.size() - 1);
@@ -1095,7 +1162,7 @@ std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path) {
         for (uint32_t i = 0; i < n_cig; i++) ops.push_back(le32(cg + 4 * (size_t)i));
         recs.push_back(std::move(r));
     }
-    gzclose(f);
+
     const size_t n = recs.size();
     std::vector<uint64_t> op_off(n + 1, 0), zero(n, 0);
     std::vector<uint8_t> strand(n, (uint8_t)'+');
@@ -1349,10 +1416,8 @@ struct BamReads { // every record of the file, in file order: the arrays of rb_r
 uint64_t nf_key(int32_t tid, uint64_t p) { return ((uint64_t)(uint32_t)tid << 32) | std::min<uint64_t>(p, 0xFFFFFFFFull); }
 
 void load_bam_reads(const std::string &path, BamReads &B) {
-    gzFile f = path == "-" ? gzdopen(0, "rb") : gzopen(path.c_str(), "rb");
-    if (!f) throw Panic("Failed to open " + path); // nucfreq.rs:115
-    gzbuffer(f, 1 << 20);
-    uint8_t h8[8], b4[4];
+    BamStream f(path);
+    uint8_t h8[8] = {0}, b4[4] = {0};
     if (!gz_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw Panic(path + " is not a BAM file");
     std::vector<char> text(le32(h8 + 4) + 1);
     gz_exact(f, text.data(), text.size() - 1);
@@ -1424,7 +1489,7 @@ void load_bam_reads(const std::string &path, BamReads &B) {
         if (enters) run = std::max(run, nf_key(tid, endpos));
         B.end_key_pmax.push_back(run);
     }
-    gzclose(f);
+
     B.ops.resize(B.ops.size() + 4, 0);
     B.seq.resize(B.seq.size() + 32, 0);
 }
@@ -1439,8 +1504,10 @@ void put_u64(std::string &o, uint64_t v) {
 
 void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Region> &rgns, bool small,
                  const std::function<void(const std::string &)> &put) {
+    double tl = now_s();
     BamReads B;
     load_bam_reads(bam_path, B);
+    lap("nucfreq: inflate + decode BAM", tl);
     const uint64_t n_all = B.tid.size();
     for (uint64_t i = 1; i < n_all; i++) // the pileup iterator refuses unsorted input ("the input is not sorted"), p.unwrap() panics
         if (nf_key(B.tid[i], (uint64_t)B.pos[i]) < nf_key(B.tid[i - 1], (uint64_t)B.pos[i - 1]) && B.tid[i] >= 0 && B.pos[i] >= 0)
@@ -1484,46 +1551,61 @@ void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Reg
                         throw Panic("nucfreq: read " + std::to_string(i0 + i) + " has a cigar htslib's pileup cannot walk");
                 }
             }
+            lap("nucfreq: device", tl);
             for (uint64_t m0 = b0; m0 < b1; m0 += MED) {
-                const uint64_t m1 = std::min(m0 + MED, b1);
+                const uint64_t m1 = std::min(m0 + MED, b1), me = std::min(m1, c1);
                 out.clear();
                 if (!small) out += "#chr\tstart\tend\tA\tC\tG\tT\tregion_id\n"; // nucfreq.rs:127-131, once per piece
-                bool first = true;
-                for (uint64_t p = m0; p < std::min(m1, c1); p++) {
-                    const uint32_t *c = &counts[(size_t)(p - b0) * 4];
-                    if (!(c[0] & RB_NF_COVERED)) continue;
-                    const uint64_t a = c[0] & ~RB_NF_COVERED;
-                    if (small) { // nucfreq.rs:139-153
-                        if (first) {
-                            out += '#', out += R.name, out += '\t';
-                            put_u64(out, p);
-                            out += '\t', out += R.id, out += '\n';
+                // the lines of the piece, formatted by all host threads (each its own run of positions), put out in order
+                const size_t n_pos = me > m0 ? (size_t)(me - m0) : 0;
+                const unsigned T = parallel_chunk_count(n_pos / 4096 + 1);
+                std::vector<std::string> part(T);
+                std::vector<uint64_t> first_pos(T, ~0ull);
+                parallel_chunks(T, [&](unsigned, size_t tlo, size_t thi) {
+                    for (size_t t = tlo; t < thi; t++) {
+                        std::string &o = part[t];
+                        for (uint64_t p = m0 + n_pos * t / T; p < m0 + n_pos * (t + 1) / T; p++) {
+                            const uint32_t *c = &counts[(size_t)(p - b0) * 4];
+                            if (!(c[0] & RB_NF_COVERED)) continue;
+                            if (first_pos[t] == ~0ull) first_pos[t] = p;
+                            const uint64_t a = c[0] & ~RB_NF_COVERED;
+                            if (small) { // nucfreq.rs:139-153
+                                uint64_t mc[4] = {a, c[1], c[2], c[3]};
+                                std::sort(mc, mc + 4);
+                                put_u64(o, mc[3]);
+                                o += '\t';
+                                put_u64(o, mc[2]);
+                                o += '\n';
+                            } else { // impl Display for Nucfreq, nucfreq.rs:17-33
+                                o += R.name, o += '\t';
+                                put_u64(o, p);
+                                o += '\t';
+                                put_u64(o, (uint32_t)(p + 1));
+                                o += '\t';
+                                put_u64(o, a);
+                                o += '\t';
+                                put_u64(o, c[1]);
+                                o += '\t';
+                                put_u64(o, c[2]);
+                                o += '\t';
+                                put_u64(o, c[3]);
+                                o += '\t', o += R.id, o += '\n';
+                            }
                         }
-                        first = false;
-                        uint64_t mc[4] = {a, c[1], c[2], c[3]};
-                        std::sort(mc, mc + 4);
-                        put_u64(out, mc[3]);
-                        out += '\t';
-                        put_u64(out, mc[2]);
-                        out += '\n';
-                    } else { // impl Display for Nucfreq, nucfreq.rs:17-33
-                        out += R.name, out += '\t';
-                        put_u64(out, p);
-                        out += '\t';
-                        put_u64(out, (uint32_t)(p + 1));
-                        out += '\t';
-                        put_u64(out, a);
-                        out += '\t';
-                        put_u64(out, c[1]);
-                        out += '\t';
-                        put_u64(out, c[2]);
-                        out += '\t';
-                        put_u64(out, c[3]);
-                        out += '\t', out += R.id, out += '\n';
                     }
-                }
+                });
+                if (small) // the "#name pos id" line in front of the piece's first reported position
+                    for (unsigned t = 0; t < T; t++)
+                        if (first_pos[t] != ~0ull) {
+                            out += '#', out += R.name, out += '\t';
+                            put_u64(out, first_pos[t]);
+                            out += '\t', out += R.id, out += '\n';
+                            break;
+                        }
                 put(out);
+                for (unsigned t = 0; t < T; t++) put(part[t]);
             }
+            lap("nucfreq: format + write", tl);
         }
     }
 }
