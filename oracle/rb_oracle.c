@@ -1796,7 +1796,7 @@ int rbo_bam_stats(const char *path, int qbed, FILE *out) {
  * nucfreq (nucfreq.rs:61-95, :111-125; main.rs:82-121): A/C/G/T counts at every covered position of a region.
  *
  * The pileup engine is third-party: rust-htslib 0.44.1 (Cargo.lock:1533-1534) `Read::pileup()` over hts-sys 2.2.0
- * (Cargo.lock:723-724; it bundles htslib 1.21) = htslib `bam_plp_init` / `bam_plp_auto` with
+ * (Cargo.lock:723-724, which vendors htslib) = htslib `bam_plp_init` / `bam_plp_auto` with
  * the default mask (UNMAP | SECONDARY | QCFAIL | DUP) and maxcnt 8000.  It is absent from /root/reference; the
  * published algorithm (htslib sam.c: bam_plp_push, bam_plp64_next, resolve_cigar2) is restated below, position by
  * position with the same per-read cursor.  Only KA13 (nucfreq.rs:41-60) pins it: the depth cap and the behaviour on
