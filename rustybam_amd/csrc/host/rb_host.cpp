@@ -1512,21 +1512,29 @@ void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Reg
     for (uint64_t i = 1; i < n_all; i++) // the pileup iterator refuses unsorted input ("the input is not sorted"), p.unwrap() panics
         if (nf_key(B.tid[i], (uint64_t)B.pos[i]) < nf_key(B.tid[i - 1], (uint64_t)B.pos[i - 1]) && B.tid[i] >= 0 && B.pos[i] >= 0)
             throw Panic("nucfreq: the BAM file is not coordinate sorted");
-    const uint64_t MED = 1000000, BATCH = 32; // main.rs:101 (one header per piece); pieces handed to the device per call
+    const uint64_t MED = 1000000; // main.rs:101: one header per piece of this size
+    // the work list: every region cut into chunks of at most 32 pieces; consecutive chunks on one contig share a device call
+    struct Chunk {
+        size_t rg;
+        int32_t tid;
+        uint64_t b0, b1, c1; // positions [b0, b1) are printed, [b0, c1) computed (nothing lies past the contig's end)
+    };
     std::vector<uint32_t> counts, status;
     std::string out;
-    for (const Region &R : rgns) {
-        int32_t tid = -1;
-        for (size_t k = 0; k < B.ref_nm.size(); k++)
-            if (B.ref_nm[k] == R.name) { tid = (int32_t)k; break; }
-        for (uint64_t b0 = R.st; b0 < R.en; b0 += MED * BATCH) {
-            if (tid < 0) // nucfreq.rs:121-122 (fetch fails)
-                throw Panic("Is this region (" + R.name + ":" + std::to_string(R.st + 1) + "-" + std::to_string(R.en) + ") in your reference/bam?");
-            const uint64_t b1 = std::min(b0 + MED * BATCH, R.en);
-            // positions past the last base any read of this contig reaches are never reported: the device gets [b0, c1)
-            const uint64_t c1 = std::min<uint64_t>(b1, std::max<uint64_t>(b0, std::min<uint64_t>(B.ref_len[tid], 0xFFFFFFFFull)));
-            // the slice of reads that can reach [b0, c1)
-            const uint64_t k_st = nf_key(tid, b0), k_en = nf_key(tid, c1);
+    auto run_batch = [&](const std::vector<Chunk> &batch) {
+        if (batch.empty()) return;
+        const int32_t tid = batch[0].tid;
+        std::vector<int32_t> rt(batch.size(), tid);
+        std::vector<uint64_t> st(batch.size()), en(batch.size()), off(batch.size() + 1, 0);
+        uint64_t lo_pos = ~0ull, hi_pos = 0;
+        for (size_t k = 0; k < batch.size(); k++) {
+            st[k] = batch[k].b0, en[k] = batch[k].c1;
+            off[k + 1] = off[k] + (en[k] - st[k]);
+            if (en[k] > st[k]) lo_pos = std::min(lo_pos, st[k]), hi_pos = std::max(hi_pos, en[k]);
+        }
+        counts.assign((size_t)off[batch.size()] * 4 + 4, 0);
+        if (hi_pos > lo_pos) { // the slice of reads that can reach any chunk of the batch
+            const uint64_t k_st = nf_key(tid, lo_pos), k_en = nf_key(tid, hi_pos);
             const uint64_t i0 = (uint64_t)(std::upper_bound(B.end_key_pmax.begin(), B.end_key_pmax.end(), k_st) - B.end_key_pmax.begin());
             uint64_t lo = i0, hi = n_all;
             while (lo < hi) {
@@ -1534,26 +1542,31 @@ void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Reg
                 if (nf_key(B.tid[mid], (uint64_t)B.pos[mid]) >= k_en) hi = mid; else lo = mid + 1;
             }
             const uint64_t i1 = std::max(lo, i0);
-            rb_nucfreq_counters ctr{};
-            const uint64_t n_pos = c1 - b0;
-            counts.assign((size_t)n_pos * 4 + 4, 0);
-            if (n_pos && i1 > i0) {
+            if (i1 > i0) {
+                rb_nucfreq_counters ctr{};
                 rb_reads_view v{};
                 v.n_reads = i1 - i0;
                 v.ops = B.ops.data(), v.op_off = B.op_off.data() + i0, v.seq = B.seq.data(), v.seq_off = B.seq_off.data() + i0;
                 v.l_seq = B.l_seq.data() + i0, v.tid = B.tid.data() + i0, v.pos = B.pos.data() + i0, v.flag = B.flag.data() + i0;
-                const int32_t rt = tid;
                 status.assign((size_t)v.n_reads, 0);
-                eng.check(rb_host_nucfreq(eng.ctx(), &v, 1, &rt, &b0, &c1, counts.data(), status.data(), &ctr), "rb_host_nucfreq");
+                eng.check(rb_host_nucfreq(eng.ctx(), &v, batch.size(), rt.data(), st.data(), en.data(), counts.data(), status.data(), &ctr), "rb_host_nucfreq");
                 for (uint64_t i = 0; i < v.n_reads; i++) {
                     if (status[i] == RB_RD_SEQ_SHORT) throw Panic("index out of bounds: a base of read " + std::to_string(i0 + i) + " lies past its sequence");
-                    if (status[i] == RB_RD_BAD_CIGAR && B.pos[i0 + i] < (int64_t)c1) // (a read the fetch returns: htslib's cursor asserts on it)
-                        throw Panic("nucfreq: read " + std::to_string(i0 + i) + " has a cigar htslib's pileup cannot walk");
+                    if (status[i] == RB_RD_BAD_CIGAR) { // htslib's cursor asserts on it -- if a fetch of one of these chunks returns the read
+                        const int64_t p0 = B.pos[i0 + i];
+                        for (const Chunk &c : batch)
+                            if (p0 < (int64_t)c.c1 && p0 + 1 > (int64_t)c.b0) throw Panic("nucfreq: read " + std::to_string(i0 + i) + " has a cigar htslib's pileup cannot walk");
+                    }
                 }
             }
-            lap("nucfreq: device", tl);
-            for (uint64_t m0 = b0; m0 < b1; m0 += MED) {
-                const uint64_t m1 = std::min(m0 + MED, b1), me = std::min(m1, c1);
+        }
+        lap("nucfreq: device", tl);
+        for (size_t k = 0; k < batch.size(); k++) {
+            const Chunk &C = batch[k];
+            const Region &R = rgns[C.rg];
+            const uint32_t *cbase = counts.data() + (size_t)off[k] * 4;
+            for (uint64_t m0 = C.b0; m0 < C.b1; m0 += MED) {
+                const uint64_t m1 = std::min(m0 + MED, C.b1), me = std::min(m1, C.c1);
                 out.clear();
                 if (!small) out += "#chr\tstart\tend\tA\tC\tG\tT\tregion_id\n"; // nucfreq.rs:127-131, once per piece
                 // the lines of the piece, formatted by all host threads (each its own run of positions), put out in order
@@ -1565,7 +1578,7 @@ void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Reg
                     for (size_t t = tlo; t < thi; t++) {
                         std::string &o = part[t];
                         for (uint64_t p = m0 + n_pos * t / T; p < m0 + n_pos * (t + 1) / T; p++) {
-                            const uint32_t *c = &counts[(size_t)(p - b0) * 4];
+                            const uint32_t *c = cbase + (size_t)(p - C.b0) * 4;
                             if (!(c[0] & RB_NF_COVERED)) continue;
                             if (first_pos[t] == ~0ull) first_pos[t] = p;
                             const uint64_t a = c[0] & ~RB_NF_COVERED;
@@ -1605,9 +1618,38 @@ void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Reg
                 put(out);
                 for (unsigned t = 0; t < T; t++) put(part[t]);
             }
-            lap("nucfreq: format + write", tl);
+        }
+        lap("nucfreq: format + write", tl);
+    };
+    std::vector<Chunk> batch;
+    uint64_t batch_pos = 0, batch_lo = 0, batch_hi = 0;
+    for (size_t rg = 0; rg < rgns.size(); rg++) {
+        const Region &R = rgns[rg];
+        int32_t tid = -1;
+        for (size_t k = 0; k < B.ref_nm.size(); k++)
+            if (B.ref_nm[k] == R.name) { tid = (int32_t)k; break; }
+        for (uint64_t b0 = R.st; b0 < R.en; b0 += MED * 32) {
+            if (tid < 0) { // nucfreq.rs:121-122 (fetch fails) -- after everything before it has been printed
+                run_batch(batch);
+                throw Panic("Is this region (" + R.name + ":" + std::to_string(R.st + 1) + "-" + std::to_string(R.en) + ") in your reference/bam?");
+            }
+            const uint64_t b1 = std::min(b0 + MED * 32, R.en);
+            const uint64_t c1 = std::min<uint64_t>(b1, std::max<uint64_t>(b0, std::min<uint64_t>(B.ref_len[tid], 0xFFFFFFFFull)));
+            // a chunk joins the open batch while the batch stays on one contig, under 32 M positions and 4096 chunks, and its
+            // positions stay within 64 Mbp of each other (the reads in between are uploaded too)
+            const bool fits = !batch.empty() && batch[0].tid == tid && batch.size() < 4096 && batch_pos + (c1 - b0) <= 32000000ull &&
+                              std::max(batch_hi, c1) - std::min(batch_lo, b0) <= 64000000ull;
+            if (!fits) {
+                run_batch(batch);
+                batch.clear();
+                batch_pos = 0, batch_lo = b0, batch_hi = c1;
+            }
+            batch.push_back({rg, tid, b0, b1, c1});
+            batch_pos += c1 - b0;
+            batch_lo = std::min(batch_lo, b0), batch_hi = std::max(batch_hi, c1);
         }
     }
+    run_batch(batch);
 }
 
 // ---------------------------------------------------------------- header-only commands (paf.rs:91-207)

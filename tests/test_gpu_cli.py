@@ -317,3 +317,27 @@ def test_nucfreq_synthetic_bam_flags_and_clips(oracle, tmp_path):
         assert out == oout, a
     rc, out = rb("nucfreq", "-r", "chrA:1-50000", str(p))
     assert out.count(b"\n") == 1 + 140 + 20   # r1 [100,146) and r2 [110,240) merge; r3 [4090,4110); dup / secondary reads add nothing
+
+
+def test_nucfreq_many_bed_regions_share_device_calls(oracle, golden, tmp_path):
+    """hundreds of small regions, contigs interleaved, some overlapping, some empty: the host groups consecutive regions of a
+    contig into one device call; the text must still be the reference's, region by region"""
+    import random
+    rc, st = rb("stats", f"{golden}/asm_small.bam")
+    recs = [l.split(b"\t") for l in st.splitlines()[1:]]
+    rnd = random.Random(3)
+    lines = []
+    for k in range(240):
+        f = recs[rnd.randrange(len(recs))] if k % 7 else recs[k % 3]
+        name, r_st, r_en = f[0].decode(), int(f[1]), int(f[2])
+        a = rnd.randrange(max(r_st - 2000, 0), r_en + 2000)
+        b = a + (0 if k % 41 == 0 else rnd.randrange(1, 3000))
+        lines.append(f"{name}\t{a}\t{b}" + (f"\tid{k}" if k % 3 == 0 else ""))
+    bed = tmp_path / "many.bed"
+    bed.write_text("\n".join(lines) + "\n")
+    for extra in ([], ["-s"]):
+        a = ["nucfreq", "--bed", str(bed)] + extra + [f"{golden}/asm_small.bam"]
+        rc, out = rb(*a)
+        orc, oout = oracle.cli(*a)
+        assert (rc, orc) == (0, 0)
+        assert out == oout and out.count(b"\n") > 1000
