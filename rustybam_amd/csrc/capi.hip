@@ -12,6 +12,7 @@
 #include <ctime>
 #include <numeric>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rustybam_amd.h"
@@ -1208,11 +1209,14 @@ extern "C" int rb_host_overlap_split(rb_ctx *ctx, uint64_t n_rec, const uint32_t
     for (uint64_t i = 0; i < n_pairs; i++)
         if (rows[i].status == RB_ST_OK) total += rows[i].out_n[0] + rows[i].out_n[1];
     *out_ops = (uint32_t *)malloc((size_t)(total + 1) * 4);
+    if (!*out_ops) return fail(ctx, RB_E_NOMEM, "malloc(%llu ops)", (unsigned long long)total);
+    // dense offsets first, then the copies on all host threads
+    std::vector<uint64_t> src(2 * (size_t)n_pairs);
     uint64_t o = 0;
     for (uint64_t i = 0; i < n_pairs; i++) {
         for (int s = 0; s < 2; s++) {
+            src[2 * i + s] = rows[i].out_off[s];
             if (rows[i].status == RB_ST_OK) {
-                memcpy(*out_ops + o, raw.data() + rows[i].out_off[s], (size_t)rows[i].out_n[s] * 4);
                 rows[i].out_off[s] = o;
                 o += rows[i].out_n[s];
             } else {
@@ -1220,6 +1224,17 @@ extern "C" int rb_host_overlap_split(rb_ctx *ctx, uint64_t n_rec, const uint32_t
                 rows[i].out_n[s] = 0;
             }
         }
+    }
+    {
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(std::thread::hardware_concurrency(), n_pairs / 1024));
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                for (uint64_t i = n_pairs * t / T; i < n_pairs * (t + 1) / T; i++)
+                    for (int s = 0; s < 2; s++)
+                        if (rows[i].out_n[s]) memcpy(*out_ops + rows[i].out_off[s], raw.data() + src[2 * i + s], (size_t)rows[i].out_n[s] * 4);
+            });
+        for (auto &x : th) x.join();
     }
     *n_out = o;
     return rb_ctx_sync(ctx);

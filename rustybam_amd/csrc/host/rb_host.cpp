@@ -1346,17 +1346,20 @@ void Paf::overlapping_paf_recs(Engine &eng, int match_score, int diff_score, int
                                             b.q_en.data(), b.strand.data(), left.size(), sl.data(), sr.data(), match_score, diff_score,
                                             indel_score, eng.bsearch_policy, rows.data(), &out, &n_out),
                       "rb_host_overlap_split");
-            for (size_t k = 0; k < left.size(); k++) {
+            for (size_t k = 0; k < left.size(); k++)
                 if (rows[k].status != RB_ST_OK) throw Panic("trim_overlapping_pafs: pair " + std::to_string(k) + " status " + std::to_string(rows[k].status));
-                const uint32_t idx[2] = {left[k], right[k]};
-                for (int s = 0; s < 2; s++) {
-                    PafRecord &r = records[idx[s]];
-                    r.t_st = rows[k].t_st[s], r.t_en = rows[k].t_en[s], r.q_st = rows[k].q_st[s], r.q_en = rows[k].q_en[s];
-                    r.nmatch = rows[k].nmatch[s], r.aln_len = rows[k].aln_len[s];
-                    r.cigar.assign(out + rows[k].out_off[s], out + rows[k].out_off[s] + rows[k].out_n[s]);
-                    dirty.push_back(idx[s]);
+            parallel_chunks(left.size(), [&](unsigned, size_t lo, size_t hi) { // (a record is in at most one pair of a pass)
+                for (size_t k = lo; k < hi; k++) {
+                    const uint32_t idx[2] = {left[k], right[k]};
+                    for (int s = 0; s < 2; s++) {
+                        PafRecord &r = records[idx[s]];
+                        r.t_st = rows[k].t_st[s], r.t_en = rows[k].t_en[s], r.q_st = rows[k].q_st[s], r.q_en = rows[k].q_en[s];
+                        r.nmatch = rows[k].nmatch[s], r.aln_len = rows[k].aln_len[s];
+                        r.cigar.assign(out + rows[k].out_off[s], out + rows[k].out_off[s] + rows[k].out_n[s]);
+                    }
                 }
-            }
+            });
+            for (size_t k = 0; k < left.size(); k++) dirty.push_back(left[k]), dirty.push_back(right[k]);
             rb_host_free(out);
         }
         lap("  pass: split + clip on the device", tl);
