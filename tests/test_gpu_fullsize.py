@@ -1,0 +1,132 @@
+"""BASELINE.json configs[2] at FULL size (1e6 records, 5e9 ops, 3000 sliding windows: what bench.py times) through properties that
+need no oracle: every one of the ~12.6 M clipped records must pass the reference's own check_integrity (paf.rs:825-857: target span =
+reference-consuming lengths, query span = query-consuming lengths, nmatch = M/=/X lengths, aln_len = all lengths), and the two
+independent emission routes of the clip kernel -- copied ops and clip descriptors into the original CIGAR -- must describe the same
+ops (a checksum per clip).  Segment sums come from prefix sums over the whole op arrays (torch, on the device)."""
+import os
+
+import numpy as np
+import pytest
+
+import rustybam_amd
+from rustybam_amd import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _seg(P, a, b):
+    """sum over [a, b) from an inclusive prefix array"""
+    import torch
+    hi = P[(b - 1).clamp(min=0)]
+    hi = torch.where(b > 0, hi, torch.zeros_like(hi))
+    lo = P[(a - 1).clamp(min=0)]
+    lo = torch.where(a > 0, lo, torch.zeros_like(lo))
+    return hi - lo
+
+
+def test_full_size_liftover_integrity_and_descriptor_checksums():
+    import torch
+    n_rec = int(os.environ.get("RB_FULLSIZE_RECORDS", "1000000"))
+    dev = torch.device("cuda", 0)
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    seed = wl.SEED_CONFIG3
+    w_c, w_st, w_en = wl.sliding_windows(3000)
+    nops = wl.n_ops(seed, 0, n_rec)
+    op_off = wl.op_offsets(nops)
+    total_ops = int(op_off[-1])
+    i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    d_off = i64(op_off)
+    d_ops = torch.empty(total_ops + 64, dtype=torch.int32, device=dev)
+    eng.dev_synth_fill_ops(seed, 0, n_rec, d_off.data_ptr(), d_ops.data_ptr())
+    zeros = torch.zeros(n_rec, dtype=torch.int64, device=dev)
+    d_contig = torch.zeros(n_rec, dtype=torch.int32, device=dev)
+    d_strand0 = torch.full((n_rec,), ord("+"), dtype=torch.uint8, device=dev)
+    d_red = torch.empty(n_rec * 72, dtype=torch.uint8, device=dev)
+    d_norm = torch.empty(n_rec * 64, dtype=torch.uint8, device=dev)
+    v0 = eng.batch_view(n_rec, total_ops, d_ops.data_ptr(), d_off.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), zeros.data_ptr(),
+                        zeros.data_ptr(), d_strand0.data_ptr(), d_contig.data_ptr())
+    eng.dev_scan_records(v0, d_red.data_ptr(), 0)
+    torch.cuda.synchronize()
+    red = d_red.cpu().numpy().view(rustybam_amd.REDUCE_DT)
+    t_st, t_en, q_st, q_en, strand = wl.headers(seed, 0, red["t_bases"], red["q_bases"], "uniform")
+    d_c = [i64(x) for x in (t_st, t_en, q_st, q_en)]
+    d_strand = torch.from_numpy(strand).to(dev)
+    view = eng.batch_view(n_rec, total_ops, d_ops.data_ptr(), d_off.data_ptr(), *[x.data_ptr() for x in d_c], d_strand.data_ptr(), d_contig.data_ptr())
+    plan = eng.plan_create(op_off, np.zeros(n_rec, np.uint32), w_c, w_st, w_en)
+    d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
+
+    def run(policy, rows_cap, out_cap):
+        for _ in range(6):
+            ws = torch.empty(eng.plan_workspace_bytes(plan, rows_cap), dtype=torch.uint8, device=dev)
+            rows = torch.full(((rows_cap + 1) * 64,), 0xEE, dtype=torch.uint8, device=dev)   # (a row nobody writes stays 0xEE..)
+            out = torch.empty(out_cap + 64, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()   # the engine runs on its own stream: torch's fill must have landed before it starts
+            eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(), out_cap, d_cnt.data_ptr())
+            torch.cuda.synchronize()
+            cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
+            if not cnt["overflow"]:
+                n = int(cnt["n_hits"])
+                r = rows[:n * 64].view(torch.int32).view(n, 16).clone()
+                torch.cuda.synchronize()   # ... and the copy must be done before the buffer is freed and handed to the next call
+                return r, out
+            rows_cap = max(rows_cap, int(cnt["n_hits"]) + 64)
+            out_cap = max(out_cap * 2, int(int(cnt["out_ops_needed"]) * 1.25) + 4096)
+            del ws, rows, out
+        raise AssertionError("could not size the outputs")
+
+    base = rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN
+    rows_c, out_c = run(base, 16 * n_rec, int(1.6 * total_ops))
+    rows_d, desc = run(base | rustybam_amd.LIFT_DESCRIPTORS, rows_c.shape[0] + 64, 4 * (rows_c.shape[0] + 64) + 65536)
+    n = rows_c.shape[0]
+    assert n > 12 * n_rec and rows_d.shape[0] == n
+    assert int((rows_c[:, 0] == -286331154).sum()) == 0 and int((rows_d[:, 0] == -286331154).sum()) == 0   # every row was written
+    u64 = lambda r, c: (r[:, c].to(torch.int64) & 0xFFFFFFFF) | (r[:, c + 1].to(torch.int64) << 32)
+    status = rows_c[:, 2] & 0xFFFF
+    assert int((status != 0).sum()) == 0                       # every (record, window) hit of this workload clips
+    # ---- the two routes agree on everything but where the ops are: same canonical order, same coordinates ----
+    for c in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+        assert torch.equal(rows_c[:, c], rows_d[:, c]), f"column {c}"
+    assert torch.equal(rows_c[:, 2] & 0xFFFF, rows_d[:, 2] & 0xFFFF)
+    out_n = rows_c[:, 3].to(torch.int64)
+    off_c = u64(rows_c, 14)
+    t_span, q_span = u64(rows_c, 6) - u64(rows_c, 4), u64(rows_c, 10) - u64(rows_c, 8)
+    nmatch, aln_len = rows_c[:, 12].to(torch.int64) & 0xFFFFFFFF, rows_c[:, 13].to(torch.int64) & 0xFFFFFFFF
+    # ---- check_integrity on every clipped record (copied route) ----
+    cap = int((off_c + out_n).max().item())
+    words = out_c[:cap]
+    one = torch.ones((), dtype=torch.int32, device=dev)
+    for name, class_mask, want in (("aln_len", None, aln_len), ("nmatch", 0x181, nmatch), ("target span", 0x18D, t_span), ("query span", 0x193, q_span)):
+        x = words >> 4                                     # lengths (one 4 B/op temporary at a time: the arenas span 32 GB)
+        if class_mask is not None:                         # ... of the ops whose code belongs to the class (paf.rs:946-996)
+            m = words & 15
+            m = torch.bitwise_right_shift(one * class_mask, m)
+            m &= 1
+            x *= m
+            del m
+        P = torch.cumsum(x, 0, dtype=torch.int64)
+        got = _seg(P, off_c, off_c + out_n)
+        bad = int((got != want).sum())
+        assert bad == 0, f"{name}: {bad} of {n} clipped records fail check_integrity"
+        del P, x, got
+    # ---- checksum per clip: copied ops vs the descriptor applied to the original cigar ----
+    P_out = torch.cumsum(words, 0, dtype=torch.int64)
+    sum_c = _seg(P_out, off_c, off_c + out_n)
+    del P_out, words, out_c
+    torch.cuda.empty_cache()
+    d4 = desc[:4 * n].view(n, 4).to(torch.int64) & 0xFFFFFFFF   # first op (in the record's original cigar), count, first length, last length
+    rec = rows_d[:, 0].to(torch.int64) & 0xFFFFFFFF
+    first = d_off[rec] + d4[:, 0]
+    cntd, fl, ll = d4[:, 1], d4[:, 2], d4[:, 3]
+    assert torch.equal(cntd, out_n)
+    P_in = torch.cumsum(d_ops[:total_ops], 0, dtype=torch.int64)
+    sum_d = _seg(P_in, first, first + cntd)
+    del P_in
+    w_first = d_ops[first].to(torch.int64)
+    w_last = d_ops[first + cntd - 1].to(torch.int64)
+    one = cntd == 1
+    new_first = torch.where(one & (fl > 0) & (ll > 0), fl + ll - (w_first >> 4), torch.where(fl > 0, fl, w_first >> 4))
+    new_last = torch.where(ll > 0, ll, w_last >> 4)
+    sum_d = sum_d + ((new_first - (w_first >> 4)) << 4) + torch.where(one, torch.zeros_like(sum_d), (new_last - (w_last >> 4)) << 4)
+    bad = int((sum_d != sum_c).sum())
+    assert bad == 0, f"{bad} of {n} clips differ between the copied and the descriptor route"
+    eng.close()

@@ -91,6 +91,7 @@ def main():
         eng.dev_nucfreq(n, d_ops.data_ptr(), d_opoff.data_ptr(), d_seq.data_ptr(), d_seqoff.data_ptr(), d_lseq.data_ptr(), d_tid.data_ptr(),
                         d_pos.data_ptr(), d_flag.data_ptr(), 1, d_rgtid.data_ptr(), d_rgst.data_ptr(), d_rgen.data_ptr(), d_outoff.data_ptr(),
                         a.contig, d_counts.data_ptr(), d_status.data_ptr(), d_ctr.data_ptr(), ws_ptr, wsb)
+    torch.cuda.synchronize()  # (the engine has its own stream: torch's generation kernels must be done before it reads their output)
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize()
