@@ -130,3 +130,63 @@ def test_full_size_liftover_integrity_and_descriptor_checksums():
     bad = int((sum_d != sum_c).sum())
     assert bad == 0, f"{bad} of {n} clips differ between the copied and the descriptor route"
     eng.close()
+
+
+def test_full_size_nucfreq_checksums():
+    """SURVEY 8d config 5 at full size (30x of a 250 Mbp contig, 5e5 reads of 15 kb): every M base lands in exactly one of the four
+    counters of a position inside its read's span (sum of all counters = number of M bases), and coverage / maximum depth equal
+    what a difference array over the reads' spans gives"""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_nucfreq import make_reads, N_EVENTS
+    contig = int(os.environ.get("RB_FULLSIZE_CONTIG", "250000000"))
+    dev = torch.device("cuda", 0)
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    pos, ops, op_off, n = make_reads(contig, 30, 15000)
+    bpr = 7500
+    lut = torch.tensor([(1 << (k >> 2)) << 4 | (1 << (k & 3)) for k in range(16)], dtype=torch.uint8, device=dev)
+    d_seq = torch.empty(n * bpr + 64, dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    for o in range(0, d_seq.numel(), 1 << 27):
+        m = min(1 << 27, d_seq.numel() - o)
+        d_seq[o:o + m] = lut[torch.randint(0, 16, (m,), dtype=torch.uint8, device=dev, generator=g).long()]
+    i64 = lambda x: torch.from_numpy(np.ascontiguousarray(x).view(np.int64)).to(dev)
+    d_pos, d_opoff = i64(pos), i64(op_off)
+    d_ops = torch.from_numpy(np.concatenate([ops, np.zeros(8, np.uint32)]).view(np.int32)).to(dev)
+    d_seqoff = i64(np.arange(n, dtype=np.uint64) * np.uint64(bpr))
+    d_lseq = torch.full((n,), 15000, dtype=torch.int32, device=dev)
+    d_tid = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_flag = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_rgtid = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_rgst = torch.zeros(1, dtype=torch.int64, device=dev)
+    d_rgen = torch.full((1,), contig, dtype=torch.int64, device=dev)
+    d_outoff = torch.tensor([0, contig], dtype=torch.int64, device=dev)
+    d_counts = torch.empty(contig * 4 + 16, dtype=torch.int32, device=dev)
+    d_status = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    d_ctr = torch.zeros(4, dtype=torch.int64, device=dev)
+    wsb = eng.nucfreq_workspace_bytes(n, 1, contig)
+    d_ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng.dev_nucfreq(n, d_ops.data_ptr(), d_opoff.data_ptr(), d_seq.data_ptr(), d_seqoff.data_ptr(), d_lseq.data_ptr(), d_tid.data_ptr(), d_pos.data_ptr(),
+                    d_flag.data_ptr(), 1, d_rgtid.data_ptr(), d_rgst.data_ptr(), d_rgen.data_ptr(), d_outoff.data_ptr(), contig, d_counts.data_ptr(),
+                    d_status.data_ptr(), d_ctr.data_ptr(), (d_ws.data_ptr() + 255) & ~255, wsb)
+    torch.cuda.synchronize()
+    ctr = d_ctr.cpu().numpy()
+    assert int((d_status[:n] != 0).sum()) == 0 and ctr[3] == 0 and ctr[2] == 0
+    c = d_counts[:contig * 4].view(-1, 4)
+    covered = (c[:, 0] < 0)                                     # bit 31 of the A word
+    total = int((c[:, 0] & 0x7FFFFFFF).sum() + c[:, 1].sum() + c[:, 2].sum() + c[:, 3].sum())
+    o = ops.reshape(n, 2 * N_EVENTS + 1)
+    assert total == int(((o >> 4) * ((o & 15) == 0)).sum())     # every M base counted once (all bases are A/C/G/T here)
+    ref = ((o >> 4) * np.isin(o & 15, [0, 2])).sum(axis=1)
+    d = torch.zeros(contig + 1, dtype=torch.int32, device=dev)
+    d.index_add_(0, d_pos, torch.ones(n, dtype=torch.int32, device=dev))
+    d.index_add_(0, i64(pos + ref.astype(np.int64)), -torch.ones(n, dtype=torch.int32, device=dev))
+    depth = torch.cumsum(d[:contig], 0)
+    assert int(depth.max()) == int(ctr[0]) and int((depth > 0).sum()) == int(ctr[1])
+    assert torch.equal(depth > 0, covered)
+    # a position's four counters never exceed its depth
+    assert bool(((c[:, 0] & 0x7FFFFFFF) + c[:, 1] + c[:, 2] + c[:, 3] <= depth).all())
+    eng.close()
