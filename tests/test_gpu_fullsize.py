@@ -24,7 +24,7 @@ def _seg(P, a, b):
     return hi - lo
 
 
-def test_full_size_liftover_integrity_and_descriptor_checksums():
+def _config3(is_break=False):
     import torch
     n_rec = int(os.environ.get("RB_FULLSIZE_RECORDS", "1000000"))
     dev = torch.device("cuda", 0)
@@ -61,7 +61,10 @@ def test_full_size_liftover_integrity_and_descriptor_checksums():
             rows = torch.full(((rows_cap + 1) * 64,), 0xEE, dtype=torch.uint8, device=dev)   # (a row nobody writes stays 0xEE..)
             out = torch.empty(out_cap + 64, dtype=torch.int32, device=dev)
             torch.cuda.synchronize()   # the engine runs on its own stream: torch's fill must have landed before it starts
-            eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(), out_cap, d_cnt.data_ptr())
+            if is_break:
+                eng.dev_break(plan, view, d_norm.data_ptr(), 100, policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(), out_cap, d_cnt.data_ptr())
+            else:
+                eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(), out_cap, d_cnt.data_ptr())
             torch.cuda.synchronize()
             cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
             if not cnt["overflow"]:
@@ -74,26 +77,23 @@ def test_full_size_liftover_integrity_and_descriptor_checksums():
             del ws, rows, out
         raise AssertionError("could not size the outputs")
 
-    base = rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN
-    rows_c, out_c = run(base, 16 * n_rec, int(1.6 * total_ops))
-    rows_d, desc = run(base | rustybam_amd.LIFT_DESCRIPTORS, rows_c.shape[0] + 64, 4 * (rows_c.shape[0] + 64) + 65536)
-    n = rows_c.shape[0]
-    assert n > 12 * n_rec and rows_d.shape[0] == n
-    assert int((rows_c[:, 0] == -286331154).sum()) == 0 and int((rows_d[:, 0] == -286331154).sum()) == 0   # every row was written
-    u64 = lambda r, c: (r[:, c].to(torch.int64) & 0xFFFFFFFF) | (r[:, c + 1].to(torch.int64) << 32)
-    status = rows_c[:, 2] & 0xFFFF
-    assert int((status != 0).sum()) == 0                       # every (record, window) hit of this workload clips
-    # ---- the two routes agree on everything but where the ops are: same canonical order, same coordinates ----
-    for c in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
-        assert torch.equal(rows_c[:, c], rows_d[:, c]), f"column {c}"
-    assert torch.equal(rows_c[:, 2] & 0xFFFF, rows_d[:, 2] & 0xFFFF)
-    out_n = rows_c[:, 3].to(torch.int64)
-    off_c = u64(rows_c, 14)
-    t_span, q_span = u64(rows_c, 6) - u64(rows_c, 4), u64(rows_c, 10) - u64(rows_c, 8)
-    nmatch, aln_len = rows_c[:, 12].to(torch.int64) & 0xFFFFFFFF, rows_c[:, 13].to(torch.int64) & 0xFFFFFFFF
-    # ---- check_integrity on every clipped record (copied route) ----
-    cap = int((off_c + out_n).max().item())
-    words = out_c[:cap]
+    return dict(torch=torch, dev=dev, eng=eng, run=run, n_rec=n_rec, total_ops=total_ops, d_ops=d_ops, d_off=d_off, keep=(d_c, d_strand, d_contig, d_norm, zeros, plan, view))
+
+
+def _u64(r, c):
+    import torch
+    return (r[:, c].to(torch.int64) & 0xFFFFFFFF) | (r[:, c + 1].to(torch.int64) << 32)
+
+
+def _check_integrity(torch, dev, rows, out):
+    """paf.rs:825-857 on every row: spans and counts against segment sums of the row's ops"""
+    n = rows.shape[0]
+    out_n = rows[:, 3].to(torch.int64)
+    off = _u64(rows, 14)
+    t_span, q_span = _u64(rows, 6) - _u64(rows, 4), _u64(rows, 10) - _u64(rows, 8)
+    nmatch, aln_len = rows[:, 12].to(torch.int64) & 0xFFFFFFFF, rows[:, 13].to(torch.int64) & 0xFFFFFFFF
+    cap = int((off + out_n).max().item())
+    words = out[:cap]
     one = torch.ones((), dtype=torch.int32, device=dev)
     for name, class_mask, want in (("aln_len", None, aln_len), ("nmatch", 0x181, nmatch), ("target span", 0x18D, t_span), ("query span", 0x193, q_span)):
         x = words >> 4                                     # lengths (one 4 B/op temporary at a time: the arenas span 32 GB)
@@ -104,10 +104,30 @@ def test_full_size_liftover_integrity_and_descriptor_checksums():
             x *= m
             del m
         P = torch.cumsum(x, 0, dtype=torch.int64)
-        got = _seg(P, off_c, off_c + out_n)
+        got = _seg(P, off, off + out_n)
         bad = int((got != want).sum())
         assert bad == 0, f"{name}: {bad} of {n} clipped records fail check_integrity"
         del P, x, got
+    return words, off, out_n
+
+
+def test_full_size_liftover_integrity_and_descriptor_checksums():
+    C = _config3()
+    torch, dev, eng, run, n_rec, total_ops, d_ops, d_off = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops", "d_ops", "d_off"))
+    base = rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN
+    rows_c, out_c = run(base, 16 * n_rec, int(1.6 * total_ops))
+    rows_d, desc = run(base | rustybam_amd.LIFT_DESCRIPTORS, rows_c.shape[0] + 64, 4 * (rows_c.shape[0] + 64) + 65536)
+    n = rows_c.shape[0]
+    assert n > 12 * n_rec and rows_d.shape[0] == n
+    assert int((rows_c[:, 0] == -286331154).sum()) == 0 and int((rows_d[:, 0] == -286331154).sum()) == 0   # every row was written
+    status = rows_c[:, 2] & 0xFFFF
+    assert int((status != 0).sum()) == 0                       # every (record, window) hit of this workload clips
+    # ---- the two routes agree on everything but where the ops are: same canonical order, same coordinates ----
+    for c in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
+        assert torch.equal(rows_c[:, c], rows_d[:, c]), f"column {c}"
+    assert torch.equal(rows_c[:, 2] & 0xFFFF, rows_d[:, 2] & 0xFFFF)
+    # ---- check_integrity on every clipped record (copied route) ----
+    words, off_c, out_n = _check_integrity(torch, dev, rows_c, out_c)
     # ---- checksum per clip: copied ops vs the descriptor applied to the original cigar ----
     P_out = torch.cumsum(words, 0, dtype=torch.int64)
     sum_c = _seg(P_out, off_c, off_c + out_n)
@@ -189,4 +209,28 @@ def test_full_size_nucfreq_checksums():
     assert torch.equal(depth > 0, covered)
     # a position's four counters never exceed its depth
     assert bool(((c[:, 0] & 0x7FFFFFFF) + c[:, 1] + c[:, 2] + c[:, 3] <= depth).all())
+    eng.close()
+
+
+def test_full_size_break_paf_integrity():
+    """break-paf --max-size 100 on the same 1e6 records: every piece passes check_integrity, pieces of a record come in target order
+    and do not overlap, and no piece contains an insertion or deletion longer than the limit"""
+    C = _config3(is_break=True)
+    torch, dev, eng, run, n_rec, total_ops = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops"))
+    rows, out = run(rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN, 8 * n_rec, int(1.4 * total_ops))
+    n = rows.shape[0]
+    assert n > 2 * n_rec and int((rows[:, 0] == -286331154).sum()) == 0
+    st = rows[:, 2] & 0xFFFF
+    ok = st == 0
+    assert int((st >= 16).sum()) == 0 and int((~ok).sum()) < n // 10000   # a few pieces are None in the reference too (liftover.rs:52-102); nothing panics
+    rows = rows[ok]
+    words, off, out_n = _check_integrity(torch, dev, rows, out)
+    rec = rows[:, 0].to(torch.int64) & 0xFFFFFFFF
+    same = rec[1:] == rec[:-1]
+    assert bool((rec[1:] >= rec[:-1]).all())                                        # record order (main.rs:274-280)
+    assert bool((_u64(rows, 4)[1:][same] >= _u64(rows, 6)[:-1][same]).all())        # next piece starts at or after the previous one's end
+    # long indels: prefix count of (I or D with len > 100) over the output; none may fall inside a piece
+    big = (((words & 15) == 1) | ((words & 15) == 2)) & ((words >> 4) > 100)
+    P = torch.cumsum(big, 0, dtype=torch.int64)
+    assert int(_seg(P, off, off + out_n).sum()) == 0
     eng.close()
