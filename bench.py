@@ -62,7 +62,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # one real stream for torch's kernels AND the engine's (the default stream's
+    stream = torch.cuda.current_stream().cuda_stream  # handle is NULL, which rb_ctx_create reads as "make a private stream")
     eng = rustybam_amd.Engine(local_rank, stream)
 
     n_rec = args.records

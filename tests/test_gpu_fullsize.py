@@ -28,6 +28,7 @@ def _config3(is_break=False):
     import torch
     n_rec = int(os.environ.get("RB_FULLSIZE_RECORDS", "1000000"))
     dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # torch's kernels and the engine's on one real stream (a NULL handle would mean "private stream")
     eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
     seed = wl.SEED_CONFIG3
     w_c, w_st, w_en = wl.sliding_windows(3000)
@@ -162,6 +163,7 @@ def test_full_size_nucfreq_checksums():
     from bench_nucfreq import make_reads, N_EVENTS
     contig = int(os.environ.get("RB_FULLSIZE_CONTIG", "250000000"))
     dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))  # torch's kernels and the engine's on one real stream (a NULL handle would mean "private stream")
     eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
     pos, ops, op_off, n = make_reads(contig, 30, 15000)
     bpr = 7500
