@@ -105,3 +105,22 @@ def gather_counts(parts, pieces_per_shard, rg_st, rg_en):
             out[off[r] + (st - rg_st[r]):off[r] + (en - rg_st[r])] = counts[o:o + (en - st)]
             o += en - st
     return out
+
+
+# ---- trim-paf: the dependency unit is the query name (paf.rs:223, :235): whole groups per rank ----
+def shard_query_groups(q_names, weights, n_shards):
+    """Records -> shards by query name: names are sorted (the order trim-paf prints in, paf.rs:223), cut into n_shards contiguous
+    runs of whole groups with (nearly) equal total weight (ops).  Returns per shard the record indices in input order; running
+    trim-paf on each shard and concatenating the outputs in shard order gives the output of the whole file."""
+    names = np.asarray(q_names)
+    w = np.asarray(weights, dtype=np.float64)
+    uniq, inv = np.unique(names, return_inverse=True)           # sorted unique names; byte order = Rust's String order for ASCII
+    gw = np.bincount(inv, weights=w, minlength=len(uniq))
+    cum = np.cumsum(gw)
+    total = cum[-1] if len(cum) else 0.0
+    cuts = [0]
+    for s in range(1, n_shards):
+        cuts.append(int(np.searchsorted(cum, total * s / n_shards, side="left")))
+    cuts.append(len(uniq))
+    cuts = np.maximum.accumulate(np.minimum(cuts, len(uniq)))
+    return [np.flatnonzero((inv >= cuts[s]) & (inv < cuts[s + 1])) for s in range(n_shards)]

@@ -162,3 +162,26 @@ def test_two_rank_nucfreq_position_shards_match_single_process(oracle):
         cnt[p.astype(np.int64) - st, 0] |= 0x80000000
         want.append(cnt)
     assert np.array_equal(got, np.concatenate(want))
+
+
+def test_trim_paf_shards_by_query_group_concatenate_to_the_whole(oracle, golden, tmp_path):
+    """trim-paf partitions by query name: whole groups per rank, outputs concatenated in shard order.  The per-rank
+    compute stand-in is the oracle CLI; under test is shard_query_groups."""
+    from rustybam_amd import shard
+    lines = [l for l in open(os.path.join(golden, "asm_small.paf")).read().split("\n") if l]
+    q = [l.split("\t")[0] for l in lines]
+    w = [l.count("=") + l.count("X") + 1 for l in lines]           # ~ ops per record
+    rc, whole = oracle.cli("trim-paf", os.path.join(golden, "asm_small.paf"))
+    assert rc == 0 and whole.count(b"\n") > 100
+    for n_shards in (2, 3):
+        parts = shard.shard_query_groups(q, w, n_shards)
+        assert sorted(np.concatenate(parts).tolist()) == list(range(len(lines)))      # a partition of the records
+        assert len({q[i] for i in parts[0]} & {q[i] for i in parts[1]}) == 0           # no group is split
+        got = b""
+        for s, idx in enumerate(parts):
+            f = tmp_path / f"shard{n_shards}_{s}.paf"
+            f.write_text("\n".join(lines[i] for i in idx) + "\n")
+            rc, out = oracle.cli("trim-paf", str(f))
+            assert rc == 0
+            got += out
+        assert got == whole
