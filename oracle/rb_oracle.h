@@ -13,7 +13,7 @@
  *
  * PARITY PINNING.  The Rust reference cannot be built in this environment (no
  * cargo/rustc, un-vendored crates), so there is no oracle/_ref.  The oracle is pinned by
- * the reference's own known-answer tests (tests/golden/known_answers.json, KA1..KA12 of
+ * the reference's own known-answer tests (tests/golden/known_answers.json, KA1..KA13 of
  * SURVEY.md section 4) and cross-checked against the independent digests recorded in
  * SURVEY.md section 8c.  The following third-party behaviours have NO reference test and
  * are "parity unpinned":
@@ -24,7 +24,10 @@
  *   - bio 1.6.0 BED reader corner cases (ragged columns);
  *   - rayon par_bridge output order (we use the single-thread order);
  *   - rust-htslib CigarStringView::read_pos / end_pos / clip accessors behind `rb stats <bam>` (restated from
- *     the published algorithm; supported by asm_small.bam vs asm_small.paf: all 70 stats lines coincide).
+ *     the published algorithm; supported by asm_small.bam vs asm_small.paf: all 70 stats lines coincide);
+ *   - htslib's pileup behind `rb nucfreq` (rust-htslib 0.44.1 over hts-sys 2.2.0): bam_plp_push / bam_plp64_next /
+ *     resolve_cigar2 are restated literally and pinned by KA13 (nucfreq.rs:41-60) plus an independent read-major model
+ *     (tests/test_oracle_nucfreq.py); the depth cap (maxcnt 8000) and the outcome of htslib's assertions have no test.
  */
 #ifndef RB_ORACLE_H
 #define RB_ORACLE_H
