@@ -1027,23 +1027,21 @@ struct BamStream {
         buf.reset(new uint8_t[n + 1]);
         if (n) memcpy(buf.get(), all.data(), n);
     }
+    bool underflow = false; // a read ran past the loaded bytes
     bool exact(void *dst, size_t k) {
-        if (k > n - pos) return false;
+        if (k > n - pos) {
+            underflow = true;
+            return false;
+        }
         memcpy(dst, buf.get() + pos, k);
         pos += k;
         return true;
     }
-    bool inflate_bgzf(const std::string &path) {
-        TextBuf raw;
-        try {
-            raw = read_text(path, true);
-        } catch (const Panic &) {
-            return false;
-        }
-        const uint8_t *d = (const uint8_t *)raw.data();
-        const size_t sz = raw.size();
-        struct Member { size_t off, data, clen, out, isize; };
-        std::vector<Member> mem;
+    struct Member { size_t off, data, clen, out, isize; }; // file offset of the gzip member, of its deflate data; sizes; place in buf
+    std::vector<Member> mem;
+    // the members found in raw[0 .. sz) (file offset of raw[0] = base): walk the headers, inflate all of them on all host threads
+    bool inflate_members(const uint8_t *d, size_t sz, size_t base) {
+        mem.clear();
         size_t off = 0, out = 0;
         while (off < sz) {
             if (sz - off < 18 || d[off] != 0x1f || d[off + 1] != 0x8b || d[off + 2] != 8 || !(d[off + 3] & 4)) return false;
@@ -1057,12 +1055,12 @@ struct BamStream {
             }
             if (bsize < 12 + xlen + 8 || bsize > sz - off) return false;
             const size_t isize = le32(d + off + bsize - 4);
-            mem.push_back({off, off + 12 + xlen, bsize - xlen - 12 - 8, out, isize});
+            mem.push_back({base + off, off + 12 + xlen, bsize - xlen - 12 - 8, out, isize});
             out += isize;
             off += bsize;
         }
         buf.reset(new uint8_t[out + 1]);
-        n = out;
+        n = out, pos = 0;
         std::atomic<bool> ok{true};
         parallel_chunks(mem.size(), [&](unsigned, size_t lo, size_t hi) {
             z_stream zs;
@@ -1080,6 +1078,27 @@ struct BamStream {
             }
         });
         return ok;
+    }
+    bool inflate_bgzf(const std::string &path) {
+        TextBuf raw;
+        try {
+            raw = read_text(path, true);
+        } catch (const Panic &) {
+            return false;
+        }
+        return inflate_members((const uint8_t *)raw.data(), raw.size(), 0);
+    }
+    BamStream() = default;
+    // place in buf of a BGZF virtual offset (file offset of a member << 16 | offset inside its data); ~0 if the member is not loaded
+    size_t upos(uint64_t v) const {
+        const size_t c = (size_t)(v >> 16);
+        size_t lo = 0, hi = mem.size();
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (mem[mid].off < c) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= mem.size() || mem[lo].off != c) return ~(size_t)0;
+        return mem[lo].out + (size_t)(v & 0xFFFF);
     }
 };
 bool gz_exact(BamStream &f, void *buf, size_t n) { return f.exact(buf, n); }
@@ -1418,8 +1437,8 @@ struct BamReads { // every record of the file, in file order: the arrays of rb_r
 };
 uint64_t nf_key(int32_t tid, uint64_t p) { return ((uint64_t)(uint32_t)tid << 32) | std::min<uint64_t>(p, 0xFFFFFFFFull); }
 
-void load_bam_reads(const std::string &path, BamReads &B) {
-    BamStream f(path);
+// the BAM header: reference names and lengths
+static void bam_read_header(BamStream &f, const std::string &path, BamReads &B) {
     uint8_t h8[8] = {0}, b4[4] = {0};
     if (!gz_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw Panic(path + " is not a BAM file");
     std::vector<char> text(le32(h8 + 4) + 1);
@@ -1435,10 +1454,14 @@ void load_bam_reads(const std::string &path, BamReads &B) {
         gz_exact(f, b4, 4);
         B.ref_len[i] = le32(b4);
     }
+}
+// the records from the cursor up to (not including) the one that starts at or behind `stop`
+static void bam_read_records(BamStream &f, size_t stop, BamReads &B) {
     std::vector<uint8_t> rec;
-    B.op_off.push_back(0);
-    uint64_t run = 0;
-    while (gz_exact(f, b4, 4)) {
+    uint8_t b4[4] = {0};
+    if (B.op_off.empty()) B.op_off.push_back(0);
+    uint64_t run = B.end_key_pmax.empty() ? 0 : B.end_key_pmax.back();
+    while (f.pos < stop && gz_exact(f, b4, 4)) {
         const uint32_t bs = le32(b4);
         rec.resize(bs);
         if (!gz_exact(f, rec.data(), bs)) break;
@@ -1493,8 +1516,180 @@ void load_bam_reads(const std::string &path, BamReads &B) {
         B.end_key_pmax.push_back(run);
     }
 
+}
+static void bam_finish(BamReads &B) {
     B.ops.resize(B.ops.size() + 4, 0);
     B.seq.resize(B.seq.size() + 32, 0);
+}
+void load_bam_reads(const std::string &path, BamReads &B) {
+    BamStream f(path);
+    bam_read_header(f, path, B);
+    bam_read_records(f, ~(size_t)0, B);
+    bam_finish(B);
+}
+
+// ---- .bai: bins -> chunks of BGZF virtual offsets, and the 16 kb linear index (SAM spec 5.2) ----
+struct Bai {
+    struct Ref {
+        std::unordered_map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+        std::vector<uint64_t> ioffset;
+    };
+    std::vector<Ref> refs;
+    bool load(const std::string &path) {
+        FILE *fp = fopen(path.c_str(), "rb");
+        if (!fp) return false;
+        std::vector<uint8_t> d;
+        uint8_t tmp[1 << 16];
+        size_t r;
+        while ((r = fread(tmp, 1, sizeof tmp, fp)) > 0) d.insert(d.end(), tmp, tmp + r);
+        fclose(fp);
+        auto u64 = [&](size_t p) { return (uint64_t)le32(&d[p]) | ((uint64_t)le32(&d[p + 4]) << 32); };
+        if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return false;
+        const uint32_t n_ref = le32(&d[4]);
+        size_t p = 8;
+        refs.resize(n_ref);
+        for (uint32_t i = 0; i < n_ref; i++) {
+            if (p + 4 > d.size()) return false;
+            const uint32_t n_bin = le32(&d[p]);
+            p += 4;
+            for (uint32_t b = 0; b < n_bin; b++) {
+                if (p + 8 > d.size()) return false;
+                const uint32_t bin = le32(&d[p]), n_chunk = le32(&d[p + 4]);
+                p += 8;
+                if (p + 16 * (size_t)n_chunk > d.size()) return false;
+                auto &v = refs[i].bins[bin];
+                for (uint32_t c = 0; c < n_chunk; c++, p += 16) v.emplace_back(u64(p), u64(p + 8));
+            }
+            if (p + 4 > d.size()) return false;
+            const uint32_t n_intv = le32(&d[p]);
+            p += 4;
+            if (p + 8 * (size_t)n_intv > d.size()) return false;
+            refs[i].ioffset.resize(n_intv);
+            for (uint32_t k = 0; k < n_intv; k++, p += 8) refs[i].ioffset[k] = u64(p);
+        }
+        return true;
+    }
+    // a range of virtual offsets that holds every record overlapping [st, en) of tid (a superset); false = no such record
+    bool range(int32_t tid, uint64_t st, uint64_t en, uint64_t *vlo, uint64_t *vhi) const {
+        if (tid < 0 || (size_t)tid >= refs.size() || en <= st) return false;
+        const Ref &R = refs[tid];
+        if (en > (1ull << 29)) en = 1ull << 29; // the binning scheme of BAI ends at 512 Mbp
+        if (st >= en) return false;
+        uint64_t min_off = 0;
+        if (!R.ioffset.empty()) min_off = R.ioffset[std::min<size_t>((size_t)(st >> 14), R.ioffset.size() - 1)];
+        uint64_t lo = ~0ull, hi = 0;
+        const uint64_t e = en - 1;
+        auto visit = [&](uint32_t bin) {
+            auto it = R.bins.find(bin);
+            if (it == R.bins.end()) return;
+            for (const auto &c : it->second)
+                if (c.second > min_off) lo = std::min(lo, c.first), hi = std::max(hi, c.second);
+        };
+        visit(0); // reg2bins (SAM spec 5.3)
+        for (uint64_t k = 1 + (st >> 26); k <= 1 + (e >> 26); k++) visit((uint32_t)k);
+        for (uint64_t k = 9 + (st >> 23); k <= 9 + (e >> 23); k++) visit((uint32_t)k);
+        for (uint64_t k = 73 + (st >> 20); k <= 73 + (e >> 20); k++) visit((uint32_t)k);
+        for (uint64_t k = 585 + (st >> 17); k <= 585 + (e >> 17); k++) visit((uint32_t)k);
+        for (uint64_t k = 4681 + (st >> 14); k <= 4681 + (e >> 14); k++) visit((uint32_t)k);
+        if (hi <= lo) return false;
+        *vlo = lo, *vhi = hi;
+        return true;
+    }
+};
+
+// the member at file offset c and everything up to and including the member at file offset c_last, read and inflated
+static bool bgzf_load_range(int fd, size_t file_size, size_t c, size_t c_last, BamStream &f) {
+    if (c > c_last || c_last >= file_size) return false;
+    uint8_t hd[18];
+    if (pread(fd, hd, 18, (off_t)c_last) != 18 || hd[0] != 0x1f || hd[1] != 0x8b) return false;
+    const size_t xlen = (size_t)hd[10] | ((size_t)hd[11] << 8);
+    if (xlen != 6 || hd[12] != 'B' || hd[13] != 'C') return false; // (the layout every BGZF writer produces; anything else: full scan)
+    const size_t end = c_last + (((size_t)hd[16] | ((size_t)hd[17] << 8)) + 1);
+    if (end > file_size) return false;
+    std::unique_ptr<uint8_t[]> raw(new uint8_t[end - c]);
+    std::atomic<bool> ok{true};
+    parallel_chunks((end - c + (1u << 22) - 1) >> 22, [&](unsigned, size_t lo, size_t hi) {
+        size_t a = c + (lo << 22);
+        const size_t e = std::min(end, c + (hi << 22));
+        while (a < e) {
+            const ssize_t r = pread(fd, raw.get() + (a - c), e - a, (off_t)a);
+            if (r <= 0) {
+                ok = false;
+                return;
+            }
+            a += (size_t)r;
+        }
+    });
+    return ok && f.inflate_members(raw.get(), end - c, c);
+}
+
+// load only what the regions need, through <bam>.bai.  false = no usable index (the caller reads the whole file)
+static bool load_bam_reads_indexed(const std::string &path, const std::vector<Region> &rgns, BamReads &B) {
+    if (path == "-" || getenv("RB_NO_BAI")) return false;
+    Bai bai;
+    if (!bai.load(path + ".bai")) return false;
+    const int fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    struct Close {
+        int fd;
+        ~Close() { close(fd); }
+    } closer{fd};
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return false;
+    const size_t file_size = (size_t)st.st_size;
+    // the header: members from the start of the file, more of them until it parses
+    BamReads H;
+    {
+        bool got = false;
+        for (size_t want = 1u << 20; !got; want *= 4) {
+            // last member that starts inside the first `want` bytes
+            size_t off = 0, last = 0;
+            uint8_t hd[18];
+            while (off < std::min(want, file_size)) {
+                if (pread(fd, hd, 18, (off_t)off) != 18 || hd[0] != 0x1f || hd[1] != 0x8b || hd[12] != 'B' || hd[13] != 'C') return false;
+                last = off;
+                off += ((size_t)hd[16] | ((size_t)hd[17] << 8)) + 1;
+            }
+            BamStream f;
+            if (!bgzf_load_range(fd, file_size, 0, last, f)) return false;
+            H = BamReads();
+            try {
+                bam_read_header(f, path, H);
+            } catch (const Panic &) {
+                return false;
+            }
+            if (!f.underflow) got = true;
+            else if (want >= file_size) return false;
+        }
+    }
+    if (bai.refs.size() != H.ref_nm.size()) return false;
+    // virtual-offset ranges of all regions, merged where their members touch
+    std::vector<std::pair<uint64_t, uint64_t>> rg;
+    for (const Region &R : rgns) {
+        int32_t tid = -1;
+        for (size_t k = 0; k < H.ref_nm.size(); k++)
+            if (H.ref_nm[k] == R.name) { tid = (int32_t)k; break; }
+        if (tid < 0) continue; // (the panic for it comes when its turn to print comes)
+        uint64_t lo, hi;
+        if (bai.range(tid, R.st, std::min<uint64_t>(R.en, H.ref_len[tid]), &lo, &hi)) rg.emplace_back(lo, hi);
+    }
+    std::sort(rg.begin(), rg.end());
+    B.ref_nm = H.ref_nm, B.ref_len = H.ref_len;
+    for (size_t i = 0; i < rg.size();) {
+        uint64_t lo = rg[i].first, hi = rg[i].second;
+        size_t j = i + 1;
+        while (j < rg.size() && (rg[j].first >> 16) <= (hi >> 16)) hi = std::max(hi, rg[j].second), j++; // same or overlapping members
+        BamStream f;
+        if (!bgzf_load_range(fd, file_size, (size_t)(lo >> 16), (size_t)(hi >> 16), f)) return false;
+        const size_t a = f.upos(lo), e = f.upos(hi);
+        if (a == ~(size_t)0 || e == ~(size_t)0 || a > e || e > f.n) return false;
+        f.pos = a;
+        bam_read_records(f, e, B);
+        i = j;
+    }
+    if (B.op_off.empty()) B.op_off.push_back(0);
+    bam_finish(B);
+    return true;
 }
 
 void put_u64(std::string &o, uint64_t v) {
@@ -1509,7 +1704,10 @@ void nucfreq_bam(Engine &eng, const std::string &bam_path, const std::vector<Reg
                  const std::function<void(const std::string &)> &put) {
     double tl = now_s();
     BamReads B;
-    load_bam_reads(bam_path, B);
+    if (!load_bam_reads_indexed(bam_path, rgns, B)) {
+        B = BamReads();
+        load_bam_reads(bam_path, B);
+    }
     lap("nucfreq: inflate + decode BAM", tl);
     const uint64_t n_all = B.tid.size();
     for (uint64_t i = 1; i < n_all; i++) // the pileup iterator refuses unsorted input ("the input is not sorted"), p.unwrap() panics

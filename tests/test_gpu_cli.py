@@ -341,3 +341,24 @@ def test_nucfreq_many_bed_regions_share_device_calls(oracle, golden, tmp_path):
         orc, oout = oracle.cli(*a)
         assert (rc, orc) == (0, 0)
         assert out == oout and out.count(b"\n") > 1000
+
+
+def test_nucfreq_bai_index_and_full_scan_agree(oracle, golden, tmp_path):
+    """with <bam>.bai next to the file only the BGZF members the regions need are inflated; without it (RB_NO_BAI) the whole file is.
+    Same text either way, and the oracle's (which always scans)"""
+    import subprocess
+    rc, st = rb("stats", f"{golden}/asm_small.bam")
+    recs = [l.split(b"\t") for l in st.splitlines()[1:]]
+    bed = tmp_path / "r.bed"
+    bed.write_text("".join(f"{f[0].decode()}\t{max(int(f[1]) - 50, 0)}\t{int(f[1]) + 400}\n" for f in recs[::9]) +
+                   "".join(f"{f[0].decode()}\t{int(f[2]) - 300}\t{int(f[2]) + 50}\n" for f in recs[4::11]))
+    for args in (["--bed", str(bed)], ["-r", f"{recs[0][0].decode()}:{int(recs[0][1]) + 1}-{int(recs[0][1]) + 70000}", "-s"],
+                 ["-r", "chr1:1-1000"]):
+        a = ["nucfreq", *args, f"{golden}/asm_small.bam"]
+        rc, out = rb(*a)
+        env = dict(os.environ, RB_NO_BAI="1")
+        full = subprocess.run([RB, *a], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env)
+        orc, oout = oracle.cli(*a)
+        assert rc == 0 and full.returncode == 0 and orc == 0
+        assert out == full.stdout == oout
+    assert os.path.exists(f"{golden}/asm_small.bam.bai")
