@@ -56,6 +56,7 @@ __device__ __forceinline__ uint32_t rb_op_code_of(uint32_t c) {
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
+    __shared__ uint32_t stage_all[FILL ? 4 : 1][FILL ? 512 + 64 : 1]; // fill pass: the ops of one step per wave (+ a scrap word per lane)
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const uint64_t r = (uint64_t)blockIdx.x * 4u + wib;
     if (r >= p.n_rec) return;
@@ -132,33 +133,40 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
         const uint32_t incl = rb_wave_scan_incl(cnt);
         const uint32_t step_total = rb_readlane<uint32_t>(incl, 63);
         if (FILL) {
-            uint64_t o = out_base + (incl - cnt);
+            // the ops of this step go through LDS: every lane drops its (at most 8) ops at their rank -- absent slots go to a
+            // scrap word, so there is no branch per slot -- and the wave then writes the step's ops out side by side
+            uint32_t *stg = stage_all[wib];
+            uint32_t rank = incl - cnt;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                if (sinfo[j] & 0x1000000u) {
-                    uint32_t l = slen[j];
-                    if (sinfo[j] & 0x20000u) { // the first op of the chunk: incoming digits are more significant
-                        const uint32_t ind = in_nd & 0xFFu;
-                        const uint32_t tnd = ind + lead_nd;
-                        uint64_t full = l;
-                        if (ind && in_val != 0u) { // (incoming zeros change nothing)
-                            if (lead_nd >= 10u) {
-                                full = ~0ull; // a non-zero value followed by ten more digits is past u32::MAX
-                            } else {
-                                uint64_t pw = 1;
-                                for (uint32_t e = 0; e < lead_nd; e++) pw *= 10u;
-                                full = (uint64_t)in_val * pw + l; // < 2^32 * 10^9
-                            }
+                const bool present = (sinfo[j] & 0x1000000u) != 0u;
+                uint32_t l = slen[j];
+                if (sinfo[j] & 0x20000u) { // the first op of the chunk: incoming digits are more significant
+                    const uint32_t ind = in_nd & 0xFFu;
+                    const uint32_t tnd = ind + lead_nd;
+                    uint64_t full = l;
+                    if (ind && in_val != 0u) { // (incoming zeros change nothing)
+                        if (lead_nd >= 10u) {
+                            full = ~0ull; // a non-zero value followed by ten more digits is past u32::MAX
+                        } else {
+                            uint64_t pw = 1;
+                            for (uint32_t e = 0; e < lead_nd; e++) pw *= 10u;
+                            full = (uint64_t)in_val * pw + l; // < 2^32 * 10^9
                         }
-                        if ((in_nd & 0x100u) || (sinfo[j] & 0x10000u)) full = ~0ull;
-                        if (tnd == 0u || full > 0xFFFFFFFFull) err = (err == 0 || err == RB_TEXT_TOO_LONG) ? RB_TEXT_BAD : err;
-                        else if (full >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;
-                        l = (uint32_t)full;
                     }
-                    if (o < p.ops_cap) p.ops[o] = (l << 4) | (sinfo[j] & 15u);
-                    o++;
+                    if ((in_nd & 0x100u) || (sinfo[j] & 0x10000u)) full = ~0ull;
+                    if (tnd == 0u || full > 0xFFFFFFFFull) err = (err == 0 || err == RB_TEXT_TOO_LONG) ? RB_TEXT_BAD : err;
+                    else if (full >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;
+                    l = (uint32_t)full;
                 }
+                stg[present ? rank : 512u + (uint32_t)lane] = (l << 4) | (sinfo[j] & 15u);
+                rank += present ? 1u : 0u;
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t k = (uint32_t)lane; k < step_total; k += 64u)
+                if (out_base + k < p.ops_cap) p.ops[out_base + k] = stg[k];
+            __builtin_amdgcn_wave_barrier();
             out_base += step_total;
         }
         total += step_total;
