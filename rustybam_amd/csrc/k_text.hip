@@ -54,6 +54,8 @@ __device__ __forceinline__ uint32_t rb_op_code_of(uint32_t c) {
     return (o < 32u && nib != 15u) ? nib : 255u;
 }
 
+__device__ __constant__ uint64_t rb_pow10[10] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull};
+
 template <bool FILL>
 __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
     __shared__ uint32_t stage_all[FILL ? 4 : 1][FILL ? 512 + 64 : 1]; // fill pass: the ops of one step per wave (+ a scrap word per lane)
@@ -137,28 +139,31 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
             // scrap word, so there is no branch per slot -- and the wave then writes the step's ops out side by side
             uint32_t *stg = stage_all[wib];
             uint32_t rank = incl - cnt;
+            // the first op of the chunk (at most one per lane) takes the digits that came in from the lanes before: done once, outside
+            // the slot loop, so that the loop has no branch
+            uint32_t l_first = 0, first_ovf = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const bool f = (sinfo[j] & 0x20000u) != 0u;
+                l_first = f ? slen[j] : l_first;
+                first_ovf = f ? (sinfo[j] & 0x10000u) : first_ovf;
+            }
+            uint32_t fixed_first = l_first;
+            if (seen) {
+                const uint32_t ind = in_nd & 0xFFu;
+                const uint32_t tnd = ind + lead_nd;
+                uint64_t full = l_first;
+                if (ind && in_val != 0u) // (incoming zeros change nothing; a non-zero value followed by ten more digits is past u32::MAX)
+                    full = lead_nd >= 10u ? ~0ull : (uint64_t)in_val * rb_pow10[lead_nd] + l_first; // < 2^32 * 10^9
+                if ((in_nd & 0x100u) || first_ovf) full = ~0ull;
+                if (tnd == 0u || full > 0xFFFFFFFFull) err = (err == 0 || err == RB_TEXT_TOO_LONG) ? RB_TEXT_BAD : err;
+                else if (full >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;
+                fixed_first = (uint32_t)full;
+            }
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const bool present = (sinfo[j] & 0x1000000u) != 0u;
-                uint32_t l = slen[j];
-                if (sinfo[j] & 0x20000u) { // the first op of the chunk: incoming digits are more significant
-                    const uint32_t ind = in_nd & 0xFFu;
-                    const uint32_t tnd = ind + lead_nd;
-                    uint64_t full = l;
-                    if (ind && in_val != 0u) { // (incoming zeros change nothing)
-                        if (lead_nd >= 10u) {
-                            full = ~0ull; // a non-zero value followed by ten more digits is past u32::MAX
-                        } else {
-                            uint64_t pw = 1;
-                            for (uint32_t e = 0; e < lead_nd; e++) pw *= 10u;
-                            full = (uint64_t)in_val * pw + l; // < 2^32 * 10^9
-                        }
-                    }
-                    if ((in_nd & 0x100u) || (sinfo[j] & 0x10000u)) full = ~0ull;
-                    if (tnd == 0u || full > 0xFFFFFFFFull) err = (err == 0 || err == RB_TEXT_TOO_LONG) ? RB_TEXT_BAD : err;
-                    else if (full >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;
-                    l = (uint32_t)full;
-                }
+                const uint32_t l = (sinfo[j] & 0x20000u) ? fixed_first : slen[j];
                 stg[present ? rank : 512u + (uint32_t)lane] = (l << 4) | (sinfo[j] & 15u);
                 rank += present ? 1u : 0u;
             }
