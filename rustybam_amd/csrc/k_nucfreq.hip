@@ -6,8 +6,8 @@
 // unless the position falls in a D / N op.  Positions no read covers are not reported.
 //
 // Here the loop is turned inside out (partition by position range, not by read):
-//   rb_k_nf_read_spans  wave per read: reference span of the CIGAR, the pileup's flag filter, the cases where htslib
-//                       asserts, sortedness of (tid, pos); writes each read's end and a key (tid << 32 | end)
+//   rb_k_nf_read_spans  lane per read (the whole wave on a long cigar): reference span of the CIGAR, the pileup's flag filter, the
+//                       cases where htslib asserts, sortedness of (tid, pos); writes each read's record and a key (tid << 32 | end)
 //   rb_k_nf_pmax_*      inclusive prefix MAXIMUM of the end keys in file order: the first read that can reach a position
 //                       is then one binary search away (reads are sorted by start, not by end)
 //   rb_k_nf_plan_tiles  thread per tile of NF_TILE positions: its region, and the range of reads that can overlap it
@@ -32,6 +32,7 @@
 #endif
 #define NF_PER_THREAD (NF_TILE / NF_THREADS) // positions per thread in the depth scan
 #define NF_WAVES (NF_THREADS / 64)
+#define NF_LANE_OPS 4u // reads with at most this many ops are walked by one lane each where a tile is crowded
 #define NF_PLP_MASK (0x4u | 0x100u | 0x200u | 0x400u) // htslib BAM_DEF_MASK: UNMAP | SECONDARY | QCFAIL | DUP
 
 struct rb_nf_params {
@@ -74,48 +75,60 @@ __device__ __forceinline__ uint64_t nf_key(int32_t tid, uint64_t pos32) { return
 
 // ---- per-read spans ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void rb_k_nf_read_spans(rb_nf_params p) {
-    const uint64_t i = (uint64_t)blockIdx.x * 4u + rb_first(threadIdx.x >> 6);
-    if (i >= p.n_reads) return;
+    // a wave takes 64 consecutive reads, one per lane (coalesced loads of the per-read arrays); a lane walks a short cigar itself,
+    // the reads with longer ones are then done one after the other by the whole wave
+    const uint64_t i = ((uint64_t)blockIdx.x * 4u + rb_first(threadIdx.x >> 6)) * 64u + (uint64_t)rb_lane();
     const int lane = rb_lane();
-    const int32_t tid = p.tid[i];
-    const int64_t pos = p.pos[i];
-    const uint32_t flag = p.flag[i];
-    const uint64_t o0 = p.op_off[i], o1 = p.op_off[i + 1];
+    const bool in = i < p.n_reads;
+    const int32_t tid = in ? p.tid[i] : -1;
+    const int64_t pos = in ? p.pos[i] : 0;
+    const uint32_t flag = in ? p.flag[i] : 0u;
+    const uint64_t o0 = in ? p.op_off[i] : 0, o1 = in ? p.op_off[i + 1] : 0;
     const bool filtered = tid < 0 || (flag & NF_PLP_MASK) != 0; // bam_plp_push: tid < 0 or a masked flag never enters the pileup
     uint64_t ref = 0;
     uint32_t bad = 0, any_ref = 0;
-    for (uint64_t o = o0 + (uint64_t)lane; o < o1; o += 64) {
-        const uint32_t w = p.ops[o], c = rb_opc(w), l = rb_len(w);
+    auto one_op = [](uint32_t w, uint64_t &r, uint32_t &b, uint32_t &a) {
+        const uint32_t c = rb_opc(w), l = rb_len(w);
         if (rb_in(RB_REF_MASK, c)) {
-            ref += l;
-            any_ref = 1;
-            if (l == 0) bad = 1; // (resolve_cigar2 steps one op per position: a zero-length M / D / N / = / X is not walked the way it reads)
+            r += l;
+            a = 1;
+            if (l == 0) b = 1; // (resolve_cigar2 steps one op per position: a zero-length M / D / N / = / X is not walked the way it reads)
         }
-        if (c > 8u) bad = 1;
+        if (c > 8u) b = 1;
+    };
+    const bool short_cigar = in && o1 - o0 <= 8u;
+    if (short_cigar)
+        for (uint64_t o = o0; o < o1; o++) one_op(p.ops[o], ref, bad, any_ref);
+    uint64_t cm = __ballot(in && !short_cigar);
+    while (cm) {
+        const int l = __builtin_ctzll(cm);
+        cm &= cm - 1;
+        const uint64_t a0 = rb_readlane<uint64_t>(o0, l), a1 = rb_readlane<uint64_t>(o1, l);
+        uint64_t r = 0;
+        uint32_t b = 0, a = 0;
+        for (uint64_t o = a0 + (uint64_t)lane; o < a1; o += 64) one_op(p.ops[o], r, b, a);
+        r = rb_wave_sum_u64(r), b = rb_wave_or_u32(b), a = rb_wave_or_u32(a);
+        if (lane == l) ref = r, bad = b, any_ref = a;
     }
-    ref = rb_wave_sum_u64(ref);
-    bad = rb_wave_or_u32(bad);
-    any_ref = rb_wave_or_u32(any_ref);
+    if (!in) return;
     // the cases in which htslib's cursor runs into an assertion (or off the cigar): no op at all, no reference-consuming op, a lone
     // op that is not M / = / X; plus what the 32-bit arithmetic of the tile kernel cannot hold
     if (o1 == o0 || !any_ref) bad = 1;
     if (o1 - o0 == 1 && !rb_in(RB_MATCH_MASK, rb_opc(p.ops[o0]))) bad = 1;
     if (pos < 0 || pos > 0x7FFFFFFFll || ref > 0x7FFFFFFFull || o1 - o0 > 0x7FFFFFFFull) bad = 1;
     const uint32_t status = filtered ? RB_RD_FILTERED : (bad ? RB_RD_BAD_CIGAR : RB_RD_OK);
-    if (lane == 0) {
-        uint64_t end = (uint64_t)pos + ref;
-        if (end > 0xFFFFFFFFull) end = 0xFFFFFFFFull;
-        p.read_status[i] = status;
-        nf_read h;
-        h.pos = (uint32_t)pos, h.end = status == RB_RD_OK ? (uint32_t)end : 0u;
-        h.tid = tid, h.l_seq = p.l_seq[i];
-        h.op_off = o0, h.n_ops = (uint32_t)(o1 - o0 < 0xFFFFFFFFull ? o1 - o0 : 0xFFFFFFFFull), h.pad0 = 0;
-        h.nib0 = 2ull * p.seq_off[i], h.pad1 = 0;
-        p.hd[i] = h;
-        p.end_key[i] = status == RB_RD_OK ? nf_key(tid, end) : 0ull;
-        if (status == RB_RD_BAD_CIGAR) atomicAdd((unsigned long long *)&p.counters->n_bad, 1ull);
-        if (i > 0 && nf_key(tid, (uint64_t)pos) < nf_key(p.tid[i - 1], (uint64_t)p.pos[i - 1])) p.counters->unsorted = 1;
-    }
+    uint64_t end = (uint64_t)pos + ref;
+    if (end > 0xFFFFFFFFull) end = 0xFFFFFFFFull;
+    p.read_status[i] = status;
+    nf_read h;
+    h.pos = (uint32_t)pos, h.end = status == RB_RD_OK ? (uint32_t)end : 0u;
+    h.tid = tid, h.l_seq = p.l_seq[i];
+    h.op_off = o0, h.n_ops = (uint32_t)(o1 - o0 < 0xFFFFFFFFull ? o1 - o0 : 0xFFFFFFFFull), h.pad0 = 0;
+    h.nib0 = 2ull * p.seq_off[i], h.pad1 = 0;
+    p.hd[i] = h;
+    p.end_key[i] = status == RB_RD_OK ? nf_key(tid, end) : 0ull;
+    if (status == RB_RD_BAD_CIGAR) atomicAdd((unsigned long long *)&p.counters->n_bad, 1ull);
+    if (i > 0 && nf_key(tid, (uint64_t)pos) < nf_key(p.tid[i - 1], (uint64_t)p.pos[i - 1])) p.counters->unsorted = 1;
 }
 
 // ---- inclusive prefix maximum (u64), three launches ----------------------------------------------------------------------
@@ -271,27 +284,11 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     const uint64_t lo = p.tile_lo[t], hi = p.tile_hi[t];
     const uint32_t *__restrict__ sw32 = reinterpret_cast<const uint32_t *>(p.seq);
     uint32_t *stage = stage_all[wib] + 4;
-    // the wave's reads, one after the other.  Two loads run ahead of the work: the record of the read after next, and the first 64
-    // ops of the next read (whose record arrived one turn earlier) -- a read then starts with its ops in registers instead of
-    // waiting for three dependent trips to memory
-    nf_read h_cur, h_nxt;
-    h_cur.end = 0, h_nxt.end = 0, h_cur.n_ops = 0, h_nxt.n_ops = 0, h_cur.op_off = 0, h_nxt.op_off = 0;
-    uint32_t w_cur = RB_NULL_OP;
-    if (lo + wib < hi) h_cur = p.hd[lo + wib];
-    if (lo + wib + NF_WAVES < hi) h_nxt = p.hd[lo + wib + NF_WAVES];
-    if ((uint32_t)lane < h_cur.n_ops) w_cur = p.ops[h_cur.op_off + (uint32_t)lane];
-    for (uint64_t i = lo + wib; i < hi; i += NF_WAVES) {
-        nf_read h_nn;
-        h_nn.end = 0, h_nn.n_ops = 0, h_nn.op_off = 0;
-        if (i + 2 * NF_WAVES < hi) h_nn = p.hd[i + 2 * NF_WAVES];
-        uint32_t w_nxt = RB_NULL_OP;
-        if ((uint32_t)lane < h_nxt.n_ops) w_nxt = p.ops[h_nxt.op_off + (uint32_t)lane];
-        const nf_read h = h_cur;
-        const uint32_t w_first = w_cur;
-        h_cur = h_nxt, h_nxt = h_nn, w_cur = w_nxt;
+    // one read, the whole wave on it (w_first: its first 64 ops, already in registers)
+    auto read_by_wave = [&](const nf_read &h, uint32_t w_first, uint64_t i) {
         const int64_t pos = h.pos;
         const uint64_t rend = h.end;
-        if (h.tid != T.tid || (uint64_t)pos >= T.en || rend <= T.st) continue; // hts_itr_next: pos < en && endpos > st (end = 0: not in the pileup)
+        if (h.tid != T.tid || (uint64_t)pos >= T.en || rend <= T.st) return; // hts_itr_next: pos < en && endpos > st (end = 0: not in the pileup)
         const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = rend < T.en ? rend : T.en;
         if (lane == 0) {
             atomicAdd(&diff[(uint32_t)(c0 - T.st)], 1);
@@ -392,6 +389,81 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
             if ((int64_t)R >= rel_en) break;
         }
         if (__ballot(seq_short) != 0 && lane == 0) p.read_status[i] = RB_RD_SEQ_SHORT;
+    };
+    if (hi - lo > 8u * 64u) {
+        // ---- a tile crowded with reads (short reads): 64 reads per wave and turn, one lane per read with at most NF_LANE_OPS ops
+        //      -- it walks its ops and drops its bases one by one; the wave scans would idle on 150-base reads -- and the few
+        //      reads with longer cigars one after the other with the whole wave ----
+        for (uint64_t g = lo + 64u * wib; g < hi; g += 64u * NF_WAVES) {
+            const uint64_t i = g + (uint64_t)lane;
+            nf_read h;
+            h.end = 0, h.n_ops = 0, h.op_off = 0, h.pos = 0, h.tid = -1, h.l_seq = 0, h.nib0 = 0;
+            if (i < hi) h = p.hd[i];
+            const bool overl = h.tid == T.tid && (uint64_t)h.pos < T.en && (uint64_t)h.end > T.st;
+            const bool simple = overl && h.n_ops <= NF_LANE_OPS;
+            uint64_t cm = __ballot(overl && !simple);
+            if (simple) {
+                const int64_t pos = h.pos;
+                const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = (uint64_t)h.end < T.en ? (uint64_t)h.end : T.en;
+                atomicAdd(&diff[(uint32_t)(c0 - T.st)], 1);
+                atomicAdd(&diff[(uint32_t)(c1 - T.st)], -1);
+                const int64_t rel_st = (int64_t)T.st - pos, rel_en = (int64_t)T.en - pos, idx0 = pos - (int64_t)T.st;
+                const uint8_t *__restrict__ sq = p.seq;
+                int64_t R = 0, Q = 0;
+                bool seq_short = false;
+                for (uint32_t j = 0; j < h.n_ops; j++) {
+                    const uint32_t w = p.ops[h.op_off + j], c = rb_opc(w);
+                    const int64_t len = rb_len(w);
+                    if (rb_in(RB_MATCH_MASK, c)) {
+                        const int64_t a = R > rel_st ? R : rel_st, e = R + len < rel_en ? R + len : rel_en;
+                        for (int64_t x = a; x < e; x++) {
+                            const int64_t q = Q + (x - R); // bam_pileup1_t::qpos
+                            if (q >= (int64_t)h.l_seq) {   // record().seq()[qpos] is out of bounds: the reference panics
+                                seq_short = true;
+                                break;
+                            }
+                            const uint64_t nb = h.nib0 + (uint64_t)q;
+                            const uint32_t nib = ((uint32_t)sq[nb >> 1] >> ((~nb & 1u) << 2)) & 15u;
+                            atomicAdd(&cnt[nf_slot((uint32_t)(idx0 + x)) + __builtin_amdgcn_ubfe(0x110u, nib, 1u)], lut[nib]);
+                        }
+                    }
+                    if (rb_in(RB_REF_MASK, c)) R += len;
+                    if (rb_in(RB_QRY_MASK, c)) Q += len;
+                }
+                if (seq_short) p.read_status[i] = RB_RD_SEQ_SHORT;
+            }
+            while (cm) {
+                const int l = __builtin_ctzll(cm);
+                cm &= cm - 1;
+                nf_read hh;
+                hh.pos = rb_readlane<uint32_t>(h.pos, l), hh.end = rb_readlane<uint32_t>(h.end, l), hh.tid = rb_readlane<int>(h.tid, l);
+                hh.l_seq = rb_readlane<uint32_t>(h.l_seq, l), hh.n_ops = rb_readlane<uint32_t>(h.n_ops, l);
+                hh.op_off = rb_readlane<uint64_t>(h.op_off, l), hh.nib0 = rb_readlane<uint64_t>(h.nib0, l);
+                const uint32_t wf = (uint32_t)lane < hh.n_ops ? p.ops[hh.op_off + (uint32_t)lane] : RB_NULL_OP;
+                read_by_wave(hh, wf, g + (uint64_t)l);
+            }
+        }
+    } else {
+        // ---- the wave's reads, one after the other.  Two loads run ahead of the work: the record of the read after next, and the
+        //      first 64 ops of the next read (whose record arrived one turn earlier) -- a read then starts with its ops in registers
+        //      instead of waiting for three dependent trips to memory ----
+        nf_read h_cur, h_nxt;
+        h_cur.end = 0, h_nxt.end = 0, h_cur.n_ops = 0, h_nxt.n_ops = 0, h_cur.op_off = 0, h_nxt.op_off = 0;
+        uint32_t w_cur = RB_NULL_OP;
+        if (lo + wib < hi) h_cur = p.hd[lo + wib];
+        if (lo + wib + NF_WAVES < hi) h_nxt = p.hd[lo + wib + NF_WAVES];
+        if ((uint32_t)lane < h_cur.n_ops) w_cur = p.ops[h_cur.op_off + (uint32_t)lane];
+        for (uint64_t i = lo + wib; i < hi; i += NF_WAVES) {
+            nf_read h_nn;
+            h_nn.end = 0, h_nn.n_ops = 0, h_nn.op_off = 0;
+            if (i + 2 * NF_WAVES < hi) h_nn = p.hd[i + 2 * NF_WAVES];
+            uint32_t w_nxt = RB_NULL_OP;
+            if ((uint32_t)lane < h_nxt.n_ops) w_nxt = p.ops[h_nxt.op_off + (uint32_t)lane];
+            const nf_read h = h_cur;
+            const uint32_t w_first = w_cur;
+            h_cur = h_nxt, h_nxt = h_nn, w_cur = w_nxt;
+            read_by_wave(h, w_first, i);
+        }
     }
     __syncthreads();
     // depth = prefix sum of the difference array: NF_PER_THREAD positions per thread
@@ -442,7 +514,7 @@ extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t
 extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stream) {
     const rb_nf_params p = *pp;
     if (p.n_reads) {
-        hipLaunchKernelGGL(rb_k_nf_read_spans, dim3((unsigned)((p.n_reads + 3) / 4)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(rb_k_nf_read_spans, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, stream, p);
         const uint64_t nb = rb_nf_scan_blocks(p.n_reads);
         hipLaunchKernelGGL(rb_k_nf_pmax_partial, dim3((unsigned)nb), dim3(256), 0, stream, p.end_key, p.n_reads, p.blk);
         hipLaunchKernelGGL(rb_k_nf_pmax_top, dim3(1), dim3(64), 0, stream, p.blk, nb);

@@ -30,6 +30,10 @@ def oracle():
 @pytest.fixture(scope="session")
 def engine():
     """The product library on cuda:0.  No fallback: a missing library or device is a test ERROR."""
+    # torch first: it brings its own copy of the HIP runtime, and whichever copy is loaded first serves the whole process.  With
+    # librustybam_amd.so (linked against /opt/rocm) loaded first, a later torch.cuda initialisation in the same process finds no
+    # device (tests/test_gpu_fullsize.py uses torch for device memory and segment sums).
+    import torch  # noqa: F401
     import rustybam_amd
     eng = rustybam_amd.Engine(0)
     yield eng
