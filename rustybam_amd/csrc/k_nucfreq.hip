@@ -408,7 +408,6 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
                 atomicAdd(&diff[(uint32_t)(c0 - T.st)], 1);
                 atomicAdd(&diff[(uint32_t)(c1 - T.st)], -1);
                 const int64_t rel_st = (int64_t)T.st - pos, rel_en = (int64_t)T.en - pos, idx0 = pos - (int64_t)T.st;
-                const uint8_t *__restrict__ sq = p.seq;
                 int64_t R = 0, Q = 0;
                 bool seq_short = false;
                 for (uint32_t j = 0; j < h.n_ops; j++) {
@@ -416,15 +415,19 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
                     const int64_t len = rb_len(w);
                     if (rb_in(RB_MATCH_MASK, c)) {
                         const int64_t a = R > rel_st ? R : rel_st, e = R + len < rel_en ? R + len : rel_en;
-                        for (int64_t x = a; x < e; x++) {
-                            const int64_t q = Q + (x - R); // bam_pileup1_t::qpos
-                            if (q >= (int64_t)h.l_seq) {   // record().seq()[qpos] is out of bounds: the reference panics
-                                seq_short = true;
-                                break;
-                            }
-                            const uint64_t nb = h.nib0 + (uint64_t)q;
-                            const uint32_t nib = ((uint32_t)sq[nb >> 1] >> ((~nb & 1u) << 2)) & 15u;
+                        int64_t e2 = e;
+                        if (Q + (e - R) > (int64_t)h.l_seq) { // record().seq()[qpos] would be out of bounds: the reference panics
+                            seq_short = true;
+                            e2 = R + ((int64_t)h.l_seq - Q);
+                        }
+                        // eight bases per load: the aligned dword that holds the base, nibbles swapped into base order
+                        uint64_t nb = h.nib0 + (uint64_t)(Q + (a - R)); // 4-bit index of the base at x = a (bam_pileup1_t::qpos + the read's start)
+                        uint32_t word = a < e2 ? nf_swap_nibbles(sw32[nb >> 3]) >> ((uint32_t)(nb & 7u) * 4u) : 0u;
+                        for (int64_t x = a; x < e2; x++) {
+                            const uint32_t nib = word & 15u;
                             atomicAdd(&cnt[nf_slot((uint32_t)(idx0 + x)) + __builtin_amdgcn_ubfe(0x110u, nib, 1u)], lut[nib]);
+                            nb++;
+                            word = (nb & 7u) ? word >> 4 : (x + 1 < e2 ? nf_swap_nibbles(sw32[nb >> 3]) : 0u);
                         }
                     }
                     if (rb_in(RB_REF_MASK, c)) R += len;

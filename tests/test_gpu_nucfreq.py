@@ -109,3 +109,30 @@ def test_long_insertions_inside_a_tile(engine, oracle):
         poss.append(100 + 37 * k)
     rd = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, seqs)
     check_regions(engine, oracle, rd, [(0, 0, 1200), (0, 300, 301), (0, 0, 5000)])
+
+
+def test_crowded_tile_lane_per_read_path(engine, oracle):
+    """more than 512 reads over one tile: the tile kernel gives every read of at most four ops to one lane.  All op kinds that
+    fit four ops, both routes mixed (some reads have longer cigars), and the sequence-too-short flag of that route"""
+    rng = np.random.default_rng(21)
+    M, I, D, N, S, EQ, X = 0, 1, 2, 3, 4, 7, 8
+    shapes = [[(40, M)], [(10, EQ), (1, X), (12, EQ)], [(5, M), (2, D), (7, M)], [(3, S), (9, M), (1, I), (6, M)], [(4, M), (30, N), (5, M)],
+              [(3, M), (1, I), (3, M), (1, D), (3, M), (2, I), (4, M)]]          # the last one has 7 ops: whole-wave route
+    cigs, seqs, poss = [], [], []
+    for k in range(900):
+        c = [(l << 4) | o for l, o in shapes[int(rng.integers(0, len(shapes)))]]
+        q = sum(w >> 4 for w in c if (w & 15) in (0, 1, 4, 7, 8))
+        cigs.append(c)
+        seqs.append(rng.choice([1, 2, 4, 8, 15, 3], size=q).tolist())
+        poss.append(int(rng.integers(100, 1500)))
+    order = np.argsort(poss, kind="stable")
+    rd = Reads([0] * 900, [poss[i] for i in order], [0] * 900, [cigs[i] for i in order], [seqs[i] for i in order])
+    counts, status, ctr = check_regions(engine, oracle, rd, [(0, 0, 2000), (0, 700, 701), (0, 4000, 4100)])
+    assert ctr["max_depth"] > 5 and (status == 0).all()
+    # the same reads, a few of them with fewer bases than their cigar consumes
+    short = set(rng.choice(900, size=12, replace=False).tolist())
+    sorted_seqs = [seqs[i] for i in order]
+    seqs2 = [s[:max(len(s) - 3, 0)] if i in short else s for i, s in enumerate(sorted_seqs)]
+    rd2 = Reads([0] * 900, [poss[i] for i in order], [0] * 900, [cigs[i] for i in order], seqs2)
+    counts, status, ctr = engine.nucfreq(*rd2.args(), [0], [0], [2000])
+    assert set(np.flatnonzero(status == rustybam_amd.RD_SEQ_SHORT).tolist()) == short
