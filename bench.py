@@ -5,9 +5,17 @@ One "step" = one full liftover pass of the hot path over one resident batch: hit
 the streaming clip kernel, the generic kernel and the summary kernel, through the C ABI
 (rb_dev_liftover), inputs already in HBM.  Per GPU: 1e6 synthetic PAF records (n_ops uniform
 [1000, 9000], ~5e9 CIGAR ops, 20 GB packed) placed uniformly on a chr1-sized target x 3000 windows
-(st = i * 82,796, width 100 kb).  N > 1: every rank owns its own record range (weak scaling, records
-shard by contiguous range, no data-path collective; torch.distributed only carries the barrier and
-the max-over-ranks time).
+(st = i * 82,796, width 100 kb).
+
+N > 1 (`--gpus N`): one process per GPU.  Under torch.distributed.run (WORLD_SIZE set) the ranks are
+the launcher's; otherwise this script starts them itself, as fresh child processes, BEFORE anything
+here touches the GPU.  Records shard by contiguous range, no data-path collective; torch.distributed
+(RCCL) only carries the barrier, the max-over-ranks time and the verification digests.
+  --scaling weak   (default) every rank owns its own 1e6 records: rank r = records [r * 1e6, (r + 1) * 1e6)
+  --scaling strong the one 1e6-record batch of configs[2] is cut into N op-balanced record ranges
+                   (rustybam_amd.shard.shard_bounds): "records sharded 1 -> 8 GPUs"
+`output_digest` is an order-sensitive digest of every hit row and clipped CIGAR of the whole job in
+canonical (gathered) order; with --scaling strong it must be the same for N = 1, 2, 4, 8.
 
 Prints ONE JSON line on rank 0: metric CIGAR-ops/s (whole job), plus `roofline` for the streaming
 kernel (HIP events on the launch stream) and `cpu_baseline` (the oracle, a faithful per-base port of
@@ -42,32 +50,90 @@ def parse():
                     help="liftover (headline) or break-paf --max-size 100 on the same records (secondary measurement)")
     ap.add_argument("--descriptors", action="store_true",
                     help="RB_LIFT_DESCRIPTORS: return which ops each clip keeps instead of copying them (not the headline mode)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --records per GPU; strong: --records in all, cut into one op-balanced record range per GPU")
+    ap.add_argument("--launch-dry-run", action="store_true", help=argparse.SUPPRESS)  # tests: ranks report their environment and exit
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU) and wait for them.
+    Nothing in this process has touched the GPU (no torch, no HIP): a process that has must never fork + exec."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                try:
+                    code = p.wait(timeout=0.2)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:  # one rank failed: the others would wait in a barrier forever
+                    rc = code
+                    for q in pending:
+                        q.terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-    import rustybam_amd
-    from rustybam_amd import workload as wl
-
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))  # (before torch / HIP are even imported)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_dry_run:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "addr": os.environ.get("MASTER_ADDR"),
+                          "port": os.environ.get("MASTER_PORT"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
+        return
+    import torch
+    import torch.distributed as dist
+    import rustybam_amd
+    from rustybam_amd import shard
+    from rustybam_amd import workload as wl
+
     use_dist = world > 1 or os.environ.get("RB_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL path on one GPU
     if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_stream(torch.cuda.Stream(dev))  # one real stream for torch's kernels AND the engine's (the default stream's
     stream = torch.cuda.current_stream().cuda_stream  # handle is NULL, which rb_ctx_create reads as "make a private stream")
     eng = rustybam_amd.Engine(local_rank, stream)
 
-    n_rec = args.records
-    first = rank * n_rec
+    if args.scaling == "strong":  # one batch of --records, one op-balanced contiguous record range per rank
+        seed_ = wl.SEED_CONFIG3 if args.workload == "config3" else wl.SEED_CONFIG2
+        bounds = shard.shard_bounds(wl.op_offsets(wl.n_ops(seed_, 0, args.records)), world)
+        first, n_rec = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+    else:
+        n_rec = args.records
+        first = rank * n_rec
     if args.workload == "config3":
         seed, placement = wl.SEED_CONFIG3, "uniform"
         w_c, w_st, w_en = wl.sliding_windows(args.windows)
@@ -184,6 +250,28 @@ def main():
 
     # ---- post-run facts for the roofline (rank 0's shard) ----
     cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
+    # ---- digest of the whole job's output in gathered (canonical) order: every rank digests its rows with the number of rows /
+    #      records of the ranks before it as bases; the sum is what one GPU holding all records would get (verification only,
+    #      outside the timed region; the data path itself has no collective) ----
+    mask64 = (1 << 64) - 1
+    if use_dist:
+        g = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([n_hits, n_rec], dtype=torch.int64, device=dev))
+        per_rank = [[int(x) for x in t.tolist()] for t in g]
+    else:
+        per_rank = [[n_hits, n_rec]]
+    row_base = sum(h for h, _ in per_rank[:rank])
+    d_dig = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    eng.dev_digest_rows(view, d_rows.data_ptr(), n_hits, d_out.data_ptr(), row_base, first, d_dig.data_ptr())
+    torch.cuda.synchronize()
+    if use_dist:
+        g = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(g, d_dig)
+        digest = sum(int(t.item()) & mask64 for t in g) & mask64
+    else:
+        digest = int(d_dig.item()) & mask64
+    job_hits = sum(h for h, _ in per_rank)
     if args.debug_skip & 32:  # diagnostics: per-phase shader-clock sums of the clip kernel (last step, every 16th record)
         ph = [int(x) * 16 * 16 for x in cnt["_pad"]]
         names = ["job+windows", "stream+resolve", "verdict+finalize", "reservation", "rows+end groups", "interior copy", "-"]
@@ -230,15 +318,17 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": f"BASELINE.json {args.workload}: {n_rec} records/GPU (uniform 1000-9000 ops, "
                                f"{total_ops} ops on rank 0) x {len(w_st)} windows, seed {seed:#x}",
-                   "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world}",
+                   "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
+                                   + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops"},
         "paf_records_per_s": job_recs * args.steps / elapsed,
+        "output_digest": f"{digest:#018x}", "job_records": int(job_recs), "job_hits": job_hits,
         "hits_per_gpu": n_hits, "ok_hits_per_gpu": n_ok, "out_ops_per_gpu": n_out_ops,
         "generic_hits_per_gpu": int(cnt["n_generic"]),
         "roofline": roofline,

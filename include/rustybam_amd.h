@@ -377,6 +377,16 @@ int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t n_regions, 
 int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t n_regions, const int32_t *rg_tid, const uint64_t *rg_st,
                     const uint64_t *rg_en, uint32_t *counts, uint32_t *read_status, rb_nucfreq_counters *counters);
 
+/* ---- verification aid (tests, bench; not a reference function): digest of hit rows and their clipped CIGARs ---------------
+ * *digest += sum over i < n_rows of mix(row i) * (2 * (row_base + i) + 1), wrapping u64 (the caller zeroes *digest).  mix covers
+ * rec + rec_base, win, status and -- for RB_ST_OK rows -- the INSIDE flag, out_n, the coordinates, nmatch, aln_len and every op of
+ * the clip in order.  It does NOT cover out_off, nor how the clip is stored: a descriptor row (RB_HIT_DESCRIPTOR) is expanded
+ * through batch->ops / batch->op_off.  Two runs that produce the same records in the same order have the same digest wherever
+ * the ops were placed, and the digests of contiguous record-range shards add up to the digest of the whole batch when each shard
+ * passes the rows / records that precede it as row_base / rec_base (the 1/2/4/8-GPU determinism check of bench.py). */
+int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const rb_hit_row *rows, uint64_t n_rows, const uint32_t *out_ops,
+                       uint64_t row_base, uint64_t rec_base, uint64_t *digest);
+
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and
  * device versions produce identical bytes.  n_ops per record comes from rb_synth_n_ops. */

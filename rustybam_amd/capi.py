@@ -149,6 +149,10 @@ class Engine:
         self._chk(self.L.rb_dev_scan_records(self.ctx, C.byref(view), C.c_void_p(reduce_ptr or 0),
                                              C.c_void_p(norm_ptr or 0)), "rb_dev_scan_records")
 
+    def dev_digest_rows(self, view, rows_ptr, n_rows, out_ptr, row_base, rec_base, digest_ptr):
+        self._chk(self.L.rb_dev_digest_rows(self.ctx, C.byref(view), C.c_void_p(rows_ptr), C.c_uint64(n_rows), C.c_void_p(out_ptr),
+                                            C.c_uint64(row_base), C.c_uint64(rec_base), C.c_void_p(digest_ptr)), "rb_dev_digest_rows")
+
     def plan_create(self, op_off, contig, w_contig=None, w_st=None, w_en=None):
         op_off, contig = _arr(op_off, np.uint64), _arr(contig, np.uint32)
         nw = 0 if w_st is None else len(w_st)

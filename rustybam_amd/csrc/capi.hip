@@ -1256,6 +1256,33 @@ extern "C" int rb_dev_synth_fill_ops(rb_ctx *ctx, uint64_t seed, uint64_t first_
     return RB_OK;
 }
 
+// ---- verification aid: digest of rows + clipped cigars ----------------------------------------------
+struct rb_digest_params {
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const rb_hit_row *rows;
+    uint64_t n_rows;
+    const uint32_t *out_ops;
+    uint64_t row_base, rec_base;
+    unsigned long long *digest;
+};
+extern "C" hipError_t rb_launch_digest_rows(const rb_digest_params *p, hipStream_t stream);
+extern "C" int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const rb_hit_row *rows, uint64_t n_rows, const uint32_t *out_ops,
+                                  uint64_t row_base, uint64_t rec_base, uint64_t *digest) {
+    if (!ctx || !batch || !digest || (n_rows && (!rows || !out_ops))) return RB_E_INVALID;
+    rb_digest_params p;
+    p.ops = batch->ops;
+    p.op_off = batch->op_off;
+    p.rows = rows;
+    p.n_rows = n_rows;
+    p.out_ops = out_ops;
+    p.row_base = row_base;
+    p.rec_base = rec_base;
+    p.digest = (unsigned long long *)digest;
+    HIPCHK(ctx, rb_launch_digest_rows(&p, ctx->stream));
+    return RB_OK;
+}
+
 // ---- nucfreq ----------------------------------------------------------------------------------------------------------
 namespace {
 struct nf_layout {

@@ -260,3 +260,83 @@ extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint
     hipLaunchKernelGGL(rb_k_synth, dim3((unsigned)((n_rec + 3) / 4)), dim3(256), 0, stream, seed, first_record, n_rec, op_off, ops);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// verification aid: order-sensitive digest of hit rows and the clipped CIGARs they point at
+// (include/rustybam_amd.h, rb_dev_digest_rows).  One wavefront per row.
+// ------------------------------------------------------------------------------------------------
+struct rb_digest_params {
+    const uint32_t *ops;     // the batch's packed ops (descriptor rows are expanded through them)
+    const uint64_t *op_off;
+    const rb_hit_row *rows;
+    uint64_t n_rows;
+    const uint32_t *out_ops;
+    uint64_t row_base, rec_base;
+    unsigned long long *digest;
+};
+__global__ __launch_bounds__(256) void rb_k_digest_rows(rb_digest_params p) {
+    __shared__ unsigned long long part[4];
+    const uint32_t wib = threadIdx.x >> 6;
+    const uint64_t i = (uint64_t)blockIdx.x * 4u + wib;
+    const int lane = rb_lane();
+    unsigned long long contrib = 0;
+    if (i < p.n_rows) {
+        const rb_hit_row h = p.rows[i];
+        const bool ok = h.status == RB_ST_OK;
+        uint64_t hops = 0;
+        if (ok) {
+            const bool desc = (h.flags & RB_HIT_DESCRIPTOR) != 0;
+            const uint32_t n = h.out_n;
+            const uint32_t *src = p.out_ops + h.out_off;
+            uint32_t fl = 0, ll = 0;
+            if (desc) { // {first kept op in the record's original cigar, op count, first length, last length}
+                const uint32_t first = src[0];
+                fl = src[2], ll = src[3];
+                src = p.ops + p.op_off[h.rec] + first;
+            }
+            for (uint32_t k = (uint32_t)lane; k < n; k += 64u) {
+                uint32_t w = src[k];
+                if (desc) {
+                    const uint32_t len0 = rb_len(w);
+                    uint32_t len = len0;
+                    if (n == 1u && fl && ll) len = fl + ll - len0;
+                    else {
+                        if (k == 0 && fl) len = fl;
+                        if (k == n - 1u && ll) len = ll;
+                    }
+                    w = (len << 4) | rb_opc(w);
+                }
+                hops += rb_splitmix64(((uint64_t)k << 32) | w);
+            }
+            hops = rb_wave_sum_u64(hops);
+        }
+        if (lane == 0) {
+            uint64_t x = rb_splitmix64((uint64_t)h.rec + p.rec_base);
+            x = rb_splitmix64(x ^ h.win);
+            x = rb_splitmix64(x ^ (uint64_t)h.status);
+            if (ok) {
+                x = rb_splitmix64(x ^ ((h.flags & RB_HIT_INSIDE) ? 1ull : 0ull));
+                x = rb_splitmix64(x ^ h.out_n);
+                x = rb_splitmix64(x ^ h.t_st);
+                x = rb_splitmix64(x ^ h.t_en);
+                x = rb_splitmix64(x ^ h.q_st);
+                x = rb_splitmix64(x ^ h.q_en);
+                x = rb_splitmix64(x ^ h.nmatch);
+                x = rb_splitmix64(x ^ h.aln_len);
+                x = rb_splitmix64(x ^ hops);
+            }
+            contrib = x * (2ull * (p.row_base + i) + 1ull);
+        }
+    }
+    if (lane == 0) part[wib] = contrib;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long s = part[0] + part[1] + part[2] + part[3];
+        if (s) atomicAdd(p.digest, s);
+    }
+}
+extern "C" hipError_t rb_launch_digest_rows(const rb_digest_params *p, hipStream_t stream) {
+    if (p->n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_digest_rows, dim3((unsigned)((p->n_rows + 3) / 4)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}

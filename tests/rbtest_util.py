@@ -198,3 +198,34 @@ def compare_hits(g_rows, g_ops, o_rows, o_ops, what=""):
         a = g_ops[int(g_rows["out_off"][i]):int(g_rows["out_off"][i]) + int(g_rows["out_n"][i])]
         b = o_ops[int(o_rows["out_off"][i]):int(o_rows["out_off"][i]) + int(o_rows["out_n"][i])]
         assert np.array_equal(a, b), f"{what}: cigar differs at row {i} (rec {o_rows['rec'][i]} win {o_rows['win'][i]}): gpu {unpack(a[:12])}.. oracle {unpack(b[:12])}.."
+
+
+# ------------------------------------------------------------------ numpy twin of rb_dev_digest_rows
+def _sm64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def digest_rows(rows, ops, row_base=0, rec_base=0):
+    """The digest include/rustybam_amd.h defines for rb_dev_digest_rows, over rows whose clips are copied ops in `ops`
+    (oracle output, or GPU output in copied-ops mode)."""
+    total = 0
+    with np.errstate(over="ignore"):
+        for i, h in enumerate(rows):
+            x = _sm64(np.uint64(int(h["rec"]) + rec_base))
+            x = _sm64(x ^ np.uint64(h["win"]))
+            x = _sm64(x ^ np.uint64(h["status"]))
+            if int(h["status"]) == 0:
+                n, off = int(h["out_n"]), int(h["out_off"])
+                w = ops[off:off + n].astype(np.uint64)
+                hops = int(_sm64((np.arange(n, dtype=np.uint64) << np.uint64(32)) | w).sum(dtype=np.uint64)) if n else 0
+                x = _sm64(x ^ np.uint64(int(h["flags"]) & 1))
+                for k in ("out_n", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len"):
+                    x = _sm64(x ^ np.uint64(h[k]))
+                x = _sm64(x ^ np.uint64(hops))
+            total = (total + int(x) * (2 * (row_base + i) + 1)) & ((1 << 64) - 1)
+    return total

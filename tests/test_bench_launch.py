@@ -1,0 +1,36 @@
+"""bench.py --gpus N without a launcher starts N ranks itself, as fresh child processes, before anything touches the GPU
+(VERDICT r01 item 1).  The dry-run flag makes every rank report its environment and leave, so this runs without a GPU."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=120)
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    r = _run(["--gpus", "3", "--launch-dry-run"])
+    assert r.returncode == 0, r.stderr
+    ranks = sorted((json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")), key=lambda d: d["rank"])
+    assert [d["rank"] for d in ranks] == [0, 1, 2] and [d["local_rank"] for d in ranks] == [0, 1, 2]
+    assert all(d["world"] == 3 and d["addr"] == "127.0.0.1" and d["ipc_legacy"] == "0" for d in ranks)
+    assert len({d["port"] for d in ranks}) == 1
+
+
+def test_launcher_world_size_is_taken_as_is_and_must_match():
+    r = _run(["--gpus", "2", "--launch-dry-run"], {"WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1"})
+    assert r.returncode == 0 and json.loads(r.stdout)["rank"] == 1      # under torch.distributed.run: no second spawn
+    r = _run(["--gpus", "8", "--launch-dry-run"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_a_failing_rank_fails_the_job():
+    r = _run(["--gpus", "2", "--records", "1000", "--steps", "1", "--warmup", "0"],
+             {"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})   # no GPU: every rank exits non-zero
+    assert r.returncode != 0

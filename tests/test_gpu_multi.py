@@ -1,0 +1,40 @@
+"""bench.py as the driver runs it, on a small batch: `--gpus N` starts N ranks, `--scaling strong` cuts one batch into N record
+ranges, and the digest of the gathered output is the same for every N ("1/2/4/8-GPU outputs byte-identical to each
+other").  With one visible GPU the N = 2 leg is skipped and the RCCL path is exercised with a world of one."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--records", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--scaling", "strong"]
+
+
+def _bench(gpus, extra_env=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus)] + ARGS, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints the one JSON line
+    return json.loads(lines[0])
+
+
+def test_strong_scaling_digest_is_the_same_for_every_gpu_count():
+    import torch
+    one = _bench(1)
+    assert one["n_gpus"] == 1 and one["scaling"] == "strong" and one["job_records"] == 20000 and one["job_hits"] > 200000
+    forced = _bench(1, {"RB_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1",
+                        "LOCAL_RANK": "0"})   # the RCCL init / barrier / gather path with a world of one
+    assert forced["output_digest"] == one["output_digest"]
+    n_dev = torch.cuda.device_count()
+    for n in (2, 4, 8):
+        if n > n_dev:
+            break
+        many = _bench(n)
+        assert many["n_gpus"] == n and many["job_records"] == 20000
+        assert many["job_hits"] == one["job_hits"] and many["output_digest"] == one["output_digest"]
