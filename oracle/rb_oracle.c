@@ -1692,19 +1692,35 @@ int rbo_bam_stats(const char *path, int qbed, FILE *out) {
     int rc = 0;
     uint8_t *rec = NULL;
     size_t cap = 0;
-    while (bam_read_exact(f, b4, 4)) {
+    for (;;) {
+        /* htslib bam_read1 (sam.c): 0 bytes where a record would start = end of file; a file that ends inside the length field
+         * or inside the record, a block_size < 32, or name + cigar + sequence that do not fit the block are read errors, and the
+         * reference's rec.unwrap() (main.rs:72) panics -- after the records before it have been printed */
+        int got = gzread(f, b4, 4);
+        if (got == 0) break;
+        if (got != 4) {
+            rc = -RBO_PANIC_NOTFOUND;
+            break;
+        }
         uint32_t bs = rd_u32(b4);
         if (bs > cap) {
-            cap = bs * 2;
+            cap = (size_t)bs * 2;
             rec = (uint8_t *)xrealloc(rec, cap);
         }
-        if (!bam_read_exact(f, rec, bs)) break;
+        if (!bam_read_exact(f, rec, bs) || bs < 32) {
+            rc = -RBO_PANIC_NOTFOUND;
+            break;
+        }
         int32_t refID = (int32_t)rd_u32(rec);
         int64_t pos = (int32_t)rd_u32(rec + 4);
         uint32_t l_rn = rec[8];
         uint32_t n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
         uint32_t flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8);
         uint32_t l_seq = rd_u32(rec + 16);
+        if (32ull + l_rn + 4ull * n_cig + ((uint64_t)l_seq + 1) / 2 + l_seq > bs || l_rn == 0 || rec[32 + l_rn - 1] != 0) {
+            rc = -RBO_PANIC_NOTFOUND;
+            break;
+        }
         if (flag & 4) continue; /* main.rs:73 */
         const char *qname = (const char *)(rec + 32);
         const uint8_t *cg_raw = rec + 32 + l_rn;

@@ -1352,6 +1352,7 @@ extern "C" int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t
     rb_reads_view d{};
     d.n_reads = n;
     int rc;
+    std::vector<uint64_t> opo, sqo; // (function scope: the asynchronous uploads below read them until the stream is synchronised)
     if (n) {
         // only the part of ops / seq these reads use goes up, offsets rebased
         const uint64_t op0 = reads->op_off[0], op1 = reads->op_off[n];
@@ -1360,7 +1361,7 @@ extern "C" int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t
             const uint64_t a = reads->seq_off[i], e = a + ((uint64_t)reads->l_seq[i] + 1) / 2;
             s0 = std::min(s0, a), s1 = std::max(s1, e);
         }
-        std::vector<uint64_t> opo(n + 1), sqo(n);
+        opo.resize(n + 1), sqo.resize(n);
         for (uint64_t i = 0; i <= n; i++) opo[i] = reads->op_off[i] - op0;
         for (uint64_t i = 0; i < n; i++) sqo[i] = reads->seq_off[i] - s0;
         if ((rc = b.up(reads->ops + op0, (size_t)(op1 - op0), &d.ops))) return rc;

@@ -707,7 +707,15 @@ struct TextFile {
                     HeaderOnly h;
                     const int rc = paf_header_new(all.data(), lines[i].first, lines[i].second, h);
                     if (rc == 0) part[t].push_back(h);
-                    else if (rc == 1) skipped[t].push_back(i);
+                    else if (rc == 1) {
+                        // PafRecord::new parses the tags before the columns (paf.rs:387-399): a malformed cg:Z: value panics there
+                        // ("Unable to parse cigar string.") before a bad numeric column can make from_file skip the line
+                        if (h.cg_n) {
+                            std::vector<uint32_t> cig;
+                            parse_cigar(all.data() + h.cg, h.cg_n, cig);
+                        }
+                        skipped[t].push_back(i);
+                    }
                     else general[t] = 1;
                 }
             } catch (const Panic &e) {
@@ -1102,45 +1110,103 @@ struct BamStream {
     }
 };
 bool gz_exact(BamStream &f, void *buf, size_t n) { return f.exact(buf, n); }
+// a header field that must be there: a file that ends inside its header is an error in htslib, a panic in the reference
+void bam_need(BamStream &f, void *buf, size_t n, const std::string &path) {
+    if (!f.exact(buf, n)) throw Panic("truncated BAM header in " + path);
+}
+// the fixed part of one BAM record and the places of its variable parts, with the bounds htslib's bam_read1 enforces
+// (block_size >= 32; l_read_name + 4 n_cigar + (l_seq + 1) / 2 + l_seq <= block_size - 32; sam.c): a record that breaks them is a
+// read error there and a panic at the reference's rec.unwrap() (main.rs:72)
+struct BamCore {
+    int32_t tid;
+    int64_t pos;
+    uint32_t l_rn, n_cig, flag, l_seq;
+    const uint8_t *cg, *sq;
+    size_t aux0;
+};
+BamCore bam_core(const uint8_t *rec, size_t bs) {
+    if (bs < 32) throw Panic("invalid BAM record: block_size < 32");
+    BamCore c;
+    c.tid = (int32_t)le32(rec);
+    c.pos = (int32_t)le32(rec + 4);
+    c.l_rn = rec[8];
+    c.n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
+    c.flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8);
+    c.l_seq = le32(rec + 16);
+    const uint64_t need = 32ull + c.l_rn + 4ull * c.n_cig + ((uint64_t)c.l_seq + 1) / 2 + c.l_seq;
+    if (need > bs) throw Panic("invalid BAM record: name, cigar and sequence do not fit the block");
+    if (c.l_rn == 0 || rec[32 + c.l_rn - 1] != 0) throw Panic("invalid BAM record: read name is not NUL-terminated");
+    c.cg = rec + 32 + c.l_rn;
+    c.sq = c.cg + 4 * (size_t)c.n_cig;
+    c.aux0 = (size_t)need;
+    return c;
+}
+// the next record's bytes; false at a clean end of file; a file that ends inside a record is a panic (htslib: truncated file)
+bool bam_next(BamStream &f, std::vector<uint8_t> &rec) {
+    uint8_t b4[4];
+    if (f.pos == f.n) return false;
+    if (!f.exact(b4, 4)) throw Panic("truncated BAM file (inside a block_size field)");
+    const uint32_t bs = le32(b4);
+    if (bs > f.n - f.pos) throw Panic("truncated BAM file (inside a record)");
+    rec.resize(bs);
+    f.exact(rec.data(), bs);
+    return true;
+}
 } // namespace
 
-std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path) {
+std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path, std::string *trailing_panic) {
     BamStream f(path);
     uint8_t h8[8] = {0}, b4[4] = {0};
     if (!gz_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw Panic(path + " is not a BAM file");
-    std::vector<char> text(le32(h8 + 4) + 1);
-    gz_exact(f, text.data(), text.size() - 1);
-    gz_exact(f, b4, 4);
+    if (le32(h8 + 4) > f.n - f.pos) throw Panic("truncated BAM header in " + path); // (sizes are checked before they size anything)
+    f.pos += le32(h8 + 4);                                                           // the SAM text is not used
+    bam_need(f, b4, 4, path);
     const uint32_t n_ref = le32(b4);
+    if ((uint64_t)n_ref * 8 > f.n - f.pos) throw Panic("truncated BAM header in " + path);
     std::vector<std::string> ref_nm(n_ref);
     std::vector<uint32_t> ref_len(n_ref);
     for (uint32_t i = 0; i < n_ref; i++) {
-        gz_exact(f, b4, 4);
+        bam_need(f, b4, 4, path);
+        if (le32(b4) > f.n - f.pos) throw Panic("truncated BAM header in " + path);
         std::vector<char> nm(le32(b4) + 1, 0);
-        gz_exact(f, nm.data(), nm.size() - 1);
+        bam_need(f, nm.data(), nm.size() - 1, path);
         ref_nm[i] = nm.data();
-        gz_exact(f, b4, 4);
+        bam_need(f, b4, 4, path);
         ref_len[i] = le32(b4);
     }
     // decode every mapped record; cigars go straight into one packed array (BAM's encoding IS the ABI's)
     std::vector<BamRec> recs;
     std::vector<uint32_t> ops;
     std::vector<uint8_t> rec;
-    while (gz_exact(f, b4, 4)) {
-        const uint32_t bs = le32(b4);
-        rec.resize(bs);
-        if (!gz_exact(f, rec.data(), bs)) break;
+    // The reference prints record by record (main.rs:71-76): what was decoded before a broken record, and the stats of the
+    // records before one whose read_pos panics, are printed before the panic.  The first such panic is kept in *trailing_panic
+    // (or thrown right away when the caller does not ask for it) and the records before it are returned.
+    std::string pending;
+    while (pending.empty()) {
+        try {
+            if (!bam_next(f, rec)) break;
+        } catch (const Panic &e) {
+            pending = e.what();
+            break;
+        }
+        const size_t bs = rec.size();
+        BamCore core;
+        try {
+            core = bam_core(rec.data(), bs);
+        } catch (const Panic &e) {
+            pending = e.what();
+            break;
+        }
         BamRec r;
-        r.ref_id = (int32_t)le32(rec.data());
-        r.pos = (int32_t)le32(rec.data() + 4);
-        const uint32_t l_rn = rec[8];
-        uint32_t n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
-        r.flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8);
-        r.l_seq = le32(rec.data() + 16);
+        r.ref_id = core.tid;
+        r.pos = core.pos;
+        uint32_t n_cig = core.n_cig;
+        r.flag = core.flag;
+        r.l_seq = core.l_seq;
         if (r.flag & 4) continue; // main.rs:73 is_unmapped
         r.qname = (const char *)(rec.data() + 32);
-        const uint8_t *cg = rec.data() + 32 + l_rn;
-        const size_t aux0 = 32 + l_rn + 4 * (size_t)n_cig + (r.l_seq + 1) / 2 + r.l_seq;
+        const uint8_t *cg = core.cg;
+        const size_t aux0 = core.aux0;
         const uint8_t *cg_tag = nullptr;
         uint32_t cg_n = 0;
         for (size_t p = aux0; p + 3 <= bs;) { // aux fields: MD:Z and the CG:B,I long-cigar convention
@@ -1163,6 +1229,7 @@ std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path) {
                 const char sub = (char)rec[p];
                 const uint32_t cnt = le32(rec.data() + p + 1);
                 const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+                if (p + 5 + es * (uint64_t)cnt > bs) break; // (an array that runs past the record: the aux walk stops, as htslib's does)
                 if (tag[0] == 'C' && tag[1] == 'G' && sub == 'I') {
                     cg_tag = rec.data() + p + 5;
                     cg_n = cnt;
@@ -1192,8 +1259,7 @@ std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path) {
                                    red.data(), nullptr),
               "rb_host_scan_records");
     std::vector<Stats> out(n);
-    bool warned = false;
-    for (size_t i = 0; i < n; i++) {
+    for (size_t i = 0; i < n; i++) try {
         const BamRec &r = recs[i];
         const uint32_t *cg = ops.data() + r.cig0;
         const size_t nc = r.ncig;
@@ -1257,10 +1323,17 @@ std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &path) {
             s.id_by_all = num / (float)(uint32_t)(s.equal + s.diff + s.del + s.ins);
             s.id_by_events = num / (float)(uint32_t)(s.equal + s.diff + s.del_events + s.ins_events);
             s.id_by_matches = num / (float)(uint32_t)(s.equal + s.diff);
-        } else if (s.matches > 0 && !r.has_md && !warned) { // bamstats.rs:145-153
+        } else if (s.matches > 0 && !r.has_md) { // bamstats.rs:145-153 (once per such record, like the reference)
             fprintf(stderr, "\r⚠ warning: cigar string contains 'M', assuming mismatch since there is no MD tag.");
-            warned = true;
         }
+    } catch (const Panic &e) { // the reference has printed the records before this one (main.rs:71-76)
+        out.resize(i);
+        pending = e.what();
+        break;
+    }
+    if (!pending.empty()) {
+        if (!trailing_panic) throw Panic(pending);
+        *trailing_panic = pending;
     }
     return out;
 }
@@ -1441,40 +1514,39 @@ uint64_t nf_key(int32_t tid, uint64_t p) { return ((uint64_t)(uint32_t)tid << 32
 static void bam_read_header(BamStream &f, const std::string &path, BamReads &B) {
     uint8_t h8[8] = {0}, b4[4] = {0};
     if (!gz_exact(f, h8, 8) || memcmp(h8, "BAM\1", 4) != 0) throw Panic(path + " is not a BAM file");
-    std::vector<char> text(le32(h8 + 4) + 1);
-    gz_exact(f, text.data(), text.size() - 1);
-    gz_exact(f, b4, 4);
+    if (le32(h8 + 4) > f.n - f.pos) throw Panic("truncated BAM header in " + path); // (sizes are checked before they size anything)
+    f.pos += le32(h8 + 4);                                                           // the SAM text is not used
+    bam_need(f, b4, 4, path);
     const uint32_t n_ref = le32(b4);
+    if ((uint64_t)n_ref * 8 > f.n - f.pos) throw Panic("truncated BAM header in " + path);
     B.ref_nm.resize(n_ref), B.ref_len.resize(n_ref);
     for (uint32_t i = 0; i < n_ref; i++) {
-        gz_exact(f, b4, 4);
+        bam_need(f, b4, 4, path);
+        if (le32(b4) > f.n - f.pos) throw Panic("truncated BAM header in " + path);
         std::vector<char> nm(le32(b4) + 1, 0);
-        gz_exact(f, nm.data(), nm.size() - 1);
+        bam_need(f, nm.data(), nm.size() - 1, path);
         B.ref_nm[i] = nm.data();
-        gz_exact(f, b4, 4);
+        bam_need(f, b4, 4, path);
         B.ref_len[i] = le32(b4);
     }
 }
 // the records from the cursor up to (not including) the one that starts at or behind `stop`
 static void bam_read_records(BamStream &f, size_t stop, BamReads &B) {
     std::vector<uint8_t> rec;
-    uint8_t b4[4] = {0};
     if (B.op_off.empty()) B.op_off.push_back(0);
     uint64_t run = B.end_key_pmax.empty() ? 0 : B.end_key_pmax.back();
-    while (f.pos < stop && gz_exact(f, b4, 4)) {
-        const uint32_t bs = le32(b4);
-        rec.resize(bs);
-        if (!gz_exact(f, rec.data(), bs)) break;
-        const int32_t tid = (int32_t)le32(rec.data());
-        const int64_t pos = (int32_t)le32(rec.data() + 4);
-        const uint32_t l_rn = rec[8];
-        uint32_t n_cig = (uint32_t)rec[12] | ((uint32_t)rec[13] << 8);
-        const uint32_t flag = (uint32_t)rec[14] | ((uint32_t)rec[15] << 8), l_seq = le32(rec.data() + 16);
-        const uint8_t *cg = rec.data() + 32 + l_rn;
-        const uint8_t *sq = cg + 4 * (size_t)n_cig;
+    while (f.pos < stop && bam_next(f, rec)) {
+        const size_t bs = rec.size();
+        const BamCore core = bam_core(rec.data(), bs);
+        const int32_t tid = core.tid;
+        const int64_t pos = core.pos;
+        uint32_t n_cig = core.n_cig;
+        const uint32_t flag = core.flag, l_seq = core.l_seq;
+        const uint8_t *cg = core.cg;
+        const uint8_t *sq = core.sq;
         // htslib resolves the CG:B,I long-cigar convention while reading (bam_tag2cigar): <l_seq>S<ref_len>N + CG tag
         if (n_cig >= 1 && (le32(cg) & 15u) == RB_OP_S && (le32(cg) >> 4) == l_seq) {
-            const size_t aux0 = 32 + l_rn + 4 * (size_t)n_cig + (l_seq + 1) / 2 + l_seq;
+            const size_t aux0 = core.aux0;
             for (size_t p = aux0; p + 3 <= bs;) {
                 const uint8_t *tag = rec.data() + p;
                 const char ty = (char)rec[p + 2];
@@ -1490,6 +1562,7 @@ static void bam_read_records(BamStream &f, size_t stop, BamReads &B) {
                     const char sub = (char)rec[p];
                     const uint32_t cnt = le32(rec.data() + p + 1);
                     const size_t es = (sub == 'c' || sub == 'C') ? 1 : ((sub == 's' || sub == 'S') ? 2 : 4);
+                    if (p + 5 + es * (uint64_t)cnt > bs) break; // (an array that runs past the record)
                     if (tag[0] == 'C' && tag[1] == 'G' && sub == 'I') {
                         cg = rec.data() + p + 5;
                         n_cig = cnt;

@@ -99,7 +99,9 @@ std::vector<Stats> stats_from_paf(Engine &eng, const std::vector<PafRecord> &paf
 void parse_md_for_stats(const std::string &md, uint32_t out[4]);
 // main.rs:60-77 + bamstats::cigar_stats (bamstats.rs:156-222): every mapped record of a BAM file (BGZF through zlib);
 // the CIGAR counters come from the device record-scan kernel (BAM cigars are already the packed u32 form)
-std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &bam_path);
+// trailing_panic: where the reference panics part-way through the file (a broken record, read_pos), the stats of the records
+// before it come back and the panic message goes here (NULL: thrown instead) -- the reference has printed them by then
+std::vector<Stats> cigar_stats_bam(Engine &eng, const std::string &bam_path, std::string *trailing_panic = nullptr);
 std::string cigar_stats_header(bool qbed);              // bamstats.rs:225-236
 // bed::parse_region (bed.rs:88-131): "name:st-en", 1-based inclusive start -> 0-based half-open; id = the same text
 Region parse_region(const std::string &region);

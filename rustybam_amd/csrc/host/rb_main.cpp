@@ -48,6 +48,9 @@ static int usage() {
     if (getenv("RB_FULL_EXIT") || (pre && strstr(pre, "rocprofiler"))) exit(rc);
     _exit(rc);
 }
+// stdout's buffer lives as long as the process: it must still be there when a panic unwinds out of main's try block and the
+// handler (and exit) flush what was printed before the panic (the reference prints the stats header / earlier regions first)
+static char g_obuf[1 << 22];
 static void put(const std::string &s) { fwrite(s.data(), 1, s.size(), stdout); }
 static void put(const std::vector<std::string> &chunks) {
     for (const std::string &s : chunks) fwrite(s.data(), 1, s.size(), stdout);
@@ -57,8 +60,6 @@ static void put(const std::vector<std::string> &chunks) {
 // Same counter-based generator as the device one (csrc/synth.h) and the same header rule as rustybam_amd/workload.py.
 static int synth_paf(uint64_t seed, uint64_t first, uint64_t n_rec, bool overlap_window) {
     const uint64_t T_LEN = 248387497ull;
-    std::vector<char> obuf(1 << 22);
-    setvbuf(stdout, obuf.data(), _IOFBF, obuf.size());
     std::string cg;
     for (uint64_t r = first; r < first + n_rec; r++) {
         const uint32_t n = rb_synth_n_ops_impl(seed, r, 1000, 9000);
@@ -98,6 +99,7 @@ static int synth_bed(uint64_t n_win) {
 }
 
 int main(int argc, char **argv) {
+    setvbuf(stdout, g_obuf, _IOFBF, sizeof g_obuf);
     int a = 1, device = 0, policy = RB_BSEARCH_MODERN;
     while (a + 1 < argc && argv[a][0] == '-') {
         if (!strcmp(argv[a], "--bsearch")) policy = !strcmp(argv[a + 1], "legacy") ? RB_BSEARCH_LEGACY : RB_BSEARCH_MODERN;
@@ -153,8 +155,6 @@ int main(int argc, char **argv) {
         rb::Engine eng(device);
         lap("device context", tl);
         eng.bsearch_policy = policy;
-        std::vector<char> obuf(1 << 22);
-        setvbuf(stdout, obuf.data(), _IOFBF, obuf.size());
         if (nucfreq) { // main.rs:82-121: --region first, then the bed file
             std::vector<rb::Region> rgns;
             if (!region.empty()) rgns.push_back(rb::parse_region(region));
@@ -164,7 +164,9 @@ int main(int argc, char **argv) {
         } else if (cmd == "stats") {
             put(rb::cigar_stats_header(qbed));
             if (!is_paf) { // BAM input (main.rs:60-77)
-                for (const rb::Stats &s : rb::cigar_stats_bam(eng, paf_path)) put(rb::cigar_stats_line(s, qbed));
+                std::string panic;
+                for (const rb::Stats &s : rb::cigar_stats_bam(eng, paf_path, &panic)) put(rb::cigar_stats_line(s, qbed));
+                if (!panic.empty()) throw rb::Panic(panic);
             } else {
                 std::vector<std::string> text;
                 if (text_path && rb::stats_file_text(eng, paf_path, qbed, text)) {

@@ -163,6 +163,78 @@ def test_stats_bam_md_tag_cg_tag_and_panics(oracle, tmp_path):
     assert rb("stats", bad2)[0] == 101 and oracle.cli("stats", bad2)[0] == 101
 
 
+def test_stats_bam_prints_what_came_before_a_panic(oracle, golden, tmp_path):
+    """The reference prints record by record (main.rs:71-76), so the header and the lines of the records before the one that panics
+    are on stdout when it dies; `rb` must leave the same bytes behind (the stdout buffer used to die with the try block)."""
+    refs = [("chrA", 100000)]
+    good = [dict(name=f"ok{i}", ref=0, pos=100 * i, flag=0, l_seq=30, cigar=[(10, "="), (2, "X"), (18, "=")]) for i in range(5)]
+    bad = dict(name="ends_in_D", ref=0, pos=900, flag=0, l_seq=10, cigar=[(10, "="), (5, "D")])
+    bam = tmp_path / "mid_panic.bam"
+    _write_bam(bam, refs, good[:3] + [bad] + good[3:])
+    rc, out = rb("stats", bam)
+    orc, oout = oracle.cli("stats", bam)
+    assert (rc, orc) == (101, 101)
+    assert out == oout and out.count(b"\n") == 1 + 3        # header + the three records before the panic
+    # nucfreq: the regions before an unknown contig are printed (main.rs:98-120 goes region by region)
+    bed = tmp_path / "r.bed"
+    bed.write_text("CHROMOSOME_I\t0\t50\nnope\t0\t10\n")
+    a = ["nucfreq", "-b", bed, f"{golden}/test_nucfreq.bam"]
+    rc, out = rb(*a)
+    orc, oout = oracle.cli(*a)
+    assert (rc, orc) == (101, 101) and out == oout and len(out) > 50
+
+
+def test_stats_truncated_and_malformed_bam(oracle, golden, tmp_path):
+    """htslib's bam_read1 refuses a file that ends inside a record, a block_size below 32 and a record whose name + cigar + sequence
+    do not fit its block; the reference's rec.unwrap() (main.rs:72) then panics after the records it has printed.  The host
+    decoder used to trust every length field."""
+    import gzip
+    import struct
+    raw = gzip.decompress(open(f"{golden}/stats.bam", "rb").read())
+    # walk the header to the first record
+    p = 12 + struct.unpack_from("<i", raw, 4)[0]
+    n_ref = struct.unpack_from("<i", raw, p - 4)[0]
+    for _ in range(n_ref):
+        p += 4 + struct.unpack_from("<i", raw, p)[0] + 4
+    recs = []
+    while p < len(raw):
+        bs = struct.unpack_from("<i", raw, p)[0]
+        recs.append((p, bs))
+        p += 4 + bs
+    assert len(recs) > 20
+    k = 12
+    cut_at = recs[k][0] + 4 + recs[k][1] // 2            # inside record k
+    cases = {"cut_in_record": raw[:cut_at], "cut_in_length": raw[:recs[k][0] + 2], "cut_in_header": raw[:20]}
+    tiny = bytearray(raw)                                 # block_size 16 for record k
+    struct.pack_into("<i", tiny, recs[k][0], 16)
+    cases["block_size_16"] = bytes(tiny[:recs[k][0] + 4 + 16])
+    big = bytearray(raw)                                  # n_cigar_op = 65535 in record k: the cigar runs past the block
+    struct.pack_into("<H", big, recs[k][0] + 4 + 12, 65535)
+    cases["cigar_past_block"] = bytes(big)
+    lseq = bytearray(raw)                                 # l_seq = 2^31 - 1
+    struct.pack_into("<i", lseq, recs[k][0] + 4 + 16, 0x7FFFFFFF)
+    cases["l_seq_past_block"] = bytes(lseq)
+    noname = bytearray(raw)                               # read name without its NUL
+    l_rn = raw[recs[k][0] + 4 + 8]
+    noname[recs[k][0] + 4 + 32 + l_rn - 1] = ord("x")
+    cases["name_not_terminated"] = bytes(noname)
+    full_rc, full_out = rb("stats", f"{golden}/stats.bam")
+    assert full_rc == 0
+    for name, data in cases.items():
+        f = tmp_path / f"{name}.bam"
+        with gzip.open(f, "wb") as g:
+            g.write(data)
+        rc, out = rb("stats", f)
+        assert rc == 101, name
+        if name == "cut_in_header":
+            continue
+        orc, oout = oracle.cli("stats", f)
+        assert orc == 101 and out == oout, name
+        assert full_out.startswith(out) and out.count(b"\n") >= 2, name    # header + the mapped records before record k
+        # nucfreq reads the same records: it must refuse the file too, not read past the block
+        assert rb("nucfreq", "-r", "chr1:1-100", f)[0] in (101, 1), name
+
+
 def test_readme_pipeline(oracle, golden, tmp_path):
     """The reference README's showcase chain (trim-paf | break-paf | orient | liftover | filter | stats), every stage through
     `rb`, against the same chain through the oracle CLI; each intermediate file must be byte-identical too."""
@@ -221,6 +293,11 @@ def test_liftover_text_path_panics_and_skips(tmp_path):
     assert rb("liftover", "--bed", bed, bad)[0] == 101   # check_integrity().unwrap() (paf.rs:70)
     bad.write_text("Q 10 0 5 + T 10\n")
     assert rb("liftover", "--bed", bed, bad)[0] == 101   # assert!(t.len() >= 12)
+    # a line with a bad numeric column AND a malformed cigar: PafRecord::new parses the tags first (paf.rs:387-399), so the
+    # reference panics instead of skipping the line; the text path and the general path must agree on that
+    bad.write_text("Q 10 0 5 + T 10 0 5 0 0 60 cg:Z:5=\nQ x 0 5 + T 10 0 5 0 0 60 cg:Z:5Q\n")
+    assert rb("liftover", "--bed", bed, bad)[0] == 101
+    assert rb("liftover", "--bed", bed, bad, env={"RB_GENERAL_PATH": "1"})[0] == 101
     ok = tmp_path / "ok.paf"
     ok.write_text("Q x 0 5 + T 10 0 5 0 0 60 cg:Z:5=\nQ 10 0 5 + T 10 0 5 0 0 60 cg:Z:5=\n")
     rc, out = rb("liftover", "--bed", bed, ok)

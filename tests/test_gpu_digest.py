@@ -24,10 +24,13 @@ def test_digest_matches_numpy_twin_on_oracle_output_and_shards_add_up(oracle, mo
     orows, oops = oracle.liftover(oracle.Batch(*batch_args(b), b["contig"]), *w)
     want = digest_rows(orows, oops)
     D = DevBatch(torch, eng, dev, b)
-    rows, out, cnt = D.run(w)
+    # (mixed: some records make the reference panic; with the fused scan their rows are kept and carry the status, the stand-alone
+    #  scan drops them before the hit count as the oracle does)
+    base = rustybam_amd.BSEARCH_MODERN | (rustybam_amd.LIFT_FUSED_SCAN if mode == "regular" else 0)
+    rows, out, cnt = D.run(w, policy=base)
     assert rows.shape[0] == len(orows) and len(orows) > 100
     assert D.digest(rows, out) == want
-    rows_d, out_d, _ = D.run(w, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN | rustybam_amd.LIFT_DESCRIPTORS)
+    rows_d, out_d, _ = D.run(w, policy=base | rustybam_amd.LIFT_DESCRIPTORS)
     assert D.digest(rows_d, out_d) == want                      # descriptors into the original cigar: same records
     # a different order or a changed op changes it
     assert digest_rows(orows[::-1], oops) != want
@@ -38,7 +41,7 @@ def test_digest_matches_numpy_twin_on_oracle_output_and_shards_add_up(oracle, mo
         lo, hi = int(bounds[s]), int(bounds[s + 1])
         sb = shard.shard_slice(b, b["op_off"], lo, hi)
         S = DevBatch(torch, eng, dev, sb)
-        r_s, o_s, _ = S.run(w)
+        r_s, o_s, _ = S.run(w, policy=base)
         total = (total + S.digest(r_s, o_s, row_base, lo)) & ((1 << 64) - 1)
         row_base += r_s.shape[0]
     assert row_base == len(orows) and total == want
