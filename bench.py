@@ -185,7 +185,9 @@ def main():
     if not args.unfused:
         policy |= rustybam_amd.LIFT_FUSED_SCAN
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
-    rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, total_ops // 4)
+    # out_ops: as many positional copies of the batch's op index space as the windows overlap deep (2 for the sliding windows; 1
+    # for break-paf) + arena room; the clipped cigars land there while their record streams past
+    rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, eng.plan_out_capacity(plan, args.op == "break"))
 
     def run_op(ws, rows, out):
         if args.op == "break":

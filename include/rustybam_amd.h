@@ -32,7 +32,8 @@
  *     entry point fails with RB_E_NO_DEVICE.
  *
  * Data model (all little-endian, in HBM):
- *   ops[]      u32  packed BAM encoding  len << 4 | op   (M0 I1 D2 N3 S4 H5 P6 =7 X8); len < 2^28
+ *   ops[]      u32  packed BAM encoding  len << 4 | op   (M0 I1 D2 N3 S4 H5 P6 =7 X8); len < 2^28; 16-byte aligned (128 is
+ *              faster), and readable -- contents ignored -- up to the next multiple of 32 ops behind the last one
  *   op_off[]   u64  [n_rec + 1] exclusive prefix of ops-per-record
  *   t_st,t_en,q_st,q_en u64 [n_rec];  strand u8 ('+' / '-');  contig u32 (dense ids, host keeps names)
  *   windows: contig u32, st u64, en u64   [n_win]  in BED file order
@@ -221,6 +222,12 @@ void rb_plan_destroy(rb_plan *plan);
 /* bytes of device workspace rb_dev_liftover / rb_dev_break need for this plan and row capacity (the workspace must be
  * 256-byte aligned, as rb_dev_alloc returns it) */
 size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap);
+/* out_ops capacity (in ops) with which rb_dev_liftover (for_break = 0) / rb_dev_break (1) can emit every clip while the record
+ * streams past: the clipped cigars go to up to 4 positional copies of the batch's op index space (as many as the sorted window
+ * lists overlap deep; one for break-paf), and only rows' out_off says where a clip is.  A smaller out_cap still works -- clips
+ * without a place are then copied by a second kernel into what room there is, and counters report overflow / out_ops_needed as
+ * before -- a larger one is never needed for sorted, at most 4-deep window lists. */
+uint64_t rb_plan_out_capacity(const rb_plan *plan, int for_break);
 
 /* ---- liftover --------------------------------------------------------------------------------- *
  * For every record (status OK in norm_rows) and every window of the same contig with

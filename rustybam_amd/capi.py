@@ -59,6 +59,7 @@ def lib():
         _lib.rb_ctx_last_error.restype = C.c_char_p
         _lib.rb_ctx_stream.restype = C.c_void_p
         _lib.rb_plan_workspace_bytes.restype = C.c_size_t
+        _lib.rb_plan_out_capacity.restype = C.c_uint64
         _lib.rb_synth_n_ops.restype = C.c_uint32
         _lib.rb_synth_n_ops.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     return _lib
@@ -166,6 +167,9 @@ class Engine:
 
     def plan_destroy(self, plan):
         self.L.rb_plan_destroy(plan)
+
+    def plan_out_capacity(self, plan, for_break=False):
+        return int(self.L.rb_plan_out_capacity(plan, C.c_int(1 if for_break else 0)))
 
     def plan_workspace_bytes(self, plan, rows_cap):
         return int(self.L.rb_plan_workspace_bytes(plan, C.c_uint64(rows_cap)))

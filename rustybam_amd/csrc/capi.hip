@@ -151,8 +151,9 @@ struct rb_ctx {
 
 struct rb_plan {
     rb_ctx *ctx = nullptr;
-    uint64_t n_rec = 0, n_win = 0;
+    uint64_t n_rec = 0, n_win = 0, n_ops = 0;
     uint32_t n_contig = 0;
+    uint32_t depth = 0; // most windows of a sorted per-contig window list that overlap at one point (0: no sorted list)
     // device arrays
     uint32_t *sched = nullptr, *slot_of = nullptr, *canon_pos = nullptr, *w_orig = nullptr, *ident = nullptr;
     uint64_t *w_st = nullptr, *w_en = nullptr, *wo_st = nullptr, *wo_en = nullptr, *cw_off = nullptr;
@@ -370,6 +371,17 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
     for (uint32_t c = 0; c < n_contig; c++)
         for (uint64_t i = cw_off[c] + 1; i < cw_off[c + 1]; i++)
             if (g_st[i] < g_st[i - 1] || g_en[i] < g_en[i - 1]) mono[c] = 0;
+    // how deep the sorted window lists overlap: clip j of a record goes to output slot j mod depth (k_liftover.hip), so that
+    // clips sharing a slot follow one another along the record; en == st counts as overlapping (both clips may cut one op)
+    pl->n_ops = n_rec ? op_off[n_rec] : 0;
+    for (uint32_t c = 0; c < n_contig; c++) {
+        if (!mono[c]) continue;
+        uint64_t lo = cw_off[c];
+        for (uint64_t i = cw_off[c]; i < cw_off[c + 1]; i++) {
+            while (g_en[lo] < g_st[i]) lo++;
+            pl->depth = std::max<uint32_t>(pl->depth, (uint32_t)std::min<uint64_t>(i - lo + 1, 1u << 20));
+        }
+    }
     int rc = RB_OK;
     std::vector<uint32_t> slot_of(n_rec);
     for (uint64_t w = 0; w < n_rec; w++) slot_of[sched[w]] = (uint32_t)w;
@@ -401,7 +413,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, copy_count, copy_list, total;
 };
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     ws_layout w;
@@ -424,12 +436,23 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     w.bp_tmp = take((rows_cap + 1) * 8); // break-paf: piece windows between the collect pass and their rows
     w.bp_off = take((n_rec + 1) * 8);
     w.bp_cur = take((size_t)RB_MAX_ARENA * 128);
+    w.copy_count = take(256);
+    w.copy_list = take((rows_cap + 1) * 16);
     w.total = o;
     return w;
 }
 extern "C" size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap) {
     if (!plan) return 0;
     return ws_of(plan->n_rec, rows_cap).total;
+}
+
+// ops per output slot: the batch's op index space, 32 ops (one 128-byte line) of room per record (records that share a line in the
+// input must not share one in the output), a multiple of 32
+static uint64_t slot_stride_of(uint64_t n_ops, uint64_t n_rec) { return ((n_ops + 31) & ~(uint64_t)31) + 32 * n_rec + 64; }
+extern "C" uint64_t rb_plan_out_capacity(const rb_plan *plan, int for_break) {
+    if (!plan) return 0;
+    const uint64_t slots = for_break ? 1 : std::min<uint32_t>(plan->depth, RB_MS);
+    return slots * slot_stride_of(plan->n_ops, plan->n_rec) + plan->n_ops / 16 + 32 * plan->n_rec + (1u << 20);
 }
 
 static uint32_t pick_arenas(uint64_t n_rec) {
@@ -477,9 +500,22 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.arena_cur = (unsigned long long *)(ws + w.arena);
     p.n_arena = pick_arenas(b->n_rec);
     p.desc_mode = (policy & RB_LIFT_DESCRIPTORS) ? 1 : 0;
-    p.arena_origin = p.desc_mode ? 4 * rows_cap : 0;
+    // out_ops = [slots the streaming kernel emits into | arenas of the generic and the copy kernel] (descriptor mode: [descriptors | arenas]).
+    // As many slots as the window lists overlap deep (break-paf pieces do not overlap: one), as far as out_cap allows; with fewer,
+    // or none, the clips that lose their place are copied into the arenas instead: slower, same rows.
+    p.slot_stride = slot_stride_of(b->n_ops, b->n_rec);
+    const uint32_t want = p.desc_mode ? 0u : std::min<uint32_t>(is_break ? 1u : plan->depth, RB_MS);
+    const uint64_t min_arena = 1024ull * p.n_arena;
+    uint32_t n_slots = want;
+    while (n_slots && (uint64_t)n_slots * p.slot_stride + min_arena > out_cap) n_slots--;
+    if (getenv("RB_DEBUG_SLOTS")) n_slots = std::min<uint32_t>(n_slots, (uint32_t)atoi(getenv("RB_DEBUG_SLOTS"))); // tests: force the copy path
+    p.n_slots = n_slots;
+    p.needed_base = p.desc_mode ? 4 * rows_cap : (uint64_t)want * p.slot_stride;
+    p.arena_origin = p.desc_mode ? 4 * rows_cap : (uint64_t)n_slots * p.slot_stride;
     if (p.desc_mode && out_cap < p.arena_origin + 1024) return fail(ctx, RB_E_CAPACITY, "descriptor mode needs out_cap >= 4 * rows_cap + 1024");
-    p.arena_size = ((out_cap - p.arena_origin) / p.n_arena) & ~(uint64_t)3;
+    p.arena_size = out_cap > p.arena_origin ? ((out_cap - p.arena_origin) / p.n_arena) & ~(uint64_t)3 : 0;
+    p.copy_list = (uint4 *)(ws + w.copy_list);
+    p.copy_count = (unsigned long long *)(ws + w.copy_count);
     p.gen_list = (uint32_t *)(ws + w.gen_list);
     p.jobs = (rb_job *)(ws + w.jobs);
     p.fused = (policy & RB_LIFT_FUSED_SCAN) ? 1 : 0;
@@ -504,6 +540,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.debug_skip = (policy >> 8) & 0xFFF; // diagnostics only, undocumented on purpose
     uint64_t *block_sums = (uint64_t *)(ws + w.block_sums);
     HIPCHK(ctx, hipMemsetAsync(counters, 0, sizeof(rb_counters), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(p.copy_count, 0, 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(p.arena_cur, 0, (size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8, ctx->stream));
     if (b->n_rec == 0) return RB_OK;
     if (is_break) {
@@ -661,7 +698,7 @@ struct DevBatch {
     template <typename T>
     int up(const T *host, size_t n, const T **dev) {
         void *d = nullptr;
-        int rc = rb_dev_alloc(ctx, n * sizeof(T) + 64, &d);
+        int rc = rb_dev_alloc(ctx, n * sizeof(T) + 256, &d); // (the kernels read whole 128-byte lines of the ops)
         if (rc) return rc;
         owned.push_back(d);
         if (host && n) rc = rb_dev_upload(ctx, d, host, n * sizeof(T));
@@ -775,7 +812,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     }
     const uint64_t n_ops = n_rec ? op_off[n_rec] : 0;
     uint64_t rows_cap = 16 * n_rec + n_win + 1024; // a first guess; the counters say what is needed if it is short
-    uint64_t out_cap = ((policy & RB_LIFT_DESCRIPTORS) ? n_ops / 4 : 2 * n_ops) + 16 * rows_cap + 4096;
+    uint64_t out_cap = ((policy & RB_LIFT_DESCRIPTORS) ? n_ops / 4 : rb_plan_out_capacity(plan, is_break ? 1 : 0)) + 16 * rows_cap + 4096;
     rb_counters hc;
     memset(&hc, 0, sizeof hc);
     void *ws = nullptr;

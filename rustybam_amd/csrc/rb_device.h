@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/rustybam_amd.h"
 
@@ -41,6 +42,15 @@ __device__ __forceinline__ uint32_t rb_first(uint32_t v) { return (uint32_t)__bu
 __device__ __forceinline__ uint64_t rb_first64(uint64_t v) {
     uint32_t lo = rb_first((uint32_t)v), hi = rb_first((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant in the body
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void rb_static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        rb_static_for<N, I + 1>(f);
+    }
 }
 
 // DPP controls (GFX9 encoding)

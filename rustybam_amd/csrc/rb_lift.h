@@ -8,6 +8,9 @@
 #define RB_HMAX 32            // hits resolved per streaming pass of one record (lanes 0-31 starts, 32-63 ends)
 #define RB_LDS_PER_HIT 6      // dwords of per-hit (start) state in LDS
 #define RB_ARENA_STRIDE 16    // u64 words between arena cursors (128 B)
+#ifndef RB_MS
+#define RB_MS 2               // positional copies ("slots") of the batch the streaming kernel can emit clips into
+#endif
 
 // One clip job per schedule slot, 64 bytes, written by rb_k_make_jobs after the hit scan: everything a wave needs to
 // start streaming its record arrives with one load instead of a chain of dependent ones (schedule -> record row ->
@@ -71,6 +74,13 @@ struct rb_lift_params {
     rb_norm_row *norm_w;           // == norm, writable
     uint32_t *pend_list;           // [n_rec]
     unsigned long long *pend_count;
+    // positional output: slot k of out_ops mirrors the input (op at batch index g of record r -> out_ops[k * slot_stride + 4 r + g]);
+    // the arena area behind the slots takes what the generic kernel and rb_k_copy_clips emit
+    uint32_t n_slots;              // 0 .. RB_MS
+    uint64_t slot_stride;          // ops per slot (a multiple of 4): pad4(n_ops) + 4 n_rec + 8
+    uint64_t needed_base;          // ops the slots the plan asks for would take (what out_ops_needed reports in front of the arenas)
+    uint4 *copy_list;              // [rows_cap] {row, first kept op, clipped first / last length}: clips that found no place in a slot
+    unsigned long long *copy_count;
 };
 
 // ------------------------------------------------------------------------------------------------

@@ -37,7 +37,7 @@ class DevBatch:
             eng.dev_scan_records(self.view, 0, self.d_norm.data_ptr())
         plan = eng.plan_create(self.op_off_host, self.contig_host, *(windows if windows is not None else (None, None, None)))
         rows_cap = rows_cap or max(1024, 4 * self.n_rec)
-        out_cap = out_cap or max(4096, self.n_ops // 2)
+        out_cap = out_cap or max(4096, eng.plan_out_capacity(plan, max_size is not None))
         if policy & rustybam_amd.LIFT_DESCRIPTORS:
             out_cap = max(out_cap, 4 * rows_cap + 65536)
         try:

@@ -57,6 +57,8 @@ def _config3(is_break=False):
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
 
     def run(policy, rows_cap, out_cap):
+        if not (policy & rustybam_amd.LIFT_DESCRIPTORS):
+            out_cap = max(out_cap, eng.plan_out_capacity(plan, is_break))
         for _ in range(6):
             ws = torch.empty(eng.plan_workspace_bytes(plan, rows_cap), dtype=torch.uint8, device=dev)
             rows = torch.full(((rows_cap + 1) * 64,), 0xEE, dtype=torch.uint8, device=dev)   # (a row nobody writes stays 0xEE..)
