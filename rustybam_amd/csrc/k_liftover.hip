@@ -505,6 +505,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                             m0 &= __ballot(c0 >= carry[q]);
                             m1 &= __ballot(c0 + 4u >= carry[q]);
                         }
+#ifdef RB_LINE_ROUND
+                        { // whole 128-byte lines (4 lanes): a partly written line costs a read of the rest
+                            unsigned long long q4 = (m0 | m1);
+                            q4 = (q4 | (q4 >> 1) | (q4 >> 2) | (q4 >> 3)) & 0x1111111111111111ull;
+                            q4 |= q4 << 1;
+                            q4 |= q4 << 2;
+                            const unsigned long long keep0 = m0 | ~msk[q], keep1 = m1 | ~msk[q]; // (what the edge / carry filters took away stays away)
+                            m0 = q4 & v0 & keep0;
+                            m1 = q4 & v1 & keep1;
+                        }
+#endif
                         if (p.debug_skip & 64) m0 = m1 = 0ull; // diagnostics: everything but the stores themselves
                         const uint32_t *sb = p.out_ops + slot_row0 + (uint64_t)q * p.slot_stride;
 #define RB_RING_STORE(RA, RB_)                                                                                                  \
