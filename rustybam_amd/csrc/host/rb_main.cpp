@@ -8,6 +8,7 @@
 #include <cstring>
 #include <unistd.h>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <chrono>
@@ -60,32 +61,54 @@ static void put(const std::vector<std::string> &chunks) {
 // Same counter-based generator as the device one (csrc/synth.h) and the same header rule as rustybam_amd/workload.py.
 static int synth_paf(uint64_t seed, uint64_t first, uint64_t n_rec, bool overlap_window) {
     const uint64_t T_LEN = 248387497ull;
-    std::string cg;
-    for (uint64_t r = first; r < first + n_rec; r++) {
-        const uint32_t n = rb_synth_n_ops_impl(seed, r, 1000, 9000);
-        uint64_t R = 0, Q = 0;
-        cg.clear();
-        char buf[24];
-        for (uint32_t j = 0; j < n; j++) {
-            const uint32_t v = rb_synth_op(seed, r, j), op = v & 15u, len = v >> 4;
-            if (op != 1) R += len;
-            if (op != 2) Q += len;
-            const int k = snprintf(buf, sizeof buf, "%u%c", len, "MIDNSHP=X"[op]);
-            cg.append(buf, (size_t)k);
+    // records are independent (counter-based generator): all host threads write slices of them, printed in order
+    const unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 64u));
+    const uint64_t slice = 256; // records per work item
+    std::vector<std::string> buf(T);
+    auto put_u = [](std::string &o, uint64_t v) {
+        char tmp[24];
+        int k = 24;
+        do { tmp[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+        o.append(tmp + k, (size_t)(24 - k));
+    };
+    for (uint64_t base = 0; base < n_rec; base += slice * T) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) {
+            th.emplace_back([&, t]() {
+                std::string &o = buf[t];
+                o.clear();
+                const uint64_t lo = base + t * slice, hi = std::min(n_rec, lo + slice);
+                std::string cg;
+                for (uint64_t i = lo; i < hi; i++) {
+                    const uint64_t r = first + i;
+                    const uint32_t n = rb_synth_n_ops_impl(seed, r, 1000, 9000);
+                    uint64_t R = 0, Q = 0;
+                    cg.clear();
+                    for (uint32_t j = 0; j < n; j++) {
+                        const uint32_t v = rb_synth_op(seed, r, j), op = v & 15u, len = v >> 4;
+                        if (op != 1) R += len;
+                        if (op != 2) Q += len;
+                        put_u(cg, len);
+                        cg.push_back("MIDNSHP=X"[op]);
+                    }
+                    const uint64_t h1 = rb_splitmix64(seed ^ rb_splitmix64(r ^ 0x1111111111111111ull)), h2 = rb_splitmix64(h1), h3 = rb_splitmix64(h2);
+                    uint64_t t_st;
+                    if (!overlap_window) {
+                        t_st = h1 % (T_LEN - (R < T_LEN ? R : T_LEN) + 1);
+                    } else {
+                        const uint64_t w0 = 12000000ull, w1 = 13000000ull, lo_ = R > w0 ? 0 : w0 - R + 1, hi_ = w1 - 1;
+                        t_st = lo_ + h1 % (hi_ - lo_ + 1);
+                    }
+                    const char strand = (h2 & 1ull) == 0 ? '+' : '-';
+                    const uint64_t q_st = h3 % 100001ull, q_en = q_st + Q;
+                    o.push_back('q'); put_u(o, r); o.push_back('\t'); put_u(o, q_en + 1000); o.push_back('\t'); put_u(o, q_st); o.push_back('\t');
+                    put_u(o, q_en); o.push_back('\t'); o.push_back(strand); o.append("\tchr1\t"); put_u(o, T_LEN); o.push_back('\t'); put_u(o, t_st);
+                    o.push_back('\t'); put_u(o, t_st + R); o.append("\t0\t0\t60\ttp:A:P\tcg:Z:"); o.append(cg); o.push_back('\n');
+                }
+            });
         }
-        const uint64_t h1 = rb_splitmix64(seed ^ rb_splitmix64(r ^ 0x1111111111111111ull)), h2 = rb_splitmix64(h1), h3 = rb_splitmix64(h2);
-        uint64_t t_st;
-        if (!overlap_window) {
-            t_st = h1 % (T_LEN - (R < T_LEN ? R : T_LEN) + 1);
-        } else {
-            const uint64_t w0 = 12000000ull, w1 = 13000000ull, lo = R > w0 ? 0 : w0 - R + 1, hi = w1 - 1;
-            t_st = lo + h1 % (hi - lo + 1);
-        }
-        const char strand = (h2 & 1ull) == 0 ? '+' : '-';
-        const uint64_t q_st = h3 % 100001ull, q_en = q_st + Q;
-        printf("q%llu\t%llu\t%llu\t%llu\t%c\tchr1\t%llu\t%llu\t%llu\t0\t0\t60\ttp:A:P\tcg:Z:%s\n", (unsigned long long)r,
-               (unsigned long long)(q_en + 1000), (unsigned long long)q_st, (unsigned long long)q_en, strand, (unsigned long long)T_LEN,
-               (unsigned long long)t_st, (unsigned long long)(t_st + R), cg.c_str());
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < T; t++) fwrite(buf[t].data(), 1, buf[t].size(), stdout);
     }
     fflush(stdout);
     return 0;

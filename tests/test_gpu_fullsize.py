@@ -24,14 +24,16 @@ def _seg(P, a, b):
     return hi - lo
 
 
-def _config3(is_break=False):
+def _config3(is_break=False, config2=False):
     import torch
-    n_rec = int(os.environ.get("RB_FULLSIZE_RECORDS", "1000000"))
+    n_rec = int(os.environ.get("RB_FULLSIZE_RECORDS", "100000" if config2 else "1000000"))
     dev = torch.device("cuda", 0)
     torch.cuda.set_stream(torch.cuda.Stream(dev))  # torch's kernels and the engine's on one real stream (a NULL handle would mean "private stream")
     eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
-    seed = wl.SEED_CONFIG3
+    seed = wl.SEED_CONFIG2 if config2 else wl.SEED_CONFIG3
     w_c, w_st, w_en = wl.sliding_windows(3000)
+    if config2:  # BASELINE.json configs[1]: one 1 Mbp window, every record placed so that it overlaps it
+        w_c, w_st, w_en = np.zeros(1, np.uint32), np.array([12_000_000], np.uint64), np.array([13_000_000], np.uint64)
     nops = wl.n_ops(seed, 0, n_rec)
     op_off = wl.op_offsets(nops)
     total_ops = int(op_off[-1])
@@ -49,7 +51,7 @@ def _config3(is_break=False):
     eng.dev_scan_records(v0, d_red.data_ptr(), 0)
     torch.cuda.synchronize()
     red = d_red.cpu().numpy().view(rustybam_amd.REDUCE_DT)
-    t_st, t_en, q_st, q_en, strand = wl.headers(seed, 0, red["t_bases"], red["q_bases"], "uniform")
+    t_st, t_en, q_st, q_en, strand = wl.headers(seed, 0, red["t_bases"], red["q_bases"], "overlap" if config2 else "uniform")
     d_c = [i64(x) for x in (t_st, t_en, q_st, q_en)]
     d_strand = torch.from_numpy(strand).to(dev)
     view = eng.batch_view(n_rec, total_ops, d_ops.data_ptr(), d_off.data_ptr(), *[x.data_ptr() for x in d_c], d_strand.data_ptr(), d_contig.data_ptr())
@@ -80,7 +82,8 @@ def _config3(is_break=False):
             del ws, rows, out
         raise AssertionError("could not size the outputs")
 
-    return dict(torch=torch, dev=dev, eng=eng, run=run, n_rec=n_rec, total_ops=total_ops, d_ops=d_ops, d_off=d_off, keep=(d_c, d_strand, d_contig, d_norm, zeros, plan, view))
+    return dict(torch=torch, dev=dev, eng=eng, run=run, n_rec=n_rec, total_ops=total_ops, d_ops=d_ops, d_off=d_off, keep=(d_c, d_strand, d_contig, d_norm, zeros, plan, view),
+                host=dict(seed=seed, nops=nops, op_off=op_off, t_st=t_st, t_en=t_en, q_st=q_st, q_en=q_en, strand=strand, windows=(w_c, w_st, w_en)), view=view)
 
 
 def _u64(r, c):
@@ -152,6 +155,63 @@ def test_full_size_liftover_integrity_and_descriptor_checksums():
     sum_d = sum_d + ((new_first - (w_first >> 4)) << 4) + torch.where(one, torch.zeros_like(sum_d), (new_last - (w_last >> 4)) << 4)
     bad = int((sum_d != sum_c).sum())
     assert bad == 0, f"{bad} of {n} clips differ between the copied and the descriptor route"
+    eng.close()
+
+
+def test_full_size_config2_one_window_every_record_overlaps(oracle):
+    """BASELINE.json configs[1] at full size: 1e5 records of 1000-9000 ops, each placed so that it overlaps the one
+    window chr1:12,000,000-13,000,000.  Properties that need no oracle: one hit per record, in record order; every clip passes the
+    reference's check_integrity, lies inside the window and its record, and starts / ends within the window's first / last bases
+    the record covers (a clip only shrinks to the next match op); plus the oracle on a sample, row by row and op by op, and the
+    digest of the copied clips against the digest of their descriptors."""
+    from rustybam_amd import capi
+    C = _config3(config2=True)
+    torch, dev, eng, run, n_rec, total_ops = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops"))
+    H = C["host"]
+    base = rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN
+    rows, out = run(base, n_rec + 64, int(1.2 * total_ops))
+    n = rows.shape[0]
+    assert n == n_rec                                                        # every record overlaps the window exactly once
+    assert torch.equal(rows[:, 0].to(torch.int64), torch.arange(n, device=dev)) and int(rows[:, 1].abs().sum()) == 0
+    st = rows[:, 2] & 0xFFFF
+    assert int((st >= 16).sum()) == 0 and int((st != 0).sum()) < n // 1000   # nothing panics; a window edge inside an indel gives None, rarely
+    ok = st == 0
+    r_ok = rows[ok]
+    _check_integrity(torch, dev, r_ok, out)
+    i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    t_st, t_en = i64(H["t_st"])[ok], i64(H["t_en"])[ok]
+    c_st, c_en = _u64(r_ok, 4), _u64(r_ok, 6)
+    lo, hi = torch.clamp(t_st, min=12_000_000), torch.clamp(t_en, max=13_000_000)
+    inside = (r_ok[:, 2] >> 16) & 1
+    free = inside == 0
+    assert bool((c_st >= lo).all()) and bool((c_en <= hi).all()) and bool((c_st < c_en).all())
+    # the reference walks from the window edge to the next match op: what it skips is one run of non-match ops (I / D of at most 5000 bases here)
+    assert bool(((c_st - lo)[free] <= 5000).all()) and bool(((hi - c_en)[free] <= 5000).all())
+    assert int(inside.sum()) == int(((i64(H["t_st"]) > 12_000_000) & (i64(H["t_en"]) < 13_000_000))[ok].sum())   # liftover.rs:23-25
+    # ---- the oracle on the first records ----
+    k = 300
+    so = wl.op_offsets(H["nops"][:k])
+    sops = capi.synth_fill_ops_host(H["seed"], 0, so)
+    ob = oracle.Batch(sops, so, H["t_st"][:k], H["t_en"][:k], H["q_st"][:k], H["q_en"][:k], H["strand"][:k], np.zeros(k, np.uint32))
+    orows, oops = oracle.liftover(ob, *H["windows"])
+    g = rows[:k].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
+    assert len(orows) == k
+    for key in ("rec", "win", "status"):
+        assert np.array_equal(g[key].astype(np.int64), orows[key].astype(np.int64)), key
+    good = orows["status"] == 0
+    for key in ("t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
+        assert np.array_equal(g[key][good].astype(np.uint64), orows[key][good].astype(np.uint64)), key
+    for i in np.nonzero(good)[0][::7]:
+        a = out[int(g["out_off"][i]): int(g["out_off"][i]) + int(g["out_n"][i])].cpu().numpy().view(np.uint32)
+        assert np.array_equal(a, oops[int(orows["out_off"][i]): int(orows["out_off"][i]) + int(orows["out_n"][i])]), i
+    # ---- copied clips and descriptors describe the same records (rb_dev_digest_rows expands descriptors through the batch) ----
+    dig = torch.zeros(2, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    eng.dev_digest_rows(C["view"], rows.data_ptr(), n, out.data_ptr(), 0, 0, dig[0:1].data_ptr())
+    rows_d, desc = run(base | rustybam_amd.LIFT_DESCRIPTORS, n + 64, 4 * (n + 64) + 65536)
+    eng.dev_digest_rows(C["view"], rows_d.data_ptr(), n, desc.data_ptr(), 0, 0, dig[1:2].data_ptr())
+    torch.cuda.synchronize()
+    assert int(dig[0]) == int(dig[1]) and int(dig[0]) != 0
     eng.close()
 
 

@@ -316,3 +316,67 @@ def test_liftover_unsorted_tpos_array(engine, oracle):
     w = (np.zeros(len(ws), np.uint32), ws, we)
     for pol in (rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY):
         _check_liftover(engine, oracle, b, w, pol, f"unsorted tpos policy {pol}")
+
+
+# ---- positional output slots of the streaming clip kernel: clips that lose their place must still come out right ----
+def _run_slots(oracle, b, w, env_slots, what):
+    """rb_host_liftover in a fresh process with RB_DEBUG_SLOTS (the library reads it per call, but a fresh engine keeps this honest)"""
+    import subprocess
+    import sys
+    import tempfile
+    import pickle
+    code = r'''
+import pickle, sys
+sys.path.insert(0, %r)
+import torch  # noqa: F401 (HIP runtime load order, see conftest)
+import rustybam_amd
+b, w = pickle.load(open(sys.argv[1], "rb"))
+eng = rustybam_amd.Engine(0)
+out = {}
+for pol in (rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN):
+    rows, ops, norm, cnt = eng.liftover(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], b["contig"], *w, policy=pol)
+    out[pol] = (rows, ops)
+pickle.dump(out, open(sys.argv[2], "wb"))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        pickle.dump((b, w), open(os.path.join(d, "in.pkl"), "wb"))
+        env = dict(os.environ)
+        if env_slots is not None:
+            env["RB_DEBUG_SLOTS"] = str(env_slots)
+        r = subprocess.run([sys.executable, "-c", code, os.path.join(d, "in.pkl"), os.path.join(d, "out.pkl")], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = pickle.load(open(os.path.join(d, "out.pkl"), "rb"))
+    orows, oops = oracle.liftover(_obatch(oracle, b), *w)
+    for pol, (rows, ops) in out.items():
+        compare_hits(rows, ops, orows, oops, f"{what} slots={env_slots} policy={pol}")
+    return len(orows)
+
+
+@pytest.mark.parametrize("slots", [None, 0, 1])
+def test_liftover_clips_without_a_slot_are_copied(oracle, slots):
+    """windows overlapping 5 deep (more than the kernel has slots), and the slots switched off / cut to one: every clip that loses
+    its place goes through rb_k_copy_clips and must be the same bytes"""
+    rng = np.random.default_rng(4242)
+    b = random_batch(rng, 120, "regular", n_contig=1, long_frac=0.6)
+    hi = int(b["t_en"].max())
+    st = np.arange(0, hi, 40, dtype=np.uint64)
+    w = (np.zeros(len(st), np.uint32), st, st + 200)          # five windows over every base
+    n = _run_slots(oracle, b, w, slots, "deep windows")
+    assert n > 2000
+
+
+def test_liftover_many_windows_inside_one_op(oracle):
+    """disjoint windows that all cut the same long '=' op: their clips are one op each, at the same position of the record -- in a
+    positional slot they would sit on top of each other, so all but the first of a class must be copied; also clips that share a
+    16-byte group with the previous one of their class"""
+    lines = ["Q 200000 0 100000 + T 200000 0 100000 100000 100000 60 cg:Z:100000=",
+             "Q 200000 100 50103 - T 200000 1000 51003 0 0 60 cg:Z:3=1X20000=1I2=1D29996="]
+    r = recs_from_lines(lines)
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand, contig=r.contig)
+    st = np.arange(0, 100000, 150, dtype=np.uint64)
+    w = (np.zeros(len(st), np.uint32), st, st + 100)           # gaps between the windows: depth 1
+    n = _run_slots(oracle, b, w, None, "one op")
+    assert n > 900
+    st = np.arange(0, 100000, 70, dtype=np.uint64)
+    w = (np.zeros(len(st), np.uint32), st, st + 100)           # depth 2, still inside single ops
+    _run_slots(oracle, b, w, None, "one op, overlapping")

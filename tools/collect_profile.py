@@ -1,0 +1,61 @@
+"""Copy what the judge reads from a tools/prof_r02.sh run (gpurun_out/<tag>/) into profiles/: the kernel-trace stats, the bench line,
+per-launch PMC numbers of the clip kernel (largest launch = a full-size one) and profiles/traffic_r02.json.
+usage: python tools/collect_profile.py <tag> [<bench json>]"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(src, "kt_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
+bench = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"{tag}_bench.json")
+line = [ln for ln in open(bench) if ln.startswith("{")][-1]
+open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
+B = json.loads(line)
+per = collections.defaultdict(dict)
+for f in sorted(glob.glob(os.path.join(src, "*counter_collection.csv"))):
+    for row in csv.DictReader(open(f)):
+        if "liftover_stream" in row["Kernel_Name"]:
+            per[(os.path.basename(f), row["Dispatch_Id"])][row["Counter_Name"]] = float(row["Counter_Value"])
+best = {}
+for (_f, _d), c in per.items():
+    for k, v in c.items():
+        best[k] = max(best.get(k, 0.0), v)
+stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "kt_kernel_stats.csv")))}
+ks = next(v for k, v in stats.items() if "liftover_stream" in k)
+fetch, write = best["FETCH_SIZE"] * 2 * 1024, best["WRITE_SIZE"] * 1024
+algo = B["roofline"]["algorithmic_bytes"]
+traffic = {"_comment": "PMC traffic of rb_k_liftover_stream per full-size launch on the bench.py default workload (config 3, 1e6 records x 3000 "
+                       "windows, 1 GPU, fused record scan); separate --pmc passes (tools/prof_r02.sh), FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                       f"(16 B / lane streaming loads). Source: profiles/{tag}_summary.md",
+           "workload": {"records_per_gpu": B["config"]["records_per_gpu"], "windows": B["config"]["windows"], "workload": "config3"},
+           "fetch_size_kb_raw": best["FETCH_SIZE"], "write_size_kb_raw": best["WRITE_SIZE"], "fetch_bytes_corrected": fetch, "write_bytes": write,
+           "traffic_bytes_per_launch": fetch + write, "kernel": "rb_k_liftover_stream", "build": f"round 2 profile {tag}"}
+json.dump(traffic, open(os.path.join(dst, "traffic_r02.json"), "w"), indent=1)
+md = f"""# Round 2, profile {tag} -- the headline step (config 3: 1e6 records, 5e9 ops, 3000 sliding 100 kb windows, 1 MI355X)
+
+`tools/prof_r02.sh {tag}` (kernel trace + stats; FETCH_SIZE / WRITE_SIZE / SQ counters in separate `--pmc` passes), then an unprofiled
+`python bench.py` -> `profiles/{tag}_bench.json`.  Fused record scan, clips copied out (emitted from the load ring into positional slots).
+
+| | |
+|---|---|
+| `ms_per_step` (bench.py, unprofiled) | {B['ms_per_step']:.2f} -> {B['value']:.3e} CIGAR-ops/s, {B['paf_records_per_s']:.3e} PAF-records/s |
+| `rb_k_liftover_stream`, HIP events inside bench.py | {B['roofline']['kernel_ms']:.2f} ms -> {B['roofline']['achieved']:.0f} GB/s of algorithmic bytes = **{B['roofline']['frac']:.3f} of 8 TB/s** |
+| the same kernel in `profiles/{tag}_kernel_stats.csv` (full-size launches = the maximum; the average mixes in sizing / parity-sample launches) | max {float(ks['MaxNs']) / 1e6:.2f} ms over {ks['Calls']} calls |
+| FETCH_SIZE per full launch | {best['FETCH_SIZE']:.4g} KB raw x2 (gfx950 correction) = {fetch / 1e9:.2f} GB |
+| WRITE_SIZE per full launch | {best['WRITE_SIZE']:.4g} KB = {write / 1e9:.2f} GB |
+| traffic | **{(fetch + write) / 1e9:.1f} GB = {(fetch + write) / algo:.3f} x the {algo / 1e9:.2f} GB of algorithmic bytes** (round 1: 70.9 GB, 1.56 x) |
+| SQ_INSTS_VALU / SALU per full launch | {best.get('SQ_INSTS_VALU', 0):.3g} / {best.get('SQ_INSTS_SALU', 0):.3g} ({best.get('SQ_INSTS_VALU', 0) / 1e6:.0f} / {best.get('SQ_INSTS_SALU', 0) / 1e6:.0f} per record) |
+| SQ_INSTS_VMEM_RD / VMEM_WR / LDS per full launch | {best.get('SQ_INSTS_VMEM_RD', 0):.3g} / {best.get('SQ_INSTS_VMEM_WR', 0):.3g} / {best.get('SQ_INSTS_LDS', 0):.3g} |
+| end to end (`rb liftover`, text in -> text out, {B.get('e2e', {}).get('records', 0)} records) | {B.get('e2e_paf_records_per_s', 0):.0f} PAF-records/s ({B.get('e2e', {}).get('seconds', 0)} s) |
+| cpu_baseline (the oracle: a per-base restatement, not the Rust binary) | {B.get('cpu_baseline', {}).get('value', 0):.3e} CIGAR-ops/s on {B.get('cpu_baseline', {}).get('cores', 0)} threads; -t 8: {B.get('cpu_baseline', {}).get('t8', {}).get('value', 0):.3e} |
+| parity | {B.get('parity_sample', '-')}; output digest {B.get('output_digest', '-')} |
+"""
+open(os.path.join(dst, f"{tag}_summary.md"), "w").write(md)
+print(md)

@@ -9,7 +9,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o kt --
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag -o fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $args > gpurun_out/${tag}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$tag -o write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $args > gpurun_out/${tag}_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/$tag -o sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $args > gpurun_out/${tag}_sq.log 2>&1
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVES --output-format csv -d gpurun_out/$tag -o sq2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $args > gpurun_out/${tag}_sq2.log 2>&1
+
 # per-kernel sums of every counter file
 python3 - "$tag" <<'PY'
 import csv, glob, sys, collections
