@@ -261,6 +261,23 @@ int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *batch, const rb_norm_
                          const uint32_t *left, const uint32_t *right, const uint64_t *pair_out_off, int match_score,
                          int diff_score, int indel_score, int bsearch_policy, rb_pair_row *rows, uint32_t *out_ops);
 
+/* ---- trim-paf with the batch resident on the device across the passes of Paf::overlapping_paf_recs (paf.rs:210-305) ----------
+ * rb_dev_apply_pairs: the records a pass has cut become the batch's current records.  For every pair k with status RB_ST_OK and
+ *     side s (0 = left[k], 1 = right[k]):  op_off[rec] = rows[k].out_off[s] and norm_rows[rec] = the clipped record (coordinates,
+ *     nmatch, aln_len, first_op 0, n_ops = out_n; a clip starts and ends on a match op, so the remove_trailing_indels of the next
+ *     pass, paf.rs:218-220, finds nothing to strip).  out_off must index the SAME array as the batch's ops: call
+ *     rb_dev_overlap_split with out_ops = batch->ops and pair_out_off pointing behind the ops in use.  From then on op_off is a
+ *     table of starts, no longer a prefix array: only rb_dev_overlap_split, rb_dev_gather_records and rb_dev_format_cigars -- which
+ *     take a record's extent from norm_rows / explicit counts -- may be used on the batch.
+ * rb_dev_gather_records: the current records (ops[op_off[r] + first_op ..][n_ops], records whose status is not RB_ST_OK count as
+ *     empty) copied into a dense array in record order; new_op_off [n_rec + 1] is its exclusive prefix.  new_ops NULL: sizes only.
+ *     scratch: rb_text_scratch_bytes(n_rec) bytes.  The dense array with the coordinates of norm_rows is an ordinary batch again
+ *     (e.g. for rb_dev_break: the README pipeline trim-paf | break-paf). */
+int rb_dev_apply_pairs(rb_ctx *ctx, uint64_t n_pairs, const uint32_t *left, const uint32_t *right, const rb_pair_row *rows,
+                       uint64_t *op_off, rb_norm_row *norm_rows);
+int rb_dev_gather_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const rb_norm_row *norm_rows,
+                          uint64_t *new_op_off, uint32_t *new_ops, void *scratch);
+
 /* ---- host-buffer wrappers (H2D, kernels, D2H; results malloc'ed, free with rb_host_free) ------ */
 int rb_host_scan_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off,
                          const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,

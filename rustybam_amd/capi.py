@@ -154,6 +154,24 @@ class Engine:
         self._chk(self.L.rb_dev_digest_rows(self.ctx, C.byref(view), C.c_void_p(rows_ptr), C.c_uint64(n_rows), C.c_void_p(out_ptr),
                                             C.c_uint64(row_base), C.c_uint64(rec_base), C.c_void_p(digest_ptr)), "rb_dev_digest_rows")
 
+    def dev_overlap_split(self, view, norm_ptr, n_pairs, left_ptr, right_ptr, pair_out_off_ptr, scores, policy, rows_ptr, out_ptr):
+        self._chk(self.L.rb_dev_overlap_split(self.ctx, C.byref(view), C.c_void_p(norm_ptr), C.c_uint64(n_pairs), C.c_void_p(left_ptr),
+                                              C.c_void_p(right_ptr), C.c_void_p(pair_out_off_ptr), C.c_int(scores[0]), C.c_int(scores[1]),
+                                              C.c_int(scores[2]), C.c_int(policy), C.c_void_p(rows_ptr), C.c_void_p(out_ptr)), "rb_dev_overlap_split")
+
+    def dev_apply_pairs(self, n_pairs, left_ptr, right_ptr, rows_ptr, op_off_ptr, norm_ptr):
+        self._chk(self.L.rb_dev_apply_pairs(self.ctx, C.c_uint64(n_pairs), C.c_void_p(left_ptr), C.c_void_p(right_ptr), C.c_void_p(rows_ptr),
+                                            C.c_void_p(op_off_ptr), C.c_void_p(norm_ptr)), "rb_dev_apply_pairs")
+
+    def dev_gather_records(self, n_rec, ops_ptr, op_off_ptr, norm_ptr, new_off_ptr, new_ops_ptr, scratch_ptr):
+        self._chk(self.L.rb_dev_gather_records(self.ctx, C.c_uint64(n_rec), C.c_void_p(ops_ptr), C.c_void_p(op_off_ptr), C.c_void_p(norm_ptr),
+                                               C.c_void_p(new_off_ptr), C.c_void_p(new_ops_ptr or 0), C.c_void_p(scratch_ptr)), "rb_dev_gather_records")
+
+    def text_scratch_bytes(self, n):
+        f = self.L.rb_text_scratch_bytes
+        f.restype = C.c_size_t
+        return int(f(C.c_uint64(n)))
+
     def plan_create(self, op_off, contig, w_contig=None, w_st=None, w_en=None):
         op_off, contig = _arr(op_off, np.uint64), _arr(contig, np.uint32)
         nw = 0 if w_st is None else len(w_st)

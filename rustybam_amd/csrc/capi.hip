@@ -640,6 +640,46 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     return RB_OK;
 }
 
+struct rb_apply_params {
+    uint64_t n_pairs;
+    const uint32_t *left, *right;
+    const rb_pair_row *rows;
+    uint64_t *op_off;
+    rb_norm_row *norm;
+};
+struct rb_gather_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const rb_norm_row *norm;
+    uint64_t *new_off;
+    uint32_t *new_ops;
+    int fill;
+};
+extern "C" hipError_t rb_launch_apply_pairs(const rb_apply_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_gather_records(const rb_gather_params *p, hipStream_t stream);
+extern "C" int rb_dev_apply_pairs(rb_ctx *ctx, uint64_t n_pairs, const uint32_t *left, const uint32_t *right, const rb_pair_row *rows,
+                                  uint64_t *op_off, rb_norm_row *norm_rows) {
+    if (!ctx || (n_pairs && (!left || !right || !rows || !op_off || !norm_rows))) return RB_E_INVALID;
+    rb_apply_params p{n_pairs, left, right, rows, op_off, norm_rows};
+    HIPCHK(ctx, rb_launch_apply_pairs(&p, ctx->stream));
+    return RB_OK;
+}
+extern "C" int rb_dev_gather_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const rb_norm_row *norm_rows,
+                                     uint64_t *new_op_off, uint32_t *new_ops, void *scratch) {
+    if (!ctx || !new_op_off || !scratch || (n_rec && (!ops || !op_off || !norm_rows))) return RB_E_INVALID;
+    rb_gather_params p{n_rec, ops, op_off, norm_rows, new_op_off, new_ops, 0};
+    HIPCHK(ctx, hipMemsetAsync(new_op_off + n_rec, 0, 8, ctx->stream));
+    if (n_rec == 0) return RB_OK;
+    HIPCHK(ctx, rb_launch_gather_records(&p, ctx->stream));
+    HIPCHK(ctx, rb_launch_exclusive_scan(new_op_off, n_rec, (uint64_t *)scratch, nullptr, ctx->stream));
+    if (new_ops) { // (NULL: sizes only -- new_op_off[n_rec] says how many ops the dense batch holds)
+        p.fill = 1;
+        HIPCHK(ctx, rb_launch_gather_records(&p, ctx->stream));
+    }
+    return RB_OK;
+}
+
 // ---- CIGAR text ----------------------------------------------------------------------------------
 extern "C" size_t rb_text_scratch_bytes(uint64_t n) { return (rb_scan_block_sums_count(n) + 4) * 8; }
 extern "C" int rb_dev_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint64_t *text_off, const uint64_t *text_end, uint64_t n_rec,

@@ -713,3 +713,65 @@ extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream
     hipLaunchKernelGGL(rb_k_overlap_split, dim3((unsigned)((p->n_pairs + 63) / 64)), dim3(64), 0, stream, q);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// between two passes of trim-paf: the clipped records of a pass become the batch's current records (include/rustybam_amd.h,
+// rb_dev_apply_pairs), and the current records gathered into a dense batch again (rb_dev_gather_records)
+// ------------------------------------------------------------------------------------------------
+struct rb_apply_params {
+    uint64_t n_pairs;
+    const uint32_t *left, *right;
+    const rb_pair_row *rows;
+    uint64_t *op_off;
+    rb_norm_row *norm;
+};
+__global__ __launch_bounds__(256) void rb_k_apply_pairs(rb_apply_params p) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t k = t >> 1;
+    const int s = (int)(t & 1);
+    if (k >= p.n_pairs) return;
+    const rb_pair_row *row = &p.rows[k];
+    if (row->status != RB_ST_OK) return;
+    const uint32_t rec = s ? p.right[k] : p.left[k];
+    rb_norm_row n = p.norm[rec];
+    n.t_st = row->t_st[s], n.t_en = row->t_en[s], n.q_st = row->q_st[s], n.q_en = row->q_en[s];
+    n.first_op = 0, n.n_ops = row->out_n[s];
+    n.lead_ops = n.trail_ops = 0; // (a clip starts and ends on a match op: remove_trailing_indels finds nothing, paf.rs:218-220)
+    n.nmatch = row->nmatch[s], n.aln_len = row->aln_len[s];
+    p.norm[rec] = n;
+    p.op_off[rec] = row->out_off[s];
+}
+extern "C" hipError_t rb_launch_apply_pairs(const rb_apply_params *p, hipStream_t stream) {
+    if (p->n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_apply_pairs, dim3((unsigned)((2 * p->n_pairs + 255) / 256)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+
+struct rb_gather_params {
+    uint64_t n_rec;
+    const uint32_t *ops;
+    const uint64_t *op_off;
+    const rb_norm_row *norm;
+    uint64_t *new_off; // [n_rec + 1]: counts (fill == 0) then their exclusive prefix
+    uint32_t *new_ops;
+    int fill;
+};
+__global__ __launch_bounds__(256) void rb_k_gather_records(rb_gather_params p) {
+    if (!p.fill) { // the kept length of every record
+        const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (r < p.n_rec) p.new_off[r] = p.norm[r].status == RB_ST_OK ? p.norm[r].n_ops : 0u;
+        return;
+    }
+    const uint64_t r = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r >= p.n_rec) return;
+    const uint64_t n = p.new_off[r + 1] - p.new_off[r];
+    const uint32_t *src = p.ops + p.op_off[r] + p.norm[r].first_op;
+    uint32_t *dst = p.new_ops + p.new_off[r];
+    for (uint64_t j = rb_lane(); j < n; j += 64) dst[j] = src[j];
+}
+extern "C" hipError_t rb_launch_gather_records(const rb_gather_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    if (!p->fill) hipLaunchKernelGGL(rb_k_gather_records, dim3((unsigned)((p->n_rec + 255) / 256)), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(rb_k_gather_records, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}

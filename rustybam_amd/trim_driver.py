@@ -83,3 +83,147 @@ def overlapping_paf_recs(eng, recs, scores=(1, 1, 1), remove_contained=False, po
             recs = [r for r, c in zip(recs, contained) if not c]
         return recs
     raise RuntimeError("trim-paf did not converge")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# The same driver with the batch RESIDENT on the device across the passes: only pair lists go up and a few columns of the pair
+# rows come down.  Array-based (numpy) so that it scales to SURVEY 8d config 4 (1e7 records); the per-pass bookkeeping of
+# Paf::overlapping_paf_recs (paf.rs:223-301) is vectorised over the query groups:
+#   - records are (stably) ordered by query name once; a pass looks at every pair (i < j) of one name (paf.rs:231-261),
+#   - overlap == length of one of the two marks it contained, otherwise the pair is a candidate, left = smaller q_st (:244-256),
+#   - candidates are stably sorted by overlap, descending, and the first of every name is cut in this pass (:262-284);
+#     if a name had more than one candidate the whole thing runs again (:286-288),
+#   - the contained flags of the LAST pass are what --remove-contained applies (:289-301).
+# ------------------------------------------------------------------------------------------------------------------------------
+def select_pairs(order, grp_sorted, q_st, q_en):
+    """One pass of pair selection.  order: record indices stably sorted by query name; grp_sorted: the dense group id of each record in that
+    order (non-decreasing).  Returns (left, right, unseen, contained) with left/right as RECORD indices."""
+    n = len(order)
+    contained = np.zeros(n, bool)              # by position in `order`
+    if n < 2:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint32), 0, contained
+    qs, qe = q_st[order].astype(np.int64), q_en[order].astype(np.int64)
+    start = np.flatnonzero(np.r_[True, grp_sorted[1:] != grp_sorted[:-1]])
+    size = np.diff(np.r_[start, n])
+    pos_in = np.arange(n) - np.repeat(start, size)
+    left_room = np.repeat(size, size) - pos_in - 1   # records of the same name behind this one
+    ci, cj, cov = [], [], []
+    for d in range(1, int(size.max())):
+        i = np.flatnonzero(left_room >= d)
+        j = i + d
+        ov = np.minimum(qe[i], qe[j]) - np.maximum(qs[i], qs[j])
+        keep = ov >= 1
+        i, j, ov = i[keep], j[keep], ov[keep]
+        c2 = ov == (qe[j] - qs[j])
+        c1 = ~c2 & (ov == (qe[i] - qs[i]))
+        contained[j[c2]] = True
+        contained[i[c1]] = True
+        cand = ~(c1 | c2)
+        ci.append(i[cand]); cj.append(j[cand]); cov.append(ov[cand])
+    if not ci:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint32), 0, contained
+    ci, cj, cov = np.concatenate(ci), np.concatenate(cj), np.concatenate(cov)
+    if len(ci) == 0:
+        return np.zeros(0, np.uint32), np.zeros(0, np.uint32), 0, contained
+    # the reference pushes candidates in (i, j) order and stable-sorts by overlap descending; the first of every name wins
+    k = np.lexsort((cj, ci, -cov, grp_sorted[ci]))
+    g = grp_sorted[ci][k]
+    first = np.r_[True, g[1:] != g[:-1]]
+    sel = k[first]
+    i, j = ci[sel], cj[sel]
+    swap = qs[i] > qs[j]
+    li, ri = np.where(swap, j, i), np.where(swap, i, j)
+    return order[li].astype(np.uint32), order[ri].astype(np.uint32), int(len(ci) - len(sel)), contained
+
+
+class ResidentTrim:
+    """trim-paf over a batch that stays in HBM.  `torch` supplies device memory; all compute goes through the C ABI."""
+
+    def __init__(self, eng, torch, dev, ops, op_off, t_st, t_en, q_st, q_en, strand, group, room_factor=3.0):
+        self.eng, self.torch, self.dev = eng, torch, dev
+        self.n = len(op_off) - 1
+        n_ops = int(op_off[-1])
+        self.n_ops0 = n_ops
+        cap = int(n_ops * (1.0 + room_factor)) + 4096
+        self.d_ops = torch.zeros(cap + 64, dtype=torch.int32, device=dev)   # [original ops | room for the clips of the passes]
+        if isinstance(ops, np.ndarray):
+            self.d_ops[:n_ops] = torch.from_numpy(np.ascontiguousarray(ops, dtype=np.uint32).view(np.int32)).to(dev)
+        else:
+            self.d_ops[:n_ops] = ops[:n_ops]                                # (a device tensor already)
+        self.cap, self.cursor = cap, (n_ops + 31) // 32 * 32
+        i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).to(dev)  # noqa: E731
+        self.d_off = i64(op_off)
+        self.d_c = [i64(x) for x in (t_st, t_en, q_st, q_en)]
+        self.d_strand = torch.from_numpy(np.ascontiguousarray(strand, dtype=np.uint8)).to(dev)
+        self.d_contig = torch.zeros(self.n, dtype=torch.int32, device=dev)
+        self.d_norm = torch.zeros(max(self.n, 1) * 64, dtype=torch.uint8, device=dev)
+        self.view = eng.batch_view(self.n, n_ops, self.d_ops.data_ptr(), self.d_off.data_ptr(), *[x.data_ptr() for x in self.d_c],
+                                   self.d_strand.data_ptr(), self.d_contig.data_ptr())
+        torch.cuda.synchronize()
+        eng.dev_scan_records(self.view, 0, self.d_norm.data_ptr())            # remove_trailing_indels + check_integrity, once
+        torch.cuda.synchronize()
+        norm = self.d_norm.cpu().numpy().view(capi.NORM_DT)[:self.n]
+        if (norm["status"] != 0).any():
+            raise RuntimeError("remove_trailing_indels / check_integrity: the reference panics on this input")
+        self.q_st, self.q_en = norm["q_st"].astype(np.uint64), norm["q_en"].astype(np.uint64)
+        self.cur_n = norm["n_ops"].astype(np.uint64)
+        group = np.asarray(group)
+        self.order = np.argsort(group, kind="stable")
+        gs = group[self.order]
+        self.grp_sorted = np.cumsum(np.r_[0, gs[1:] != gs[:-1]])
+        self.passes, self.pairs_done = 0, 0
+
+    def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000):
+        torch, eng, dev = self.torch, self.eng, self.dev
+        for _ in range(max_passes):
+            left, right, unseen, contained = select_pairs(self.order, self.grp_sorted, self.q_st, self.q_en)
+            self.passes += 1
+            if len(left):
+                need = self.cur_n[left] + self.cur_n[right]
+                poff = self.cursor + np.r_[0, np.cumsum(need)[:-1]].astype(np.uint64)
+                end = int(self.cursor + need.sum())
+                if end > self.cap:
+                    raise RuntimeError("ResidentTrim: out of room for the clips (raise room_factor)")
+                d_l = torch.from_numpy(left.view(np.int32)).to(dev)
+                d_r = torch.from_numpy(right.view(np.int32)).to(dev)
+                d_po = torch.from_numpy(poff.view(np.int64)).to(dev)
+                d_rows = torch.empty(len(left) * 128, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()
+                eng.dev_overlap_split(self.view, self.d_norm.data_ptr(), len(left), d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), scores, policy,
+                                      d_rows.data_ptr(), self.d_ops.data_ptr())
+                eng.dev_apply_pairs(len(left), d_l.data_ptr(), d_r.data_ptr(), d_rows.data_ptr(), self.d_off.data_ptr(), self.d_norm.data_ptr())
+                torch.cuda.synchronize()
+                r64 = d_rows.view(torch.int64).view(len(left), 16)
+                # what the host keeps track of: status, the new query spans and lengths (a few columns of the 128-byte rows)
+                st = (r64[:, 1] >> 32).cpu().numpy()
+                if (st != 0).any():
+                    raise RuntimeError(f"trim pair status {int(st[st != 0][0])}: the reference panics")
+                qcols = r64[:, 6:10].cpu().numpy().view(np.uint64)            # q_st[2], q_en[2]
+                outn = r64[:, 14].cpu().numpy().view(np.uint32).reshape(-1, 2)
+                self.q_st[left], self.q_st[right] = qcols[:, 0], qcols[:, 1]
+                self.q_en[left], self.q_en[right] = qcols[:, 2], qcols[:, 3]
+                self.cur_n[left], self.cur_n[right] = outn[:, 0], outn[:, 1]
+                self.cursor = (end + 31) // 32 * 32
+                self.pairs_done += len(left)
+            if unseen > 0:
+                continue
+            self.contained = np.zeros(self.n, bool)
+            self.contained[self.order] = contained
+            return self
+        raise RuntimeError("trim-paf did not converge")
+
+    def gather(self):
+        """The current records as a dense batch: (d_new_ops, new_op_off host, norm rows host)."""
+        torch, eng, dev = self.torch, self.eng, self.dev
+        d_new_off = torch.zeros(self.n + 1, dtype=torch.int64, device=dev)
+        scratch = torch.empty(eng.text_scratch_bytes(self.n) + 64, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.dev_gather_records(self.n, self.d_ops.data_ptr(), self.d_off.data_ptr(), self.d_norm.data_ptr(), d_new_off.data_ptr(), 0, scratch.data_ptr())
+        torch.cuda.synchronize()
+        total = int(d_new_off[self.n].item())
+        d_new = torch.zeros(total + 64, dtype=torch.int32, device=dev)
+        eng.dev_gather_records(self.n, self.d_ops.data_ptr(), self.d_off.data_ptr(), self.d_norm.data_ptr(), d_new_off.data_ptr(), d_new.data_ptr(),
+                               scratch.data_ptr())
+        torch.cuda.synchronize()
+        norm = self.d_norm.cpu().numpy().view(capi.NORM_DT)[:self.n].copy()
+        return d_new, d_new_off.cpu().numpy().view(np.uint64), norm

@@ -28,6 +28,25 @@ class DevBatch:
                                    self.d_strand.data_ptr(), self.d_contig.data_ptr())
         self.d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
 
+    @classmethod
+    def from_device(cls, torch, eng, dev, d_ops, n_ops, op_off_host, d_coords, d_strand):
+        """a batch whose arrays are already in HBM (d_ops int32 with readable slack behind n_ops, d_coords = [t_st, t_en, q_st, q_en] int64)"""
+        self = cls.__new__(cls)
+        self.torch, self.eng, self.dev = torch, eng, dev
+        self.n_rec, self.n_ops = len(op_off_host) - 1, int(n_ops)
+        self.op_off_host = np.ascontiguousarray(op_off_host, dtype=np.uint64)
+        self.contig_host = np.zeros(self.n_rec, np.uint32)
+        self.d_ops = d_ops
+        self.d_off = _i64(torch, dev, self.op_off_host)
+        self.d_c = d_coords
+        self.d_strand = d_strand
+        self.d_contig = torch.zeros(self.n_rec, dtype=torch.int32, device=dev)
+        self.d_norm = torch.zeros(max(self.n_rec, 1) * 64, dtype=torch.uint8, device=dev)
+        self.view = eng.batch_view(self.n_rec, self.n_ops, self.d_ops.data_ptr(), self.d_off.data_ptr(), *[x.data_ptr() for x in self.d_c],
+                                   self.d_strand.data_ptr(), self.d_contig.data_ptr())
+        self.d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
+        return self
+
     def run(self, windows=None, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN, max_size=None, rows_cap=None, out_cap=None):
         """liftover over `windows` = (w_contig, w_st, w_en), or break-paf when max_size is given.  Returns (rows tensor [n, 16] int32,
         out tensor, counters) with the buffers left on the device."""

@@ -276,17 +276,14 @@ def test_full_size_nucfreq_checksums():
     eng.close()
 
 
-def test_full_size_break_paf_integrity():
-    """break-paf --max-size 100 on the same 1e6 records: every piece passes check_integrity, pieces of a record come in target order
-    and do not overlap, and no piece contains an insertion or deletion longer than the limit"""
-    C = _config3(is_break=True)
-    torch, dev, eng, run, n_rec, total_ops = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops"))
-    rows, out = run(rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN, 8 * n_rec, int(1.4 * total_ops))
+def _check_break_rows(torch, dev, rows, out, n_rec):
+    """every piece passes check_integrity, pieces of a record come in target order and do not overlap, and no piece contains an
+    insertion or deletion longer than the limit (100)"""
     n = rows.shape[0]
-    assert n > 2 * n_rec and int((rows[:, 0] == -286331154).sum()) == 0
+    assert n >= n_rec and int((rows[:, 0] == -286331154).sum()) == 0
     st = rows[:, 2] & 0xFFFF
     ok = st == 0
-    assert int((st >= 16).sum()) == 0 and int((~ok).sum()) < n // 10000   # a few pieces are None in the reference too (liftover.rs:52-102); nothing panics
+    assert int((st >= 16).sum()) == 0 and int((~ok).sum()) < max(n // 10000, 4)   # a few pieces are None in the reference too (liftover.rs:52-102); nothing panics
     rows = rows[ok]
     words, off, out_n = _check_integrity(torch, dev, rows, out)
     rec = rows[:, 0].to(torch.int64) & 0xFFFFFFFF
@@ -297,4 +294,126 @@ def test_full_size_break_paf_integrity():
     big = (((words & 15) == 1) | ((words & 15) == 2)) & ((words >> 4) > 100)
     P = torch.cumsum(big, 0, dtype=torch.int64)
     assert int(_seg(P, off, off + out_n).sum()) == 0
+    return rows
+
+
+def test_full_size_break_paf_integrity():
+    """break-paf --max-size 100 on the same 1e6 records: every piece passes check_integrity, pieces of a record come in target order
+    and do not overlap, and no piece contains an insertion or deletion longer than the limit"""
+    C = _config3(is_break=True)
+    torch, dev, eng, run, n_rec, total_ops = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops"))
+    rows, out = run(rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN, 8 * n_rec, int(1.4 * total_ops))
+    assert rows.shape[0] > 2 * n_rec
+    _check_break_rows(torch, dev, rows, out, n_rec)
+    eng.close()
+
+
+def test_full_size_config4_trim_paf_then_break_paf(oracle, tmp_path):
+    """BASELINE.json configs[3]: trim-paf (scores 1,1,1) -> break-paf --max-size 100 on 1e7 synthetic records
+    (300-700 ops, 5e9 ops; 4 records per query whose consecutive query spans overlap by U[100, 10000] bases).  The batch stays in HBM
+    from the first byte to the last: the passes of Paf::overlapping_paf_recs run over it in place (trim_driver.ResidentTrim:
+    rb_dev_overlap_split + rb_dev_apply_pairs), rb_dev_gather_records makes it dense, rb_dev_break cuts it.  Properties that need no
+    oracle: no two records of a query overlap any more, every record still passes check_integrity and lies inside the record it
+    came from, every piece of break-paf passes the checks of the config-3 test; and the oracle CLI on the first query groups,
+    line by line, for both commands."""
+    import torch
+    from devutil import DevBatch
+    from rbtest_util import unpack
+    from rustybam_amd import capi, trim_driver
+    n = int(os.environ.get("RB_FULLSIZE_C4_RECORDS", "10000000")) // 4 * 4
+    seed = 0x5EED0004
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    nops = wl.n_ops(seed, 0, n, 300, 700)
+    op_off = wl.op_offsets(nops)
+    total_ops = int(op_off[-1])
+    i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    d_off = i64(op_off)
+    d_ops = torch.empty(total_ops + 64, dtype=torch.int32, device=dev)
+    eng.dev_synth_fill_ops(seed, 0, n, d_off.data_ptr(), d_ops.data_ptr())
+    zeros = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_strand0 = torch.full((n,), ord("+"), dtype=torch.uint8, device=dev)
+    d_contig = torch.zeros(n, dtype=torch.int32, device=dev)
+    d_red = torch.empty(n * 72, dtype=torch.uint8, device=dev)
+    v0 = eng.batch_view(n, total_ops, d_ops.data_ptr(), d_off.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), zeros.data_ptr(),
+                        d_strand0.data_ptr(), d_contig.data_ptr())
+    torch.cuda.synchronize()
+    eng.dev_scan_records(v0, d_red.data_ptr(), 0)
+    torch.cuda.synchronize()
+    red = d_red.cpu().numpy().view(rustybam_amd.REDUCE_DT)
+    tb, qb = red["t_bases"].astype(np.uint64), red["q_bases"].astype(np.uint64)
+    del d_red, red
+    rng = np.random.default_rng(seed)
+    q_st = np.zeros(n, np.uint64)
+    ov = rng.integers(100, 10001, n).astype(np.uint64)
+    for j in range(1, 4):       # each record starts `ov` bases before the previous one of its query ends (nothing contained)
+        prev_en = q_st[j - 1::4] + qb[j - 1::4]
+        q_st[j::4] = prev_en - np.minimum(ov[j::4], np.minimum(qb[j - 1::4], qb[j::4]) // np.uint64(2))
+    q_en = q_st + qb
+    t_st = rng.integers(0, 200_000_000, n).astype(np.uint64)
+    t_en = t_st + tb
+    strand = np.where(rng.integers(0, 2, n) == 0, ord("+"), ord("-")).astype(np.uint8)
+    group = np.arange(n) // 4
+    T = trim_driver.ResidentTrim(eng, torch, dev, d_ops, op_off, t_st, t_en, q_st, q_en, strand, group, room_factor=1.6)
+    del d_ops
+    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN)
+    assert T.passes == 3 and T.pairs_done == 3 * (n // 4)         # (0,1) (1,2) (2,3) of every query, one per pass
+    # ---- no overlap left inside a query ----
+    qs, qe = T.q_st.reshape(-1, 4).astype(np.int64), T.q_en.reshape(-1, 4).astype(np.int64)
+    assert (qe[:, :-1] <= qs[:, 1:]).all() and (qs < qe).all()
+    assert (qs >= q_st.reshape(-1, 4).astype(np.int64)).all() and (qe <= q_en.reshape(-1, 4).astype(np.int64)).all()
+    d_new, new_off, norm = T.gather()
+    assert (norm["status"] == 0).all() and int(new_off[-1]) <= total_ops
+    assert (norm["t_st"] >= t_st).all() and (norm["t_en"] <= t_en).all() and (norm["q_st"] == T.q_st).all() and (norm["q_en"] == T.q_en).all()
+    # ---- check_integrity of every trimmed record, from segment sums over the dense ops ----
+    fake = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+    dn = torch.from_numpy(norm.view(np.uint8).reshape(n, 64).view(np.int32).copy()).to(dev)     # norm rows as 16 int32 columns
+    fake[:, 3] = dn[:, 9]                                   # out_n = n_ops
+    fake[:, 4:12] = dn[:, 0:8]                              # t_st, t_en, q_st, q_en
+    fake[:, 12], fake[:, 13] = dn[:, 12], dn[:, 13]         # nmatch, aln_len
+    offs = torch.from_numpy(new_off[:-1].view(np.int64).copy()).to(dev)
+    fake[:, 14], fake[:, 15] = (offs & 0xFFFFFFFF).to(torch.int32), (offs >> 32).to(torch.int32)
+    _check_integrity(torch, dev, fake, d_new)
+    del fake, dn
+    # ---- break-paf --max-size 100 on the trimmed batch ----
+    d_c = [torch.from_numpy(np.ascontiguousarray(norm[k]).view(np.int64)).to(dev) for k in ("t_st", "t_en", "q_st", "q_en")]
+    B = DevBatch.from_device(torch, eng, dev, d_new, int(new_off[-1]), new_off, d_c, torch.from_numpy(strand).to(dev))
+    T.d_ops = None
+    torch.cuda.empty_cache()
+    rows, out, cnt = B.run(None, max_size=100, rows_cap=4 * n)
+    rows_ok = _check_break_rows(torch, dev, rows, out, n)
+    # ---- the oracle CLI on the first query groups: trim-paf, then break-paf of its output ----
+    k = 4 * 120
+    so = wl.op_offsets(nops[:k])
+    sops = capi.synth_fill_ops_host(seed, 0, so)
+    paf = tmp_path / "c4.paf"
+    with open(paf, "w") as f:
+        for r in range(k):
+            cg = unpack(sops[int(so[r]):int(so[r + 1])])
+            f.write(f"q{r // 4:07d}\t{int(q_en[r // 4 * 4 + 3]) + 1000}\t{int(q_st[r])}\t{int(q_en[r])}\t{chr(strand[r])}\tchr1\t250000000\t"
+                    f"{int(t_st[r])}\t{int(t_en[r])}\t0\t0\t60\tcg:Z:{cg}\n")
+    rc, otrim = oracle.cli("trim-paf", paf)
+    assert rc == 0
+    new_ops = d_new[:int(new_off[k])].cpu().numpy().view(np.uint32)
+    mine = []
+    for r in range(k):                                            # (names sort like the record numbers: q0000000, q0000001, ...)
+        cg = unpack(new_ops[int(new_off[r]):int(new_off[r + 1])])
+        mine.append(f"q{r // 4:07d}\t{int(q_en[r // 4 * 4 + 3]) + 1000}\t{int(norm['q_st'][r])}\t{int(norm['q_en'][r])}\t{chr(strand[r])}\tchr1\t250000000\t"
+                    f"{int(norm['t_st'][r])}\t{int(norm['t_en'][r])}\t{int(norm['nmatch'][r])}\t{int(norm['aln_len'][r])}\t60\tid:Z:\tcg:Z:{cg}\n")
+    assert "".join(mine).encode() == otrim
+    trimmed = tmp_path / "c4_trim.paf"
+    trimmed.write_bytes(otrim)
+    rc, obreak = oracle.cli("break-paf", "--max-size", "100", trimmed)
+    assert rc == 0
+    hr = rows_ok[(rows_ok[:, 0].to(torch.int64) & 0xFFFFFFFF) < k].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
+    allr = rows[(rows[:, 0].to(torch.int64) & 0xFFFFFFFF) < k].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
+    assert len(allr) >= len(hr)
+    mine = []
+    for h in hr:
+        r = int(h["rec"])
+        cg = unpack(out[int(h["out_off"]):int(h["out_off"]) + int(h["out_n"])].cpu().numpy().view(np.uint32))
+        mine.append(f"q{r // 4:07d}\t{int(q_en[r // 4 * 4 + 3]) + 1000}\t{int(h['q_st'])}\t{int(h['q_en'])}\t{chr(strand[r])}\tchr1\t250000000\t"
+                    f"{int(h['t_st'])}\t{int(h['t_en'])}\t{int(h['nmatch'])}\t{int(h['aln_len'])}\t60\tid:Z:\tcg:Z:{cg}\n")
+    assert "".join(mine).encode() == obreak
     eng.close()

@@ -154,6 +154,44 @@ def test_trim_paf_fixture_end_to_end(engine, golden, policy, key):
     assert hashlib.md5("".join(lines).encode()).hexdigest() == dig
 
 
+@pytest.mark.parametrize("policy,key", [(rustybam_amd.BSEARCH_MODERN, "trim_paf_modern"),
+                                        (rustybam_amd.BSEARCH_LEGACY, "trim_paf_legacy")])
+def test_trim_paf_fixture_with_the_batch_resident_on_the_device(golden, policy, key):
+    """the same file through trim_driver.ResidentTrim: the batch is uploaded once, every pass cuts its pairs in place
+    (rb_dev_overlap_split writing behind the ops, rb_dev_apply_pairs), only pair lists and a few row columns cross PCIe, and
+    rb_dev_gather_records makes the result a dense batch again.  Same digest as the oracle CLI."""
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    r = read_paf(os.path.join(golden, "asm_small.paf"))
+    names = {}
+    group = np.array([names.setdefault(q, len(names)) for q in r.q_name])
+    rank = {q: i for i, q in enumerate(sorted(names))}           # groups in the order of the names (the reference sorts by name)
+    group = np.array([rank[q] for q in r.q_name])
+    T = trim_driver.ResidentTrim(eng, torch, dev, r.ops, r.op_off, r.t_st, r.t_en, r.q_st, r.q_en, r.strand, group)
+    norm0 = T.d_norm.cpu().numpy().view(rustybam_amd.NORM_DT)[:r.n].copy()
+    T.run((1, 1, 1), policy)
+    assert T.passes >= 2 and T.pairs_done > 100
+    d_new, new_off, norm = T.gather()
+    ops = d_new.cpu().numpy().view(np.uint32)
+    lines = []
+    for i in T.order:
+        rid = ""
+        if norm0[i]["lead_ops"] or norm0[i]["trail_ops"]:
+            c = r.cigars[i]
+            lead, trail = c[:norm0[i]["lead_ops"]], c[len(c) - norm0[i]["trail_ops"]:][::-1]
+            rid = f"_TO.{unpack(lead)}.{unpack(trail)}"
+        cg = ops[int(new_off[i]):int(new_off[i + 1])]
+        lines.append("\t".join(map(str, [r.q_name[i], r.q_len[i], int(norm[i]["q_st"]), int(norm[i]["q_en"]), chr(r.strand[i]), r.t_name[i],
+                                          r.t_len[i], int(norm[i]["t_st"]), int(norm[i]["t_en"]), int(norm[i]["nmatch"]), int(norm[i]["aln_len"]),
+                                          r.mapq[i], "id:Z:" + rid, "cg:Z:" + unpack(cg)])) + "\n")
+    dig = json.load(open(os.path.join(golden, "digests.json")))[key]["md5"]
+    assert len(lines) == 249
+    assert hashlib.md5("".join(lines).encode()).hexdigest() == dig
+    eng.close()
+
+
 @pytest.mark.parametrize("policy", [rustybam_amd.BSEARCH_MODERN, rustybam_amd.BSEARCH_LEGACY])
 def test_pairs_unsorted_qpos_array(engine, oracle, policy):
     """q_st == 0 on '+' with a leading op that consumes no query: qpos_aln starts at q_pos = -1 (u64::MAX) and is not sorted;
