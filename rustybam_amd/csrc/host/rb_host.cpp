@@ -908,6 +908,205 @@ bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_le
     return true;
 }
 
+// main.rs:218-230 (trim-paf), text in -> text out with the batch resident on the device across the passes of
+// Paf::overlapping_paf_recs (paf.rs:210-305): the file's cg:Z: values are parsed on the device once; every pass picks its pairs on
+// the host from three small arrays (query group, q_st, q_en), cuts them in place (rb_dev_overlap_split writing behind the ops in use,
+// rb_dev_apply_pairs) and brings back the pair rows; the CIGARs are printed by the device at the end.  false = the caller takes the
+// record-based path (a file the text loader declines, or not enough room for the clips of an unusually long run of passes).
+bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, int diff_score, int indel_score, bool remove_contained,
+                    std::vector<std::string> &out_text) {
+    TextFile &f = *new TextFile; // (one-shot command: left to the end of the process, like the buffers of the other text routes)
+    if (!f.load(paf_path)) return false;
+    double tl = now_s();
+    const size_t n = f.recs.size();
+    if (n == 0) {
+        out_text.clear();
+        return true;
+    }
+    rb_ctx *ctx = eng.ctx();
+    struct Dev { // device allocations of this call
+        rb_ctx *ctx;
+        std::vector<void *> owned;
+        ~Dev() { for (void *q : owned) rb_dev_free(ctx, q); }
+        void *take(Engine &e, size_t bytes) {
+            void *d = nullptr;
+            e.check(rb_dev_alloc(ctx, bytes + 256, &d), "rb_dev_alloc");
+            owned.push_back(d);
+            return d;
+        }
+    } D{ctx, {}};
+    auto up = [&](const void *host, size_t bytes) {
+        void *d = D.take(eng, bytes);
+        if (bytes) eng.check(rb_dev_upload(ctx, d, host, bytes), "rb_dev_upload");
+        return d;
+    };
+    uint64_t cig_bytes = 0;
+    for (size_t r = 0; r < n; r++) cig_bytes += f.cig_end[r] - f.cig_off[r];
+    const uint64_t ops_bound = cig_bytes / 2 + 8;        // an op is at least two characters
+    const uint64_t ops_cap = 3 * ops_bound + 4096;       // the file's ops + room for the clips of the passes (every pass rewrites at most all of them)
+    uint8_t *d_text = (uint8_t *)up(f.all.data(), f.text_bytes + 32 <= f.all.size() ? f.text_bytes : f.text_bytes);
+    const uint64_t *d_coff = (const uint64_t *)up(f.cig_off.data(), n * 8), *d_cend = (const uint64_t *)up(f.cig_end.data(), n * 8);
+    uint64_t *d_opoff = (uint64_t *)D.take(eng, (n + 2) * 8);
+    uint32_t *d_ops = (uint32_t *)D.take(eng, (size_t)ops_cap * 4);
+    uint8_t *d_status = (uint8_t *)D.take(eng, n + 1);
+    void *d_scr = D.take(eng, rb_text_scratch_bytes(std::max<uint64_t>(n, 2 * n)));
+    eng.check(rb_dev_parse_cigars(ctx, d_text, d_coff, d_cend, n, d_opoff, d_ops, ops_bound, d_status, d_scr), "rb_dev_parse_cigars");
+    std::vector<uint8_t> cig_status(n);
+    eng.check(rb_dev_download(ctx, cig_status.data(), d_status, n), "rb_dev_download");
+    std::vector<uint64_t> op_off(n + 1);
+    eng.check(rb_dev_download(ctx, op_off.data(), d_opoff, (n + 1) * 8), "rb_dev_download");
+    rb_batch_view v;
+    v.n_rec = n, v.n_ops = op_off[n], v.ops = d_ops, v.op_off = d_opoff;
+    v.t_st = (const uint64_t *)up(f.t_st.data(), n * 8), v.t_en = (const uint64_t *)up(f.t_en.data(), n * 8);
+    v.q_st = (const uint64_t *)up(f.q_st.data(), n * 8), v.q_en = (const uint64_t *)up(f.q_en.data(), n * 8);
+    v.strand = (const uint8_t *)up(f.strand.data(), n), v.contig = (const uint32_t *)up(f.contig.data(), n * 4);
+    rb_reduce_row *d_red = (rb_reduce_row *)D.take(eng, n * sizeof(rb_reduce_row));
+    rb_norm_row *d_norm = (rb_norm_row *)D.take(eng, n * sizeof(rb_norm_row));
+    bool all_ok = true;
+    for (size_t r = 0; r < n; r++) all_ok &= cig_status[r] == RB_TEXT_OK;
+    std::vector<rb_reduce_row> red(n);
+    std::vector<rb_norm_row> norm(n);
+    if (all_ok) {
+        eng.check(rb_dev_scan_records(ctx, &v, d_red, d_norm), "rb_dev_scan_records");
+        eng.check(rb_dev_download(ctx, red.data(), d_red, n * sizeof(rb_reduce_row)), "rb_dev_download");
+        eng.check(rb_dev_download(ctx, norm.data(), d_norm, n * sizeof(rb_norm_row)), "rb_dev_download");
+    }
+    if (!f.check_loaded(cig_status, red)) return false;                                  // the panics of Paf::from_file, in its order
+    for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "remove_trailing_indels", i); // paf.rs:218-220
+    lap("  text -> ops, scan (device)", tl);
+    // what the host tracks per record: its current place and length in d_ops, its current coordinates
+    struct Cur { uint64_t off, t_st, t_en, q_st, q_en; uint32_t n, nmatch, aln_len; };
+    std::vector<Cur> cur(n);
+    for (size_t i = 0; i < n; i++)
+        cur[i] = {op_off[i] + norm[i].first_op, norm[i].t_st, norm[i].t_en, norm[i].q_st, norm[i].q_en, norm[i].n_ops, norm[i].nmatch, norm[i].aln_len};
+    // records stably ordered by query name (:223); a group = a run of equal names
+    std::vector<uint32_t> order(n);
+    std::iota(order.begin(), order.end(), 0u);
+    auto qname = [&](uint32_t i) { return f.name(f.recs[i].q_name, f.recs[i].q_name_n); };
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return qname(a) < qname(b); });
+    std::vector<uint32_t> grp_end(n); // for position p in `order`: one past the last position of its group
+    for (size_t p0 = 0; p0 < n;) {
+        size_t p1 = p0 + 1;
+        while (p1 < n && qname(order[p1]) == qname(order[p0])) p1++;
+        for (size_t q = p0; q < p1; q++) grp_end[q] = (uint32_t)p1;
+        p0 = p1;
+    }
+    lap("  sort by query name", tl);
+    uint64_t cursor = (v.n_ops + 31) & ~(uint64_t)31;
+    std::vector<char> contained(n, 0); // by position in `order`
+    uint32_t *d_left = (uint32_t *)D.take(eng, n * 4), *d_right = (uint32_t *)D.take(eng, n * 4);
+    uint64_t *d_poff = (uint64_t *)D.take(eng, n * 8);
+    rb_pair_row *d_rows = (rb_pair_row *)D.take(eng, (n / 2 + 1) * sizeof(rb_pair_row));
+    for (int pass = 0;; pass++) {
+        if (pass > 100000) throw Panic("trim-paf did not converge");
+        std::fill(contained.begin(), contained.end(), 0);
+        struct Pair { uint64_t overlap; uint32_t i, j, first; }; // positions in `order` (left, right) and the first position of the pair's group
+        std::vector<Pair> pairs;
+        for (size_t pi = 0; pi + 1 < n; pi++) { // :231-261
+            const Cur &r1 = cur[order[pi]];
+            for (size_t pj = pi + 1; pj < grp_end[pi]; pj++) {
+                const Cur &r2 = cur[order[pj]];
+                const uint64_t mn = std::min(r1.q_en, r2.q_en), mx = std::max(r1.q_st, r2.q_st);
+                const uint64_t ov = mn < mx ? 0 : mn - mx;
+                if (ov < 1) continue;
+                if (ov == r2.q_en - r2.q_st) contained[pj] = 1;
+                else if (ov == r1.q_en - r1.q_st) contained[pi] = 1;
+                else if (r1.q_st <= r2.q_st) pairs.push_back({ov, (uint32_t)pi, (uint32_t)pj, 0});
+                else pairs.push_back({ov, (uint32_t)pj, (uint32_t)pi, 0});
+            }
+        }
+        std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &b) { return a.overlap > b.overlap; }); // :262
+        std::vector<char> seen(n, 0); // by the group's first position
+        std::vector<uint32_t> left, right;
+        std::vector<uint64_t> poff;
+        size_t unseen = 0;
+        uint64_t room = cursor;
+        for (const Pair &pr : pairs) { // :266-284: one pair per query name per pass
+            // (the group of a position: all positions p with grp_end[p] equal)
+            const uint32_t g = grp_end[pr.i];
+            if (!seen[g - 1]) {
+                seen[g - 1] = 1;
+                left.push_back(order[pr.i]), right.push_back(order[pr.j]);
+                poff.push_back(room);
+                room += (uint64_t)cur[order[pr.i]].n + cur[order[pr.j]].n;
+            } else {
+                unseen++;
+            }
+        }
+        if (room + 64 > ops_cap) return false; // (nothing has been printed: the record-based path starts over)
+        if (!left.empty()) {
+            const size_t np = left.size();
+            eng.check(rb_dev_upload(ctx, d_left, left.data(), np * 4), "rb_dev_upload");
+            eng.check(rb_dev_upload(ctx, d_right, right.data(), np * 4), "rb_dev_upload");
+            eng.check(rb_dev_upload(ctx, d_poff, poff.data(), np * 8), "rb_dev_upload");
+            eng.check(rb_dev_overlap_split(ctx, &v, d_norm, np, d_left, d_right, d_poff, match_score, diff_score, indel_score, eng.bsearch_policy,
+                                           d_rows, d_ops),
+                      "rb_dev_overlap_split");
+            eng.check(rb_dev_apply_pairs(ctx, np, d_left, d_right, d_rows, d_opoff, d_norm), "rb_dev_apply_pairs");
+            std::vector<rb_pair_row> rows(np);
+            eng.check(rb_dev_download(ctx, rows.data(), d_rows, np * sizeof(rb_pair_row)), "rb_dev_download"); // (synchronises: the uploads above are done with their vectors)
+            for (size_t k = 0; k < np; k++) {
+                if (rows[k].status != RB_ST_OK) throw Panic("trim_overlapping_pafs: pair " + std::to_string(k) + " status " + std::to_string(rows[k].status));
+                const uint32_t idx[2] = {left[k], right[k]};
+                for (int s2 = 0; s2 < 2; s2++)
+                    cur[idx[s2]] = {rows[k].out_off[s2], rows[k].t_st[s2], rows[k].t_en[s2], rows[k].q_st[s2], rows[k].q_en[s2], rows[k].out_n[s2],
+                                    rows[k].nmatch[s2], rows[k].aln_len[s2]};
+            }
+            cursor = (room + 31) & ~(uint64_t)31;
+        }
+        lap("  pass (pairs on the host, split + clip on the device)", tl);
+        if (unseen == 0) break; // :286-288
+    }
+    // ---- print: kept records in the sorted order, CIGAR text from the device ----
+    std::vector<uint32_t> keep;
+    keep.reserve(n);
+    for (size_t p0 = 0; p0 < n; p0++)
+        if (!(remove_contained && contained[p0])) keep.push_back(order[p0]); // :289-301 (the flags of the last pass)
+    const size_t nk = keep.size();
+    std::vector<uint64_t> first(nk);
+    std::vector<uint32_t> count(nk);
+    uint64_t out_ops_total = 0;
+    for (size_t k = 0; k < nk; k++) first[k] = cur[keep[k]].off, count[k] = cur[keep[k]].n, out_ops_total += count[k];
+    const uint64_t *d_first = (const uint64_t *)up(first.data(), nk * 8);
+    const uint32_t *d_count = (const uint32_t *)up(count.data(), nk * 4);
+    uint64_t *d_toff = (uint64_t *)D.take(eng, (nk + 2) * 8);
+    const uint64_t text_cap = 11 * out_ops_total + 16;
+    uint8_t *d_out = (uint8_t *)D.take(eng, text_cap);
+    eng.check(rb_dev_format_cigars(ctx, d_ops, nullptr, nk, d_first, d_count, nullptr, nullptr, d_toff, d_out, text_cap, d_scr), "rb_dev_format_cigars");
+    std::vector<uint64_t> &toff = *new std::vector<uint64_t>(nk + 1);
+    eng.check(rb_dev_download(ctx, toff.data(), d_toff, (nk + 1) * 8), "rb_dev_download");
+    std::vector<uint8_t> &text = *new std::vector<uint8_t>((size_t)toff[nk] + 1);
+    if (toff[nk]) eng.check(rb_dev_download(ctx, text.data(), d_out, (size_t)toff[nk]), "rb_dev_download");
+    lap("  print cigars (device) + D2H", tl);
+    const unsigned TO = parallel_chunk_count(nk);
+    out_text.assign(TO, std::string());
+    parallel_chunks(nk, [&](unsigned t, size_t lo, size_t hi) {
+        std::string &o = out_text[t];
+        size_t est = 0;
+        for (size_t k = lo; k < hi; k++) est += 160 + (size_t)(toff[k + 1] - toff[k]);
+        o.reserve(est);
+        char nb[24];
+        auto num = [&](uint64_t x) {
+            auto r = std::to_chars(nb, nb + sizeof nb, x);
+            o.append(nb, r.ptr);
+        };
+        for (size_t k = lo; k < hi; k++) {
+            const uint32_t i = keep[k];
+            const HeaderOnly &s = f.recs[i];
+            const Cur &c = cur[i];
+            o.append(f.all.data() + s.q_name, s.q_name_n); o += '\t'; num(s.q_len); o += '\t'; num(c.q_st); o += '\t'; num(c.q_en); o += '\t';
+            o += s.strand; o += '\t'; o.append(f.all.data() + s.t_name, s.t_name_n); o += '\t'; num(s.t_len); o += '\t'; num(c.t_st); o += '\t';
+            num(c.t_en); o += '\t'; num(c.nmatch); o += '\t'; num(c.aln_len); o += '\t'; num(s.mapq); o += "\tid:Z:";
+            o += f.stripped_suffix(i, norm[i]);
+            o += "\tcg:Z:";
+            o.append((const char *)text.data() + toff[k], (size_t)(toff[k + 1] - toff[k]));
+            o += '\n';
+        }
+    });
+    lap("  assemble lines", tl);
+    return true;
+}
+
 // main.rs:50-58 (stats --paf), text in -> stats lines
 bool stats_file_text(Engine &eng, const std::string &paf_path, bool qbed, std::vector<std::string> &out_text) {
     TextFile f;

@@ -254,6 +254,14 @@ int main(int argc, char **argv) {
             if (do_scaffold) paf.scaffold(insert);
             put(rb::records_to_text(paf.records));
         } else if (trim) {
+            std::vector<std::string> ttext;
+            if (text_path && rb::trim_file_text(eng, paf_path, ms, ds, is, remove_contained, ttext)) {
+                lap("trim-paf (text to text)", tl);
+                put(ttext);
+                fflush(stdout);
+                lap("write", tl);
+                done(0);
+            }
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             lap("decode + check_integrity", tl);
             paf.overlapping_paf_recs(eng, ms, ds, is, remove_contained);
