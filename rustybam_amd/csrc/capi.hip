@@ -61,6 +61,8 @@ struct rb_trim_params {
     rb_pair_row *rows;
     uint32_t *out_ops;
     int only_pending;
+    uint32_t *scratch;
+    uint32_t scratch_blocks;
 };
 struct rb_swap_params {
     uint64_t n_rec;
@@ -106,6 +108,7 @@ extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream
 extern "C" hipError_t rb_launch_break_place(const rb_break_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_swap(const rb_swap_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream);
+extern "C" size_t rb_trim_scratch_bytes(uint32_t blocks);
 extern "C" hipError_t rb_launch_synth(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops, hipStream_t stream);
 
 struct rb_nf_params {
@@ -147,6 +150,9 @@ struct rb_ctx {
     bool timing = false;
     std::vector<hipEvent_t> ev_a, ev_b;
     uint64_t timed_calls = 0;
+    // trim-paf: slabs of device memory for pairs whose overlap region does not fit LDS (allocated at the first rb_dev_overlap_split)
+    void *trim_scratch = nullptr;
+    uint32_t trim_scratch_blocks = 0;
 };
 
 struct rb_plan {
@@ -215,6 +221,7 @@ extern "C" void rb_ctx_destroy(rb_ctx *ctx) {
     if (!ctx) return;
     for (auto e : ctx->ev_a) hipEventDestroy(e);
     for (auto e : ctx->ev_b) hipEventDestroy(e);
+    if (ctx->trim_scratch) hipFree(ctx->trim_scratch);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -636,6 +643,13 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     p.rows = rows;
     p.out_ops = out_ops;
     p.only_pending = 0;
+    if (!ctx->trim_scratch) { // (40 MB, once per context; without it those pairs simply stay with the serial kernel)
+        const uint32_t blocks = 48;
+        if (hipMalloc(&ctx->trim_scratch, rb_trim_scratch_bytes(blocks)) == hipSuccess) ctx->trim_scratch_blocks = blocks;
+        else ctx->trim_scratch = nullptr, (void)hipGetLastError();
+    }
+    p.scratch = (uint32_t *)ctx->trim_scratch;
+    p.scratch_blocks = ctx->trim_scratch_blocks;
     HIPCHK(ctx, rb_launch_overlap_split(&p, ctx->stream));
     return RB_OK;
 }

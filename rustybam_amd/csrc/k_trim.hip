@@ -24,6 +24,8 @@ struct rb_trim_params {
     rb_pair_row *rows;
     uint32_t *out_ops;
     int only_pending;
+    uint32_t *scratch;       // device memory for the third attempt of the wave kernel (regions too large for LDS), or NULL
+    uint32_t scratch_blocks; // slabs in it
 };
 
 struct rb_qstream {
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split(rb_trim_params p) {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Wave-per-pair form for the common case: both records REGULAR (only M I D N = X, every length >= 1, no two adjacent ops of one
-// type, a match-type op at both ends), at most RB_TW_CAP ops each, modern binary-search policy.  Every question the serial
+// type, a match-type op at both ends) of any length whose overlap spans at most RB_TW_CAP - 128 ops, modern binary-search policy.  Every question the serial
 // kernel answers by walking the ops becomes a binary search in prefix arrays built once per record with wave scans:
 // the op words are staged in LDS together with exclusive prefixes built with wave scans:
 //   Qc[i] query bases before op i     (a query offset x lies in the query-consuming op with Qc <= x < Qc + len)
@@ -339,23 +341,30 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split(rb_trim_params p) {
 // The split (trim_overlap.rs:50-76) is the first strict maximum of f(k) = l[0..k) + r[k..n): f is piecewise linear, so it is
 // evaluated only where either record's score changes (op starts and the special last base), all candidates in parallel.
 // Pairs this kernel does not take are marked RB_ST_PENDING_INTERNAL and done by rb_k_overlap_split afterwards.
-#define RB_TW_CAP 768
-#define RB_TW_NCP (RB_TW_CAP / 16 + 1)
+#define RB_TW_CAP 768   // ops of a record's region, first attempt (19.7 KB of LDS per pair: 8 pairs per CU)
+#define RB_TW_CAP2 6144 // second attempt for the pairs whose overlap spans more ops (one pair per CU at a time; such overlaps are rare)
+#define RB_TW_CAP3 32768 // third attempt: the same arrays in device memory (whole-chromosome alignments that overlap by hundreds of kilobases)
+#define RB_TW_SLAB_WORDS(CAP) (2u * 3u * ((CAP) + 1u) + 2u * 3u * ((CAP) / 16u + 2u))
 #define RB_ST_PENDING_INTERNAL 0x7FFF0001u
 
+// A record of a pair as the wave kernel sees it.  Only the REGION of the record that the overlap can touch is staged in LDS --
+// the ops that hold the overlapped query bases plus a 64-op step on either side -- with prefixes that are absolute (counted from
+// the record's first op), so a record may be as long as it likes: what lies in front of the region is streamed once for its
+// totals, what lies behind it is only copied when the clip keeps it.
 struct rb_wrec {
-    const uint32_t *ops;
-    uint32_t n, ncp; // ops; checkpoints in use = ceil(n / 16) + 1 (the last one holds the totals)
+    const uint32_t *ops; // the record's kept ops, in memory
+    uint32_t n;          // how many
+    uint32_t i0, m, ncp; // region = ops [i0, i0 + m); checkpoints in use = ceil(m / 16) + 1 (the last one holds the prefixes at the region's end)
     uint64_t t_st, t_en, q_st, q_en;
     bool minus;
-    uint32_t N, Qtot, Rtot;
-    int32_t Stot;
-    uint32_t *w;            // LDS [n + 1]: the op words; w[n] = a zero-length M (ends every D / N run, contains nothing)
-    uint32_t *Qc;           // LDS [n + 1]: query bases before op i
-    int32_t *SP;            // LDS [n + 1]: score of the query bases before op i, in op order
-    uint32_t *cU, *cQ, *cR; // LDS [ncp]: units / query bases / reference bases before op 16 c
+    bool bad;            // a search left the region: the pair goes to the serial kernel
+    uint32_t N, Qtot, Rtot; // totals of the whole record (units from the norm row, bases from the coordinates)
+    uint32_t *w;            // LDS [m + 1]: the op words of the region; w[m] = a zero-length M (ends every D / N run, contains nothing)
+    uint32_t *Qc;           // LDS [m + 1]: query bases before op i0 + k
+    int32_t *SP;            // LDS [m + 1]: score of the query bases of the region before op i0 + k, in op order
+    uint32_t *cU, *cQ, *cR; // LDS [ncp]: units / query bases / reference bases before op i0 + 16 c
 };
-struct rb_wpos { // an op (i = n: past the end) and the exclusive prefix of the searched quantity at it
+struct rb_wpos { // an op (i = n: none) and the exclusive prefix of the searched quantity at it
     uint32_t i, w, pre;
 };
 
@@ -363,53 +372,84 @@ __device__ __forceinline__ int32_t rb_tw_score(uint32_t opc, int32_t ms, int32_t
     return opc == RB_OP_EQ ? ms : ((opc == RB_OP_I || opc == RB_OP_D) ? -is : -ds);
 }
 
-__device__ void rb_tw_stage(rb_wrec &v, int lane, int32_t ms, int32_t ds, int32_t is) {
-    // pass 1: the op words into LDS, every load in flight at once (addresses past the record re-read its last op)
-    {
-        uint32_t t[RB_TW_CAP / 64];
-#pragma unroll
-        for (int c = 0; c < RB_TW_CAP / 64; c++) {
-            const uint32_t i = (uint32_t)c * 64u + (uint32_t)lane;
-            t[c] = v.ops[i < v.n ? i : v.n - 1u];
-        }
-#pragma unroll
-        for (int c = 0; c < RB_TW_CAP / 64; c++) {
-            const uint32_t i = (uint32_t)c * 64u + (uint32_t)lane;
-            if (i < v.n) v.w[i] = t[c];
-        }
-        if (lane == 0) v.w[v.n] = RB_OP_M; // length 0
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    // pass 2: prefixes, 64 ops at a time; every 16th op leaves a checkpoint
-    uint32_t Ub = 0, Qb = 0, Rb = 0;
-    int32_t Sb = 0;
+// Stage the region of v that holds the query offsets [xa, xb] (op order).  false: it does not fit RB_TW_CAP ops.
+template <int CAP>
+__device__ bool rb_tw_stage(rb_wrec &v, int lane, int32_t ms, int32_t ds, int32_t is, uint32_t xa, uint32_t xb) {
+    v.bad = false;
+    // phase A: 64 ops at a time from the record's first op, totals only, up to the step that holds xb; the region starts one step
+    // before the step that holds xa and ends one step behind the one that holds xb
+    uint32_t Ub = 0, Qb = 0, Rb = 0, pU = 0, pQ = 0, pR = 0; // prefixes at the current step / at the step before
+    uint32_t i0 = 0, bU = 0, bQ = 0, bR = 0, i1 = v.n;
+    bool found = false;
     for (uint32_t c0 = 0; c0 < v.n; c0 += 64) {
         const uint32_t i = c0 + (uint32_t)lane;
-        const bool in = i < v.n;
-        const uint32_t w = in ? v.w[i] : 0u;
+        const uint32_t w = i < v.n ? v.ops[i] : 0u;
+        const uint32_t opc = rb_opc(w), len = i < v.n ? rb_len(w) : 0u;
+        const uint32_t tu = rb_wave_sum_u32(len), tq = rb_wave_sum_u32(rb_in(RB_QRY_MASK, opc) ? len : 0u), tr = rb_wave_sum_u32(rb_in(RB_REF_MASK, opc) ? len : 0u);
+        if (!found && Qb + tq > xa) {
+            found = true;
+            if (c0 >= 64u) i0 = c0 - 64u, bU = pU, bQ = pQ, bR = pR;
+        }
+        if (found && Qb + tq > xb) {
+            i1 = c0 + 128u < v.n ? c0 + 128u : v.n;
+            break;
+        }
+        pU = Ub, pQ = Qb, pR = Rb;
+        Ub += tu, Qb += tq, Rb += tr;
+    }
+    if (!found || i1 - i0 > (uint32_t)CAP) return false;
+    const uint32_t m = i1 - i0;
+    v.i0 = i0, v.m = m;
+    // phase B: the op words of the region into LDS (the common size: every load in flight at once; addresses past the region
+    // re-read its last op)
+    if constexpr (CAP <= 1024) {
+        uint32_t t[CAP / 64];
+#pragma unroll
+        for (int c = 0; c < CAP / 64; c++) {
+            const uint32_t k = (uint32_t)c * 64u + (uint32_t)lane;
+            t[c] = v.ops[i0 + (k < m ? k : m - 1u)];
+        }
+#pragma unroll
+        for (int c = 0; c < CAP / 64; c++) {
+            const uint32_t k = (uint32_t)c * 64u + (uint32_t)lane;
+            if (k < m) v.w[k] = t[c];
+        }
+    } else {
+        for (uint32_t k = (uint32_t)lane; k < m; k += 64u) v.w[k] = v.ops[i0 + k];
+    }
+    if (lane == 0) v.w[m] = RB_OP_M; // length 0
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // phase C: prefixes, 64 ops at a time; every 16th op leaves a checkpoint
+    Ub = bU, Qb = bQ, Rb = bR;
+    int32_t Sb = 0;
+    for (uint32_t c0 = 0; c0 < m; c0 += 64) {
+        const uint32_t k = c0 + (uint32_t)lane;
+        const bool in = k < m;
+        const uint32_t w = in ? v.w[k] : 0u;
         const uint32_t opc = rb_opc(w), len = in ? rb_len(w) : 0u;
         const bool q = in && rb_in(RB_QRY_MASK, opc), r = in && rb_in(RB_REF_MASK, opc);
-        int32_t m = 0;
+        int32_t mm = 0;
         if (q) { // own score for all bases but the last in op order, which takes the score of the last D / N op of the run behind it
             int32_t sp = rb_tw_score(opc, ms, ds, is);
             const int32_t own = sp;
-            for (uint32_t j = i + 1;; j++) { // (regular records: short; the sentinel at w[n] stops it)
+            for (uint32_t j = k + 1;; j++) { // (regular records: short; the sentinel at w[m] stops it -- a run cut by the region's end
+                                             //  lies in the step behind the overlap, where no score is looked up)
                 const uint32_t oj = rb_opc(v.w[j]);
                 if (rb_in(RB_QRY_MASK, oj)) break;
                 sp = rb_tw_score(oj, ms, ds, is);
             }
-            m = (int32_t)(len - 1u) * own + sp;
+            mm = (int32_t)(len - 1u) * own + sp;
         }
         const uint32_t iu = rb_wave_scan_incl(len), iq = rb_wave_scan_incl(q ? len : 0u), ir = rb_wave_scan_incl(r ? len : 0u);
-        const int32_t isc = (int32_t)rb_wave_scan_incl((uint32_t)m);
+        const int32_t isc = (int32_t)rb_wave_scan_incl((uint32_t)mm);
         if (in) {
-            v.Qc[i] = Qb + iq - (q ? len : 0u);
-            v.SP[i] = Sb + isc - m;
-            if ((i & 15u) == 0u) {
-                v.cU[i >> 4] = Ub + iu - len;
-                v.cQ[i >> 4] = Qb + iq - (q ? len : 0u);
-                v.cR[i >> 4] = Rb + ir - (r ? len : 0u);
+            v.Qc[k] = Qb + iq - (q ? len : 0u);
+            v.SP[k] = Sb + isc - mm;
+            if ((k & 15u) == 0u) {
+                v.cU[k >> 4] = Ub + iu - len;
+                v.cQ[k >> 4] = Qb + iq - (q ? len : 0u);
+                v.cR[k >> 4] = Rb + ir - (r ? len : 0u);
             }
         }
         Ub += rb_readlane<uint32_t>(iu, 63);
@@ -417,37 +457,51 @@ __device__ void rb_tw_stage(rb_wrec &v, int lane, int32_t ms, int32_t ds, int32_
         Rb += rb_readlane<uint32_t>(ir, 63);
         Sb += rb_readlane<int>(isc, 63);
     }
-    v.ncp = (v.n + 15u) / 16u + 1u;
+    v.ncp = (m + 15u) / 16u + 1u;
     if (lane == 0) {
         v.cU[v.ncp - 1] = Ub, v.cQ[v.ncp - 1] = Qb, v.cR[v.ncp - 1] = Rb;
-        v.Qc[v.n] = Qb, v.SP[v.n] = Sb;
+        v.Qc[m] = Qb, v.SP[m] = Sb;
     }
-    v.N = Ub, v.Qtot = Qb, v.Rtot = Rb, v.Stot = Sb;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    return true;
 }
 
-// units (KIND 0) / reference bases (KIND 1) before op i: the checkpoint of its chunk + the ops of the chunk in front of it
+// units (KIND 0) / reference bases (KIND 1) before op i of the region: the checkpoint of its chunk + the ops of the chunk in front of it
 template <int KIND>
 __device__ __forceinline__ uint32_t rb_tw_before(const rb_wrec &v, uint32_t i, int lane) {
-    const uint32_t c = i >> 4, j = 16u * c + (uint32_t)lane;
+    const uint32_t k = i - v.i0, c = k >> 4, j = 16u * c + (uint32_t)lane;
     uint32_t x = 0;
-    if (lane < 16 && j < i) {
+    if (lane < 16 && j < k) {
         const uint32_t w = v.w[j];
         x = (KIND == 0 || rb_in(RB_REF_MASK, rb_opc(w))) ? rb_len(w) : 0u;
     }
     return (KIND == 0 ? v.cU[c] : v.cR[c]) + rb_wave_sum_u32(x);
 }
-// wave-uniform search: the op that holds unit x (BY_UNIT) / query offset x, found by all lanes at once -- one ballot over the
-// checkpoints, then the 16 ops of that chunk side by side
+// wave-uniform search inside the region: the op that holds unit x (BY_UNIT) / query offset x, found by all lanes at once -- one
+// ballot over the checkpoints, then the 16 ops of that chunk side by side.  i = n: no op of the region holds x.
 template <bool BY_UNIT>
 __device__ rb_wpos rb_tw_find(const rb_wrec &v, uint32_t x, int lane) {
     const uint32_t *cp = BY_UNIT ? v.cU : v.cQ;
-    const bool le = (uint32_t)lane + 1u < v.ncp && cp[lane] <= x; // (the totals entry is not a chunk)
-    const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(le)) - 1u; // cp[0] = 0 <= x
-    const uint32_t i = 16u * c + (uint32_t)lane;
-    const bool in = lane < 16 && i < v.n;
-    const uint32_t w = in ? v.w[i] : 0u;
+    rb_wpos o;
+    o.i = v.n, o.w = RB_NULL_OP, o.pre = 0;
+    // the last chunk whose checkpoint is <= x: 64 checkpoints per ballot, a 64-ary search when the region has more chunks
+    uint32_t cbase = 0, ccount = v.ncp - 1u; // (the last entry is not a chunk)
+    while (ccount > 64u) {
+        const uint32_t stride = (ccount + 63u) / 64u, t = (uint32_t)lane * stride;
+        const uint64_t mk0 = __ballot(t < ccount && cp[cbase + t] <= x);
+        if (!mk0) return o; // in front of the region
+        const uint32_t j = (uint32_t)__builtin_popcountll(mk0) - 1u;
+        cbase += j * stride;
+        ccount = ccount - j * stride < stride ? ccount - j * stride : stride;
+    }
+    const bool le = (uint32_t)lane < ccount && cp[cbase + (uint32_t)lane] <= x;
+    const uint64_t lem = __ballot(le);
+    if (!lem) return o; // in front of the region
+    const uint32_t c = cbase + (uint32_t)__builtin_popcountll(lem) - 1u;
+    const uint32_t k = 16u * c + (uint32_t)lane;
+    const bool in = lane < 16 && k < v.m;
+    const uint32_t w = in ? v.w[k] : 0u;
     const uint32_t len = in ? rb_len(w) : 0u;
     uint32_t pre;
     bool hit;
@@ -455,124 +509,154 @@ __device__ rb_wpos rb_tw_find(const rb_wrec &v, uint32_t x, int lane) {
         pre = v.cU[c] + rb_wave_scan_incl(len) - len;
         hit = in && pre <= x && x - pre < len;
     } else {
-        pre = in ? v.Qc[i] : 0u;
+        pre = in ? v.Qc[k] : 0u;
         hit = in && rb_in(RB_QRY_MASK, rb_opc(w)) && pre <= x && x - pre < len;
     }
     const uint64_t mk = __ballot(hit);
-    rb_wpos o;
-    if (!mk) {
-        o.i = v.n, o.w = RB_NULL_OP, o.pre = BY_UNIT ? v.N : v.Qtot;
-        return o;
-    }
+    if (!mk) return o; // behind the region (or behind the record)
     const int l = __builtin_ctzll(mk);
-    o.i = 16u * c + (uint32_t)l;
+    o.i = v.i0 + 16u * c + (uint32_t)l;
     o.w = rb_readlane<uint32_t>(w, l), o.pre = rb_readlane<uint32_t>(pre, l);
     return o;
 }
-// score of the first x query bases in op order, wave-uniform x
-__device__ __forceinline__ int64_t rb_tw_W(const rb_wrec &v, uint32_t x, int lane, int32_t ms, int32_t ds, int32_t is) {
+// score of the region's query bases in front of query offset x (op order), wave-uniform x inside the region (or just behind it)
+__device__ __forceinline__ int64_t rb_tw_W(rb_wrec &v, uint32_t x, int lane, int32_t ms, int32_t ds, int32_t is) {
+    if (x >= v.Qc[v.m]) return v.SP[v.m];
     const rb_wpos o = rb_tw_find<false>(v, x, lane);
-    if (o.i >= v.n) return v.Stot;
-    return (int64_t)v.SP[o.i] + (int64_t)(x - o.pre) * rb_tw_score(rb_opc(o.w), ms, ds, is);
+    if (o.i >= v.n) {
+        v.bad = true;
+        return 0;
+    }
+    return (int64_t)v.SP[o.i - v.i0] + (int64_t)(x - o.pre) * rb_tw_score(rb_opc(o.w), ms, ds, is);
 }
 // the same for a per-lane x: binary search in Qc (non-query ops share the value of the query op behind them, and that op comes
 // later: the last index with Qc <= x is the query op that holds x)
 __device__ int64_t rb_tw_W_lane(const rb_wrec &v, uint32_t x, int32_t ms, int32_t ds, int32_t is) {
-    if (x >= v.Qtot) return v.Stot;
-    uint32_t lo = 0, hi = v.n;
+    if (x >= v.Qc[v.m]) return v.SP[v.m];
+    uint32_t lo = 0, hi = v.m;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (v.Qc[mid] <= x) lo = mid; else hi = mid;
     }
     return (int64_t)v.SP[lo] + (int64_t)(x - v.Qc[lo]) * rb_tw_score(rb_opc(v.w[lo]), ms, ds, is);
 }
-// score of the query positions [q_st, p) in increasing position order
-__device__ __forceinline__ int64_t rb_tw_G(const rb_wrec &v, uint64_t p, int lane, int32_t ms, int32_t ds, int32_t is) {
-    return !v.minus ? rb_tw_W(v, (uint32_t)(p - v.q_st), lane, ms, ds, is) : (int64_t)v.Stot - rb_tw_W(v, (uint32_t)(v.q_en - p), lane, ms, ds, is);
+// score of the query positions below p, in increasing position order, up to a constant of the record (only differences are used)
+__device__ __forceinline__ int64_t rb_tw_G(rb_wrec &v, uint64_t p, int lane, int32_t ms, int32_t ds, int32_t is) {
+    return !v.minus ? rb_tw_W(v, (uint32_t)(p - v.q_st), lane, ms, ds, is) : -rb_tw_W(v, (uint32_t)(v.q_en - p), lane, ms, ds, is);
 }
 __device__ __forceinline__ int64_t rb_tw_G_lane(const rb_wrec &v, uint64_t p, int32_t ms, int32_t ds, int32_t is) {
-    return !v.minus ? rb_tw_W_lane(v, (uint32_t)(p - v.q_st), ms, ds, is) : (int64_t)v.Stot - rb_tw_W_lane(v, (uint32_t)(v.q_en - p), ms, ds, is);
+    return !v.minus ? rb_tw_W_lane(v, (uint32_t)(p - v.q_st), ms, ds, is) : -rb_tw_W_lane(v, (uint32_t)(v.q_en - p), ms, ds, is);
 }
 
-// truncate_record_by_query (paf.rs:785-823) on a staged regular record; same results as rb_clip_by_query
-__device__ uint32_t rb_tw_clip(const rb_wrec &v, uint64_t new_q_st, uint64_t new_q_en, uint32_t *out, rb_pair_row *row, int s, uint64_t out_base,
+// truncate_record_by_query (paf.rs:785-823) on a staged regular record; same results as rb_clip_by_query.  One end of the new
+// query range is the record's own end (trim_overlap.rs:77-78), the other lies in the staged region.
+struct rb_wend { // a unit of the record: its index, the op that holds it, and the prefixes before that op
+    uint32_t k;   // unit
+    rb_wpos o;    // op, its word, units before it
+    uint32_t R, Q; // reference / query bases before the op
+};
+__device__ uint32_t rb_tw_clip(rb_wrec &v, uint64_t new_q_st, uint64_t new_q_en, uint32_t *out, rb_pair_row *row, int s, uint64_t out_base,
                                int lane) {
     if (!(new_q_st >= v.q_st) || !(new_q_en <= v.q_en) || new_q_en == 0) return RB_ST_PANIC_ASSERT; // :787-788
+    if (new_q_en <= new_q_st) { // an empty range: the serial kernel says what the reference does with it
+        v.bad = true;
+        return RB_ST_OK;
+    }
     const uint32_t n = v.n, N = v.N;
-    auto qlast = [&](uint64_t p, uint32_t *k) -> bool { // qpos_to_idx, modern policy: the LAST unit whose qpos equals p
+    // the match-type unit truncate_record_by_query ends up at for query position p: qpos_to_idx_match (paf.rs:564-590) = the last
+    // unit whose qpos equals p (modern policy), then the nearest match-type unit in the search direction
+    auto resolve = [&](uint64_t p, bool search_up, rb_wend *e) -> bool {
         if (p < v.q_st || p >= v.q_en) return false;
         const uint32_t x = (uint32_t)(v.minus ? v.q_en - 1 - p : p - v.q_st);
+        if (x < v.Qc[0] || x >= v.Qc[v.m]) {
+            // outside the region: only the record's own first / last query base is asked for there.  A regular record starts and
+            // ends on a match op; its last base is its last unit, its first base its first unit unless that op has one base and a
+            // D / N run behind it (the run repeats the position: left to the serial kernel)
+            if (x == 0u) {
+                const uint32_t w0 = v.ops[0];
+                if (rb_len(w0) < 2u && n > 1u && !rb_in(RB_QRY_MASK, rb_opc(v.ops[1]))) return false;
+                e->k = 0, e->o.i = 0, e->o.w = w0, e->o.pre = 0, e->R = 0, e->Q = 0;
+                return true;
+            }
+            if (x + 1u == v.Qtot) {
+                const uint32_t wl = v.ops[n - 1u], len = rb_len(wl);
+                e->k = N - 1u, e->o.i = n - 1u, e->o.w = wl, e->o.pre = N - len, e->R = v.Rtot - len, e->Q = v.Qtot - len;
+                return true;
+            }
+            return false;
+        }
         const rb_wpos o = rb_tw_find<false>(v, x, lane);
+        if (o.i >= n) return false;
         const uint32_t j = x - o.pre, len = rb_len(o.w);
         uint32_t u = rb_tw_before<0>(v, o.i, lane) + j;
-        if (j + 1u == len) // last base of the op: the D / N units behind it repeat its position
-            for (uint32_t i2 = o.i + 1; i2 < n && !rb_in(RB_QRY_MASK, rb_opc(v.w[i2])); i2++) u += rb_len(v.w[i2]);
-        *k = u;
+        if (j + 1u == len) { // last base of the op: the D / N units behind it repeat its position
+            uint32_t k2 = o.i - v.i0 + 1u;
+            for (; k2 < v.m && !rb_in(RB_QRY_MASK, rb_opc(v.w[k2])); k2++) u += rb_len(v.w[k2]);
+            if (k2 >= v.m && v.i0 + v.m < n) return false; // (the run leaves the region)
+        }
+        // nearest match-type unit, up (paf.rs:581-583) or down (:585-587)
+        rb_wpos om = rb_tw_find<true>(v, u, lane);
+        if (om.i >= n) return false;
+        uint32_t km = u;
+        if (!rb_in(RB_MATCH_MASK, rb_opc(om.w))) {
+            if (search_up) {
+                uint32_t uu = om.pre + rb_len(om.w), k2 = om.i - v.i0 + 1u;
+                for (; k2 < v.m && !rb_in(RB_MATCH_MASK, rb_opc(v.w[k2])); k2++) uu += rb_len(v.w[k2]);
+                if (k2 >= v.m) return false; // (no match op behind it inside the region; at the record's end the reference panics: serial kernel)
+                km = uu;
+                om.i = v.i0 + k2, om.w = v.w[k2], om.pre = uu;
+            } else {
+                uint32_t uu = om.pre, k2 = om.i - v.i0;
+                bool got = false;
+                while (k2 > 0u) {
+                    k2--;
+                    if (rb_in(RB_MATCH_MASK, rb_opc(v.w[k2]))) {
+                        got = true;
+                        break;
+                    }
+                    uu -= rb_len(v.w[k2]);
+                }
+                if (!got) return false;
+                km = uu - 1u;
+                om.i = v.i0 + k2, om.w = v.w[k2], om.pre = uu - rb_len(v.w[k2]);
+            }
+        }
+        e->k = km, e->o = om, e->R = rb_tw_before<1>(v, om.i, lane), e->Q = v.Qc[om.i - v.i0];
         return true;
     };
-    auto match_ge = [&](uint32_t k) -> uint32_t { // paf.rs:581-583
-        const rb_wpos o = rb_tw_find<true>(v, k, lane);
-        if (rb_in(RB_MATCH_MASK, rb_opc(o.w))) return k;
-        uint32_t u = o.pre + rb_len(o.w);
-        for (uint32_t i = o.i + 1; i < n; i++) {
-            if (rb_in(RB_MATCH_MASK, rb_opc(v.w[i]))) return u;
-            u += rb_len(v.w[i]);
-        }
-        return N;
-    };
-    auto match_le = [&](uint32_t k) -> uint32_t { // paf.rs:585-587
-        const rb_wpos o = rb_tw_find<true>(v, k, lane);
-        if (rb_in(RB_MATCH_MASK, rb_opc(o.w))) return k;
-        uint32_t u = o.pre; // first unit of the op after the candidate
-        for (uint32_t i = o.i; i > 0;) {
-            i--;
-            if (rb_in(RB_MATCH_MASK, rb_opc(v.w[i]))) return u - 1u;
-            u -= rb_len(v.w[i]);
-        }
-        return 0u;
-    };
-    uint32_t ks, ke;
-    if (!qlast(new_q_st, &ks) || !qlast(new_q_en - 1, &ke)) return RB_ST_PANIC_NOTFOUND;
-    uint32_t aln_st = !v.minus ? match_ge(ks) : match_le(ks);
-    uint32_t aln_en = !v.minus ? match_le(ke) : match_ge(ke);
-    if (aln_st >= N || aln_en >= N) return RB_ST_PANIC_NOTFOUND; // :795-796
-    rb_wpos oa = rb_tw_find<true>(v, aln_st, lane), ob = rb_tw_find<true>(v, aln_en, lane);
-    uint32_t Ra = rb_tw_before<1>(v, oa.i, lane), Rb = rb_tw_before<1>(v, ob.i, lane);
-    auto unit = [&](const rb_wpos &o, uint32_t Rpre, uint32_t k, uint64_t *tpos, uint64_t *qpos) {
-        const uint32_t off = k - o.pre, opc = rb_opc(o.w), Qpre = v.Qc[o.i];
-        const bool r = rb_in(RB_REF_MASK, opc), q = rb_in(RB_QRY_MASK, opc);
-        *tpos = r ? v.t_st + Rpre + off : v.t_st + Rpre - 1;
-        *qpos = q ? (v.minus ? v.q_en - 1 - Qpre - off : v.q_st + Qpre + off) : (v.minus ? v.q_en - Qpre : v.q_st + Qpre - 1);
+    rb_wend A, B; // paf.rs:792-796: the start searches up on '+' and down on '-', the end the other way
+    if (!resolve(new_q_st, !v.minus, &A) || !resolve(new_q_en - 1, v.minus, &B)) {
+        v.bad = true;
+        return RB_ST_OK;
+    }
+    auto unit = [&](const rb_wend &e, uint64_t *tpos, uint64_t *qpos) { // both are match-type units
+        const uint32_t off = e.k - e.o.pre;
+        *tpos = v.t_st + e.R + off;
+        *qpos = v.minus ? v.q_en - 1 - e.Q - off : v.q_st + e.Q + off;
     };
     uint64_t tp, qp_st, qp_en;
-    unit(oa, Ra, aln_st, &tp, &qp_st);
-    unit(ob, Rb, aln_en, &tp, &qp_en);
+    unit(A, &tp, &qp_st);
+    unit(B, &tp, &qp_en);
     const uint64_t nq_st = qp_st, nq_en = qp_en + 1;
-    if (aln_st > aln_en) { // :799-801
-        const uint32_t t = aln_st;
-        aln_st = aln_en;
-        aln_en = t;
-        const rb_wpos to = oa;
-        oa = ob;
-        ob = to;
-        const uint32_t tr = Ra;
-        Ra = Rb;
-        Rb = tr;
+    if (A.k > B.k) { // :799-801
+        const rb_wend t = A;
+        A = B;
+        B = t;
     }
     uint64_t t0, t1, qd;
-    unit(oa, Ra, aln_st, &t0, &qd);
-    unit(ob, Rb, aln_en, &t1, &qd);
+    unit(A, &t0, &qd);
+    unit(B, &t1, &qd);
     const uint64_t nt_st = t0, nt_en = t1 + 1; // :802-803
     // subset_cigar + collapse (:807-808): ops ia..ib with the first / last length cut; adjacent ops differ, nothing merges; both
     // ends are match-type units, so the strip of :819-822 removes nothing
-    const uint32_t ia = oa.i, ib = ob.i, cnt = ib - ia + 1;
+    const uint32_t ia = A.o.i, ib = B.o.i, cnt = ib - ia + 1;
     uint64_t R = 0, Q = 0, M = 0;
     for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) {
-        const uint32_t i = ia + j, opc = rb_opc(v.w[i]);
-        uint32_t len = rb_len(v.w[i]);
-        if (cnt == 1) len = aln_en - aln_st + 1u;
-        else if (j == 0) len = oa.pre + len - aln_st;
-        else if (j == cnt - 1) len = aln_en - ob.pre + 1u;
+        const uint32_t wv = v.ops[ia + j], opc = rb_opc(wv);
+        uint32_t len = rb_len(wv);
+        if (cnt == 1) len = B.k - A.k + 1u;
+        else if (j == 0) len = A.o.pre + len - A.k;
+        else if (j == cnt - 1) len = B.k - B.o.pre + 1u;
         out[j] = (len << 4) | opc;
         if (rb_in(RB_REF_MASK, opc)) R += len;
         if (rb_in(RB_QRY_MASK, opc)) Q += len;
@@ -586,17 +670,14 @@ __device__ uint32_t rb_tw_clip(const rb_wrec &v, uint64_t new_q_st, uint64_t new
     row->q_st[s] = nq_st;
     row->q_en[s] = nq_en;
     row->nmatch[s] = (uint32_t)M;
-    row->aln_len[s] = aln_en - aln_st + 1u;
+    row->aln_len[s] = B.k - A.k + 1u;
     row->out_off[s] = out_base;
     row->out_n[s] = cnt;
     return RB_ST_OK;
 }
 
-__global__ __launch_bounds__(64) void rb_k_overlap_split_wave(rb_trim_params p) {
-    __shared__ uint32_t lds_w[2][3][RB_TW_CAP + 1];
-    __shared__ uint32_t lds_c[2][3][RB_TW_NCP + 1];
-    const uint64_t pi = blockIdx.x;
-    if (pi >= p.n_pairs) return;
+template <int CAP>
+__device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t (*lds_w)[3][CAP + 1], uint32_t (*lds_c)[3][CAP / 16 + 2]) {
     const int lane = rb_lane();
     rb_pair_row w;
     w.split_idx = 0;
@@ -616,31 +697,44 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_wave(rb_trim_params p) 
         if (lane == 0) p.rows[pi] = w;
         return;
     }
-    if (p.policy == RB_BSEARCH_LEGACY || !(nl->flags & RB_F_REGULAR) || !(nr->flags & RB_F_REGULAR) || nl->n_ops > RB_TW_CAP ||
-        nr->n_ops > RB_TW_CAP || nl->n_ops == 0 || nr->n_ops == 0) {
-        if (lane == 0) p.rows[pi].status = RB_ST_PENDING_INTERNAL;
+    auto pending = [&](uint32_t why = 0) { // (why: diagnostics, RB_DEBUG_TRIM_NO_SERIAL; the serial kernel rewrites the whole row)
+        if (lane == 0) p.rows[pi].status = RB_ST_PENDING_INTERNAL, p.rows[pi].split_idx = why;
+    };
+    if (p.policy == RB_BSEARCH_LEGACY || !(nl->flags & RB_F_REGULAR) || !(nr->flags & RB_F_REGULAR) || nl->n_ops == 0 || nr->n_ops == 0) {
+        pending(1);
         return;
     }
     const int32_t ms = p.match_score, ds = p.diff_score, is = p.indel_score;
     rb_wrec L, R;
     L.ops = p.ops + p.op_off[rl] + nl->first_op, L.n = nl->n_ops;
     L.t_st = nl->t_st, L.t_en = nl->t_en, L.q_st = nl->q_st, L.q_en = nl->q_en, L.minus = p.strand[rl] == (uint8_t)'-';
+    L.N = nl->aln_len, L.Qtot = (uint32_t)(nl->q_en - nl->q_st), L.Rtot = (uint32_t)(nl->t_en - nl->t_st);
     L.w = lds_w[0][0], L.Qc = lds_w[0][1], L.SP = reinterpret_cast<int32_t *>(lds_w[0][2]), L.cU = lds_c[0][0], L.cQ = lds_c[0][1], L.cR = lds_c[0][2];
     R.ops = p.ops + p.op_off[rr] + nr->first_op, R.n = nr->n_ops;
     R.t_st = nr->t_st, R.t_en = nr->t_en, R.q_st = nr->q_st, R.q_en = nr->q_en, R.minus = p.strand[rr] == (uint8_t)'-';
+    R.N = nr->aln_len, R.Qtot = (uint32_t)(nr->q_en - nr->q_st), R.Rtot = (uint32_t)(nr->t_en - nr->t_st);
     R.w = lds_w[1][0], R.Qc = lds_w[1][1], R.SP = reinterpret_cast<int32_t *>(lds_w[1][2]), R.cU = lds_c[1][0], R.cQ = lds_c[1][1], R.cR = lds_c[1][2];
-    rb_tw_stage(L, lane, ms, ds, is);
-    rb_tw_stage(R, lane, ms, ds, is);
-    if ((uint64_t)L.Qtot != L.q_en - L.q_st || (uint64_t)R.Qtot != R.q_en - R.q_st) { // (cannot happen for rows that passed the scan)
-        if (lane == 0) p.rows[pi].status = RB_ST_PENDING_INTERNAL;
-        return;
-    }
     const uint64_t st_ovl = L.q_st > R.q_st ? L.q_st : R.q_st; // trim_overlap.rs:43-44
     const uint64_t en_ovl = L.q_en < R.q_en ? L.q_en : R.q_en;
-    const uint64_t n_ov = en_ovl > st_ovl ? en_ovl - st_ovl : 0;
+    if (en_ovl <= st_ovl || st_ovl < L.q_st || en_ovl > L.q_en || st_ovl < R.q_st || en_ovl > R.q_en) { // (no overlap: the serial kernel says what the reference does)
+        pending(2);
+        return;
+    }
+    // query offsets of the overlap in each record's op order
+    auto span = [&](const rb_wrec &v, uint32_t *xa, uint32_t *xb) {
+        *xa = (uint32_t)(!v.minus ? st_ovl - v.q_st : v.q_en - en_ovl);
+        *xb = (uint32_t)(!v.minus ? en_ovl - 1 - v.q_st : v.q_en - 1 - st_ovl);
+    };
+    uint32_t lxa, lxb, rxa, rxb;
+    span(L, &lxa, &lxb);
+    span(R, &rxa, &rxb);
+    if (!rb_tw_stage<CAP>(L, lane, ms, ds, is, lxa, lxb) || !rb_tw_stage<CAP>(R, lane, ms, ds, is, rxa, rxb)) { // an overlap of more ops than the region holds
+        pending(3);
+        return;
+    }
     int64_t best = 0;
     uint64_t best_idx = 0;
-    if (n_ov > 0) {
+    {
         const int64_t gl0 = rb_tw_G(L, st_ovl, lane, ms, ds, is), gr0 = rb_tw_G(R, st_ovl, lane, ms, ds, is), gr1 = rb_tw_G(R, en_ovl, lane, ms, ds, is);
         const int64_t rsum = gr1 - gr0; // f(0)
         if (rsum > best) best = rsum;   // (index stays 0)
@@ -656,16 +750,19 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_wave(rb_trim_params p) 
             const uint64_t k = pos - st_ovl;
             if (f > cb || (f == cb && k < ck)) cb = f, ck = k;
         };
-        auto candidates = [&](const rb_wrec &v, const rb_wrec &other, bool is_left) {
+        auto candidates = [&](rb_wrec &v, const rb_wrec &other, bool is_left, uint32_t xa, uint32_t xb) {
             // ops whose query bases intersect the overlap: a contiguous op range
-            const uint32_t xa = (uint32_t)(!v.minus ? st_ovl - v.q_st : v.q_en - en_ovl);
-            const uint32_t xb = (uint32_t)(!v.minus ? en_ovl - 1 - v.q_st : v.q_en - 1 - st_ovl);
             const uint32_t ia = rb_tw_find<false>(v, xa, lane).i, ib = rb_tw_find<false>(v, xb, lane).i;
-            for (uint32_t i = ia + (uint32_t)lane; i <= ib && i < v.n; i += 64) {
-                const uint32_t wv = v.w[i];
+            if (ia >= v.n || ib >= v.n) {
+                v.bad = true;
+                return;
+            }
+            for (uint32_t i = ia + (uint32_t)lane; i <= ib; i += 64) {
+                const uint32_t k = i - v.i0;
+                const uint32_t wv = v.w[k];
                 if (!rb_in(RB_QRY_MASK, rb_opc(wv))) continue;
-                const uint64_t len = rb_len(wv), Qi = v.Qc[i];
-                const int64_t Si = v.SP[i], mi = (int64_t)v.SP[i + 1] - Si, own = rb_tw_score(rb_opc(wv), ms, ds, is);
+                const uint64_t len = rb_len(wv), Qi = v.Qc[k];
+                const int64_t Si = v.SP[k], mi = (int64_t)v.SP[k + 1] - Si, own = rb_tw_score(rb_opc(wv), ms, ds, is);
                 const int64_t w0 = Si, w1 = Si + (int64_t)(len - 1) * own, w2 = Si + mi; // W at offsets Qi, Qi + len - 1, Qi + len
                 if (!v.minus) {
                     const uint64_t lo = v.q_st + Qi;
@@ -673,15 +770,15 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_wave(rb_trim_params p) 
                     consider(lo + len - 1, other, is_left, w1); // the special base (the last one in op order) starts
                     consider(lo + len, other, is_left, w2);
                 } else {
-                    const uint64_t lo = v.q_en - Qi - len; // G(p) = Stot - W(q_en - p)
-                    consider(lo, other, is_left, (int64_t)v.Stot - w2);
-                    consider(lo + 1, other, is_left, (int64_t)v.Stot - w1); // the special base (lowest position) ends
-                    consider(lo + len, other, is_left, (int64_t)v.Stot - w0);
+                    const uint64_t lo = v.q_en - Qi - len; // G(p) = -W(q_en - p)
+                    consider(lo, other, is_left, -w2);
+                    consider(lo + 1, other, is_left, -w1); // the special base (lowest position) ends
+                    consider(lo + len, other, is_left, -w0);
                 }
             }
         };
-        candidates(L, R, true);
-        candidates(R, L, false);
+        candidates(L, R, true, lxa, lxb);
+        candidates(R, L, false, rxa, rxb);
         if (lane == 0) consider(en_ovl, R, true, rb_tw_G_lane(L, en_ovl, ms, ds, is));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -691,25 +788,81 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_wave(rb_trim_params p) 
         }
         if (cb > best) best = cb, best_idx = ck;
     }
+    if (L.bad || R.bad) {
+        pending(4);
+        return;
+    }
     w.split_idx = best_idx;
     w.split_score = (int32_t)best;
     const uint64_t split = st_ovl + best_idx;
     const uint64_t ob = p.pair_out_off[pi];
     uint32_t st = rb_tw_clip(L, L.q_st, split, p.out_ops + ob, &w, 0, ob, lane); // trim_overlap.rs:77
-    if (st == RB_ST_OK) {
+    if (st == RB_ST_OK && !L.bad) {
         const uint64_t ob2 = ob + L.n;
         st = rb_tw_clip(R, split, R.q_en, p.out_ops + ob2, &w, 1, ob2, lane); // :78
     }
+    if (L.bad || R.bad) { // a boundary the region cannot answer: the serial kernel does the pair (it rewrites both clips)
+        pending(L.bad ? 5 : 6);
+        return;
+    }
     w.status = st;
+    w._pad = 1; // (diagnostic: done by the wave kernel; the serial kernel leaves 0)
     if (lane == 0) p.rows[pi] = w;
 }
+// first attempt: a wavefront per pair
+template <int CAP>
+__global__ __launch_bounds__(64) void rb_k_overlap_split_wave(rb_trim_params p) {
+    __shared__ uint32_t lds_w[2][3][CAP + 1];
+    __shared__ uint32_t lds_c[2][3][CAP / 16 + 2];
+    if (blockIdx.x < p.n_pairs) rb_tw_pair<CAP>(p, blockIdx.x, lds_w, lds_c);
+}
+// third attempt: the region arrays of a wavefront live in a slab of device memory (same code: the arrays are pointers).  Stores
+// and loads of one wavefront go through its CU's vector L1 in program order, so a lane sees what another lane of its own wave
+// has stored (wavefront-scope fences are empty on this target for exactly that reason).
+template <int CAP>
+__global__ __launch_bounds__(64) void rb_k_overlap_split_wave_scratch(rb_trim_params p) {
+    if (!p.scratch || blockIdx.x >= p.scratch_blocks) return;
+    uint32_t *slab = p.scratch + (size_t)blockIdx.x * RB_TW_SLAB_WORDS(CAP);
+    auto *aw = reinterpret_cast<uint32_t (*)[3][CAP + 1]>(slab);
+    auto *ac = reinterpret_cast<uint32_t (*)[3][CAP / 16 + 2]>(slab + 2u * 3u * (CAP + 1u));
+    for (uint64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+        const uint32_t st = rb_first(p.rows[pi].status);
+        if (st == RB_ST_PENDING_INTERNAL) rb_tw_pair<CAP>(p, pi, aw, ac);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// second attempt, for the pairs the first one left: a few wavefronts with a large region each walk the rows
+template <int CAP>
+__global__ __launch_bounds__(64) void rb_k_overlap_split_wave_pending(rb_trim_params p) {
+    __shared__ uint32_t lds_w[2][3][CAP + 1];
+    __shared__ uint32_t lds_c[2][3][CAP / 16 + 2];
+    for (uint64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+        const uint32_t st = rb_first(p.rows[pi].status);
+        if (st == RB_ST_PENDING_INTERNAL) rb_tw_pair<CAP>(p, pi, lds_w, lds_c);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the LDS arrays are reused by the next pair)
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 
+extern "C" size_t rb_trim_scratch_bytes(uint32_t blocks) { return (size_t)blocks * RB_TW_SLAB_WORDS(RB_TW_CAP3) * 4u; }
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream) {
     if (p->n_pairs == 0) return hipSuccess;
     rb_trim_params q = *p;
     static const bool serial_only = getenv("RB_DEBUG_TRIM_SERIAL") != nullptr; // diagnostics: the general kernel for every pair
+    if (!serial_only) {
+        q.only_pending = 0;
+        hipLaunchKernelGGL(rb_k_overlap_split_wave<RB_TW_CAP>, dim3((unsigned)p->n_pairs), dim3(64), 0, stream, q);
+        const unsigned g2 = (unsigned)(p->n_pairs < 2048 ? p->n_pairs : 2048);
+        hipLaunchKernelGGL(rb_k_overlap_split_wave_pending<RB_TW_CAP2>, dim3(g2), dim3(64), 0, stream, q);
+        if (q.scratch && q.scratch_blocks) {
+            const unsigned g3 = (unsigned)(p->n_pairs < q.scratch_blocks ? p->n_pairs : q.scratch_blocks);
+            hipLaunchKernelGGL(rb_k_overlap_split_wave_scratch<RB_TW_CAP3>, dim3(g3), dim3(64), 0, stream, q);
+        }
+    }
     q.only_pending = serial_only ? 0 : 1;
-    if (!serial_only) hipLaunchKernelGGL(rb_k_overlap_split_wave, dim3((unsigned)p->n_pairs), dim3(64), 0, stream, q);
+    static const bool no_serial = getenv("RB_DEBUG_TRIM_NO_SERIAL") != nullptr; // diagnostics: leave what the wave kernels declined as it is
+    if (no_serial) return hipGetLastError();
     hipLaunchKernelGGL(rb_k_overlap_split, dim3((unsigned)((p->n_pairs + 63) / 64)), dim3(64), 0, stream, q);
     return hipGetLastError();
 }

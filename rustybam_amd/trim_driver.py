@@ -171,7 +171,7 @@ class ResidentTrim:
         self.order = np.argsort(group, kind="stable")
         gs = group[self.order]
         self.grp_sorted = np.cumsum(np.r_[0, gs[1:] != gs[:-1]])
-        self.passes, self.pairs_done = 0, 0
+        self.passes, self.pairs_done, self.pairs_by_wave = 0, 0, 0
 
     def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000):
         torch, eng, dev = self.torch, self.eng, self.dev
@@ -200,6 +200,7 @@ class ResidentTrim:
                     raise RuntimeError(f"trim pair status {int(st[st != 0][0])}: the reference panics")
                 qcols = r64[:, 6:10].cpu().numpy().view(np.uint64)            # q_st[2], q_en[2]
                 outn = r64[:, 14].cpu().numpy().view(np.uint32).reshape(-1, 2)
+                self.pairs_by_wave += int((r64[:, 15] == 1).sum().item())   # (diagnostic word of the row: 1 = done by the wave-per-pair kernel)
                 self.q_st[left], self.q_st[right] = qcols[:, 0], qcols[:, 1]
                 self.q_en[left], self.q_en[right] = qcols[:, 2], qcols[:, 3]
                 self.cur_n[left], self.cur_n[right] = outn[:, 0], outn[:, 1]

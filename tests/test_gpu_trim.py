@@ -14,7 +14,7 @@ from rbtest_util import random_cigar, read_paf, recs_from_lines, sums, unpack
 pytestmark = pytest.mark.gpu
 
 
-def _pairs_batch(rng, n_pairs, mode, zero_bias=False, ops_range=(3, 60)):
+def _pairs_batch(rng, n_pairs, mode, zero_bias=False, ops_range=(3, 60), max_overlap=None):
     cig, t_st, t_en, q_st, q_en, strand = [], [], [], [], [], []
     left, right = [], []
     for _ in range(n_pairs):
@@ -24,7 +24,7 @@ def _pairs_batch(rng, n_pairs, mode, zero_bias=False, ops_range=(3, 60)):
         if min(qa, qb) < 2:
             continue
         a0 = 0 if (zero_bias and rng.random() < 0.5) else int(rng.integers(0, 1000))
-        o = int(rng.integers(1, min(qa, qb)))  # 1 <= overlap < both lengths: neither is contained
+        o = int(rng.integers(1, min(qa, qb) if max_overlap is None else min(qa, qb, max_overlap)))  # 1 <= overlap < both lengths: neither is contained
         b0 = a0 + qa - o
         for c, r, q, s0 in ((ca, ra, qa, a0), (cb, rb, qb, b0)):
             ts = int(rng.integers(0, 5000))
@@ -89,6 +89,23 @@ def test_pairs_long_regular_cigars(engine, oracle, ops_range):
         ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
         orows, oout = oracle.overlap_split(ob, left, right, scores)
         _compare(rows, out, orows, oout, f"long regular {ops_range} {scores}")
+
+
+@pytest.mark.parametrize("ops_range,max_overlap", [((2000, 9000), 4000), ((700, 1200), 150000), ((9000, 30000), 60)])
+def test_pairs_records_longer_than_the_staged_region(engine, oracle, ops_range, max_overlap):
+    """records of thousands of ops (whole-chromosome alignments) whose overlap is short: the wave kernel stages only the ops around
+    the overlap, streams what lies in front of them for the totals and copies what the clip keeps; overlaps wider than the region
+    still go to the serial kernel"""
+    rng = np.random.default_rng(ops_range[0] + max_overlap)
+    b, left, right = _pairs_batch(rng, 24, "regular", ops_range=ops_range, max_overlap=max_overlap)
+    for scores in ((1, 1, 1), (3, 1, 7)):
+        rows, out = engine.overlap_split(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"], left, right, scores)
+        ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
+        orows, oout = oracle.overlap_split(ob, left, right, scores)
+        _compare(rows, out, orows, oout, f"long records {ops_range} overlap<{max_overlap} {scores}")
+    by_wave = int((rows["_pad"] == 1).sum())
+    if max_overlap <= 4000:
+        assert by_wave >= len(rows) * 3 // 4, f"only {by_wave} of {len(rows)} pairs were done by the wave kernel"
 
 
 def test_pairs_odd_geometries(engine, oracle):
@@ -173,6 +190,8 @@ def test_trim_paf_fixture_with_the_batch_resident_on_the_device(golden, policy, 
     norm0 = T.d_norm.cpu().numpy().view(rustybam_amd.NORM_DT)[:r.n].copy()
     T.run((1, 1, 1), policy)
     assert T.passes >= 2 and T.pairs_done > 100
+    if policy == rustybam_amd.BSEARCH_MODERN:   # whole-chromosome alignments of up to 75 k ops: the wave kernel takes (nearly) all of their pairs
+        assert T.pairs_by_wave >= 0.95 * T.pairs_done, f"{T.pairs_by_wave} of {T.pairs_done} pairs by the wave kernel"
     d_new, new_off, norm = T.gather()
     ops = d_new.cpu().numpy().view(np.uint32)
     lines = []
