@@ -63,6 +63,8 @@ struct rb_trim_params {
     int only_pending;
     uint32_t *scratch;
     uint32_t scratch_blocks;
+    unsigned long long *pend;
+    uint32_t *pend_list;
 };
 struct rb_swap_params {
     uint64_t n_rec;
@@ -153,6 +155,8 @@ struct rb_ctx {
     // trim-paf: slabs of device memory for pairs whose overlap region does not fit LDS (allocated at the first rb_dev_overlap_split)
     void *trim_scratch = nullptr;
     uint32_t trim_scratch_blocks = 0;
+    void *trim_pend = nullptr; // [count (256 B) | indices of the pairs the first wave kernel declined]
+    uint64_t trim_pend_cap = 0;
 };
 
 struct rb_plan {
@@ -222,6 +226,7 @@ extern "C" void rb_ctx_destroy(rb_ctx *ctx) {
     for (auto e : ctx->ev_a) hipEventDestroy(e);
     for (auto e : ctx->ev_b) hipEventDestroy(e);
     if (ctx->trim_scratch) hipFree(ctx->trim_scratch);
+    if (ctx->trim_pend) hipFree(ctx->trim_pend);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -650,6 +655,20 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     }
     p.scratch = (uint32_t *)ctx->trim_scratch;
     p.scratch_blocks = ctx->trim_scratch_blocks;
+    if (ctx->trim_pend_cap < n_pairs) { // (grows with the largest pass seen; a few bytes per pair)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->trim_pend) hipFree(ctx->trim_pend);
+        ctx->trim_pend = nullptr, ctx->trim_pend_cap = 0;
+        const uint64_t cap = n_pairs + n_pairs / 4 + 1024;
+        if (hipMalloc(&ctx->trim_pend, 256 + cap * 4) == hipSuccess) ctx->trim_pend_cap = cap;
+        else (void)hipGetLastError();
+    }
+    p.pend = nullptr, p.pend_list = nullptr;
+    if (ctx->trim_pend) {
+        p.pend = (unsigned long long *)ctx->trim_pend;
+        p.pend_list = (uint32_t *)((char *)ctx->trim_pend + 256);
+        HIPCHK(ctx, hipMemsetAsync(p.pend, 0, 8, ctx->stream));
+    }
     HIPCHK(ctx, rb_launch_overlap_split(&p, ctx->stream));
     return RB_OK;
 }

@@ -10,6 +10,7 @@
 // independent (one pair per query name and pass, paf.rs:264-284); the pass/recursion driver stays on the
 // host.  Fully general (all op codes, both binary-search policies).
 #include "rb_serial.h"
+#include <algorithm>
 
 struct rb_trim_params {
     uint64_t n_pairs;
@@ -26,6 +27,10 @@ struct rb_trim_params {
     int only_pending;
     uint32_t *scratch;       // device memory for the third attempt of the wave kernel (regions too large for LDS), or NULL
     uint32_t scratch_blocks; // slabs in it
+    // pairs the first wave kernel declines, so that the attempts behind it do not have to look at every row: pend[0] = how many,
+    // pend_list[0 .. n_pairs) their indices (NULL: every row is looked at)
+    unsigned long long *pend;
+    uint32_t *pend_list;
 };
 
 struct rb_qstream {
@@ -193,10 +198,22 @@ __device__ uint32_t rb_clip_by_query(const rb_sview &v, uint64_t N, uint64_t new
     return RB_ST_OK;
 }
 
+__device__ void rb_serial_pair(const rb_trim_params &p, const uint64_t pi);
 __global__ __launch_bounds__(64) void rb_k_overlap_split(rb_trim_params p) {
+    if (p.only_pending && p.pend_list) { // what the wave kernels left, from their list
+        const uint64_t n = *p.pend;
+        for (uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (uint64_t)gridDim.x * blockDim.x) {
+            const uint64_t pi = p.pend_list[e];
+            if (p.rows[pi].status == 0x7FFF0001u) rb_serial_pair(p, pi);
+        }
+        return;
+    }
     const uint64_t pi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pi >= p.n_pairs) return;
-    if (p.only_pending && p.rows[pi].status != 0x7FFF0001u) return; // (second launch: what the wave-per-pair kernel left)
+    if (p.only_pending && p.rows[pi].status != 0x7FFF0001u) return; // (what the wave-per-pair kernels left, every row looked at)
+    rb_serial_pair(p, pi);
+}
+__device__ void rb_serial_pair(const rb_trim_params &p, const uint64_t pi) {
     rb_pair_row w;
     w.split_idx = 0;
     w.split_score = 0;
@@ -380,8 +397,8 @@ __device__ bool rb_tw_stage(rb_wrec &v, int lane, int32_t ms, int32_t ds, int32_
     // before the step that holds xa and ends one step behind the one that holds xb
     uint32_t Ub = 0, Qb = 0, Rb = 0, pU = 0, pQ = 0, pR = 0; // prefixes at the current step / at the step before
     uint32_t i0 = 0, bU = 0, bQ = 0, bR = 0, i1 = v.n;
-    bool found = false;
-    for (uint32_t c0 = 0; c0 < v.n; c0 += 64) {
+    bool found = v.n <= (uint32_t)CAP; // a record that fits is staged whole: nothing to look for
+    for (uint32_t c0 = 0; c0 < v.n && !found; c0 += 64) {
         const uint32_t i = c0 + (uint32_t)lane;
         const uint32_t w = i < v.n ? v.ops[i] : 0u;
         const uint32_t opc = rb_opc(w), len = i < v.n ? rb_len(w) : 0u;
@@ -698,7 +715,10 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
         return;
     }
     auto pending = [&](uint32_t why = 0) { // (why: diagnostics, RB_DEBUG_TRIM_NO_SERIAL; the serial kernel rewrites the whole row)
-        if (lane == 0) p.rows[pi].status = RB_ST_PENDING_INTERNAL, p.rows[pi].split_idx = why;
+        if (lane == 0) {
+            if (p.pend_list && !p.only_pending) p.pend_list[atomicAdd(p.pend, 1ull)] = (uint32_t)pi; // (listed once: by the first attempt)
+            p.rows[pi].status = RB_ST_PENDING_INTERNAL, p.rows[pi].split_idx = why;
+        }
     };
     if (p.policy == RB_BSEARCH_LEGACY || !(nl->flags & RB_F_REGULAR) || !(nr->flags & RB_F_REGULAR) || nl->n_ops == 0 || nr->n_ops == 0) {
         pending(1);
@@ -764,16 +784,20 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
                 const uint64_t len = rb_len(wv), Qi = v.Qc[k];
                 const int64_t Si = v.SP[k], mi = (int64_t)v.SP[k + 1] - Si, own = rb_tw_score(rb_opc(wv), ms, ds, is);
                 const int64_t w0 = Si, w1 = Si + (int64_t)(len - 1) * own, w2 = Si + mi; // W at offsets Qi, Qi + len - 1, Qi + len
+                // the score changes where the op starts, where its special last base starts (only if that base scores differently:
+                // a D / N run behind the op) and where the op ends -- which is where the next query op starts, so only the last op
+                // of the range looks at its end
+                const bool special = mi != (int64_t)len * own;
                 if (!v.minus) {
                     const uint64_t lo = v.q_st + Qi;
                     consider(lo, other, is_left, w0);
-                    consider(lo + len - 1, other, is_left, w1); // the special base (the last one in op order) starts
-                    consider(lo + len, other, is_left, w2);
+                    if (special) consider(lo + len - 1, other, is_left, w1); // the special base (the last one in op order) starts
+                    if (i == ib) consider(lo + len, other, is_left, w2);
                 } else {
-                    const uint64_t lo = v.q_en - Qi - len; // G(p) = -W(q_en - p)
-                    consider(lo, other, is_left, -w2);
-                    consider(lo + 1, other, is_left, -w1); // the special base (lowest position) ends
+                    const uint64_t lo = v.q_en - Qi - len; // G(p) = -W(q_en - p); positions fall as the ops go on
                     consider(lo + len, other, is_left, -w0);
+                    if (special) consider(lo + 1, other, is_left, -w1); // the special base (lowest position) ends
+                    if (i == ib) consider(lo, other, is_left, -w2);
                 }
             }
         };
@@ -825,26 +849,29 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_wave_scratch(rb_trim_pa
     uint32_t *slab = p.scratch + (size_t)blockIdx.x * RB_TW_SLAB_WORDS(CAP);
     auto *aw = reinterpret_cast<uint32_t (*)[3][CAP + 1]>(slab);
     auto *ac = reinterpret_cast<uint32_t (*)[3][CAP / 16 + 2]>(slab + 2u * 3u * (CAP + 1u));
-    for (uint64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    const uint64_t n = p.pend_list ? rb_first64(*p.pend) : p.n_pairs;
+    for (uint64_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint64_t pi = p.pend_list ? (uint64_t)rb_first(p.pend_list[e]) : e;
         const uint32_t st = rb_first(p.rows[pi].status);
         if (st == RB_ST_PENDING_INTERNAL) rb_tw_pair<CAP>(p, pi, aw, ac);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
 }
-// second attempt, for the pairs the first one left: a few wavefronts with a large region each walk the rows
+// second attempt, for the pairs the first one left: a few wavefronts with a large region each walk the list
 template <int CAP>
 __global__ __launch_bounds__(64) void rb_k_overlap_split_wave_pending(rb_trim_params p) {
     __shared__ uint32_t lds_w[2][3][CAP + 1];
     __shared__ uint32_t lds_c[2][3][CAP / 16 + 2];
-    for (uint64_t pi = blockIdx.x; pi < p.n_pairs; pi += gridDim.x) {
+    const uint64_t n = p.pend_list ? rb_first64(*p.pend) : p.n_pairs;
+    for (uint64_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const uint64_t pi = p.pend_list ? (uint64_t)rb_first(p.pend_list[e]) : e;
         const uint32_t st = rb_first(p.rows[pi].status);
         if (st == RB_ST_PENDING_INTERNAL) rb_tw_pair<CAP>(p, pi, lds_w, lds_c);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the LDS arrays are reused by the next pair)
         __builtin_amdgcn_wave_barrier();
     }
 }
-
 extern "C" size_t rb_trim_scratch_bytes(uint32_t blocks) { return (size_t)blocks * RB_TW_SLAB_WORDS(RB_TW_CAP3) * 4u; }
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream) {
     if (p->n_pairs == 0) return hipSuccess;
@@ -861,9 +888,11 @@ extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream
         }
     }
     q.only_pending = serial_only ? 0 : 1;
+    if (serial_only) q.pend_list = nullptr;
     static const bool no_serial = getenv("RB_DEBUG_TRIM_NO_SERIAL") != nullptr; // diagnostics: leave what the wave kernels declined as it is
     if (no_serial) return hipGetLastError();
-    hipLaunchKernelGGL(rb_k_overlap_split, dim3((unsigned)((p->n_pairs + 63) / 64)), dim3(64), 0, stream, q);
+    const uint64_t sblocks = (q.only_pending && q.pend_list) ? std::min<uint64_t>((p->n_pairs + 63) / 64, 256) : (p->n_pairs + 63) / 64;
+    hipLaunchKernelGGL(rb_k_overlap_split, dim3((unsigned)sblocks), dim3(64), 0, stream, q);
     return hipGetLastError();
 }
 

@@ -56,7 +56,13 @@ def main():
     t0 = time.time()
     hits, bout, norm, cnt = eng.break_paf(ops, off, t_st, t_en, q_st, q_en, strand, 100)
     t_break = time.time() - t0
+    # algorithmic bytes of the pair pass: both records of a pair read once (4 B per op) + 128 B row written + 4 B per emitted op
+    nops64 = nops.astype(np.int64)
+    pair_in = int((nops64[left] + nops64[right]).sum())
+    pair_out = int(rows["out_n"].astype(np.int64).sum())
+    pair_bytes = 4 * pair_in + 128 * len(left) + 4 * pair_out
     print(json.dumps({"workload": f"config4 scaled: {n} records, {int(off[-1])} ops, {len(left)} overlapping pairs, seed 0x5eed0004",
+                      "trim_pair_pass_algorithmic_bytes": pair_bytes, "trim_pair_ops_in": pair_in, "trim_pair_ops_out": pair_out,
                       "trim_pairs": len(left), "trim_pairs_ok": ok, "trim_wall_s": round(t_trim, 3), "trim_pairs_per_s_wall": len(left) / t_trim,
                       "break_pieces": int(len(hits)), "break_wall_s": round(t_break, 3), "break_records_per_s_wall": n / t_break,
                       "setup_s": round(gen, 2)}))
