@@ -40,7 +40,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=int, default=1_000_000, help="records per GPU")
     ap.add_argument("--windows", type=int, default=3000)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "irregular"],
+                    help="config3: the headline; config2: one 1 Mbp window; irregular: config 3's records made irregular (adjacent ops of one "
+                         "type at the start, an N / H op at an end of two thirds of them) so that every hit takes the generic wave-per-hit kernel")
+    ap.add_argument("--legacy", action="store_true", help="RB_BSEARCH_LEGACY (rustc 1.52 .. 1.81 binary search): duplicates resolved by probe replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--early-exit", action="store_true", help="allow the kernel to stop a record early (off: full walk)")
@@ -168,13 +171,13 @@ def main():
     eng = rustybam_amd.Engine(local_rank, stream)
 
     if args.scaling == "strong":  # one batch of --records, one op-balanced contiguous record range per rank
-        seed_ = wl.SEED_CONFIG3 if args.workload == "config3" else wl.SEED_CONFIG2
+        seed_ = wl.SEED_CONFIG2 if args.workload == "config2" else wl.SEED_CONFIG3
         bounds = shard.shard_bounds(wl.op_offsets(wl.n_ops(seed_, 0, args.records)), world)
         first, n_rec = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
     else:
         n_rec = args.records
         first = rank * n_rec
-    if args.workload == "config3":
+    if args.workload in ("config3", "irregular"):
         seed, placement = wl.SEED_CONFIG3, "uniform"
         w_c, w_st, w_en = wl.sliding_windows(args.windows)
     else:
@@ -193,6 +196,18 @@ def main():
     d_off = dev_u64(op_off)
     d_ops = torch.empty(total_ops + 64, dtype=torch.int32, device=dev)
     eng.dev_synth_fill_ops(seed, first, n_rec, d_off.data_ptr(), d_ops.data_ptr())
+    if args.workload == "irregular":
+        # op 1 (the first event) becomes an '=': three adjacent '=' ops that the reference's collapse merges (paf.rs:602-620); a third of
+        # the records also end on an N, a third start on an H: no match op at that end.  None of them can take the streaming kernel.
+        torch.cuda.synchronize()
+        rr = torch.arange(n_rec, device=dev)
+        i1 = d_off[:-1] + 1
+        d_ops[i1] = (d_ops[i1] & ~15) | 7
+        il = (d_off[1:] - 1)[rr % 3 == 1]
+        d_ops[il] = (d_ops[il] & ~15) | 3
+        i0 = d_off[:-1][rr % 3 == 2]
+        d_ops[i0] = (d_ops[i0] & ~15) | 5
+        torch.cuda.synchronize()
     zeros = torch.zeros(n_rec, dtype=torch.int64, device=dev)
     d_contig = torch.zeros(n_rec, dtype=torch.int32, device=dev)
     d_strand0 = torch.full((n_rec,), ord("+"), dtype=torch.uint8, device=dev)
@@ -214,6 +229,7 @@ def main():
     torch.cuda.synchronize()
     red = d_red.cpu().numpy().view(rustybam_amd.REDUCE_DT)
     assert (red["status"] == 0).all(), "synthetic records must pass check_integrity"
+    irregular = args.workload == "irregular"
     del d_red
     tp = time.perf_counter()
     plan = eng.plan_create(op_off, np.zeros(n_rec, np.uint32), w_c, w_st, w_en)
@@ -221,7 +237,7 @@ def main():
     gen_s = time.time() - t0
 
     # ---- size the outputs (first call tells what is needed) ----
-    policy = rustybam_amd.BSEARCH_MODERN | (rustybam_amd.LIFT_EARLY_EXIT if args.early_exit else 0) | (args.debug_skip << 8)
+    policy = (rustybam_amd.BSEARCH_LEGACY if args.legacy else rustybam_amd.BSEARCH_MODERN) | (rustybam_amd.LIFT_EARLY_EXIT if args.early_exit else 0) | (args.debug_skip << 8)
     if args.descriptors:
         policy |= rustybam_amd.LIFT_DESCRIPTORS
     if not args.unfused:
@@ -339,7 +355,7 @@ def main():
         ks = np.sort(np.asarray(kern_ms[-args.steps:]))
         print(f"[kernel ms] min {ks[0]:.3f}  median {ks[len(ks) // 2]:.3f}  mean {ks.mean():.3f}  max {ks[-1]:.3f}"
               f"  | out_cap {out_cap} rows_cap {rows_cap} d_out 0x{d_out.data_ptr():x} d_ops 0x{d_ops.data_ptr():x}", file=sys.stderr)
-    if args.op == "break":
+    if args.op == "break" or irregular:  # (no single dominant kernel under HIP events: the rate is taken over the whole step)
         k_ms = elapsed / args.steps * 1e3
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     traffic = None  # HBM-side bytes per launch from the committed PMC run of this same workload (bench.py is not run under --pmc)
@@ -349,13 +365,15 @@ def main():
             traffic = tj["traffic_bytes_per_launch"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "rb_k_liftover_stream" if args.op == "liftover" else "rb_dev_break (rb_k_break_pieces + rb_k_liftover_stream)", "achieved": round(achieved, 1), "peak": 8000.0,
+    roofline = {"bound": "hbm", "kernel": ("rb_k_liftover_generic_wave (whole step: the streaming kernel only verifies and defers)" if irregular else "rb_k_liftover_stream") if args.op == "liftover"
+                else "rb_dev_break (rb_k_break_pieces + rb_k_liftover_stream)", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)}
 
     result = {
         "metric": (("CIGAR-ops/s, liftover over 100 kb sliding windows (whole pass, inputs resident in HBM)" if args.workload == "config3" else
+                    f"CIGAR-ops/s, liftover over 100 kb sliding windows, irregular CIGARs{', legacy binary search' if args.legacy else ''} (generic kernel; whole pass, inputs resident in HBM)" if irregular else
                     "CIGAR-ops/s, liftover over one 1 Mbp window (whole pass, inputs resident in HBM)") if args.op == "liftover"
                    else "CIGAR-ops/s, break-paf --max-size 100 (whole pass, inputs resident in HBM)"),
         "value": job_ops * args.steps / elapsed,
@@ -387,7 +405,7 @@ def main():
         result.update(e2e)
 
     # ---- CPU baseline + sample parity (rank 0, N = 1 only) ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.descriptors and args.op == "liftover":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.descriptors and args.op == "liftover" and not irregular:
         from oracle import pyoracle  # checker / baseline only; never on the product path
         from rustybam_amd import capi
         threads = os.cpu_count() or 1

@@ -894,9 +894,9 @@ __device__ bool rb_bsearch_units(const uint32_t *ops, uint32_t n, uint64_t t_st,
     return false;
 }
 
-__global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
-    const uint64_t n_gen = p.counters->n_generic;
-    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_gen; g += (uint64_t)gridDim.x * blockDim.x) {
+// one hit, one thread, serial (the general case of the general case: also what the wave kernel below hands unsorted arrays to)
+__device__ void rb_generic_serial_hit(const rb_lift_params &p, const uint64_t g) {
+    for (int once = 0; once < 1; once++) {
         const uint64_t hrow = p.gen_list[g];
         rb_hit_row *row = &p.rows[hrow];
         const uint32_t r = row->rec, win = row->win;
@@ -1111,6 +1111,254 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
         *row = w;
     }
 }
+__global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) { // (diagnostics: RB_DEBUG_GENERIC_SERIAL)
+    const uint64_t n_gen = p.counters->n_generic;
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_gen; g += (uint64_t)gridDim.x * blockDim.x) rb_generic_serial_hit(p, g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// generic kernel, one WAVEFRONT per hit: the same unit semantics, every walk of the ops a pass of 64 ops per step with wave scans.
+//   pass 1  equal ranges of the window's first / last base in the virtual tpos_aln (paf.rs:505-534) and the number of units
+//   pass 2  first match-type unit >= the start index, last one <= the end index (paf.rs:551-558), with the prefixes there
+//   pass 3  the ops between them, first / last length cut, adjacent ops of one type merged (paf.rs:602-620), zero lengths dropped
+// A tpos_aln that is not sorted (units at position -1, see rb_bsearch_units) goes to the serial code above.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rb_wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t rb_wave_max_u64(uint64_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+__global__ __launch_bounds__(256) void rb_k_liftover_generic_wave(rb_lift_params p) {
+    __shared__ uint32_t run_tot_all[4][64], run_opc_all[4][64];
+    const uint32_t wib = threadIdx.x >> 6;
+    uint32_t *run_tot = run_tot_all[wib], *run_opc = run_opc_all[wib];
+    const int lane = rb_lane();
+    const uint64_t n_gen = p.counters->n_generic;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4u + wib; g < n_gen; g += (uint64_t)gridDim.x * 4u) {
+        const uint64_t hrow = p.gen_list[g];
+        rb_hit_row *row = &p.rows[hrow];
+        const uint32_t r = row->rec, win = row->win;
+        const rb_norm_row *nr = &p.norm[r];
+        rb_hit_row w;
+        w.rec = r;
+        w.win = win;
+        w.flags = RB_HIT_GENERIC;
+        w.status = RB_ST_OK;
+        w.out_n = 0;
+        w.out_off = 0;
+        w.t_st = w.t_en = w.q_st = w.q_en = 0;
+        w.nmatch = w.aln_len = 0;
+        if (nr->status != RB_ST_OK) { // fused scan: the record was handed back and the full scan found the reference would panic on it
+            w.status = (uint16_t)nr->status;
+            w.flags = row->flags;
+            if (lane == 0) *row = w;
+            continue;
+        }
+        const uint64_t t_st = nr->t_st, t_en = nr->t_en, q_st = nr->q_st, q_en = nr->q_en;
+        const bool minus = p.strand[r] == (uint8_t)'-';
+        const uint32_t n = nr->n_ops;
+        const uint32_t *ops = p.ops + p.op_off[r] + nr->first_op;
+        const uint64_t wst = p.x_st ? p.x_st[hrow] : p.wo_st[win];
+        const uint64_t wen = p.x_en ? p.x_en[hrow] : p.wo_en[win];
+        const uint32_t arena = (uint32_t)(g % p.n_arena);
+        auto reserve = [&](uint32_t padded, uint64_t *off) -> bool { // room in an arena, for the whole wave
+            unsigned long long b0 = 0;
+            if (lane == 0) b0 = atomicAdd(&p.arena_cur[(uint64_t)arena * RB_ARENA_STRIDE], (unsigned long long)padded);
+            b0 = rb_first64(b0);
+            if (b0 + padded > p.arena_size) {
+                if (lane == 0) p.counters->overflow = 1;
+                return false;
+            }
+            *off = p.arena_origin + (uint64_t)arena * p.arena_size + b0;
+            return true;
+        };
+        if (t_st > wst && t_en < wen) { // liftover.rs:23-25: verbatim clone, own id
+            w.flags |= RB_HIT_INSIDE;
+            w.t_st = t_st, w.t_en = t_en, w.q_st = q_st, w.q_en = q_en;
+            w.nmatch = nr->nmatch, w.aln_len = nr->aln_len;
+            w.out_n = n;
+            uint64_t off;
+            if (reserve((n + 3u) & ~3u, &off)) {
+                w.out_off = off;
+                for (uint32_t i = (uint32_t)lane; i < n; i += 64u) p.out_ops[off + i] = ops[i];
+            }
+            if (lane == 0) *row = w;
+            continue;
+        }
+        const int64_t ps = (int64_t)(wst > t_st ? wst : t_st); // positions to look up (liftover.rs:28, :38-40)
+        const int64_t pe = (int64_t)(wen < t_en ? wen : t_en) - 1;
+        // ---- pass 1 ----
+        uint64_t s_lo = ~0ull, s_hi = 0, e_lo = ~0ull, e_hi = 0;
+        uint64_t Ub = 0, Rb = 0;
+        bool first_seen = false, wrapped = false;
+        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+            const uint32_t i = c0 + (uint32_t)lane;
+            const uint32_t wv = i < n ? ops[i] : 0u;
+            const uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
+            const bool isref = opc <= 8u && rb_in(RB_REF_MASK, opc);
+            const uint32_t iu = rb_wave_scan_incl(len), ir = rb_wave_scan_incl(isref ? len : 0u);
+            if (!first_seen) {
+                const uint64_t m = __ballot(len != 0u);
+                if (m) {
+                    first_seen = true;
+                    wrapped = t_st == 0 && !((__ballot(isref) >> __builtin_ctzll(m)) & 1ull);
+                }
+            }
+            if (len) {
+                const uint64_t U = Ub + iu - len;
+                const int64_t tpos = (int64_t)t_st - 1 + (int64_t)(Rb + ir - (isref ? len : 0u));
+                if (isref) { // units U .. U + len - 1 hold tpos + 1 .. tpos + len
+                    if (ps > tpos && ps <= tpos + (int64_t)len) {
+                        const uint64_t u = U + (uint64_t)(ps - tpos - 1);
+                        s_lo = s_lo < u ? s_lo : u, s_hi = s_hi > u ? s_hi : u;
+                    }
+                    if (pe > tpos && pe <= tpos + (int64_t)len) {
+                        const uint64_t u = U + (uint64_t)(pe - tpos - 1);
+                        e_lo = e_lo < u ? e_lo : u, e_hi = e_hi > u ? e_hi : u;
+                    }
+                } else {
+                    if (ps == tpos && tpos >= 0) s_lo = s_lo < U ? s_lo : U, s_hi = s_hi > U + len - 1 ? s_hi : U + len - 1;
+                    if (pe == tpos && tpos >= 0) e_lo = e_lo < U ? e_lo : U, e_hi = e_hi > U + len - 1 ? e_hi : U + len - 1;
+                }
+            }
+            Ub += rb_readlane<uint32_t>(iu, 63);
+            Rb += rb_readlane<uint32_t>(ir, 63);
+            if ((int64_t)t_st - 1 + (int64_t)Rb > pe) break; // every unit behind this step lies behind the window's last base
+        }
+        if (wrapped) { // an unsorted tpos_aln: binary_search returns what its probe sequence leads to (serial replay)
+            if (lane == 0) rb_generic_serial_hit(p, g);
+            continue;
+        }
+        const uint64_t N = nr->aln_len; // all units of the (normalised) record
+        s_lo = rb_wave_min_u64(s_lo), s_hi = rb_wave_max_u64(s_hi), e_lo = rb_wave_min_u64(e_lo), e_hi = rb_wave_max_u64(e_hi);
+        if (s_lo == ~0ull || e_lo == ~0ull) { // binary_search Err -> panic (liftover.rs:31, :42)
+            w.status = RB_ST_PANIC_NOTFOUND;
+            if (lane == 0) *row = w;
+            continue;
+        }
+        const uint64_t ks = p.policy == RB_BSEARCH_LEGACY ? rb_legacy_probe(N, s_lo, s_hi) : s_hi;
+        const uint64_t ke = p.policy == RB_BSEARCH_LEGACY ? rb_legacy_probe(N, e_lo, e_hi) : e_hi;
+        // ---- pass 2: a = first match-type unit >= ks (else N); b = last match-type unit <= ke (else 0) ----
+        uint64_t a = N, b = 0, Ra = 0, Qa = 0, Ma = 0, nRb = 0, nQb = 0, nMb = 0, Ua_op = 0, Ub_op = 0;
+        uint32_t ia = 0, ib = 0, len_a = 0, len_b = 0;
+        bool a_set = false, b_set = false;
+        {
+            uint64_t U0 = 0, R0 = 0, Q0 = 0, M0 = 0;
+            for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+                if (a_set && U0 > ke) break; // (nothing behind this can be <= ke)
+                const uint32_t i = c0 + (uint32_t)lane;
+                const uint32_t wv = i < n ? ops[i] : 0u;
+                const uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
+                const bool okc = opc <= 8u;
+                const bool isref = okc && rb_in(RB_REF_MASK, opc), isq = okc && rb_in(RB_QRY_MASK, opc), ism = okc && rb_in(RB_MATCH_MASK, opc);
+                const uint32_t iu = rb_wave_scan_incl(len), ir = rb_wave_scan_incl(isref ? len : 0u), iq = rb_wave_scan_incl(isq ? len : 0u),
+                               im = rb_wave_scan_incl(ism ? len : 0u);
+                const uint64_t U = U0 + iu - len, R = R0 + ir - (isref ? len : 0u), Q = Q0 + iq - (isq ? len : 0u), M = M0 + im - (ism ? len : 0u);
+                if (!a_set) {
+                    const uint64_t m = __ballot(ism && len != 0u && U + len > ks);
+                    if (m) {
+                        const int l = __builtin_ctzll(m);
+                        const uint64_t Ul = rb_readlane<uint64_t>(U, l);
+                        a = ks > Ul ? ks : Ul;
+                        const uint64_t off = a - Ul;
+                        Ra = rb_readlane<uint64_t>(R, l) + off, Qa = rb_readlane<uint64_t>(Q, l) + off, Ma = rb_readlane<uint64_t>(M, l) + off;
+                        Ua_op = Ul, ia = c0 + (uint32_t)l, len_a = rb_readlane<uint32_t>(len, l);
+                        a_set = true;
+                    }
+                }
+                {
+                    const uint64_t m = __ballot(ism && len != 0u && U <= ke);
+                    if (m) {
+                        const int l = 63 - __builtin_clzll(m);
+                        const uint64_t Ul = rb_readlane<uint64_t>(U, l);
+                        const uint32_t ll = rb_readlane<uint32_t>(len, l);
+                        b = Ul + ll - 1 < ke ? Ul + ll - 1 : ke;
+                        const uint64_t off = b - Ul;
+                        nRb = rb_readlane<uint64_t>(R, l) + off + 1, nQb = rb_readlane<uint64_t>(Q, l) + off + 1, nMb = rb_readlane<uint64_t>(M, l) + off + 1;
+                        Ub_op = Ul, ib = c0 + (uint32_t)l, len_b = ll;
+                        b_set = true;
+                    }
+                }
+                U0 += rb_readlane<uint32_t>(iu, 63), R0 += rb_readlane<uint32_t>(ir, 63), Q0 += rb_readlane<uint32_t>(iq, 63), M0 += rb_readlane<uint32_t>(im, 63);
+            }
+        }
+        if (a > b || a >= N || !a_set || !b_set) { // liftover.rs:52-54
+            w.status = RB_ST_NONE_INDEL;
+            if (lane == 0) *row = w;
+            continue;
+        }
+        w.t_st = t_st + Ra; // liftover.rs:57-60, :77-82 (a and b are match-type units)
+        w.t_en = t_st + nRb;
+        if (!minus) w.q_st = q_st + Qa, w.q_en = q_st + nQb;
+        else w.q_st = q_en - nQb, w.q_en = q_en - Qa;
+        w.nmatch = (uint32_t)(nMb - Ma);
+        w.aln_len = (uint32_t)(b - a + 1);
+        // ---- pass 3: ops ia .. ib, zero lengths dropped, first / last cut, runs of one type merged ----
+        uint64_t off;
+        if (!reserve((ib - ia + 1u + 3u) & ~3u, &off)) { // (at least as many slots as the merge leaves)
+            if (lane == 0) *row = w;
+            continue;
+        }
+        uint32_t out_pos = 0, c_tot = 0, c_opc = 0;
+        bool has_carry = false;
+        for (uint32_t c0 = ia & ~63u; c0 <= ib; c0 += 64u) {
+            const uint32_t i = c0 + (uint32_t)lane;
+            const uint32_t wv = (i >= ia && i <= ib) ? ops[i] : 0u;
+            const uint32_t opc = rb_opc(wv), len = rb_len(wv);
+            const bool in = i >= ia && i <= ib && len != 0u;
+            uint32_t piece = len;
+            if (i == ia) piece = ia == ib ? (uint32_t)(b - a + 1) : (uint32_t)(Ua_op + len_a - a);
+            else if (i == ib) piece = (uint32_t)(b - Ub_op + 1);
+            // code of the last kept op in front of this lane (bit 4: there is one); lane 0 takes the run carried over
+            const uint32_t key = in ? ((uint32_t)lane << 5) | 16u | opc : 0u;
+            const uint32_t incl = rb_wave_scan_incl_max_u32(key);
+            const uint32_t ckey = has_carry ? 16u | c_opc : 0u;
+            uint32_t prev = rb_prev_lane(incl, ckey);
+            prev = (prev & 16u) ? prev : ckey; // (no kept op in front of this lane in this step: the run carried over)
+            const bool start = in && !((prev & 16u) && (prev & 15u) == opc);
+            const uint64_t sm = __ballot(start);
+            const uint32_t nstarts = (uint32_t)__builtin_popcountll(sm);
+            const int32_t ridx = (int32_t)__builtin_popcountll(sm & ((2ull << lane) - 1ull)) - 1; // run of this lane inside the step (-1: the carried one)
+            run_tot[lane] = 0u;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (in && ridx >= 0) atomicAdd(&run_tot[ridx], piece);
+            if (start) run_opc[ridx] = opc;
+            c_tot += rb_wave_sum_u32((in && ridx < 0) ? piece : 0u);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (nstarts) {
+                if (has_carry) {
+                    if (lane == 0) p.out_ops[off + out_pos] = (c_tot << 4) | c_opc;
+                    out_pos++;
+                }
+                if ((uint32_t)lane + 1u < nstarts) p.out_ops[off + out_pos + (uint32_t)lane] = (run_tot[lane] << 4) | run_opc[lane];
+                out_pos += nstarts - 1u;
+                c_tot = run_tot[nstarts - 1u], c_opc = run_opc[nstarts - 1u];
+                has_carry = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (has_carry) {
+            if (lane == 0) p.out_ops[off + out_pos] = (c_tot << 4) | c_opc;
+            out_pos++;
+        }
+        w.out_n = out_pos;
+        w.out_off = off;
+        if (lane == 0) *row = w;
+    }
+}
 
 // out_ops_used / out_ops_needed from the arena cursors
 __global__ __launch_bounds__(64) void rb_k_finish(rb_lift_params p) {
@@ -1167,7 +1415,9 @@ extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStre
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_copy_clips, dim3(2048), dim3(256), 0, stream, *p);
-    hipLaunchKernelGGL(rb_k_liftover_generic, dim3(1024), dim3(256), 0, stream, *p);
+    static const bool serial_generic = getenv("RB_DEBUG_GENERIC_SERIAL") != nullptr; // diagnostics: one thread per hit, as in round 1
+    if (serial_generic) hipLaunchKernelGGL(rb_k_liftover_generic, dim3(1024), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(rb_k_liftover_generic_wave, dim3(2048), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
     return hipGetLastError();
 }

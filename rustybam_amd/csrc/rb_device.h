@@ -71,6 +71,18 @@ __device__ __forceinline__ uint32_t rb_wave_scan_incl(uint32_t v) {
     return v;
 }
 
+// wave64 inclusive prefix maximum of one u32 per lane (same network as the sum)
+__device__ __forceinline__ uint32_t rb_wave_scan_incl_max_u32(uint32_t v) {
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(8), 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_BCAST15, 0xa, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_BCAST31, 0xc, 0xf, false));
+    return v;
+}
+
 // value of lane-1 (lane 0 receives `carry`)
 __device__ __forceinline__ uint32_t rb_prev_lane(uint32_t v, uint32_t carry) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)carry, (int)v, RB_DPP_WAVE_SHR1, 0xf, 0xf, false);
