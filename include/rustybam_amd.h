@@ -201,7 +201,11 @@ int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_out);
 /* device memory helpers for hosts without their own allocator (the C++ host and ctypes tests) */
 int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr);
 int rb_dev_free(rb_ctx *ctx, void *dev_ptr);
-int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);   /* async */
+/* Transfers of 8 MB and more go through the context's pinned staging ring (two page-locked 32 MB chunks, hipHostMalloc): the
+ * host side of a chunk is copied on several host threads while the DMA of the other chunk runs, so pageable caller memory moves
+ * at the link's rate and host_src may be reused as soon as rb_dev_upload returns (the DMAs are queued on the context's stream).
+ * Smaller uploads are plain asynchronous copies: host_src must then stay valid until the stream has been synchronised. */
+int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes);   /* async with respect to the device */
 int rb_dev_download(rb_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes); /* synchronises */
 int rb_dev_memset(rb_ctx *ctx, void *dev_dst, int value, size_t bytes);              /* async */
 

@@ -157,7 +157,14 @@ struct rb_ctx {
     uint32_t trim_scratch_blocks = 0;
     void *trim_pend = nullptr; // [count (256 B) | indices of the pairs the first wave kernel declined]
     uint64_t trim_pend_cap = 0;
+    // pinned staging ring of the host-buffer entry points (rb_dev_upload / rb_dev_download): large transfers go through two
+    // page-locked chunks (hipHostMalloc), the copy into / out of a chunk on several host threads while the DMA of the other runs
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
+    bool pin_busy[2] = {false, false};
 };
+#define RB_PIN_CHUNK ((size_t)32 << 20)
+#define RB_PIN_MIN ((size_t)8 << 20) // smaller transfers take the runtime's own pageable path
 
 struct rb_plan {
     rb_ctx *ctx = nullptr;
@@ -225,6 +232,10 @@ extern "C" void rb_ctx_destroy(rb_ctx *ctx) {
     if (!ctx) return;
     for (auto e : ctx->ev_a) hipEventDestroy(e);
     for (auto e : ctx->ev_b) hipEventDestroy(e);
+    for (int k = 0; k < 2; k++) {
+        if (ctx->pin[k]) hipHostFree(ctx->pin[k]);
+        if (ctx->pin_ev[k]) hipEventDestroy(ctx->pin_ev[k]);
+    }
     if (ctx->trim_scratch) hipFree(ctx->trim_scratch);
     if (ctx->trim_pend) hipFree(ctx->trim_pend);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -280,14 +291,87 @@ extern "C" int rb_dev_free(rb_ctx *ctx, void *dev_ptr) {
     if (dev_ptr) HIPCHK(ctx, hipFree(dev_ptr));
     return RB_OK;
 }
+static bool pin_ready(rb_ctx *ctx) {
+    if (ctx->pin[0]) return true;
+    static const bool off = getenv("RB_NO_PINNED") != nullptr; // diagnostics: the runtime's pageable path for everything
+    if (off) return false;
+    for (int k = 0; k < 2; k++) {
+        if (hipHostMalloc(&ctx->pin[k], RB_PIN_CHUNK, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&ctx->pin_ev[k], hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int j = 0; j <= k; j++) {
+                if (ctx->pin[j]) hipHostFree(ctx->pin[j]);
+                if (ctx->pin_ev[j]) hipEventDestroy(ctx->pin_ev[j]);
+                ctx->pin[j] = nullptr, ctx->pin_ev[j] = nullptr;
+            }
+            return false;
+        }
+    }
+    return true;
+}
+static void par_memcpy(void *dst, const void *src, size_t n) { // a chunk of the staging ring, on a few host threads
+    const unsigned T = n >= ((size_t)4 << 20) ? 4u : 1u;
+    if (T == 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t part = (n / T + 63) & ~(size_t)63;
+    for (unsigned t = 1; t < T; t++) {
+        const size_t lo = std::min(n, t * part), hi = std::min(n, (t + 1) * part);
+        if (hi > lo) th.emplace_back([=]() { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    memcpy(dst, src, std::min(n, part));
+    for (auto &x : th) x.join();
+}
 extern "C" int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
     if (!ctx) return RB_E_INVALID;
-    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (!bytes) return RB_OK;
+    if (bytes < RB_PIN_MIN || !pin_ready(ctx)) {
+        HIPCHK(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return RB_OK;
+    }
+    // host_src is consumed chunk by chunk into page-locked memory; when the call returns the caller may reuse it, the DMAs are
+    // queued on the context's stream
+    for (size_t off = 0, k = 0; off < bytes; off += RB_PIN_CHUNK, k++) {
+        const int slot = (int)(k & 1);
+        const size_t n = std::min(RB_PIN_CHUNK, bytes - off);
+        if (ctx->pin_busy[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[slot]));
+        par_memcpy(ctx->pin[slot], (const char *)host_src + off, n);
+        HIPCHK(ctx, hipMemcpyAsync((char *)dev_dst + off, ctx->pin[slot], n, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+        ctx->pin_busy[slot] = true;
+    }
     return RB_OK;
 }
 extern "C" int rb_dev_download(rb_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
     if (!ctx) return RB_E_INVALID;
-    if (bytes) HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (bytes < RB_PIN_MIN || !pin_ready(ctx)) {
+        if (bytes) HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return RB_OK;
+    }
+    // chunk k + 1 is in flight into one page-locked slot while chunk k leaves the other for host_dst
+    size_t prev_off = 0, prev_n = 0;
+    int prev_slot = -1;
+    for (size_t off = 0, k = 0; off < bytes; off += RB_PIN_CHUNK, k++) {
+        const int slot = (int)(k & 1);
+        const size_t n = std::min(RB_PIN_CHUNK, bytes - off);
+        if (ctx->pin_busy[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[slot])); // (an upload that used the slot)
+        HIPCHK(ctx, hipMemcpyAsync(ctx->pin[slot], (const char *)dev_src + off, n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(ctx->pin_ev[slot], ctx->stream));
+        ctx->pin_busy[slot] = true;
+        if (prev_slot >= 0) {
+            HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[prev_slot]));
+            par_memcpy((char *)host_dst + prev_off, ctx->pin[prev_slot], prev_n);
+            ctx->pin_busy[prev_slot] = false;
+        }
+        prev_off = off, prev_n = n, prev_slot = slot;
+    }
+    if (prev_slot >= 0) {
+        HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[prev_slot]));
+        par_memcpy((char *)host_dst + prev_off, ctx->pin[prev_slot], prev_n);
+        ctx->pin_busy[prev_slot] = false;
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return RB_OK;
 }
