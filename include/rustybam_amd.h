@@ -374,9 +374,14 @@ int rb_host_scan_text(rb_ctx *ctx, uint64_t n_rec, const uint8_t *text, uint64_t
  *           SECONDARY | QCFAIL | DUP).  BAD_CIGAR = htslib's cursor would assert (no reference-consuming op, a lone op that
  *           is not M/=/X, a zero-length M/D/N/=/X) or the spans do not fit 31 bits.  SEQ_SHORT = a counted base lies past
  *           l_seq (the reference panics on the index).  Reads that are not OK contribute nothing.
- *   counters OUT: max_depth (reads covering one position, deletions included), n_covered, n_bad, unsorted.  htslib's pileup
- *           stops admitting reads once 8000 are buffered; that cap is NOT restated (parity unpinned): a caller must treat
- *           max_depth + 2 > 8000 as unsupported, rb_host_nucfreq returns RB_E_INVALID for it, and for unsorted input.
+ *   counters OUT: max_depth (reads covering one position, deletions included), n_covered, n_bad, unsorted, n_dropped,
+ *           cap_overflow.  htslib's pileup (bam_plp_push) drops a read that starts where the iterator stands while more than
+ *           maxcnt = 8000 reads are buffered; that rule is restated on the device per region (= per fetch of the reference),
+ *           oracle/rb_oracle.c rbo_nucfreq holds the same restatement: n_dropped counts the (region, read) pairs it removed.
+ *           cap_overflow = 1 when the bookkeeping of that rule did not fit (more than 15360 reads buffered at once, or regions
+ *           deeper than the cap overlapping each other more than 64-fold): the counts are then not the reference's.  The same
+ *           goes for max_depth > 65535 (16-bit counters).  rb_host_nucfreq returns RB_E_INVALID for all three, and for
+ *           unsorted input.
  *   ws      rb_nucfreq_workspace_bytes(n_reads, n_regions, n_positions) bytes, 256-byte aligned
  */
 typedef struct {
@@ -392,7 +397,7 @@ typedef struct {
 } rb_reads_view;
 enum rb_read_status { RB_RD_OK = 0, RB_RD_FILTERED = 1, RB_RD_BAD_CIGAR = 2, RB_RD_SEQ_SHORT = 3 };
 typedef struct {
-    uint64_t max_depth, n_covered, n_bad, unsorted;
+    uint64_t max_depth, n_covered, n_bad, unsorted, n_dropped, cap_overflow;
 } rb_nucfreq_counters;
 #define RB_NF_COVERED 0x80000000u
 #define RB_NF_DEPTH_CAP 8000u /* htslib bam_plp_init: maxcnt */

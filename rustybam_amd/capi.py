@@ -365,10 +365,11 @@ class Engine:
                  pos.ctypes.data, flag.ctypes.data)
         counts = np.zeros((max(n_pos, 1), 4), np.uint32)
         status = np.zeros(max(n, 1), np.uint32)
-        ctr = np.zeros(4, np.uint64)
+        ctr = np.zeros(6, np.uint64)
         self._chk(self.L.rb_host_nucfreq(self.ctx, C.byref(v), C.c_uint64(nr), _p(rg_tid), _p(rg_st), _p(rg_en), _p(counts), _p(status),
                                          _p(ctr)), "rb_host_nucfreq")
-        return counts[:n_pos], status[:n], dict(max_depth=int(ctr[0]), n_covered=int(ctr[1]), n_bad=int(ctr[2]), unsorted=int(ctr[3]))
+        return counts[:n_pos], status[:n], dict(max_depth=int(ctr[0]), n_covered=int(ctr[1]), n_bad=int(ctr[2]), unsorted=int(ctr[3]),
+                                                    n_dropped=int(ctr[4]), cap_overflow=int(ctr[5]))
 
 
 def synth_n_ops(seed, first_record, n_rec, lo, hi):

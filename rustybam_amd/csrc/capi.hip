@@ -135,6 +135,11 @@ struct rb_nf_params {
     uint64_t *blk;
     uint64_t *tile_lo, *tile_hi;
     uint64_t max_tiles;
+    uint64_t *drop_off;
+    uint64_t *drop_bits;
+    uint64_t drop_words;
+    uint32_t *deep_list;
+    uint32_t flags;
 };
 extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *p, hipStream_t stream);
 extern "C" size_t rb_nf_tile_positions(void);
@@ -1480,8 +1485,8 @@ extern "C" int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const
 // ---- nucfreq ----------------------------------------------------------------------------------------------------------
 namespace {
 struct nf_layout {
-    size_t end_key, rd_end, tile_off, blk, tile_lo, tile_hi, total;
-    uint64_t max_tiles;
+    size_t end_key, rd_end, tile_off, blk, tile_lo, tile_hi, drop_off, deep_list, drop_pool, total;
+    uint64_t max_tiles, drop_words;
 };
 nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_positions) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1494,6 +1499,11 @@ nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_position
     L.blk = o, o = up(o + (std::max(rb_nf_scan_blocks(n_reads), rb_scan_block_sums_count(n_regions)) + 2) * 8);
     L.tile_lo = o, o = up(o + ((size_t)L.max_tiles + 1) * 8);
     L.tile_hi = o, o = up(o + ((size_t)L.max_tiles + 1) * 8);
+    // the depth cap's bookkeeping: a bitmap of dropped reads per region that can reach the cap, from a pool of 64 bits per read
+    L.drop_off = o, o = up(o + ((size_t)n_regions + 1) * 8);
+    L.deep_list = o, o = up(o + ((size_t)n_regions + 2) * 4);
+    L.drop_words = n_reads + 1024;
+    L.drop_pool = o, o = up(o + ((size_t)L.drop_words + 1) * 8); // (word 0: the pool's cursor)
     L.total = o;
     return L;
 }
@@ -1526,6 +1536,12 @@ extern "C" int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t 
     p.end_key = (uint64_t *)(w + L.end_key), p.hd = (void *)(w + L.rd_end), p.tile_off = (uint64_t *)(w + L.tile_off);
     p.blk = (uint64_t *)(w + L.blk), p.tile_lo = (uint64_t *)(w + L.tile_lo), p.tile_hi = (uint64_t *)(w + L.tile_hi);
     p.max_tiles = L.max_tiles;
+    p.drop_off = (uint64_t *)(w + L.drop_off), p.deep_list = (uint32_t *)(w + L.deep_list);
+    p.drop_bits = (uint64_t *)(w + L.drop_pool) + 1, p.drop_words = L.drop_words;
+    static const bool all_atomic = getenv("RB_DEBUG_NF_ATOMIC") != nullptr; // (diagnostic: every tile through the LDS-atomic kernel)
+    p.flags = all_atomic ? 1u : 0u;
+    HIPCHK(ctx, hipMemsetAsync(p.drop_bits - 1, 0, 8, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(p.deep_list + n_regions, 0, 8, ctx->stream)); // (how many deep regions; can the cap be reached at all)
     HIPCHK(ctx, rb_launch_nucfreq(&p, ctx->stream));
     return RB_OK;
 }
@@ -1591,8 +1607,9 @@ extern "C" int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t
     if (read_status && n && (rc = rb_dev_download(ctx, read_status, d_status, (size_t)n * 4))) return rc;
     if (n_pos && (rc = rb_dev_download(ctx, counts, d_counts, (size_t)n_pos * 16))) return rc;
     if (counters->unsorted) return fail(ctx, RB_E_INVALID, "nucfreq: the reads are not sorted by (tid, pos)");
-    if (counters->max_depth + 2 > RB_NF_DEPTH_CAP)
-        return fail(ctx, RB_E_INVALID, "nucfreq: depth %llu reaches htslib's pileup cap of %u reads, which is not restated",
-                    (unsigned long long)counters->max_depth, RB_NF_DEPTH_CAP);
+    if (counters->cap_overflow)
+        return fail(ctx, RB_E_INVALID, "nucfreq: the bookkeeping of htslib's cap of %u buffered reads does not fit (depth %llu)", RB_NF_DEPTH_CAP,
+                    (unsigned long long)counters->max_depth);
+    if (counters->max_depth > 65535) return fail(ctx, RB_E_INVALID, "nucfreq: depth %llu does not fit the 16-bit counters", (unsigned long long)counters->max_depth);
     return RB_OK;
 }

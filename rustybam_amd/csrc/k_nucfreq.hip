@@ -11,7 +11,10 @@
 //   rb_k_nf_pmax_*      inclusive prefix MAXIMUM of the end keys in file order: the first read that can reach a position
 //                       is then one binary search away (reads are sorted by start, not by end)
 //   rb_k_nf_plan_tiles  thread per tile of NF_TILE positions: its region, and the range of reads that can overlap it
-//   rb_k_nf_tiles       workgroup per tile: the tile's counters live in LDS (4 x u16 in one u64 per position + a coverage
+//   rb_k_nf_crowded / _deep_regions / _admit   htslib's cap of 8000 buffered reads, replayed per region only where it can be reached:
+//                       a bitmap of the reads each such region's fetch drops (see the comment at rb_k_nf_admit)
+//   rb_k_nf_tiles       workgroup per tile: the tile's counters live in LDS (4 x u16 in one u64 per position, or 4 bytes in one dword
+//                       where at most 255 reads are in range: then one ds_add_u64 covers two positions; + a coverage
 //                       difference array); each wave takes reads of the range in turn, walks the CIGAR 64 ops at a time
 //                       (wave scans give every op its reference / query start), and for every match-type op that
 //                       overlaps the tile each lane takes 8 consecutive positions: the read's bases over the tile are fetched
@@ -58,6 +61,12 @@ struct rb_nf_params {
     uint64_t *blk;      // block partials of the scans
     uint64_t *tile_lo, *tile_hi; // [max_tiles] reads that can overlap the tile
     uint64_t max_tiles;
+    // htslib's cap on buffered reads (rb_k_nf_admit): per region the bit offset of its dropped-read bitmap in drop_bits (~0: none)
+    uint64_t *drop_off;   // [n_regions]
+    uint64_t *drop_bits;  // pool of drop_words 64-bit words; drop_bits[-1] is the pool's cursor
+    uint64_t drop_words;
+    uint32_t *deep_list;  // [n_regions + 1] regions whose fetch holds more reads than the cap; [n_regions] = how many
+    uint32_t flags;       // bit 0: 16-bit counters for every tile (diagnostic)
 };
 
 // one read as the tile kernel sees it: a single 48-byte record (one scalar load) instead of eight arrays
@@ -252,6 +261,129 @@ __global__ __launch_bounds__(256) void rb_k_nf_plan_tiles(rb_nf_params p) {
     p.tile_hi[t] = hi;
 }
 
+// ---- htslib's cap on buffered reads (bam_plp_push: `iter->tid == b->core.tid && iter->pos == b->core.pos && iter->mp->cnt >
+//      iter->maxcnt` drops the read; maxcnt = 8000, htslib sam.c) --------------------------------------------------------------------
+// The iterator only stands at a read's own start when an earlier read of the fetch starts there too, so the first read of a
+// start position always enters.  The j-th (j >= 2) enters unless 8000 reads are buffered: those admitted before it in this fetch
+// whose end is >= the position (a read is released while the position behind its end is processed, and the position the iterator
+// stands on has not been).  Admission is per fetch -- per region -- and sequential in file order, so it only runs for regions whose
+// fetch holds more than 8000 reads at all: one wavefront per such region, the ends of the buffered reads in LDS.
+#define NFA_LIVE 15360u // buffered reads the wave can hold (8000 + one per start position reached at the cap)
+// Can the cap be reached at all?  An upper bound of what is buffered when read i arrives, whatever the fetch: the reads in front of
+// it in the file down to the first one whose prefix maximum of (tid, end) reaches (tid, pos) -- everything before that one has
+// ended.  Only if the bound reaches the cap somewhere do the per-region simulations below run.
+__global__ __launch_bounds__(256) void rb_k_nf_crowded(rb_nf_params p) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= p.n_reads || i < RB_NF_DEPTH_CAP) return;
+    const nf_read h = p.hd[i];
+    if (!h.end) return;
+    const uint64_t key = nf_key(h.tid, h.pos);
+    if (p.end_key[i - RB_NF_DEPTH_CAP] >= key) p.deep_list[p.n_regions + 1] = 1u; // (8000 reads back something may still be open)
+}
+__global__ __launch_bounds__(256) void rb_k_nf_deep_regions(rb_nf_params p) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= p.n_regions) return;
+    p.drop_off[r] = ~0ull;
+    if (!p.deep_list[p.n_regions + 1]) return;
+    const uint64_t t0 = p.tile_off[r], t1 = p.tile_off[r + 1];
+    if (t0 == t1) return;
+    const uint64_t lo = p.tile_lo[t0], hi = p.tile_hi[t1 - 1];
+    if (hi > lo && hi - lo > RB_NF_DEPTH_CAP) p.deep_list[atomicAdd(&p.deep_list[p.n_regions], 1u)] = (uint32_t)r;
+}
+
+__global__ __launch_bounds__(64) void rb_k_nf_admit(rb_nf_params p) {
+    __shared__ uint32_t live[NFA_LIVE];
+    const int lane = rb_lane();
+    const uint64_t lt = (1ull << lane) - 1ull;
+    const uint32_t n_deep = p.deep_list[p.n_regions];
+    for (uint32_t k = blockIdx.x; k < n_deep; k += gridDim.x) {
+        const uint64_t r = p.deep_list[k];
+        const uint64_t t0 = p.tile_off[r], t1 = p.tile_off[r + 1];
+        const uint64_t rlo = p.tile_lo[t0], rhi = p.tile_hi[t1 - 1];
+        const int32_t rtid = p.rg_tid[r];
+        const uint64_t st = p.rg_st[r], en = p.rg_en[r];
+        const uint64_t words = (rhi - rlo + 63) >> 6;
+        uint64_t off = 0;
+        if (lane == 0) off = atomicAdd((unsigned long long *)(p.drop_bits - 1), (unsigned long long)words);
+        off = rb_first64(off);
+        if (off + words > p.drop_words) { // (the pool holds 64 regions per read: only regions that overlap en masse get here)
+            if (lane == 0) p.counters->cap_overflow = 1;
+            continue;
+        }
+        uint32_t n_live = 0, quota = 0, n_drop = 0;
+        int64_t cur_p = -1;
+        bool overflow = false;
+        for (uint64_t b0 = rlo; b0 < rhi; b0 += 64) { // 64 reads of the fetch = one word of the bitmap
+            const uint64_t i = b0 + (uint64_t)lane;
+            uint32_t pos = 0, end = 0;
+            bool cand = false;
+            if (i < rhi) { // hts_itr_next: same contig, pos < en, endpos > st; filtered / unusable reads carry end = 0
+                const nf_read h = p.hd[i];
+                pos = h.pos, end = h.end;
+                cand = h.tid == rtid && (uint64_t)h.pos < en && (uint64_t)h.end > st;
+            }
+            uint64_t cm = __ballot(cand), dropm = 0;
+            while (cm) {
+                const uint32_t gp = rb_readlane<uint32_t>(pos, __builtin_ctzll(cm));
+                const bool mine = cand && pos == gp;
+                const uint64_t grp = __ballot(mine);
+                if ((int64_t)gp != cur_p) {
+                    // a new start position: release what ended before it (compaction in place: a chunk is read before anything
+                    // of it is overwritten), the rest is what the iterator holds when the second read of this position arrives
+                    uint32_t wi = 0;
+                    for (uint32_t c0 = 0; c0 < n_live; c0 += 64) {
+                        const bool in = c0 + (uint32_t)lane < n_live;
+                        const uint32_t e = in ? live[c0 + (uint32_t)lane] : 0u;
+                        const bool keep = in && e >= gp;
+                        const uint64_t km = __ballot(keep);
+                        if (keep) live[wi + (uint32_t)__builtin_popcountll(km & lt)] = e;
+                        wi += (uint32_t)__builtin_popcountll(km);
+                    }
+                    n_live = wi;
+                    cur_p = gp;
+                    quota = n_live < RB_NF_DEPTH_CAP ? RB_NF_DEPTH_CAP - n_live : 1u; // the first read of a position is never at it
+                }
+                const uint32_t g = (uint32_t)__builtin_popcountll(grp), rank = (uint32_t)__builtin_popcountll(grp & lt);
+                const uint32_t a = g < quota ? g : quota;
+                const bool admit = mine && rank < quota;
+                if (n_live + a > NFA_LIVE) overflow = true;
+                else if (admit) live[n_live + rank] = end;
+                if (!overflow) n_live += a;
+                quota -= a;
+                dropm |= __ballot(mine && !admit);
+                cm &= ~grp;
+            }
+            if (lane == 0) p.drop_bits[off + ((b0 - rlo) >> 6)] = dropm;
+            n_drop += (uint32_t)__builtin_popcountll(dropm);
+        }
+        if (lane == 0) {
+            if (overflow) p.counters->cap_overflow = 1;
+            p.drop_off[r] = off * 64ull;
+            if (n_drop) atomicAdd((unsigned long long *)&p.counters->n_dropped, (unsigned long long)n_drop);
+        }
+    }
+}
+
+struct nf_drop {
+    uint64_t off, rlo;
+    const uint64_t *bits;
+};
+__device__ __forceinline__ nf_drop nf_drop_of(const rb_nf_params &p, const nf_tile &T) {
+    nf_drop d;
+    d.off = p.drop_off[T.r], d.rlo = 0, d.bits = p.drop_bits;
+    if (d.off != ~0ull) d.rlo = p.tile_lo[p.tile_off[T.r]];
+    return d;
+}
+__device__ __forceinline__ bool nf_dropped(const nf_drop &d, uint64_t i) { // did this region's fetch drop read i at the cap?
+    if (d.off == ~0ull) return false;
+    const uint64_t b = d.off + (i - d.rlo);
+    return (d.bits[b >> 6] >> (b & 63u)) & 1ull;
+}
+
+// a tile with at most this many reads in range cannot count past 255 anywhere: its counters are bytes (see rb_k_nf_tiles)
+#define NF_U8_MAX_READS 255u
+__device__ __forceinline__ bool nf_u8_tile(const rb_nf_params &p, uint64_t lo, uint64_t hi) { return !(p.flags & 1u) && hi - lo <= NF_U8_MAX_READS; }
+
 // LDS place of tile position i: two dwords (A | C << 16, G | T << 16); 8 guard positions in front (a lane's group of 8 may start
 // before the tile), and one dword skipped after every 8 positions so that the lanes of an atomic -- lane l adds to position
 // 8 l + k -- are 17 dwords apart and fall on different banks
@@ -260,8 +392,9 @@ __device__ __forceinline__ uint32_t nf_slot(uint32_t i) { return 2u * (i + 8u) +
 __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { return ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu); }
 
 __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
-    __shared__ uint32_t cnt[NF_CNT_DW]; // per position: A | C << 16, G | T << 16
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[NF_CNT_DW]; // per position: A | C << 16, G | T << 16 -- or one dword of four byte counters (U8 tiles)
     __shared__ uint32_t lut[16];        // what a base code adds to its word: 1 4 = A G: 1; 2 8 = C T: 1 << 16; everything else 0 (nucfreq.rs:83-90)
+    __shared__ uint32_t lut8[16];       // U8 tiles: 1 2 4 8 = A C G T: 1 << 0, 8, 16, 24
     __shared__ int32_t diff[NF_TILE + 8];        // +1 where a read starts covering, -1 where it stops; then the depth
     __shared__ int32_t wsum[NF_WAVES];
     __shared__ uint32_t blk_max, blk_cov;
@@ -269,6 +402,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     const uint64_t t = blockIdx.x;
     if (t >= p.tile_off[p.n_regions]) return;
     const nf_tile T = nf_tile_of(p, t);
+    const nf_drop drop = nf_drop_of(p, T);
     const uint32_t n_pos = (uint32_t)(T.en - T.st);
     for (uint32_t k = threadIdx.x; k < NF_CNT_DW; k += NF_THREADS) cnt[k] = 0;
     if ((threadIdx.x & 63u) < 4u) stage_all[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
@@ -276,19 +410,25 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     if (threadIdx.x < 16) {
         const uint32_t n = threadIdx.x;
         lut[n] = (n == 1 || n == 4) ? 1u : (n == 2 || n == 8) ? 0x10000u : 0u;
+        lut8[n] = n == 1 ? 1u : n == 2 ? 0x100u : n == 4 ? 0x10000u : n == 8 ? 0x1000000u : 0u;
     }
     if (threadIdx.x == 0) blk_max = 0, blk_cov = 0;
     __syncthreads();
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const int lane = rb_lane();
     const uint64_t lo = p.tile_lo[t], hi = p.tile_hi[t];
+    // U8 tiles (at most 255 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
+    // per 8 positions (lane l of an add is 10 l dwords on: all of a half-wave's 8-byte accesses on different banks), and one
+    // ds_add_u64 covers two positions -- half the atomics of the 16-bit layout and no choice of word per base
+    const bool tile_u8 = nf_u8_tile(p, lo, hi);
     const uint32_t *__restrict__ sw32 = reinterpret_cast<const uint32_t *>(p.seq);
     uint32_t *stage = stage_all[wib] + 4;
     // one read, the whole wave on it (w_first: its first 64 ops, already in registers)
-    auto read_by_wave = [&](const nf_read &h, uint32_t w_first, uint64_t i) {
+    auto read_by_wave = [&](auto U8, const nf_read &h, uint32_t w_first, uint64_t i) {
         const int64_t pos = h.pos;
         const uint64_t rend = h.end;
         if (h.tid != T.tid || (uint64_t)pos >= T.en || rend <= T.st) return; // hts_itr_next: pos < en && endpos > st (end = 0: not in the pileup)
+        if (nf_dropped(drop, i)) return;
         const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = rend < T.en ? rend : T.en;
         if (lane == 0) {
             atomicAdd(&diff[(uint32_t)(c0 - T.st)], 1);
@@ -364,12 +504,20 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
                     uint32_t x = __builtin_amdgcn_alignbit(d1, d0, shift4); // (d0, d1: nibbles already in base order)
                     const uint32_t width = (uint32_t)(j1 - j0) * 4u;
                     x &= width >= 32u ? 0xFFFFFFFFu : (((1u << width) - 1u) << ((uint32_t)j0 * 4u)); // bases outside [ia, ib) become code 0: add nothing
-                    uint32_t *g = &cnt[17u * ((uint32_t)P >> 3)];
                     uint32_t inc[8]; // (the table reads first, all eight in flight, then the atomics)
+                    if constexpr (decltype(U8)::value) {
+                        unsigned long long *g = reinterpret_cast<unsigned long long *>(&cnt[10u * ((uint32_t)P >> 3)]);
 #pragma unroll
-                    for (int k = 0; k < 8; k++) inc[k] = lut[(x >> (4 * k)) & 15u];
+                        for (int k = 0; k < 8; k++) inc[k] = lut8[(x >> (4 * k)) & 15u];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) atomicAdd(g + 2 * k + __builtin_amdgcn_ubfe(0x110u, (x >> (4 * k)) & 15u, 1u), inc[k]);
+                        for (int k = 0; k < 4; k++) atomicAdd(g + k, (unsigned long long)inc[2 * k] | ((unsigned long long)inc[2 * k + 1] << 32));
+                    } else {
+                        uint32_t *g = &cnt[17u * ((uint32_t)P >> 3)];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) inc[k] = lut[(x >> (4 * k)) & 15u];
+#pragma unroll
+                        for (int k = 0; k < 8; k++) atomicAdd(g + 2 * k + __builtin_amdgcn_ubfe(0x110u, (x >> (4 * k)) & 15u, 1u), inc[k]);
+                    }
                 };
                 const int32_t P0 = ((ia + 8) & ~7) + 8 * lane;
                 if (staged) {
@@ -399,7 +547,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
             nf_read h;
             h.end = 0, h.n_ops = 0, h.op_off = 0, h.pos = 0, h.tid = -1, h.l_seq = 0, h.nib0 = 0;
             if (i < hi) h = p.hd[i];
-            const bool overl = h.tid == T.tid && (uint64_t)h.pos < T.en && (uint64_t)h.end > T.st;
+            const bool overl = h.tid == T.tid && (uint64_t)h.pos < T.en && (uint64_t)h.end > T.st && !nf_dropped(drop, i);
             const bool simple = overl && h.n_ops <= NF_LANE_OPS;
             uint64_t cm = __ballot(overl && !simple);
             if (simple) {
@@ -443,7 +591,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
                 hh.l_seq = rb_readlane<uint32_t>(h.l_seq, l), hh.n_ops = rb_readlane<uint32_t>(h.n_ops, l);
                 hh.op_off = rb_readlane<uint64_t>(h.op_off, l), hh.nib0 = rb_readlane<uint64_t>(h.nib0, l);
                 const uint32_t wf = (uint32_t)lane < hh.n_ops ? p.ops[hh.op_off + (uint32_t)lane] : RB_NULL_OP;
-                read_by_wave(hh, wf, g + (uint64_t)l);
+                read_by_wave(std::false_type{}, hh, wf, g + (uint64_t)l);
             }
         }
     } else {
@@ -465,7 +613,8 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
             const nf_read h = h_cur;
             const uint32_t w_first = w_cur;
             h_cur = h_nxt, h_nxt = h_nn, w_cur = w_nxt;
-            read_by_wave(h, w_first, i);
+            if (tile_u8) read_by_wave(std::true_type{}, h, w_first, i);
+            else read_by_wave(std::false_type{}, h, w_first, i);
         }
     }
     __syncthreads();
@@ -503,6 +652,13 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         atomicAdd((unsigned long long *)&p.counters->n_covered, (unsigned long long)blk_cov);
     }
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(p.counts + 4ull * T.out);
+    if (tile_u8) {
+        for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
+            const uint32_t v = cnt[10u * ((k + 8u) >> 3) + ((k + 8u) & 7u)];
+            out[k] = make_uint4((v & 255u) | (diff[k] > 0 ? RB_NF_COVERED : 0u), (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
+        }
+        return;
+    }
     for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
         const uint32_t ac = cnt[nf_slot(k)], gt = cnt[nf_slot(k) + 1];
         out[k] = make_uint4((ac & 0xFFFFu) | (diff[k] > 0 ? RB_NF_COVERED : 0u), ac >> 16, gt & 0xFFFFu, gt >> 16);
@@ -528,6 +684,9 @@ extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stre
     hipError_t e = rb_launch_exclusive_scan(p.tile_off, p.n_regions, p.blk, p.tile_off + p.n_regions, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rb_k_nf_plan_tiles, dim3((unsigned)((p.max_tiles + 255) / 256)), dim3(256), 0, stream, p);
+    if (p.n_reads > RB_NF_DEPTH_CAP) hipLaunchKernelGGL(rb_k_nf_crowded, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(rb_k_nf_deep_regions, dim3((unsigned)((p.n_regions + 255) / 256)), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(rb_k_nf_admit, dim3(512), dim3(64), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_tiles, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
     return hipGetLastError();
 }

@@ -249,7 +249,7 @@ def test_full_size_nucfreq_checksums():
     d_outoff = torch.tensor([0, contig], dtype=torch.int64, device=dev)
     d_counts = torch.empty(contig * 4 + 16, dtype=torch.int32, device=dev)
     d_status = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    d_ctr = torch.zeros(4, dtype=torch.int64, device=dev)
+    d_ctr = torch.zeros(6, dtype=torch.int64, device=dev)
     wsb = eng.nucfreq_workspace_bytes(n, 1, contig)
     d_ws = torch.empty(wsb + 256, dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()

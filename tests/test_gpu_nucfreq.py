@@ -82,17 +82,53 @@ def test_bad_reads_are_flagged_not_counted(engine, oracle):
     assert oracle.nucfreq(*rd.slice(5, 6).args(), 0, 0, 100)[0] == -4   # the reference panics on the same read
 
 
-def test_unsorted_and_depth_cap_are_refused(engine):
+def test_unsorted_is_refused(engine):
     rd = Reads([0, 0], [50, 10], [0, 0], [[(10 << 4)], [(10 << 4)]], [[1] * 10, [1] * 10])
     with pytest.raises(rustybam_amd.RbError):
         engine.nucfreq(*rd.args(), [0], [0], [100])
-    n = 8000
-    rd = Reads([0] * n, [5] * n, [0] * n, [[(4 << 4)]] * n, [[1] * 4] * n)
-    with pytest.raises(rustybam_amd.RbError):
-        engine.nucfreq(*rd.args(), [0], [0], [100])
+
+
+def test_depth_cap_one_start_position(engine, oracle):
+    """htslib's pileup buffers at most 8000 reads (bam_plp_push drops a read that starts where the iterator stands while more are
+    buffered): 8100 reads on one start position -> the first 8000 count"""
+    n = 8100
+    rng = np.random.default_rng(3)
+    seqs = rng.choice([1, 2, 4, 8], size=(n, 4)).tolist()
+    rd = Reads([0] * n, [5] * n, [0] * n, [[(4 << 4)]] * n, seqs)
+    counts, status, ctr = check_regions(engine, oracle, rd, [(0, 0, 100)])
+    assert ctr["max_depth"] == 8000 and ctr["n_dropped"] == 100 and ctr["cap_overflow"] == 0
+    assert int((counts[5] & 0x7FFFFFFF).sum()) == 8000
     rd = rd.slice(0, 7000)
     counts, status, ctr = engine.nucfreq(*rd.args(), [0], [0], [100])
-    assert ctr["max_depth"] == 7000 and (counts[5:9, 0] & 0x7FFFFFFF).tolist() == [7000] * 4
+    assert ctr["max_depth"] == 7000 and ctr["n_dropped"] == 0 and int((counts[5:9] & 0x7FFFFFFF).sum()) == 4 * 7000
+
+
+def test_depth_cap_spread_starts_and_regions(engine, oracle):
+    """a pile that crosses the cap over many start positions; what is dropped depends on the fetch (the region): the same reads
+    through three regions in one call.  A long read dropped at the cap must also stay out of the far tiles it reaches"""
+    rng = np.random.default_rng(4)
+    n = 14000
+    pos = np.sort(rng.integers(0, 40, n)).tolist()
+    cigs, seqs = [], []
+    for k in range(n):
+        l = int(rng.integers(20, 60))
+        if rng.random() < 0.1:
+            d = int(rng.integers(1, 5))
+            cigs.append([((l // 2) << 4), (d << 4) | 2, ((l - l // 2) << 4)])
+        else:
+            cigs.append([(l << 4)])
+        seqs.append(rng.choice([1, 2, 4, 8, 15], size=l).tolist())
+    # two long reads that start late on a crowded position: the second of them is dropped there
+    at = max(i for i in range(n) if pos[i] == 25) + 1
+    for _ in range(2):
+        pos.insert(at, 25)
+        cigs.insert(at, [(9000 << 4)])
+        seqs.insert(at, rng.choice([1, 2, 4, 8], size=9000).tolist())
+    n += 2
+    rd = Reads([0] * n, pos, [0] * n, cigs, seqs)
+    counts, status, ctr = check_regions(engine, oracle, rd, [(0, 0, 9500), (0, 30, 35), (0, 45, 200)])
+    assert ctr["max_depth"] >= 8000 and ctr["n_dropped"] > 1000 and ctr["cap_overflow"] == 0
+    assert (status == 0).all()
 
 
 def test_long_insertions_inside_a_tile(engine, oracle):

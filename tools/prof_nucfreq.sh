@@ -2,7 +2,7 @@
 # rocprofv3 passes over tools/bench_nucfreq.py: kernel trace + stats, HBM traffic, instruction mix / LDS counters of rb_k_nf_tiles
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-tag=${1:-r01_nf}
+tag=${1:-r02_nf}
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o kt -- python3 tools/bench_nucfreq.py --steps 5 > gpurun_out/${tag}_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/$tag -o fetch -- python3 tools/bench_nucfreq.py --steps 2 > gpurun_out/${tag}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/$tag -o write -- python3 tools/bench_nucfreq.py --steps 2 > gpurun_out/${tag}_write.log 2>&1
@@ -16,7 +16,7 @@ for f in sorted(glob.glob("gpurun_out/%s/**/*counter_collection.csv" % (tag or "
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if "nf_tiles" in r["Kernel_Name"]:
-            a = acc[r["Counter_Name"]]
+            a = acc[r["Kernel_Name"].split("(")[0][:24] + " " + r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
     for k, (v, n) in acc.items():
         print(os.path.basename(f)[:12], k, "per launch: %.4g" % (v / max(n, 1) * (1 if True else 1)), "rows", n)
