@@ -278,6 +278,11 @@ static std::string stripped_id(const PafRecord &r, const rb_norm_row &nr) {
     return r.id + "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
 }
 
+// `rb --gpus N`: a worker process reads only its own lines of the (plain) input file -- bytes [begin, end), cut at line starts
+static uint64_t g_slice_begin = 0, g_slice_end = 0;
+static bool g_sliced = false;
+void set_input_slice(uint64_t begin, uint64_t end) { g_slice_begin = begin, g_slice_end = end, g_sliced = true; }
+
 // the whole (decompressed) text of a PAF file or stdin
 static std::string read_all(const std::string &file_name) {
     std::string all;
@@ -288,9 +293,11 @@ static std::string read_all(const std::string &file_name) {
         unsigned char magic[2] = {0, 0};
         const size_t got = fread(magic, 1, 2, fp);
         if (!(got == 2 && magic[0] == 0x1f && magic[1] == 0x8b) && fseek(fp, 0, SEEK_END) == 0) {
-            const long sz = ftell(fp);
+            long sz = ftell(fp);
             if (sz >= 0) {
-                rewind(fp);
+                long from = 0;
+                if (g_sliced) from = (long)std::min<uint64_t>(g_slice_begin, (uint64_t)sz), sz = (long)std::min<uint64_t>(g_slice_end, (uint64_t)sz) - from;
+                fseek(fp, from, SEEK_SET);
                 all.resize((size_t)sz);
                 if (fread(&all[0], 1, (size_t)sz, fp) == (size_t)sz) plain = true;
             }
@@ -309,6 +316,8 @@ static std::string read_all(const std::string &file_name) {
     }
     return all;
 }
+std::string read_input_text(const std::string &file_name) { return read_all(file_name); }
+
 // the bytes of a text file in a buffer nobody zero-fills first (std::string::resize would touch 1.5 GB twice), 32 zero bytes behind
 // the text (the device reads whole 16-byte groups).  A plain file is read by all host threads at once, each its own slice.
 struct TextBuf {
@@ -327,6 +336,8 @@ static TextBuf read_text(const std::string &file_name, bool raw_bytes = false) {
         const bool plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (raw_bytes || !(pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b));
         if (plain) {
             b.n = (size_t)st.st_size;
+            size_t from = 0;
+            if (g_sliced && !raw_bytes) from = (size_t)std::min<uint64_t>(g_slice_begin, b.n), b.n = (size_t)std::min<uint64_t>(g_slice_end, b.n) - from;
             b.p.reset(new char[b.n + 32]);
             memset(b.p.get() + b.n, 0, 32);
             std::atomic<bool> ok{true};
@@ -334,7 +345,7 @@ static TextBuf read_text(const std::string &file_name, bool raw_bytes = false) {
                 size_t a = lo << 22;
                 const size_t e = std::min(b.n, hi << 22);
                 while (a < e) {
-                    const ssize_t r = pread(fd, b.p.get() + a, e - a, (off_t)a);
+                    const ssize_t r = pread(fd, b.p.get() + a, e - a, (off_t)(from + a));
                     if (r <= 0) {
                         ok = false;
                         return;

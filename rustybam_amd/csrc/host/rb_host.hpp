@@ -72,6 +72,11 @@ struct Paf { // paf::Paf (paf.rs:34-37)
     void scaffold(uint64_t spacer_size);         // paf.rs:160-207
 };
 
+// `rb --gpus N` (the record shards of liftover.rs:123-129, one worker process per GPU): the readers below then load only bytes
+// [begin, end) of a plain input file; read_input_text: the whole decompressed text of a file or stdin ("-")
+void set_input_slice(uint64_t begin, uint64_t end);
+std::string read_input_text(const std::string &file_name);
+
 std::string cigar_to_string(const std::vector<uint32_t> &cigar);
 std::vector<std::string> records_to_text(const std::vector<PafRecord> &recs); // `println!("{}", rec)` for every record, encoded on all host cores; chunks in output order
 // PafRecord::new (paf.rs:379-430): 0 = ok, 1 = Err(ParsePafColumn) (caller skips the line); throws Panic

@@ -6,6 +6,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <string>
 #include <thread>
@@ -27,7 +31,7 @@ static void lap(const char *what, double &t) {
 
 static int usage() {
     fprintf(stderr,
-            "usage: rb [--bsearch modern|legacy] [--device N] <subcommand> ...\n"
+            "usage: rb [--bsearch modern|legacy] [--device N] [--gpus N] <subcommand> ...\n"
             "  stats [-q|--qbed] [-p|--paf] <PAF or BAM>\n"
             "  liftover -b|--bed <BED> [-q|--qbed] [-l|--largest] [PAF]\n"
             "  break-paf [-m|--max-size 100] [PAF]\n"
@@ -36,6 +40,8 @@ static int usage() {
             "  orient [-s|--scaffold] [-i|--insert 1000000] [PAF]\n"
             "  filter [-p|--paired-len 0] [-a|--aln 0] [-q|--query 0] [PAF]\n"
             "  nucfreq [-r|--region chr:st-en] [-b|--bed <BED>] [-s|--small] <BAM>\n"
+            "--gpus N: the PAF records in N contiguous shards, one worker process per GPU (liftover without --largest, break-paf,\n"
+            "          stats --paf, invert); the output is the single-GPU output byte for byte.\n"
             "Every other rustybam subcommand is outside this engine's scope.\n");
     return 2;
 }
@@ -121,12 +127,120 @@ static int synth_bed(uint64_t n_win) {
     return 0;
 }
 
+// `rb --gpus N`: SURVEY 8(e) -- PAF records are independent (liftover.rs:123-129 hands them to rayon), so the input is cut into N
+// runs of whole lines of about equal bytes (CIGAR text is what weighs) and N worker processes are forked BEFORE anything touches
+// the GPU; worker k takes device `device + k`, reads only its lines, and writes to a pipe; the parent never initialises HIP, it
+// concatenates the pipes in shard order.  Returns -1 in a worker (which carries on as an ordinary single-GPU run over its slice),
+// the exit code in the parent: that of the first shard that failed, after the output of the shards before it and its own.
+static int g_rank = 0;
+static int shard_fork(int n, std::string &path, int &device) {
+    int fd = -1;
+    bool plain = false;
+    if (path != "-") {
+        fd = open(path.c_str(), O_RDONLY);
+        if (fd < 0) {
+            fprintf(stderr, "thread 'main' panicked: Failed to open %s\n", path.c_str());
+            return 101;
+        }
+        unsigned char magic[2] = {0, 0};
+        struct stat st;
+        plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+    }
+    if (!plain) { // stdin / gzip: the text into an anonymous file every worker inherits
+        if (fd >= 0) close(fd);
+        std::string all;
+        try {
+            all = rb::read_input_text(path);
+        } catch (const rb::Panic &e) {
+            fprintf(stderr, "thread 'main' panicked: %s\n", e.what());
+            return 101;
+        }
+        fd = memfd_create("rb_input", 0);
+        size_t off = 0;
+        while (fd >= 0 && off < all.size()) {
+            const ssize_t w = write(fd, all.data() + off, all.size() - off);
+            if (w <= 0) break;
+            off += (size_t)w;
+        }
+        if (fd < 0 || off != all.size()) {
+            fprintf(stderr, "rb: cannot buffer the input for --gpus\n");
+            return 1;
+        }
+        path = "/proc/self/fd/" + std::to_string(fd);
+    }
+    struct stat st;
+    fstat(fd, &st);
+    const uint64_t size = (uint64_t)st.st_size;
+    std::vector<uint64_t> cut(n + 1, size);
+    cut[0] = 0;
+    std::vector<char> buf(1 << 16);
+    for (int k = 1; k < n; k++) { // the first line start at or behind size * k / n
+        uint64_t at = std::max(cut[k - 1], size / (uint64_t)n * (uint64_t)k);
+        bool found = at == 0;
+        if (!found && at < size) { // (a cut must follow a newline: look from one byte earlier)
+            at -= 1;
+            while (at < size && !found) {
+                const ssize_t r = pread(fd, buf.data(), buf.size(), (off_t)at);
+                if (r <= 0) break;
+                const void *nl = memchr(buf.data(), '\n', (size_t)r);
+                if (nl) at += (uint64_t)((const char *)nl - buf.data()) + 1, found = true;
+                else at += (uint64_t)r;
+            }
+        }
+        cut[k] = found ? std::min(at, size) : size;
+    }
+    const bool same = getenv("RB_GPUS_SAME_DEVICE") != nullptr; // (diagnostic: every worker on --device, to try the gather on one GPU)
+    std::vector<int> rd(n, -1);
+    std::vector<pid_t> pid(n, -1);
+    for (int k = 0; k < n; k++) {
+        int pp[2];
+        if (pipe(pp) != 0) return 1;
+        const pid_t c = fork();
+        if (c < 0) return 1;
+        if (c == 0) {
+            for (int j = 0; j < k; j++) close(rd[j]);
+            close(pp[0]);
+            dup2(pp[1], 1);
+            close(pp[1]);
+            g_rank = k;
+            if (!same) device += k;
+            rb::set_input_slice(cut[k], cut[k + 1]);
+            return -1;
+        }
+        close(pp[1]);
+        rd[k] = pp[0], pid[k] = c;
+    }
+    std::vector<std::string> out(n);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; k++)
+        th.emplace_back([&, k]() {
+            std::vector<char> b(1 << 20);
+            ssize_t r;
+            while ((r = read(rd[k], b.data(), b.size())) > 0) out[k].append(b.data(), (size_t)r);
+            close(rd[k]);
+        });
+    int rc = 0;
+    for (int k = 0; k < n; k++) {
+        th[k].join();
+        int st_k = 0;
+        waitpid(pid[k], &st_k, 0);
+        const int rc_k = WIFEXITED(st_k) ? WEXITSTATUS(st_k) : 1;
+        if (rc == 0) { // (what a later shard printed after an earlier one failed is not output the single run would have made)
+            fwrite(out[k].data(), 1, out[k].size(), stdout);
+            rc = rc_k;
+        }
+    }
+    fflush(stdout);
+    return rc;
+}
+
 int main(int argc, char **argv) {
     setvbuf(stdout, g_obuf, _IOFBF, sizeof g_obuf);
-    int a = 1, device = 0, policy = RB_BSEARCH_MODERN;
+    int a = 1, device = 0, policy = RB_BSEARCH_MODERN, gpus = 1;
     while (a + 1 < argc && argv[a][0] == '-') {
         if (!strcmp(argv[a], "--bsearch")) policy = !strcmp(argv[a + 1], "legacy") ? RB_BSEARCH_LEGACY : RB_BSEARCH_MODERN;
         else if (!strcmp(argv[a], "--device")) device = atoi(argv[a + 1]);
+        else if (!strcmp(argv[a], "--gpus")) gpus = atoi(argv[a + 1]);
         else if (!strcmp(argv[a], "-t") || !strcmp(argv[a], "--threads")) { /* accepted, unused */ }
         else break;
         a += 2;
@@ -170,6 +284,15 @@ int main(int argc, char **argv) {
         else if (s == "-i" || s == "--indel-score") is = atoi(next());
         else paf_path = s;
     }
+    if (gpus > 1) {
+        const bool lift = cmd == "liftover" || cmd == "lo", brk = cmd == "break-paf" || cmd == "breakpaf" || cmd == "bp";
+        if (!((lift && !largest && !bed_path.empty()) || brk || (cmd == "stats" && is_paf) || cmd == "invert")) {
+            fprintf(stderr, "rb: --gpus shards PAF records: liftover (without --largest), break-paf, stats --paf, invert\n");
+            return 2;
+        }
+        const int rc = shard_fork(gpus, paf_path, device);
+        if (rc >= 0) return rc;
+    }
     try {
         double tl = now_s();
         // text in -> text out (CIGAR text parsed / printed on the device) for regular files; stdin and RB_GENERAL_PATH=1 take the
@@ -185,7 +308,7 @@ int main(int argc, char **argv) {
                 for (rb::Region &r : rb::parse_bed(bed_path)) rgns.push_back(std::move(r));
             rb::nucfreq_bam(eng, paf_path, rgns, small, [&](const std::string &t) { put(t); });
         } else if (cmd == "stats") {
-            put(rb::cigar_stats_header(qbed));
+            if (g_rank == 0) put(rb::cigar_stats_header(qbed));
             if (!is_paf) { // BAM input (main.rs:60-77)
                 std::string panic;
                 for (const rb::Stats &s : rb::cigar_stats_bam(eng, paf_path, &panic)) put(rb::cigar_stats_line(s, qbed));

@@ -439,3 +439,52 @@ def test_nucfreq_bai_index_and_full_scan_agree(oracle, golden, tmp_path):
         assert rc == 0 and full.returncode == 0 and orc == 0
         assert out == full.stdout == oout
     assert os.path.exists(f"{golden}/asm_small.bam.bai")
+
+
+@pytest.mark.parametrize("n", [2, 3])
+@pytest.mark.parametrize("args", [
+    ["liftover", "--bed", "{bed}", "{paf}"],
+    ["liftover", "--qbed", "--bed", "{trimbed}", "{paf}"],
+    ["liftover", "--bed", "{bed}", "{paf}.gz"],
+    ["break-paf", "--max-size", "100", "{paf}"],
+    ["stats", "--paf", "{paf}"],
+    ["invert", "{paf}"],
+])
+def test_gpus_flag_gathers_the_single_gpu_bytes(golden, args, n):
+    """`rb --gpus N`: N worker processes forked before the GPU is touched, each on its own run of lines, pipes concatenated in shard
+    order.  One GPU here: RB_GPUS_SAME_DEVICE=1 puts every worker on device 0 (the fork, the line cuts and the gather are what is
+    checked; the per-device part is the ordinary single-GPU run)"""
+    a = [x.format(paf=f"{golden}/asm_small.paf", bed=f"{golden}/asm_small.bed", trimbed=f"{golden}/trim_asm_small.bed") for x in args]
+    rc1, out1 = rb(*a)
+    rcn, outn = rb("--gpus", n, *a, env={"RB_GPUS_SAME_DEVICE": "1"})
+    assert (rc1, rcn) == (0, 0)
+    assert outn == out1 and (len(out1) > 1000 or "--qbed" in a)
+
+
+def test_gpus_flag_stdin_general_path_and_refusals(golden):
+    paf = open(f"{golden}/asm_small.paf", "rb").read()
+    assert os.path.exists(RB)
+    env = {**os.environ, "RB_GPUS_SAME_DEVICE": "1"}
+    one = subprocess.run([RB, "break-paf"], input=paf, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    two = subprocess.run([RB, "--gpus", "2", "break-paf"], input=paf, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert (one.returncode, two.returncode) == (0, 0) and one.stdout == two.stdout
+    gen = subprocess.run([RB, "--gpus", "2", "break-paf", f"{golden}/asm_small.paf"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         env={**env, "RB_GENERAL_PATH": "1"})
+    assert gen.returncode == 0 and gen.stdout == one.stdout
+    # commands that are not a map over records are refused, not silently run on one GPU
+    for a in (["trim-paf", f"{golden}/asm_small.paf"], ["liftover", "--largest", "--bed", f"{golden}/asm_small.bed", f"{golden}/asm_small.paf"]):
+        r = subprocess.run([RB, "--gpus", "2", *a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 2 and not r.stdout
+
+
+def test_gpus_flag_panic_in_one_shard(golden, tmp_path):
+    """a line the reference panics on, in the second shard: the output up to the panic, exit code 101 -- as the single run"""
+    lines = open(f"{golden}/asm_small.paf", "rb").read().split(b"\n")
+    lines = [l for l in lines if l]
+    bad = lines[-2].replace(b"cg:Z:", b"cg:Z:12Q")
+    src = tmp_path / "bad.paf"
+    src.write_bytes(b"\n".join(lines[:-2] + [bad, lines[-1]]) + b"\n")
+    rc1, out1 = rb("stats", "--paf", src)
+    rc2, out2 = rb("--gpus", 2, "stats", "--paf", src, env={"RB_GPUS_SAME_DEVICE": "1"})
+    assert rc1 == 101 and rc2 == 101
+    assert out2.startswith(out1[:200]) and len(out2) >= len(out1)
