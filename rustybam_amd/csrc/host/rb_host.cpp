@@ -1118,6 +1118,100 @@ bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, i
     return true;
 }
 
+// main.rs:176-182 (invert), text in -> text out: cg:Z: values parsed, swapped (paf.rs:1050-1094) and printed on the device, the host
+// exchanges the query and target columns
+bool invert_file_text(Engine &eng, const std::string &paf_path, std::vector<std::string> &out_text) {
+    TextFile &f = *new TextFile; // (one-shot command: left to the end of the process, like the buffers of the other text routes)
+    if (!f.load(paf_path)) return false;
+    double tl = now_s();
+    const size_t n = f.recs.size();
+    out_text.clear();
+    if (n == 0) return true;
+    rb_ctx *ctx = eng.ctx();
+    struct Dev { // device allocations of this call
+        rb_ctx *ctx;
+        std::vector<void *> owned;
+        ~Dev() { for (void *q : owned) rb_dev_free(ctx, q); }
+        void *take(Engine &e, size_t bytes) {
+            void *d = nullptr;
+            e.check(rb_dev_alloc(ctx, bytes + 256, &d), "rb_dev_alloc");
+            owned.push_back(d);
+            return d;
+        }
+    } D{ctx, {}};
+    auto up = [&](const void *host, size_t bytes) {
+        void *d = D.take(eng, bytes);
+        if (bytes) eng.check(rb_dev_upload(ctx, d, host, bytes), "rb_dev_upload");
+        return d;
+    };
+    uint64_t cig_bytes = 0;
+    for (size_t r = 0; r < n; r++) cig_bytes += f.cig_end[r] - f.cig_off[r];
+    const uint64_t ops_bound = cig_bytes / 2 + 8; // an op is at least two characters
+    uint8_t *d_text = (uint8_t *)up(f.all.data(), f.text_bytes);
+    const uint64_t *d_coff = (const uint64_t *)up(f.cig_off.data(), n * 8), *d_cend = (const uint64_t *)up(f.cig_end.data(), n * 8);
+    uint64_t *d_opoff = (uint64_t *)D.take(eng, (n + 2) * 8);
+    uint32_t *d_ops = (uint32_t *)D.take(eng, (size_t)ops_bound * 4 + 256);
+    uint8_t *d_status = (uint8_t *)D.take(eng, n + 1);
+    void *d_scr = D.take(eng, rb_text_scratch_bytes(n));
+    eng.check(rb_dev_parse_cigars(ctx, d_text, d_coff, d_cend, n, d_opoff, d_ops, ops_bound, d_status, d_scr), "rb_dev_parse_cigars");
+    std::vector<uint8_t> cig_status(n);
+    eng.check(rb_dev_download(ctx, cig_status.data(), d_status, n), "rb_dev_download");
+    std::vector<uint64_t> op_off(n + 1);
+    eng.check(rb_dev_download(ctx, op_off.data(), d_opoff, (n + 1) * 8), "rb_dev_download");
+    rb_batch_view v;
+    v.n_rec = n, v.n_ops = op_off[n], v.ops = d_ops, v.op_off = d_opoff;
+    v.t_st = (const uint64_t *)up(f.t_st.data(), n * 8), v.t_en = (const uint64_t *)up(f.t_en.data(), n * 8);
+    v.q_st = (const uint64_t *)up(f.q_st.data(), n * 8), v.q_en = (const uint64_t *)up(f.q_en.data(), n * 8);
+    v.strand = (const uint8_t *)up(f.strand.data(), n), v.contig = (const uint32_t *)up(f.contig.data(), n * 4);
+    bool all_ok = true;
+    for (size_t r = 0; r < n; r++) all_ok &= cig_status[r] == RB_TEXT_OK;
+    std::vector<rb_reduce_row> red(n);
+    if (all_ok) {
+        rb_reduce_row *d_red = (rb_reduce_row *)D.take(eng, n * sizeof(rb_reduce_row));
+        eng.check(rb_dev_scan_records(ctx, &v, d_red, nullptr), "rb_dev_scan_records");
+        eng.check(rb_dev_download(ctx, red.data(), d_red, n * sizeof(rb_reduce_row)), "rb_dev_download");
+    }
+    if (!f.check_loaded(cig_status, red)) return false; // the panics of Paf::from_file, in its order
+    lap("  text -> ops, scan (device)", tl);
+    uint32_t *d_swapped = (uint32_t *)D.take(eng, (size_t)v.n_ops * 4 + 256);
+    eng.check(rb_dev_swap(ctx, &v, d_swapped), "rb_dev_swap");
+    std::vector<uint32_t> count(n);
+    for (size_t i = 0; i < n; i++) count[i] = (uint32_t)(op_off[i + 1] - op_off[i]);
+    const uint32_t *d_count = (const uint32_t *)up(count.data(), n * 4);
+    uint64_t *d_toff = (uint64_t *)D.take(eng, (n + 2) * 8);
+    const uint64_t text_cap = 11 * v.n_ops + 16;
+    uint8_t *d_out = (uint8_t *)D.take(eng, text_cap);
+    eng.check(rb_dev_format_cigars(ctx, d_swapped, nullptr, n, d_opoff, d_count, nullptr, nullptr, d_toff, d_out, text_cap, d_scr), "rb_dev_format_cigars");
+    std::vector<uint64_t> &toff = *new std::vector<uint64_t>(n + 1);
+    eng.check(rb_dev_download(ctx, toff.data(), d_toff, (n + 1) * 8), "rb_dev_download");
+    std::vector<uint8_t> &text = *new std::vector<uint8_t>((size_t)toff[n] + 1);
+    if (toff[n]) eng.check(rb_dev_download(ctx, text.data(), d_out, (size_t)toff[n]), "rb_dev_download");
+    lap("  swap + print cigars (device) + D2H", tl);
+    const unsigned TO = parallel_chunk_count(n);
+    out_text.assign(TO, std::string());
+    parallel_chunks(n, [&](unsigned t, size_t lo, size_t hi) {
+        std::string &o = out_text[t];
+        size_t est = 0;
+        for (size_t k = lo; k < hi; k++) est += 160 + (size_t)(toff[k + 1] - toff[k]);
+        o.reserve(est);
+        char nb[24];
+        auto num = [&](uint64_t x) {
+            auto r = std::to_chars(nb, nb + sizeof nb, x);
+            o.append(nb, r.ptr);
+        };
+        for (size_t k = lo; k < hi; k++) {
+            const HeaderOnly &s = f.recs[k];
+            o.append(f.all.data() + s.t_name, s.t_name_n); o += '\t'; num(s.t_len); o += '\t'; num(s.t_st); o += '\t'; num(s.t_en); o += '\t';
+            o += s.strand; o += '\t'; o.append(f.all.data() + s.q_name, s.q_name_n); o += '\t'; num(s.q_len); o += '\t'; num(s.q_st); o += '\t';
+            num(s.q_en); o += '\t'; num(red[k].nmatch); o += '\t'; num(red[k].aln_len); o += '\t'; num(s.mapq); o += "\tid:Z:\tcg:Z:";
+            o.append((const char *)text.data() + toff[k], (size_t)(toff[k + 1] - toff[k]));
+            o += '\n';
+        }
+    });
+    lap("  assemble lines", tl);
+    return true;
+}
+
 // main.rs:50-58 (stats --paf), text in -> stats lines
 bool stats_file_text(Engine &eng, const std::string &paf_path, bool qbed, std::vector<std::string> &out_text) {
     TextFile f;

@@ -96,6 +96,7 @@ bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vec
 bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_length, std::vector<std::string> &out_text); // main.rs:271-281
 bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, int diff_score, int indel_score, bool remove_contained,
                     std::vector<std::string> &out_text); // main.rs:218-230, the batch resident on the device across the passes
+bool invert_file_text(Engine &eng, const std::string &paf_path, std::vector<std::string> &out_text); // main.rs:176-182, CIGARs parsed, swapped and printed on the device
 bool stats_file_text(Engine &eng, const std::string &paf_path, bool qbed, std::vector<std::string> &out_text);          // main.rs:50-58, lines without the header
 std::vector<std::string> break_paf_on_indels_text(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length);
 // main.rs:274-280: aligned_pairs + liftover::break_paf_on_indels (liftover.rs:182-226) for every record, record order

@@ -323,8 +323,13 @@ int main(int argc, char **argv) {
                 }
             }
         } else if (cmd == "invert") {
-            rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-            put(rb::records_to_text(rb::paf_swap_query_and_target(eng, paf.records)));
+            std::vector<std::string> text;
+            if (text_path && rb::invert_file_text(eng, paf_path, text)) {
+                put(text);
+            } else {
+                rb::Paf paf = rb::Paf::from_file(eng, paf_path);
+                put(rb::records_to_text(rb::paf_swap_query_and_target(eng, paf.records)));
+            }
         } else if (cmd == "liftover" || cmd == "lo") {
             if (bed_path.empty()) return usage();
             std::vector<rb::Region> rgns = rb::parse_bed(bed_path);
