@@ -552,7 +552,7 @@ extern "C" size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap
 static uint64_t slot_stride_of(uint64_t n_ops, uint64_t n_rec) { return ((n_ops + 31) & ~(uint64_t)31) + 32 * n_rec + 64; }
 extern "C" uint64_t rb_plan_out_capacity(const rb_plan *plan, int for_break) {
     if (!plan) return 0;
-    const uint64_t slots = for_break ? 1 : std::min<uint32_t>(plan->depth, RB_MS);
+    const uint64_t slots = for_break ? std::min<uint32_t>(2u, RB_MS) : std::min<uint32_t>(plan->depth, RB_MS);
     return slots * slot_stride_of(plan->n_ops, plan->n_rec) + plan->n_ops / 16 + 32 * plan->n_rec + (1u << 20);
 }
 
@@ -602,10 +602,11 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.n_arena = pick_arenas(b->n_rec);
     p.desc_mode = (policy & RB_LIFT_DESCRIPTORS) ? 1 : 0;
     // out_ops = [slots the streaming kernel emits into | arenas of the generic and the copy kernel] (descriptor mode: [descriptors | arenas]).
-    // As many slots as the window lists overlap deep (break-paf pieces do not overlap: one), as far as out_cap allows; with fewer,
+    // As many slots as the window lists overlap deep (break-paf: two -- its pieces do not overlap, but neighbours end and begin in
+    // the same 128-byte line, and a slot wants its clips four lines apart), as far as out_cap allows; with fewer,
     // or none, the clips that lose their place are copied into the arenas instead: slower, same rows.
     p.slot_stride = slot_stride_of(b->n_ops, b->n_rec);
-    const uint32_t want = p.desc_mode ? 0u : std::min<uint32_t>(is_break ? 1u : plan->depth, RB_MS);
+    const uint32_t want = p.desc_mode ? 0u : std::min<uint32_t>(is_break ? 2u : plan->depth, RB_MS);
     const uint64_t min_arena = 1024ull * p.n_arena;
     uint32_t n_slots = want;
     while (n_slots && (uint64_t)n_slots * p.slot_stride + min_arena > out_cap) n_slots--;
