@@ -10,16 +10,23 @@
 //   rb_k_make_jobs      one thread per schedule slot: a 64-byte job descriptor, so that a wave starts on its record
 //                       after ONE load instead of a chain of dependent ones
 //   rb_k_liftover_stream  ONE WAVEFRONT PER RECORD.  The record's packed ops stream from HBM once (32 contiguous
-//                       bytes per lane, 2 KiB per step, two steps in flight); per lane the reference / query /
-//                       unit lengths of 8 ops are summed (op class -> mask with one v_bfe_i32), three 6-step DPP
-//                       prefix scans give the running offsets, every second lane leaves a 16-op checkpoint in
-//                       LDS; window boundaries are resolved lane-parallel against the checkpoints (lane j: start
-//                       of window j, lane j + 32: its end).  One atomic per pass reserves the output; every clip
-//                       is placed so that it keeps the 16-byte phase of its ops in the input, hence its interior
-//                       is copied (out of L2 / Infinity Cache: the record has just been streamed) with aligned
-//                       16-byte loads and stores through a hand-pipelined 4-buffer ring, and only the two end
-//                       groups of a clip are patched.
-//   rb_k_liftover_generic  one thread per hit, serial walk: every case the streaming kernel declines
+//                       bytes per lane, 2 KiB per step, two steps in flight in a register ring the compiler cannot
+//                       see); per lane the reference / query / unit lengths of 8 ops are summed (op class -> mask
+//                       with one v_bfe_i32), three 6-step DPP prefix scans give the running offsets, every second
+//                       lane leaves a 16-op checkpoint in LDS; window boundaries are resolved lane-parallel against
+//                       the checkpoints (lane j: start of window j, lane j + 32: its end).  Clips are emitted FROM
+//                       THE LOAD RING while the record streams: output slot k mirrors the input's op positions
+//                       (out_ops[k * slot_stride + 32 r + position]), clip j of a record goes to slot j mod n_slots,
+//                       and a lane stores the 8 ops it has just loaded into every slot whose current clip its
+//                       reference span touches -- no size is needed to place a clip, so there is no reservation,
+//                       no atomic and no second read.  After the segment's resolution only the two end groups of a
+//                       clip are patched (clipped first / last length).  Clips that would land within four lines of
+//                       the previous clip of their slot, and clips of windows that are not sorted, are listed and
+//                       copied by rb_k_copy_clips into the arenas behind the slots.
+//   rb_k_liftover_generic_wave  one wavefront per hit the streaming kernel declines: three passes over the record's
+//                       ops (boundaries, merge of adjacent runs through LDS, emission); rb_k_liftover_generic, the
+//                       serial one-thread-per-hit form, stays as the diagnostic reference (RB_DEBUG_GENERIC_SERIAL).
+//                       They take every case the streaming kernel declines
 //                       (irregular CIGARs: N/S/H/P, zero lengths, adjacent ops of one type that must
 //                       merge (paf.rs:602-620); the legacy binary-search policy when the duplicate
 //                       choice matters; look-aheads / look-backs longer than RB_WALK_MAX ops).
