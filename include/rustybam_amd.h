@@ -228,7 +228,7 @@ void rb_plan_destroy(rb_plan *plan);
 size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap);
 /* out_ops capacity (in ops) with which rb_dev_liftover (for_break = 0) / rb_dev_break (1) can emit every clip while the record
  * streams past: the clipped cigars go to up to 4 positional copies of the batch's op index space (as many as the sorted window
- * lists overlap deep; one for break-paf), and only rows' out_off says where a clip is.  A smaller out_cap still works -- clips
+ * lists overlap deep; two for break-paf), and only rows' out_off says where a clip is.  A smaller out_cap still works -- clips
  * without a place are then copied by a second kernel into what room there is, and counters report overflow / out_ops_needed as
  * before -- a larger one is never needed for sorted, at most 4-deep window lists. */
 uint64_t rb_plan_out_capacity(const rb_plan *plan, int for_break);
