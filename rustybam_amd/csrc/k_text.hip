@@ -190,8 +190,13 @@ __device__ __forceinline__ uint32_t rb_ndigits(uint32_t v) {
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u);
 }
 
+#define RB_FMT_STAGE (256 * 10 + 32) // bytes of text one step of 256 ops can make (9 digits + the op character each) + the 16-byte phase
 template <bool FILL>
 __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
+    // fill pass: the text of a step is put together in LDS (one byte per digit, at the 16-byte phase it has in memory) and leaves with
+    // aligned 16-byte stores; only the ragged head and tail of a step -- bytes of 16-byte groups it shares with its neighbours -- go
+    // out byte by byte.  (One global byte store per character made this pass 1.8e9 scattered stores per 1.8 GB.)
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[FILL ? 4 : 1][FILL ? RB_FMT_STAGE : 16];
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const uint64_t it = (uint64_t)blockIdx.x * 4u + wib;
     if (it >= p.n_items) return;
@@ -204,6 +209,7 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
     const uint32_t ll = p.last_len ? rb_first(p.last_len[it]) : 0u;
     uint64_t out = FILL ? rb_first64(p.text_off[it]) : 0;
     uint64_t bytes = 0;
+    uint8_t *stg = stage_all[wib];
     for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
         uint32_t len[4], opc[4], nb[4];
         uint32_t mine = 0;
@@ -223,23 +229,40 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
         const uint32_t incl = rb_wave_scan_incl(mine);
         const uint32_t step_bytes = rb_readlane<uint32_t>(incl, 63);
         if (FILL) {
-            uint64_t o = out + (incl - mine);
+            const uint32_t phase = (uint32_t)(out & 15u);
+            uint32_t o = phase + (incl - mine); // place in the stage buffer: byte k of the buffer is byte (out - phase + k) of the text
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (nb[q]) {
                     const uint32_t nd = nb[q] - 1u;
                     uint32_t l = len[q];
-                    if (o + nb[q] <= p.text_cap) {
-                        p.text[o + nd] = (uint8_t)("MIDNSHP=X??????"[opc[q] < 9u ? opc[q] : 9u]);
-                        for (uint32_t k = nd; k-- > 0u;) {
-                            const uint32_t t = l / 10u;
-                            p.text[o + k] = (uint8_t)(48u + (l - t * 10u));
-                            l = t;
-                        }
+                    stg[o + nd] = (uint8_t)("MIDNSHP=X??????"[opc[q] < 9u ? opc[q] : 9u]);
+                    for (uint32_t k = nd; k-- > 0u;) {
+                        const uint32_t t = l / 10u;
+                        stg[o + k] = (uint8_t)(48u + (l - t * 10u));
+                        l = t;
                     }
                     o += nb[q];
                 }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint64_t cap_end = p.text_cap;
+            const uint32_t end = phase + step_bytes;                 // buffer bytes [phase, end) are this step's
+            const uint32_t a16 = (phase + 15u) & ~15u, b16 = end & ~15u; // whole 16-byte groups [a16, b16)
+            uint8_t *__restrict__ dst = p.text + (out - phase);      // 16-byte aligned (text is, by contract)
+            if (out + step_bytes <= cap_end) {
+                if (a16 < b16) {
+                    for (uint32_t k = a16 + 16u * (uint32_t)lane; k < b16; k += 1024u)
+                        *reinterpret_cast<uint4 *>(dst + k) = *reinterpret_cast<const uint4 *>(stg + k);
+                    if ((uint32_t)lane < a16 - phase) dst[phase + (uint32_t)lane] = stg[phase + (uint32_t)lane];         // head (< 16 bytes)
+                    if ((uint32_t)lane < end - b16) dst[b16 + (uint32_t)lane] = stg[b16 + (uint32_t)lane];               // tail (< 16 bytes)
+                } else { // a step of a few bytes inside one or two groups
+                    for (uint32_t k = phase + (uint32_t)lane; k < end; k += 64u) dst[k] = stg[k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             out += step_bytes;
         }
         bytes += step_bytes;
