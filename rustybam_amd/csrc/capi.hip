@@ -142,6 +142,15 @@ struct rb_nf_params {
     uint32_t flags;
 };
 extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *p, hipStream_t stream);
+struct rb_compact_params {
+    uint64_t n_rows;
+    rb_hit_row *rows;
+    const uint32_t *src;
+    uint64_t *off;
+    uint32_t *dst;
+    int fill;
+};
+extern "C" hipError_t rb_launch_compact_clips(const rb_compact_params *p, hipStream_t stream);
 extern "C" size_t rb_nf_tile_positions(void);
 extern "C" size_t rb_nf_scan_blocks(uint64_t n);
 
@@ -1006,35 +1015,33 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     rb_lap("alloc + kernels", tl);
     if (!rc && fused && norm_out) rc = rb_dev_download(ctx, norm_out, d_norm, n_rec * sizeof(rb_norm_row));
     if (!rc) {
+        // the clips packed side by side in row order ON THE DEVICE (the slots of out_ops are as large as the batch: only the clips
+        // themselves cross PCIe), rows' out_off rebased onto the dense array
         *n_rows = hc.n_hits;
         *rows = (rb_hit_row *)malloc((size_t)(hc.n_hits + 1) * sizeof(rb_hit_row));
-        // compact the clipped cigars to a dense host array in row order
-        std::vector<rb_hit_row> hr((size_t)hc.n_hits);
-        if (hc.n_hits) rc = rb_dev_download(ctx, hr.data(), d_rows, (size_t)hc.n_hits * sizeof(rb_hit_row));
-        uint64_t total = 0;
-        auto words = [](const rb_hit_row &h) -> uint64_t { return h.status != RB_ST_OK ? 0 : ((h.flags & RB_HIT_DESCRIPTOR) ? 4 : h.out_n); };
-        for (auto &h : hr) total += words(h);
-        *out_ops = (uint32_t *)malloc((size_t)(total + 1) * 4);
-        std::vector<uint32_t> dev_out;
-        if (!rc && hc.n_hits) {
-            uint64_t hi = 0;
-            for (auto &h : hr)
-                if (h.status == RB_ST_OK) hi = std::max<uint64_t>(hi, h.out_off + words(h));
-            dev_out.resize((size_t)hi + 4);
-            if (hi) rc = rb_dev_download(ctx, dev_out.data(), d_out, (size_t)hi * 4);
-        }
         uint64_t o = 0;
-        for (size_t i = 0; i < hr.size() && !rc; i++) {
-            rb_hit_row h = hr[i];
-            if (h.status == RB_ST_OK) {
-                memcpy(*out_ops + o, dev_out.data() + h.out_off, (size_t)words(h) * 4);
-                h.out_off = o;
-                o += words(h);
-            } else {
-                h.out_off = 0;
-                h.out_n = 0;
-            }
-            (*rows)[i] = h;
+        if (hc.n_hits) {
+            uint64_t *d_off = nullptr, *d_blk = nullptr;
+            uint32_t *d_dense = nullptr;
+            rc = rb_dev_alloc(ctx, (hc.n_hits + 2) * 8, (void **)&d_off);
+            if (!rc) rc = rb_dev_alloc(ctx, (rb_scan_block_sums_count(hc.n_hits) + 2) * 8, (void **)&d_blk);
+            rb_compact_params cp{hc.n_hits, d_rows, d_out, d_off, nullptr, 0};
+            if (!rc && rb_launch_compact_clips(&cp, ctx->stream) != hipSuccess) rc = RB_E_HIP;
+            if (!rc && rb_launch_exclusive_scan(d_off, hc.n_hits, d_blk, d_off + hc.n_hits, ctx->stream) != hipSuccess) rc = RB_E_HIP;
+            if (!rc) rc = rb_dev_download(ctx, &o, d_off + hc.n_hits, 8);
+            if (!rc) rc = rb_dev_alloc(ctx, (o + 4) * 4, (void **)&d_dense);
+            cp.dst = d_dense, cp.fill = 1;
+            if (!rc && rb_launch_compact_clips(&cp, ctx->stream) != hipSuccess) rc = RB_E_HIP;
+            if (!rc) rc = rb_dev_download(ctx, *rows, d_rows, (size_t)hc.n_hits * sizeof(rb_hit_row));
+            *out_ops = (uint32_t *)malloc((size_t)(o + 1) * 4);
+            if (!rc && o) rc = rb_dev_download(ctx, *out_ops, d_dense, (size_t)o * 4);
+            if (d_off) hipFree(d_off);
+            if (d_blk) hipFree(d_blk);
+            if (d_dense) hipFree(d_dense);
+            for (uint64_t i = 0; i < hc.n_hits && !rc; i++) // (rows that carry no clip: the fields the reference has no value for)
+                if ((*rows)[i].status != RB_ST_OK) (*rows)[i].out_off = 0, (*rows)[i].out_n = 0;
+        } else {
+            *out_ops = (uint32_t *)malloc(4);
         }
         *n_out = o;
         if (counters) *counters = hc;

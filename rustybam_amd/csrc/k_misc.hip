@@ -340,3 +340,40 @@ extern "C" hipError_t rb_launch_digest_rows(const rb_digest_params *p, hipStream
     hipLaunchKernelGGL(rb_k_digest_rows, dim3((unsigned)((p->n_rows + 3) / 4)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
+
+// ---- clips of a finished clip call, packed side by side in row order (host-buffer callers: the slots of out_ops mirror the input's op
+//      positions and are as large as the batch; what goes over PCIe is the clips alone) ----------------------------------------------
+struct rb_compact_params {
+    uint64_t n_rows;
+    rb_hit_row *rows;
+    const uint32_t *src; // out_ops of the clip call
+    uint64_t *off;       // [n_rows + 1] words per row, then their exclusive prefix
+    uint32_t *dst;
+    int fill;
+};
+__device__ __forceinline__ uint64_t rb_row_words(const rb_hit_row &h) {
+    return h.status != RB_ST_OK ? 0ull : ((h.flags & RB_HIT_DESCRIPTOR) ? 4ull : (uint64_t)h.out_n);
+}
+__global__ __launch_bounds__(256) void rb_k_compact_clips(rb_compact_params p) {
+    if (!p.fill) {
+        const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        if (i < p.n_rows) p.off[i] = rb_row_words(p.rows[i]);
+        return;
+    }
+    const uint64_t i = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (i >= p.n_rows) return;
+    const uint64_t at = p.off[i], n = p.off[i + 1] - at;
+    const uint32_t *src = p.src + p.rows[i].out_off;
+    for (uint64_t j = rb_lane(); j < n; j += 64) p.dst[at + j] = src[j];
+    __builtin_amdgcn_wave_barrier();
+    if (rb_lane() == 0) { // (every lane has read out_off by now: the loads above were issued before this store in program order)
+        p.rows[i].out_off = n ? at : 0ull;
+        if (!n) p.rows[i].out_n = 0;
+    }
+}
+extern "C" hipError_t rb_launch_compact_clips(const rb_compact_params *p, hipStream_t stream) {
+    if (p->n_rows == 0) return hipSuccess;
+    if (!p->fill) hipLaunchKernelGGL(rb_k_compact_clips, dim3((unsigned)((p->n_rows + 255) / 256)), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(rb_k_compact_clips, dim3((unsigned)((p->n_rows + 3) / 4)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
