@@ -162,7 +162,7 @@ typedef struct rb_counters { /* device-written job summary, 64 bytes */
 
 /* per-record outcome of rb_dev_parse_cigars */
 enum { RB_TEXT_OK = 0, RB_TEXT_BAD = 1 /* the reference's "Unable to parse cigar string." panic */, RB_TEXT_TOO_LONG = 2 /* a length >= 2^28 */,
-       RB_TEXT_UNUSUAL = 3 /* a number written with more than 15 digits (zero padded): not decided on the device, parse it on the host */ };
+       RB_TEXT_UNUSUAL = 3 /* a number written with ten or more digits (zero padded, or past u32): not decided on the device, parse it on the host */ };
 
 /* ---- views over caller-owned device memory ---------------------------------------------------- */
 typedef struct rb_batch_view {

@@ -56,9 +56,21 @@ __device__ __forceinline__ uint32_t rb_op_code_of(uint32_t c) {
 
 __device__ __constant__ uint64_t rb_pow10[10] = {1ull, 10ull, 100ull, 1000ull, 10000ull, 100000ull, 1000000ull, 10000000ull, 100000000ull, 1000000000ull};
 
+// One step = 1 KiB of text, 16 bytes per lane.  A lane classifies its bytes four at a time (SWAR on the dwords: letters are >= ':',
+// anything below '0' or above 0x7f is malformed), which gives a 16-bit map L of where op characters sit; everything about LENGTHS OF
+// DIGIT RUNS -- a letter with no digits, ten or more digits, a string that does not end with a letter -- is bit arithmetic on L.
+// Only the values need the bytes one after the other: acc = acc * 10 + digit, reset behind a letter (five instructions a byte, no
+// branch).  An op takes at least two bytes, so the op whose character sits in byte pair j gets slot j; its code comes from a
+// 256-byte table in LDS.  A number that straddles two lanes is completed with the previous lane's unfinished digits (DPP
+// wave_shr:1); a number of ten or more digits (zero-padded, or past u32) is left to the host (RB_TEXT_UNUSUAL).
 template <bool FILL>
 __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
     __shared__ uint32_t stage_all[FILL ? 4 : 1][FILL ? 512 + 64 : 1]; // fill pass: the ops of one step per wave (+ a scrap word per lane)
+    __shared__ uint8_t code_lut[FILL ? 256 : 4];                       // op character -> code 0..8, 0x80: not an op character
+    if (FILL) {
+        code_lut[threadIdx.x] = (uint8_t)(rb_op_code_of(threadIdx.x) == 255u ? 0x80u : rb_op_code_of(threadIdx.x));
+        __syncthreads();
+    }
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const uint64_t r = (uint64_t)blockIdx.x * 4u + wib;
     if (r >= p.n_rec) return;
@@ -69,119 +81,139 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
     const uint64_t n_steps = (b1 - a0 + 1023u) >> 10; // 1 KiB of text per step
     uint64_t out_base = FILL ? rb_first64(p.op_off[r]) : 0; // next op slot of this record
     uint32_t total = 0;                               // ops found
-    uint32_t err = 0;                                 // RB_TEXT_* of this lane
-    // unfinished number at the end of lane 63 of the previous step
-    uint32_t carry_val = 0, carry_nd = 0;
+    uint32_t err = 0;                                 // bit 0: malformed, bit 1: a length >= 2^28, bit 2: left to the host
+    uint32_t carry_val = 0, carry_nd = 0;             // unfinished number at the end of lane 63 of the previous step
     for (uint64_t st = 0; st < n_steps; st++) {
         const uint64_t la = a0 + (st << 10) + (uint64_t)lane * 16u;
         uint4 q = make_uint4(0x30303030u, 0x30303030u, 0x30303030u, 0x30303030u);
         if (la < b1) q = *reinterpret_cast<const uint4 *>(p.text + la); // (the buffer is padded to 16 bytes)
-        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
-        // lane-local walk: ops that end in this chunk.  An op takes at least two bytes, so the op whose character sits
-        // in byte pair k / 2 gets slot k / 2 (statically indexed registers); the first one may have begun in the
-        // previous lane.
-        uint32_t slen[8], sinfo[8]; // length so far; code | digits << 8 | overflow << 16 | present << 24
-#pragma unroll
-        for (int j = 0; j < 8; j++) slen[j] = 0u, sinfo[j] = 0u;
-        uint32_t cnt = 0;
-        uint32_t acc = 0;     // value of the number being read (32-bit; `ovf` says it went past u32::MAX)
-        bool ovf = false;
-        uint32_t nd = 0;      // digits of the number being read
-        uint32_t lead_nd = 0; // digits before the first op character of the chunk (to combine with the carry)
-        bool seen = false, any_valid = false;
-        // (written with selects, not branches: sixteen divergent ifs per lane cost ~1600 scalar instructions of exec-mask
-        //  handling per step and made the kernel scalar-issue-bound)
-        const uint32_t first_valid = b0 > la ? (uint32_t)(b0 - la) : 0u;                     // bytes [first_valid, end_valid) of the
+        uint32_t w[4] = {q.x, q.y, q.z, q.w};
+        const uint32_t first_valid = b0 > la ? (uint32_t)(b0 - la) : 0u;                       // bytes [first_valid, end_valid) of the
         const uint32_t end_valid = b1 > la ? (b1 - la < 16u ? (uint32_t)(b1 - la) : 16u) : 0u; // chunk belong to the string
-        uint32_t errb = 0; // bit 0: malformed, bit 1: a length >= 2^28
+        const uint32_t fv = first_valid < 16u ? first_valid : 16u;
+        if (__ballot(fv != 0u || end_valid != 16u) != 0ull) { // first / last step only: bytes outside the string read as '0'
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const bool valid = (uint32_t)k >= first_valid && (uint32_t)k < end_valid;
-            const uint32_t c = (w[k >> 2] >> ((k & 3) * 8)) & 255u;
-            const uint32_t d = c - 48u;
-            const bool isdig = valid & (d < 10u), islet = valid & !(d < 10u);
-            const uint32_t code = rb_op_code_of(c);
-            // digit: the value leaves u32 (leading zeros may run on), acc * 10 + d without the slow 32-bit multiply
-            ovf |= isdig & ((acc > 429496729u) | ((acc == 429496729u) & (d > 5u)));
-            const uint32_t acc10 = ((acc << 3) + (acc << 1)) + d;
-            // op character
-            const bool later = islet & seen; // (the first op of the chunk is completed below, with the incoming digits)
-            errb |= (islet & (code == 255u)) ? 1u : 0u;
-            errb |= (later & ((nd == 0u) | ovf)) ? 1u : 0u;                      // no length / overflow of u32
-            errb |= (later & !ovf & (acc >= (1u << 28))) ? 2u : 0u;              // not representable in the packed form
-            errb |= (islet & (sinfo[k >> 1] != 0u)) ? 1u : 0u;                   // two op characters in one byte pair
-            lead_nd = (islet & !seen) ? nd : lead_nd;
-            slen[k >> 1] = islet ? acc : slen[k >> 1];                           // (completed below for the first op)
-            sinfo[k >> 1] = islet ? ((code & 15u) | (ovf ? 0x10000u : 0u) | (seen ? 0u : 0x20000u) | 0x1000000u) : sinfo[k >> 1];
-            cnt += islet ? 1u : 0u;
-            seen |= islet;
-            any_valid |= valid;
-            acc = isdig ? acc10 : (islet ? 0u : acc);
-            nd = isdig ? nd + 1u : (islet ? 0u : nd);
-            ovf = ovf & !islet;
+            for (int j = 0; j < 4; j++) {
+                const int32_t lo = (int32_t)fv - 4 * j, hi = (int32_t)end_valid - 4 * j;
+                const uint32_t l2 = lo < 0 ? 0u : (lo > 4 ? 4u : (uint32_t)lo), h2 = hi < 0 ? 0u : (hi > 4 ? 4u : (uint32_t)hi);
+                const uint32_t m = h2 > l2 ? ((0xFFFFFFFFu << (8u * l2)) & (0xFFFFFFFFu >> (32u - 8u * h2))) : 0u; // (l2 <= 3, h2 >= 1 here)
+                w[j] = (w[j] & m) | (0x30303030u & ~m);
+            }
         }
-        if (errb & 1u) err = RB_TEXT_BAD;
-        else if ((errb & 2u) && err == 0) err = RB_TEXT_TOO_LONG;
-        // the string must end with an op character
-        if (la + 16u >= b1 && la < b1 && nd != 0u) err = RB_TEXT_BAD;
-        // my unfinished tail -> the next lane; lane 0 takes the previous step's lane 63
-        const uint32_t tail_val = acc, tail_nd = nd | (ovf ? 0x100u : 0u);
-        const uint32_t in_val = rb_prev_lane(tail_val, carry_val), in_nd = rb_prev_lane(tail_nd, carry_nd);
-        // a chunk of digits only is the (short) head of the string, or part of a number padded with zeros to more than a
-        // lane holds: legal for the reference (u32::from_str), not handled here -> the host decides (RB_TEXT_UNUSUAL)
-        if (!seen && any_valid && ((in_nd & 0xFFu) != 0u || nd >= 16u)) err = err ? err : RB_TEXT_UNUSUAL;
-        carry_val = rb_readlane<uint32_t>(tail_val, 63);
-        carry_nd = rb_readlane<uint32_t>(tail_nd, 63);
-        const uint32_t incl = rb_wave_scan_incl(cnt);
-        const uint32_t step_total = rb_readlane<uint32_t>(incl, 63);
-        if (FILL) {
-            // the ops of this step go through LDS: every lane drops its (at most 8) ops at their rank -- absent slots go to a
-            // scrap word, so there is no branch per slot -- and the wave then writes the step's ops out side by side
-            uint32_t *stg = stage_all[wib];
-            uint32_t rank = incl - cnt;
-            // the first op of the chunk (at most one per lane) takes the digits that came in from the lanes before: done once, outside
-            // the slot loop, so that the loop has no branch
-            uint32_t l_first = 0, first_ovf = 0;
+        const bool any_valid = end_valid > fv;
+        // where the op characters are
+        uint32_t L = 0, junk = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = w[j];
+            junk |= (x & 0x80808080u) | ((((x | 0x80808080u) - 0x30303030u) ^ 0x80808080u) & 0x80808080u); // > 0x7f, < '0'
+            uint32_t t = (((x & 0x7F7F7F7Fu) + 0x46464646u) & 0x80808080u) >> 7;                          // >= ':' -> bit 0 of its byte
+            if (!FILL) {
+                L += (uint32_t)__builtin_popcount(t); // (the count pass wants nothing else)
+            } else {
+                t |= t >> 7;
+                t |= t >> 14;
+                L |= (t & 15u) << (4 * j);
+            }
+        }
+        uint32_t cnt;
+        if (!FILL) {
+            cnt = L;
+        } else {
+            cnt = (uint32_t)__builtin_popcount((L | (L >> 1)) & 0x5555u); // byte pairs with an op character = slots filled
+            if (junk) err |= 1u;
+            // runs of digits, from L alone.  V: the bytes of the string in this chunk
+            const uint32_t V = ((1u << end_valid) - 1u) & ~((1u << fv) - 1u);
+            if (L & (L << 1)) err |= 1u;                                  // two op characters in a row: no length
+            {
+                const uint32_t Z = ~L & V;                                  // digits
+                uint32_t rr = Z & (Z >> 1);
+                rr &= rr >> 2;
+                rr &= rr >> 4;                                              // eight in a row
+                if (rr & (Z >> 8) & (Z >> 9)) err |= 4u;                    // ten: zero-padded or past u32 -- the host decides
+            }
+            const bool seen = L != 0u;
+            const uint32_t f_pos = seen ? (uint32_t)__builtin_ctz(L) : 16u;           // first op character of the chunk
+            const uint32_t lead_nd = seen ? f_pos - fv : 0u;                          // digits in front of it
+            const uint32_t l_pos = seen ? 31u - (uint32_t)__builtin_clz(L) : 0u;      // last op character
+            const uint32_t trail_nd = any_valid ? (seen ? end_valid - 1u - l_pos : end_valid - fv) : 0u;
+            if (la + 16u >= b1 && la < b1 && trail_nd != 0u) err |= 1u;  // the string must end with an op character
+            // values: one pass over the bytes
+            uint32_t slen[8];
+            uint32_t acc = 0;
+            const uint32_t Ln = ~L;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const bool f = (sinfo[j] & 0x20000u) != 0u;
-                l_first = f ? slen[j] : l_first;
-                first_ovf = f ? (sinfo[j] & 0x10000u) : first_ovf;
+                const uint32_t x = w[j >> 1] >> (16 * (j & 1));
+                const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)L, 2 * j, 1), m1 = (uint32_t)__builtin_amdgcn_sbfe((int)L, 2 * j + 1, 1);
+                const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe((int)Ln, 2 * j, 1), k1 = (uint32_t)__builtin_amdgcn_sbfe((int)Ln, 2 * j + 1, 1);
+                const uint32_t a_before0 = acc;
+                acc = ((acc << 3) + (acc << 1) + (x & 15u)) & k0;
+                const uint32_t a_before1 = acc;
+                acc = ((acc << 3) + (acc << 1) + ((x >> 8) & 15u)) & k1;
+                slen[j] = (a_before0 & m0) | (a_before1 & m1); // (both set: flagged above)
             }
-            uint32_t fixed_first = l_first;
+            // my unfinished tail -> the next lane; lane 0 takes the previous step's lane 63
+            const uint32_t tail_val = acc, tail_nd = trail_nd;
+            const uint32_t in_val = rb_prev_lane(tail_val, carry_val), in_nd = rb_prev_lane(tail_nd, carry_nd);
+            // a chunk of digits only is the (short) head of the string, or part of a number of more digits than a lane holds: the
+            // second is left to the host
+            if (!seen && any_valid && (in_nd != 0u || trail_nd >= 16u)) err |= 4u;
+            carry_val = rb_readlane<uint32_t>(tail_val, 63);
+            carry_nd = rb_readlane<uint32_t>(tail_nd, 63);
+            // the first op of the chunk takes the digits that came in from the lane before
+            uint32_t fixed_first = 0;
             if (seen) {
-                const uint32_t ind = in_nd & 0xFFu;
-                const uint32_t tnd = ind + lead_nd;
-                uint64_t full = l_first;
-                if (ind && in_val != 0u) // (incoming zeros change nothing; a non-zero value followed by ten more digits is past u32::MAX)
-                    full = lead_nd >= 10u ? ~0ull : (uint64_t)in_val * rb_pow10[lead_nd] + l_first; // < 2^32 * 10^9
-                if ((in_nd & 0x100u) || first_ovf) full = ~0ull;
-                if (tnd == 0u || full > 0xFFFFFFFFull) err = (err == 0 || err == RB_TEXT_TOO_LONG) ? RB_TEXT_BAD : err;
-                else if (full >= (1ull << 28) && err == 0) err = RB_TEXT_TOO_LONG;
-                fixed_first = (uint32_t)full;
+                const uint32_t tnd = in_nd + lead_nd;
+                if (tnd == 0u) err |= 1u;     // an op character with no length
+                if (tnd >= 10u) err |= 4u;
+                uint32_t own = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) own = (f_pos >> 1) == (uint32_t)j ? slen[j] : own;
+                fixed_first = in_nd ? in_val * (uint32_t)rb_pow10[lead_nd < 10u ? lead_nd : 9u] + own : own;
             }
+            uint32_t mx = fixed_first;
+#pragma unroll
+            for (int j = 0; j < 8; j++) mx = mx > slen[j] ? mx : slen[j];
+            if (mx >= (1u << 28)) err |= 2u; // not representable in the packed form
+            // the ops of this step go through LDS: every lane drops its (at most 8) ops at their rank -- absent slots go to a scrap
+            // word -- and the wave then writes the step's ops out side by side
+            const uint32_t incl0 = rb_wave_scan_incl(cnt);
+            uint32_t *stg = stage_all[wib];
+            const uint32_t rank0 = incl0 - cnt;
+            const uint32_t P = (L | (L >> 1)) & 0x5555u; // bit 2 j: slot j holds an op
+            uint32_t badc = 0;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const bool present = (sinfo[j] & 0x1000000u) != 0u;
-                const uint32_t l = (sinfo[j] & 0x20000u) ? fixed_first : slen[j];
-                stg[present ? rank : 512u + (uint32_t)lane] = (l << 4) | (sinfo[j] & 15u);
-                rank += present ? 1u : 0u;
+                const uint32_t x = (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                const uint32_t c = ((L >> (2 * j)) & 1u) ? (x & 255u) : (x >> 8);
+                const uint32_t code = code_lut[c];
+                const bool present = (P >> (2 * j)) & 1u;
+                badc |= present ? code : 0u;
+                const uint32_t rank = rank0 + (uint32_t)__builtin_popcount(P & ((1u << (2 * j)) - 1u));
+                stg[present ? rank : 512u + (uint32_t)lane] = (slen[j] << 4) | (code & 15u);
             }
+            if (badc & 0x80u) err |= 1u; // not one of MIDNSHP=X
+            if (seen) stg[rank0] = (fixed_first << 4) | (stg[rank0] & 15u);
+            const uint32_t step_total_f = rb_readlane<uint32_t>(incl0, 63);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t k = (uint32_t)lane; k < step_total; k += 64u)
+            for (uint32_t k = (uint32_t)lane; k < step_total_f; k += 64u)
                 if (out_base + k < p.ops_cap) p.ops[out_base + k] = stg[k];
             __builtin_amdgcn_wave_barrier();
-            out_base += step_total;
+            out_base += step_total_f;
+            total += step_total_f;
+            continue;
         }
-        total += step_total;
+        total += rb_wave_sum_u32(cnt);
     }
     // (an empty string is an empty CIGAR)
-    const uint32_t any_err = rb_wave_or_u32(err == RB_TEXT_BAD ? 1u : (err == RB_TEXT_TOO_LONG ? 2u : (err == RB_TEXT_UNUSUAL ? 4u : 0u)));
-    if (lane == 0) {
-        if (!FILL) p.op_off[r] = total;
-        else // (an unusual string may also be a bad one: the host's parser has the last word on it)
+    if (FILL) {
+        const uint32_t any_err = rb_wave_or_u32(err);
+        if (lane == 0) // (an unusual string may also be a bad one: the host's parser has the last word on it)
             p.status[r] = (uint8_t)((any_err & 4u) ? RB_TEXT_UNUSUAL : ((any_err & 1u) ? RB_TEXT_BAD : ((any_err & 2u) ? RB_TEXT_TOO_LONG : RB_TEXT_OK)));
+    } else if (lane == 0) {
+        p.op_off[r] = total;
     }
 }
 
@@ -201,22 +233,39 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
     const uint64_t it = (uint64_t)blockIdx.x * 4u + wib;
     if (it >= p.n_items) return;
     const int lane = rb_lane();
-    const uint64_t f_raw = rb_first64(p.first[it]);
+    // (the item's five scalars: all loads issued before the first one is waited for -- one trip to memory, not five)
+    const uint64_t f_v = p.first[it];
+    const uint32_t n_v = p.count[it];
+    const uint32_t fl_v = p.first_len ? p.first_len[it] : 0u;
+    const uint32_t ll_v = p.last_len ? p.last_len[it] : 0u;
+    const uint64_t out_v = FILL ? p.text_off[it] : 0;
+    const uint64_t f_raw = rb_first64(f_v);
     const uint32_t *__restrict__ src = (f_raw >> 63) ? p.ops_alt : p.ops;
     const uint64_t f0 = f_raw & ~(1ull << 63);
-    const uint32_t n = rb_first(p.count[it]);
-    const uint32_t fl = p.first_len ? rb_first(p.first_len[it]) : 0u;
-    const uint32_t ll = p.last_len ? rb_first(p.last_len[it]) : 0u;
-    uint64_t out = FILL ? rb_first64(p.text_off[it]) : 0;
+    const uint32_t n = rb_first(n_v);
+    const uint32_t fl = rb_first(fl_v);
+    const uint32_t ll = rb_first(ll_v);
+    uint64_t out = rb_first64(out_v);
     uint64_t bytes = 0;
     uint8_t *stg = stage_all[wib];
     for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
         uint32_t len[4], opc[4], nb[4];
         uint32_t mine = 0;
+        // my four ops: one 16-byte load where all four exist (the array may end with the item: no reading past it)
+        const uint32_t ib = i0 + (uint32_t)lane * 4u;
+        uint32_t vv[4] = {0u, 0u, 0u, 0u};
+        if (ib + 3u < n) {
+            const uint4 t4 = rb_load4_unaligned(src + f0 + ib);
+            vv[0] = t4.x, vv[1] = t4.y, vv[2] = t4.z, vv[3] = t4.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (ib + (uint32_t)q < n) vv[q] = src[f0 + ib + (uint32_t)q];
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t i = i0 + (uint32_t)lane * 4u + (uint32_t)q;
-            uint32_t v = i < n ? src[f0 + i] : 0u;
+            uint32_t v = vv[q];
             uint32_t l = v >> 4;
             if (n == 1u && fl && ll) l = fl + ll - l; // the middle of one op (liftover.rs via subset_cigar, paf.rs:593-620)
             else if (i == 0u && fl) l = fl;             // first op keeps its tail

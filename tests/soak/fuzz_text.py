@@ -22,7 +22,8 @@ for it in range(0, n_cases, 500):
     for _ in range(500):
         if rng.random() < 0.5:  # mostly valid, then damaged
             k = int(rng.integers(0, 400))
-            parts = [f"{'0' * int(rng.choice([0, 0, 0, 1, 3, 9]))}{int(rng.integers(0, 10 ** int(rng.integers(1, 9))))}{'MIDNSHP=X'[int(rng.integers(0, 9))]}" for _ in range(k)]
+            pads = [0, 0, 0, 1, 3, 9] if rng.random() < 0.1 else [0, 0, 0, 0, 1]  # (ten digits or more: the device hands the string to the host)
+            parts = [f"{'0' * int(rng.choice(pads))}{int(rng.integers(0, 10 ** int(rng.integers(1, 9))))}{'MIDNSHP=X'[int(rng.integers(0, 9))]}" for _ in range(k)]
             s = bytearray("".join(parts).encode())
             for _ in range(int(rng.integers(0, 2))):
                 if s:

@@ -131,9 +131,9 @@ def test_format_matches_oracle_and_clips(engine, oracle):
 
 
 def test_parse_zero_padded_numbers(engine, oracle):
-    """u32::from_str accepts any number of leading zeros: short paddings are parsed on the device, a number longer than one
-    16-byte lane is handed to the host (status 3), never rejected"""
-    cigs = ["00000000005M", "0000000000000012=3X", "7=" + "0" * 9 + "4294967295D"[:0] + "000000000268435455D", "0" * 40 + "9M", "5=" + "0" * 20 + "1X"]
+    """u32::from_str accepts any number of leading zeros: paddings up to nine digits in all are parsed on the device, a number written
+    with ten or more digits is handed to the host (status 3), never rejected"""
+    cigs = ["000000005M", "0000000000000012=3X", "7=" + "0" * 9 + "4294967295D"[:0] + "000000000268435455D", "0" * 40 + "9M", "5=" + "0" * 20 + "1X"]
     op_off, ops, status = engine.parse_cigars(cigs)
     for i, c in enumerate(cigs):
         want = oracle_parse(oracle, c)
