@@ -834,9 +834,10 @@ extern "C" int rb_dev_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint6
     HIPCHK(ctx, rb_launch_parse_cigars(&p, true, ctx->stream));
     return RB_OK;
 }
-extern "C" int rb_dev_format_cigars(rb_ctx *ctx, const uint32_t *ops, const uint32_t *ops_alt, uint64_t n_items, const uint64_t *first,
-                                    const uint32_t *count, const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off,
-                                    uint8_t *text, uint64_t text_cap, void *scratch) {
+// offsets_ready: text_off already holds the prefix of a sizes-only call on the same items (the host wrappers size, allocate, fill)
+static int format_cigars_impl(rb_ctx *ctx, const uint32_t *ops, const uint32_t *ops_alt, uint64_t n_items, const uint64_t *first,
+                              const uint32_t *count, const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off,
+                              uint8_t *text, uint64_t text_cap, void *scratch, bool offsets_ready) {
     if (!ctx || !text_off || !scratch || (n_items && (!ops || !first || !count))) return RB_E_INVALID;
     rb_format_params p;
     p.n_items = n_items;
@@ -849,12 +850,19 @@ extern "C" int rb_dev_format_cigars(rb_ctx *ctx, const uint32_t *ops, const uint
     p.text_off = text_off;
     p.text = text;
     p.text_cap = text_cap;
-    HIPCHK(ctx, hipMemsetAsync(text_off + n_items, 0, 8, ctx->stream));
+    if (!offsets_ready) HIPCHK(ctx, hipMemsetAsync(text_off + n_items, 0, 8, ctx->stream));
     if (n_items == 0) return RB_OK;
-    HIPCHK(ctx, rb_launch_format_cigars(&p, false, ctx->stream));
-    HIPCHK(ctx, rb_launch_exclusive_scan(text_off, n_items, (uint64_t *)scratch, nullptr, ctx->stream));
+    if (!offsets_ready) {
+        HIPCHK(ctx, rb_launch_format_cigars(&p, false, ctx->stream));
+        HIPCHK(ctx, rb_launch_exclusive_scan(text_off, n_items, (uint64_t *)scratch, nullptr, ctx->stream));
+    }
     if (text) HIPCHK(ctx, rb_launch_format_cigars(&p, true, ctx->stream));
     return RB_OK;
+}
+extern "C" int rb_dev_format_cigars(rb_ctx *ctx, const uint32_t *ops, const uint32_t *ops_alt, uint64_t n_items, const uint64_t *first,
+                                    const uint32_t *count, const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off,
+                                    uint8_t *text, uint64_t text_cap, void *scratch) {
+    return format_cigars_impl(ctx, ops, ops_alt, n_items, first, count, first_len, last_len, text_off, text, text_cap, scratch, false);
 }
 
 // ---- host-buffer wrappers ----------------------------------------------------------------------
@@ -1140,7 +1148,7 @@ extern "C" int rb_host_format_cigars(rb_ctx *ctx, const uint32_t *ops, uint64_t 
     if ((rc = rb_dev_download(ctx, text_off, d_toff, ((size_t)n_items + 1) * 8))) return rc;
     const uint64_t bytes = text_off[n_items];
     if ((rc = b.alloc((size_t)bytes + 16, &d_text))) return rc;
-    if ((rc = rb_dev_format_cigars(ctx, d_ops, nullptr, n_items, d_first, d_count, d_fl, d_ll, d_toff, d_text, bytes, d_scr))) return rc;
+    if ((rc = format_cigars_impl(ctx, d_ops, nullptr, n_items, d_first, d_count, d_fl, d_ll, d_toff, d_text, bytes, d_scr, true))) return rc;
     *text = (uint8_t *)malloc((size_t)bytes + 16);
     if (!*text) return fail(ctx, RB_E_NOMEM, "malloc(%llu text bytes)", (unsigned long long)bytes);
     if (bytes) return rb_dev_download(ctx, *text, d_text, (size_t)bytes);
@@ -1314,7 +1322,7 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
         if (!rc) rc = rb_dev_download(ctx, *row_text_off, d_toff, ((size_t)nr + 1) * 8);
         const uint64_t bytes = rc ? 0 : (*row_text_off)[nr];
         if (!rc) rc = b.alloc((size_t)bytes + 16, &d_rtext);
-        if (!rc) rc = rb_dev_format_cigars(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, d_rtext, bytes, d_scr2);
+        if (!rc) rc = format_cigars_impl(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, d_rtext, bytes, d_scr2, true);
         if (!rc) {
             *row_text = (uint8_t *)malloc((size_t)bytes + 16);
             if (!*row_text) rc = fail(ctx, RB_E_NOMEM, "malloc(%llu text bytes)", (unsigned long long)bytes);
