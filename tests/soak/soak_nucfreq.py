@@ -32,6 +32,36 @@ for case in range(n_cases):
     check_regions(eng, oracle, rd, regions)
     pos_total += sum(e - s for _t, s, e in regions)
 
+# piles that cross htslib's cap of 8000 buffered reads: random starts, lengths, flags and regions (every region at most one
+# 10 kb fetch of the reference, so that the oracle's per-fetch admission is the device's per-region admission)
+n_deep = max(2, n_cases // 10)
+for case in range(n_deep):
+    rng = np.random.default_rng(0xDEE9000 + case)
+    n = int(rng.integers(8500, 20000))
+    span = int(rng.choice([1, 5, 60, 300]))
+    pos = np.sort(rng.integers(0, span, n)).tolist()
+    cigs, seqs, flags = [], [], []
+    for k in range(n):
+        l = int(rng.integers(5, 120)) if rng.random() < 0.98 else int(rng.integers(2000, 9000))
+        if rng.random() < 0.15 and l > 8:
+            d = int(rng.integers(1, 6))
+            cigs.append([((l // 2) << 4), (d << 4) | int(rng.choice([1, 2])), ((l - l // 2) << 4)])
+            q = l + (d if cigs[-1][1] & 15 == 1 else 0)
+        else:
+            cigs.append([(l << 4)])
+            q = l
+        seqs.append(rng.choice([1, 2, 4, 8, 15], size=q).tolist())
+        flags.append(int(rng.choice([0, 0, 0, 0, 0, 0, 16, 1024, 256])))
+    rd = Reads([0] * n, pos, flags, cigs, seqs)
+    regions = [(0, 0, 9000)]
+    for _ in range(int(rng.integers(1, 4))):
+        st = int(rng.integers(0, span + 100))
+        regions.append((0, st, st + int(rng.integers(1, 9000))))
+    counts, status, ctr = check_regions(eng, oracle, rd, regions)
+    assert ctr["cap_overflow"] == 0
+    pos_total += sum(e - s for _t, s, e in regions)
+    print(f"deep case {case}: {n} reads over {span} starts, max depth {ctr['max_depth']}, dropped {ctr['n_dropped']}", flush=True)
+
 # the bench workload, scaled down: 30x of 3 Mbp by 15 kb reads
 import bench_nucfreq as B
 pos, ops, op_off, n = B.make_reads(3_000_000, 30, 15000)
