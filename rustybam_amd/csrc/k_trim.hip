@@ -358,7 +358,13 @@ __device__ void rb_serial_pair(const rb_trim_params &p, const uint64_t pi) {
 // The split (trim_overlap.rs:50-76) is the first strict maximum of f(k) = l[0..k) + r[k..n): f is piecewise linear, so it is
 // evaluated only where either record's score changes (op starts and the special last base), all candidates in parallel.
 // Pairs this kernel does not take are marked RB_ST_PENDING_INTERNAL and done by rb_k_overlap_split afterwards.
-#define RB_TW_CAP 768   // ops of a record's region, first attempt (19.7 KB of LDS per pair: 8 pairs per CU)
+#ifndef RB_TW_CAP
+#define RB_TW_CAP 192   // ops of a record's region, first attempt: 5 KB of LDS per pair and 64 VGPRs = 32 pairs per CU.  The kernel waits on
+                        // memory, not on the ALUs: 768 ops (8 pairs per CU, whole 500-op records staged) took 20.1 ms per 1.5e6 pairs, this 7.2
+#endif
+#ifndef RB_TW_CAP1
+#define RB_TW_CAP1 1024 // the pairs the first attempt lists, second attempt (26 KB: 6 pairs per CU)
+#endif
 #define RB_TW_CAP2 6144 // second attempt for the pairs whose overlap spans more ops (one pair per CU at a time; such overlaps are rare)
 #define RB_TW_CAP3 32768 // third attempt: the same arrays in device memory (whole-chromosome alignments that overlap by hundreds of kilobases)
 #define RB_TW_SLAB_WORDS(CAP) (2u * 3u * ((CAP) + 1u) + 2u * 3u * ((CAP) / 16u + 2u))
@@ -834,8 +840,11 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
     if (lane == 0) p.rows[pi] = w;
 }
 // first attempt: a wavefront per pair
+#ifndef RB_TW_WPE
+#define RB_TW_WPE 8
+#endif
 template <int CAP>
-__global__ __launch_bounds__(64) void rb_k_overlap_split_wave(rb_trim_params p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RB_TW_WPE))) void rb_k_overlap_split_wave(rb_trim_params p) {
     __shared__ uint32_t lds_w[2][3][CAP + 1];
     __shared__ uint32_t lds_c[2][3][CAP / 16 + 2];
     if (blockIdx.x < p.n_pairs) rb_tw_pair<CAP>(p, blockIdx.x, lds_w, lds_c);
@@ -880,6 +889,9 @@ extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream
     if (!serial_only) {
         q.only_pending = 0;
         hipLaunchKernelGGL(rb_k_overlap_split_wave<RB_TW_CAP>, dim3((unsigned)p->n_pairs), dim3(64), 0, stream, q);
+        q.only_pending = 2; // (the attempts behind the first walk its list; what they decline is listed already)
+        const unsigned g1 = (unsigned)(p->n_pairs < 8192 ? p->n_pairs : 8192);
+        hipLaunchKernelGGL(rb_k_overlap_split_wave_pending<RB_TW_CAP1>, dim3(g1), dim3(64), 0, stream, q);
         const unsigned g2 = (unsigned)(p->n_pairs < 2048 ? p->n_pairs : 2048);
         hipLaunchKernelGGL(rb_k_overlap_split_wave_pending<RB_TW_CAP2>, dim3(g2), dim3(64), 0, stream, q);
         if (q.scratch && q.scratch_blocks) {
