@@ -391,22 +391,38 @@ __device__ __forceinline__ bool nf_u8_tile(const rb_nf_params &p, uint64_t lo, u
 __device__ __forceinline__ uint32_t nf_slot(uint32_t i) { return 2u * (i + 8u) + ((i + 8u) >> 3); }
 __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { return ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu); }
 
+// Two builds of the tile kernel.  U8T: tiles with at most 255 reads in range (byte counters, the coverage differences as 16-bit
+// halves of a dword, a staging buffer of 640 dwords): 49 KB of LDS, three workgroups per CU instead of two -- the kernel waits on
+// LDS and memory latency, and the third workgroup is worth 20 % (4.43 -> 3.6 ms on config 5).  The other build takes the tiles
+// crowded with reads (16-bit counters, 32-bit differences: 77 KB).  Both are launched over all tiles and leave the other's alone.
+#define NF_CNT8_DW (10 * ((NF_TILE + 16) / 8))
+template <bool U8T>
 __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[NF_CNT_DW]; // per position: A | C << 16, G | T << 16 -- or one dword of four byte counters (U8 tiles)
+    constexpr uint32_t STG = U8T ? 640u : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
+    constexpr int STG_IT = (int)((STG + 255u) / 256u);
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[U8T ? NF_CNT8_DW : NF_CNT_DW]; // per position: one dword of four byte counters / A | C << 16, G | T << 16
     __shared__ uint32_t lut[16];        // what a base code adds to its word: 1 4 = A G: 1; 2 8 = C T: 1 << 16; everything else 0 (nucfreq.rs:83-90)
     __shared__ uint32_t lut8[16];       // U8 tiles: 1 2 4 8 = A C G T: 1 << 0, 8, 16, 24
-    __shared__ int32_t diff[NF_TILE + 8];        // +1 where a read starts covering, -1 where it stops; then the depth
+    // +1 where a read starts covering, -1 where it stops; then the depth.  U8T: two positions a dword -- the halves are added as
+    // whole 32-bit integers (a borrow of the low half travels into the high one and is taken back when the word is read)
+    __shared__ int32_t diff[U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8];
+    __shared__ uint8_t covb[U8T ? NF_THREADS : 4]; // U8T: which of a thread's 8 positions are covered
     __shared__ int32_t wsum[NF_WAVES];
     __shared__ uint32_t blk_max, blk_cov;
-    __shared__ __attribute__((aligned(16))) uint32_t stage_all[NF_WAVES][NF_STAGE_DW + 8]; // per wave: the bases one read lays over the tile (4 zero dwords in front)
+    __shared__ __attribute__((aligned(16))) uint32_t stage_all[NF_WAVES][STG + 8]; // per wave: the bases one read lays over the tile (4 zero dwords in front)
     const uint64_t t = blockIdx.x;
     if (t >= p.tile_off[p.n_regions]) return;
+    if (nf_u8_tile(p, p.tile_lo[t], p.tile_hi[t]) != U8T) return; // the other build's
     const nf_tile T = nf_tile_of(p, t);
     const nf_drop drop = nf_drop_of(p, T);
     const uint32_t n_pos = (uint32_t)(T.en - T.st);
-    for (uint32_t k = threadIdx.x; k < NF_CNT_DW; k += NF_THREADS) cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < (U8T ? NF_CNT8_DW : NF_CNT_DW); k += NF_THREADS) cnt[k] = 0;
     if ((threadIdx.x & 63u) < 4u) stage_all[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
-    for (uint32_t k = threadIdx.x; k < NF_TILE + 8; k += NF_THREADS) diff[k] = 0;
+    for (uint32_t k = threadIdx.x; k < (U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8); k += NF_THREADS) diff[k] = 0;
+    auto diff_add = [&](uint32_t i, int32_t delta) {
+        if constexpr (U8T) atomicAdd(&diff[i >> 1], (int32_t)((uint32_t)delta << (16u * (i & 1u))));
+        else atomicAdd(&diff[i], delta);
+    };
     if (threadIdx.x < 16) {
         const uint32_t n = threadIdx.x;
         lut[n] = (n == 1 || n == 4) ? 1u : (n == 2 || n == 8) ? 0x10000u : 0u;
@@ -420,7 +436,6 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     // U8 tiles (at most 255 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
     // per 8 positions (lane l of an add is 10 l dwords on: all of a half-wave's 8-byte accesses on different banks), and one
     // ds_add_u64 covers two positions -- half the atomics of the 16-bit layout and no choice of word per base
-    const bool tile_u8 = nf_u8_tile(p, lo, hi);
     const uint32_t *__restrict__ sw32 = reinterpret_cast<const uint32_t *>(p.seq);
     uint32_t *stage = stage_all[wib] + 4;
     // one read, the whole wave on it (w_first: its first 64 ops, already in registers)
@@ -431,8 +446,8 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         if (nf_dropped(drop, i)) return;
         const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = rend < T.en ? rend : T.en;
         if (lane == 0) {
-            atomicAdd(&diff[(uint32_t)(c0 - T.st)], 1);
-            atomicAdd(&diff[(uint32_t)(c1 - T.st)], -1);
+            diff_add((uint32_t)(c0 - T.st), 1);
+            diff_add((uint32_t)(c1 - T.st), -1);
         }
         const uint64_t o0 = h.op_off, o1 = h.op_off + h.n_ops;
         const int64_t nib0 = (int64_t)h.nib0;
@@ -467,17 +482,17 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
                 wd_lo = (nib0 + q_lo - 7) >> 3;
                 wd_lo = wd_lo > 0 ? wd_lo : 0;
                 const int64_t n_dw = ((nib0 + q_hi + 7) >> 3) + 2 - wd_lo; // (+ the second dword of the last group)
-                staged = n_dw <= NF_STAGE_DW && q_hi > q_lo;
+                staged = n_dw <= (int64_t)STG && q_hi > q_lo;
                 if (staged) {
-                    uint4 v[NF_STAGE_DW / 256];
+                    uint4 v[STG_IT];
 #pragma unroll
-                    for (int r = 0; r < NF_STAGE_DW / 256; r++) {
+                    for (int r = 0; r < STG_IT; r++) {
                         int64_t idx = 4 * lane + 256 * r;
                         idx = idx < n_dw ? idx : (n_dw - 1 > 0 ? (n_dw - 1) & ~3ll : 0); // (past the stretch: re-read its last piece)
                         v[r] = rb_load4_unaligned(sw32 + wd_lo + idx);
                     }
 #pragma unroll
-                    for (int r = 0; r < NF_STAGE_DW / 256; r++)
+                    for (int r = 0; r < STG_IT; r++)
                         if (4 * lane + 256 * r < n_dw) // (kept in base order: BAM packs the first base of a byte into its high half)
                             *reinterpret_cast<uint4 *>(stage + 4 * lane + 256 * r) =
                                 make_uint4(nf_swap_nibbles(v[r].x), nf_swap_nibbles(v[r].y), nf_swap_nibbles(v[r].z), nf_swap_nibbles(v[r].w));
@@ -538,7 +553,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         }
         if (__ballot(seq_short) != 0 && lane == 0) p.read_status[i] = RB_RD_SEQ_SHORT;
     };
-    if (hi - lo > 8u * 64u) {
+    if (!U8T && hi - lo > 8u * 64u) {
         // ---- a tile crowded with reads (short reads): 64 reads per wave and turn, one lane per read with at most NF_LANE_OPS ops
         //      -- it walks its ops and drops its bases one by one; the wave scans would idle on 150-base reads -- and the few
         //      reads with longer cigars one after the other with the whole wave ----
@@ -553,8 +568,8 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
             if (simple) {
                 const int64_t pos = h.pos;
                 const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = (uint64_t)h.end < T.en ? (uint64_t)h.end : T.en;
-                atomicAdd(&diff[(uint32_t)(c0 - T.st)], 1);
-                atomicAdd(&diff[(uint32_t)(c1 - T.st)], -1);
+                diff_add((uint32_t)(c0 - T.st), 1);
+                diff_add((uint32_t)(c1 - T.st), -1);
                 const int64_t rel_st = (int64_t)T.st - pos, rel_en = (int64_t)T.en - pos, idx0 = pos - (int64_t)T.st;
                 int64_t R = 0, Q = 0;
                 bool seq_short = false;
@@ -613,8 +628,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
             const nf_read h = h_cur;
             const uint32_t w_first = w_cur;
             h_cur = h_nxt, h_nxt = h_nn, w_cur = w_nxt;
-            if (tile_u8) read_by_wave(std::true_type{}, h, w_first, i);
-            else read_by_wave(std::false_type{}, h, w_first, i);
+            read_by_wave(std::integral_constant<bool, U8T>{}, h, w_first, i);
         }
     }
     __syncthreads();
@@ -624,7 +638,14 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         int32_t d[NF_PER_THREAD], s = 0;
 #pragma unroll
         for (int k = 0; k < NF_PER_THREAD; k++) {
-            s += diff[b0 + k];
+            int32_t dk;
+            if constexpr (U8T) { // (b0 is even: positions b0 + k and b0 + k + 1, k even, share a dword)
+                const int32_t v = diff[(b0 + (uint32_t)k) >> 1], lo16 = (int32_t)(int16_t)(uint16_t)((uint32_t)v & 0xFFFFu);
+                dk = (k & 1) ? ((v - lo16) >> 16) : lo16;
+            } else {
+                dk = diff[b0 + k];
+            }
+            s += dk;
             d[k] = s;
         }
         const int32_t inc = (int32_t)rb_wave_scan_incl((uint32_t)s);
@@ -633,16 +654,18 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         int32_t before = inc - s;
         for (uint32_t k = 0; k < wib; k++) before += wsum[k];
         int32_t mx = 0;
-        uint32_t cov = 0;
+        uint32_t cov = 0, cbits = 0;
 #pragma unroll
         for (int k = 0; k < NF_PER_THREAD; k++) {
             const int32_t dep = before + d[k];
-            diff[b0 + k] = dep;
+            if constexpr (U8T) cbits |= dep > 0 ? (1u << k) : 0u;
+            else diff[b0 + k] = dep;
             if (b0 + k < n_pos) {
                 mx = mx > dep ? mx : dep;
                 cov += dep > 0;
             }
         }
+        if constexpr (U8T) covb[threadIdx.x] = (uint8_t)cbits;
         atomicMax(&blk_max, (uint32_t)mx);
         atomicAdd(&blk_cov, cov);
     }
@@ -652,16 +675,18 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         atomicAdd((unsigned long long *)&p.counters->n_covered, (unsigned long long)blk_cov);
     }
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(p.counts + 4ull * T.out);
-    if (tile_u8) {
+    if constexpr (U8T) {
+        static_assert(NF_PER_THREAD == 8, "one byte of coverage flags per thread");
         for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
             const uint32_t v = cnt[10u * ((k + 8u) >> 3) + ((k + 8u) & 7u)];
-            out[k] = make_uint4((v & 255u) | (diff[k] > 0 ? RB_NF_COVERED : 0u), (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
+            const bool covered = (covb[k >> 3] >> (k & 7u)) & 1u;
+            out[k] = make_uint4((v & 255u) | (covered ? RB_NF_COVERED : 0u), (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
         }
-        return;
-    }
-    for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
-        const uint32_t ac = cnt[nf_slot(k)], gt = cnt[nf_slot(k) + 1];
-        out[k] = make_uint4((ac & 0xFFFFu) | (diff[k] > 0 ? RB_NF_COVERED : 0u), ac >> 16, gt & 0xFFFFu, gt >> 16);
+    } else {
+        for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
+            const uint32_t ac = cnt[nf_slot(k)], gt = cnt[nf_slot(k) + 1];
+            out[k] = make_uint4((ac & 0xFFFFu) | (diff[k] > 0 ? RB_NF_COVERED : 0u), ac >> 16, gt & 0xFFFFu, gt >> 16);
+        }
     }
 }
 
@@ -687,6 +712,7 @@ extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stre
     if (p.n_reads > RB_NF_DEPTH_CAP) hipLaunchKernelGGL(rb_k_nf_crowded, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_deep_regions, dim3((unsigned)((p.n_regions + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_admit, dim3(512), dim3(64), 0, stream, p);
-    hipLaunchKernelGGL(rb_k_nf_tiles, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(rb_k_nf_tiles<true>, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(rb_k_nf_tiles<false>, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
     return hipGetLastError();
 }
