@@ -1146,7 +1146,10 @@ __device__ __forceinline__ uint64_t rb_wave_max_u64(uint64_t v) {
     }
     return v;
 }
-__global__ __launch_bounds__(256) void rb_k_liftover_generic_wave(rb_lift_params p) {
+#ifndef RB_GW_WPE
+#define RB_GW_WPE 8 // (the kernel waits on its three dependent passes over the record: 8 waves per SIMD at 64 VGPRs beat 5 at 83 by 9 %)
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))) void rb_k_liftover_generic_wave(rb_lift_params p) {
     __shared__ uint32_t run_tot_all[4][64], run_opc_all[4][64];
     const uint32_t wib = threadIdx.x >> 6;
     uint32_t *run_tot = run_tot_all[wib], *run_opc = run_opc_all[wib];
