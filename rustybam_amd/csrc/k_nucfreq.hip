@@ -398,7 +398,7 @@ __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { return ((v & 0
 #define NF_CNT8_DW (10 * ((NF_TILE + 16) / 8))
 template <bool U8T>
 __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
-    constexpr uint32_t STG = U8T ? 640u : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
+    constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + 128) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
     constexpr int STG_IT = (int)((STG + 255u) / 256u);
     __shared__ __attribute__((aligned(16))) uint32_t cnt[U8T ? NF_CNT8_DW : NF_CNT_DW]; // per position: one dword of four byte counters / A | C << 16, G | T << 16
     __shared__ uint32_t lut[16];        // what a base code adds to its word: 1 4 = A G: 1; 2 8 = C T: 1 << 16; everything else 0 (nucfreq.rs:83-90)
@@ -676,10 +676,10 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     }
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(p.counts + 4ull * T.out);
     if constexpr (U8T) {
-        static_assert(NF_PER_THREAD == 8, "one byte of coverage flags per thread");
+        static_assert(NF_PER_THREAD <= 8, "one byte of coverage flags per thread");
         for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
             const uint32_t v = cnt[10u * ((k + 8u) >> 3) + ((k + 8u) & 7u)];
-            const bool covered = (covb[k >> 3] >> (k & 7u)) & 1u;
+            const bool covered = (covb[k / NF_PER_THREAD] >> (k % NF_PER_THREAD)) & 1u;
             out[k] = make_uint4((v & 255u) | (covered ? RB_NF_COVERED : 0u), (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
         }
     } else {
