@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: skip kernel phases (invalid results)")
     ap.add_argument("--op", default="liftover", choices=["liftover", "break"],
                     help="liftover (headline) or break-paf --max-size 100 on the same records (secondary measurement)")
+    ap.add_argument("--two-walk", action="store_true", help="--op break: collect the pieces in a pass of its own, then clip (the round-1 path)")
     ap.add_argument("--descriptors", action="store_true",
                     help="RB_LIFT_DESCRIPTORS: return which ops each clip keeps instead of copying them (not the headline mode)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -247,9 +248,13 @@ def main():
     # for break-paf) + arena room; the clipped cigars land there while their record streams past
     rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, eng.plan_out_capacity(plan, args.op == "break"))
 
+    # break-paf: the clip kernel finds the long indels itself (one walk of the ops); a batch it does not take says so in the
+    # counters and is done with the collect pass in front (two walks) -- decided once, by the sizing call below
+    brk_policy = [policy | (rustybam_amd.BREAK_ONE_WALK if (args.op == "break" and not args.descriptors and not args.two_walk) else 0)]
+
     def run_op(ws, rows, out):
         if args.op == "break":
-            eng.dev_break(plan, view, d_norm.data_ptr(), 100, policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(),
+            eng.dev_break(plan, view, d_norm.data_ptr(), 100, brk_policy[0], ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(),
                           out_cap, d_cnt.data_ptr())
         else:
             eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(),
@@ -265,6 +270,10 @@ def main():
         run_op(d_ws, d_rows, d_out)
         torch.cuda.synchronize()
         cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
+        if cnt["redo_two_walk"] and (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK):
+            brk_policy[0] &= ~rustybam_amd.BREAK_ONE_WALK
+            del d_ws, d_rows, d_out
+            continue
         if not cnt["overflow"]:
             break
         rows_cap = max(rows_cap, int(cnt["n_hits"]) + 64)
@@ -391,7 +400,8 @@ def main():
                                f"{total_ops} ops on rank 0) x {len(w_st)} windows, seed {seed:#x}",
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
-                   "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops"},
+                   "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
+                   **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {})},
         "paf_records_per_s": job_recs * args.steps / elapsed,
         "output_digest": f"{digest:#018x}", "job_records": int(job_recs), "job_hits": job_hits,
         "hits_per_gpu": n_hits, "ok_hits_per_gpu": n_ok, "out_ops_per_gpu": n_out_ops,

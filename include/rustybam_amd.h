@@ -94,7 +94,12 @@ enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY
         * looks at the ends of every record (remove_trailing_indels), verifies integrity and regularity while the clip kernel
         * streams the record, and runs the full record scan only for records that fail that check.  Rows of a record whose
         * norm row ends up with status != RB_ST_OK carry that status. */
-       RB_LIFT_FUSED_SCAN = 64 };
+       RB_LIFT_FUSED_SCAN = 64,
+       /* RB_BREAK_ONE_WALK (rb_dev_break): the clip kernel finds the long indels itself while it streams a record (no separate pass
+        * that collects the pieces first: the ops are read once).  The caller must look at counters->redo_two_walk afterwards: set,
+        * the batch holds something this path does not take (an irregular record, more than 32 pieces in one record, a boundary the
+        * fast path cannot resolve), the results are incomplete and the call is to be repeated without this flag (rb_host_break does). */
+       RB_BREAK_ONE_WALK = 128 };
 
 /* rb_norm_row.flags / rb_reduce_row.flags */
 enum {
@@ -157,7 +162,9 @@ typedef struct rb_counters { /* device-written job summary, 64 bytes */
     uint64_t out_ops_used;       /* highest op index written + 1                                  */
     uint64_t n_generic;          /* hits routed to the generic kernel                             */
     uint32_t overflow;           /* != 0: rows or out_ops capacity exceeded, results incomplete   */
-    uint32_t _pad[7];
+    uint32_t _pad[6];
+    uint32_t redo_two_walk;      /* RB_BREAK_ONE_WALK only: != 0: the batch holds what the one-walk path does not take (irregular
+                                    records, more than 32 pieces in a record): results incomplete, call again without the flag */
 } rb_counters;
 
 /* per-record outcome of rb_dev_parse_cigars */

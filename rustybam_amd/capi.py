@@ -10,6 +10,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "rustybam_amd.h")
 
 BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, LIFT_DESCRIPTORS, LIFT_FUSED_SCAN = 0, 1, 16, 32, 64
+BREAK_ONE_WALK = 128  # rb_dev_break: the clip kernel finds the long indels itself; look at counters redo_two_walk afterwards
 HIT_INSIDE, HIT_GENERIC, HIT_DESCRIPTOR = 1, 2, 4
 NF_COVERED = 0x80000000
 RD_OK, RD_FILTERED, RD_BAD_CIGAR, RD_SEQ_SHORT = 0, 1, 2, 3
@@ -32,7 +33,7 @@ PAIR_DT = np.dtype(
      ("out_n", "<u4", 2), ("_pad", "<u8")])
 COUNTERS_DT = np.dtype(
     [("n_hits", "<u8"), ("out_ops_needed", "<u8"), ("out_ops_used", "<u8"), ("n_generic", "<u8"),
-     ("overflow", "<u4"), ("_pad", "<u4", 7)])
+     ("overflow", "<u4"), ("_pad", "<u4", 6), ("redo_two_walk", "<u4")])
 assert REDUCE_DT.itemsize == 72 and NORM_DT.itemsize == 64 and HIT_DT.itemsize == 64 and COUNTERS_DT.itemsize == 64
 assert PAIR_DT.itemsize == 128
 

@@ -105,6 +105,7 @@ extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t
 extern "C" hipError_t rb_launch_make_jobs(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_break_gather(const rb_lift_params *p, hipStream_t stream);
 extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec);
 extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_break_place(const rb_break_params *p, hipStream_t stream);
@@ -523,7 +524,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, copy_count, copy_list, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, total;
 };
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     ws_layout w;
@@ -546,6 +547,7 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     w.bp_tmp = take((rows_cap + 1) * 8); // break-paf: piece windows between the collect pass and their rows
     w.bp_off = take((n_rec + 1) * 8);
     w.bp_cur = take((size_t)RB_MAX_ARENA * 128);
+    w.brk_rows = take((rows_cap + 1) * sizeof(rb_hit_row)); // break-paf in one walk: the rows before they are in record order
     w.copy_count = take(256);
     w.copy_list = take((rows_cap + 1) * 16);
     w.total = o;
@@ -654,6 +656,39 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     HIPCHK(ctx, hipMemsetAsync(p.copy_count, 0, 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(p.arena_cur, 0, (size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8, ctx->stream));
     if (b->n_rec == 0) return RB_OK;
+    const bool one_walk = is_break && (policy & RB_BREAK_ONE_WALK) && !p.desc_mode;
+    if (one_walk) {
+        // the clip kernel finds the long indels while it streams (k_liftover.hip, BRK): no pass over the ops before it.  Rows land
+        // in scratch (one bump cursor of 256 per record), the piece counts are scanned, rb_k_break_gather orders the rows
+        p.brk_mode = 1, p.brk_max = max_size;
+        p.rows_final = rows;
+        p.rows = (rb_hit_row *)(ws + w.brk_rows);
+        p.brk_off = (uint64_t *)(ws + w.bp_off);
+        p.brk_cursor = (unsigned long long *)(ws + w.bp_cur);
+        p.brk_n_arena = pick_arenas(b->n_rec);
+        p.brk_arena_cap = rows_cap / p.brk_n_arena;
+        HIPCHK(ctx, hipMemsetAsync(p.brk_cursor, 0, (size_t)RB_MAX_ARENA * 128, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(p.hit_off, 0, (size_t)(b->n_rec + 2) * 8, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(p.brk_off, 0xFF, (size_t)(b->n_rec + 1) * 8, ctx->stream));
+        HIPCHK(ctx, rb_launch_make_jobs(&p, ctx->stream));
+        const size_t slot1 = (size_t)(ctx->timed_calls % RB_TIMING_RING);
+        if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_a[slot1], ctx->stream));
+        p.wave0 = 0;
+        p.wave_end = (uint32_t)b->n_rec;
+        HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
+        if (p.fused) {
+            sp.list = p.pend_list;
+            sp.n_list = (const uint64_t *)p.pend_count;
+            HIPCHK(ctx, rb_launch_scan_records(&sp, ctx->stream));
+        }
+        if (ctx->timing) {
+            HIPCHK(ctx, hipEventRecord(ctx->ev_b[slot1], ctx->stream));
+            ctx->timed_calls++;
+        }
+        HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, false, ctx->stream));
+        HIPCHK(ctx, rb_launch_break_gather(&p, ctx->stream));
+        return RB_OK;
+    }
     if (is_break) {
         rb_break_params bp;
         bp.n_rec = b->n_rec;
@@ -998,6 +1033,7 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     void *ws = nullptr;
     rb_hit_row *d_rows = nullptr;
     uint32_t *d_out = nullptr;
+    bool one_walk = is_break && !(policy & RB_LIFT_DESCRIPTORS) && !getenv("RB_BREAK_TWO_WALK"); // (the env: diagnostics)
     for (int attempt = 0; attempt < 6; attempt++) {
         if (ws) hipFree(ws);
         if (d_rows) hipFree(d_rows);
@@ -1009,11 +1045,18 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         if (!rc) rc = rb_dev_alloc(ctx, (rows_cap + 1) * sizeof(rb_hit_row), (void **)&d_rows);
         if (!rc) rc = rb_dev_alloc(ctx, (out_cap + 4) * 4, (void **)&d_out);
         if (rc) break;
-        rc = is_break ? rb_dev_break(ctx, plan, &b.v, d_norm, max_size, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt)
+        rc = is_break ? rb_dev_break(ctx, plan, &b.v, d_norm, max_size, policy | (one_walk ? RB_BREAK_ONE_WALK : 0), ws, d_rows, rows_cap, d_out,
+                                     out_cap, d_cnt)
                       : rb_dev_liftover(ctx, plan, &b.v, d_norm, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt);
         if (rc) break;
         rc = rb_dev_download(ctx, &hc, d_cnt, sizeof hc);
         if (rc) break;
+        if (one_walk && hc.redo_two_walk) { // something the one-walk path does not take: the same buffers, the two-walk path
+            one_walk = false;
+            attempt--;
+            rc = RB_E_CAPACITY;
+            continue;
+        }
         if (!hc.overflow) break;
         rows_cap = std::max<uint64_t>(rows_cap, hc.n_hits + 16);
         out_cap = std::max<uint64_t>(out_cap * 2, hc.out_ops_needed + hc.out_ops_needed / 4 + 4096 + 4 * rows_cap);
@@ -1255,6 +1298,7 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
     void *ws = nullptr;
     rb_hit_row *d_rows = nullptr;
     uint32_t *d_out = nullptr;
+    bool one_walk = is_break && !(policy & RB_LIFT_DESCRIPTORS) && !getenv("RB_BREAK_TWO_WALK"); // (the env: diagnostics)
     for (int attempt = 0; attempt < 6; attempt++) {
         if (ws) hipFree(ws);
         if (d_rows) hipFree(d_rows);
@@ -1264,11 +1308,18 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
         if (!rc) rc = rb_dev_alloc(ctx, (rows_cap + 1) * sizeof(rb_hit_row), (void **)&d_rows);
         if (!rc) rc = rb_dev_alloc(ctx, (out_cap + 4) * 4, (void **)&d_out);
         if (rc) break;
-        rc = is_break ? rb_dev_break(ctx, plan, &b.v, d_norm, max_size, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt)
+        rc = is_break ? rb_dev_break(ctx, plan, &b.v, d_norm, max_size, policy | (one_walk ? RB_BREAK_ONE_WALK : 0), ws, d_rows, rows_cap, d_out,
+                                     out_cap, d_cnt)
                       : rb_dev_liftover(ctx, plan, &b.v, d_norm, policy, ws, d_rows, rows_cap, d_out, out_cap, d_cnt);
         if (rc) break;
         rc = rb_dev_download(ctx, &hc, d_cnt, sizeof hc);
         if (rc) break;
+        if (one_walk && hc.redo_two_walk) { // something the one-walk path does not take: the same buffers, the two-walk path
+            one_walk = false;
+            attempt--;
+            rc = RB_E_CAPACITY;
+            continue;
+        }
         if (!hc.overflow) break;
         rows_cap = std::max<uint64_t>(rows_cap, hc.n_hits + 16);
         out_cap = std::max<uint64_t>(out_cap * 2, hc.out_ops_needed + hc.out_ops_needed / 4 + 4096 + 4 * rows_cap);

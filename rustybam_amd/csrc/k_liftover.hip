@@ -158,8 +158,9 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
     j.rec0 = p.op_off[r] + nr->first_op;
     j.t_st = nr->t_st, j.t_en = nr->t_en, j.q_st = nr->q_st, j.q_en = nr->q_en;
     const uint64_t k = p.canon_pos[r];
-    const uint64_t h0 = p.hit_off[k], nh = p.hit_off[k + 1] - h0;
-    const bool explicit_w = p.x_st != nullptr;
+    const bool brk = p.brk_mode != 0; // one-walk break-paf: the pieces are not known yet (one pass per record, rows placed afterwards)
+    const uint64_t h0 = brk ? 0ull : p.hit_off[k], nh = brk ? 1ull : p.hit_off[k + 1] - h0;
+    const bool explicit_w = brk || p.x_st != nullptr;
     const uint32_t cg = p.contig[r];
     const bool mono = explicit_w || (cg < p.n_contig && p.cw_mono[cg] != 0);
     uint32_t f = 0;
@@ -221,6 +222,9 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 // registers OFF .. OFF + W of the ring, as the assembler reads them (it evaluates the sums)
 #define RB_RREG(OFF, W) "v[" RB_STR(RB_RING_BASE) "+" #OFF ":" RB_STR(RB_RING_BASE) "+" #OFF "+" #W "]"
 static_assert(RB_PF == 2, "the ring's asm statements are written out for two slots");
+// BRK: break-paf in one walk (rb_lift.h, brk_max): the windows of a record are not given, they are the stretches between the indels
+// longer than brk_max, found while the record streams; one pass of at most 32 pieces.  The liftover build has none of that code.
+template <bool BRK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), amdgpu_num_vgpr(RB_RING_BASE))) void rb_k_liftover_stream(rb_lift_params p) {
     // checkpoints: exclusive (R,Q,U) prefixes every 16 ops, SoA so that R can be binary-searched
     __shared__ uint32_t cp_all[4][3][RB_SMAX * RB_CP_PER_STEP];
@@ -242,8 +246,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
     const rb_norm_row *nr = &p.norm[r];
     const uint64_t h0 = rb_first(jb_.h0);
     const uint64_t nh = rb_first(jb_.nh);
-    const bool explicit_w = p.x_st != nullptr;
-    const bool mono = (jflags & RB_JOB_MONO) != 0;
+    const bool explicit_w = BRK || p.x_st != nullptr;
+    const bool mono = BRK || (jflags & RB_JOB_MONO) != 0;
     uint64_t ws = 0, we = 0;
     if (!explicit_w && (!mono || !(jflags & RB_JOB_REGULAR))) { // the contig's window slice: only the rare paths need it
         const uint32_t cg = p.contig[r];
@@ -251,6 +255,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         we = p.cw_off[cg + 1];
     }
     if (!(jflags & RB_JOB_REGULAR)) { // window order does not matter on the fast path: resolution is per lane
+        if constexpr (BRK) { // (its pieces would have to be known before the generic kernel can clip them: the two-walk path's business)
+            if (lane == 0) p.counters->redo_two_walk = 1;
+            return;
+        }
         if (p.fused && lane == 0) { // (a provisional row that cannot take the fast path: the full scan completes it)
             const unsigned long long i = atomicAdd(p.pend_count, 1ull);
             p.pend_list[i] = r;
@@ -301,27 +309,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
     const bool fused = p.fused != 0;
     uint32_t rec_nmatch = 0, rec_aln_len = 0; // of the whole (normalised) record: taken from its row, or from the fused verification
     if (!fused) rec_nmatch = nr->nmatch, rec_aln_len = nr->aln_len;
-    const uint64_t n_items = (nh == 0 && fused) ? 1 : nh; // (a record no window overlaps is still streamed once, to verify it)
+    const uint64_t n_items = BRK ? 1 : ((nh == 0 && fused) ? 1 : nh); // (a record no window overlaps is still streamed once, to verify it)
     // where a later pass may start streaming: the segment in which the previous pass resolved the start of its last window
     // (windows are sorted, so nothing of the next pass lies before it), with the running totals at that point
     uint32_t resume_seg = 0, resume_R = 0, resume_Q = 0, resume_U = 0;
     for (uint64_t jb = 0; jb < n_items; jb += RB_HMAX) {
-        const uint32_t nb = (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX);
+        uint32_t nb = BRK ? 1u : (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX); // (BRK: pieces known so far, the open one included)
         const bool validate = fused && jb == 0;
         // ---- per-hit setup: lanes j and j + 32 both look at window jb + j; lane j resolves its start
         //      boundary, lane j + 32 its end boundary; lane j then owns the row ----
         const uint32_t hl = (uint32_t)lane & 31u;
-        const bool own = hl < nb;
-        const bool mine = own && lane < 32;
+        bool own = hl < nb;
+        bool mine = own && lane < 32;
         const bool is_start = lane < 32;
-        const rb_pass_win pw = rb_pass_windows(p, &wx_all[wib][0], explicit_w, mono, ws, we, lo, h0, jb, nb, t_st, t_en, scan_pos, lane);
-        const uint64_t wst = pw.wst, wen = pw.wen;
-        const uint32_t win = pw.win;
-        const bool inside = own && (t_st > wst && t_en < wen); // liftover.rs:23-25
+        uint64_t wst = 0, wen = 0;
+        uint32_t win = hl;
+        if constexpr (!BRK) {
+            const rb_pass_win pw = rb_pass_windows(p, &wx_all[wib][0], explicit_w, mono, ws, we, lo, h0, jb, nb, t_st, t_en, scan_pos, lane);
+            wst = pw.wst, wen = pw.wen, win = pw.win;
+        }
+        const bool inside = !BRK && own && (t_st > wst && t_en < wen); // liftover.rs:23-25 (a piece never contains its record)
         // D = (relative ref offset of the boundary base) + 1
-        const uint32_t D = is_start ? (uint32_t)((wst > t_st ? wst : t_st) - t_st) + 1u // liftover.rs:28
-                                    : (uint32_t)((wen < t_en ? wen : t_en) - t_st);     // (min(en,t_en) - 1 - t_st) + 1, :38-40
+        uint32_t D = is_start ? (uint32_t)((wst > t_st ? wst : t_st) - t_st) + 1u // liftover.rs:28
+                              : (uint32_t)((wen < t_en ? wen : t_en) - t_st);     // (min(en,t_en) - 1 - t_st) + 1, :38-40
         bool need = own && !inside;
+        // BRK: piece j is the stretch from the end of a long indel (liftover.rs:203-206: pre_tpos) to the start of the next one
+        // (cur_tpos, :190-201), kept if it holds reference bases; lane j carries its start, lane j + 32 its end, both as D above.
+        // Piece brk_cnt is OPEN: its start is known (brk_pre), its end not yet (D = ~0 keeps it in every test below).
+        uint32_t brk_cnt = 0, brk_pre = 0;
+        unsigned long long brk_def = 0ull; // lanes whose D is final
+        if constexpr (BRK) {
+            D = lane == 0 ? 1u : 0xFFFFFFFFu;
+            brk_def = 1ull;
+            need = false;
+        }
         rb_bres O;
         O.st = RB_S_UNRES;
         O.op = O.part = O.R = O.Q = O.U = 0;
@@ -345,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         uint32_t v_reg = 0xFFFFFFFFu, v_minw = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_maxsu = 0u;
         uint32_t v_carry = 0xFu;       // last op word of the previous step (code 15: equals nothing)
         unsigned long long v_utot = 0; // 64-bit sum of all lengths
-        const bool streams = (__ballot(need) != 0 || validate || (spec && any_inside)) && !(p.debug_skip & 4);
+        const bool streams = BRK || ((__ballot(need) != 0 || validate || (spec && any_inside)) && !(p.debug_skip & 4));
         if (streams) {
             // The load ring and the speculative stores are written by hand.  vmcnt retires in issue order on gfx9 and counts
             // loads and stores together; left to the compiler, the wait for a step's loads would also wait for the stores of
@@ -472,6 +493,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                         v_maxsu = v_maxsu > su ? v_maxsu : su;
                         v_utot += rb_readlane<uint32_t>(iu, 63);
                     }
+                    if constexpr (BRK) {
+                        // long indels among my 8 ops (ops of the neighbouring records are zero words here: an M of length 0).  They are
+                        // rare -- one step in six has one -- and are taken one by one, in op order, with wave-uniform arithmetic
+                        bool lane_big = false;
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const uint32_t cq = w[q] & 15u;
+                            lane_big |= (cq == RB_OP_I || cq == RB_OP_D) && rb_len(w[q]) > p.brk_max;
+                        }
+                        unsigned long long cm = __ballot(lane_big);
+                        const uint32_t lane_r0 = R0 + ir - sr; // reference offset of my first op
+                        while (cm) {
+                            const int l = __builtin_ctzll(cm);
+                            cm &= cm - 1ull;
+                            uint32_t rx = rb_readlane<uint32_t>(lane_r0, l);
+#pragma unroll
+                            for (int q = 0; q < 8; q++) {
+                                const uint32_t wq = rb_readlane<uint32_t>(w[q], l);
+                                const uint32_t cq = wq & 15u, lq = rb_len(wq);
+                                const uint32_t rlq = cq == RB_OP_I ? 0u : lq; // (regular records: M I D N = X)
+                                if ((cq == RB_OP_I || cq == RB_OP_D) && lq > p.brk_max) {
+                                    if (rx > brk_pre) { // liftover.rs:191: the piece in front of the indel, if it holds reference bases
+                                        if (brk_cnt < 32u) {
+                                            D = (uint32_t)lane == 32u + brk_cnt ? rx : D;
+                                            brk_def |= 1ull << (32u + brk_cnt);
+                                        }
+                                        brk_cnt++;
+                                    }
+                                    brk_pre = rx + rlq; // :203-206
+                                    if (brk_cnt < 32u) { // the next piece opens here (its lanes are rewritten if it turns out empty)
+                                        D = (uint32_t)lane == brk_cnt ? brk_pre + 1u : ((uint32_t)lane == 32u + brk_cnt ? 0xFFFFFFFFu : D);
+                                        brk_def |= 1ull << brk_cnt;
+                                        brk_def &= ~(1ull << (32u + brk_cnt));
+                                    }
+                                }
+                                rx += rlq;
+                            }
+                        }
+                        nb = brk_cnt + 1u < 32u ? brk_cnt + 1u : 32u;
+                    }
                     if (spec) {
                         // Which of this lane's 8 ops a clip keeps is not known yet (boundaries are resolved per segment),
                         // but which 8-op chunks can hold ops of clip j is: those whose reference span [cR, cE) reaches
@@ -561,6 +622,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 const bool last_seg = seg1 == n_steps;
                 const uint32_t n_cp = (seg1 - seg0) * RB_CP_PER_STEP;
                 const int32_t cp_idx0 = (int32_t)(seg0 << RB_STEP_SHIFT) - head; // op index of checkpoint 0
+                if constexpr (BRK) {
+                    if (last_seg) { // liftover.rs:213-224: what lies behind the last long indel
+                        if (Rb > brk_pre) {
+                            if (brk_cnt < 32u) {
+                                D = (uint32_t)lane == 32u + brk_cnt ? Rb : D;
+                                brk_def |= 1ull << (32u + brk_cnt);
+                            }
+                            brk_cnt++;
+                        } else if (brk_cnt < 32u) {
+                            brk_def &= ~(1ull << brk_cnt); // the record ends with a long indel: no piece was open after all
+                        }
+                    }
+                    need = ((brk_def >> lane) & 1ull) != 0ull && O.st == RB_S_UNRES;
+                }
                 {
                     const bool todo = need && D >= Rseg && (D < Rb || (last_seg && D == Rb));
                     if (todo && !(p.debug_skip & 2)) {
@@ -585,9 +660,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                     //  The resolving lanes have waited for those loads -- the youngest in the queue -- anyway.)
                     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
                     // the start of the pass's last window was found in this segment: the next pass begins here
-                    if (nb && ((__ballot(todo) >> (nb - 1u)) & 1ull)) next_seg = seg0 / RB_SMAX, next_R = Rseg, next_Q = Qseg, next_U = Useg;
+                    if (!BRK && nb && ((__ballot(todo) >> (nb - 1u)) & 1ull)) next_seg = seg0 / RB_SMAX, next_R = Rseg, next_Q = Qseg, next_U = Useg;
                 }
-                if ((p.early_exit || resumable) && !validate && !(spec && any_inside) && __ballot(need) == 0) break;
+                if (!BRK && (p.early_exit || resumable) && !validate && !(spec && any_inside) && __ballot(need) == 0) break;
             }
             // nothing of the ring may still be in flight when its registers go back to the compiler (a pass that leaves early
             // has loads out), and the end groups below must land after the speculative stores to the same addresses
@@ -607,11 +682,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
             const bool bad = __ballot(lane_bad) != 0 || rb_first64(v_utot) > 0xFFFFFFFFull || t_en < t_st || q_en < q_st ||
                              (uint64_t)Rb != t_en - t_st || (uint64_t)Qb != q_en - q_st;
             if (bad) {
+                if constexpr (BRK) {
+                    if (lane == 0) p.counters->redo_two_walk = 1;
+                }
                 if (lane == 0) {
                     const unsigned long long i = atomicAdd(p.pend_count, 1ull);
                     p.pend_list[i] = r;
                 }
-                if (nh) {
+                if (!BRK && nh) {
                     if (!explicit_w) {
                         const uint32_t cg = p.contig[r];
                         ws = p.cw_off[cg];
@@ -629,7 +707,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 w->aln_len = rec_aln_len;
                 w->flags = (nr->flags & RB_F_STRIPPED) | RB_F_REGULAR;
             }
-            if (nh == 0) return;
+            if (!BRK && nh == 0) return;
+        }
+        uint64_t brk_row0 = 0; // BRK: the record's first (scratch) row
+        if constexpr (BRK) {
+            if (brk_cnt > 32u) { // more pieces than one pass holds
+                if (lane == 0) p.counters->redo_two_walk = 1;
+                return;
+            }
+            nb = brk_cnt;
+            own = hl < nb, mine = own && lane < 32;
+            // rows: a place for the record's pieces from one of the bump cursors (one atomic per record; a single cursor would
+            // serialise the records at one L2 line), the count for the scan that orders the rows afterwards
+            unsigned long long b0 = 0;
+            const uint32_t ar = (uint32_t)(wave % p.brk_n_arena);
+            if (lane == 0 && nb) b0 = atomicAdd(&p.brk_cursor[(size_t)ar * 16u], (unsigned long long)nb);
+            b0 = rb_first64(b0);
+            if (b0 + nb > p.brk_arena_cap) { // (this cursor's share of the scratch rows is used up: rb_k_finish asks for more rows)
+                if (lane == 0) p.counters->_pad[5] = 1, p.hit_off[r] = nb, p.brk_off[r] = ~0ull;
+                return;
+            }
+            brk_row0 = (uint64_t)ar * p.brk_arena_cap + b0;
+            if (lane == 0) p.hit_off[r] = nb, p.brk_off[r] = brk_row0;
+            if (nb == 0) return;
         }
         // ---- finalize: lane j (< 32) computes the row of hit jb + j; the end comes from lane j + 32 ----
         const rb_bres A = O;
@@ -718,10 +818,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         //  the streaming loop and carries -- or spills -- them through it)
         uint32_t lane_late = (uint32_t)lane;
         asm volatile("" : "+v"(lane_late));
-        const uint64_t my_row = h0 + jb + lane_late;
+        const uint64_t my_row = (BRK ? brk_row0 : h0 + jb) + lane_late;
         if (mine) {
             rb_hit_row *row = &p.rows[my_row];
             if (defer) {
+                if constexpr (BRK) p.counters->redo_two_walk = 1; // (the generic kernel wants the piece's window in its row's place)
                 row->rec = r;
                 row->win = win;
                 row->flags = RB_HIT_GENERIC;
@@ -1388,8 +1489,29 @@ __global__ __launch_bounds__(64) void rb_k_finish(rb_lift_params p) {
     // what makes the job fit: the slots the window lists ask for, plus every arena as large as the fullest one got
     p.counters->out_ops_needed = p.needed_base + (mx + 3ull) / 4ull * 4ull * p.n_arena + 1024ull * p.n_arena;
     if (p.counters->n_hits > p.rows_cap) p.counters->overflow = 1;
+    if (p.brk_mode && p.counters->_pad[5]) { // one of the scratch-row cursors ran out before the rows did: ask for a quarter more
+        p.counters->overflow = 1;
+        const uint64_t have = p.counters->n_hits > p.rows_cap ? p.counters->n_hits : p.rows_cap;
+        p.counters->n_hits = have + have / 4u + 1024u;
+    }
 }
 
+// one-walk break-paf: the rows of a record leave their scratch place for rows_final[hit_off[r] ..] (hit_off scanned by now)
+__global__ __launch_bounds__(256) void rb_k_break_gather(rb_lift_params p) {
+    const uint64_t r = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (r >= p.n_rec) return;
+    const uint64_t h0 = p.hit_off[r], n = p.hit_off[r + 1] - h0, src = p.brk_off[r];
+    if (src == ~0ull) return;
+    for (uint64_t j = rb_lane(); j < n; j += 64)
+        if (h0 + j < p.rows_cap) p.rows_final[h0 + j] = p.rows[src + j];
+}
+extern "C" hipError_t rb_launch_break_gather(const rb_lift_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_copy_clips, dim3(2048), dim3(256), 0, stream, *p); // (clips without a slot: their rows are still where the list says)
+    hipLaunchKernelGGL(rb_k_break_gather, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
+    return hipGetLastError();
+}
 extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t *block_sums, uint64_t *total_out, hipStream_t stream);
 extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
@@ -1419,7 +1541,8 @@ extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStre
     const unsigned blocks = (unsigned)(((uint64_t)(p->wave_end - p->wave0) + 3) / 4);
     // diagnostics: RB_DEBUG_DYN_LDS=<bytes> adds unused dynamic LDS to lower the occupancy
     static const unsigned dyn = getenv("RB_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("RB_DEBUG_DYN_LDS")) : 0u;
-    hipLaunchKernelGGL(rb_k_liftover_stream, dim3(blocks), dim3(256), dyn, stream, *p);
+    if (p->brk_mode) hipLaunchKernelGGL(rb_k_liftover_stream<true>, dim3(blocks), dim3(256), dyn, stream, *p);
+    else hipLaunchKernelGGL(rb_k_liftover_stream<false>, dim3(blocks), dim3(256), dyn, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream) {

@@ -73,6 +73,9 @@ class DevBatch:
                                      self.d_cnt.data_ptr())
                 torch.cuda.synchronize()
                 cnt = self.d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0].copy()
+                if cnt["redo_two_walk"]:  # RB_BREAK_ONE_WALK declined the batch: the caller decides what to do about it
+                    self.last = (rows, out, ws)
+                    return rows[:0].view(torch.int32).view(0, 16), out, cnt
                 if not cnt["overflow"]:
                     n = int(cnt["n_hits"])
                     self.last = (rows, out, ws)  # keep the buffers alive for the caller

@@ -1,0 +1,87 @@
+"""rb_dev_break with RB_BREAK_ONE_WALK: the clip kernel finds the long indels itself while it streams a record.  Same rows and clipped
+CIGARs as the two-walk path and the oracle (liftover.rs:182-226); batches it does not take are declined, not mangled."""
+import numpy as np
+import pytest
+
+import rustybam_amd
+from devutil import DevBatch
+from rbtest_util import batch_args, digest_rows, random_batch, random_cigar, sums
+
+pytestmark = pytest.mark.gpu
+BASE = rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import torch
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    yield torch, eng, dev
+    eng.close()
+
+
+@pytest.mark.parametrize("max_size", [0, 2, 25, 100])
+@pytest.mark.parametrize("seed", [1, 2])
+def test_one_walk_equals_two_walks_and_the_oracle(ctx, oracle, max_size, seed):
+    torch, eng, dev = ctx
+    rng = np.random.default_rng(4000 + seed)
+    # seed 2: leading / trailing indel runs, some of which make the reference panic -- with the fused scan such a record keeps its
+    # rows (they carry the status) where the oracle has none, so that batch is compared between the two device paths only
+    mode = "regular" if seed == 1 else "indel_ends"
+    b = random_batch(rng, 400, mode, n_contig=1, long_frac=0.4)
+    D = DevBatch(torch, eng, dev, b)
+    rows2, out2, cnt2 = D.run(max_size=max_size, policy=BASE)
+    assert cnt2["redo_two_walk"] == 0
+    want = D.digest(rows2, out2)
+    n_rows = rows2.shape[0]
+    most = int(np.bincount(D.host_rows(rows2, out2)[0]["rec"].astype(np.int64)).max())
+    if mode == "regular":
+        orows, oops = oracle.break_paf(oracle.Batch(*batch_args(b), b["contig"]), max_size)
+        assert n_rows == len(orows) and want == digest_rows(orows, oops)
+    rows1, out1, cnt1 = D.run(max_size=max_size, policy=BASE | rustybam_amd.BREAK_ONE_WALK)
+    if cnt1["redo_two_walk"]:  # declined: some record has more pieces than one pass holds, or a boundary only the generic kernel resolves
+        assert most > 32 or cnt2["n_generic"] > 0, (max_size, most)
+    else:
+        assert most <= 32 and rows1.shape[0] == n_rows and D.digest(rows1, out1) == want
+
+
+def test_short_records_take_the_one_walk_path(ctx, oracle):
+    """records of at most 30 ops cannot have more than 32 pieces: the one-walk path must take the batch, for every --max-size"""
+    torch, eng, dev = ctx
+    rng = np.random.default_rng(4100)
+    b = random_batch(rng, 3000, "regular", n_contig=1, max_ops=30, long_frac=0.0)
+    D = DevBatch(torch, eng, dev, b)
+    for max_size in (0, 1, 7, 1000):
+        orows, oops = oracle.break_paf(oracle.Batch(*batch_args(b), b["contig"]), max_size)
+        rows, out, cnt = D.run(max_size=max_size, policy=BASE | rustybam_amd.BREAK_ONE_WALK)
+        assert cnt["redo_two_walk"] == 0 and cnt["n_generic"] == 0
+        assert rows.shape[0] == len(orows) and D.digest(rows, out) == digest_rows(orows, oops)
+        r = D.host_rows(rows, out)[0]
+        assert (np.diff(r["rec"].astype(np.int64)) >= 0).all()          # record order, then piece order
+        same = np.flatnonzero(np.diff(r["rec"].astype(np.int64)) == 0)
+        assert (r["win"][same + 1] == r["win"][same] + 1).all()
+
+
+def test_declines_irregular_records_and_too_many_pieces(ctx):
+    torch, eng, dev = ctx
+    rng = np.random.default_rng(4200)
+    b = random_batch(rng, 200, "mixed", n_contig=1, long_frac=0.2)      # N / S / H / P ops, zero lengths, adjacent ops of one type
+    D = DevBatch(torch, eng, dev, b)
+    _, _, cnt = D.run(max_size=10, policy=BASE | rustybam_amd.BREAK_ONE_WALK)
+    assert cnt["redo_two_walk"] == 1
+    # 40 long deletions in one regular record: more pieces than one pass of the kernel holds
+    M, D_ = 0, 2
+    cig = []
+    for k in range(40):
+        cig += [(50 << 4) | M, (500 << 4) | D_]
+    cig.append((50 << 4) | M)
+    cig = np.array(cig, np.uint32)
+    R, Q = sums(cig)
+    one = dict(ops=cig, op_off=np.array([0, len(cig)], np.uint64), t_st=np.array([100], np.uint64), t_en=np.array([100 + R], np.uint64),
+               q_st=np.array([7], np.uint64), q_en=np.array([7 + Q], np.uint64), strand=np.array([ord("+")], np.uint8), contig=np.zeros(1, np.uint32))
+    D1 = DevBatch(torch, eng, dev, one)
+    _, _, cnt = D1.run(max_size=100, policy=BASE | rustybam_amd.BREAK_ONE_WALK)
+    assert cnt["redo_two_walk"] == 1
+    rows, out, cnt = D1.run(max_size=100, policy=BASE)
+    assert cnt["redo_two_walk"] == 0 and rows.shape[0] == 41
