@@ -97,8 +97,8 @@ enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY
        RB_LIFT_FUSED_SCAN = 64,
        /* RB_BREAK_ONE_WALK (rb_dev_break): the clip kernel finds the long indels itself while it streams a record (no separate pass
         * that collects the pieces first: the ops are read once).  The caller must look at counters->redo_two_walk afterwards: set,
-        * the batch holds something this path does not take (an irregular record, more than 32 pieces in one record, a boundary the
-        * fast path cannot resolve), the results are incomplete and the call is to be repeated without this flag (rb_host_break does). */
+        * the batch holds something this path does not take (an irregular record, a boundary the fast path cannot
+        * resolve), the results are incomplete and the call is to be repeated without this flag (rb_host_break does). */
        RB_BREAK_ONE_WALK = 128 };
 
 /* rb_norm_row.flags / rb_reduce_row.flags */
@@ -164,7 +164,7 @@ typedef struct rb_counters { /* device-written job summary, 64 bytes */
     uint32_t overflow;           /* != 0: rows or out_ops capacity exceeded, results incomplete   */
     uint32_t _pad[6];
     uint32_t redo_two_walk;      /* RB_BREAK_ONE_WALK only: != 0: the batch holds what the one-walk path does not take (irregular
-                                    records, more than 32 pieces in a record): results incomplete, call again without the flag */
+                                    records, boundaries only the generic kernel resolves): results incomplete, call again without the flag */
 } rb_counters;
 
 /* per-record outcome of rb_dev_parse_cigars */

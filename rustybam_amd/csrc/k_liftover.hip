@@ -223,7 +223,7 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #define RB_RREG(OFF, W) "v[" RB_STR(RB_RING_BASE) "+" #OFF ":" RB_STR(RB_RING_BASE) "+" #OFF "+" #W "]"
 static_assert(RB_PF == 2, "the ring's asm statements are written out for two slots");
 // BRK: break-paf in one walk (rb_lift.h, brk_max): the windows of a record are not given, they are the stretches between the indels
-// longer than brk_max, found while the record streams; one pass of at most 32 pieces.  The liftover build has none of that code.
+// longer than brk_max, found while the record streams; 32 pieces a pass.  The liftover build has none of that code.
 template <bool BRK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), amdgpu_num_vgpr(RB_RING_BASE))) void rb_k_liftover_stream(rb_lift_params p) {
     // checkpoints: exclusive (R,Q,U) prefixes every 16 ops, SoA so that R can be binary-searched
@@ -309,12 +309,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
     const bool fused = p.fused != 0;
     uint32_t rec_nmatch = 0, rec_aln_len = 0; // of the whole (normalised) record: taken from its row, or from the fused verification
     if (!fused) rec_nmatch = nr->nmatch, rec_aln_len = nr->aln_len;
-    const uint64_t n_items = BRK ? 1 : ((nh == 0 && fused) ? 1 : nh); // (a record no window overlaps is still streamed once, to verify it)
+    uint64_t n_items = BRK ? 1 : ((nh == 0 && fused) ? 1 : nh); // (a record no window overlaps is still streamed once, to verify it; BRK: set by the first pass)
+    // BRK, across passes: where the scratch rows of the record begin, and the cut state (pieces closed, end of the last long indel)
+    // at the start of the segment in which the next pass's first piece opens
+    uint64_t brk_row0 = 0;
+    uint32_t brk_res_cnt = 0, brk_res_pre = 0;
     // where a later pass may start streaming: the segment in which the previous pass resolved the start of its last window
     // (windows are sorted, so nothing of the next pass lies before it), with the running totals at that point
     uint32_t resume_seg = 0, resume_R = 0, resume_Q = 0, resume_U = 0;
     for (uint64_t jb = 0; jb < n_items; jb += RB_HMAX) {
-        uint32_t nb = BRK ? 1u : (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX); // (BRK: pieces known so far, the open one included)
+        uint32_t nb = BRK ? 0u : (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX); // (BRK: pieces of this pass known so far, the open one included)
         const bool validate = fused && jb == 0;
         // ---- per-hit setup: lanes j and j + 32 both look at window jb + j; lane j resolves its start
         //      boundary, lane j + 32 its end boundary; lane j then owns the row ----
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         bool mine = own && lane < 32;
         const bool is_start = lane < 32;
         uint64_t wst = 0, wen = 0;
-        uint32_t win = hl;
+        uint32_t win = (uint32_t)jb + hl; // (BRK: the piece's ordinal)
         if constexpr (!BRK) {
             const rb_pass_win pw = rb_pass_windows(p, &wx_all[wib][0], explicit_w, mono, ws, we, lo, h0, jb, nb, t_st, t_en, scan_pos, lane);
             wst = pw.wst, wen = pw.wen, win = pw.win;
@@ -336,11 +340,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         // BRK: piece j is the stretch from the end of a long indel (liftover.rs:203-206: pre_tpos) to the start of the next one
         // (cur_tpos, :190-201), kept if it holds reference bases; lane j carries its start, lane j + 32 its end, both as D above.
         // Piece brk_cnt is OPEN: its start is known (brk_pre), its end not yet (D = ~0 keeps it in every test below).
+        // A pass takes pieces jb .. jb + 31; the first pass streams the whole record and counts all of them, a later one starts at
+        // the segment in which its first piece opened (the cut state of that segment's start comes with it) and stops when its
+        // pieces are closed and resolved.
         uint32_t brk_cnt = 0, brk_pre = 0;
-        unsigned long long brk_def = 0ull; // lanes whose D is final
+        uint32_t brk_seg_cnt = 0, brk_seg_pre = 0; // ... at the start of the current segment
+        uint32_t brk_nx_cnt = 0, brk_nx_pre = 0;   // ... of the segment the next pass resumes at
+        unsigned long long brk_def = 0ull;         // lanes whose D is final
+        const uint32_t brk_j0 = (uint32_t)jb;
         if constexpr (BRK) {
-            D = lane == 0 ? 1u : 0xFFFFFFFFu;
-            brk_def = 1ull;
+            if (jb != 0) brk_cnt = rb_first(brk_res_cnt), brk_pre = rb_first(brk_res_pre);
+            D = 0xFFFFFFFFu;
+            if (brk_cnt >= brk_j0 && brk_cnt - brk_j0 < 32u) { // the open piece is one of this pass's
+                D = (uint32_t)lane == brk_cnt - brk_j0 ? brk_pre + 1u : D;
+                brk_def = 1ull << (brk_cnt - brk_j0);
+                nb = brk_cnt - brk_j0 + 1u;
+            }
             need = false;
         }
         rb_bres O;
@@ -359,6 +374,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals
         uint32_t seg_first = 0;
         if (resumable) seg_first = resume_seg, Rb = resume_R, Qb = resume_Q, Ub = resume_U;
+        if constexpr (BRK) // (set inside the step lambda: told to the compiler as the wave-uniform values they are)
+            seg_first = rb_first(seg_first), Rb = rb_first(Rb), Qb = rb_first(Qb), Ub = rb_first(Ub);
         uint32_t next_seg = seg_first, next_R = Rb, next_Q = Qb, next_U = Ub; // resume point for the pass after this one
         // fused verification (first pass), per lane: AND of the "regular op" masks, minimum op word (below 16: a zero length),
         // minimum of code XOR previous code (0: two adjacent ops of one type), maximum of the per-lane length sums (2^25 and
@@ -515,23 +532,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                                 const uint32_t rlq = cq == RB_OP_I ? 0u : lq; // (regular records: M I D N = X)
                                 if ((cq == RB_OP_I || cq == RB_OP_D) && lq > p.brk_max) {
                                     if (rx > brk_pre) { // liftover.rs:191: the piece in front of the indel, if it holds reference bases
-                                        if (brk_cnt < 32u) {
-                                            D = (uint32_t)lane == 32u + brk_cnt ? rx : D;
-                                            brk_def |= 1ull << (32u + brk_cnt);
+                                        const uint32_t li = brk_cnt - brk_j0; // (its lane in this pass; wraps far above 32 for earlier pieces)
+                                        if (li < 32u) {
+                                            D = (uint32_t)lane == 32u + li ? rx : D;
+                                            brk_def |= 1ull << (32u + li);
                                         }
                                         brk_cnt++;
+                                        if (brk_cnt == brk_j0 + 32u) // the next pass's first piece opens in this segment: it resumes here
+                                            next_seg = seg0 / RB_SMAX, next_R = Rseg, next_Q = Qseg, next_U = Useg, brk_nx_cnt = brk_seg_cnt, brk_nx_pre = brk_seg_pre;
                                     }
                                     brk_pre = rx + rlq; // :203-206
-                                    if (brk_cnt < 32u) { // the next piece opens here (its lanes are rewritten if it turns out empty)
-                                        D = (uint32_t)lane == brk_cnt ? brk_pre + 1u : ((uint32_t)lane == 32u + brk_cnt ? 0xFFFFFFFFu : D);
-                                        brk_def |= 1ull << brk_cnt;
-                                        brk_def &= ~(1ull << (32u + brk_cnt));
+                                    {
+                                        const uint32_t li = brk_cnt - brk_j0;
+                                        if (li < 32u) { // the next piece opens here (its lanes are rewritten if it turns out empty)
+                                            D = (uint32_t)lane == li ? brk_pre + 1u : ((uint32_t)lane == 32u + li ? 0xFFFFFFFFu : D);
+                                            brk_def |= 1ull << li;
+                                            brk_def &= ~(1ull << (32u + li));
+                                        }
                                     }
                                 }
                                 rx += rlq;
                             }
                         }
-                        nb = brk_cnt + 1u < 32u ? brk_cnt + 1u : 32u;
+                        nb = brk_cnt < brk_j0 ? 0u : (brk_cnt - brk_j0 + 1u < 32u ? brk_cnt - brk_j0 + 1u : 32u);
                     }
                     if (spec) {
                         // Which of this lane's 8 ops a clip keeps is not known yet (boundaries are resolved per segment),
@@ -605,6 +628,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
             for (seg0 = seg_first * RB_SMAX; seg0 < n_steps; seg0 += RB_SMAX) {
                 const uint32_t seg1 = (seg0 + RB_SMAX < n_steps) ? seg0 + RB_SMAX : n_steps;
                 Rseg = Rb, Qseg = Qb, Useg = Ub;
+                if constexpr (BRK) brk_seg_cnt = brk_cnt, brk_seg_pre = brk_pre;
                 // the ring is indexed statically (unrolled by RB_PF): rotating it with register moves would make
                 // every step wait for ALL loads in flight (the moves read their destination registers)
                 for (uint32_t st0 = seg0; st0 < seg1; st0 += RB_PF) {
@@ -624,14 +648,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 const int32_t cp_idx0 = (int32_t)(seg0 << RB_STEP_SHIFT) - head; // op index of checkpoint 0
                 if constexpr (BRK) {
                     if (last_seg) { // liftover.rs:213-224: what lies behind the last long indel
+                        const uint32_t li = brk_cnt - brk_j0;
                         if (Rb > brk_pre) {
-                            if (brk_cnt < 32u) {
-                                D = (uint32_t)lane == 32u + brk_cnt ? Rb : D;
-                                brk_def |= 1ull << (32u + brk_cnt);
+                            if (li < 32u) {
+                                D = (uint32_t)lane == 32u + li ? Rb : D;
+                                brk_def |= 1ull << (32u + li);
                             }
                             brk_cnt++;
-                        } else if (brk_cnt < 32u) {
-                            brk_def &= ~(1ull << brk_cnt); // the record ends with a long indel: no piece was open after all
+                        } else if (li < 32u) {
+                            brk_def &= ~(1ull << li); // the record ends with a long indel: no piece was open after all
                         }
                     }
                     need = ((brk_def >> lane) & 1ull) != 0ull && O.st == RB_S_UNRES;
@@ -663,6 +688,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                     if (!BRK && nb && ((__ballot(todo) >> (nb - 1u)) & 1ull)) next_seg = seg0 / RB_SMAX, next_R = Rseg, next_Q = Qseg, next_U = Useg;
                 }
                 if (!BRK && (p.early_exit || resumable) && !validate && !(spec && any_inside) && __ballot(need) == 0) break;
+                if constexpr (BRK) { // a later pass is done when its 32 pieces are closed and every boundary of theirs is resolved
+                    if (jb != 0 && brk_cnt >= brk_j0 + 32u && __ballot(((brk_def >> lane) & 1ull) != 0ull && O.st == RB_S_UNRES) == 0ull) break;
+                }
             }
             // nothing of the ring may still be in flight when its registers go back to the compiler (a pass that leaves early
             // has loads out), and the end groups below must land after the speculative stores to the same addresses
@@ -709,27 +737,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
             }
             if (!BRK && nh == 0) return;
         }
-        uint64_t brk_row0 = 0; // BRK: the record's first (scratch) row
         if constexpr (BRK) {
-            if (brk_cnt > 32u) { // more pieces than one pass holds
-                if (lane == 0) p.counters->redo_two_walk = 1;
-                return;
+            brk_cnt = rb_first(brk_cnt), brk_nx_cnt = rb_first(brk_nx_cnt), brk_nx_pre = rb_first(brk_nx_pre);
+            if (jb == 0) {
+                // the first pass has seen every piece.  Rows: a place for all of them from one of the bump cursors (one atomic per
+                // record; a single cursor would serialise the records at one L2 line), the count for the scan that orders the rows
+                n_items = brk_cnt;
+                unsigned long long b0 = 0;
+                const uint32_t ar = (uint32_t)(wave % p.brk_n_arena);
+                if (lane == 0 && brk_cnt) b0 = atomicAdd(&p.brk_cursor[(size_t)ar * 16u], (unsigned long long)brk_cnt);
+                b0 = rb_first64(b0);
+                if (b0 + brk_cnt > p.brk_arena_cap) { // (this cursor's share of the scratch rows is used up: rb_k_finish asks for more rows)
+                    if (lane == 0) p.counters->_pad[5] = 1, p.hit_off[r] = brk_cnt, p.brk_off[r] = ~0ull;
+                    return;
+                }
+                brk_row0 = (uint64_t)ar * p.brk_arena_cap + b0;
+                if (lane == 0) p.hit_off[r] = brk_cnt, p.brk_off[r] = brk_row0;
+                if (brk_cnt == 0) return;
             }
-            nb = brk_cnt;
+            nb = (uint32_t)(n_items - jb < 32u ? n_items - jb : 32u);
             own = hl < nb, mine = own && lane < 32;
-            // rows: a place for the record's pieces from one of the bump cursors (one atomic per record; a single cursor would
-            // serialise the records at one L2 line), the count for the scan that orders the rows afterwards
-            unsigned long long b0 = 0;
-            const uint32_t ar = (uint32_t)(wave % p.brk_n_arena);
-            if (lane == 0 && nb) b0 = atomicAdd(&p.brk_cursor[(size_t)ar * 16u], (unsigned long long)nb);
-            b0 = rb_first64(b0);
-            if (b0 + nb > p.brk_arena_cap) { // (this cursor's share of the scratch rows is used up: rb_k_finish asks for more rows)
-                if (lane == 0) p.counters->_pad[5] = 1, p.hit_off[r] = nb, p.brk_off[r] = ~0ull;
-                return;
-            }
-            brk_row0 = (uint64_t)ar * p.brk_arena_cap + b0;
-            if (lane == 0) p.hit_off[r] = nb, p.brk_off[r] = brk_row0;
-            if (nb == 0) return;
+            brk_res_cnt = brk_nx_cnt, brk_res_pre = brk_nx_pre;
         }
         // ---- finalize: lane j (< 32) computes the row of hit jb + j; the end comes from lane j + 32 ----
         const rb_bres A = O;
@@ -818,7 +846,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         //  the streaming loop and carries -- or spills -- them through it)
         uint32_t lane_late = (uint32_t)lane;
         asm volatile("" : "+v"(lane_late));
-        const uint64_t my_row = (BRK ? brk_row0 : h0 + jb) + lane_late;
+        const uint64_t my_row = (BRK ? brk_row0 + jb : h0 + jb) + lane_late;
         if (mine) {
             rb_hit_row *row = &p.rows[my_row];
             if (defer) {

@@ -84,8 +84,7 @@ struct rb_lift_params {
     // break-paf in ONE walk (RB_BREAK_ONE_WALK): the clip kernel finds the long indels itself while it streams a record, so the
     // pieces of a record are known only when it ends: rows go to a place taken from one of brk_n_arena bump cursors in `rows`
     // (a scratch array then), the counts to hit_off, the place to brk_off; after the scan of the counts rb_k_break_gather moves
-    // the rows to rows_final in record order.  What this path does not take (irregular records, more than 32 pieces, a boundary
-    // it cannot resolve) sets counters->redo_two_walk: the caller runs the call again without the flag.
+    // the rows to rows_final in record order.  What this path does not take (irregular records, a boundary it cannot resolve) sets counters->redo_two_walk: the caller runs the call again without the flag.
     int brk_mode;                  // != 0: this is that call
     uint32_t brk_max;              // indels longer than this cut (0: every indel)
     uint32_t brk_n_arena;
