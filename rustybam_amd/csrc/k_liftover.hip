@@ -1526,17 +1526,22 @@ __global__ __launch_bounds__(64) void rb_k_finish(rb_lift_params p) {
 
 // one-walk break-paf: the rows of a record leave their scratch place for rows_final[hit_off[r] ..] (hit_off scanned by now)
 __global__ __launch_bounds__(256) void rb_k_break_gather(rb_lift_params p) {
-    const uint64_t r = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    // four lanes per record, 16 bytes of a 64-byte row each (a record has a handful of pieces: a wavefront per record idles)
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t r = t >> 2;
     if (r >= p.n_rec) return;
     const uint64_t h0 = p.hit_off[r], n = p.hit_off[r + 1] - h0, src = p.brk_off[r];
     if (src == ~0ull) return;
-    for (uint64_t j = rb_lane(); j < n; j += 64)
-        if (h0 + j < p.rows_cap) p.rows_final[h0 + j] = p.rows[src + j];
+    const uint32_t part = (uint32_t)(t & 3u);
+    const uint4 *from = reinterpret_cast<const uint4 *>(p.rows + src);
+    uint4 *to = reinterpret_cast<uint4 *>(p.rows_final + h0);
+    for (uint64_t j = 0; j < n; j++)
+        if (h0 + j < p.rows_cap) to[4 * j + part] = from[4 * j + part];
 }
 extern "C" hipError_t rb_launch_break_gather(const rb_lift_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_copy_clips, dim3(2048), dim3(256), 0, stream, *p); // (clips without a slot: their rows are still where the list says)
-    hipLaunchKernelGGL(rb_k_break_gather, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(rb_k_break_gather, dim3((unsigned)((p->n_rec * 4 + 255) / 256)), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
     return hipGetLastError();
 }
