@@ -822,7 +822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         before = before > cprev ? before : cprev;
         const bool in_slot = spec && streams && emits && e_cnt != 0u && eg_f >= before;
         const bool copied = emits && !in_slot; // (an empty clip cannot happen: out_n >= 1 for an OK row)
-        if (jb + RB_HMAX < nh) {                // another pass follows: what it must stay behind
+        if (jb + RB_HMAX < (BRK ? n_items : nh)) { // another pass follows: what it must stay behind
 #pragma unroll
             for (int q = 0; q < RB_MS; q++) {
                 uint32_t v = (lane < 32 && cls == (uint32_t)q) ? pm : 0u;

@@ -93,3 +93,20 @@ def test_declines_irregular_records_and_takes_many_pieces_in_several_passes(ctx)
         assert cnt1["redo_two_walk"] == 0 and cnt2["redo_two_walk"] == 0
         assert rows1.shape[0] == rows2.shape[0] == n_cut + 1, (n_cut, rows1.shape, rows2.shape)
         assert D1.digest(rows1, out1) == D1.digest(rows2, out2), n_cut
+    # long pieces (each keeps its place in an output slot) around a piece of one op at a pass boundary: pieces 30 and 32 then lie
+    # in the same slot within one 16-byte group of each other, and belong to different passes
+    for tiny_at in (31, 63, 33):
+        cig = []
+        for k in range(70):
+            cig += [((1 if k == tiny_at else 300 + k) << 4) | M] + ([(2 << 4) | I_, (250 << 4) | M] if k != tiny_at else []) + [(500 << 4) | D_]
+        cig.append((40 << 4) | M)
+        cig = np.array(cig, np.uint32)
+        R, Q = sums(cig)
+        one = dict(ops=cig, op_off=np.array([0, len(cig)], np.uint64), t_st=np.array([0], np.uint64), t_en=np.array([R], np.uint64),
+                   q_st=np.array([3], np.uint64), q_en=np.array([3 + Q], np.uint64), strand=np.array([ord("+")], np.uint8),
+                   contig=np.zeros(1, np.uint32))
+        D1 = DevBatch(torch, eng, dev, one)
+        rows2, out2, cnt2 = D1.run(max_size=100, policy=BASE, rows_cap=8192)
+        rows1, out1, cnt1 = D1.run(max_size=100, policy=BASE | rustybam_amd.BREAK_ONE_WALK, rows_cap=8192)
+        assert cnt1["redo_two_walk"] == 0 and rows1.shape[0] == rows2.shape[0] == 71
+        assert D1.digest(rows1, out1) == D1.digest(rows2, out2), tiny_at
