@@ -216,6 +216,10 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef RB_RING_BASE
 #define RB_RING_BASE 80
 #define RB_RING_TOP "v95" // the last register of the ring (RB_RING_BASE + 8 RB_PF - 1): named as a clobber so that the kernel's register count covers it
+// (NOT all sixteen: a register named as clobbered is one the compiler may use for its own temporaries between two asm statements --
+//  tried, it did.  What keeps the compiler out of the ring is amdgpu_num_vgpr, with one gap: the VGPRs it spills scalar registers into
+//  are placed behind its own allocation, and one build of this kernel had them at v78 v79 v80.  tests/test_ring_registers.py
+//  disassembles both builds and fails if anything outside the asm statements names v80..v95.)
 #endif
 #define RB_STR2(x) #x
 #define RB_STR(x) RB_STR2(x)
