@@ -3,6 +3,7 @@
 // No CPU fallback lives here: every compute entry point needs a gfx950 device and fails with
 // RB_E_NO_DEVICE otherwise.  Nothing in this file (or this library) touches oracle/.
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <cstdarg>
@@ -900,6 +901,13 @@ extern "C" int rb_dev_format_cigars(rb_ctx *ctx, const uint32_t *ops, const uint
     return format_cigars_impl(ctx, ops, ops_alt, n_items, first, count, first_len, last_len, text_off, text, text_cap, scratch, false);
 }
 
+// gigabyte-sized host buffers: ask for huge pages where the system lets a process opt in (transparent_hugepage = madvise): a
+// 2 GB buffer is then a thousand faults and a thousand pages to free instead of half a million of each
+static void rb_advise_huge(void *p, size_t bytes) {
+    if (!p || bytes < ((size_t)8 << 20)) return;
+    const uintptr_t a = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+    if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
+}
 // ---- host-buffer wrappers ----------------------------------------------------------------------
 namespace {
 struct DevBatch {
@@ -1194,6 +1202,7 @@ extern "C" int rb_host_format_cigars(rb_ctx *ctx, const uint32_t *ops, uint64_t 
     if ((rc = format_cigars_impl(ctx, d_ops, nullptr, n_items, d_first, d_count, d_fl, d_ll, d_toff, d_text, bytes, d_scr, true))) return rc;
     *text = (uint8_t *)malloc((size_t)bytes + 16);
     if (!*text) return fail(ctx, RB_E_NOMEM, "malloc(%llu text bytes)", (unsigned long long)bytes);
+    rb_advise_huge(*text, (size_t)bytes);
     if (bytes) return rb_dev_download(ctx, *text, d_text, (size_t)bytes);
     return RB_OK;
 }
@@ -1377,6 +1386,7 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
         if (!rc) {
             *row_text = (uint8_t *)malloc((size_t)bytes + 16);
             if (!*row_text) rc = fail(ctx, RB_E_NOMEM, "malloc(%llu text bytes)", (unsigned long long)bytes);
+            else rb_advise_huge(*row_text, (size_t)bytes);
         }
         if (!rc && bytes) rc = rb_dev_download(ctx, *row_text, d_rtext, (size_t)bytes);
         rb_lap("format cigars + text D2H", tl);

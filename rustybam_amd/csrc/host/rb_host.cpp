@@ -15,6 +15,7 @@
 #include <exception>
 #include <memory>
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <functional>
@@ -320,6 +321,12 @@ std::string read_input_text(const std::string &file_name) { return read_all(file
 
 // the bytes of a text file in a buffer nobody zero-fills first (std::string::resize would touch 1.5 GB twice), 32 zero bytes behind
 // the text (the device reads whole 16-byte groups).  A plain file is read by all host threads at once, each its own slice.
+// gigabyte-sized host buffers: huge pages where the system lets a process opt in (transparent_hugepage = madvise)
+static void advise_huge(const void *p, size_t bytes) {
+    if (!p || bytes < ((size_t)8 << 20)) return;
+    const uintptr_t a = ((uintptr_t)p + ((size_t)2 << 20) - 1) & ~(uintptr_t)(((size_t)2 << 20) - 1), e = ((uintptr_t)p + bytes) & ~(uintptr_t)(((size_t)2 << 20) - 1);
+    if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);
+}
 struct TextBuf {
     std::unique_ptr<char[]> p;
     size_t n = 0;
@@ -339,6 +346,7 @@ static TextBuf read_text(const std::string &file_name, bool raw_bytes = false) {
             size_t from = 0;
             if (g_sliced && !raw_bytes) from = (size_t)std::min<uint64_t>(g_slice_begin, b.n), b.n = (size_t)std::min<uint64_t>(g_slice_end, b.n) - from;
             b.p.reset(new char[b.n + 32]);
+            advise_huge(b.p.get(), b.n);
             memset(b.p.get() + b.n, 0, 32);
             std::atomic<bool> ok{true};
             parallel_chunks((b.n + (1u << 22) - 1) >> 22, [&](unsigned, size_t lo, size_t hi) { // 4 MiB pieces
@@ -514,6 +522,7 @@ static std::vector<std::string> rows_to_text(const std::vector<PafRecord> &src, 
         size_t est = 0; // ~2.7 text bytes per op on alignment cigars; one allocation instead of a dozen doublings
         for (size_t k = lo; k < hi; k++) est += rows[k].status == RB_ST_OK ? 160 + (size_t)rows[k].out_n * 3 : 0;
         o.reserve(est);
+        advise_huge(o.data(), est);
         char nb[24];
         auto num = [&](uint64_t v) {
             auto r = std::to_chars(nb, nb + sizeof nb, v);
@@ -841,6 +850,7 @@ std::vector<std::string> assemble_lines(const TextFile &f, const std::vector<rb_
         size_t est = 0;
         for (size_t k = lo; k < hi; k++) est += R.rows[k].status == RB_ST_OK ? 160 + (size_t)(R.toff[k + 1] - R.toff[k]) : 0;
         o.reserve(est);
+        advise_huge(o.data(), est);
         char nb[24];
         auto num = [&](uint64_t v) {
             auto r = std::to_chars(nb, nb + sizeof nb, v);
@@ -1096,6 +1106,7 @@ bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, i
         size_t est = 0;
         for (size_t k = lo; k < hi; k++) est += 160 + (size_t)(toff[k + 1] - toff[k]);
         o.reserve(est);
+        advise_huge(o.data(), est);
         char nb[24];
         auto num = [&](uint64_t x) {
             auto r = std::to_chars(nb, nb + sizeof nb, x);
@@ -1194,6 +1205,7 @@ bool invert_file_text(Engine &eng, const std::string &paf_path, std::vector<std:
         size_t est = 0;
         for (size_t k = lo; k < hi; k++) est += 160 + (size_t)(toff[k + 1] - toff[k]);
         o.reserve(est);
+        advise_huge(o.data(), est);
         char nb[24];
         auto num = [&](uint64_t x) {
             auto r = std::to_chars(nb, nb + sizeof nb, x);

@@ -48,8 +48,10 @@ static int usage() {
 
 // a finished run leaves without tearing down gigabytes of buffers and the HIP runtime piece by piece
 // (a profiler that reports at exit needs the ordinary exit path: RB_FULL_EXIT=1, or rocprofv3's library in LD_PRELOAD)
+static double g_t_main = 0;
 [[noreturn]] static void done(int rc) {
     fflush(stdout);
+    if (getenv("RB_TIMING")) fprintf(stderr, "[rb timing] main entry to last byte written %.3f s\n", now_s() - g_t_main);
     fflush(stderr);
     const char *pre = getenv("LD_PRELOAD");
     if (getenv("RB_FULL_EXIT") || (pre && strstr(pre, "rocprofiler"))) exit(rc);
@@ -235,6 +237,7 @@ static int shard_fork(int n, std::string &path, int &device) {
 }
 
 int main(int argc, char **argv) {
+    g_t_main = now_s();
     setvbuf(stdout, g_obuf, _IOFBF, sizeof g_obuf);
     int a = 1, device = 0, policy = RB_BSEARCH_MODERN, gpus = 1;
     while (a + 1 < argc && argv[a][0] == '-') {
