@@ -246,7 +246,7 @@ def main():
     d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
     # out_ops: as many positional copies of the batch's op index space as the windows overlap deep (2 for the sliding windows; 1
     # for break-paf) + arena room; the clipped cigars land there while their record streams past
-    rows_cap, out_cap = max(1024, 2 * n_rec), max(4096, eng.plan_out_capacity(plan, args.op == "break"))
+    rows_cap, out_cap = max(1024, 16 * n_rec), max(4096, eng.plan_out_capacity(plan, args.op == "break"))  # (a first guess; the counters of the first call say what is needed)
 
     # break-paf: the clip kernel finds the long indels itself (one walk of the ops); a batch it does not take says so in the
     # counters and is done with the collect pass in front (two walks) -- decided once, by the sizing call below
