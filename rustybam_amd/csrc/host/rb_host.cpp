@@ -1384,6 +1384,7 @@ struct BamStream {
             off += bsize;
         }
         buf.reset(new uint8_t[out + 1]);
+        advise_huge(buf.get(), out);
         n = out, pos = 0;
         std::atomic<bool> ok{true};
         parallel_chunks(mem.size(), [&](unsigned, size_t lo, size_t hi) {
