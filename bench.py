@@ -344,8 +344,8 @@ def main():
         digest = int(d_dig.item()) & mask64
     job_hits = sum(h for h, _ in per_rank)
     if args.debug_skip & 32:  # diagnostics: per-phase shader-clock sums of the clip kernel (last step, every 16th record)
-        ph = [int(x) * 16 * 16 for x in cnt["_pad"]]
-        names = ["job+windows", "stream+resolve", "verdict+finalize", "reservation", "rows+end groups", "interior copy", "-"]
+        ph = [int(x) * 16 * 16 for x in cnt["phase"]]
+        names = ["job+windows", "stream+resolve", "verdict+finalize", "reservation", "rows+end groups"]
         tot = sum(ph) or 1
         print("[phases] " + "  ".join(f"{n_}={v / tot:.3f}" for n_, v in zip(names, ph)) + f"  | mean cycles/record {tot / max(1, n_rec):.0f}",
               file=sys.stderr)

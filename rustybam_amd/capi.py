@@ -33,7 +33,7 @@ PAIR_DT = np.dtype(
      ("out_n", "<u4", 2), ("_pad", "<u8")])
 COUNTERS_DT = np.dtype(
     [("n_hits", "<u8"), ("out_ops_needed", "<u8"), ("out_ops_used", "<u8"), ("n_generic", "<u8"),
-     ("overflow", "<u4"), ("_pad", "<u4", 6), ("redo_two_walk", "<u4")])
+     ("overflow", "<u4"), ("phase", "<u4", 5), ("brk_scratch_short", "<u4"), ("redo_two_walk", "<u4")])
 assert REDUCE_DT.itemsize == 72 and NORM_DT.itemsize == 64 and HIT_DT.itemsize == 64 and COUNTERS_DT.itemsize == 64
 assert PAIR_DT.itemsize == 128
 

@@ -508,7 +508,7 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
         if (!mono[c]) continue;
         uint64_t lo = cw_off[c];
         for (uint64_t i = cw_off[c]; i < cw_off[c + 1]; i++) {
-            while (g_en[lo] < g_st[i]) lo++;
+            while (lo < i && g_en[lo] < g_st[i]) lo++; // (a window with en < st may not push lo past i)
             pl->depth = std::max<uint32_t>(pl->depth, (uint32_t)std::min<uint64_t>(i - lo + 1, 1u << 20));
         }
     }

@@ -37,12 +37,11 @@
 #include <type_traits>
 
 // diagnostics (debug_skip & 32): shader-clock time of each phase of a record, every 16th record, summed in units of 16
-// cycles into counters->_pad[0..6]: job + windows, stream + resolve, verdict + finalize, reservation, rows + end groups,
-// interior copy, (unused)
+// cycles into counters->phase[0..4]: job + windows, stream + resolve, verdict + finalize, reservation, rows + end groups
 #define RB_PHASE(i)                                                                                                  \
     if (p.debug_skip & 32) {                                                                                         \
         const long long t_now = clock64();                                                                           \
-        if (lane == 0 && (wave & 15) == 0) atomicAdd(&p.counters->_pad[i], (uint32_t)((t_now - t_prev) >> 4));       \
+        if (lane == 0 && (wave & 15) == 0) atomicAdd(&p.counters->phase[i], (uint32_t)((t_now - t_prev) >> 4));       \
         t_prev = t_now;                                                                                              \
     }
 
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 if (lane == 0 && brk_cnt) b0 = atomicAdd(&p.brk_cursor[(size_t)ar * 16u], (unsigned long long)brk_cnt);
                 b0 = rb_first64(b0);
                 if (b0 + brk_cnt > p.brk_arena_cap) { // (this cursor's share of the scratch rows is used up: rb_k_finish asks for more rows)
-                    if (lane == 0) p.counters->_pad[5] = 1, p.hit_off[r] = brk_cnt, p.brk_off[r] = ~0ull;
+                    if (lane == 0) p.counters->brk_scratch_short = 1, p.hit_off[r] = brk_cnt, p.brk_off[r] = ~0ull;
                     return;
                 }
                 brk_row0 = (uint64_t)ar * p.brk_arena_cap + b0;
@@ -920,7 +919,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
             }
         }
         RB_PHASE(4)
-        RB_PHASE(5)
     }
 }
 
@@ -1521,7 +1519,7 @@ __global__ __launch_bounds__(64) void rb_k_finish(rb_lift_params p) {
     // what makes the job fit: the slots the window lists ask for, plus every arena as large as the fullest one got
     p.counters->out_ops_needed = p.needed_base + (mx + 3ull) / 4ull * 4ull * p.n_arena + 1024ull * p.n_arena;
     if (p.counters->n_hits > p.rows_cap) p.counters->overflow = 1;
-    if (p.brk_mode && p.counters->_pad[5]) { // one of the scratch-row cursors ran out before the rows did: ask for a quarter more
+    if (p.brk_mode && p.counters->brk_scratch_short) { // one of the scratch-row cursors ran out before the rows did: ask for a quarter more
         p.counters->overflow = 1;
         const uint64_t have = p.counters->n_hits > p.rows_cap ? p.counters->n_hits : p.rows_cap;
         p.counters->n_hits = have + have / 4u + 1024u;

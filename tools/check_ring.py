@@ -1,0 +1,70 @@
+"""Guard for the streaming clip kernel's load ring: VGPRs v80..v95 are reserved outside the compiler's allocation
+(k_liftover.hip: amdgpu_num_vgpr(80), the ring named literally in inline asm).  Nothing in the language guarantees that the
+compiler stays out of them, so this script compiles k_liftover.hip to assembly (hipcc cross-compiles without a GPU) and fails
+if any instruction outside the inline-asm blocks of rb_k_liftover_stream names a register in the ring -- a single register
+v80..v95 or ANY tuple v[a:b] whose range intersects it (v[78:81] as well as v[80:83]).  Run by the Makefile on every build of
+k_liftover.o and by tests/test_ring_registers.py."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RING = (80, 95)
+_SINGLE = re.compile(r"\bv(\d+)\b")
+_TUPLE = re.compile(r"\bv\[(\d+):(\d+)\]")
+
+
+def ring_uses(line, ring=RING):
+    """Register operands of one assembly line that intersect the ring."""
+    lo, hi = ring
+    bad = [f"v[{a}:{b}]" for a, b in ((int(x), int(y)) for x, y in _TUPLE.findall(line)) if a <= hi and b >= lo]
+    bad += [f"v{a}" for a in (int(x) for x in _SINGLE.findall(line)) if lo <= a <= hi]
+    return bad
+
+
+def check_assembly(text, expect_kernels=2):
+    """-> list of (kernel, line) offences; raises if the expected kernels are not in the assembly."""
+    found, offences = 0, []
+    for m in re.finditer(r"^(_Z20rb_k_liftover_streamILb[01]E\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+        found += 1
+        in_asm = False
+        for ln in m.group(2).splitlines():
+            if "#ASMSTART" in ln:
+                in_asm = True
+            elif "#ASMEND" in ln:
+                in_asm = False
+            elif not in_asm and ring_uses(ln.split(";")[0]):
+                offences.append((m.group(1), ln.strip()))
+    if found != expect_kernels:
+        raise RuntimeError(f"{found} builds of rb_k_liftover_stream in the assembly, {expect_kernels} expected")
+    return offences
+
+
+def spills(text):
+    """-> {kernel: (sgpr_spill_count, vgpr_spill_count, vgpr_count)} from the code-object metadata at the end of the assembly."""
+    out = {}
+    for m in re.finditer(r"\.name: +(_Z20rb_k_liftover_stream\w*)\n(.*?)\.wavefront_size", text, re.S):
+        f = dict(re.findall(r"\.(sgpr_spill_count|vgpr_spill_count|vgpr_count): +(\d+)", m.group(2)))
+        out[m.group(1)] = (int(f.get("sgpr_spill_count", -1)), int(f.get("vgpr_spill_count", -1)), int(f.get("vgpr_count", -1)))
+    return out
+
+
+def compile_to_asm(hipcc, extra=()):
+    src = os.path.join(ROOT, "rustybam_amd", "csrc", "k_liftover.hip")
+    with tempfile.TemporaryDirectory(prefix="rb_ring_") as d:
+        out = os.path.join(d, "k.s")
+        flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", *extra]  # the Makefile's code-generation flags
+        subprocess.check_call([hipcc, *flags, "-S", "--cuda-device-only", src, "-o", out], stderr=subprocess.DEVNULL)
+        return open(out).read()
+
+
+if __name__ == "__main__":
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    text = compile_to_asm(hipcc, sys.argv[1:])
+    bad = check_assembly(text)
+    for k, ln in bad[:10]:
+        print(f"ring register used by the compiler in {k}: {ln}", file=sys.stderr)
+    print(f"check_ring: {'FAILED' if bad else 'ok'}; spills (sgpr, vgpr) = {spills(text)}")
+    sys.exit(1 if bad else 0)
