@@ -159,17 +159,27 @@ def main():
     from rustybam_amd import workload as wl
 
     use_dist = world > 1 or os.environ.get("RB_BENCH_FORCE_DIST") == "1"  # the latter: exercise the RCCL path on one GPU
+    # RB_BENCH_SAME_DEVICE=1 (tests on a 1-GPU lease): every rank on GPU 0, so that the N > 1 path -- shard bounds, per-rank
+    # generation, barrier, max-over-ranks time, gathered digest -- runs for real with N processes.  RCCL refuses two ranks on one
+    # device ("duplicate GPU"), so the three control collectives then go over gloo with host tensors; the data path has no
+    # collective either way.
+    same_device = os.environ.get("RB_BENCH_SAME_DEVICE") == "1"
+    dev_index = 0 if same_device else local_rank
     if use_dist:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank}, this node shows {torch.cuda.device_count()}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {dev_index}, this node shows {torch.cuda.device_count()}")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = torch.device("cpu") if (use_dist and same_device) else dev  # where the control collectives' tensors live
     torch.cuda.set_stream(torch.cuda.Stream(dev))  # one real stream for torch's kernels AND the engine's (the default stream's
     stream = torch.cuda.current_stream().cuda_stream  # handle is NULL, which rb_ctx_create reads as "make a private stream")
-    eng = rustybam_amd.Engine(local_rank, stream)
+    eng = rustybam_amd.Engine(dev_index, stream)
 
     if args.scaling == "strong":  # one batch of --records, one op-balanced contiguous record range per rank
         seed_ = wl.SEED_CONFIG2 if args.workload == "config2" else wl.SEED_CONFIG3
@@ -310,10 +320,10 @@ def main():
     kern_ms = eng.get_timing()
     eng.set_timing(False)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([float(total_ops), float(n_rec)], dtype=torch.float64, device=dev)
+        tot = torch.tensor([float(total_ops), float(n_rec)], dtype=torch.float64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         job_ops, job_recs = float(tot[0].item()), float(tot[1].item())
     else:
@@ -326,8 +336,8 @@ def main():
     #      outside the timed region; the data path itself has no collective) ----
     mask64 = (1 << 64) - 1
     if use_dist:
-        g = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(g, torch.tensor([n_hits, n_rec], dtype=torch.int64, device=dev))
+        g = [torch.zeros(2, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([n_hits, n_rec], dtype=torch.int64, device=cdev))
         per_rank = [[int(x) for x in t.tolist()] for t in g]
     else:
         per_rank = [[n_hits, n_rec]]
@@ -337,8 +347,8 @@ def main():
     eng.dev_digest_rows(view, d_rows.data_ptr(), n_hits, d_out.data_ptr(), row_base, first, d_dig.data_ptr())
     torch.cuda.synchronize()
     if use_dist:
-        g = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(g, d_dig)
+        g = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+        dist.all_gather(g, d_dig.to(cdev))
         digest = sum(int(t.item()) & mask64 for t in g) & mask64
     else:
         digest = int(d_dig.item()) & mask64

@@ -284,6 +284,43 @@ static uint64_t g_slice_begin = 0, g_slice_end = 0;
 static bool g_sliced = false;
 void set_input_slice(uint64_t begin, uint64_t end) { g_slice_begin = begin, g_slice_end = end, g_sliced = true; }
 
+// `rb --gpus N trim-paf`: the unit of dependency is the query-name group (paf.rs:223, :235), and the output is ordered by query
+// name (the stable sort at :223), so worker k takes the lines whose first column lies in the k-th range of the sorted names:
+// [lo, hi) bytewise (Rust's String order), an absent bound = open.  The readers below then keep only those lines.
+static bool g_qrange = false, g_q_has_lo = false, g_q_has_hi = false;
+static std::string g_q_lo, g_q_hi;
+void set_input_query_range(const std::string *lo, const std::string *hi) {
+    g_qrange = true, g_q_has_lo = lo != nullptr, g_q_has_hi = hi != nullptr;
+    if (lo) g_q_lo = *lo;
+    if (hi) g_q_hi = *hi;
+}
+static inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f'; }
+static inline std::string_view first_token(const char *a, const char *e) { // split_ascii_whitespace().next()
+    while (a < e && is_ws(*a)) a++;
+    const char *q = a;
+    while (q < e && !is_ws(*q)) q++;
+    return std::string_view(a, (size_t)(q - a));
+}
+static inline bool in_query_range(std::string_view t) {
+    return (!g_q_has_lo || t.compare(g_q_lo) >= 0) && (!g_q_has_hi || t.compare(g_q_hi) < 0);
+}
+// the kept lines of text [a, e) (whole lines; the last one may lack its newline), appended to `out` with their newlines
+static void keep_query_lines(const char *a, const char *e, std::vector<char> &out) {
+    const char *run = nullptr; // start of the current run of kept lines
+    while (a < e) {
+        const char *nl = (const char *)memchr(a, '\n', (size_t)(e - a));
+        const char *next = nl ? nl + 1 : e;
+        if (in_query_range(first_token(a, nl ? nl : e))) {
+            if (!run) run = a;
+        } else if (run) {
+            out.insert(out.end(), run, a);
+            run = nullptr;
+        }
+        a = next;
+    }
+    if (run) out.insert(out.end(), run, e);
+}
+
 // the whole (decompressed) text of a PAF file or stdin
 static std::string read_all(const std::string &file_name) {
     std::string all;
@@ -315,6 +352,11 @@ static std::string read_all(const std::string &file_name) {
         while ((r = gzread(f, buf.data(), (unsigned)buf.size())) > 0) all.append(buf.data(), (size_t)r);
         gzclose(f);
     }
+    if (g_qrange) {
+        std::vector<char> kept;
+        keep_query_lines(all.data(), all.data() + all.size(), kept);
+        all.assign(kept.data(), kept.size());
+    }
     return all;
 }
 std::string read_input_text(const std::string &file_name) { return read_all(file_name); }
@@ -341,6 +383,63 @@ static TextBuf read_text(const std::string &file_name, bool raw_bytes = false) {
         unsigned char magic[2] = {0, 0};
         struct stat st;
         const bool plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (raw_bytes || !(pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b));
+        if (plain && g_qrange && !raw_bytes) { // every host thread filters its own run of whole lines, then the kept lines side by side
+            const size_t size = (size_t)st.st_size;
+            const unsigned T = parallel_chunk_count((size >> 22) + 1);
+            std::vector<size_t> cut(T + 1, size);
+            cut[0] = 0;
+            std::vector<char> probe(1 << 16);
+            for (unsigned t = 1; t < T; t++) { // the first line start at or behind size * t / T
+                size_t at = std::max(cut[t - 1], size / T * t);
+                bool found = at == 0;
+                if (!found) at -= 1;
+                while (!found && at < size) {
+                    const ssize_t r = pread(fd, probe.data(), probe.size(), (off_t)at);
+                    if (r <= 0) break;
+                    const void *nl = memchr(probe.data(), '\n', (size_t)r);
+                    if (nl) at += (size_t)((const char *)nl - probe.data()) + 1, found = true;
+                    else at += (size_t)r;
+                }
+                cut[t] = found ? std::min(at, size) : size;
+            }
+            std::vector<std::vector<char>> kept(T);
+            std::atomic<bool> ok{true};
+            parallel_chunks(T, [&](unsigned, size_t lo, size_t hi) {
+                for (size_t t = lo; t < hi; t++) {
+                    std::vector<char> blk((size_t)8 << 20);
+                    size_t pos = cut[t];
+                    while (pos < cut[t + 1]) {
+                        const size_t want = std::min(blk.size(), cut[t + 1] - pos);
+                        size_t got = 0;
+                        while (got < want) {
+                            const ssize_t r = pread(fd, blk.data() + got, want - got, (off_t)(pos + got));
+                            if (r <= 0) { ok = false; return; }
+                            got += (size_t)r;
+                        }
+                        size_t use = got; // whole lines only, unless this is the end of the run
+                        if (pos + got < cut[t + 1]) {
+                            while (use > 0 && blk[use - 1] != '\n') use--;
+                            if (use == 0) { blk.resize(blk.size() * 2); continue; } // a line longer than the block
+                        }
+                        keep_query_lines(blk.data(), blk.data() + use, kept[t]);
+                        pos += use;
+                    }
+                }
+            });
+            close(fd);
+            if (!ok) throw Panic("Failed to read " + file_name);
+            std::vector<size_t> at(T + 1, 0);
+            for (unsigned t = 0; t < T; t++) at[t + 1] = at[t] + kept[t].size();
+            b.n = at[T];
+            b.p.reset(new char[b.n + 32]);
+            advise_huge(b.p.get(), b.n);
+            memset(b.p.get() + b.n, 0, 32);
+            parallel_chunks(T, [&](unsigned, size_t lo, size_t hi) {
+                for (size_t t = lo; t < hi; t++)
+                    if (!kept[t].empty()) memcpy(b.p.get() + at[t], kept[t].data(), kept[t].size());
+            });
+            return b;
+        }
         if (plain) {
             b.n = (size_t)st.st_size;
             size_t from = 0;
@@ -375,6 +474,84 @@ static TextBuf read_text(const std::string &file_name, bool raw_bytes = false) {
     memset(b.p.get() + b.n, 0, 32);
     return b;
 }
+// `rb --gpus N trim-paf`, parent side (no device): the N - 1 query names that cut the sorted names of a plain file into N ranges
+// of about equal text bytes; whole query groups stay together (paf.rs:223).  Fewer cuts come back when there are fewer names.
+std::vector<std::string> query_name_cuts(const std::string &file_name, int n) {
+    const int fd = open(file_name.c_str(), O_RDONLY);
+    if (fd < 0) throw Panic("Failed to open " + file_name);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); throw Panic("Failed to read " + file_name); }
+    const size_t size = (size_t)st.st_size;
+    const unsigned T = parallel_chunk_count((size >> 22) + 1);
+    std::vector<size_t> cut(T + 1, size);
+    cut[0] = 0;
+    std::vector<char> probe(1 << 16);
+    for (unsigned t = 1; t < T; t++) {
+        size_t at = std::max(cut[t - 1], size / T * t);
+        bool found = at == 0;
+        if (!found) at -= 1;
+        while (!found && at < size) {
+            const ssize_t r = pread(fd, probe.data(), probe.size(), (off_t)at);
+            if (r <= 0) break;
+            const void *nl = memchr(probe.data(), '\n', (size_t)r);
+            if (nl) at += (size_t)((const char *)nl - probe.data()) + 1, found = true;
+            else at += (size_t)r;
+        }
+        cut[t] = found ? std::min(at, size) : size;
+    }
+    std::vector<std::unordered_map<std::string, uint64_t>> part(T);
+    std::atomic<bool> ok{true};
+    parallel_chunks(T, [&](unsigned, size_t lo, size_t hi) {
+        for (size_t t = lo; t < hi; t++) {
+            std::vector<char> blk((size_t)8 << 20);
+            size_t pos = cut[t];
+            std::string key;
+            while (pos < cut[t + 1]) {
+                const size_t want = std::min(blk.size(), cut[t + 1] - pos);
+                size_t got = 0;
+                while (got < want) {
+                    const ssize_t r = pread(fd, blk.data() + got, want - got, (off_t)(pos + got));
+                    if (r <= 0) { ok = false; return; }
+                    got += (size_t)r;
+                }
+                size_t use = got;
+                if (pos + got < cut[t + 1]) {
+                    while (use > 0 && blk[use - 1] != '\n') use--;
+                    if (use == 0) { blk.resize(blk.size() * 2); continue; }
+                }
+                const char *a = blk.data(), *e = a + use;
+                while (a < e) {
+                    const char *nl = (const char *)memchr(a, '\n', (size_t)(e - a));
+                    const char *next = nl ? nl + 1 : e;
+                    const std::string_view tk = first_token(a, nl ? nl : e);
+                    key.assign(tk.data(), tk.size());
+                    part[t][key] += (uint64_t)(next - a);
+                    a = next;
+                }
+                pos += use;
+            }
+        }
+    });
+    close(fd);
+    if (!ok) throw Panic("Failed to read " + file_name);
+    std::map<std::string, uint64_t> all; // bytewise order = Rust's String order
+    uint64_t total = 0;
+    for (auto &m : part)
+        for (auto &kv : m) all[kv.first] += kv.second, total += kv.second;
+    std::vector<std::string> cuts;
+    uint64_t acc = 0;
+    int k = 1;
+    for (auto it = all.begin(); it != all.end() && k < n; ++it) {
+        // `it` opens range k when the names before it hold k / n of the bytes
+        while (k < n && acc >= total / (uint64_t)n * (uint64_t)k && it != all.begin()) {
+            if (cuts.empty() || cuts.back() != it->first) cuts.push_back(it->first);
+            k++;
+        }
+        acc += it->second;
+    }
+    return cuts;
+}
+
 // BufRead::lines: split on \n, strip one trailing \r
 static std::vector<std::pair<size_t, size_t>> split_lines(std::string_view all) {
     // newline positions, every thread its slice of the bytes; then the (start, length) pairs in file order
@@ -511,12 +688,26 @@ static std::vector<PafRecord> rows_to_records(const std::vector<PafRecord> &src,
 // `println!("{}", rec)` for every Some(rec) of a liftover / break-paf result, straight from the hit rows: no
 // intermediate PafRecord is built (1.3 M of them cost more than the whole device pass), text is encoded on all
 // host cores and returned in the reference's output order.
+// per chunk of output text: (contig id, byte offset in the chunk) wherever the rows of another contig begin (and at the chunk's start)
+typedef std::vector<std::vector<std::pair<uint32_t, size_t>>> RunMarks;
+static void marks_to_runs(const RunMarks &marks, const std::vector<std::string> &text, TextRuns &tr) {
+    tr.runs.clear();
+    for (size_t t = 0; t < text.size(); t++)
+        for (size_t m = 0; m < marks[t].size(); m++) {
+            const size_t end = m + 1 < marks[t].size() ? marks[t][m + 1].second : text[t].size();
+            const uint64_t bytes = end - marks[t][m].second;
+            if (!bytes) continue;
+            if (!tr.runs.empty() && tr.runs.back().first == marks[t][m].first) tr.runs.back().second += bytes;
+            else tr.runs.emplace_back(marks[t][m].first, bytes);
+        }
+}
 static std::vector<std::string> rows_to_text(const std::vector<PafRecord> &src, const std::vector<rb_norm_row> &norm, const rb_hit_row *rows, uint64_t n_rows,
-                                const uint32_t *out, const std::vector<Region> *rgns) {
+                                const uint32_t *out, const std::vector<Region> *rgns, const uint32_t *contig_of_rec = nullptr, RunMarks *marks = nullptr) {
     for (uint64_t k = 0; k < n_rows; k++)
         if (rows[k].status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(rows[k].rec + 1));
     const unsigned T = parallel_chunk_count((size_t)n_rows);
     std::vector<std::string> part(T);
+    if (marks) marks->assign(T, {});
     parallel_chunks((size_t)n_rows, [&](unsigned t, size_t lo, size_t hi) {
         std::string &o = part[t];
         size_t est = 0; // ~2.7 text bytes per op on alignment cigars; one allocation instead of a dozen doublings
@@ -537,6 +728,7 @@ static std::vector<std::string> rows_to_text(const std::vector<PafRecord> &src, 
             const rb_hit_row &h = rows[k];
             if (h.status != RB_ST_OK) continue;
             const PafRecord &s = src[h.rec];
+            if (marks && ((*marks)[t].empty() || (*marks)[t].back().first != contig_of_rec[h.rec])) (*marks)[t].emplace_back(contig_of_rec[h.rec], o.size());
             o += s.q_name; o += '\t'; num(s.q_len); o += '\t'; num(h.q_st); o += '\t'; num(h.q_en); o += '\t'; o += s.strand; o += '\t';
             o += s.t_name; o += '\t'; num(s.t_len); o += '\t'; num(h.t_st); o += '\t'; num(h.t_en); o += '\t'; num(h.nmatch); o += '\t';
             num(h.aln_len); o += '\t'; num(s.mapq); o += "\tid:Z:";
@@ -583,6 +775,8 @@ struct LiftResult { // rows + clip descriptors of one liftover / break-paf call 
     std::vector<PafRecord> swapped;
     const std::vector<PafRecord> *recs = nullptr;
     std::vector<rb_norm_row> norm;
+    std::vector<uint32_t> contig;          // per record: dense target id, first appearance order
+    std::vector<std::string> contig_names; // of the records (windows on other names come after)
     rb_hit_row *rows = nullptr;
     uint32_t *out = nullptr;
     uint64_t n_rows = 0, n_out = 0;
@@ -613,6 +807,7 @@ void run_liftover(Engine &eng, const std::vector<Region> &rgns, const std::vecto
                                &cnt),
               "rb_host_liftover"); // (fused scan: aligned_pairs' strip + integrity check happen inside the clip kernel)
     lap("rb_host_liftover", tl);
+    L.contig.swap(b.contig), L.contig_names.swap(b.contig_names);
     for (size_t i = 0; i < L.norm.size(); i++) panic_on(L.norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
 }
 void run_break(Engine &eng, const std::vector<PafRecord> &paf_recs, uint32_t break_length, LiftResult &L) {
@@ -634,11 +829,17 @@ std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &
     run_liftover(eng, rgns, paf_recs, invert_query, L);
     return rows_to_records(*L.recs, L.norm, L.rows, L.n_rows, L.out, &rgns);
 }
-std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query) {
+std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query,
+                                               TextRuns *runs) {
     LiftResult L;
     run_liftover(eng, rgns, paf_recs, invert_query, L);
     double tl = now_s();
-    std::vector<std::string> text = rows_to_text(*L.recs, L.norm, L.rows, L.n_rows, L.out, &rgns);
+    RunMarks marks;
+    std::vector<std::string> text = rows_to_text(*L.recs, L.norm, L.rows, L.n_rows, L.out, &rgns, L.contig.data(), runs ? &marks : nullptr);
+    if (runs) {
+        runs->contigs = L.contig_names;
+        marks_to_runs(marks, text, *runs);
+    }
     lap("rows -> text", tl);
     return text;
 }
@@ -840,11 +1041,13 @@ struct TextRows { // results of rb_host_liftover_text / rb_host_break_text (free
     ~TextRows() { rb_host_free(rows), rb_host_free(toff), rb_host_free(text); }
 };
 // `println!("{}", rec)` for every Some(rec): header columns from the file text and the hit rows, CIGAR text from the device
-std::vector<std::string> assemble_lines(const TextFile &f, const std::vector<rb_norm_row> &norm, const TextRows &R, const std::vector<Region> *rgns) {
+std::vector<std::string> assemble_lines(const TextFile &f, const std::vector<rb_norm_row> &norm, const TextRows &R, const std::vector<Region> *rgns,
+                                        RunMarks *marks = nullptr) {
     for (uint64_t k = 0; k < R.n_rows; k++)
         if (R.rows[k].status >= RB_ST_PANIC_NOTFOUND) throw Panic("Problem getting index in cigar: record " + std::to_string(R.rows[k].rec + 1));
     const unsigned TO = parallel_chunk_count((size_t)R.n_rows);
     std::vector<std::string> out_text(TO);
+    if (marks) marks->assign(TO, {});
     parallel_chunks((size_t)R.n_rows, [&](unsigned t, size_t lo, size_t hi) {
         std::string &o = out_text[t];
         size_t est = 0;
@@ -860,6 +1063,7 @@ std::vector<std::string> assemble_lines(const TextFile &f, const std::vector<rb_
             const rb_hit_row &h = R.rows[k];
             if (h.status != RB_ST_OK) continue;
             const HeaderOnly &s = f.recs[h.rec];
+            if (marks && ((*marks)[t].empty() || (*marks)[t].back().first != f.contig[h.rec])) (*marks)[t].emplace_back(f.contig[h.rec], o.size());
             o.append(f.all.data() + s.q_name, s.q_name_n); o += '\t'; num(s.q_len); o += '\t'; num(h.q_st); o += '\t'; num(h.q_en); o += '\t';
             o += s.strand; o += '\t'; o.append(f.all.data() + s.t_name, s.t_name_n); o += '\t'; num(s.t_len); o += '\t'; num(h.t_st); o += '\t';
             num(h.t_en); o += '\t'; num(h.nmatch); o += '\t'; num(h.aln_len); o += '\t'; num(s.mapq); o += "\tid:Z:";
@@ -874,12 +1078,16 @@ std::vector<std::string> assemble_lines(const TextFile &f, const std::vector<rb_
 }
 } // namespace
 
-bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text) {
+bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text, TextRuns *runs) {
     // (one-shot command: the gigabytes behind these two are left to the end of the process instead of being unmapped piece by piece)
     TextFile &f = *new TextFile;
     if (!f.load(paf_path)) return false; // the caller takes the general path
     double tl = now_s();
     const size_t n = f.recs.size();
+    if (runs) { // the records' contigs by first appearance (before windows on other names get ids of their own below)
+        runs->contigs.assign(f.contig_id.size(), std::string());
+        for (const auto &kv : f.contig_id) runs->contigs[kv.second].assign(kv.first.data(), kv.first.size());
+    }
     std::vector<uint32_t> w_contig(rgns.size());
     std::vector<uint64_t> w_st(rgns.size()), w_en(rgns.size());
     for (size_t i = 0; i < rgns.size(); i++) {
@@ -900,7 +1108,9 @@ bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vec
     lap("rb_host_liftover_text", tl);
     if (!f.check_loaded(cig_status, red)) return false;
     for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i); // liftover.rs:119-121
-    out_text = assemble_lines(f, norm, R, &rgns);
+    RunMarks marks;
+    out_text = assemble_lines(f, norm, R, &rgns, runs ? &marks : nullptr);
+    if (runs) marks_to_runs(marks, out_text, *runs);
     lap("assemble lines", tl);
     return true;
 }

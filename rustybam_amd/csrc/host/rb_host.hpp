@@ -75,6 +75,17 @@ struct Paf { // paf::Paf (paf.rs:34-37)
 // `rb --gpus N` (the record shards of liftover.rs:123-129, one worker process per GPU): the readers below then load only bytes
 // [begin, end) of a plain input file; read_input_text: the whole decompressed text of a file or stdin ("-")
 void set_input_slice(uint64_t begin, uint64_t end);
+// `rb --gpus N trim-paf` (query groups are the unit, paf.rs:223): the readers keep only the lines whose query name lies in [lo, hi)
+// (bytewise order, nullptr = open); query_name_cuts: the names that cut a plain file's sorted query names into n ranges of about equal bytes
+void set_input_query_range(const std::string *lo, const std::string *hi);
+std::vector<std::string> query_name_cuts(const std::string &file_name, int n);
+// where the contigs lie in a liftover output (canonical order is contig-major, liftover.rs:151-164): what `rb --gpus N` needs to
+// put the shards' outputs together.  contigs = target names of the (possibly swapped) records in order of first appearance,
+// runs = (index into contigs, bytes of output text) in output order
+struct TextRuns {
+    std::vector<std::string> contigs;
+    std::vector<std::pair<uint32_t, uint64_t>> runs;
+};
 std::string read_input_text(const std::string &file_name);
 
 std::string cigar_to_string(const std::vector<uint32_t> &cigar);
@@ -89,10 +100,12 @@ std::vector<PafRecord> paf_swap_query_and_target(Engine &eng, const std::vector<
 // liftover::trim_paf_by_rgns (liftover.rs:134-167), single-thread output order
 std::vector<PafRecord> trim_paf_by_rgns(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query);
 // the same, printed: every Some(rec) as `println!("{}", rec)` would, without materialising the records
-std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query);
+std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Region> &rgns, const std::vector<PafRecord> &paf_recs, bool invert_query,
+                                               TextRuns *runs = nullptr);
 // main.rs:186-214 without --qbed / --largest, text in -> text out: the CIGAR text is parsed and printed on the device
 // (rb_host_liftover_text); false = the file needs the general path (a line with two cg tags), nothing was produced
-bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text);
+bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text,
+                        TextRuns *runs = nullptr);
 bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_length, std::vector<std::string> &out_text); // main.rs:271-281
 bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, int diff_score, int indel_score, bool remove_contained,
                     std::vector<std::string> &out_text); // main.rs:218-230, the batch resident on the device across the passes

@@ -8,11 +8,15 @@
 #include <cstring>
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/socket.h>
 #include <sys/stat.h>
 #include <sys/wait.h>
 #include <unistd.h>
+#include <map>
 #include <string>
 #include <thread>
+#include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include <chrono>
@@ -40,8 +44,8 @@ static int usage() {
             "  orient [-s|--scaffold] [-i|--insert 1000000] [PAF]\n"
             "  filter [-p|--paired-len 0] [-a|--aln 0] [-q|--query 0] [PAF]\n"
             "  nucfreq [-r|--region chr:st-en] [-b|--bed <BED>] [-s|--small] <BAM>\n"
-            "--gpus N: the PAF records in N contiguous shards, one worker process per GPU (liftover without --largest, break-paf,\n"
-            "          stats --paf, invert); the output is the single-GPU output byte for byte.\n"
+            "--gpus N: the PAF records in N shards, one worker process per GPU (liftover, break-paf, stats --paf, invert: contiguous\n"
+            "          runs of lines; trim-paf: ranges of the sorted query names); the output is the single-GPU output byte for byte.\n"
             "Every other rustybam subcommand is outside this engine's scope.\n");
     return 2;
 }
@@ -175,13 +179,176 @@ static int synth_bed(uint64_t n_win) {
     return 0;
 }
 
-// `rb --gpus N`: SURVEY 8(e) -- PAF records are independent (liftover.rs:123-129 hands them to rayon), so the input is cut into N
-// runs of whole lines of about equal bytes (CIGAR text is what weighs) and N worker processes are forked BEFORE anything touches
-// the GPU; worker k takes device `device + k`, reads only its lines, and writes to a pipe; the parent never initialises HIP, it
-// concatenates the pipes in shard order.  Returns -1 in a worker (which carries on as an ordinary single-GPU run over its slice),
-// the exit code in the parent: that of the first shard that failed, after the output of the shards before it and its own.
-static int g_rank = 0;
-static int shard_fork(int n, std::string &path, int &device) {
+// ---- `rb --gpus N` -----------------------------------------------------------------------------------------------
+// PAF records are independent (liftover.rs:123-129 hands them to rayon), so the input is cut into N runs of whole lines of about
+// equal bytes (CIGAR text is what weighs) -- for trim-paf, whose unit is the query-name group (paf.rs:223, :235), into N ranges of
+// the sorted query names -- and N worker processes are forked BEFORE anything touches the GPU; worker k takes device `device + k`
+// and runs the ordinary single-GPU command over its lines.  No data-path collective: the workers' outputs are put together on the
+// host.  The parent never initialises HIP and never holds output text: a worker keeps its output in memory (as the single run
+// does), tells the parent what PIECES it consists of (a small index over a socket), and is told in which order -- and, when stdout
+// is a regular file, at which file offsets -- to write them:
+//   concat   break-paf, stats --paf, invert, trim-paf: one piece per worker, shard order = record order (= sorted-name order).
+//   contig   liftover: the reference emits contig-major, contigs by first appearance over the WHOLE file (liftover.rs:151-164), and
+//            within a contig in record order.  A worker's pieces are its per-contig runs; it also lists every contig of its records
+//            in local first-appearance order (also those without output: they still take their rank).  Global rank = first
+//            appearance over (shard, local rank); pieces go out by (rank, shard).  `A B | A B` gives `A A B B`, as one GPU does.
+//   largest  liftover --largest (main.rs:200-208): stable sort by id, keep the LAST record of maximal target span per id.  Workers
+//            reduce per (id, contig) and send one candidate line each; the parent keeps, per id, the greatest span, among equals the
+//            last in canonical order (contig rank, shard, local order), and has the winners written in id order.
+// Into a regular file the workers pwrite side by side (no byte passes through the parent); otherwise each worker writes its pieces
+// in the order it was given into its own pipe and the parent copies exactly the announced byte counts to stdout in global order.
+// A worker that fails (a reference panic: exit code 101) does so before it sends its index, as the single run panics before it
+// prints: the parent then has nothing written and returns the code of the first shard that failed.
+namespace {
+enum GatherMode { GATHER_CONCAT, GATHER_CONTIG, GATHER_LARGEST };
+struct Piece {
+    uint32_t contig = 0; // index into Output::contigs
+    std::string key;     // largest: the record's id
+    uint64_t aux = 0;    // largest: target span
+    uint64_t bytes = 0;
+};
+struct Output {
+    std::vector<std::string> chunks;  // the text, in local output order
+    std::vector<std::string> contigs; // liftover: the records' contigs, local first-appearance order
+    std::vector<Piece> pieces;        // consecutive byte ranges of the chunks' concatenation (none = one piece holding everything)
+};
+struct Worker {
+    bool on = false, to_file = false;
+    int ctl = -1;
+} g_worker;
+
+bool write_all(int fd, const void *p, size_t n) {
+    const char *c = (const char *)p;
+    while (n) {
+        const ssize_t w = write(fd, c, n);
+        if (w <= 0) return false;
+        c += w, n -= (size_t)w;
+    }
+    return true;
+}
+bool read_all_fd(int fd, void *p, size_t n) {
+    char *c = (char *)p;
+    while (n) {
+        const ssize_t r = read(fd, c, n);
+        if (r <= 0) return false;
+        c += r, n -= (size_t)r;
+    }
+    return true;
+}
+void msg_u64(std::string &m, uint64_t v) { m.append((const char *)&v, 8); }
+void msg_str(std::string &m, const std::string &v) { msg_u64(m, v.size()), m.append(v); }
+struct MsgIn {
+    std::string buf;
+    size_t at = 0;
+    bool ok = true;
+    uint64_t u64() {
+        uint64_t v = 0;
+        if (at + 8 > buf.size()) { ok = false; return 0; }
+        memcpy(&v, buf.data() + at, 8), at += 8;
+        return v;
+    }
+    std::string str() {
+        const uint64_t n = u64();
+        if (!ok || at + n > buf.size()) { ok = false; return std::string(); }
+        std::string v = buf.substr(at, (size_t)n);
+        at += (size_t)n;
+        return v;
+    }
+};
+bool send_msg(int fd, const std::string &m) {
+    const uint64_t n = m.size();
+    return write_all(fd, &n, 8) && write_all(fd, m.data(), m.size());
+}
+bool recv_msg(int fd, MsgIn &m) {
+    uint64_t n = 0;
+    if (!read_all_fd(fd, &n, 8) || n > ((uint64_t)1 << 40)) return false;
+    m.buf.resize((size_t)n), m.at = 0, m.ok = true;
+    return read_all_fd(fd, &m.buf[0], (size_t)n);
+}
+
+// worker side: announce the pieces, learn order / offsets, write, leave
+[[noreturn]] void worker_emit(Output &o) {
+    uint64_t total = 0;
+    for (const std::string &c : o.chunks) total += c.size();
+    if (o.pieces.empty()) {
+        Piece p;
+        p.bytes = total;
+        o.pieces.push_back(p);
+        if (o.contigs.empty()) o.contigs.push_back(std::string());
+    }
+    std::string m;
+    msg_u64(m, o.contigs.size());
+    for (const std::string &c : o.contigs) msg_str(m, c);
+    msg_u64(m, o.pieces.size());
+    for (const Piece &p : o.pieces) msg_u64(m, p.contig), msg_str(m, p.key), msg_u64(m, p.aux), msg_u64(m, p.bytes);
+    MsgIn plan;
+    if (!send_msg(g_worker.ctl, m) || !recv_msg(g_worker.ctl, plan)) _exit(1); // (the parent gave up: another shard failed)
+    std::vector<uint64_t> start(o.pieces.size() + 1, 0), cstart(o.chunks.size() + 1, 0);
+    for (size_t k = 0; k < o.pieces.size(); k++) start[k + 1] = start[k] + o.pieces[k].bytes;
+    for (size_t k = 0; k < o.chunks.size(); k++) cstart[k + 1] = cstart[k] + o.chunks[k].size();
+    struct Seg { const char *p; size_t n; int64_t at; };
+    std::vector<Seg> segs;
+    const uint64_t n_writes = plan.u64();
+    for (uint64_t w = 0; w < n_writes && plan.ok; w++) {
+        const uint64_t k = plan.u64();
+        int64_t at = (int64_t)plan.u64();
+        if (!plan.ok || k >= o.pieces.size()) _exit(1);
+        uint64_t a = start[k];
+        const uint64_t e = start[k + 1];
+        size_t c = (size_t)(std::upper_bound(cstart.begin(), cstart.end(), a) - cstart.begin()) - 1;
+        while (a < e) { // the chunks this piece runs through, in parts of at most 64 MB
+            while (c < o.chunks.size() && cstart[c + 1] <= a) c++;
+            const uint64_t n = std::min<uint64_t>(std::min(e, cstart[c + 1]) - a, (uint64_t)64 << 20);
+            segs.push_back({o.chunks[c].data() + (a - cstart[c]), (size_t)n, at});
+            a += n;
+            if (at >= 0) at += (int64_t)n;
+        }
+    }
+    bool ok = true;
+    if (g_worker.to_file) {
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 8));
+        std::vector<std::thread> th;
+        std::vector<int> bad(T, 0);
+        for (unsigned t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                for (size_t k = t; k < segs.size(); k += T) {
+                    size_t d = 0;
+                    while (d < segs[k].n) {
+                        const ssize_t w = pwrite(1, segs[k].p + d, segs[k].n - d, (off_t)(segs[k].at + (int64_t)d));
+                        if (w <= 0) { bad[t] = 1; return; }
+                        d += (size_t)w;
+                    }
+                }
+            });
+        for (auto &x : th) x.join();
+        for (int b : bad) ok = ok && !b;
+    } else {
+        for (const Seg &sg : segs) ok = ok && write_all(1, sg.p, sg.n);
+    }
+    if (!ok) perror("rb: write");
+    close(1);
+    if (getenv("RB_TIMING")) fprintf(stderr, "[rb timing] worker: main entry to last byte written %.3f s\n", now_s() - g_t_main);
+    fflush(stderr);
+    const char *pre = getenv("LD_PRELOAD");
+    if (getenv("RB_FULL_EXIT") || (pre && strstr(pre, "rocprofiler"))) exit(ok ? 0 : 1);
+    _exit(ok ? 0 : 1);
+}
+} // namespace
+
+// what a finished arm does with its text: the single run prints it; a `--gpus` worker hands it to the gather (and does not return)
+static void emit(Output &o) {
+    if (g_worker.on) worker_emit(o);
+    put(o.chunks);
+}
+static void emit(std::vector<std::string> &chunks) {
+    Output o;
+    o.chunks.swap(chunks);
+    emit(o);
+}
+
+// parent side.  Returns -1 in a worker (which carries on as an ordinary single-GPU run over its share of the input), the exit code
+// in the parent.  `header`: printed by the parent before anything else (stats --paf).
+static int shard_fork(int n, GatherMode mode, bool by_query, std::string &path, int &device, const std::string &header) {
     int fd = -1;
     bool plain = false;
     if (path != "-") {
@@ -196,21 +363,16 @@ static int shard_fork(int n, std::string &path, int &device) {
     }
     if (!plain) { // stdin / gzip: the text into an anonymous file every worker inherits
         if (fd >= 0) close(fd);
-        std::string all;
+        fd = memfd_create("rb_input", 0);
+        bool ok = fd >= 0;
         try {
-            all = rb::read_input_text(path);
+            const std::string all = rb::read_input_text(path);
+            ok = ok && write_all(fd, all.data(), all.size());
         } catch (const rb::Panic &e) {
             fprintf(stderr, "thread 'main' panicked: %s\n", e.what());
             return 101;
-        }
-        fd = memfd_create("rb_input", 0);
-        size_t off = 0;
-        while (fd >= 0 && off < all.size()) {
-            const ssize_t w = write(fd, all.data() + off, all.size() - off);
-            if (w <= 0) break;
-            off += (size_t)w;
-        }
-        if (fd < 0 || off != all.size()) {
+        } // (the text itself is gone here: the anonymous file is the only copy)
+        if (!ok) {
             fprintf(stderr, "rb: cannot buffer the input for --gpus\n");
             return 1;
         }
@@ -220,66 +382,235 @@ static int shard_fork(int n, std::string &path, int &device) {
     fstat(fd, &st);
     const uint64_t size = (uint64_t)st.st_size;
     std::vector<uint64_t> cut(n + 1, size);
-    cut[0] = 0;
-    std::vector<char> buf(1 << 16);
-    for (int k = 1; k < n; k++) { // the first line start at or behind size * k / n
-        uint64_t at = std::max(cut[k - 1], size / (uint64_t)n * (uint64_t)k);
-        bool found = at == 0;
-        if (!found && at < size) { // (a cut must follow a newline: look from one byte earlier)
-            at -= 1;
-            while (at < size && !found) {
-                const ssize_t r = pread(fd, buf.data(), buf.size(), (off_t)at);
-                if (r <= 0) break;
-                const void *nl = memchr(buf.data(), '\n', (size_t)r);
-                if (nl) at += (uint64_t)((const char *)nl - buf.data()) + 1, found = true;
-                else at += (uint64_t)r;
+    std::vector<std::string> qcut;
+    if (by_query) {
+        try {
+            qcut = rb::query_name_cuts(path, n);
+        } catch (const rb::Panic &e) {
+            fprintf(stderr, "thread 'main' panicked: %s\n", e.what());
+            return 101;
+        }
+        n = (int)qcut.size() + 1; // (fewer names than GPUs: fewer workers)
+    } else {
+        cut[0] = 0;
+        std::vector<char> buf(1 << 16);
+        for (int k = 1; k < n; k++) { // the first line start at or behind size * k / n
+            uint64_t at = std::max(cut[k - 1], size / (uint64_t)n * (uint64_t)k);
+            bool found = at == 0;
+            if (!found && at < size) { // (a cut must follow a newline: look from one byte earlier)
+                at -= 1;
+                while (at < size && !found) {
+                    const ssize_t r = pread(fd, buf.data(), buf.size(), (off_t)at);
+                    if (r <= 0) break;
+                    const void *nl = memchr(buf.data(), '\n', (size_t)r);
+                    if (nl) at += (uint64_t)((const char *)nl - buf.data()) + 1, found = true;
+                    else at += (uint64_t)r;
+                }
             }
-        }
-        cut[k] = found ? std::min(at, size) : size;
-    }
-    const bool same = getenv("RB_GPUS_SAME_DEVICE") != nullptr; // (diagnostic: every worker on --device, to try the gather on one GPU)
-    std::vector<int> rd(n, -1);
-    std::vector<pid_t> pid(n, -1);
-    for (int k = 0; k < n; k++) {
-        int pp[2];
-        if (pipe(pp) != 0) return 1;
-        const pid_t c = fork();
-        if (c < 0) return 1;
-        if (c == 0) {
-            for (int j = 0; j < k; j++) close(rd[j]);
-            close(pp[0]);
-            dup2(pp[1], 1);
-            close(pp[1]);
-            g_rank = k;
-            if (!same) device += k;
-            rb::set_input_slice(cut[k], cut[k + 1]);
-            return -1;
-        }
-        close(pp[1]);
-        rd[k] = pp[0], pid[k] = c;
-    }
-    std::vector<std::string> out(n);
-    std::vector<std::thread> th;
-    for (int k = 0; k < n; k++)
-        th.emplace_back([&, k]() {
-            std::vector<char> b(1 << 20);
-            ssize_t r;
-            while ((r = read(rd[k], b.data(), b.size())) > 0) out[k].append(b.data(), (size_t)r);
-            close(rd[k]);
-        });
-    int rc = 0;
-    for (int k = 0; k < n; k++) {
-        th[k].join();
-        int st_k = 0;
-        waitpid(pid[k], &st_k, 0);
-        const int rc_k = WIFEXITED(st_k) ? WEXITSTATUS(st_k) : 1;
-        if (rc == 0) { // (what a later shard printed after an earlier one failed is not output the single run would have made)
-            fwrite(out[k].data(), 1, out[k].size(), stdout);
-            rc = rc_k;
+            cut[k] = found ? std::min(at, size) : size;
         }
     }
     fflush(stdout);
-    return rc;
+    if (!header.empty() && !write_all(1, header.data(), header.size())) return 1;
+    struct stat so;
+    const int fl = fcntl(1, F_GETFL);
+    off_t base = -1;
+    if (fstat(1, &so) == 0 && S_ISREG(so.st_mode) && fl >= 0 && !(fl & O_APPEND)) base = lseek(1, 0, SEEK_CUR);
+    const bool to_file = base >= 0;
+    const bool same = getenv("RB_GPUS_SAME_DEVICE") != nullptr; // (diagnostic: every worker on --device, to try the gather on one GPU)
+    std::vector<int> rd(n, -1), ctl(n, -1);
+    std::vector<pid_t> pid(n, -1);
+    for (int k = 0; k < n; k++) {
+        int pp[2] = {-1, -1}, sp[2];
+        if (socketpair(AF_UNIX, SOCK_STREAM, 0, sp) != 0) return 1;
+        if (!to_file && pipe(pp) != 0) return 1;
+        const pid_t c = fork();
+        if (c < 0) return 1;
+        if (c == 0) {
+            for (int j = 0; j < k; j++) {
+                if (rd[j] >= 0) close(rd[j]);
+                close(ctl[j]);
+            }
+            close(sp[0]);
+            if (!to_file) {
+                close(pp[0]);
+                dup2(pp[1], 1);
+                close(pp[1]);
+            }
+            g_worker.on = true, g_worker.to_file = to_file, g_worker.ctl = sp[1];
+            if (!same) device += k;
+            if (by_query) rb::set_input_query_range(k > 0 ? &qcut[k - 1] : nullptr, k + 1 < n ? &qcut[k] : nullptr);
+            else rb::set_input_slice(cut[k], cut[k + 1]);
+            return -1;
+        }
+        close(sp[1]);
+        if (!to_file) close(pp[1]), rd[k] = pp[0];
+        ctl[k] = sp[0], pid[k] = c;
+    }
+    // the workers' indexes
+    struct Item { uint64_t rank; int shard; uint64_t idx, bytes; };
+    std::vector<std::vector<std::string>> contigs(n);
+    std::vector<std::vector<Piece>> pieces(n);
+    bool all_ok = true;
+    std::vector<char> failed(n, 0);
+    for (int k = 0; k < n; k++) {
+        MsgIn m;
+        bool ok = recv_msg(ctl[k], m);
+        if (ok) {
+            const uint64_t nc = m.u64();
+            for (uint64_t i = 0; i < nc && m.ok; i++) contigs[k].push_back(m.str());
+            const uint64_t np = m.u64();
+            for (uint64_t i = 0; i < np && m.ok; i++) {
+                Piece p;
+                p.contig = (uint32_t)m.u64(), p.key = m.str(), p.aux = m.u64(), p.bytes = m.u64();
+                if (p.contig >= contigs[k].size()) m.ok = false;
+                pieces[k].push_back(std::move(p));
+            }
+            ok = m.ok;
+        }
+        all_ok = all_ok && ok;
+        failed[k] = !ok;
+    }
+    auto reap = [&]() { // the exit code of the first shard that failed by itself (the others only stop because the parent gave up)
+        int rc = 0, rc_own = 0;
+        for (int k = 0; k < n; k++) {
+            int st_k = 0;
+            waitpid(pid[k], &st_k, 0);
+            const int rc_k = WIFEXITED(st_k) ? WEXITSTATUS(st_k) : 1;
+            if (rc == 0) rc = rc_k;
+            if (rc_own == 0 && failed[k]) rc_own = rc_k ? rc_k : 1;
+        }
+        return rc_own ? rc_own : rc;
+    };
+    if (!all_ok) { // a shard failed (it has said why on stderr): nobody writes
+        for (int k = 0; k < n; k++) close(ctl[k]);
+        const int rc = reap();
+        return rc ? rc : 1;
+    }
+    // the global order
+    std::unordered_map<std::string, uint64_t> rank;
+    for (int k = 0; k < n; k++)
+        for (const std::string &c : contigs[k]) rank.emplace(c, (uint64_t)rank.size());
+    std::vector<Item> plan;
+    if (mode == GATHER_LARGEST) {
+        struct Best { uint64_t aux; Item it; };
+        std::map<std::string, Best> best; // bytewise order of the ids = Rust's String order
+        for (int k = 0; k < n; k++)
+            for (uint64_t i = 0; i < pieces[k].size(); i++) {
+                const Piece &p = pieces[k][i];
+                const Item it{rank[contigs[k][p.contig]], k, i, p.bytes};
+                auto f = best.find(p.key);
+                if (f == best.end()) { best.emplace(p.key, Best{p.aux, it}); continue; }
+                Best &b = f->second;
+                const bool later = std::make_tuple(it.rank, it.shard, it.idx) > std::make_tuple(b.it.rank, b.it.shard, b.it.idx);
+                if (p.aux > b.aux || (p.aux == b.aux && later)) b = Best{p.aux, it};
+            }
+        for (auto &kv : best) plan.push_back(kv.second.it);
+    } else {
+        for (int k = 0; k < n; k++)
+            for (uint64_t i = 0; i < pieces[k].size(); i++)
+                plan.push_back({mode == GATHER_CONTIG ? rank[contigs[k][pieces[k][i].contig]] : 0, k, i, pieces[k][i].bytes});
+        if (mode == GATHER_CONTIG)
+            std::stable_sort(plan.begin(), plan.end(), [](const Item &a, const Item &b) { return a.rank < b.rank; }); // (shard, idx) order kept inside a rank
+    }
+    std::vector<std::string> msg(n);
+    std::vector<uint64_t> count(n, 0);
+    uint64_t at = to_file ? (uint64_t)base : 0;
+    for (const Item &it : plan) count[it.shard]++;
+    for (int k = 0; k < n; k++) msg_u64(msg[k], count[k]);
+    for (const Item &it : plan) {
+        msg_u64(msg[it.shard], it.idx);
+        msg_u64(msg[it.shard], to_file ? at : ~(uint64_t)0);
+        at += it.bytes;
+    }
+    bool ok = true;
+    for (int k = 0; k < n; k++) ok = send_msg(ctl[k], msg[k]) && ok;
+    if (!to_file && ok) { // exactly the announced bytes of each piece, in global order
+        std::vector<char> b((size_t)4 << 20);
+        for (const Item &it : plan) {
+            uint64_t left = it.bytes;
+            while (left && ok) {
+                const ssize_t r = read(rd[it.shard], b.data(), (size_t)std::min<uint64_t>(left, b.size()));
+                if (r <= 0) { ok = false; break; }
+                ok = write_all(1, b.data(), (size_t)r);
+                left -= (uint64_t)r;
+            }
+        }
+    }
+    for (int k = 0; k < n; k++) {
+        close(ctl[k]);
+        if (rd[k] >= 0) close(rd[k]);
+    }
+    const int rc = reap();
+    if (to_file) lseek(1, (off_t)at, SEEK_SET);
+    return rc ? rc : (ok ? 0 : 1);
+}
+
+// `rb [--gpus N] regroup [-q] [-l] <PAF>`: not a reference subcommand and no device work -- the lines of a PAF file put in the ORDER
+// the hot-path commands emit (so that the `--gpus` gather can be checked on a machine without a GPU, tests/test_rb_gather_cpu.py):
+// default = liftover's canonical order with one output line per record (contig-major by first appearance of column 6, then file
+// order); -q = trim-paf's order (stable sort by column 1); -l = liftover --largest's reduction with id := column 1, span := col 9 - col 8.
+static int regroup(const std::string &path, bool by_query, bool largest_) {
+    const std::string all = rb::read_input_text(path);
+    struct Ln { std::string_view text, q, t; uint64_t span; uint32_t contig; };
+    std::vector<Ln> lines;
+    Output o;
+    std::unordered_map<std::string, uint32_t> cid;
+    for (size_t a = 0; a < all.size();) {
+        size_t e = all.find('\n', a);
+        if (e == std::string::npos) e = all.size();
+        std::string_view ln(all.data() + a, e - a);
+        std::vector<std::string_view> col;
+        for (size_t i = 0; i < ln.size() && col.size() < 9;) {
+            size_t j = ln.find('\t', i);
+            if (j == std::string_view::npos) j = ln.size();
+            col.push_back(ln.substr(i, j - i));
+            i = j + 1;
+        }
+        if (col.size() >= 9) {
+            Ln l{ln, col[0], col[5], strtoull(std::string(col[8]).c_str(), nullptr, 10) - strtoull(std::string(col[7]).c_str(), nullptr, 10), 0};
+            auto it = cid.emplace(std::string(l.t), (uint32_t)o.contigs.size());
+            if (it.second) o.contigs.push_back(std::string(l.t));
+            l.contig = it.first->second;
+            lines.push_back(l);
+        }
+        a = e + 1;
+    }
+    o.chunks.emplace_back();
+    auto add = [&](const Ln &l, const std::string &key, bool new_piece) {
+        if (new_piece || o.pieces.empty()) {
+            Piece p;
+            p.contig = l.contig, p.key = key, p.aux = l.span;
+            o.pieces.push_back(p);
+        }
+        o.chunks[0].append(l.text), o.chunks[0].push_back('\n');
+        o.pieces.back().bytes += l.text.size() + 1;
+    };
+    if (by_query) {
+        std::stable_sort(lines.begin(), lines.end(), [](const Ln &x, const Ln &y) { return x.q < y.q; });
+        for (const Ln &l : lines) o.chunks[0].append(l.text), o.chunks[0].push_back('\n');
+        o.contigs.clear(); // (one piece: worker_emit fills it in)
+    } else {
+        std::stable_sort(lines.begin(), lines.end(), [](const Ln &x, const Ln &y) { return x.contig < y.contig; });
+        if (largest_) {
+            std::stable_sort(lines.begin(), lines.end(), [](const Ln &x, const Ln &y) { return x.q < y.q; });
+            for (size_t i = 0; i < lines.size();) {
+                size_t j = i, best = i;
+                for (; j < lines.size() && lines[j].q == lines[i].q && (!g_worker.on || lines[j].contig == lines[i].contig); j++)
+                    if (lines[j].span >= lines[best].span) best = j;
+                add(lines[best], std::string(lines[best].q), true);
+                i = j;
+            }
+        } else {
+            for (size_t i = 0; i < lines.size(); i++) add(lines[i], std::string(), i == 0 || lines[i].contig != lines[i - 1].contig);
+        }
+        if (o.contigs.empty()) o.contigs.push_back(std::string());
+        if (o.pieces.empty()) o.pieces.push_back(Piece());
+    }
+    if (!g_worker.on) o.pieces.clear();
+    emit(o);
+    fflush(stdout);
+    return 0;
 }
 
 int main(int argc, char **argv) {
@@ -335,13 +666,17 @@ int main(int argc, char **argv) {
     }
     if (gpus > 1) {
         const bool lift = cmd == "liftover" || cmd == "lo", brk = cmd == "break-paf" || cmd == "breakpaf" || cmd == "bp";
-        if (!((lift && !largest && !bed_path.empty()) || brk || (cmd == "stats" && is_paf) || cmd == "invert")) {
-            fprintf(stderr, "rb: --gpus shards PAF records: liftover (without --largest), break-paf, stats --paf, invert\n");
+        const bool stats_paf = cmd == "stats" && is_paf;
+        const bool regr = cmd == "regroup";
+        if (!((lift && !bed_path.empty()) || brk || stats_paf || cmd == "invert" || trim || regr)) {
+            fprintf(stderr, "rb: --gpus shards PAF records: liftover, break-paf, stats --paf, invert, trim-paf\n");
             return 2;
         }
-        const int rc = shard_fork(gpus, paf_path, device);
+        const GatherMode mode = lift || (regr && !qbed) ? (largest ? GATHER_LARGEST : GATHER_CONTIG) : GATHER_CONCAT;
+        const int rc = shard_fork(gpus, mode, trim || (regr && qbed), paf_path, device, stats_paf ? rb::cigar_stats_header(qbed) : std::string());
         if (rc >= 0) return rc;
     }
+    if (cmd == "regroup") return regroup(paf_path, qbed, largest);
     try {
         double tl = now_s();
         // text in -> text out (CIGAR text parsed / printed on the device) for regular files; stdin and RB_GENERAL_PATH=1 take the
@@ -357,7 +692,7 @@ int main(int argc, char **argv) {
                 for (rb::Region &r : rb::parse_bed(bed_path)) rgns.push_back(std::move(r));
             rb::nucfreq_bam(eng, paf_path, rgns, small, [&](const std::string &t) { put(t); });
         } else if (cmd == "stats") {
-            if (g_rank == 0) put(rb::cigar_stats_header(qbed));
+            if (!g_worker.on) put(rb::cigar_stats_header(qbed)); // (`--gpus`: the parent has printed it)
             if (!is_paf) { // BAM input (main.rs:60-77)
                 std::string panic;
                 for (const rb::Stats &s : rb::cigar_stats_bam(eng, paf_path, &panic)) put(rb::cigar_stats_line(s, qbed));
@@ -365,28 +700,46 @@ int main(int argc, char **argv) {
             } else {
                 std::vector<std::string> text;
                 if (text_path && rb::stats_file_text(eng, paf_path, qbed, text)) {
-                    put(text);
+                    emit(text);
                 } else {
                     rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-                    for (const rb::Stats &s : rb::stats_from_paf(eng, paf.records)) put(rb::cigar_stats_line(s, qbed));
+                    text.assign(1, std::string());
+                    for (const rb::Stats &s : rb::stats_from_paf(eng, paf.records)) text[0] += rb::cigar_stats_line(s, qbed);
+                    emit(text);
                 }
             }
         } else if (cmd == "invert") {
             std::vector<std::string> text;
-            if (text_path && rb::invert_file_text(eng, paf_path, text)) {
-                put(text);
-            } else {
+            if (!(text_path && rb::invert_file_text(eng, paf_path, text))) {
                 rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-                put(rb::records_to_text(rb::paf_swap_query_and_target(eng, paf.records)));
+                text = rb::records_to_text(rb::paf_swap_query_and_target(eng, paf.records));
             }
+            emit(text);
         } else if (cmd == "liftover" || cmd == "lo") {
             if (bed_path.empty()) return usage();
             std::vector<rb::Region> rgns = rb::parse_bed(bed_path);
+            rb::TextRuns runs;
+            auto with_runs = [&](std::vector<std::string> &text) { // a worker of `--gpus` announces where its contigs lie
+                Output o;
+                o.chunks.swap(text);
+                if (g_worker.on) {
+                    o.contigs = runs.contigs;
+                    for (const auto &r : runs.runs) {
+                        Piece p;
+                        p.contig = r.first, p.bytes = r.second;
+                        o.pieces.push_back(p);
+                    }
+                    if (o.contigs.empty()) o.contigs.push_back(std::string()); // (no record at all)
+                    if (o.pieces.empty()) o.pieces.push_back(Piece());
+                }
+                return o;
+            };
             if (!largest && !qbed && text_path) { // text in -> text out, CIGAR text handled on the device
                 std::vector<std::string> text;
-                if (rb::liftover_file_text(eng, paf_path, rgns, text)) {
+                if (rb::liftover_file_text(eng, paf_path, rgns, text, g_worker.on ? &runs : nullptr)) {
                     lap("liftover (text to text)", tl);
-                    put(text);
+                    Output o = with_runs(text);
+                    emit(o);
                     fflush(stdout);
                     lap("write", tl);
                     done(0);
@@ -396,29 +749,47 @@ int main(int argc, char **argv) {
             lap("decode + check_integrity", tl);
             if (largest) { // main.rs:200-208: stable sort by id, keep the LAST record with maximal target span per id
                 std::vector<rb::PafRecord> out = rb::trim_paf_by_rgns(eng, rgns, paf.records, qbed);
+                Output o;
+                o.chunks.emplace_back();
+                std::unordered_map<std::string, uint32_t> cid; // (a worker: the contigs of its records, first appearance order)
+                if (g_worker.on)
+                    for (const rb::PafRecord &r : paf.records) {
+                        const std::string &nm = qbed ? r.q_name : r.t_name;
+                        if (cid.emplace(nm, (uint32_t)o.contigs.size()).second) o.contigs.push_back(nm);
+                    }
                 std::stable_sort(out.begin(), out.end(), [](const rb::PafRecord &x, const rb::PafRecord &y) { return x.id < y.id; });
                 for (size_t i = 0; i < out.size();) {
+                    // a worker keeps one candidate per (id, contig): equal ids are still in canonical, i.e. contig-major, order
                     size_t j = i, best = i;
-                    for (; j < out.size() && out[j].id == out[i].id; j++)
+                    for (; j < out.size() && out[j].id == out[i].id && (!g_worker.on || out[j].t_name == out[i].t_name); j++)
                         if (out[j].t_en - out[j].t_st >= out[best].t_en - out[best].t_st) best = j;
-                    put(out[best].to_string() + "\n");
+                    const std::string line = out[best].to_string() + "\n";
+                    o.chunks[0] += line;
+                    if (g_worker.on) {
+                        Piece p;
+                        p.contig = cid[out[best].t_name], p.key = out[best].id, p.aux = out[best].t_en - out[best].t_st, p.bytes = line.size();
+                        o.pieces.push_back(std::move(p));
+                    }
                     i = j;
                 }
+                if (g_worker.on && o.contigs.empty()) o.contigs.push_back(std::string());
+                if (g_worker.on && o.pieces.empty()) o.pieces.push_back(Piece());
+                emit(o);
             } else {
-                const std::vector<std::string> text = rb::trim_paf_by_rgns_text(eng, rgns, paf.records, qbed);
+                std::vector<std::string> text = rb::trim_paf_by_rgns_text(eng, rgns, paf.records, qbed, g_worker.on ? &runs : nullptr);
                 lap("liftover (device + encode)", tl);
-                put(text);
+                Output o = with_runs(text);
+                emit(o);
                 fflush(stdout);
                 lap("write", tl);
             }
         } else if (cmd == "break-paf" || cmd == "breakpaf" || cmd == "bp") {
             std::vector<std::string> text;
-            if (text_path && rb::break_file_text(eng, paf_path, max_size, text)) {
-                put(text);
-            } else {
+            if (!(text_path && rb::break_file_text(eng, paf_path, max_size, text))) {
                 rb::Paf paf = rb::Paf::from_file(eng, paf_path);
-                put(rb::break_paf_on_indels_text(eng, paf.records, max_size));
+                text = rb::break_paf_on_indels_text(eng, paf.records, max_size);
             }
+            emit(text);
         } else if (filter) { // main.rs:234-249
             rb::Paf paf = rb::Paf::from_file(eng, paf_path);
             paf.filter_query_len(min_query);
@@ -434,7 +805,7 @@ int main(int argc, char **argv) {
             std::vector<std::string> ttext;
             if (text_path && rb::trim_file_text(eng, paf_path, ms, ds, is, remove_contained, ttext)) {
                 lap("trim-paf (text to text)", tl);
-                put(ttext);
+                emit(ttext);
                 fflush(stdout);
                 lap("write", tl);
                 done(0);
@@ -443,9 +814,9 @@ int main(int argc, char **argv) {
             lap("decode + check_integrity", tl);
             paf.overlapping_paf_recs(eng, ms, ds, is, remove_contained);
             lap("overlapping_paf_recs (passes)", tl);
-            const std::vector<std::string> text = rb::records_to_text(paf.records);
+            std::vector<std::string> text = rb::records_to_text(paf.records);
             lap("encode", tl);
-            put(text);
+            emit(text);
             fflush(stdout);
             lap("write", tl);
         } else {

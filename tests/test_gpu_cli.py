@@ -441,24 +441,65 @@ def test_nucfreq_bai_index_and_full_scan_agree(oracle, golden, tmp_path):
     assert os.path.exists(f"{golden}/asm_small.bam.bai")
 
 
+def _shuffled(golden, tmp_path, seed):
+    """the fixture's records in random order: target contigs and query names interleave (the fixture itself is sorted by target)"""
+    import random
+    lines = [l for l in open(f"{golden}/asm_small.paf", "rb").read().split(b"\n") if l]
+    random.Random(seed).shuffle(lines)
+    p = tmp_path / f"shuf{seed}.paf"
+    p.write_bytes(b"\n".join(lines) + b"\n")
+    return str(p)
+
+
+def _qbed(golden, tmp_path):
+    """windows in QUERY coordinates that do hit: a stretch of every fifth record's query span (the fixture's own trim_asm_small.bed
+    hits nothing under --qbed, which made the old check vacuous)"""
+    p = tmp_path / "q.bed"
+    recs = [l.split("\t") for l in open(f"{golden}/asm_small.paf")]
+    p.write_text("".join(f"{f[0]}\t{int(f[2]) + 100}\t{min(int(f[3]), int(f[2]) + 30000)}\n" for f in recs[::5]))
+    return str(p)
+
+
 @pytest.mark.parametrize("n", [2, 3])
 @pytest.mark.parametrize("args", [
     ["liftover", "--bed", "{bed}", "{paf}"],
-    ["liftover", "--qbed", "--bed", "{trimbed}", "{paf}"],
+    ["liftover", "--qbed", "--bed", "{qbed}", "{paf}"],
+    ["liftover", "--qbed", "--largest", "--bed", "{qbed}", "{paf}"],
+    ["liftover", "--largest", "--bed", "{bed}", "{paf}"],
     ["liftover", "--bed", "{bed}", "{paf}.gz"],
     ["break-paf", "--max-size", "100", "{paf}"],
     ["stats", "--paf", "{paf}"],
     ["invert", "{paf}"],
+    ["trim-paf", "{paf}"],
+    ["trim-paf", "-r", "{paf}"],
 ])
-def test_gpus_flag_gathers_the_single_gpu_bytes(golden, args, n):
-    """`rb --gpus N`: N worker processes forked before the GPU is touched, each on its own run of lines, pipes concatenated in shard
-    order.  One GPU here: RB_GPUS_SAME_DEVICE=1 puts every worker on device 0 (the fork, the line cuts and the gather are what is
-    checked; the per-device part is the ordinary single-GPU run)"""
-    a = [x.format(paf=f"{golden}/asm_small.paf", bed=f"{golden}/asm_small.bed", trimbed=f"{golden}/trim_asm_small.bed") for x in args]
-    rc1, out1 = rb(*a)
-    rcn, outn = rb("--gpus", n, *a, env={"RB_GPUS_SAME_DEVICE": "1"})
-    assert (rc1, rcn) == (0, 0)
-    assert outn == out1 and (len(out1) > 1000 or "--qbed" in a)
+def test_gpus_flag_gathers_the_single_gpu_bytes(golden, args, n, tmp_path):
+    """`rb --gpus N`: N worker processes forked before the GPU is touched, each on its own share of the lines; the outputs are put
+    together in the reference's order (contig-major for liftover, liftover.rs:151-164).  One GPU here: RB_GPUS_SAME_DEVICE=1 puts
+    every worker on device 0 (the fork, the cuts and the gather are what is checked; the per-device part is the ordinary
+    single-GPU run).  Checked on the fixture (sorted by target) AND on shuffled copies where contigs and query names interleave,
+    into a pipe and into a regular file (workers pwrite at offsets)."""
+    srcs = [f"{golden}/asm_small.paf"] + ([] if ".gz" in args[-1] else [_shuffled(golden, tmp_path, 7), _shuffled(golden, tmp_path, 8)])
+    for src in srcs:
+        a = [x.format(paf=src, bed=f"{golden}/asm_small.bed", qbed=_qbed(golden, tmp_path)) for x in args]
+        rc1, out1 = rb(*a)
+        rcn, outn = rb("--gpus", n, *a, env={"RB_GPUS_SAME_DEVICE": "1"})
+        assert (rc1, rcn) == (0, 0)
+        assert len(out1) > 1000, a
+        assert outn == out1, (a, n)
+        with open(tmp_path / "out.paf", "wb") as f:
+            r = subprocess.run([RB, "--gpus", str(n), *a], stdout=f, stderr=subprocess.PIPE, env={**os.environ, "RB_GPUS_SAME_DEVICE": "1"})
+        assert r.returncode == 0 and open(tmp_path / "out.paf", "rb").read() == out1, (a, n, "file")
+
+
+def test_gpus_flag_interleaved_contigs_vs_oracle(golden, oracle, tmp_path):
+    """the order itself (not only `--gpus N` == `--gpus 1`) against the oracle CLI on a shuffled input"""
+    src = _shuffled(golden, tmp_path, 11)
+    for a in (["liftover", "--bed", f"{golden}/asm_small.bed", src], ["liftover", "--qbed", "--bed", _qbed(golden, tmp_path), src],
+              ["liftover", "--largest", "--bed", f"{golden}/asm_small.bed", src], ["trim-paf", src]):
+        orc, oout = oracle.cli(*a)
+        rc, out = rb("--gpus", 3, *a, env={"RB_GPUS_SAME_DEVICE": "1"})
+        assert (orc, rc) == (0, 0) and out == oout and len(out) > 1000, a
 
 
 def test_gpus_flag_stdin_general_path_and_refusals(golden):
@@ -471,14 +512,18 @@ def test_gpus_flag_stdin_general_path_and_refusals(golden):
     gen = subprocess.run([RB, "--gpus", "2", "break-paf", f"{golden}/asm_small.paf"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          env={**env, "RB_GENERAL_PATH": "1"})
     assert gen.returncode == 0 and gen.stdout == one.stdout
-    # commands that are not a map over records are refused, not silently run on one GPU
-    for a in (["trim-paf", f"{golden}/asm_small.paf"], ["liftover", "--largest", "--bed", f"{golden}/asm_small.bed", f"{golden}/asm_small.paf"]):
+    tone = subprocess.run([RB, "trim-paf"], input=paf, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    ttwo = subprocess.run([RB, "--gpus", "2", "trim-paf"], input=paf, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    assert (tone.returncode, ttwo.returncode) == (0, 0) and tone.stdout == ttwo.stdout and len(tone.stdout) > 1000
+    # commands that are not a map over PAF records are refused, not silently run on one GPU
+    for a in (["orient", f"{golden}/asm_small.paf"], ["stats", f"{golden}/asm_small.bam"]):
         r = subprocess.run([RB, "--gpus", "2", *a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         assert r.returncode == 2 and not r.stdout
 
 
 def test_gpus_flag_panic_in_one_shard(golden, tmp_path):
-    """a line the reference panics on, in the second shard: the output up to the panic, exit code 101 -- as the single run"""
+    """a line the reference panics on, in the second shard: what the single run printed before the panic (the stats header, nothing
+    for the other commands), exit code 101"""
     lines = open(f"{golden}/asm_small.paf", "rb").read().split(b"\n")
     lines = [l for l in lines if l]
     bad = lines[-2].replace(b"cg:Z:", b"cg:Z:12Q")
@@ -487,4 +532,6 @@ def test_gpus_flag_panic_in_one_shard(golden, tmp_path):
     rc1, out1 = rb("stats", "--paf", src)
     rc2, out2 = rb("--gpus", 2, "stats", "--paf", src, env={"RB_GPUS_SAME_DEVICE": "1"})
     assert rc1 == 101 and rc2 == 101
-    assert out2.startswith(out1[:200]) and len(out2) >= len(out1)
+    assert out2 == out1 and out1.startswith(b"#")
+    rc3, out3 = rb("--gpus", 2, "break-paf", src, env={"RB_GPUS_SAME_DEVICE": "1"})
+    assert rc3 == 101 and out3 == b""
