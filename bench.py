@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--workload", default="config3", choices=["config3", "config2", "irregular"],
                     help="config3: the headline; config2: one 1 Mbp window; irregular: config 3's records made irregular (adjacent ops of one "
                          "type at the start, an N / H op at an end of two thirds of them) so that every hit takes the generic wave-per-hit kernel")
+    ap.add_argument("--irregular-frac", type=float, default=0.0,
+                    help="config3 / --op break: this fraction of the records made irregular as in --workload irregular (0.01: what the "
+                         "one-walk break path must take record by record instead of redoing the batch)")
     ap.add_argument("--legacy", action="store_true", help="RB_BSEARCH_LEGACY (rustc 1.52 .. 1.81 binary search): duplicates resolved by probe replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -207,16 +210,18 @@ def main():
     d_off = dev_u64(op_off)
     d_ops = torch.empty(total_ops + 64, dtype=torch.int32, device=dev)
     eng.dev_synth_fill_ops(seed, first, n_rec, d_off.data_ptr(), d_ops.data_ptr())
-    if args.workload == "irregular":
+    if args.workload == "irregular" or args.irregular_frac > 0:
         # op 1 (the first event) becomes an '=': three adjacent '=' ops that the reference's collapse merges (paf.rs:602-620); a third of
         # the records also end on an N, a third start on an H: no match op at that end.  None of them can take the streaming kernel.
         torch.cuda.synchronize()
         rr = torch.arange(n_rec, device=dev)
-        i1 = d_off[:-1] + 1
+        every = 1 if args.workload == "irregular" else max(1, int(round(1.0 / args.irregular_frac)))
+        sel = (rr + first) % every == 0
+        i1 = (d_off[:-1] + 1)[sel]
         d_ops[i1] = (d_ops[i1] & ~15) | 7
-        il = (d_off[1:] - 1)[rr % 3 == 1]
+        il = (d_off[1:] - 1)[sel & (rr % 3 == 1)]
         d_ops[il] = (d_ops[il] & ~15) | 3
-        i0 = d_off[:-1][rr % 3 == 2]
+        i0 = d_off[:-1][sel & (rr % 3 == 2)]
         d_ops[i0] = (d_ops[i0] & ~15) | 5
         torch.cuda.synchronize()
     zeros = torch.zeros(n_rec, dtype=torch.int64, device=dev)
@@ -411,7 +416,8 @@ def main():
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
-                   **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {})},
+                   **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {}),
+                   **({"irregular_frac": args.irregular_frac} if args.irregular_frac > 0 else {})},
         "paf_records_per_s": job_recs * args.steps / elapsed,
         "output_digest": f"{digest:#018x}", "job_records": int(job_recs), "job_hits": job_hits,
         "hits_per_gpu": n_hits, "ok_hits_per_gpu": n_ok, "out_ops_per_gpu": n_out_ops,
@@ -425,7 +431,7 @@ def main():
         result.update(e2e)
 
     # ---- CPU baseline + sample parity (rank 0, N = 1 only) ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.descriptors and args.op == "liftover" and not irregular:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.descriptors and args.op == "liftover" and not irregular and args.irregular_frac == 0:
         from oracle import pyoracle  # checker / baseline only; never on the product path
         from rustybam_amd import capi
         threads = os.cpu_count() or 1

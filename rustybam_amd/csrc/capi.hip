@@ -48,6 +48,8 @@ struct rb_break_params {
     unsigned long long *tmp_cursor;
     uint32_t n_arena;
     uint64_t arena_cap;
+    const uint32_t *list;
+    const unsigned long long *n_list;
 };
 struct rb_trim_params {
     uint64_t n_pairs;
@@ -107,6 +109,8 @@ extern "C" hipError_t rb_launch_make_jobs(const rb_lift_params *p, hipStream_t s
 extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_break_gather(const rb_lift_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_break_declined(const rb_lift_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_break_list_declined(const rb_lift_params *p, hipStream_t stream);
 extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec);
 extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_break_place(const rb_break_params *p, hipStream_t stream);
@@ -543,7 +547,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, decl_count, decl_list, total;
 };
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     ws_layout w;
@@ -569,6 +573,8 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     w.brk_rows = take((rows_cap + 1) * sizeof(rb_hit_row)); // break-paf in one walk: the rows before they are in record order
     w.copy_count = take(256);
     w.copy_list = take((rows_cap + 1) * 16);
+    w.decl_count = take(256);
+    w.decl_list = take((n_rec + 1) * 4); // break-paf in one walk: the records its clip kernel declined
     w.total = o;
     return w;
 }
@@ -686,6 +692,9 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
         p.brk_cursor = (unsigned long long *)(ws + w.bp_cur);
         p.brk_n_arena = pick_arenas(b->n_rec);
         p.brk_arena_cap = rows_cap / p.brk_n_arena;
+        p.brk_decl_list = (uint32_t *)(ws + w.decl_list);
+        p.brk_decl_count = (unsigned long long *)(ws + w.decl_count);
+        HIPCHK(ctx, hipMemsetAsync(p.brk_decl_count, 0, 8, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(p.brk_cursor, 0, (size_t)RB_MAX_ARENA * 128, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(p.hit_off, 0, (size_t)(b->n_rec + 2) * 8, ctx->stream));
         HIPCHK(ctx, hipMemsetAsync(p.brk_off, 0xFF, (size_t)(b->n_rec + 1) * 8, ctx->stream));
@@ -704,8 +713,24 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
             HIPCHK(ctx, hipEventRecord(ctx->ev_b[slot1], ctx->stream));
             ctx->timed_calls++;
         }
+        // the records the clip kernel declined, one by one: their pieces counted (list mode) before the scan of the counts, their
+        // windows written to their rows' places after it, rows + generic-list entries made, and the generic kernel clips them
+        rb_break_params bp;
+        memset(&bp, 0, sizeof bp);
+        bp.n_rec = b->n_rec, bp.ops = b->ops, bp.op_off = b->op_off, bp.norm = norm, bp.sched = plan->sched, bp.hit_off = p.hit_off;
+        bp.x_st = (uint64_t *)(ws + w.x_st), bp.x_en = (uint64_t *)(ws + w.x_en);
+        bp.rows_cap = rows_cap, bp.max_size = max_size;
+        bp.list = p.brk_decl_list, bp.n_list = p.brk_decl_count;
+        bp.fill = 0;
+        HIPCHK(ctx, rb_launch_break_list_declined(&p, ctx->stream));
+        HIPCHK(ctx, rb_launch_break_pieces(&bp, ctx->stream));
         HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, false, ctx->stream));
-        HIPCHK(ctx, rb_launch_break_gather(&p, ctx->stream));
+        bp.fill = 1;
+        HIPCHK(ctx, rb_launch_break_pieces(&bp, ctx->stream));
+        HIPCHK(ctx, rb_launch_break_gather(&p, ctx->stream)); // (copies the clips without a slot, moves the rows into record order)
+        rb_lift_params pg = p; // the generic kernel works on the final rows, with the declined records' windows as explicit windows
+        pg.rows = rows, pg.x_st = bp.x_st, pg.x_en = bp.x_en;
+        HIPCHK(ctx, rb_launch_break_declined(&pg, ctx->stream));
         return RB_OK;
     }
     if (is_break) {

@@ -14,6 +14,8 @@
 #include <atomic>
 #include <exception>
 #include <memory>
+#include <mutex>
+#include <condition_variable>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -375,8 +377,34 @@ struct TextBuf {
     const char *data() const { return p.get(); }
     size_t size() const { return n; }
 };
-static TextBuf read_text(const std::string &file_name, bool raw_bytes = false) { // raw_bytes: a gzip file is NOT inflated
+// explicit_range: bytes [begin, end) of a plain file (a chunk of the pipelined text routes); nullptr: the process-wide slice / filter
+static TextBuf read_text(const std::string &file_name, bool raw_bytes = false, const std::pair<uint64_t, uint64_t> *explicit_range = nullptr) { // raw_bytes: a gzip file is NOT inflated
     TextBuf b;
+    if (explicit_range) {
+        const int fd = open(file_name.c_str(), O_RDONLY);
+        if (fd < 0) throw Panic("Failed to open " + file_name);
+        const size_t from = (size_t)explicit_range->first;
+        b.n = (size_t)(explicit_range->second - explicit_range->first);
+        b.p.reset(new char[b.n + 32]);
+        advise_huge(b.p.get(), b.n);
+        memset(b.p.get() + b.n, 0, 32);
+        std::atomic<bool> ok{true};
+        parallel_chunks((b.n + (1u << 22) - 1) >> 22, [&](unsigned, size_t lo, size_t hi) { // 4 MiB pieces
+            size_t a = lo << 22;
+            const size_t e = std::min(b.n, hi << 22);
+            while (a < e) {
+                const ssize_t r = pread(fd, b.p.get() + a, e - a, (off_t)(from + a));
+                if (r <= 0) {
+                    ok = false;
+                    return;
+                }
+                a += (size_t)r;
+            }
+        });
+        close(fd);
+        if (!ok) throw Panic("Failed to read " + file_name);
+        return b;
+    }
     if (file_name != "-") {
         const int fd = open(file_name.c_str(), O_RDONLY);
         if (fd < 0) throw Panic("Failed to open " + file_name);
@@ -910,9 +938,9 @@ struct TextFile {
     std::unordered_map<std::string_view, uint32_t> contig_id; // dense ids in order of first appearance (canonical contig order)
     std::string_view name(size_t off, size_t n) const { return std::string_view(all.data() + off, n); }
     // false = a line needs the general parser (two cg tags)
-    bool load(const std::string &paf_path) {
+    bool load(const std::string &paf_path, const std::pair<uint64_t, uint64_t> *range = nullptr) {
         double tl = now_s();
-        all = read_text(paf_path);
+        all = read_text(paf_path, false, range);
         text_bytes = all.size();
         const std::vector<std::pair<size_t, size_t>> lines = split_lines(std::string_view(all.data(), text_bytes));
         lap("read + split lines", tl);
@@ -1137,6 +1165,176 @@ bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_le
     out_text = assemble_lines(f, norm, R, nullptr);
     lap("assemble lines", tl);
     return true;
+}
+
+// ---- liftover / break-paf, text in -> text out, as a PIPELINE over chunks of the file (round 3) ---------------------------------------
+// Records are independent (liftover.rs:123-129), so a big file is cut at line starts into chunks of RB_CHUNK_MB (default 512) MB
+// and a few host threads, each with a context (= a stream) of its own on the same GPU, take the chunks in turn: read + header
+// columns of chunk k + 2 overlap the H2D / kernels / D2H of chunk k + 1 and the line assembly of chunk k; the caller's sink gets the
+// chunks' outputs IN ORDER (and writes while the rest is still being computed).  A chunk's output is contig-major within the
+// chunk (TextRuns says where the contigs lie); putting chunks together in the reference's order is the sink's business.
+// false = not applicable (not a plain regular file, or smaller than two chunks) or a line needs the general parser: nothing was
+// handed to the sink in the first case; in the second the sink may have seen some chunks (it is told so by the return value of
+// pipeline_started()).
+namespace {
+std::atomic<bool> g_pipeline_started{false};
+}
+bool pipeline_started() { return g_pipeline_started.load(); }
+bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uint32_t break_length, const std::string &paf_path,
+                              const std::vector<Region> &rgns, const std::function<void(std::vector<std::string> &, TextRuns &)> &sink) {
+    g_pipeline_started = false;
+    if (paf_path == "-" || g_qrange) return false;
+    const int fd = open(paf_path.c_str(), O_RDONLY);
+    if (fd < 0) return false; // (the ordinary path reports it)
+    struct stat st;
+    unsigned char magic[2] = {0, 0};
+    const bool plain = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && !(pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b);
+    if (!plain) {
+        close(fd);
+        return false;
+    }
+    uint64_t begin = 0, end = (uint64_t)st.st_size;
+    if (g_sliced) begin = std::min<uint64_t>(g_slice_begin, end), end = std::min<uint64_t>(g_slice_end, end);
+    const char *ce = getenv("RB_CHUNK_MB"), *ck = getenv("RB_CHUNK_KB"); // (KB: tests on the 2 MB fixture)
+    const uint64_t chunk = ck ? (uint64_t)std::max(1, atoi(ck)) << 10 : (uint64_t)std::max(1, ce ? atoi(ce) : 512) << 20;
+    if (end - begin < 2 * chunk) {
+        close(fd);
+        return false;
+    }
+    std::vector<uint64_t> cut{begin};
+    std::vector<char> probe(1 << 16);
+    for (uint64_t at = begin + chunk; at < end; at += chunk) { // the first line start at or behind every multiple of the chunk size
+        uint64_t a = std::max(at, cut.back()) - 1;
+        bool found = false;
+        while (a < end && !found) {
+            const ssize_t r = pread(fd, probe.data(), probe.size(), (off_t)a);
+            if (r <= 0) break;
+            const void *nl = memchr(probe.data(), '\n', (size_t)r);
+            if (nl) a += (uint64_t)((const char *)nl - probe.data()) + 1, found = true;
+            else a += (uint64_t)r;
+        }
+        if (!found || a >= end) break;
+        if (a > cut.back()) cut.push_back(a);
+    }
+    cut.push_back(end);
+    close(fd);
+    const size_t n_chunks = cut.size() - 1;
+    struct Result {
+        std::vector<std::string> text;
+        TextRuns runs;
+        std::string panic;
+        bool general = false, done = false;
+    };
+    std::vector<Result> res(n_chunks);
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<size_t> next{0};
+    std::atomic<bool> stop{false};
+    const char *we = getenv("RB_PIPE_WORKERS");
+    const unsigned W = (unsigned)std::min<size_t>(n_chunks, (size_t)std::max(1, we ? atoi(we) : 3));
+    std::vector<std::thread> workers;
+    for (unsigned w = 0; w < W; w++)
+        workers.emplace_back([&]() {
+            std::unique_ptr<Engine> eng;
+            for (;;) {
+                const size_t k = next++;
+                if (k >= n_chunks || stop) break;
+                {   // (at most W + 1 chunks ahead of the sink: their outputs are held in memory)
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || k < W + 1 || (res[k - W - 1].done && res[k - W - 1].text.empty()); });
+                }
+                Result R;
+                try {
+                    if (!eng) {
+                        eng.reset(new Engine(device));
+                        eng->bsearch_policy = bsearch_policy;
+                    }
+                    const std::pair<uint64_t, uint64_t> range(cut[k], cut[k + 1]);
+                    TextFile f;
+                    if (!f.load(paf_path, &range)) {
+                        R.general = true;
+                    } else {
+                        const size_t n = f.recs.size();
+                        R.runs.contigs.assign(f.contig_id.size(), std::string());
+                        for (const auto &kv : f.contig_id) R.runs.contigs[kv.second].assign(kv.first.data(), kv.first.size());
+                        std::vector<uint32_t> w_contig(rgns.size());
+                        std::vector<uint64_t> w_st(rgns.size()), w_en(rgns.size());
+                        for (size_t i = 0; i < rgns.size(); i++) {
+                            auto it = f.contig_id.find(std::string_view(rgns[i].name));
+                            if (it == f.contig_id.end()) it = f.contig_id.emplace(std::string_view(rgns[i].name), (uint32_t)f.contig_id.size()).first;
+                            w_contig[i] = it->second, w_st[i] = rgns[i].st, w_en[i] = rgns[i].en;
+                        }
+                        std::vector<uint8_t> cig_status(n ? n : 1);
+                        std::vector<rb_reduce_row> red(n);
+                        std::vector<rb_norm_row> norm(n);
+                        TextRows TR;
+                        rb_counters cnt;
+                        if (is_break)
+                            eng->check(rb_host_break_text(eng->ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(), f.cig_end.data(),
+                                                          f.t_st.data(), f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(), break_length,
+                                                          bsearch_policy, cig_status.data(), red.data(), norm.data(), &TR.rows, &TR.n_rows, &TR.toff,
+                                                          &TR.text, &cnt),
+                                       "rb_host_break_text");
+                        else
+                            eng->check(rb_host_liftover_text(eng->ctx(), n, (const uint8_t *)f.all.data(), f.text_bytes, f.cig_off.data(),
+                                                             f.cig_end.data(), f.t_st.data(), f.t_en.data(), f.q_st.data(), f.q_en.data(), f.strand.data(),
+                                                             f.contig.data(), rgns.size(), w_contig.data(), w_st.data(), w_en.data(), bsearch_policy,
+                                                             cig_status.data(), red.data(), norm.data(), &TR.rows, &TR.n_rows, &TR.toff, &TR.text, &cnt),
+                                       "rb_host_liftover_text");
+                        if (!f.check_loaded(cig_status, red)) {
+                            R.general = true;
+                        } else {
+                            for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i);
+                            RunMarks marks;
+                            R.text = assemble_lines(f, norm, TR, is_break ? nullptr : &rgns, &marks);
+                            marks_to_runs(marks, R.text, R.runs);
+                            if (is_break) { // (record order: one run)
+                                uint64_t total = 0;
+                                for (const std::string &t : R.text) total += t.size();
+                                R.runs.contigs.assign(1, std::string());
+                                R.runs.runs.assign(1, {0u, total});
+                            }
+                        }
+                    }
+                } catch (const Panic &e) {
+                    R.panic = e.what();
+                    if (R.panic.empty()) R.panic = "panic";
+                } catch (const std::exception &e) {
+                    R.panic = std::string("\x01") + e.what(); // (not a reference panic: the caller rethrows it as a runtime error)
+                }
+                R.done = true;
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    res[k] = std::move(R);
+                }
+                cv.notify_all();
+            }
+        });
+    bool ok = true;
+    std::string panic;
+    for (size_t k = 0; k < n_chunks && ok; k++) {
+        Result R;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return res[k].done; });
+            R = std::move(res[k]);
+            res[k].text.clear();
+            res[k].done = true;
+        }
+        cv.notify_all();
+        if (!R.panic.empty()) { panic = R.panic; ok = false; break; }
+        if (R.general) { ok = false; break; }
+        g_pipeline_started = true;
+        sink(R.text, R.runs);
+    }
+    stop = true;
+    cv.notify_all();
+    for (auto &t : workers) t.join();
+    if (!panic.empty()) {
+        if (panic[0] == '\x01') throw std::runtime_error(panic.substr(1));
+        throw Panic(panic);
+    }
+    return ok;
 }
 
 // main.rs:218-230 (trim-paf), text in -> text out with the batch resident on the device across the passes of

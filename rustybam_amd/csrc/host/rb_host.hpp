@@ -106,6 +106,13 @@ std::vector<std::string> trim_paf_by_rgns_text(Engine &eng, const std::vector<Re
 // (rb_host_liftover_text); false = the file needs the general path (a line with two cg tags), nothing was produced
 bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vector<Region> &rgns, std::vector<std::string> &out_text,
                         TextRuns *runs = nullptr);
+// the same two routes as a pipeline over chunks of a big plain file (a few host threads, each with its own context on `device`):
+// the sink receives the chunks' outputs in file order while later chunks are still being read / clipped / printed.  A chunk's text
+// is contig-major within the chunk (runs); false = not applicable or a line needs the general parser (pipeline_started(): the
+// sink has already been given chunks)
+bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uint32_t break_length, const std::string &paf_path,
+                              const std::vector<Region> &rgns, const std::function<void(std::vector<std::string> &, TextRuns &)> &sink);
+bool pipeline_started();
 bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_length, std::vector<std::string> &out_text); // main.rs:271-281
 bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, int diff_score, int indel_score, bool remove_contained,
                     std::vector<std::string> &out_text); // main.rs:218-230, the batch resident on the device across the passes

@@ -338,7 +338,31 @@ bool recv_msg(int fd, MsgIn &m) {
 // what a finished arm does with its text: the single run prints it; a `--gpus` worker hands it to the gather (and does not return)
 static void emit(Output &o) {
     if (g_worker.on) worker_emit(o);
-    put(o.chunks);
+    bool in_order = true; // pieces by contig in first-appearance order? (the chunks of the pipelined route need not be)
+    for (size_t k = 1; k < o.pieces.size(); k++) in_order = in_order && o.pieces[k].contig >= o.pieces[k - 1].contig;
+    if (in_order) {
+        put(o.chunks);
+        return;
+    }
+    // contig-major (liftover.rs:151-164): the pieces of contig 0 in the order they came, then contig 1, ...
+    std::vector<uint64_t> start(o.pieces.size() + 1, 0), cstart(o.chunks.size() + 1, 0);
+    for (size_t k = 0; k < o.pieces.size(); k++) start[k + 1] = start[k] + o.pieces[k].bytes;
+    for (size_t k = 0; k < o.chunks.size(); k++) cstart[k + 1] = cstart[k] + o.chunks[k].size();
+    std::vector<size_t> order(o.pieces.size());
+    for (size_t k = 0; k < order.size(); k++) order[k] = k;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return o.pieces[a].contig < o.pieces[b].contig; });
+    fflush(stdout);
+    for (size_t k : order) {
+        uint64_t a = start[k];
+        const uint64_t e = start[k + 1];
+        size_t c = (size_t)(std::upper_bound(cstart.begin(), cstart.end(), a) - cstart.begin()) - 1;
+        while (a < e) {
+            while (c < o.chunks.size() && cstart[c + 1] <= a) c++;
+            const uint64_t n = std::min(e, cstart[c + 1]) - a;
+            if (!write_all(1, o.chunks[c].data() + (a - cstart[c]), (size_t)n)) { perror("rb: write"); _exit(1); }
+            a += n;
+        }
+    }
 }
 static void emit(std::vector<std::string> &chunks) {
     Output o;
@@ -546,6 +570,71 @@ static int shard_fork(int n, GatherMode mode, bool by_query, std::string &path, 
     return rc ? rc : (ok ? 0 : 1);
 }
 
+// liftover / break-paf on a big plain file: the pipelined text route (rb_host: chunks of the file on a few host threads, each with a
+// context of its own).  A single run writing into a regular file streams the chunks' outputs as they arrive -- as long as that is
+// the reference's order: contig ranks (first appearance over the records seen so far) must not decrease along the output.  When they
+// do (a file that is not sorted by target: the rows of a contig seen earlier must go in FRONT of what has been written), or when a
+// line needs the general parser, the file is cut back to where the output began and the caller takes the whole-file route.  Into
+// a pipe, and in a `--gpus` worker, the outputs are kept and put in order at the end (emit).  true = the output is complete.
+static bool try_pipelined(int device, int policy, bool is_break, uint32_t max_size, const std::string &paf_path, const std::vector<rb::Region> &rgns) {
+    if (getenv("RB_NO_PIPELINE")) return false;
+    struct stat so;
+    const int fl = fcntl(1, F_GETFL);
+    fflush(stdout);
+    off_t base = -1;
+    if (!g_worker.on && fstat(1, &so) == 0 && S_ISREG(so.st_mode) && fl >= 0 && !(fl & O_APPEND)) base = lseek(1, 0, SEEK_CUR);
+    const bool streaming = base >= 0;
+    Output acc;
+    std::unordered_map<std::string, uint32_t> rank; // contig -> first-appearance rank over the chunks so far
+    int64_t last_rank = -1;
+    bool violated = false;
+    auto sink = [&](std::vector<std::string> &text, rb::TextRuns &runs) {
+        std::vector<uint32_t> gid(runs.contigs.size());
+        for (size_t c = 0; c < runs.contigs.size(); c++) {
+            auto it = rank.emplace(runs.contigs[c], (uint32_t)rank.size());
+            if (it.second) acc.contigs.push_back(runs.contigs[c]);
+            gid[c] = it.first->second;
+        }
+        if (violated) return;
+        if (streaming) {
+            for (const auto &r : runs.runs) {
+                if ((int64_t)gid[r.first] < last_rank) { violated = true; return; }
+                last_rank = gid[r.first];
+            }
+            put(text);
+            std::vector<std::string>().swap(text);
+            return;
+        }
+        for (const auto &r : runs.runs) {
+            Piece pc;
+            pc.contig = gid[r.first], pc.bytes = r.second;
+            acc.pieces.push_back(pc);
+        }
+        for (std::string &t : text) acc.chunks.push_back(std::move(t));
+    };
+    auto rewind = [&]() { // what was written is not the reference's output: back to where it began
+        if (streaming && rb::pipeline_started())
+            if (ftruncate(1, base) != 0 || lseek(1, base, SEEK_SET) != base) { perror("rb: cannot rewind the output"); _exit(1); }
+    };
+    bool ok = false;
+    try {
+        ok = rb::lift_file_text_pipelined(device, policy, is_break, max_size, paf_path, rgns, sink);
+    } catch (...) { // (a reference panic in a later chunk: the single run panics before it prints anything)
+        rewind();
+        throw;
+    }
+    if (ok && !violated) {
+        if (!streaming) {
+            if (acc.contigs.empty()) acc.contigs.push_back(std::string());
+            if (acc.pieces.empty()) acc.pieces.push_back(Piece());
+            emit(acc);
+        }
+        return true;
+    }
+    rewind();
+    return false;
+}
+
 // `rb [--gpus N] regroup [-q] [-l] <PAF>`: not a reference subcommand and no device work -- the lines of a PAF file put in the ORDER
 // the hot-path commands emit (so that the `--gpus` gather can be checked on a machine without a GPU, tests/test_rb_gather_cpu.py):
 // default = liftover's canonical order with one output line per record (contig-major by first appearance of column 6, then file
@@ -734,6 +823,10 @@ int main(int argc, char **argv) {
                 }
                 return o;
             };
+            if (!largest && !qbed && text_path && try_pipelined(device, policy, false, 0, paf_path, rgns)) {
+                lap("liftover (text to text, pipelined)", tl);
+                done(0);
+            }
             if (!largest && !qbed && text_path) { // text in -> text out, CIGAR text handled on the device
                 std::vector<std::string> text;
                 if (rb::liftover_file_text(eng, paf_path, rgns, text, g_worker.on ? &runs : nullptr)) {
@@ -784,6 +877,7 @@ int main(int argc, char **argv) {
                 lap("write", tl);
             }
         } else if (cmd == "break-paf" || cmd == "breakpaf" || cmd == "bp") {
+            if (text_path && try_pipelined(device, policy, true, max_size, paf_path, std::vector<rb::Region>())) done(0);
             std::vector<std::string> text;
             if (!(text_path && rb::break_file_text(eng, paf_path, max_size, text))) {
                 rb::Paf paf = rb::Paf::from_file(eng, paf_path);

@@ -35,11 +35,12 @@
 // emitted op.  No MFMA: integer / index work only.
 #include "rb_lift.h"
 #include <type_traits>
+#include <algorithm>
 
 // diagnostics (debug_skip & 32): shader-clock time of each phase of a record, every 16th record, summed in units of 16
 // cycles into counters->phase[0..4]: job + windows, stream + resolve, verdict + finalize, reservation, rows + end groups
 #define RB_PHASE(i)                                                                                                  \
-    if (p.debug_skip & 32) {                                                                                         \
+    if (dbg & 32) {                                                                                                  \
         const long long t_now = clock64();                                                                           \
         if (lane == 0 && (wave & 15) == 0) atomicAdd(&p.counters->phase[i], (uint32_t)((t_now - t_prev) >> 4));       \
         t_prev = t_now;                                                                                              \
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
 // streaming kernel
 // ------------------------------------------------------------------------------------------------
 #define RB_STEP_SHIFT 9  // a step is 512 ops: 8 ops (two 16-byte loads, 32 contiguous bytes) per lane
-#define RB_CP_PER_STEP 32 // one checkpoint per 16 ops (every second lane)
+#define RB_CP_PER_STEP (512 / RB_CP_OPS) // one checkpoint per RB_CP_OPS ops (16: every second lane; 8: every lane)
 #ifndef RB_PF
 #define RB_PF 2 // steps (2 KiB each) of stream loads in flight per wave
 #endif
@@ -220,6 +221,9 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 //  are placed behind its own allocation, and one build of this kernel had them at v78 v79 v80.  tests/test_ring_registers.py
 //  disassembles both builds and fails if anything outside the asm statements names v80..v95.)
 #endif
+#ifndef RB_SPILL_ROOM
+#define RB_SPILL_ROOM 0 // registers between the compiler's allocation and the ring, for the VGPRs it parks spilled scalar registers in
+#endif
 #define RB_STR2(x) #x
 #define RB_STR(x) RB_STR2(x)
 // registers OFF .. OFF + W of the ring, as the assembler reads them (it evaluates the sums)
@@ -228,7 +232,22 @@ static_assert(RB_PF == 2, "the ring's asm statements are written out for two slo
 // BRK: break-paf in one walk (rb_lift.h, brk_max): the windows of a record are not given, they are the stretches between the indels
 // longer than brk_max, found while the record streams; 32 pieces a pass.  The liftover build has none of that code.
 template <bool BRK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), amdgpu_num_vgpr(RB_RING_BASE))) void rb_k_liftover_stream(rb_lift_params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), amdgpu_num_vgpr(RB_RING_BASE - RB_SPILL_ROOM))) void rb_k_liftover_stream(rb_lift_params p_) {
+    // The 408 bytes of parameters are NOT read through `p_`: the compiler loads every by-value kernel argument a kernel uses in
+    // its entry block and then carries -- spills -- those hundred scalar registers through the whole record (round 2: 233 SGPR
+    // spills, parked in VGPRs right under the load ring).  `p.field` below reads the field from the kernel-argument segment where
+    // it is used, through a pointer the compiler cannot see through (one s_load at that place); what the streaming loop needs is
+    // copied into locals in front of it.
+    (void)p_;
+    const rb_kparams kp = (rb_kparams)__builtin_amdgcn_kernarg_segment_ptr();
+    rb_kparams kq = rb_kp_here(kp); // the pointer of the current phase (set-up / after the stream of a pass): loads through it stay inside the phase
+#define p (*kq)
+    // diagnostics (bench.py --debug-skip: phases of the kernel switched off, phase timers) only in builds made with -DRB_DIAG=1
+    // (tools/mkvariant.sh): every tested bit is a wave-uniform boolean, i.e. two scalar registers held through the whole record
+#ifndef RB_DIAG
+#define RB_DIAG 0
+#endif
+    const int dbg = RB_DIAG ? p.debug_skip : 0;
     // checkpoints: exclusive (R,Q,U) prefixes every 16 ops, SoA so that R can be binary-searched
     __shared__ uint32_t cp_all[4][3][RB_SMAX * RB_CP_PER_STEP];
     __shared__ uint32_t wx_all[4][RB_HMAX + 1]; // window indices of one pass over a window list that is not sorted
@@ -236,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
     const uint64_t wave = (uint64_t)p.wave0 + (uint64_t)blockIdx.x * 4u + wib;
     if (wave >= p.wave_end) return;
     const int lane = rb_lane();
-    long long t_prev = (p.debug_skip & 32) ? clock64() : 0;
+    long long t_prev = (dbg & 32) ? clock64() : 0;
     uint32_t *cpR = cp_all[wib][0], *cpQ = cp_all[wib][1], *cpU = cp_all[wib][2];
     const rb_job jb_ = p.jobs[wave]; // (uniform address: one 64-byte request)
     const uint32_t jflags = rb_first(jb_.flags);
@@ -257,26 +276,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         ws = p.cw_off[cg];
         we = p.cw_off[cg + 1];
     }
+    // BRK: this record is not the one-walk path's: on the list it goes (rb_k_break_pieces finds its pieces, the generic kernel clips them)
+    // (one store here: rb_k_break_list_declined collects the marked records afterwards -- the list and its counter would be two more
+    //  pointers for this kernel to carry)
+    auto brk_decline = [&]() {
+        if (lane == 0) p.brk_off[r] = ~1ull;
+    };
     if (!(jflags & RB_JOB_REGULAR)) { // window order does not matter on the fast path: resolution is per lane
-        if constexpr (BRK) { // (its pieces would have to be known before the generic kernel can clip them: the two-walk path's business)
-            if (lane == 0) p.counters->redo_two_walk = 1;
-            return;
-        }
         if (p.fused && lane == 0) { // (a provisional row that cannot take the fast path: the full scan completes it)
             const unsigned long long i = atomicAdd(p.pend_count, 1ull);
             p.pend_list[i] = r;
         }
-        rb_defer_record(p, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
+        if constexpr (BRK) {
+            brk_decline();
+            return;
+        }
+        rb_defer_record(kp, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
         return;
     }
-    // wave-uniform coordinates: pinned to scalar registers (left alone, the compiler keeps vector copies alive through the
-    // whole record and spills them)
+    // the record's coordinates are needed in front of the stream of a pass (the boundaries' offsets) and behind it (the rows), not in
+    // between: they are read again from the job behind the stream instead of being carried -- in eight scalar registers, round 2 --
+    // through it (the job is 64 bytes at an address the whole wave shares)
+    // (RB_COORD_RELOAD: the liftover build is better off with the round-2 form -- pinned to scalar registers --, the break build with
+    //  the reload; what decides is where the compiler then parks its spilled scalar registers, tools/check_ring.py)
     auto sgpr64 = [](uint64_t v) -> uint64_t {
         uint32_t lo = rb_first((uint32_t)v), hi = rb_first((uint32_t)(v >> 32));
         asm volatile("" : "+s"(lo), "+s"(hi));
         return ((uint64_t)hi << 32) | lo;
     };
-    const uint64_t t_st = sgpr64(jb_.t_st), t_en = sgpr64(jb_.t_en), q_st = sgpr64(jb_.q_st), q_en = sgpr64(jb_.q_en);
+    constexpr bool coord_reload = BRK;
+    uint64_t t_st = jb_.t_st, t_en = jb_.t_en, q_st = jb_.q_st, q_en = jb_.q_en;
+    if constexpr (!coord_reload) t_st = sgpr64(t_st), t_en = sgpr64(t_en), q_st = sgpr64(q_st), q_en = sgpr64(q_en);
     const uint32_t n = rb_first(jb_.n);
     const bool minus = (jflags & RB_JOB_MINUS) != 0;
     const uint64_t rec0 = rb_first64(jb_.rec0); // global index of the record's first kept op
@@ -303,6 +333,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
     //      from the registers it was loaded into, with the aligned address it was loaded from: no size is needed to place a
     //      clip, hence no reservation, no atomic and no second read of the ops. ----
     const uint32_t n_slots = (uint32_t)p.n_slots;
+    uint32_t *const out_ops_ = p.out_ops;        // (locals of the streaming loop, see the top of the kernel)
+    const uint64_t slot_stride_ = p.slot_stride;
+    const uint32_t brk_max_ = BRK ? p.brk_max : 0u;
+    const int policy_ = p.policy, early_exit_ = p.early_exit, desc_mode_ = p.desc_mode;
     const uint64_t slot_row0 = 32ull * r + g0; // out_ops index of coordinate 0 in slot 0
     // first coordinate a clip of class k may start at in a later pass: behind every clip the earlier passes put there
     uint32_t carry[RB_MS];
@@ -332,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         uint64_t wst = 0, wen = 0;
         uint32_t win = (uint32_t)jb + hl; // (BRK: the piece's ordinal)
         if constexpr (!BRK) {
-            const rb_pass_win pw = rb_pass_windows(p, &wx_all[wib][0], explicit_w, mono, ws, we, lo, h0, jb, nb, t_st, t_en, scan_pos, lane);
+            const rb_pass_win pw = rb_pass_windows(kp, &wx_all[wib][0], explicit_w, mono, ws, we, lo, h0, jb, nb, t_st, t_en, scan_pos, lane);
             wst = pw.wst, wen = pw.wen, win = pw.win;
         }
         const bool inside = !BRK && own && (t_st > wst && t_en < wen); // liftover.rs:23-25 (a piece never contains its record)
@@ -364,12 +398,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         rb_bres O;
         O.st = RB_S_UNRES;
         O.op = O.part = O.R = O.Q = O.U = 0;
-        if (p.debug_skip & 32) { // (the window values must have arrived for the phase boundary to mean anything)
+        if (dbg & 32) { // (the window values must have arrived for the phase boundary to mean anything)
             asm volatile("s_waitcnt vmcnt(0)");
         }
         RB_PHASE(0)
         // speculative emission: sorted windows only (the clips of a class then follow one another along the record)
-        const bool spec = n_slots != 0u && mono && nb != 0u && !p.desc_mode && !(p.debug_skip & 1);
+        const bool spec = n_slots != 0u && mono && nb != 0u && !desc_mode_ && !(dbg & 1);
         const bool any_inside = __ballot(inside && mine) != 0; // (a clip that is the whole record needs the whole stream)
         const bool resumable = mono && jb != 0 && !any_inside; // later passes start where the previous one found its last start, and stop when done
 
@@ -386,7 +420,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         uint32_t v_reg = 0xFFFFFFFFu, v_minw = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_maxsu = 0u;
         uint32_t v_carry = 0xFu;       // last op word of the previous step (code 15: equals nothing)
         unsigned long long v_utot = 0; // 64-bit sum of all lengths
-        const bool streams = BRK || ((__ballot(need) != 0 || validate || (spec && any_inside)) && !(p.debug_skip & 4));
+        const bool streams = BRK || ((__ballot(need) != 0 || validate || (spec && any_inside)) && !(dbg & 4));
         if (streams) {
             // The load ring and the speculative stores are written by hand.  vmcnt retires in issue order on gfx9 and counts
             // loads and stores together; left to the compiler, the wait for a step's loads would also wait for the stores of
@@ -499,8 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                         su += len;
                     }
                     const uint32_t ir = rb_wave_scan_incl(sr), iq = rb_wave_scan_incl(sq), iu = rb_wave_scan_incl(su);
-                    if ((lane & 1) == 0) { // checkpoint every 16 ops
-                        const uint32_t t = (st - seg0) * RB_CP_PER_STEP + ((uint32_t)lane >> 1);
+                    if (RB_CP_OPS == 8 || (lane & 1) == 0) { // checkpoint every RB_CP_OPS ops
+                        const uint32_t t = (st - seg0) * RB_CP_PER_STEP + (RB_CP_OPS == 8 ? (uint32_t)lane : ((uint32_t)lane >> 1));
                         cpR[t] = Rb + ir - sr;
                         cpQ[t] = Qb + iq - sq;
                         cpU[t] = Ub + iu - su;
@@ -520,7 +554,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
 #pragma unroll
                         for (int q = 0; q < 8; q++) {
                             const uint32_t cq = w[q] & 15u;
-                            lane_big |= (cq == RB_OP_I || cq == RB_OP_D) && rb_len(w[q]) > p.brk_max;
+                            lane_big |= (cq == RB_OP_I || cq == RB_OP_D) && rb_len(w[q]) > brk_max_;
                         }
                         unsigned long long cm = __ballot(lane_big);
                         const uint32_t lane_r0 = R0 + ir - sr; // reference offset of my first op
@@ -533,7 +567,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                                 const uint32_t wq = rb_readlane<uint32_t>(w[q], l);
                                 const uint32_t cq = wq & 15u, lq = rb_len(wq);
                                 const uint32_t rlq = cq == RB_OP_I ? 0u : lq; // (regular records: M I D N = X)
-                                if ((cq == RB_OP_I || cq == RB_OP_D) && lq > p.brk_max) {
+                                if ((cq == RB_OP_I || cq == RB_OP_D) && lq > brk_max_) {
                                     if (rx > brk_pre) { // liftover.rs:191: the piece in front of the indel, if it holds reference bases
                                         const uint32_t li = brk_cnt - brk_j0; // (its lane in this pass; wraps far above 32 for earlier pieces)
                                         if (li < 32u) {
@@ -610,8 +644,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                             m1 = q4 & v1 & keep1;
                         }
 #endif
-                        if (p.debug_skip & 64) m0 = m1 = 0ull; // diagnostics: everything but the stores themselves
-                        const uint32_t *sb = p.out_ops + slot_row0 + (uint64_t)q * p.slot_stride;
+                        if (dbg & 64) m0 = m1 = 0ull; // diagnostics: everything but the stores themselves
+                        const uint32_t *sb = out_ops_ + slot_row0 + (uint64_t)q * slot_stride_;
 #define RB_RING_STORE(RA, RB_)                                                                                                  \
     asm volatile("s_mov_b64 exec, %[m0]\n\t"                                                                                    \
                  "global_store_dwordx4 %[o], " RA ", %[sb]" RB_ST_NT "\n\t"                                                     \
@@ -666,7 +700,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 }
                 {
                     const bool todo = need && D >= Rseg && (D < Rb || (last_seg && D == Rb));
-                    if (todo && !(p.debug_skip & 2)) {
+                    if (todo && !(dbg & 2)) {
                         if (D == Rb) { // boundary on the record's last base; the last op is match-type
                             const uint32_t lv = rec_ops[n - 1];
                             O.st = RB_S_OK, O.op = n - 1;
@@ -679,7 +713,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                                 const uint32_t mid = (lo_t + hi_t) >> 1;
                                 if (cpR[mid] <= D) lo_t = mid; else hi_t = mid;
                             }
-                            O = rb_resolve(rec_ops, n, cp_idx0 + (int32_t)lo_t * 16, cpR[lo_t], cpQ[lo_t], cpU[lo_t], D, is_start, p.policy);
+                            O = rb_resolve(rec_ops, n, cp_idx0 + (int32_t)lo_t * RB_CP_OPS, cpR[lo_t], cpQ[lo_t], cpU[lo_t], D, is_start, policy_);
                         }
                         need = false;
                     }
@@ -690,7 +724,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                     // the start of the pass's last window was found in this segment: the next pass begins here
                     if (!BRK && nb && ((__ballot(todo) >> (nb - 1u)) & 1ull)) next_seg = seg0 / RB_SMAX, next_R = Rseg, next_Q = Qseg, next_U = Useg;
                 }
-                if (!BRK && (p.early_exit || resumable) && !validate && !(spec && any_inside) && __ballot(need) == 0) break;
+                if (!BRK && (early_exit_ || resumable) && !validate && !(spec && any_inside) && __ballot(need) == 0) break;
                 if constexpr (BRK) { // a later pass is done when its 32 pieces are closed and every boundary of theirs is resolved
                     if (jb != 0 && brk_cnt >= brk_j0 + 32u && __ballot(((brk_def >> lane) & 1ull) != 0ull && O.st == RB_S_UNRES) == 0ull) break;
                 }
@@ -703,6 +737,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
 #undef RB_RING_NOSTORES
         }
         resume_seg = next_seg, resume_R = next_R, resume_Q = next_Q, resume_U = next_U;
+        kq = rb_kp_here(kp); // (what the rows, patches and lists below need is loaded from here on, not carried through the stream)
+        // ---- behind the stream.  What this part needs to know about the record it reads again from the job (64 bytes at an address
+        //      the whole wave shares, L2-resident) and derives afresh: computed in front of the stream these values -- row and slot
+        //      addresses, flags, counts -- were carried through it in scalar registers the streaming loop has no room for, i.e.
+        //      spilled (round 2: 233 spills) ----
+        const rb_job jp = p.jobs[wave];
+        if constexpr (coord_reload) t_st = jp.t_st, t_en = jp.t_en, q_st = jp.q_st, q_en = jp.q_en;
+        {
+        const uint32_t r = rb_first(jp.r), n = rb_first(jp.n);
+        const rb_norm_row *nr = &p.norm[r];
+        const uint64_t rec0 = rb_first64(jp.rec0);
+        const uint32_t *rec_ops = p.ops + rec0;
+        const int32_t head = (int32_t)(rec0 & 31ull);
+        const uint64_t slot_row0 = 32ull * r + (rec0 & ~31ull);
+        const uint64_t h0 = rb_first(jp.h0), nh = rb_first(jp.nh);
+        const bool minus = (rb_first(jp.flags) & RB_JOB_MINUS) != 0;
 
         RB_PHASE(1)
         if (validate) {
@@ -713,12 +763,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
             const bool bad = __ballot(lane_bad) != 0 || rb_first64(v_utot) > 0xFFFFFFFFull || t_en < t_st || q_en < q_st ||
                              (uint64_t)Rb != t_en - t_st || (uint64_t)Qb != q_en - q_st;
             if (bad) {
-                if constexpr (BRK) {
-                    if (lane == 0) p.counters->redo_two_walk = 1;
-                }
                 if (lane == 0) {
                     const unsigned long long i = atomicAdd(p.pend_count, 1ull);
                     p.pend_list[i] = r;
+                }
+                if constexpr (BRK) {
+                    brk_decline();
+                    return;
                 }
                 if (!BRK && nh) {
                     if (!explicit_w) {
@@ -726,7 +777,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                         ws = p.cw_off[cg];
                         we = p.cw_off[cg + 1];
                     }
-                    rb_defer_record(p, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
+                    rb_defer_record(kp, r, nr, h0, nh, explicit_w, mono, ws, we, lane);
                 }
                 return;
             }
@@ -800,7 +851,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 out_n = B.op - A.op + 1;
             }
         }
-        const bool emits = mine && !defer && status == RB_ST_OK && !p.desc_mode;
+        if constexpr (BRK) { // a boundary only the generic kernel resolves (it wants the piece's window in its row's place): the whole record goes
+            if (__ballot(mine && defer) != 0ull) {
+                brk_decline();
+                return;
+            }
+        }
+        const bool emits = mine && !defer && status == RB_ST_OK && !desc_mode_;
         const uint32_t e_first = (uint32_t)head + a_op; // coordinate (op index + head, counted from the aligned g0) of the first op
         const uint32_t e_cnt = emits ? out_n : 0u;
         const uint32_t eg_last = e_first + e_cnt - 1u;
@@ -844,7 +901,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         uint4 eg_q1 = *reinterpret_cast<const uint4 *>(gsrc + eg_l);
         __builtin_amdgcn_sched_barrier(0);
         RB_PHASE(2)
-        const uint64_t my_off = (uint64_t)cls * p.slot_stride + slot_row0 + e_first; // out_ops index of my clip's first op
+        const uint64_t my_off = (uint64_t)cls * slot_stride_ + slot_row0 + e_first; // out_ops index of my clip's first op
         // (the row index is formed from an opaque copy of the lane id: otherwise the compiler hoists the row addresses above
         //  the streaming loop and carries -- or spills -- them through it)
         uint32_t lane_late = (uint32_t)lane;
@@ -853,7 +910,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         if (mine) {
             rb_hit_row *row = &p.rows[my_row];
             if (defer) {
-                if constexpr (BRK) p.counters->redo_two_walk = 1; // (the generic kernel wants the piece's window in its row's place)
                 row->rec = r;
                 row->win = win;
                 row->flags = RB_HIT_GENERIC;
@@ -864,7 +920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 w.rec = r;
                 w.win = win;
                 w.status = (uint16_t)status;
-                w.flags = (inside ? RB_HIT_INSIDE : 0) | ((p.desc_mode && status == RB_ST_OK) ? RB_HIT_DESCRIPTOR : 0);
+                w.flags = (inside ? RB_HIT_INSIDE : 0) | ((desc_mode_ && status == RB_ST_OK) ? RB_HIT_DESCRIPTOR : 0);
                 w.out_n = status == RB_ST_OK ? out_n : 0;
                 w.t_st = o_tst;
                 w.t_en = o_ten;
@@ -872,18 +928,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 w.q_en = o_qen;
                 w.nmatch = o_nm;
                 w.aln_len = o_al;
-                w.out_off = status == RB_ST_OK ? (p.desc_mode ? 4ull * my_row : (in_slot ? my_off : 0ull)) : 0; // (copied clips: rb_k_copy_clips fills it in)
+                w.out_off = status == RB_ST_OK ? (desc_mode_ ? 4ull * my_row : (in_slot ? my_off : 0ull)) : 0; // (copied clips: rb_k_copy_clips fills it in)
                 *row = w;
-                if (p.desc_mode && status == RB_ST_OK) // which ops of the ORIGINAL cigar the clip keeps
-                    *reinterpret_cast<uint4 *>(p.out_ops + 4ull * my_row) =
+                if (desc_mode_ && status == RB_ST_OK) // which ops of the ORIGINAL cigar the clip keeps
+                    *reinterpret_cast<uint4 *>(out_ops_ + 4ull * my_row) =
                         make_uint4(nr->first_op + a_op, out_n, inside ? 0u : A.part, inside ? 0u : B.part);
             }
         }
         RB_PHASE(3)
         // ---- the end groups: the lane that owns a clip writes the group(s) holding its first and last op with the clipped
         //      lengths patched in; slots of those groups outside the clip are written as zeros ----
-        if (in_slot && !(p.debug_skip & 1)) {
-            uint32_t *__restrict__ dst = p.out_ops + (uint64_t)cls * p.slot_stride + slot_row0 + eg_f; // the group holding coordinate eg_f
+        if (in_slot && !(dbg & 1)) {
+            uint32_t *__restrict__ dst = out_ops_ + (uint64_t)cls * slot_stride_ + slot_row0 + eg_f; // the group holding coordinate eg_f
             uint32_t q0[4] = {eg_q0.x, eg_q0.y, eg_q0.z, eg_q0.w}, q1[4] = {eg_q1.x, eg_q1.y, eg_q1.z, eg_q1.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -919,8 +975,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
             }
         }
         RB_PHASE(4)
+        } // (behind the stream)
     }
 }
+#undef p
 
 // ------------------------------------------------------------------------------------------------
 // clips that found no place of their own in a slot (windows overlapping deeper than the slots, window lists that are
@@ -1544,6 +1602,44 @@ extern "C" hipError_t rb_launch_break_gather(const rb_lift_params *p, hipStream_
     if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_copy_clips, dim3(2048), dim3(256), 0, stream, *p); // (clips without a slot: their rows are still where the list says)
     hipLaunchKernelGGL(rb_k_break_gather, dim3((unsigned)((p->n_rec * 4 + 255) / 256)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+// one-walk break-paf: the pieces of the records the clip kernel declined get their rows (in the final array, hit_off scanned by
+// now) and their entries in the generic list; then the generic kernel clips them (p.rows = the final rows, p.x_st / x_en = the
+// windows rb_k_break_pieces wrote in list mode) and rb_k_finish sums up
+__global__ __launch_bounds__(256) void rb_k_break_list_declined(rb_lift_params p) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (r >= p.n_rec || p.brk_off[r] != ~1ull) return;
+    p.brk_off[r] = ~0ull; // (the gather leaves the record alone)
+    p.hit_off[r] = 0;     // (rb_k_break_pieces counts its pieces next)
+    p.brk_decl_list[atomicAdd(p.brk_decl_count, 1ull)] = (uint32_t)r;
+}
+extern "C" hipError_t rb_launch_break_list_declined(const rb_lift_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_break_list_declined, dim3((unsigned)((p->n_rec + 255) / 256)), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void rb_k_break_declined_rows(rb_lift_params p) {
+    const uint64_t n_list = *p.brk_decl_count;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < n_list; i += (uint64_t)gridDim.x * 256u) {
+        const uint32_t r = p.brk_decl_list[i];
+        const uint64_t h0 = p.hit_off[r], n = p.hit_off[r + 1] - h0;
+        for (uint64_t j = 0; j < n; j++) {
+            const uint64_t h = h0 + j;
+            if (h >= p.rows_cap) break;
+            rb_hit_row *row = &p.rows[h];
+            row->rec = r;
+            row->win = (uint32_t)j;
+            row->flags = RB_HIT_GENERIC;
+            const unsigned long long g = atomicAdd((unsigned long long *)&p.counters->n_generic, 1ull);
+            p.gen_list[g] = (uint32_t)h;
+        }
+    }
+}
+extern "C" hipError_t rb_launch_break_declined(const rb_lift_params *p, hipStream_t stream) {
+    if (p->n_rec == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_break_declined_rows, dim3((unsigned)std::min<uint64_t>((p->n_rec + 255) / 256, 256)), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(rb_k_liftover_generic_wave, dim3(2048), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
     return hipGetLastError();
 }

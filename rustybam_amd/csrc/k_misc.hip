@@ -1,5 +1,6 @@
 // k_misc.hip -- break-paf piece enumeration, invert (swap), synthetic workload fill (gfx950).
 #include "rb_device.h"
+#include <algorithm>
 #include "synth.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -30,6 +31,9 @@ struct rb_break_params {
     unsigned long long *tmp_cursor; // one bump cursor per arena, 128 bytes apart (a single cursor would serialise every record at one L2 line)
     uint32_t n_arena;
     uint64_t arena_cap;             // slots of tmp[] per arena
+    // list mode (break-paf in one walk: the records its clip kernel declined): wave w takes record list[w], w < *n_list
+    const uint32_t *list;
+    const unsigned long long *n_list;
 };
 #define RB_BP_CAP 512 // pieces of one record kept in LDS by the collect pass
 
@@ -44,15 +48,10 @@ __device__ __forceinline__ uint32_t rb_wave_scan_incl_max(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
-    __shared__ uint2 keep_all[4][RB_BP_CAP];
-    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (wave >= p.n_rec) return;
+__device__ void rb_break_pieces_record(const rb_break_params &p, uint64_t wave, uint32_t r, uint2 *keep) {
     const int lane = rb_lane();
-    const uint32_t r = rb_first(p.sched[wave]);
     const rb_norm_row *nr = &p.norm[r];
     const bool collect = p.fill == 2;
-    uint2 *keep = keep_all[threadIdx.x >> 6];
     if (p.redo_only && p.tmp_off[r] != ~0ull) return;
     if (nr->status != RB_ST_OK) {
         if (p.fill != 1 && lane == 0) {
@@ -206,9 +205,23 @@ __global__ __launch_bounds__(256) void rb_k_break_place(rb_break_params p) {
     }
 }
 
+__global__ __launch_bounds__(256) void rb_k_break_pieces(rb_break_params p) {
+    __shared__ uint2 keep_all[4][RB_BP_CAP];
+    uint2 *keep = keep_all[threadIdx.x >> 6];
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (p.list) { // a fixed grid strides over the list (its length is known on the device only)
+        const uint64_t n_list = *p.n_list;
+        for (uint64_t w = wave; w < n_list; w += (uint64_t)gridDim.x * 4u) rb_break_pieces_record(p, w, rb_first(p.list[w]), keep);
+        return;
+    }
+    if (wave >= p.n_rec) return;
+    rb_break_pieces_record(p, wave, rb_first(p.sched[wave]), keep);
+}
+
 extern "C" hipError_t rb_launch_break_pieces(const rb_break_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
-    hipLaunchKernelGGL(rb_k_break_pieces, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
+    const unsigned blocks = p->list ? (unsigned)std::min<uint64_t>((p->n_rec + 3) / 4, 1024) : (unsigned)((p->n_rec + 3) / 4);
+    hipLaunchKernelGGL(rb_k_break_pieces, dim3(blocks), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t rb_launch_break_place(const rb_break_params *p, hipStream_t stream) {

@@ -90,9 +90,23 @@ struct rb_lift_params {
     uint32_t brk_n_arena;
     uint64_t brk_arena_cap;        // rows per arena
     unsigned long long *brk_cursor; // [brk_n_arena * 16]
-    uint64_t *brk_off;             // [n_rec] first scratch row of the record
+    uint64_t *brk_off;             // [n_rec] first scratch row of the record; ~0: none (no room in the scratch rows, or declined)
     rb_hit_row *rows_final;
+    // records the one-walk kernel declines (irregular CIGARs, a record its verification hands back, a boundary only the generic
+    // kernel resolves): listed here, ONE BY ONE -- their pieces are then found by rb_k_break_pieces in list mode and clipped by the
+    // generic kernel, everybody else's rows stay (round 2 redid the whole batch with two walks when one record declined)
+    uint32_t *brk_decl_list;       // [n_rec]
+    unsigned long long *brk_decl_count;
 };
+
+// the kernel-argument segment of a kernel whose one argument is an rb_lift_params, read with scalar loads where a field is used
+// (rb_k_liftover_stream); rb_kp_here makes a copy of the pointer the compiler cannot see through, so that a load through it is
+// neither merged with the others nor moved to the kernel's entry
+typedef const __attribute__((address_space(4))) rb_lift_params *rb_kparams;
+__device__ __forceinline__ rb_kparams rb_kp_here(rb_kparams q) {
+    asm volatile("" : "+s"(q));
+    return q;
+}
 
 // ------------------------------------------------------------------------------------------------
 // hit counting: paf_overlaps_rgn (paf.rs:622-627) on the NORMALISED record (trim_helper runs
@@ -122,11 +136,14 @@ enum { RB_S_UNRES = 0, RB_S_OK = 1, RB_S_NONE = 2, RB_S_DEFER = 3 };
 __device__ __forceinline__ int rb_ffs64(unsigned long long m) { return __ffsll((long long)m) - 1; }
 
 // append every hit of a record to the generic list (record not eligible for the streaming path)
-__device__ inline void rb_defer_record(const rb_lift_params &p, uint32_t r, const rb_norm_row *nr, uint64_t h0, uint64_t nh,
+__device__ inline void rb_defer_record(rb_kparams kp, uint32_t r, const rb_norm_row *nr, uint64_t h0, uint64_t nh,
                                 bool explicit_w, bool mono, uint64_t ws, uint64_t we, int lane) {
     // (an opaque copy of the lane id: this rare path is inlined into the clip kernel's pass loop, and its row addresses
     //  would otherwise be hoisted out of that loop and carried -- spilled -- through every record)
     asm volatile("" : "+v"(lane));
+    const rb_kparams q_ = rb_kp_here(kp);
+    struct { const uint64_t *w_st, *w_en; const uint32_t *w_orig; rb_hit_row *rows; uint64_t rows_cap; uint32_t *gen_list; rb_counters *counters; } p =
+        {q_->w_st, q_->w_en, q_->w_orig, q_->rows, q_->rows_cap, q_->gen_list, q_->counters};
     if (explicit_w || mono) {
         uint64_t lo = 0;
         if (!explicit_w) lo = rb_lower_en_gt(p.w_en, ws, we, nr->t_st);
@@ -185,46 +202,55 @@ __device__ __forceinline__ bool rb_ism(uint32_t v) { return rb_in(RB_MATCH_MASK,
 
 // ops[] = the record's kept ops, n of them.  (cR,cQ,cU) = prefixes at op index cidx (checkpoint).
 // D in [cR, next checkpoint's R) and D < Rtot.  is_start selects search-right (true) / search-left.
+#ifndef RB_CP_OPS
+#define RB_CP_OPS 8 // ops between two checkpoints of the streaming kernel (16: every second lane leaves one; 8: every lane)
+#endif
+// Round 3: the search inside the checkpoint group is branch-free.  With the exclusive prefixes R_k of the reference lengths,
+// "R_{k+1} <= D" is a monotone predicate p_k over the group's ops (ops in front of or behind the record count as M of length 0), so
+// the op f that holds offset D is the first one with p_k false, its index the number of true ones, and the prefixes at f are the
+// inclusive prefixes of the last op with p_k true: one conditional move each.  No index comparisons, no six-way moves under an
+// exec mask per op (the round-2 form: 27 vector instructions per op, 430 per group).  The op in front of
+// the group is loaded with the group, not after the search has shown that it is needed.
 __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, uint32_t n, int32_t cidx, uint32_t cR, uint32_t cQ,
                                               uint32_t cU, uint32_t D, bool is_start, int policy) {
     rb_bres o;
     o.st = RB_S_DEFER;
     o.op = o.part = o.R = o.Q = o.U = 0;
-    // 16 ops of the checkpoint group (cidx may be negative by up to 3 in the aligned head: masked)
-    uint32_t g[16];
+    uint32_t g[RB_CP_OPS];
+    uint32_t pv;
     {
         const uint4 *q = reinterpret_cast<const uint4 *>(ops + cidx); // 16-byte aligned by construction
-        const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+        const uint4 a0 = q[0], a1 = q[1];
         g[0] = a0.x; g[1] = a0.y; g[2] = a0.z; g[3] = a0.w; g[4] = a1.x; g[5] = a1.y; g[6] = a1.z; g[7] = a1.w;
+#if RB_CP_OPS == 16
+        const uint4 a2 = q[2], a3 = q[3];
         g[8] = a2.x; g[9] = a2.y; g[10] = a2.z; g[11] = a2.w; g[12] = a3.x; g[13] = a3.y; g[14] = a3.z; g[15] = a3.w;
+#endif
+        pv = ops[cidx > 0 ? cidx - 1 : 0]; // the op in front of the group (used only where the group's first op is f and f > 0)
     }
-    // find the ref-consuming op f with Rx <= D < Rx + len
-    int32_t fi = -1;
-    uint32_t fv = 0, fR = 0, fQ = 0, fU = 0, pv = (RB_NULL_OP);
+    uint32_t np = 0, fR = cR, fQ = cQ, fU = cU, fv = 0;
     {
-        uint32_t R = cR, Q = cQ, U = cU, prev = RB_NULL_OP;
+        uint32_t R = cR, Q = cQ, U = cU;
+        bool before = true; // p_{k-1}: every op so far ends at or in front of D
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int32_t idx = cidx + k;
-            const bool valid = (uint32_t)idx < n;
-            const uint32_t v = valid ? g[k] : RB_NULL_OP;
-            const uint32_t rl = valid ? rb_rl(v) : 0u;
-            if (fi < 0 && rl != 0 && (uint32_t)(D - R) < rl) {
-                fi = idx;
-                fv = v;
-                fR = R;
-                fQ = Q;
-                fU = U;
-                pv = prev;
-            }
-            R += rl;
-            Q += valid ? rb_ql(v) : 0u;
-            U += valid ? rb_len(v) : 0u;
-            if (valid) prev = v;
+        for (int k = 0; k < RB_CP_OPS; k++) {
+            const uint32_t v = (uint32_t)(cidx + k) < n ? g[k] : 0u; // (also the negative indices of the aligned head)
+            const uint32_t len = rb_len(v);
+            R += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFDFFFDu, v, 1u); // regular records: ref = not I
+            Q += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFF3FFF3u, v, 1u); //                  query = not D, not N
+            U += len;
+            const bool pk = R <= D;
+            fv = (before && !pk) ? v : fv; // the first op that reaches past D
+            np += pk ? 1u : 0u;
+            fR = pk ? R : fR; // (R, Q, U do not decrease and p is monotone: the last assignment is the prefix at f)
+            fQ = pk ? Q : fQ;
+            fU = pk ? U : fU;
+            pv = pk ? v : pv;
+            before = pk;
         }
     }
-    if (fi < 0) return o; // should not happen; the generic kernel sorts it out
-    if (fi > 0 && pv == RB_NULL_OP) pv = ops[fi - 1]; // previous op lives in the group before
+    if (np >= (uint32_t)RB_CP_OPS) return o; // should not happen; the generic kernel sorts it out
+    const int32_t fi = cidx + (int32_t)np;
     const uint32_t off = D - fR;
     if (is_start) {
         int32_t X; // first match-type op with index >= X
@@ -248,6 +274,7 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
         uint32_t R = fR, Q = fQ, U = fU;
         uint32_t v = fv;
         int32_t i = fi;
+#pragma nounroll // (unrolled 24-fold, each level of the nest parks an exec mask in scalar registers: 100 spills)
         for (int t = 0; t < RB_WALK_MAX; t++) {
             if (i >= X && rb_ism(v)) {
                 o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
@@ -282,6 +309,7 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
         // walk left (paf.rs:555-557): (R,Q,U) are the prefixes at the END of op i
         uint32_t R = fR, Q = fQ, U = fU;
         int32_t i = fi - 1;
+#pragma nounroll // (unrolled 24-fold, each level of the nest parks an exec mask in scalar registers: 100 spills)
         for (int t = 0; t < RB_WALK_MAX; t++) {
             if (i < 0) {
                 o.st = RB_S_NONE; // stops at unit 0, which lies before any start
@@ -311,13 +339,15 @@ struct rb_pass_win {
     uint64_t wst, wen;
     uint32_t win;
 };
-__device__ __forceinline__ rb_pass_win rb_pass_windows(const rb_lift_params &p, uint32_t *widx, bool explicit_w, bool mono, uint64_t ws,
+__device__ __forceinline__ rb_pass_win rb_pass_windows(rb_kparams kp, uint32_t *widx, bool explicit_w, bool mono, uint64_t ws,
                                                        uint64_t we, uint64_t lo, uint64_t h0, uint64_t jb, uint32_t nb, uint64_t t_st,
                                                        uint64_t t_en, uint64_t &scan_pos, int lane) {
     rb_pass_win o;
     o.wst = o.wen = 0;
     o.win = 0;
     asm volatile("" : "+v"(lane)); // (opaque: keeps lo + lane from being hoisted out of the pass loop and spilled)
+    const rb_kparams q_ = rb_kp_here(kp);
+    struct { const uint64_t *w_st, *w_en, *x_st, *x_en; const uint32_t *w_orig; } p = {q_->w_st, q_->w_en, q_->x_st, q_->x_en, q_->w_orig};
     const uint32_t hl = (uint32_t)lane & 31u;
     const bool own = hl < nb;
     if (!explicit_w && !mono) {

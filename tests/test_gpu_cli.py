@@ -535,3 +535,35 @@ def test_gpus_flag_panic_in_one_shard(golden, tmp_path):
     assert out2 == out1 and out1.startswith(b"#")
     rc3, out3 = rb("--gpus", 2, "break-paf", src, env={"RB_GPUS_SAME_DEVICE": "1"})
     assert rc3 == 101 and out3 == b""
+
+
+@pytest.mark.parametrize("args", [
+    ["liftover", "--bed", "{bed}", "{paf}"],
+    ["break-paf", "--max-size", "100", "{paf}"],
+    ["--bsearch", "legacy", "break-paf", "--max-size", "10", "{paf}"],
+])
+def test_pipelined_text_route_equals_the_whole_file_route(golden, args, tmp_path):
+    """big plain files go through a pipeline over chunks (rb_host lift_file_text_pipelined; RB_CHUNK_KB makes the 2 MB fixture 'big'):
+    same bytes as the whole-file route -- streamed into a regular file when the input is sorted by target, after a rewind when it
+    is not (shuffled copy: contig ranks decrease along the chunks), kept and ordered at the end into a pipe and under --gpus"""
+    for src in (f"{golden}/asm_small.paf", _shuffled(golden, tmp_path, 21)):
+        a = [x.format(paf=src, bed=f"{golden}/asm_small.bed") for x in args]
+        rc0, want = rb(*a, env={"RB_NO_PIPELINE": "1"})
+        assert rc0 == 0 and len(want) > 1000
+        for kb in ("64", "300", "900"):
+            env = {"RB_CHUNK_KB": kb, "RB_GPUS_SAME_DEVICE": "1"}
+            rc1, piped = rb(*a, env=env)
+            assert rc1 == 0 and piped == want, (a, kb, "pipe")
+            with open(tmp_path / "o.paf", "wb") as f:
+                r = subprocess.run([RB, *a], stdout=f, stderr=subprocess.PIPE, env={**os.environ, **env})
+            assert r.returncode == 0 and open(tmp_path / "o.paf", "rb").read() == want, (a, kb, "file")
+            rc2, sharded = rb("--gpus", 2, *a, env=env)
+            assert rc2 == 0 and sharded == want, (a, kb, "--gpus 2")
+    # a line the reference panics on, in a late chunk: exit code 101, nothing but what the single run prints
+    lines = [l for l in open(f"{golden}/asm_small.paf", "rb").read().split(b"\n") if l]
+    bad = tmp_path / "bad.paf"
+    bad.write_bytes(b"\n".join(lines[:-3] + [lines[-3].replace(b"cg:Z:", b"cg:Z:7Q")] + lines[-2:]) + b"\n")
+    a = [x.format(paf=str(bad), bed=f"{golden}/asm_small.bed") for x in args]
+    rc0, out0 = rb(*a, env={"RB_NO_PIPELINE": "1"})
+    rc1, out1 = rb(*a, env={"RB_CHUNK_KB": "200"})
+    assert rc0 == 101 and rc1 == 101 and out0 == b""

@@ -1,12 +1,25 @@
 #!/bin/bash
-# same-box A/B of prebuilt library variants (rustybam_amd/variants/<name>.so): bench.py kernel time, two interleaved rounds
+# same-box A/B of prebuilt library variants (rustybam_amd/variants/<name>.so, tools/mkvariant.sh): bench.py kernel time, AB_ROUNDS
+# interleaved rounds (default 4); the same binary differs by +-0.7 ms between two processes on one box (where the driver places the
+# 20 / 30 GB buffers), so min and median over the rounds are what to compare
 cd $GRAFT_REPO_ROOT
 cp rustybam_amd/librustybam_amd.so /tmp/keep.so
-for round in 1 2; do
+rounds=${AB_ROUNDS:-4}
+rm -f /tmp/ab_times.txt
+for round in $(seq $rounds); do
   for n in "$@"; do
     cp rustybam_amd/variants/$n.so rustybam_amd/librustybam_amd.so
     python bench.py --steps 10 --no-cpu-baseline $AB_ARGS 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('$n', 'step %.3f' % d['ms_per_step'], 'kernel %.3f' % d['roofline']['kernel_ms'], d.get('output_digest'))"
+import json,sys; d=json.loads(sys.stdin.read()); print('$n', 'step %.3f' % d['ms_per_step'], 'kernel %.3f' % d['roofline']['kernel_ms'], d.get('output_digest'))" | tee -a /tmp/ab_times.txt
   done
 done
 cp /tmp/keep.so rustybam_amd/librustybam_amd.so
+python - <<'PY'
+import collections, statistics
+t = collections.defaultdict(list)
+for ln in open('/tmp/ab_times.txt'):
+    f = ln.split()
+    t[f[0]].append(float(f[4]))
+for k, v in t.items():
+    print(f"{k:>14}: kernel ms min {min(v):.3f}  median {statistics.median(v):.3f}  max {max(v):.3f}  ({len(v)} runs)")
+PY
