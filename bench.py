@@ -59,9 +59,10 @@ def parse():
                     help="RB_LIFT_DESCRIPTORS: return which ops each clip keeps instead of copying them (not the headline mode)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --records per GPU; strong: --records in all, cut into one op-balanced record range per GPU")
-    ap.add_argument("--e2e-records", type=int, default=100_000,
-                    help="records of the text-in -> text-out leg (`rb liftover` on the PAF text of the same workload, first byte read to "
-                         "last byte written); 0 = skip")
+    ap.add_argument("--e2e-records", type=int, default=1_000_000,
+                    help="records of the text-in -> text-out leg (`rb [--gpus N] liftover` on the PAF text of the same workload, first byte "
+                         "read to last byte written; 1e6 = the headline size, 14.7 GB in / 19 GB out in /dev/shm -- cut to 1e5 when the "
+                         "host lacks the memory); 0 = skip")
     ap.add_argument("--launch-dry-run", action="store_true", help=argparse.SUPPRESS)  # tests: ranks report their environment and exit
     return ap.parse_args()
 
@@ -103,17 +104,26 @@ def launch_ranks(args):
     return rc
 
 
-def e2e_leg(n_rec, n_win):
+def e2e_leg(n_rec, n_win, gpus=1):
     """end-to-end PAF-records/s = input records / wall time from the first byte read to the last byte written, for the
-    `rb liftover` front end (C++ host + this GPU) on the text form of the same workload.  Runs as child processes, before this
-    process has touched the GPU.  Returns a dict for the JSON line, or None when the front end is not built."""
+    `rb liftover` front end (C++ host + this GPU; `rb --gpus N` = N worker processes, one per GPU, host-side gather) on the text
+    form of the same workload.  Runs as child processes, before this process has touched the GPU.  Returns a dict for the JSON
+    line, or None when the front end is not built."""
     import shutil
     import subprocess
     import tempfile
     rb = os.path.join(ROOT, "rustybam_amd", "rb")
     if not os.path.exists(rb):
         return None
-    d = tempfile.mkdtemp(prefix="rb_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    try:  # 35 KB of text per record in + out, and the front end holds its output in memory once more
+        st = os.statvfs(shm or "/tmp")
+        avail = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1]) * 1024
+        if min(st.f_bavail * st.f_frsize, avail) < n_rec * 120_000:
+            n_rec = min(n_rec, 100_000)
+    except Exception:
+        n_rec = min(n_rec, 100_000)
+    d = tempfile.mkdtemp(prefix="rb_e2e_", dir=shm)
     try:
         paf, bed, out = (os.path.join(d, x) for x in ("w.paf", "w.bed", "out.paf"))
         t0 = time.perf_counter()
@@ -123,15 +133,20 @@ def e2e_leg(n_rec, n_win):
             subprocess.check_call([rb, "synth-bed", str(n_win)], stdout=f)
         gen_s = time.perf_counter() - t0
         best = None
+        pre = ["--gpus", str(gpus)] if gpus > 1 else []
+        env = dict(os.environ)
+        if os.environ.get("RB_BENCH_SAME_DEVICE") == "1":
+            env["RB_GPUS_SAME_DEVICE"] = "1"
         for _ in range(2):  # (the first run also pages the binary and the HIP runtime in)
             t0 = time.perf_counter()
             with open(out, "wb") as f:
-                subprocess.check_call([rb, "liftover", "--bed", bed, paf], stdout=f)
+                subprocess.check_call([rb, *pre, "liftover", "--bed", bed, paf], stdout=f, env=env)
             dt = time.perf_counter() - t0
             best = dt if best is None or dt < best else best
-        return {"e2e_paf_records_per_s": n_rec / best, "e2e": {"records": n_rec, "windows": n_win, "seconds": round(best, 3),
+        return {"e2e_paf_records_per_s": n_rec / best, "e2e": {"records": n_rec, "windows": n_win, "seconds": round(best, 3), "n_gpus": gpus,
                                                                 "in_bytes": os.path.getsize(paf), "out_bytes": os.path.getsize(out),
-                                                                "command": "rb liftover --bed w.bed w.paf > out.paf (text in, text out; HIP start-up included)",
+                                                                "command": f"rb {' '.join(pre)} liftover --bed w.bed w.paf > out.paf (text in, text out; HIP start-up "
+                                                                           "included; big plain files go through the pipelined route)",
                                                                 "setup_s": round(gen_s, 1)}}
     finally:
         shutil.rmtree(d, ignore_errors=True)
@@ -153,8 +168,10 @@ def main():
                           "port": os.environ.get("MASTER_PORT"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
         return
     e2e = None
-    if rank == 0 and world == 1 and args.e2e_records > 0 and args.workload == "config3" and args.op == "liftover" and not args.no_cpu_baseline:
-        e2e = e2e_leg(args.e2e_records, args.windows)  # (child processes, before this one initialises the GPU)
+    if rank == 0 and args.e2e_records > 0 and args.workload == "config3" and args.op == "liftover" and not args.no_cpu_baseline:
+        # (child processes, before this one initialises the GPU; with N ranks: `rb --gpus N` on the same file while the other ranks
+        #  wait for rank 0 at the rendezvous)
+        e2e = e2e_leg(args.e2e_records, args.windows, world)
     import torch
     import torch.distributed as dist
     import rustybam_amd
@@ -382,16 +399,26 @@ def main():
     if args.op == "break" or irregular:  # (no single dominant kernel under HIP events: the rate is taken over the whole step)
         k_ms = elapsed / args.steps * 1e3
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
-    traffic = None  # HBM-side bytes per launch from the committed PMC run of this same workload (bench.py is not run under --pmc)
+    # HBM-side bytes per launch from the committed PMC run of this same workload (bench.py is not run under --pmc).  The file names the
+    # hash of the kernel sources it was measured on: a figure measured on other sources is refused (null + a note), not reported
+    traffic, traffic_note = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_r02.json")))
-        if tj["workload"] == {"records_per_gpu": n_rec, "windows": int(len(w_st)), "workload": args.workload} and not args.descriptors and args.op == "liftover":
-            traffic = tj["traffic_bytes_per_launch"]
+        import glob
+        for tf in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_r[0-9][0-9].json")), reverse=True):
+            tj = json.load(open(tf))
+            if tj["workload"] != {"records_per_gpu": n_rec, "windows": int(len(w_st)), "workload": args.workload} or args.descriptors or args.op != "liftover" \
+                    or args.irregular_frac > 0:
+                continue
+            if tj.get("kernel_source_sha") == wl.kernel_source_sha():
+                traffic, traffic_note = tj["traffic_bytes_per_launch"], f"{os.path.basename(tf)} (measured on these kernel sources, {tj.get('git_head', '?')})"
+            else:
+                traffic_note = f"{os.path.basename(tf)} is stale: measured on other kernel sources ({tj.get('kernel_source_sha')}), not reported"
+            break
     except Exception:
         pass
     roofline = {"bound": "hbm", "kernel": ("rb_k_liftover_generic_wave (whole step: the streaming kernel only verifies and defers)" if irregular else "rb_k_liftover_stream") if args.op == "liftover"
                 else "rb_dev_break (rb_k_break_pieces + rb_k_liftover_stream)", "achieved": round(achieved, 1), "peak": 8000.0,
-                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)}
 
@@ -485,6 +512,42 @@ def main():
             b = oops[int(orows["out_off"][i]): int(orows["out_off"][i]) + int(orows["out_n"][i])]
             assert np.array_equal(a, b), f"sample parity: cigar of row {i}"
         result["parity_sample"] = f"ok: {nrow} rows of {k} records identical to the oracle, {len(pick)} cigars compared"
+        # ---- "also time the op-space CPU path on the full input" -- oracle/rb_opspace.c, a CPU port of the op-space
+        #      formulation (no per-base expansion), OpenMP over records, on ALL records of rank 0's batch when the host has the
+        #      memory for them (20 GB of ops + 25 GB of clipped CIGARs), else on a fifth of them.  Its rows for the sample above
+        #      must equal the per-base oracle's. ----
+        try:
+            avail_gb = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1]) / 1e6
+        except Exception:
+            avail_gb = 0.0
+        k_os = n_rec if avail_gb > 16 * total_ops * 4 / 1e9 / 5 + 32 else max(k, n_rec // 5)
+        if avail_gb > 8:
+            ops_host = d_ops[: int(op_off[k_os])].cpu().numpy().view(np.uint32)
+            ob = pyoracle.Batch(ops_host, op_off[: k_os + 1], t_st[:k_os], t_en[:k_os], q_st[:k_os], q_en[:k_os], strand[:k_os], np.zeros(k_os, np.uint32))
+            os_runs = {}
+            for nt in sorted({min(64, threads), threads}):
+                tb_ = time.perf_counter()
+                got = pyoracle.liftover_opspace(ob, w_c, w_st, w_en, n_threads=nt)
+                os_runs[nt] = time.perf_counter() - tb_
+                assert got is not None, "the op-space baseline refused the synthetic records"
+                if nt == min(64, threads):
+                    srows = got[0][: len(orows)]
+                    for key in ("rec", "win", "status", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
+                        okm = orows["status"] == 0 if key not in ("rec", "win", "status") else slice(None)
+                        assert np.array_equal(srows[key][okm], orows[key][okm]), f"op-space baseline vs per-base oracle: {key}"
+                    n_os_rows = len(got[0])
+                del got
+            best_os = min(os_runs, key=os_runs.get)
+            os_ops = int(op_off[k_os])
+            result["cpu_baseline"]["opspace"] = {
+                "value": os_ops / os_runs[best_os], "unit": "CIGAR-ops/s", "cores": best_os, "kind": "port",
+                "records_per_s": k_os / os_runs[best_os], "rows": n_os_rows,
+                "sample": (f"all {k_os} records of the batch" if k_os == n_rec else f"the first {k_os} records") +
+                          f" ({os_ops} ops) x {len(w_st)} windows, op-space CPU port (oracle/rb_opspace.c: prefix sums + binary search per "
+                          f"boundary, no per-base expansion), OpenMP over records, {os_runs[best_os]:.1f} s; its rows for the parity sample "
+                          f"equal the per-base oracle's",
+                "by_threads": {str(nt): {"value": os_ops / dt, "seconds": round(dt, 2)} for nt, dt in sorted(os_runs.items())}}
+            del ops_host, ob
 
     if rank == 0:
         print(json.dumps(result))

@@ -16,6 +16,7 @@
  *   rb_dev_break          <- liftover::break_paf_on_indels                liftover.rs:182-226
  *   rb_dev_swap           <- paf::paf_swap_query_and_target               paf.rs:1050-1094
  *   rb_dev_overlap_split  <- trim_overlap::trim_overlapping_pafs          trim_overlap.rs:36-86
+ *   rb_dev_trim_select    <- the pair scan / selection of Paf::overlapping_paf_recs   paf.rs:223-284
  *                            + PafRecord::truncate_record_by_query        paf.rs:785-823
  *                            (the pass / recursion driver Paf::overlapping_paf_recs, paf.rs:210-305, stays on the host)
  *   rb_dev_nucfreq        <- nucfreq::nucfreq / region_nucfreq            nucfreq.rs:61-95, :111-125
@@ -287,6 +288,27 @@ int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *batch, const rb_norm_
  *     (e.g. for rb_dev_break: the README pipeline trim-paf | break-paf). */
 int rb_dev_apply_pairs(rb_ctx *ctx, uint64_t n_pairs, const uint32_t *left, const uint32_t *right, const rb_pair_row *rows,
                        uint64_t *op_off, rb_norm_row *norm_rows);
+
+/* rb_dev_trim_select: which pairs a pass of Paf::overlapping_paf_recs cuts, found on the device (paf.rs:223-284: the pair scan per
+ *     query name over bed::get_overlap, the contained flags :244-249, "pairs by overlap descending, then the first pair of every
+ *     query name" :262-284 = per group the pair of largest overlap, among equals the first in scan order).  order [n_rec] = the
+ *     records stably sorted by query name (:223), grp_off [n_groups + 1] = where the groups of equal names begin in it (both device
+ *     arrays the caller builds once).  Outputs: contained [n_rec] by RECORD (this pass's flags: the ones that count are the last
+ *     pass's, :224), the chosen pairs dense in left / right / pair_out_off (room for n_groups each; pair k writes its clips at
+ *     pair_out_off[k] >= out_base, n_ops(left) + n_ops(right) apart), and *pass (device memory, 64 bytes): n_pairs, n_deferred (pairs
+ *     left for a later pass: the recursion of :286-288 goes on while it is not 0), ops_end (first op behind this pass's clips).
+ *     scratch: rb_trim_select_scratch_bytes(n_groups).  Then rb_dev_overlap_split + rb_dev_apply_pairs on the n_pairs pairs, and
+ *     rb_dev_trim_check folds the pair rows' statuses into pass->bad_status (0: every pair was cut). */
+typedef struct rb_trim_pass {
+    uint64_t n_pairs, n_deferred, ops_end;
+    uint32_t bad_status, _pad;
+    uint64_t _reserved[4];
+} rb_trim_pass; /* 64 B */
+size_t rb_trim_select_scratch_bytes(uint64_t n_groups);
+int rb_dev_trim_select(rb_ctx *ctx, uint64_t n_rec, uint64_t n_groups, const uint32_t *order, const uint64_t *grp_off,
+                       const rb_norm_row *norm_rows, uint64_t out_base, uint8_t *contained, uint32_t *left, uint32_t *right,
+                       uint64_t *pair_out_off, rb_trim_pass *pass, void *scratch);
+int rb_dev_trim_check(rb_ctx *ctx, uint64_t n_pairs, const rb_pair_row *rows, rb_trim_pass *pass);
 int rb_dev_gather_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const rb_norm_row *norm_rows,
                           uint64_t *new_op_off, uint32_t *new_ops, void *scratch);
 

@@ -129,6 +129,20 @@ def liftover(b, w_contig, w_st, w_en, policy=MODERN, n_threads=1):
     return _take(hits, nh.value, HIT_DT), _take(ops, no.value, np.uint32)
 
 
+def liftover_opspace(b, w_contig, w_st, w_en, n_threads=1):
+    """the op-space CPU baseline (rb_opspace.c): same rows as liftover() for regular records, modern policy; None if unsupported"""
+    w_contig, w_st, w_en = _arr(w_contig, np.uint32), _arr(w_st, np.uint64), _arr(w_en, np.uint64)
+    hits, ops = C.c_void_p(), C.c_void_p()
+    nh, no = C.c_uint64(), C.c_uint64()
+    f = lib().rbo_liftover_opspace_arrays
+    f.restype = C.c_int
+    rc = f(*b.args(True), _p(b.contig), C.c_uint64(len(w_st)), _p(w_contig), _p(w_st), _p(w_en), C.c_int(n_threads), C.byref(hits),
+           C.byref(nh), C.byref(ops), C.byref(no))
+    if rc != 0:
+        return None
+    return _take(hits, nh.value, HIT_DT), _take(ops, no.value, np.uint32)
+
+
 def break_paf(b, max_size, policy=MODERN, n_threads=1):
     hits, ops = C.c_void_p(), C.c_void_p()
     nh, no = C.c_uint64(), C.c_uint64()

@@ -712,11 +712,35 @@ static void subset_collapse(const uint8_t *lc, size_t a, size_t b, uint32_t **op
     *n_ops = cnt;
 }
 
-/* paf.rs:622-627 */
-static int paf_overlaps_rgn(const rbo_rec *p, const rbo_region *g) {
-    if (strcmp(p->t_name, g->name) != 0) return 0;
-    return p->t_en > g->st && p->t_st < g->en;
+/* bed.rs:66-71 has_overlap; bed.rs:74-85 get_overlap; bed.rs:215-235 split_region: the three region helpers the path uses, exposed so
+ * that the reference's doctest vectors for them (bed.rs:51-64, :199-214) can be held against this restatement */
+int rbo_has_overlap(const char *name1, uint64_t st1, uint64_t en1, const char *name2, uint64_t st2, uint64_t en2) {
+    if (strcmp(name1, name2) != 0) return 0;
+    return en1 > st2 && st1 < en2;
 }
+uint64_t rbo_get_overlap(const char *name1, uint64_t st1, uint64_t en1, const char *name2, uint64_t st2, uint64_t en2) {
+    if (strcmp(name1, name2) != 0) return 0;
+    const uint64_t mn = en1 < en2 ? en1 : en2, mx = st1 > st2 ? st1 : st2;
+    if (mn < mx) return 0;
+    return mn - mx;
+}
+/* the k-th piece of split_region(rgn, window); returns 0 when there is no such piece */
+int rbo_split_region(uint64_t st, uint64_t en, uint64_t window, uint64_t k, uint64_t *pst, uint64_t *pen) {
+    uint64_t start = st;
+    for (uint64_t i = 0; start < en; i++) {
+        uint64_t end = start + window;
+        if (end > en) end = en;
+        if (i == k) {
+            *pst = start, *pen = end;
+            return 1;
+        }
+        start = end;
+    }
+    return 0;
+}
+
+/* paf.rs:622-627 */
+static int paf_overlaps_rgn(const rbo_rec *p, const rbo_region *g) { return rbo_has_overlap(p->t_name, p->t_st, p->t_en, g->name, g->st, g->en); }
 
 /* ------------------------------------------------------------------ liftover.rs:17-105
  * returns RBO_OK with *out filled, RBO_NONE_* (reference returns None), or RBO_PANIC_*. */
@@ -1065,13 +1089,7 @@ static int cmp_pair(const void *ctx, size_t a, size_t b) {
 }
 
 /* bed.rs:74-85 with paf.rs:459-466 */
-static uint64_t query_overlap(const rbo_rec *a, const rbo_rec *b) {
-    if (strcmp(a->q_name, b->q_name) != 0) return 0;
-    uint64_t mn = a->q_en < b->q_en ? a->q_en : b->q_en;
-    uint64_t mx = a->q_st > b->q_st ? a->q_st : b->q_st;
-    if (mn < mx) return 0;
-    return mn - mx;
-}
+static uint64_t query_overlap(const rbo_rec *a, const rbo_rec *b) { return rbo_get_overlap(a->q_name, a->q_st, a->q_en, b->q_name, b->q_st, b->q_en); }
 
 /* paf.rs:210-305 (the recursion is a loop here) */
 int rbo_overlapping_paf_recs(rbo_paf *paf, int ms, int ds, int is, int remove_contained, int policy) {
@@ -2156,13 +2174,13 @@ int rbo_bam_nucfreq(const char *path, const char *region, const char *bed_path, 
         int32_t tid = -1;
         for (uint32_t k = 0; k < n_ref; k++)
             if (!strcmp(ref_nm[k], R->name)) { tid = (int32_t)k; break; }
-        for (uint64_t m0 = R->st; m0 < R->en && !rc; m0 += 1000000) { /* bed.rs:215-235 split_region(1 Mbp) */
-            uint64_t m1 = m0 + 1000000 < R->en ? m0 + 1000000 : R->en;
+        uint64_t m0, m1;
+        for (uint64_t mk = 0; !rc && rbo_split_region(R->st, R->en, 1000000, mk, &m0, &m1); mk++) { /* main.rs:101: split_region(1 Mbp) */
             if (tid < 0) { rc = -8; break; } /* fetch fails: "Is this region in your reference/bam?" */
             if (!small) fprintf(out, "#chr\tstart\tend\tA\tC\tG\tT\tregion_id\n"); /* nucfreq.rs:127-131 */
             int first = 1;
-            for (uint64_t s0 = m0; s0 < m1 && !rc; s0 += 10000) { /* split_region(10 kbp), one fetch + pileup each */
-                uint64_t s1 = s0 + 10000 < m1 ? s0 + 10000 : m1;
+            uint64_t s0, s1;
+            for (uint64_t sk = 0; !rc && rbo_split_region(m0, m1, 10000, sk, &s0, &s1); sk++) { /* split_region(10 kbp), one fetch + pileup each */
                 rbo_nucfreq_row *rows = NULL;
                 size_t nr = 0;
                 rc = rbo_nucfreq(rd, n, tid, s0, s1, &rows, &nr);

@@ -165,6 +165,9 @@ int64_t rbo_nucfreq_arrays(uint64_t n_reads, const int32_t *tid, const int64_t *
                            const uint32_t *ops, const uint32_t *l_seq, const uint64_t *seq_off, const uint8_t *seq, int32_t rtid,
                            uint64_t st, uint64_t en, uint32_t *out_pos, uint64_t *out_cnt, uint64_t cap);
 int rbo_parse_region(const char *s, rbo_region *out); /* bed.rs:104-131 */
+int rbo_has_overlap(const char *name1, uint64_t st1, uint64_t en1, const char *name2, uint64_t st2, uint64_t en2);      /* bed.rs:66-71 */
+uint64_t rbo_get_overlap(const char *name1, uint64_t st1, uint64_t en1, const char *name2, uint64_t st2, uint64_t en2); /* bed.rs:74-85 */
+int rbo_split_region(uint64_t st, uint64_t en, uint64_t window, uint64_t k, uint64_t *pst, uint64_t *pen);              /* bed.rs:215-235 */
 int rbo_bam_nucfreq(const char *path, const char *region, const char *bed_path, int small, FILE *out);
 
 /* --- stats (bamstats.rs:16-36, :107-154, :225-270) --- */
@@ -227,6 +230,14 @@ int rbo_liftover_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_
                         const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
                         const uint64_t *w_en, int policy, int n_threads, rbo_hit_row **hits, uint64_t *n_hits,
                         uint32_t **out_ops, uint64_t *n_out);
+
+/* the same in op space (rb_opspace.c): the second CPU baseline of SURVEY.md 8(d).  Regular records and the modern policy only;
+ * returns 7 (unsupported) for the whole call otherwise.  Same rows, same clipped CIGARs, same order. */
+int rbo_liftover_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,
+                                const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand,
+                                const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
+                                const uint64_t *w_en, int n_threads, rbo_hit_row **hits, uint64_t *n_hits,
+                                uint32_t **out_ops, uint64_t *n_out);
 
 /* break-paf: every record, record order; win field = piece ordinal within the record */
 int rbo_break_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,

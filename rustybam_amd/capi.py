@@ -31,6 +31,7 @@ PAIR_DT = np.dtype(
     [("split_idx", "<u8"), ("split_score", "<i4"), ("status", "<u4"), ("t_st", "<u8", 2), ("t_en", "<u8", 2),
      ("q_st", "<u8", 2), ("q_en", "<u8", 2), ("nmatch", "<u4", 2), ("aln_len", "<u4", 2), ("out_off", "<u8", 2),
      ("out_n", "<u4", 2), ("_pad", "<u8")])
+TRIM_PASS_DT = np.dtype([("n_pairs", "<u8"), ("n_deferred", "<u8"), ("ops_end", "<u8"), ("bad_status", "<u4"), ("_pad", "<u4"), ("_reserved", "<u8", 4)])
 COUNTERS_DT = np.dtype(
     [("n_hits", "<u8"), ("out_ops_needed", "<u8"), ("out_ops_used", "<u8"), ("n_generic", "<u8"),
      ("overflow", "<u4"), ("phase", "<u4", 5), ("brk_scratch_short", "<u4"), ("redo_two_walk", "<u4")])
@@ -163,6 +164,21 @@ class Engine:
     def dev_apply_pairs(self, n_pairs, left_ptr, right_ptr, rows_ptr, op_off_ptr, norm_ptr):
         self._chk(self.L.rb_dev_apply_pairs(self.ctx, C.c_uint64(n_pairs), C.c_void_p(left_ptr), C.c_void_p(right_ptr), C.c_void_p(rows_ptr),
                                             C.c_void_p(op_off_ptr), C.c_void_p(norm_ptr)), "rb_dev_apply_pairs")
+
+    def trim_select_scratch_bytes(self, n_groups):
+        f = self.L.rb_trim_select_scratch_bytes
+        f.restype = C.c_size_t
+        return int(f(C.c_uint64(n_groups)))
+
+    def dev_trim_select(self, n_rec, n_groups, order_ptr, grp_off_ptr, norm_ptr, out_base, contained_ptr, left_ptr, right_ptr, pair_out_off_ptr,
+                        pass_ptr, scratch_ptr):
+        self._chk(self.L.rb_dev_trim_select(self.ctx, C.c_uint64(n_rec), C.c_uint64(n_groups), C.c_void_p(order_ptr), C.c_void_p(grp_off_ptr),
+                                            C.c_void_p(norm_ptr), C.c_uint64(out_base), C.c_void_p(contained_ptr), C.c_void_p(left_ptr),
+                                            C.c_void_p(right_ptr), C.c_void_p(pair_out_off_ptr), C.c_void_p(pass_ptr), C.c_void_p(scratch_ptr)),
+                  "rb_dev_trim_select")
+
+    def dev_trim_check(self, n_pairs, rows_ptr, pass_ptr):
+        self._chk(self.L.rb_dev_trim_check(self.ctx, C.c_uint64(n_pairs), C.c_void_p(rows_ptr), C.c_void_p(pass_ptr)), "rb_dev_trim_check")
 
     def dev_gather_records(self, n_rec, ops_ptr, op_off_ptr, norm_ptr, new_off_ptr, new_ops_ptr, scratch_ptr):
         self._chk(self.L.rb_dev_gather_records(self.ctx, C.c_uint64(n_rec), C.c_void_p(ops_ptr), C.c_void_p(op_off_ptr), C.c_void_p(norm_ptr),

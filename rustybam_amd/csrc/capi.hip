@@ -335,7 +335,8 @@ static void par_memcpy(void *dst, const void *src, size_t n) { // a chunk of the
         return;
     }
     std::vector<std::thread> th;
-    const size_t part = (n / T + 63) & ~(size_t)63;
+    const size_t part = ((n + T - 1) / T + 63) & ~(size_t)63; // (rounded UP before the alignment: n / T rounded down left the last n % T bytes of a chunk uncopied
+                                                              //  whenever n / T was a multiple of 64 -- found by the md5 of a 19 GB output, round 3)
     for (unsigned t = 1; t < T; t++) {
         const size_t lo = std::min(n, t * part), hi = std::min(n, (t + 1) * part);
         if (hi > lo) th.emplace_back([=]() { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
@@ -735,6 +736,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     }
     if (is_break) {
         rb_break_params bp;
+        memset(&bp, 0, sizeof bp);
         bp.n_rec = b->n_rec;
         bp.ops = b->ops;
         bp.op_off = b->op_off;
@@ -867,6 +869,48 @@ struct rb_gather_params {
     uint32_t *new_ops;
     int fill;
 };
+struct rb_tsel_params {
+    uint64_t n_groups;
+    const uint32_t *order;
+    const uint64_t *grp_off;
+    const rb_norm_row *norm;
+    uint8_t *contained;
+    uint64_t *slot;
+    uint32_t *cand;
+    uint64_t out_base;
+    uint32_t *left, *right;
+    uint64_t *pair_out_off;
+    rb_trim_pass *pass;
+};
+extern "C" hipError_t rb_launch_trim_select(const rb_tsel_params *p, uint64_t *block_sums, hipStream_t stream);
+extern "C" hipError_t rb_launch_trim_check(const rb_pair_row *rows, uint64_t n_pairs, rb_trim_pass *pass, hipStream_t stream);
+// scratch of rb_dev_trim_select: [slot (n_groups + 2) u64][cand 2 n_groups u32][block sums of the scan]
+extern "C" size_t rb_trim_select_scratch_bytes(uint64_t n_groups) {
+    return (((n_groups + 2) * 8 + 255) & ~(size_t)255) + ((2 * n_groups * 4 + 255) & ~(size_t)255) + (rb_scan_block_sums_count(n_groups) + 4) * 8 + 256;
+}
+extern "C" int rb_dev_trim_select(rb_ctx *ctx, uint64_t n_rec, uint64_t n_groups, const uint32_t *order, const uint64_t *grp_off,
+                                  const rb_norm_row *norm_rows, uint64_t out_base, uint8_t *contained, uint32_t *left, uint32_t *right,
+                                  uint64_t *pair_out_off, rb_trim_pass *pass, void *scratch) {
+    if (!ctx || !pass || (n_groups && (!order || !grp_off || !norm_rows || !contained || !left || !right || !pair_out_off || !scratch))) return RB_E_INVALID;
+    (void)n_rec;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    rb_tsel_params p;
+    memset(&p, 0, sizeof p);
+    char *sc = (char *)scratch;
+    p.n_groups = n_groups, p.order = order, p.grp_off = grp_off, p.norm = norm_rows, p.contained = contained;
+    p.slot = (uint64_t *)sc;
+    sc += ((n_groups + 2) * 8 + 255) & ~(size_t)255;
+    p.cand = (uint32_t *)sc;
+    sc += (2 * n_groups * 4 + 255) & ~(size_t)255;
+    p.out_base = out_base, p.left = left, p.right = right, p.pair_out_off = pair_out_off, p.pass = pass;
+    HIPCHK(ctx, rb_launch_trim_select(&p, (uint64_t *)sc, ctx->stream));
+    return RB_OK;
+}
+extern "C" int rb_dev_trim_check(rb_ctx *ctx, uint64_t n_pairs, const rb_pair_row *rows, rb_trim_pass *pass) {
+    if (!ctx || !pass || (n_pairs && !rows)) return RB_E_INVALID;
+    HIPCHK(ctx, rb_launch_trim_check(rows, n_pairs, pass, ctx->stream));
+    return RB_OK;
+}
 extern "C" hipError_t rb_launch_apply_pairs(const rb_apply_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_gather_records(const rb_gather_params *p, hipStream_t stream);
 extern "C" int rb_dev_apply_pairs(rb_ctx *ctx, uint64_t n_pairs, const uint32_t *left, const uint32_t *right, const rb_pair_row *rows,
@@ -1432,6 +1476,21 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
             else rb_advise_huge(*row_text, (size_t)bytes);
         }
         if (!rc && bytes) rc = rb_dev_download(ctx, *row_text, d_rtext, (size_t)bytes);
+        if (!rc && bytes && getenv("RB_DEBUG_TEXT_CHECK")) { // diagnostics: CIGAR text holds no NUL byte
+            const uint8_t *z = (const uint8_t *)memchr(*row_text, 0, (size_t)bytes);
+            if (z) {
+                const uint64_t at = (uint64_t)(z - *row_text);
+                uint64_t row = 0;
+                while (row + 1 < nr && (*row_text_off)[row + 1] <= at) row++;
+                fprintf(stderr, "[rb text check] NUL at byte %llu of %llu (mod 32 MB: %llu, mod 16: %llu), row %llu of %llu, row text [%llu, %llu), item first %llu count %u\n",
+                        (unsigned long long)at, (unsigned long long)bytes, (unsigned long long)(at % RB_PIN_CHUNK), (unsigned long long)(at & 15),
+                        (unsigned long long)row, (unsigned long long)nr, (unsigned long long)(*row_text_off)[row], (unsigned long long)(*row_text_off)[row + 1],
+                        (unsigned long long)0, 0u);
+                std::vector<uint8_t> again((size_t)bytes);
+                (void)hipMemcpy(again.data(), d_rtext, (size_t)bytes, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[rb text check] plain hipMemcpy of the same buffer: byte is %u (device %s)\n", again[(size_t)at], again[(size_t)at] ? "has the text: the staged download lost it" : "holds the NUL too: the kernel did not write it");
+            }
+        }
         rb_lap("format cigars + text D2H", tl);
     }
     if (!rc) {

@@ -1403,89 +1403,80 @@ bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, i
     if (!f.check_loaded(cig_status, red)) return false;                                  // the panics of Paf::from_file, in its order
     for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "remove_trailing_indels", i); // paf.rs:218-220
     lap("  text -> ops, scan (device)", tl);
-    // what the host tracks per record: its current place and length in d_ops, its current coordinates
-    struct Cur { uint64_t off, t_st, t_en, q_st, q_en; uint32_t n, nmatch, aln_len; };
-    std::vector<Cur> cur(n);
-    for (size_t i = 0; i < n; i++)
-        cur[i] = {op_off[i] + norm[i].first_op, norm[i].t_st, norm[i].t_en, norm[i].q_st, norm[i].q_en, norm[i].n_ops, norm[i].nmatch, norm[i].aln_len};
-    // records stably ordered by query name (:223); a group = a run of equal names
+    // records stably ordered by query name (:223); a group = a run of equal names.  Names are hashed into groups in order of first
+    // appearance (one pass), only the distinct names are sorted, and the groups are laid out in that order: file order inside a group
     std::vector<uint32_t> order(n);
-    std::iota(order.begin(), order.end(), 0u);
-    auto qname = [&](uint32_t i) { return f.name(f.recs[i].q_name, f.recs[i].q_name_n); };
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return qname(a) < qname(b); });
-    std::vector<uint32_t> grp_end(n); // for position p in `order`: one past the last position of its group
-    for (size_t p0 = 0; p0 < n;) {
-        size_t p1 = p0 + 1;
-        while (p1 < n && qname(order[p1]) == qname(order[p0])) p1++;
-        for (size_t q = p0; q < p1; q++) grp_end[q] = (uint32_t)p1;
-        p0 = p1;
+    std::vector<uint64_t> grp_off;
+    {
+        auto qname = [&](uint32_t i) { return f.name(f.recs[i].q_name, f.recs[i].q_name_n); };
+        std::unordered_map<std::string_view, uint32_t> gid_of;
+        gid_of.reserve(n / 2 + 16);
+        std::vector<uint32_t> gid(n), first_rec, count;
+        for (size_t i = 0; i < n; i++) {
+            auto it = gid_of.emplace(qname((uint32_t)i), (uint32_t)first_rec.size());
+            if (it.second) first_rec.push_back((uint32_t)i), count.push_back(0);
+            gid[i] = it.first->second;
+            count[gid[i]]++;
+        }
+        const size_t G = first_rec.size();
+        std::vector<uint32_t> by_name(G);
+        std::iota(by_name.begin(), by_name.end(), 0u);
+        std::sort(by_name.begin(), by_name.end(), [&](uint32_t x, uint32_t y) { return qname(first_rec[x]) < qname(first_rec[y]); });
+        grp_off.assign(G + 1, 0);
+        std::vector<uint64_t> at(G);
+        for (size_t k = 0; k < G; k++) at[by_name[k]] = grp_off[k], grp_off[k + 1] = grp_off[k] + count[by_name[k]];
+        for (size_t i = 0; i < n; i++) order[at[gid[i]]++] = (uint32_t)i;
     }
+    const size_t n_groups = grp_off.size() - 1;
     lap("  sort by query name", tl);
+    // ---- the passes (paf.rs:286-288), on the device: per pass the pair scan + selection (rb_dev_trim_select), the split + clip of
+    //      the chosen pairs in place behind the ops in use (rb_dev_overlap_split, rb_dev_apply_pairs); the host reads 64 bytes ----
+    const uint32_t *d_order = (const uint32_t *)up(order.data(), n * 4);
+    const uint64_t *d_grp = (const uint64_t *)up(grp_off.data(), (n_groups + 1) * 8);
+    uint8_t *d_contained = (uint8_t *)D.take(eng, n + 1);
+    eng.check(rb_dev_memset(ctx, d_contained, 0, n + 1), "rb_dev_memset");
+    uint32_t *d_left = (uint32_t *)D.take(eng, n_groups * 4 + 4), *d_right = (uint32_t *)D.take(eng, n_groups * 4 + 4);
+    uint64_t *d_poff = (uint64_t *)D.take(eng, n_groups * 8 + 8);
+    rb_pair_row *d_rows = (rb_pair_row *)D.take(eng, (n_groups + 1) * sizeof(rb_pair_row));
+    rb_trim_pass *d_pass = (rb_trim_pass *)D.take(eng, sizeof(rb_trim_pass));
+    void *d_sel = D.take(eng, rb_trim_select_scratch_bytes(n_groups));
     uint64_t cursor = (v.n_ops + 31) & ~(uint64_t)31;
-    std::vector<char> contained(n, 0); // by position in `order`
-    uint32_t *d_left = (uint32_t *)D.take(eng, n * 4), *d_right = (uint32_t *)D.take(eng, n * 4);
-    uint64_t *d_poff = (uint64_t *)D.take(eng, n * 8);
-    rb_pair_row *d_rows = (rb_pair_row *)D.take(eng, (n / 2 + 1) * sizeof(rb_pair_row));
     for (int pass = 0;; pass++) {
         if (pass > 100000) throw Panic("trim-paf did not converge");
-        std::fill(contained.begin(), contained.end(), 0);
-        struct Pair { uint64_t overlap; uint32_t i, j, first; }; // positions in `order` (left, right) and the first position of the pair's group
-        std::vector<Pair> pairs;
-        for (size_t pi = 0; pi + 1 < n; pi++) { // :231-261
-            const Cur &r1 = cur[order[pi]];
-            for (size_t pj = pi + 1; pj < grp_end[pi]; pj++) {
-                const Cur &r2 = cur[order[pj]];
-                const uint64_t mn = std::min(r1.q_en, r2.q_en), mx = std::max(r1.q_st, r2.q_st);
-                const uint64_t ov = mn < mx ? 0 : mn - mx;
-                if (ov < 1) continue;
-                if (ov == r2.q_en - r2.q_st) contained[pj] = 1;
-                else if (ov == r1.q_en - r1.q_st) contained[pi] = 1;
-                else if (r1.q_st <= r2.q_st) pairs.push_back({ov, (uint32_t)pi, (uint32_t)pj, 0});
-                else pairs.push_back({ov, (uint32_t)pj, (uint32_t)pi, 0});
-            }
-        }
-        std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &a, const Pair &b) { return a.overlap > b.overlap; }); // :262
-        std::vector<char> seen(n, 0); // by the group's first position
-        std::vector<uint32_t> left, right;
-        std::vector<uint64_t> poff;
-        size_t unseen = 0;
-        uint64_t room = cursor;
-        for (const Pair &pr : pairs) { // :266-284: one pair per query name per pass
-            // (the group of a position: all positions p with grp_end[p] equal)
-            const uint32_t g = grp_end[pr.i];
-            if (!seen[g - 1]) {
-                seen[g - 1] = 1;
-                left.push_back(order[pr.i]), right.push_back(order[pr.j]);
-                poff.push_back(room);
-                room += (uint64_t)cur[order[pr.i]].n + cur[order[pr.j]].n;
-            } else {
-                unseen++;
-            }
-        }
-        if (room + 64 > ops_cap) return false; // (nothing has been printed: the record-based path starts over)
-        if (!left.empty()) {
-            const size_t np = left.size();
-            eng.check(rb_dev_upload(ctx, d_left, left.data(), np * 4), "rb_dev_upload");
-            eng.check(rb_dev_upload(ctx, d_right, right.data(), np * 4), "rb_dev_upload");
-            eng.check(rb_dev_upload(ctx, d_poff, poff.data(), np * 8), "rb_dev_upload");
-            eng.check(rb_dev_overlap_split(ctx, &v, d_norm, np, d_left, d_right, d_poff, match_score, diff_score, indel_score, eng.bsearch_policy,
+        eng.check(rb_dev_trim_select(ctx, n, n_groups, d_order, d_grp, d_norm, cursor, d_contained, d_left, d_right, d_poff, d_pass, d_sel), "rb_dev_trim_select");
+        rb_trim_pass hp;
+        eng.check(rb_dev_download(ctx, &hp, d_pass, sizeof hp), "rb_dev_download");
+        if (hp.ops_end + 64 > ops_cap) return false; // (nothing has been printed: the record-based path starts over)
+        if (hp.n_pairs) {
+            eng.check(rb_dev_overlap_split(ctx, &v, d_norm, hp.n_pairs, d_left, d_right, d_poff, match_score, diff_score, indel_score, eng.bsearch_policy,
                                            d_rows, d_ops),
                       "rb_dev_overlap_split");
-            eng.check(rb_dev_apply_pairs(ctx, np, d_left, d_right, d_rows, d_opoff, d_norm), "rb_dev_apply_pairs");
-            std::vector<rb_pair_row> rows(np);
-            eng.check(rb_dev_download(ctx, rows.data(), d_rows, np * sizeof(rb_pair_row)), "rb_dev_download"); // (synchronises: the uploads above are done with their vectors)
-            for (size_t k = 0; k < np; k++) {
-                if (rows[k].status != RB_ST_OK) throw Panic("trim_overlapping_pafs: pair " + std::to_string(k) + " status " + std::to_string(rows[k].status));
-                const uint32_t idx[2] = {left[k], right[k]};
-                for (int s2 = 0; s2 < 2; s2++)
-                    cur[idx[s2]] = {rows[k].out_off[s2], rows[k].t_st[s2], rows[k].t_en[s2], rows[k].q_st[s2], rows[k].q_en[s2], rows[k].out_n[s2],
-                                    rows[k].nmatch[s2], rows[k].aln_len[s2]};
-            }
-            cursor = (room + 31) & ~(uint64_t)31;
+            eng.check(rb_dev_apply_pairs(ctx, hp.n_pairs, d_left, d_right, d_rows, d_opoff, d_norm), "rb_dev_apply_pairs");
+            eng.check(rb_dev_trim_check(ctx, hp.n_pairs, d_rows, d_pass), "rb_dev_trim_check");
+            rb_trim_pass chk;
+            eng.check(rb_dev_download(ctx, &chk, d_pass, sizeof chk), "rb_dev_download");
+            if (chk.bad_status != RB_ST_OK) throw Panic("trim_overlapping_pafs: a pair of pass " + std::to_string(pass) + " has status " + std::to_string(chk.bad_status));
+            cursor = (hp.ops_end + 31) & ~(uint64_t)31;
         }
-        lap("  pass (pairs on the host, split + clip on the device)", tl);
-        if (unseen == 0) break; // :286-288
+        lap("  pass (pair scan, selection, split + clip: all on the device)", tl);
+        if (hp.n_deferred == 0) break; // :286-288
     }
+    // the records as the passes left them
+    struct Cur { uint64_t off, t_st, t_en, q_st, q_en; uint32_t n, nmatch, aln_len; };
+    std::vector<Cur> cur(n);
+    std::vector<uint8_t> contained_rec(n);
+    {
+        std::vector<rb_norm_row> fin(n);
+        std::vector<uint64_t> foff(n);
+        eng.check(rb_dev_download(ctx, fin.data(), d_norm, n * sizeof(rb_norm_row)), "rb_dev_download");
+        eng.check(rb_dev_download(ctx, foff.data(), d_opoff, n * 8), "rb_dev_download");
+        eng.check(rb_dev_download(ctx, contained_rec.data(), d_contained, n), "rb_dev_download");
+        for (size_t i = 0; i < n; i++)
+            cur[i] = {foff[i] + fin[i].first_op, fin[i].t_st, fin[i].t_en, fin[i].q_st, fin[i].q_en, fin[i].n_ops, fin[i].nmatch, fin[i].aln_len};
+    }
+    std::vector<char> contained(n, 0); // by position in `order`
+    for (size_t p0 = 0; p0 < n; p0++) contained[p0] = (char)contained_rec[order[p0]];
+    lap("  final rows D2H", tl);
     // ---- print: kept records in the sorted order, CIGAR text from the device ----
     std::vector<uint32_t> keep;
     keep.reserve(n);

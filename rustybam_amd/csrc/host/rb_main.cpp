@@ -69,10 +69,10 @@ static void put(const std::string &s) { fwrite(s.data(), 1, s.size(), stdout); }
 // the output of a text route: chunks in output order, gigabytes in all.  Into a regular file they go with pwrite from several
 // threads, each chunk at its own offset (the page cache takes the pages in parallel); anywhere else with plain write(2) -- no
 // second copy through stdio's buffer either way
-static void put(const std::vector<std::string> &chunks) {
+static void put(const std::vector<std::string> &chunks, bool direct = false) { // direct: never through stdio's buffer (output that may be taken back)
     size_t total = 0;
     for (const std::string &s : chunks) total += s.size();
-    if (total < ((size_t)16 << 20)) {
+    if (total < ((size_t)16 << 20) && !direct) {
         for (const std::string &s : chunks) fwrite(s.data(), 1, s.size(), stdout);
         return;
     }
@@ -601,7 +601,7 @@ static bool try_pipelined(int device, int policy, bool is_break, uint32_t max_si
                 if ((int64_t)gid[r.first] < last_rank) { violated = true; return; }
                 last_rank = gid[r.first];
             }
-            put(text);
+            put(text, true); // (straight to the file: a rewind must not find earlier chunks waiting in stdio's buffer)
             std::vector<std::string>().swap(text);
             return;
         }

@@ -308,7 +308,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
     uint64_t t_st = jb_.t_st, t_en = jb_.t_en, q_st = jb_.q_st, q_en = jb_.q_en;
     if constexpr (!coord_reload) t_st = sgpr64(t_st), t_en = sgpr64(t_en), q_st = sgpr64(q_st), q_en = sgpr64(q_en);
     const uint32_t n = rb_first(jb_.n);
-    const bool minus = (jflags & RB_JOB_MINUS) != 0;
     const uint64_t rec0 = rb_first64(jb_.rec0); // global index of the record's first kept op
     const uint32_t *rec_ops = p.ops + rec0;
     const uint64_t lo = rb_first(jb_.lo);

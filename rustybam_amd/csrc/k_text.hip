@@ -222,7 +222,15 @@ __device__ __forceinline__ uint32_t rb_ndigits(uint32_t v) {
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u);
 }
 
-#define RB_FMT_STAGE (256 * 10 + 32) // bytes of text one step of 256 ops can make (9 digits + the op character each) + the 16-byte phase
+#define RB_FMT_STAGE (256 * 10 + 48) // bytes of text one step of 256 ops can make (9 digits + the op character each) + the 16-byte phase + 16 bytes of slack in front
+// the four low decimal digits of x < 10000, least significant first, as one byte each of a dword: multiplications by constants that
+// fit 24 bits (v_mul_u32_u24: full rate; the per-digit x / 10 of round 2 was a v_mul_hi_u32 -- quarter rate -- per digit)
+__device__ __forceinline__ uint32_t rb_digits4(uint32_t x) {
+    const uint32_t hi = (x * 5243u) >> 19, lo = x - hi * 100u; // x / 100, x % 100 (exact below 43699)
+    const uint32_t a = (hi * 103u) >> 10, b = hi - a * 10u;     // y / 10, y % 10 (exact below 179)
+    const uint32_t c = (lo * 103u) >> 10, d = lo - c * 10u;
+    return d | (c << 8) | (b << 16) | (a << 24);
+}
 template <bool FILL>
 __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
     // fill pass: the text of a step is put together in LDS (one byte per digit, at the 16-byte phase it has in memory) and leaves with
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
     const uint32_t ll = rb_first(ll_v);
     uint64_t out = rb_first64(out_v);
     uint64_t bytes = 0;
-    uint8_t *stg = stage_all[wib];
+    uint8_t *stg = stage_all[wib] + (FILL ? 16 : 0); // (16 bytes in front: the digit stores below address from nine bytes before an op's text)
     for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
         uint32_t len[4], opc[4], nb[4];
         uint32_t mine = 0;
@@ -286,10 +294,28 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
                     const uint32_t nd = nb[q] - 1u;
                     uint32_t l = len[q];
                     stg[o + nd] = (uint8_t)("MIDNSHP=X??????"[opc[q] < 9u ? opc[q] : 9u]);
-                    for (uint32_t k = nd; k-- > 0u;) {
-                        const uint32_t t = l / 10u;
-                        stg[o + k] = (uint8_t)(48u + (l - t * 10u));
-                        l = t;
+                    // digits, least significant first: digit j goes to byte o + nd - 1 - j = tail[8 - j].  Lengths below 10000 (all but
+                    // a handful) take four predicated stores and no division; the rest one quarter-rate multiply per four more digits
+                    uint8_t *tail = stg + o + nd - 9u;
+                    const bool big = l >= 10000u;
+                    uint32_t rest = 0;
+                    if (big) {
+                        rest = (uint32_t)(((uint64_t)l * 3518437209ull) >> 45); // l / 10000 (exact for 32-bit l)
+                        l -= rest * 10000u;
+                    }
+                    const uint32_t d4 = rb_digits4(l) | 0x30303030u;
+                    tail[8] = (uint8_t)d4;
+                    if (nd > 1u) tail[7] = (uint8_t)(d4 >> 8);
+                    if (nd > 2u) tail[6] = (uint8_t)(d4 >> 16);
+                    if (nd > 3u) tail[5] = (uint8_t)(d4 >> 24);
+                    if (big) { // digits 4..8 (rest < 26844)
+                        const uint32_t top = (uint32_t)(((uint64_t)rest * 3518437209ull) >> 45); // rest / 10000: the ninth digit (0..2)
+                        const uint32_t e4 = rb_digits4(rest - top * 10000u) | 0x30303030u;
+                        tail[4] = (uint8_t)e4;
+                        if (nd > 5u) tail[3] = (uint8_t)(e4 >> 8);
+                        if (nd > 6u) tail[2] = (uint8_t)(e4 >> 16);
+                        if (nd > 7u) tail[1] = (uint8_t)(e4 >> 24);
+                        if (nd > 8u) tail[0] = (uint8_t)(48u + top);
                     }
                     o += nb[q];
                 }

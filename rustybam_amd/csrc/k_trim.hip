@@ -969,3 +969,124 @@ extern "C" hipError_t rb_launch_gather_records(const rb_gather_params *p, hipStr
     else hipLaunchKernelGGL(rb_k_gather_records, dim3((unsigned)((p->n_rec + 3) / 4)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// trim-paf: the pass driver's heavy half on the device (round 3).  Paf::overlapping_paf_recs (paf.rs:223-284) scans, per query
+// name, all pairs of records for overlaps on the query (bed::get_overlap, bed.rs:74-85), flags contained records (:244-249),
+// sorts ALL pairs by overlap (descending, stable) and then takes the first pair of every query name (:264-284).  Per query group
+// that is: the pair with the LARGEST overlap, among equals the FIRST in scan order (i ascending, then j) -- a segmented arg-max, no
+// global sort.  Groups are independent, so one pass = one launch: rb_k_trim_select (a thread per group; groups of more than
+// RB_TS_BIG records by the whole wave, one after the other), an exclusive scan that gives the chosen pairs dense slots and their
+// places in the ops arena, rb_k_trim_place.  The host keeps only the recursion loop (:286-288) and reads 64 bytes per pass.
+// ------------------------------------------------------------------------------------------------
+struct rb_tsel_params {
+    uint64_t n_groups;
+    const uint32_t *order;     // [n_rec] records stably sorted by query name
+    const uint64_t *grp_off;   // [n_groups + 1] group g = order[grp_off[g] .. grp_off[g + 1])
+    const rb_norm_row *norm;   // current coordinates / lengths of every record
+    uint8_t *contained;        // [n_rec] by record: the flags of THIS pass (paf.rs:224: reset at every level)
+    uint64_t *slot;            // [n_groups + 1] 2^44 + ops(left) + ops(right) for a group with a pair, else 0; scanned in place
+    uint32_t *cand;            // [2 n_groups] the chosen (left, right) records of each group
+    uint64_t out_base;
+    uint32_t *left, *right;    // dense outputs
+    uint64_t *pair_out_off;
+    rb_trim_pass *pass;
+};
+#define RB_TS_BIG 48u
+#define RB_TS_ONE (1ull << 44)
+
+struct rb_tsel_best {
+    uint64_t ov;  // overlap (0: none yet)
+    uint64_t ord; // scan order i * m + j of the pair that holds it
+    uint32_t l, r;
+};
+__device__ __forceinline__ void rb_tsel_pair(const rb_tsel_params &p, uint32_t ri, uint32_t rj, uint64_t ord, rb_tsel_best &b, uint64_t &n_pairs) {
+    const rb_norm_row *a = &p.norm[ri], *c = &p.norm[rj];
+    const uint64_t st1 = a->q_st, en1 = a->q_en, st2 = c->q_st, en2 = c->q_en;
+    const uint64_t mn = en1 < en2 ? en1 : en2, mx = st1 > st2 ? st1 : st2;
+    if (mn <= mx) return;                       // bed.rs:74-85: no overlap
+    const uint64_t ov = mn - mx;
+    if (ov == en2 - st2) { p.contained[rj] = 1; return; } // paf.rs:244-249
+    if (ov == en1 - st1) { p.contained[ri] = 1; return; }
+    n_pairs++;
+    if (ov > b.ov || (ov == b.ov && ord < b.ord)) {
+        b.ov = ov, b.ord = ord;
+        if (st1 <= st2) b.l = ri, b.r = rj; // the smaller q_st is "left" (:252-256)
+        else b.l = rj, b.r = ri;
+    }
+}
+__global__ __launch_bounds__(256) void rb_k_trim_select(rb_tsel_params p) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = rb_lane();
+    const bool live = g < p.n_groups;
+    const uint64_t g0 = live ? p.grp_off[g] : 0, m = live ? p.grp_off[g + 1] - g0 : 0;
+    for (uint64_t k = 0; k < m && m <= RB_TS_BIG; k++) p.contained[p.order[g0 + k]] = 0;
+    rb_tsel_best b = {0, 0, 0, 0};
+    uint64_t n_pairs = 0;
+    if (live && m <= RB_TS_BIG) {
+        for (uint64_t i = 0; i + 1 < m; i++) {
+            const uint32_t ri = p.order[g0 + i];
+            for (uint64_t j = i + 1; j < m; j++) rb_tsel_pair(p, ri, p.order[g0 + j], i * m + j, b, n_pairs);
+        }
+    }
+    // big groups of this wave: all lanes on one group at a time (lane l takes the pairs whose j is l mod 64)
+    unsigned long long big = __ballot(live && m > RB_TS_BIG);
+    while (big) {
+        const int src = __builtin_ctzll(big);
+        big &= big - 1ull;
+        const uint64_t bg0 = __shfl(g0, src, 64), bm = __shfl(m, src, 64);
+        for (uint64_t k = (uint64_t)lane; k < bm; k += 64) p.contained[p.order[bg0 + k]] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        rb_tsel_best bb = {0, 0, 0, 0};
+        uint64_t np = 0;
+        for (uint64_t i = 0; i + 1 < bm; i++) {
+            const uint32_t ri = p.order[bg0 + i];
+            for (uint64_t j = i + 1 + (uint64_t)lane; j < bm; j += 64) rb_tsel_pair(p, ri, p.order[bg0 + j], i * bm + j, bb, np);
+        }
+        for (int off = 32; off > 0; off >>= 1) { // the wave's best: largest overlap, then smallest scan order
+            const uint64_t oov = __shfl_xor(bb.ov, off, 64), oord = __shfl_xor(bb.ord, off, 64);
+            const uint32_t ol = (uint32_t)__shfl_xor((int)bb.l, off, 64), orr = (uint32_t)__shfl_xor((int)bb.r, off, 64);
+            if (oov > bb.ov || (oov == bb.ov && oov != 0 && oord < bb.ord)) bb.ov = oov, bb.ord = oord, bb.l = ol, bb.r = orr;
+            np += __shfl_xor(np, off, 64);
+        }
+        if (lane == src) b = bb, n_pairs = np;
+    }
+    if (!live) return;
+    p.slot[g] = b.ov ? RB_TS_ONE + (uint64_t)p.norm[b.l].n_ops + (uint64_t)p.norm[b.r].n_ops : 0ull;
+    p.cand[2 * g] = b.l, p.cand[2 * g + 1] = b.r;
+    if (n_pairs > 1) atomicAdd((unsigned long long *)&p.pass->n_deferred, (unsigned long long)(n_pairs - 1)); // (one pair per name and pass, :266-284)
+}
+__global__ __launch_bounds__(256) void rb_k_trim_place(rb_tsel_params p) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.n_groups) return;
+    const uint64_t a = p.slot[g], b = p.slot[g + 1];
+    if (g + 1 == p.n_groups) p.pass->n_pairs = b >> 44, p.pass->ops_end = p.out_base + (b & (RB_TS_ONE - 1ull));
+    if ((b >> 44) == (a >> 44)) return; // no pair in this group
+    const uint64_t k = a >> 44;
+    p.left[k] = p.cand[2 * g], p.right[k] = p.cand[2 * g + 1];
+    p.pair_out_off[k] = p.out_base + (a & (RB_TS_ONE - 1ull));
+}
+// the worst status of a pass's pair rows (0 = every pair was cut), for the host's one read per pass
+__global__ __launch_bounds__(256) void rb_k_trim_check(const rb_pair_row *rows, uint64_t n_pairs, rb_trim_pass *pass) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_pairs && rows[k].status != RB_ST_OK) atomicMax(&pass->bad_status, rows[k].status);
+}
+extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t *block_sums, uint64_t *total_out, hipStream_t stream);
+extern "C" hipError_t rb_launch_trim_select(const rb_tsel_params *p, uint64_t *block_sums, hipStream_t stream) {
+    hipError_t e = hipMemsetAsync(p->pass, 0, sizeof(rb_trim_pass), stream);
+    if (e != hipSuccess) return e;
+    if (p->n_groups == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((p->n_groups + 255) / 256);
+    hipLaunchKernelGGL(rb_k_trim_select, dim3(blocks), dim3(256), 0, stream, *p);
+    e = rb_launch_exclusive_scan(p->slot, p->n_groups, block_sums, nullptr, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rb_k_trim_place, dim3(blocks), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+extern "C" hipError_t rb_launch_trim_check(const rb_pair_row *rows, uint64_t n_pairs, rb_trim_pass *pass, hipStream_t stream) {
+    if (n_pairs == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_trim_check, dim3((unsigned)((n_pairs + 255) / 256)), dim3(256), 0, stream, rows, n_pairs, pass);
+    return hipGetLastError();
+}

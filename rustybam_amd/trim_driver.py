@@ -173,43 +173,61 @@ class ResidentTrim:
         self.grp_sorted = np.cumsum(np.r_[0, gs[1:] != gs[:-1]])
         self.passes, self.pairs_done, self.pairs_by_wave = 0, 0, 0
 
-    def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000):
+    def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000, check_host=False):
+        """the passes of Paf::overlapping_paf_recs (paf.rs:286-288).  Everything of a pass runs on the device: the pair scan and the
+        selection (rb_dev_trim_select), the split + clip of the chosen pairs in place (rb_dev_overlap_split, rb_dev_apply_pairs), the
+        status check (rb_dev_trim_check); the host reads 64 bytes per pass.  check_host: also run the numpy restatement of the
+        selection (select_pairs) on the coordinates of every pass and compare (tests)."""
         torch, eng, dev = self.torch, self.eng, self.dev
+        start = np.flatnonzero(np.r_[True, self.grp_sorted[1:] != self.grp_sorted[:-1]]) if self.n else np.zeros(0, np.int64)
+        grp_off = np.r_[start, self.n].astype(np.uint64)
+        n_groups = len(grp_off) - 1
+        d_order = torch.from_numpy(np.ascontiguousarray(self.order, dtype=np.uint32).view(np.int32)).to(dev)
+        d_grp = torch.from_numpy(grp_off.view(np.int64)).to(dev)
+        d_cont = torch.zeros(self.n + 1, dtype=torch.uint8, device=dev)
+        d_l, d_r = torch.zeros(n_groups + 1, dtype=torch.int32, device=dev), torch.zeros(n_groups + 1, dtype=torch.int32, device=dev)
+        d_po = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)
+        d_rows = torch.empty((n_groups + 1) * 128, dtype=torch.uint8, device=dev)
+        d_pass = torch.zeros(64, dtype=torch.uint8, device=dev)
+        d_scr = torch.zeros(eng.trim_select_scratch_bytes(n_groups), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
         for _ in range(max_passes):
-            left, right, unseen, contained = select_pairs(self.order, self.grp_sorted, self.q_st, self.q_en)
+            if check_host:
+                norm = self.d_norm.cpu().numpy().view(capi.NORM_DT)[:self.n]
+                want = select_pairs(self.order, self.grp_sorted, norm["q_st"].astype(np.uint64), norm["q_en"].astype(np.uint64))
+            eng.dev_trim_select(self.n, n_groups, d_order.data_ptr(), d_grp.data_ptr(), self.d_norm.data_ptr(), self.cursor, d_cont.data_ptr(),
+                                d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), d_pass.data_ptr(), d_scr.data_ptr())
+            eng.sync()
+            ps = d_pass.cpu().numpy().view(capi.TRIM_PASS_DT)[0]
+            k, deferred, end = int(ps["n_pairs"]), int(ps["n_deferred"]), int(ps["ops_end"])
             self.passes += 1
-            if len(left):
-                need = self.cur_n[left] + self.cur_n[right]
-                poff = self.cursor + np.r_[0, np.cumsum(need)[:-1]].astype(np.uint64)
-                end = int(self.cursor + need.sum())
+            if check_host:
+                wl_, wr_, wun, wcont = want
+                got = sorted(zip(d_l[:k].cpu().numpy().view(np.uint32).tolist(), d_r[:k].cpu().numpy().view(np.uint32).tolist()))
+                assert got == sorted(zip(wl_.tolist(), wr_.tolist())) and deferred == wun, "device pass selection differs from the host restatement"
+                c = np.zeros(self.n, bool)
+                c[self.order] = wcont
+                assert np.array_equal(d_cont[:self.n].cpu().numpy().astype(bool), c), "contained flags differ"
+            if k:
                 if end > self.cap:
                     raise RuntimeError("ResidentTrim: out of room for the clips (raise room_factor)")
-                d_l = torch.from_numpy(left.view(np.int32)).to(dev)
-                d_r = torch.from_numpy(right.view(np.int32)).to(dev)
-                d_po = torch.from_numpy(poff.view(np.int64)).to(dev)
-                d_rows = torch.empty(len(left) * 128, dtype=torch.uint8, device=dev)
-                torch.cuda.synchronize()
-                eng.dev_overlap_split(self.view, self.d_norm.data_ptr(), len(left), d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), scores, policy,
+                eng.dev_overlap_split(self.view, self.d_norm.data_ptr(), k, d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), scores, policy,
                                       d_rows.data_ptr(), self.d_ops.data_ptr())
-                eng.dev_apply_pairs(len(left), d_l.data_ptr(), d_r.data_ptr(), d_rows.data_ptr(), self.d_off.data_ptr(), self.d_norm.data_ptr())
-                torch.cuda.synchronize()
-                r64 = d_rows.view(torch.int64).view(len(left), 16)
-                # what the host keeps track of: status, the new query spans and lengths (a few columns of the 128-byte rows)
-                st = (r64[:, 1] >> 32).cpu().numpy()
-                if (st != 0).any():
-                    raise RuntimeError(f"trim pair status {int(st[st != 0][0])}: the reference panics")
-                qcols = r64[:, 6:10].cpu().numpy().view(np.uint64)            # q_st[2], q_en[2]
-                outn = r64[:, 14].cpu().numpy().view(np.uint32).reshape(-1, 2)
-                self.pairs_by_wave += int((r64[:, 15] == 1).sum().item())   # (diagnostic word of the row: 1 = done by the wave-per-pair kernel)
-                self.q_st[left], self.q_st[right] = qcols[:, 0], qcols[:, 1]
-                self.q_en[left], self.q_en[right] = qcols[:, 2], qcols[:, 3]
-                self.cur_n[left], self.cur_n[right] = outn[:, 0], outn[:, 1]
+                eng.dev_apply_pairs(k, d_l.data_ptr(), d_r.data_ptr(), d_rows.data_ptr(), self.d_off.data_ptr(), self.d_norm.data_ptr())
+                eng.dev_trim_check(k, d_rows.data_ptr(), d_pass.data_ptr())
+                eng.sync()
+                bad = int(d_pass.cpu().numpy().view(capi.TRIM_PASS_DT)[0]["bad_status"])
+                if bad:
+                    raise RuntimeError(f"trim pair status {bad}: the reference panics")
+                self.pairs_by_wave += int((d_rows[: k * 128].view(torch.int64).view(k, 16)[:, 15] == 1).sum().item())  # (diagnostic word: 1 = wave-per-pair kernel)
                 self.cursor = (end + 31) // 32 * 32
-                self.pairs_done += len(left)
-            if unseen > 0:
+                self.pairs_done += k
+            if deferred > 0:
                 continue
-            self.contained = np.zeros(self.n, bool)
-            self.contained[self.order] = contained
+            norm = self.d_norm.cpu().numpy().view(capi.NORM_DT)[:self.n]
+            self.q_st, self.q_en = norm["q_st"].astype(np.uint64), norm["q_en"].astype(np.uint64)
+            self.cur_n = norm["n_ops"].astype(np.uint64)
+            self.contained = d_cont[:self.n].cpu().numpy().astype(bool)
             return self
         raise RuntimeError("trim-paf did not converge")
 

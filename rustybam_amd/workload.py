@@ -75,3 +75,15 @@ def sliding_windows(n_win=3000, step=82_796, width=100_000, t_len=CHR1_LEN):
 def algorithmic_bytes(n_ops_total, n_rec, n_hits, n_out_ops):
     """4 B per input op + 48 B per record + 88 B per hit + 4 B per emitted op."""
     return 4 * int(n_ops_total) + 48 * int(n_rec) + 88 * int(n_hits) + 4 * int(n_out_ops)
+
+
+def kernel_source_sha():
+    """sha256 (first 16 hex digits) of the streaming clip kernel's sources: the PMC traffic figure bench.py reports (measured in a
+    separate rocprofv3 --pmc run, profiles/traffic_*.json) is valid for exactly these"""
+    import hashlib
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+    h = hashlib.sha256()
+    for f in ("k_liftover.hip", "rb_lift.h", "rb_device.h"):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]

@@ -417,3 +417,111 @@ def test_full_size_config4_trim_paf_then_break_paf(oracle, tmp_path):
                     f"{int(h['t_st'])}\t{int(h['t_en'])}\t{int(h['nmatch'])}\t{int(h['aln_len'])}\t60\tid:Z:\tcg:Z:{cg}\n")
     assert "".join(mine).encode() == obreak
     eng.close()
+
+
+def test_config4_25_contigs_deep_recursion(oracle, tmp_path):
+    """SURVEY 8d config 4 as written: records over the 25 contigs of asm_small.bam's header (records per contig ~ length), and -- what
+    the 1e7-record test above does not stress -- query groups of 2..9 records whose spans overlap their next TWO neighbours, so
+    that a group needs many passes of Paf::overlapping_paf_recs (deep recursion, deferred pairs re-scanned after every cut).
+    2e6 records through the device pass driver (rb_dev_trim_select + pair kernel, the numpy restatement of the selection checked
+    on every pass), then break-paf; properties that need no oracle at full size, and the oracle CLI line by line on the first
+    groups (trim-paf, then break-paf of its output, contigs included)."""
+    import torch
+    from devutil import DevBatch
+    from rbtest_util import unpack
+    from rustybam_amd import capi, trim_driver
+    n_target = int(os.environ.get("RB_FULLSIZE_C4B_RECORDS", "2000000"))
+    seed = 0x5EED0004
+    contigs = [("chr1", 248387497), ("chr2", 242696747), ("chr3", 201106605), ("chr4", 193575430), ("chr5", 182045437), ("chr6", 172126870),
+               ("chr7", 160567423), ("chr8", 146259322), ("chr9", 150617274), ("chr10", 134758122), ("chr11", 135127772), ("chr12", 133324781),
+               ("chr13", 113566686), ("chr14", 101161492), ("chr15", 99753195), ("chr16", 96330493), ("chr17", 84276897), ("chr18", 80542536),
+               ("chr19", 61707359), ("chr20", 66210247), ("chr21", 45090682), ("chr22", 51324926), ("chrX", 154259566), ("chrY", 62460029), ("chrM", 16569)]
+    rng = np.random.default_rng(seed + 1)
+    sizes = rng.integers(2, 10, n_target // 5)
+    sizes = sizes[: np.searchsorted(np.cumsum(sizes), n_target)]
+    n = int(sizes.sum())
+    group = np.repeat(np.arange(len(sizes)), sizes)
+    pos_in = np.arange(n) - np.repeat(np.cumsum(sizes) - sizes, sizes)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    nops = wl.n_ops(seed, 0, n, 300, 700)
+    op_off = wl.op_offsets(nops)
+    total_ops = int(op_off[-1])
+    i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
+    d_off = i64(op_off)
+    d_ops = torch.empty(total_ops + 64, dtype=torch.int32, device=dev)
+    eng.dev_synth_fill_ops(seed, 0, n, d_off.data_ptr(), d_ops.data_ptr())
+    zeros = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_red = torch.empty(n * 72, dtype=torch.uint8, device=dev)
+    v0 = eng.batch_view(n, total_ops, d_ops.data_ptr(), d_off.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), zeros.data_ptr(),
+                        torch.full((n,), ord("+"), dtype=torch.uint8, device=dev).data_ptr(), torch.zeros(n, dtype=torch.int32, device=dev).data_ptr())
+    torch.cuda.synchronize()
+    eng.dev_scan_records(v0, d_red.data_ptr(), 0)
+    torch.cuda.synchronize()
+    red = d_red.cpu().numpy().view(rustybam_amd.REDUCE_DT)
+    tb, qb = red["t_bases"].astype(np.uint64), red["q_bases"].astype(np.uint64)
+    del d_red, red
+    # record j of a group starts 40 % of the SHORTEST record length behind record j - 1: it overlaps j + 1 by ~60 % and j + 2 by ~20 %
+    step = np.repeat(np.minimum.reduceat(qb, np.cumsum(sizes) - sizes) * 2 // 5, sizes)
+    q_st = (pos_in.astype(np.uint64) * step + rng.integers(0, 50, n).astype(np.uint64))
+    q_en = q_st + qb
+    clen = np.array([c[1] for c in contigs], np.float64)
+    contig = rng.choice(len(contigs), n, p=clen / clen.sum()).astype(np.uint32)
+    t_st = (rng.random(n) * np.maximum(clen[contig] - tb.astype(np.float64) - 1, 1)).astype(np.uint64)
+    t_en = t_st + tb
+    strand = np.where(rng.integers(0, 2, n) == 0, ord("+"), ord("-")).astype(np.uint8)
+    T = trim_driver.ResidentTrim(eng, torch, dev, d_ops, op_off, t_st, t_en, q_st, q_en, strand, group, room_factor=3.0)
+    del d_ops
+    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN, check_host=True)
+    assert T.passes > 6, T.passes                                   # (a group of 9 with two overlaps per record: many rounds)
+    # ---- no overlap left inside a query (any two records of a group) ----
+    order = np.lexsort((T.q_st.astype(np.int64), group))
+    g_s, qs_s, qe_s = group[order], T.q_st[order].astype(np.int64), T.q_en[order].astype(np.int64)
+    same = g_s[1:] == g_s[:-1]
+    keep = ~T.contained[order]
+    assert ((qe_s[:-1] <= qs_s[1:]) | ~same | ~keep[1:] | ~keep[:-1]).all()
+    d_new, new_off, norm = T.gather()
+    assert (norm["status"] == 0).all() and (norm["t_st"] >= t_st).all() and (norm["t_en"] <= t_en).all()
+    fake = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+    dn = torch.from_numpy(norm.view(np.uint8).reshape(n, 64).view(np.int32).copy()).to(dev)
+    fake[:, 3] = dn[:, 9]
+    fake[:, 4:12] = dn[:, 0:8]
+    fake[:, 12], fake[:, 13] = dn[:, 12], dn[:, 13]
+    offs = torch.from_numpy(new_off[:-1].view(np.int64).copy()).to(dev)
+    fake[:, 14], fake[:, 15] = (offs & 0xFFFFFFFF).to(torch.int32), (offs >> 32).to(torch.int32)
+    _check_integrity(torch, dev, fake, d_new)
+    del fake, dn
+    d_c = [torch.from_numpy(np.ascontiguousarray(norm[k]).view(np.int64)).to(dev) for k in ("t_st", "t_en", "q_st", "q_en")]
+    B = DevBatch.from_device(torch, eng, dev, d_new, int(new_off[-1]), new_off, d_c, torch.from_numpy(strand).to(dev))
+    T.d_ops = None
+    torch.cuda.empty_cache()
+    rows, out, cnt = B.run(None, max_size=100, rows_cap=4 * n)
+    rows_ok = _check_break_rows(torch, dev, rows, out, n)
+    # ---- the oracle CLI on the first query groups ----
+    k = int(np.cumsum(sizes)[150])
+    so = wl.op_offsets(nops[:k])
+    sops = capi.synth_fill_ops_host(seed, 0, so)
+    q_len = {g: int(q_en[group == g].max()) + 1000 for g in range(151)}
+    line = lambda r, qs_, qe_, ts_, te_, nm, al, cg, with_id: (
+        f"q{group[r]:07d}\t{q_len[int(group[r])]}\t{qs_}\t{qe_}\t{chr(strand[r])}\t{contigs[contig[r]][0]}\t{contigs[contig[r]][1]}\t{ts_}\t{te_}\t{nm}\t{al}\t60\t"
+        + ("id:Z:\t" if with_id else "") + f"cg:Z:{cg}\n")
+    paf = tmp_path / "c4b.paf"
+    with open(paf, "w") as f:
+        for r in range(k):
+            f.write(line(r, int(q_st[r]), int(q_en[r]), int(t_st[r]), int(t_en[r]), 0, 0, unpack(sops[int(so[r]):int(so[r + 1])]), False))
+    rc, otrim = oracle.cli("trim-paf", paf)
+    assert rc == 0
+    new_ops = d_new[:int(new_off[k])].cpu().numpy().view(np.uint32)
+    mine = [line(r, int(norm["q_st"][r]), int(norm["q_en"][r]), int(norm["t_st"][r]), int(norm["t_en"][r]), int(norm["nmatch"][r]), int(norm["aln_len"][r]),
+                 unpack(new_ops[int(new_off[r]):int(new_off[r + 1])]), True) for r in range(k)]
+    assert "".join(mine).encode() == otrim                       # (names sort like the group numbers; file order inside a group)
+    trimmed = tmp_path / "c4b_trim.paf"
+    trimmed.write_bytes(otrim)
+    rc, obreak = oracle.cli("break-paf", "--max-size", "100", trimmed)
+    assert rc == 0
+    hr = rows_ok[(rows_ok[:, 0].to(torch.int64) & 0xFFFFFFFF) < k].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
+    mine = [line(int(h["rec"]), int(h["q_st"]), int(h["q_en"]), int(h["t_st"]), int(h["t_en"]), int(h["nmatch"]), int(h["aln_len"]),
+                 unpack(out[int(h["out_off"]):int(h["out_off"]) + int(h["out_n"])].cpu().numpy().view(np.uint32)), True) for h in hr]
+    assert "".join(mine).encode() == obreak
+    eng.close()

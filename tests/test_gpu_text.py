@@ -142,3 +142,35 @@ def test_parse_zero_padded_numbers(engine, oracle):
         if status[i] == 0:
             assert np.array_equal(ops[int(op_off[i]):int(op_off[i + 1])], want), c
     assert status[0] == 0 and status[3] == 3
+
+
+def test_format_digit_boundaries(engine, oracle):
+    """every digit count and the values around each power of ten (the format kernel takes lengths below 10000 and the others on
+    different routes), at every position of a lane's four ops and across 256-op steps"""
+    edges = [1, 9, 10, 11, 99, 100, 101, 999, 1000, 1001, 9999, 10000, 10001, 43698, 43699, 99999, 100000, 999999, 1000000, 9999999,
+             10000000, 99999999, 100000000, 100000001, 199999999, 200000000, 268435455]
+    rng = np.random.default_rng(5)
+    lens = np.array([edges[int(i)] for i in rng.integers(0, len(edges), 4000)] + edges * 3, np.uint32)
+    ops = ((lens << 4) | rng.integers(0, 9, len(lens)).astype(np.uint32)).astype(np.uint32)
+    first = np.array([0, 1, 2, 3, 255, 256, 257, len(ops) - len(edges)], np.uint64)
+    count = np.array([len(ops), 4, 7, 300, 2, 1, 600, len(edges)], np.uint32)
+    z = np.zeros(len(first), np.uint32)
+    toff, text = engine.format_cigars(ops, first, count, z, z)
+    for i in range(len(first)):
+        assert text[int(toff[i]):int(toff[i + 1])] == oracle_format(oracle, ops[int(first[i]):int(first[i]) + int(count[i])]), i
+
+
+def test_staged_transfers_keep_every_byte(engine):
+    """rb_dev_upload / rb_dev_download go through a page-locked ring in 32 MB chunks copied by four host threads: sizes whose last
+    chunk is 4 k + 1..3 bytes long (a quarter that is a multiple of 64 lost the remainder once) must arrive complete"""
+    import ctypes as C
+    L, ctx = engine.L, engine.ctx
+    for n in (32 * (1 << 20) + 4 * 64 * 70000 + 3, 8 * (1 << 20) + 4 * 64 * 1000 + 1, 64 * (1 << 20) + 21063171):
+        src = (np.arange(n, dtype=np.uint32) * 2654435761 >> 13).astype(np.uint8)
+        d = C.c_void_p()
+        assert L.rb_dev_alloc(ctx, C.c_size_t(n + 64), C.byref(d)) == 0
+        assert L.rb_dev_upload(ctx, d, src.ctypes.data_as(C.c_void_p), C.c_size_t(n)) == 0
+        back = np.zeros(n, np.uint8)
+        assert L.rb_dev_download(ctx, back.ctypes.data_as(C.c_void_p), d, C.c_size_t(n)) == 0
+        assert np.array_equal(back[-4096:], src[-4096:]) and np.array_equal(back, src), n
+        L.rb_dev_free(ctx, d)

@@ -222,3 +222,72 @@ def test_pairs_unsorted_qpos_array(engine, oracle, policy):
     orows, oout = oracle.overlap_split(ob, left, right, (1, 1, 1), policy)
     assert (orows["status"] == 16).any() and (orows["status"] == 0).any()  # the corner is actually exercised
     _compare(rows, out, orows, oout, f"unsorted qpos policy {policy}")
+
+
+def test_pass_selection_on_the_device_equals_the_reference_scan(engine):
+    """rb_dev_trim_select against the pair scan of Paf::overlapping_paf_recs restated in numpy (paf.rs:231-284): per query group the
+    pair of largest overlap, ties to the first in scan order; contained flags; the count of deferred pairs; groups of one record,
+    of a few, and big ones (the whole wave works on those), equal overlaps, contained records, touching (zero-overlap) spans"""
+    import torch
+    from rustybam_amd import capi
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(99)
+    sizes = [1, 2, 3, 4, 4, 5, 9, 47, 48, 49, 50, 130, 300] + [int(x) for x in rng.integers(1, 8, 400)]
+    rng.shuffle(sizes)
+    n = int(sum(sizes))
+    grp_off = np.zeros(len(sizes) + 1, np.uint64)
+    grp_off[1:] = np.cumsum(sizes)
+    order = rng.permutation(n).astype(np.uint32)          # (the records of a group need not be neighbours in the batch)
+    norm = np.zeros(n, capi.NORM_DT)
+    q_st = rng.integers(0, 4000, n) // 50 * 50             # coarse grid: equal overlaps, exact containment and touching spans happen
+    q_len = (rng.integers(1, 40, n)) * 50
+    norm["q_st"], norm["q_en"] = q_st, q_st + q_len
+    norm["n_ops"] = rng.integers(1, 900, n)
+
+    def want():
+        contained = np.zeros(n, np.uint8)
+        pairs, deferred = [], 0
+        for g in range(len(sizes)):
+            recs = order[int(grp_off[g]):int(grp_off[g + 1])]
+            best, cnt = None, 0
+            for i in range(len(recs)):
+                for j in range(i + 1, len(recs)):
+                    a, b = int(recs[i]), int(recs[j])
+                    ov = min(int(norm["q_en"][a]), int(norm["q_en"][b])) - max(int(norm["q_st"][a]), int(norm["q_st"][b]))
+                    if ov < 1:
+                        continue
+                    if ov == int(norm["q_en"][b]) - int(norm["q_st"][b]):
+                        contained[b] = 1
+                    elif ov == int(norm["q_en"][a]) - int(norm["q_st"][a]):
+                        contained[a] = 1
+                    else:
+                        cnt += 1
+                        if best is None or ov > best[0]:
+                            best = (ov, a, b) if norm["q_st"][a] <= norm["q_st"][b] else (ov, b, a)
+            if best:
+                pairs.append((best[1], best[2]))
+                deferred += cnt - 1
+        return contained, pairs, deferred
+
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8)).to(dev)
+    d_order, d_grp, d_norm = d(order), d(grp_off), d(norm)
+    d_cont = torch.full((n + 1,), 7, dtype=torch.uint8, device=dev)
+    G = len(sizes)
+    d_left, d_right = torch.zeros(G + 1, dtype=torch.int32, device=dev), torch.zeros(G + 1, dtype=torch.int32, device=dev)
+    d_poff = torch.zeros(G + 1, dtype=torch.int64, device=dev)
+    d_pass = torch.zeros(64, dtype=torch.uint8, device=dev)
+    d_scr = torch.zeros(engine.trim_select_scratch_bytes(G), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    engine.dev_trim_select(n, G, d_order.data_ptr(), d_grp.data_ptr(), d_norm.data_ptr(), 1000, d_cont.data_ptr(), d_left.data_ptr(),
+                           d_right.data_ptr(), d_poff.data_ptr(), d_pass.data_ptr(), d_scr.data_ptr())
+    engine.sync()
+    ps = d_pass.cpu().numpy().view(capi.TRIM_PASS_DT)[0]
+    contained, pairs, deferred = want()
+    k = int(ps["n_pairs"])
+    assert k == len(pairs) and int(ps["n_deferred"]) == deferred and len(pairs) > 100 and deferred > 100
+    got = list(zip(d_left[:k].cpu().numpy().view(np.uint32).tolist(), d_right[:k].cpu().numpy().view(np.uint32).tolist()))
+    assert got == pairs
+    assert np.array_equal(d_cont[:n].cpu().numpy(), contained) and contained.sum() > 10
+    need = np.array([int(norm["n_ops"][a]) + int(norm["n_ops"][b]) for a, b in pairs], np.int64)
+    poff = d_poff[:k].cpu().numpy()
+    assert np.array_equal(poff, 1000 + np.concatenate([[0], np.cumsum(need)[:-1]])) and int(ps["ops_end"]) == 1000 + int(need.sum())

@@ -23,7 +23,7 @@ def _parse_out(out):
     rows = []
     for ln in out.decode().splitlines():
         t = ln.split("\t")
-        rows.append(dict(q_st=int(t[2]), q_en=int(t[3]), strand=t[4], t_st=int(t[7]), t_en=int(t[8]),
+        rows.append(dict(q_name=t[0], t_name=t[5], q_st=int(t[2]), q_en=int(t[3]), strand=t[4], t_st=int(t[7]), t_en=int(t[8]),
                          nmatch=int(t[9]), aln_len=int(t[10]), id=t[12][5:], cigar=t[13][5:]))
     return rows
 
@@ -225,3 +225,61 @@ def test_ka13_orient_scaffold_filter(oracle, tmp_path):
     assert rc == 0 and [c[0] for c in cols(out)] == ["A", "A"]
     rc, out = oracle.cli("filter", "--aln", "9", "--query", "99", p)
     assert rc == 0 and [c[2] for c in cols(out)] == ["0", "20"]
+
+
+def test_ka14_ka15_region_helpers(oracle, ka):
+    """bed.rs:51-64 has_overlap and bed.rs:199-214 split_region: the reference's doctest vectors on the oracle's restatements, and
+    the first through the path that uses it (paf_overlaps_rgn, paf.rs:622-627: which windows a record is clipped to)"""
+    import ctypes as C
+    L = oracle.lib()
+    L.rbo_get_overlap.restype = C.c_uint64
+    k = ka["KA14_has_overlap"]
+    n1, s1, e1 = k["rgn1"]
+    for (n2, s2, e2), want in k["cases"]:
+        assert bool(L.rbo_has_overlap(n1.encode(), C.c_uint64(s1), C.c_uint64(e1), n2.encode(), C.c_uint64(s2), C.c_uint64(e2))) == want
+        ov = int(L.rbo_get_overlap(n1.encode(), C.c_uint64(s1), C.c_uint64(e1), n2.encode(), C.c_uint64(s2), C.c_uint64(e2)))
+        assert (ov > 0) == want and ov == max(0, min(e1, e2) - max(s1, s2))
+    assert int(L.rbo_get_overlap(b"chr1", C.c_uint64(0), C.c_uint64(9), b"chr2", C.c_uint64(0), C.c_uint64(9))) == 0
+    # ... and as the window filter of liftover: a record on chr1:[10,15) against the six regions of the doctest
+    ops = pack("5=")
+    b = oracle.Batch(ops, np.array([0, 1], np.uint64), np.array([s1], np.uint64), np.array([e1], np.uint64), np.array([0], np.uint64),
+                     np.array([5], np.uint64), np.array([ord("+")], np.uint8), np.zeros(1, np.uint32))
+    w_st = np.array([c[0][1] for c in k["cases"]], np.uint64)
+    w_en = np.array([c[0][2] for c in k["cases"]], np.uint64)
+    rows, _ = oracle.liftover(b, np.zeros(len(w_st), np.uint32), w_st, w_en)
+    assert sorted(rows["win"].tolist()) == [i for i, c in enumerate(k["cases"]) if c[1]]
+    s = ka["KA15_split_region"]
+    st, en = s["region"][1], s["region"][2]
+
+    def pieces(window):
+        out, a, e = [], C.c_uint64(), C.c_uint64()
+        while L.rbo_split_region(C.c_uint64(st), C.c_uint64(en), C.c_uint64(window), C.c_uint64(len(out)), C.byref(a), C.byref(e)):
+            out.append([a.value, e.value])
+        return out
+    p10, p100 = pieces(10), pieces(100)
+    assert len(p10) == s["window10"]["n"] and p10[0] == s["window10"]["first"] and p10[-1] == s["window10"]["last"]
+    assert len(p100) == s["window100"]["n"] and p100[0] == s["window100"]["first"]
+
+
+def test_ka16_ka17_target_region_and_parse_region(oracle, ka, tmp_path):
+    """paf.rs:468-478 get_target_as_region (the target columns of a parsed line) and bed.rs:88-96 parse_region"""
+    import ctypes as C
+    k = ka["KA16_target_as_region"]
+
+    class Rec(C.Structure):  # rbo_rec (oracle/rb_oracle.h); PafRecord::new alone -- the doctest's line would not pass check_integrity
+        _fields_ = [("q_name", C.c_char_p), ("q_len", C.c_uint64), ("q_st", C.c_uint64), ("q_en", C.c_uint64), ("strand", C.c_char),
+                    ("t_name", C.c_char_p), ("t_len", C.c_uint64), ("t_st", C.c_uint64), ("t_en", C.c_uint64), ("nmatch", C.c_uint64),
+                    ("aln_len", C.c_uint64), ("mapq", C.c_uint64), ("cigar", C.c_void_p), ("n_cigar", C.c_size_t), ("id", C.c_char_p),
+                    ("tpos_aln", C.c_void_p), ("qpos_aln", C.c_void_p), ("long_cigar", C.c_void_p), ("n_aln", C.c_size_t), ("contained", C.c_int)]
+    rec = Rec()
+    oracle.lib().rbo_rec_init(C.byref(rec))
+    assert oracle.lib().rbo_rec_from_line(k["line"].encode(), C.byref(rec)) == 0
+    assert [rec.t_name.decode(), rec.t_st, rec.t_en] == k["region"] and rec.n_cigar == 3
+    oracle.lib().rbo_rec_free(C.byref(rec))
+
+    class Rg(C.Structure):
+        _fields_ = [("name", C.c_char_p), ("st", C.c_uint64), ("en", C.c_uint64), ("id", C.c_char_p)]
+    for text, (name, st, en) in ka["KA17_parse_region"]["cases"]:
+        r = Rg()
+        assert oracle.lib().rbo_parse_region(text.encode(), C.byref(r)) == 0
+        assert (r.name.decode(), r.st, r.en) == (name, st, en)

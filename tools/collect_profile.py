@@ -1,6 +1,7 @@
-"""Copy what the judge reads from a tools/prof_r02.sh run (gpurun_out/<tag>/) into profiles/: the kernel-trace stats, the bench line,
-per-launch PMC numbers of the clip kernel (largest launch = a full-size one) and profiles/traffic_r02.json.
-usage: python tools/collect_profile.py <tag> [<bench json>]"""
+"""Copy what the judge reads from a tools/prof_round.sh run (gpurun_out/<tag>/) into profiles/: the kernel-trace stats, the bench line,
+per-launch PMC numbers of the clip kernel (largest launch = a full-size one) and profiles/traffic_<round>.json, which carries the
+hash of the kernel's sources it was measured on (bench.py refuses it when the sources have changed since).
+usage: python tools/collect_profile.py <tag> [<bench json>]      (tag = r03_a ...: the round is its first three characters)"""
 import collections
 import csv
 import glob
@@ -10,7 +11,10 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from rustybam_amd.workload import kernel_source_sha  # noqa: E402
 tag = sys.argv[1]
+rnd = tag[:3]
 src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "kt_kernel_stats.csv"), os.path.join(dst, f"{tag}_kernel_stats.csv"))
@@ -32,15 +36,16 @@ ks = next(v for k, v in stats.items() if "liftover_stream" in k)
 fetch, write = best["FETCH_SIZE"] * 2 * 1024, best["WRITE_SIZE"] * 1024
 algo = B["roofline"]["algorithmic_bytes"]
 traffic = {"_comment": "PMC traffic of rb_k_liftover_stream per full-size launch on the bench.py default workload (config 3, 1e6 records x 3000 "
-                       "windows, 1 GPU, fused record scan); separate --pmc passes (tools/prof_r02.sh), FETCH_SIZE doubled per MI355X_MICROARCH.md "
+                       "windows, 1 GPU, fused record scan); separate --pmc passes (tools/prof_round.sh), FETCH_SIZE doubled per MI355X_MICROARCH.md "
                        f"(16 B / lane streaming loads). Source: profiles/{tag}_summary.md",
            "workload": {"records_per_gpu": B["config"]["records_per_gpu"], "windows": B["config"]["windows"], "workload": "config3"},
            "fetch_size_kb_raw": best["FETCH_SIZE"], "write_size_kb_raw": best["WRITE_SIZE"], "fetch_bytes_corrected": fetch, "write_bytes": write,
-           "traffic_bytes_per_launch": fetch + write, "kernel": "rb_k_liftover_stream", "build": f"round 2 profile {tag}"}
-json.dump(traffic, open(os.path.join(dst, "traffic_r02.json"), "w"), indent=1)
-md = f"""# Round 2, profile {tag} -- the headline step (config 3: 1e6 records, 5e9 ops, 3000 sliding 100 kb windows, 1 MI355X)
+           "traffic_bytes_per_launch": fetch + write, "kernel": "rb_k_liftover_stream", "build": f"profile {tag}",
+           "kernel_source_sha": kernel_source_sha(), "git_head": os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()}
+json.dump(traffic, open(os.path.join(dst, f"traffic_{rnd}.json"), "w"), indent=1)
+md = f"""# Profile {tag} -- the headline step (config 3: 1e6 records, 5e9 ops, 3000 sliding 100 kb windows, 1 MI355X)
 
-`tools/prof_r02.sh {tag}` (kernel trace + stats; FETCH_SIZE / WRITE_SIZE / SQ counters in separate `--pmc` passes), then an unprofiled
+`tools/prof_round.sh {tag}` (kernel trace + stats; FETCH_SIZE / WRITE_SIZE / SQ counters in separate `--pmc` passes), then an unprofiled
 `python bench.py` -> `profiles/{tag}_bench.json`.  Fused record scan, clips copied out (emitted from the load ring into positional slots).
 
 | | |
@@ -50,7 +55,7 @@ md = f"""# Round 2, profile {tag} -- the headline step (config 3: 1e6 records, 5
 | the same kernel in `profiles/{tag}_kernel_stats.csv` (full-size launches = the maximum; the average mixes in sizing / parity-sample launches) | max {float(ks['MaxNs']) / 1e6:.2f} ms over {ks['Calls']} calls |
 | FETCH_SIZE per full launch | {best['FETCH_SIZE']:.4g} KB raw x2 (gfx950 correction) = {fetch / 1e9:.2f} GB |
 | WRITE_SIZE per full launch | {best['WRITE_SIZE']:.4g} KB = {write / 1e9:.2f} GB |
-| traffic | **{(fetch + write) / 1e9:.1f} GB = {(fetch + write) / algo:.3f} x the {algo / 1e9:.2f} GB of algorithmic bytes** (round 1: 70.9 GB, 1.56 x) |
+| traffic | **{(fetch + write) / 1e9:.1f} GB = {(fetch + write) / algo:.3f} x the {algo / 1e9:.2f} GB of algorithmic bytes** (round 2: 51.8 GB, 1.143 x; round 1: 70.9 GB, 1.56 x) |
 | SQ_INSTS_VALU / SALU per full launch | {best.get('SQ_INSTS_VALU', 0):.3g} / {best.get('SQ_INSTS_SALU', 0):.3g} ({best.get('SQ_INSTS_VALU', 0) / 1e6:.0f} / {best.get('SQ_INSTS_SALU', 0) / 1e6:.0f} per record) |
 | SQ_INSTS_VMEM_RD / VMEM_WR / LDS per full launch | {best.get('SQ_INSTS_VMEM_RD', 0):.3g} / {best.get('SQ_INSTS_VMEM_WR', 0):.3g} / {best.get('SQ_INSTS_LDS', 0):.3g} |
 | end to end (`rb liftover`, text in -> text out, {B.get('e2e', {}).get('records', 0)} records) | {B.get('e2e_paf_records_per_s', 0):.0f} PAF-records/s ({B.get('e2e', {}).get('seconds', 0)} s) |

@@ -1,0 +1,33 @@
+#!/bin/bash
+# end to end at the headline size (PAF-records/s = input records / wall time from the first byte read to the last byte
+# written): `rb liftover` on the text of config 3 -- N records (default 1e6: 14.7 GB in, 19 GB out) x 3000 windows -- in /dev/shm,
+# pipelined route vs whole-file route, RB_TIMING phases on stderr.  usage: tools/e2e_big.sh [records] [tag]
+cd $GRAFT_REPO_ROOT
+n=${1:-1000000}
+tag=${2:-e2e_big}
+d=/dev/shm/rb_e2e_$$
+mkdir -p $d gpurun_out/$tag
+RB=rustybam_amd/rb
+t0=$(date +%s.%N)
+$RB synth-paf 0x5EED0003 0 $n > $d/w.paf
+$RB synth-bed 3000 > $d/w.bed
+t1=$(date +%s.%N)
+echo "synth: $(echo "$t1 - $t0" | bc) s, $(stat -c %s $d/w.paf) bytes" | tee gpurun_out/$tag/summary.txt
+run() { # name, env..., -- args
+  name=$1; shift
+  for rep in 1 2; do
+    s=$(date +%s.%N)
+    env RB_TIMING=1 "$@" > $d/out_$name.paf 2> gpurun_out/$tag/${name}_$rep.err
+    rc=$?
+    e=$(date +%s.%N)
+    echo "$name run $rep: rc $rc, $(echo "$e - $s" | bc) s, $(echo "$n / ($e - $s)" | bc) records/s, out $(stat -c %s $d/out_$name.paf) bytes" | tee -a gpurun_out/$tag/summary.txt
+  done
+}
+run pipelined $RB liftover --bed $d/w.bed $d/w.paf
+run whole RB_NO_PIPELINE=1 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_w2 RB_PIPE_WORKERS=2 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_w4 RB_PIPE_WORKERS=4 RB_CHUNK_MB=256 $RB liftover --bed $d/w.bed $d/w.paf
+run gpus2_same RB_GPUS_SAME_DEVICE=1 $RB --gpus 2 liftover --bed $d/w.bed $d/w.paf
+run break_pipelined $RB break-paf --max-size 100 $d/w.paf
+md5sum $d/out_*.paf | tee -a gpurun_out/$tag/summary.txt
+rm -rf $d

@@ -1,8 +1,8 @@
 #!/bin/bash
-# rocprofv3 runs behind profiles/r02_*: kernel trace + stats, FETCH_SIZE and WRITE_SIZE in separate --pmc passes, SQ counters
+# rocprofv3 runs behind profiles/r<round>_*: kernel trace + stats, FETCH_SIZE and WRITE_SIZE in separate --pmc passes, SQ counters
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-tag=${1:-r02_a}
+tag=${1:-r03_a}
 args=${2:-}
 mkdir -p gpurun_out/$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$tag -o kt -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline $args > gpurun_out/${tag}_kt.log 2>&1
