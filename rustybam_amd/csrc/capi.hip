@@ -876,6 +876,7 @@ struct rb_tsel_params {
     const rb_norm_row *norm;
     uint8_t *contained;
     uint64_t *slot;
+    uint64_t *has;
     uint32_t *cand;
     uint64_t out_base;
     uint32_t *left, *right;
@@ -884,9 +885,9 @@ struct rb_tsel_params {
 };
 extern "C" hipError_t rb_launch_trim_select(const rb_tsel_params *p, uint64_t *block_sums, hipStream_t stream);
 extern "C" hipError_t rb_launch_trim_check(const rb_pair_row *rows, uint64_t n_pairs, rb_trim_pass *pass, hipStream_t stream);
-// scratch of rb_dev_trim_select: [slot (n_groups + 2) u64][cand 2 n_groups u32][block sums of the scan]
+// scratch of rb_dev_trim_select: [slot (n_groups + 2) u64][has (n_groups + 2) u64][cand 2 n_groups u32][block sums of the scans]
 extern "C" size_t rb_trim_select_scratch_bytes(uint64_t n_groups) {
-    return (((n_groups + 2) * 8 + 255) & ~(size_t)255) + ((2 * n_groups * 4 + 255) & ~(size_t)255) + (rb_scan_block_sums_count(n_groups) + 4) * 8 + 256;
+    return 2 * (((n_groups + 2) * 8 + 255) & ~(size_t)255) + ((2 * n_groups * 4 + 255) & ~(size_t)255) + (rb_scan_block_sums_count(n_groups) + 4) * 8 + 256;
 }
 extern "C" int rb_dev_trim_select(rb_ctx *ctx, uint64_t n_rec, uint64_t n_groups, const uint32_t *order, const uint64_t *grp_off,
                                   const rb_norm_row *norm_rows, uint64_t out_base, uint8_t *contained, uint32_t *left, uint32_t *right,
@@ -899,6 +900,8 @@ extern "C" int rb_dev_trim_select(rb_ctx *ctx, uint64_t n_rec, uint64_t n_groups
     char *sc = (char *)scratch;
     p.n_groups = n_groups, p.order = order, p.grp_off = grp_off, p.norm = norm_rows, p.contained = contained;
     p.slot = (uint64_t *)sc;
+    sc += ((n_groups + 2) * 8 + 255) & ~(size_t)255;
+    p.has = (uint64_t *)sc;
     sc += ((n_groups + 2) * 8 + 255) & ~(size_t)255;
     p.cand = (uint32_t *)sc;
     sc += (2 * n_groups * 4 + 255) & ~(size_t)255;

@@ -3,6 +3,7 @@
 // header-only commands that sit between them in the reference's pipelines (:234-249 filter, :253-267 orient).
 // Same flag names and defaults as src/cli.rs; exits with 101 where the reference panics.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +66,44 @@ static double g_t_main = 0;
 // stdout's buffer lives as long as the process: it must still be there when a panic unwinds out of main's try block and the
 // handler (and exit) flush what was printed before the panic (the reference prints the stats header / earlier regions first)
 static char g_obuf[1 << 22];
+// Gigabytes into a regular file: parallel pwrite does not scale -- a buffered write holds the file's inode lock, so 8 or 32 writers
+// of one file take turns (4-5 GB/s into tmpfs whatever their number: 4 s of a 5 s run at the headline size).  Through a shared
+// mapping the pages are made by page faults, which run in parallel: the file is grown to its new end (`grow`: only by the one
+// process that owns the end -- a single run, or the parent of `--gpus` before its workers write), the byte range is mapped, and
+// the segments are copied in by up to 32 threads.  The descriptor of a shell redirection is write-only, so the file is reopened
+// read-write through /proc/self/fd; false = not possible here (the caller falls back to pwrite).
+struct WSeg { const char *p; size_t n; off_t at; };
+static bool write_segments_mapped(const std::vector<WSeg> &segs, bool grow) {
+    static const bool off = getenv("RB_NO_MMAP_WRITE") != nullptr;
+    if (off || segs.empty()) return false;
+    off_t lo = segs[0].at, hi = 0;
+    size_t total = 0;
+    for (const WSeg &g : segs) lo = std::min(lo, g.at), hi = std::max(hi, g.at + (off_t)g.n), total += g.n;
+    static const size_t min_total = getenv("RB_MMAP_WRITE_MIN") ? (size_t)strtoull(getenv("RB_MMAP_WRITE_MIN"), nullptr, 10) : (size_t)64 << 20; // (tests lower it)
+    if (total < min_total) return false;
+    const int fd = open("/proc/self/fd/1", O_RDWR);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { close(fd); return false; }
+    if (st.st_size < hi) {
+        if (!grow || ftruncate(fd, hi) != 0) { close(fd); return false; }
+    }
+    const long pg = sysconf(_SC_PAGESIZE);
+    const off_t m0 = lo / pg * pg;
+    char *base = (char *)mmap(nullptr, (size_t)(hi - m0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, m0);
+    close(fd);
+    if (base == MAP_FAILED) return false;
+    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 32));
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&]() {
+            for (size_t k = next++; k < segs.size(); k = next++) memcpy(base + (segs[k].at - m0), segs[k].p, segs[k].n);
+        });
+    for (auto &x : th) x.join();
+    munmap(base, (size_t)(hi - m0));
+    return true;
+}
 static void put(const std::string &s) { fwrite(s.data(), 1, s.size(), stdout); }
 // the output of a text route: chunks in output order, gigabytes in all.  Into a regular file they go with pwrite from several
 // threads, each chunk at its own offset (the page cache takes the pages in parallel); anywhere else with plain write(2) -- no
@@ -82,18 +121,30 @@ static void put(const std::vector<std::string> &chunks, bool direct = false) { /
     off_t at = -1;
     if (fstat(1, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND)) at = lseek(1, 0, SEEK_CUR);
     if (at >= 0) {
-        std::vector<off_t> off(chunks.size());
+        // segments of at most 16 MB, up to 32 threads: what bounds the write of gigabytes into a page cache (tmpfs, or a file that is
+        // not on disk yet) is the kernel making the pages, which scales with the threads asking for them (8 threads: 5 GB/s)
+        std::vector<WSeg> segs;
         off_t o = at;
-        for (size_t k = 0; k < chunks.size(); k++) off[k] = o, o += (off_t)chunks[k].size();
-        const unsigned T = (unsigned)std::min<size_t>(chunks.size(), 8);
+        for (const std::string &c : chunks)
+            for (size_t a = 0; a < c.size(); a += (size_t)16 << 20) {
+                const size_t n = std::min(c.size() - a, (size_t)16 << 20);
+                segs.push_back({c.data() + a, n, o});
+                o += (off_t)n;
+            }
+        if (write_segments_mapped(segs, true)) {
+            lseek(1, o, SEEK_SET);
+            return;
+        }
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 32));
         std::vector<std::thread> th;
         std::vector<int> bad(T, 0);
+        std::atomic<size_t> next{0};
         for (unsigned t = 0; t < T; t++)
             th.emplace_back([&, t]() {
-                for (size_t k = t; k < chunks.size(); k += T) {
+                for (size_t k = next++; k < segs.size(); k = next++) {
                     size_t done_ = 0;
-                    while (done_ < chunks[k].size()) {
-                        const ssize_t w = pwrite(1, chunks[k].data() + done_, chunks[k].size() - done_, off[k] + (off_t)done_);
+                    while (done_ < segs[k].n) {
+                        const ssize_t w = pwrite(1, segs[k].p + done_, segs[k].n - done_, segs[k].at + (off_t)done_);
                         if (w <= 0) { bad[t] = 1; return; }
                         done_ += (size_t)w;
                     }
@@ -288,6 +339,7 @@ bool recv_msg(int fd, MsgIn &m) {
     for (size_t k = 0; k < o.chunks.size(); k++) cstart[k + 1] = cstart[k] + o.chunks[k].size();
     struct Seg { const char *p; size_t n; int64_t at; };
     std::vector<Seg> segs;
+    bool mapped = false;
     const uint64_t n_writes = plan.u64();
     for (uint64_t w = 0; w < n_writes && plan.ok; w++) {
         const uint64_t k = plan.u64();
@@ -296,17 +348,22 @@ bool recv_msg(int fd, MsgIn &m) {
         uint64_t a = start[k];
         const uint64_t e = start[k + 1];
         size_t c = (size_t)(std::upper_bound(cstart.begin(), cstart.end(), a) - cstart.begin()) - 1;
-        while (a < e) { // the chunks this piece runs through, in parts of at most 64 MB
+        while (a < e) { // the chunks this piece runs through, in parts of at most 16 MB
             while (c < o.chunks.size() && cstart[c + 1] <= a) c++;
-            const uint64_t n = std::min<uint64_t>(std::min(e, cstart[c + 1]) - a, (uint64_t)64 << 20);
+            const uint64_t n = std::min<uint64_t>(std::min(e, cstart[c + 1]) - a, (uint64_t)16 << 20);
             segs.push_back({o.chunks[c].data() + (a - cstart[c]), (size_t)n, at});
             a += n;
             if (at >= 0) at += (int64_t)n;
         }
     }
     bool ok = true;
-    if (g_worker.to_file) {
-        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 8));
+    if (g_worker.to_file) { // (the parent has grown the file to its final size: every worker can map its ranges)
+        std::vector<WSeg> ws;
+        for (const Seg &sg : segs) ws.push_back({sg.p, sg.n, (off_t)sg.at});
+        mapped = write_segments_mapped(ws, false);
+    }
+    if (g_worker.to_file && !mapped) {
+        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 32)); // (the page cache scales with the writers)
         std::vector<std::thread> th;
         std::vector<int> bad(T, 0);
         for (unsigned t = 0; t < T; t++)
@@ -322,7 +379,7 @@ bool recv_msg(int fd, MsgIn &m) {
             });
         for (auto &x : th) x.join();
         for (int b : bad) ok = ok && !b;
-    } else {
+    } else if (!g_worker.to_file) {
         for (const Seg &sg : segs) ok = ok && write_all(1, sg.p, sg.n);
     }
     if (!ok) perror("rb: write");
@@ -548,6 +605,10 @@ static int shard_fork(int n, GatherMode mode, bool by_query, std::string &path, 
         at += it.bytes;
     }
     bool ok = true;
+    if (to_file) { // the file at its final size before anybody writes: the workers map their ranges of it (write_segments_mapped)
+        struct stat sn;
+        if (fstat(1, &sn) == 0 && (uint64_t)sn.st_size < at) (void)!ftruncate(1, (off_t)at);
+    }
     for (int k = 0; k < n; k++) ok = send_msg(ctl[k], msg[k]) && ok;
     if (!to_file && ok) { // exactly the announced bytes of each piece, in global order
         std::vector<char> b((size_t)4 << 20);

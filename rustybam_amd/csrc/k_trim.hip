@@ -986,7 +986,8 @@ struct rb_tsel_params {
     const uint64_t *grp_off;   // [n_groups + 1] group g = order[grp_off[g] .. grp_off[g + 1])
     const rb_norm_row *norm;   // current coordinates / lengths of every record
     uint8_t *contained;        // [n_rec] by record: the flags of THIS pass (paf.rs:224: reset at every level)
-    uint64_t *slot;            // [n_groups + 1] 2^44 + ops(left) + ops(right) for a group with a pair, else 0; scanned in place
+    uint64_t *slot;            // [n_groups + 1] ops(left) + ops(right) of the group's pair (0: none); scanned in place: where its clips go
+    uint64_t *has;             // [n_groups + 1] 1 for a group with a pair, else 0; scanned in place: the pair's dense slot
     uint32_t *cand;            // [2 n_groups] the chosen (left, right) records of each group
     uint64_t out_base;
     uint32_t *left, *right;    // dense outputs
@@ -994,7 +995,6 @@ struct rb_tsel_params {
     rb_trim_pass *pass;
 };
 #define RB_TS_BIG 48u
-#define RB_TS_ONE (1ull << 44)
 
 struct rb_tsel_best {
     uint64_t ov;  // overlap (0: none yet)
@@ -1054,19 +1054,19 @@ __global__ __launch_bounds__(256) void rb_k_trim_select(rb_tsel_params p) {
         if (lane == src) b = bb, n_pairs = np;
     }
     if (!live) return;
-    p.slot[g] = b.ov ? RB_TS_ONE + (uint64_t)p.norm[b.l].n_ops + (uint64_t)p.norm[b.r].n_ops : 0ull;
+    p.slot[g] = b.ov ? (uint64_t)p.norm[b.l].n_ops + (uint64_t)p.norm[b.r].n_ops : 0ull;
+    p.has[g] = b.ov ? 1ull : 0ull;
     p.cand[2 * g] = b.l, p.cand[2 * g + 1] = b.r;
     if (n_pairs > 1) atomicAdd((unsigned long long *)&p.pass->n_deferred, (unsigned long long)(n_pairs - 1)); // (one pair per name and pass, :266-284)
 }
 __global__ __launch_bounds__(256) void rb_k_trim_place(rb_tsel_params p) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.n_groups) return;
-    const uint64_t a = p.slot[g], b = p.slot[g + 1];
-    if (g + 1 == p.n_groups) p.pass->n_pairs = b >> 44, p.pass->ops_end = p.out_base + (b & (RB_TS_ONE - 1ull));
-    if ((b >> 44) == (a >> 44)) return; // no pair in this group
-    const uint64_t k = a >> 44;
+    const uint64_t k = p.has[g], k1 = p.has[g + 1];
+    if (g + 1 == p.n_groups) p.pass->n_pairs = k1, p.pass->ops_end = p.out_base + p.slot[g + 1];
+    if (k1 == k) return; // no pair in this group
     p.left[k] = p.cand[2 * g], p.right[k] = p.cand[2 * g + 1];
-    p.pair_out_off[k] = p.out_base + (a & (RB_TS_ONE - 1ull));
+    p.pair_out_off[k] = p.out_base + p.slot[g];
 }
 // the worst status of a pass's pair rows (0 = every pair was cut), for the host's one read per pass
 __global__ __launch_bounds__(256) void rb_k_trim_check(const rb_pair_row *rows, uint64_t n_pairs, rb_trim_pass *pass) {
@@ -1081,6 +1081,8 @@ extern "C" hipError_t rb_launch_trim_select(const rb_tsel_params *p, uint64_t *b
     const unsigned blocks = (unsigned)((p->n_groups + 255) / 256);
     hipLaunchKernelGGL(rb_k_trim_select, dim3(blocks), dim3(256), 0, stream, *p);
     e = rb_launch_exclusive_scan(p->slot, p->n_groups, block_sums, nullptr, stream);
+    if (e != hipSuccess) return e;
+    e = rb_launch_exclusive_scan(p->has, p->n_groups, block_sums, nullptr, stream);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rb_k_trim_place, dim3(blocks), dim3(256), 0, stream, *p);
     return hipGetLastError();

@@ -86,3 +86,20 @@ def test_more_shards_than_query_names(tmp_path):
     for flags in ([], ["-q"], ["-l"]):
         rc, out = run(["--gpus", 4, "regroup", *flags, str(tmp_path / "empty.paf")])
         assert rc == 0 and out == b""
+
+
+@pytest.mark.skipif(not os.path.exists(RB), reason="rustybam_amd/rb not built")
+def test_gather_through_a_shared_mapping(tmp_path):
+    """gigabyte outputs are copied into a shared mapping of the output file (parallel page faults) instead of pwrite (one inode
+    lock); RB_MMAP_WRITE_MIN=1 takes that route for the small test file: same bytes, with workers and without, appended after
+    bytes the file already holds"""
+    paf = shuffled_paf(tmp_path, 9)
+    rc1, one = run(["regroup", paf])
+    assert rc1 == 0
+    for pre in ([], ["--gpus", "3"]):
+        out = tmp_path / "m.paf"
+        with open(out, "wb") as f:
+            f.write(b"# header the output follows\n")
+            f.flush()
+            r = subprocess.run([RB, *pre, "regroup", paf], stdout=f, stderr=subprocess.PIPE, env={**os.environ, "RB_MMAP_WRITE_MIN": "1"})
+        assert r.returncode == 0 and open(out, "rb").read() == b"# header the output follows\n" + one, pre

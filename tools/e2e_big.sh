@@ -12,7 +12,7 @@ t0=$(date +%s.%N)
 $RB synth-paf 0x5EED0003 0 $n > $d/w.paf
 $RB synth-bed 3000 > $d/w.bed
 t1=$(date +%s.%N)
-echo "synth: $(echo "$t1 - $t0" | bc) s, $(stat -c %s $d/w.paf) bytes" | tee gpurun_out/$tag/summary.txt
+echo "synth: $(awk "BEGIN{print $t1 - $t0}") s, $(stat -c %s $d/w.paf) bytes" | tee gpurun_out/$tag/summary.txt
 run() { # name, env..., -- args
   name=$1; shift
   for rep in 1 2; do
@@ -20,7 +20,7 @@ run() { # name, env..., -- args
     env RB_TIMING=1 "$@" > $d/out_$name.paf 2> gpurun_out/$tag/${name}_$rep.err
     rc=$?
     e=$(date +%s.%N)
-    echo "$name run $rep: rc $rc, $(echo "$e - $s" | bc) s, $(echo "$n / ($e - $s)" | bc) records/s, out $(stat -c %s $d/out_$name.paf) bytes" | tee -a gpurun_out/$tag/summary.txt
+    echo "$name run $rep: rc $rc, $(awk "BEGIN{printf \"%.3f s, %.0f records/s\", $e - $s, $n / ($e - $s)}"), out $(stat -c %s $d/out_$name.paf) bytes" | tee -a gpurun_out/$tag/summary.txt
   done
 }
 run pipelined $RB liftover --bed $d/w.bed $d/w.paf
@@ -29,5 +29,6 @@ run pipe_w2 RB_PIPE_WORKERS=2 $RB liftover --bed $d/w.bed $d/w.paf
 run pipe_w4 RB_PIPE_WORKERS=4 RB_CHUNK_MB=256 $RB liftover --bed $d/w.bed $d/w.paf
 run gpus2_same RB_GPUS_SAME_DEVICE=1 $RB --gpus 2 liftover --bed $d/w.bed $d/w.paf
 run break_pipelined $RB break-paf --max-size 100 $d/w.paf
-md5sum $d/out_*.paf | tee -a gpurun_out/$tag/summary.txt
+for f in $d/out_*.paf; do cmp -s $d/out_whole.paf $f && echo "$(basename $f): same bytes as the whole-file route" || echo "$(basename $f): DIFFERENT from the whole-file route"; done | tee -a gpurun_out/$tag/summary.txt
+md5sum $d/out_whole.paf $d/out_break_pipelined.paf | tee -a gpurun_out/$tag/summary.txt
 rm -rf $d
