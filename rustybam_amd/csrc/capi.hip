@@ -329,7 +329,7 @@ static bool pin_ready(rb_ctx *ctx) {
     return true;
 }
 static void par_memcpy(void *dst, const void *src, size_t n) { // a chunk of the staging ring, on a few host threads
-    const unsigned T = n >= ((size_t)4 << 20) ? 4u : 1u;
+    const unsigned T = n >= ((size_t)16 << 20) ? 8u : (n >= ((size_t)4 << 20) ? 4u : 1u); // (a thread copies 6-8 GB/s; the DMA behind it does 50+)
     if (T == 1) {
         memcpy(dst, src, n);
         return;

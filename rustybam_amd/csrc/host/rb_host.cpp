@@ -1231,7 +1231,7 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
     std::atomic<size_t> next{0};
     std::atomic<bool> stop{false};
     const char *we = getenv("RB_PIPE_WORKERS");
-    const unsigned W = (unsigned)std::min<size_t>(n_chunks, (size_t)std::max(1, we ? atoi(we) : 4));
+    const unsigned W = (unsigned)std::min<size_t>(n_chunks, (size_t)std::max(1, we ? atoi(we) : 3));
     std::vector<std::thread> workers;
     for (unsigned w = 0; w < W; w++)
         workers.emplace_back([&]() {

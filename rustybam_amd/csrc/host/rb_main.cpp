@@ -67,15 +67,18 @@ static double g_t_main = 0;
 // handler (and exit) flush what was printed before the panic (the reference prints the stats header / earlier regions first)
 static char g_obuf[1 << 22];
 // Gigabytes into a regular file: parallel pwrite does not scale -- a buffered write holds the file's inode lock, so 8 or 32 writers
-// of one file take turns (4-5 GB/s into tmpfs whatever their number: 4 s of a 5 s run at the headline size).  Through a shared
-// mapping the pages are made by page faults, which run in parallel: the file is grown to its new end (`grow`: only by the one
+// of one file take turns (4-5 GB/s into tmpfs whatever their number: 4 s of a 5 s run at the headline size).  The alternative
+// tried here: through a shared mapping the pages are made by page faults: the file is grown to its new end (`grow`: only by the one
 // process that owns the end -- a single run, or the parent of `--gpus` before its workers write), the byte range is mapped, and
 // the segments are copied in by up to 32 threads.  The descriptor of a shell redirection is write-only, so the file is reopened
 // read-write through /proc/self/fd; false = not possible here (the caller falls back to pwrite).
 struct WSeg { const char *p; size_t n; off_t at; };
 static bool write_segments_mapped(const std::vector<WSeg> &segs, bool grow) {
-    static const bool off = getenv("RB_NO_MMAP_WRITE") != nullptr;
-    if (off || segs.empty()) return false;
+    // MEASURED AND SHELVED (round 3, 19 GB into /dev/shm): the mapped route is 2x SLOWER than pwrite there (11.7 s against 5.3 s for the
+    // whole run: shared-memory page faults serialise harder than the write path does), so it is off unless RB_MMAP_WRITE_MIN is set
+    // (tests keep the code alive; a file system whose faults do scale can switch it on)
+    static const bool on = getenv("RB_MMAP_WRITE_MIN") != nullptr;
+    if (!on || segs.empty()) return false;
     off_t lo = segs[0].at, hi = 0;
     size_t total = 0;
     for (const WSeg &g : segs) lo = std::min(lo, g.at), hi = std::max(hi, g.at + (off_t)g.n), total += g.n;

@@ -404,22 +404,84 @@ __device__ bool rb_tw_stage(rb_wrec &v, int lane, int32_t ms, int32_t ds, int32_
     uint32_t Ub = 0, Qb = 0, Rb = 0, pU = 0, pQ = 0, pR = 0; // prefixes at the current step / at the step before
     uint32_t i0 = 0, bU = 0, bQ = 0, bR = 0, i1 = v.n;
     bool found = v.n <= (uint32_t)CAP; // a record that fits is staged whole: nothing to look for
+    // Round 3: the overlap of a pair lies at one END of each record (the left record's last query bases, the right record's first,
+    // or the other way round on '-'), so the totals in front of the region are taken from whichever side is nearer: from the
+    // record's first op forwards, or from its last op BACKWARDS with the record's totals (known from its row) minus the suffix
+    // sums.  Same steps (multiples of 64 ops from op 0), same region, a handful of steps instead of the whole record.
+    const bool backwards = !found && xa > v.Qtot - 1u - (xb < v.Qtot ? xb : v.Qtot - 1u);
+    // ... and the region is cut to the ops that matter: 16 ops in front of the op that holds xa, 16 behind the op that holds xb
+    // (the walks to the next / previous match op and the D / N runs behind a last base stay within a few ops; a search that leaves
+    // the region still sends the pair to the serial kernel).  Round 2 took whole 64-op steps on either side: 192 ops staged and
+    // scanned for an overlap of a dozen.  The op inside its step is found with one scan of that step.
+    auto refine_start = [&](uint32_t c0, uint32_t len, uint32_t ql, uint32_t rl, uint32_t Ub4, uint32_t Qb4, uint32_t Rb4) -> bool {
+        const uint32_t iq = rb_wave_scan_incl(ql);
+        const uint64_t mk = __ballot(ql != 0u && Qb4 + iq - ql <= xa && xa < Qb4 + iq);
+        if (!mk) return false;
+        const int la = __builtin_ctzll(mk);
+        if (la < 16) return false; // (the margin reaches into the step in front: the caller takes that whole step, as before)
+        const uint32_t iu = rb_wave_scan_incl(len), ir = rb_wave_scan_incl(rl);
+        const int sl = la - 16;
+        i0 = c0 + (uint32_t)sl;
+        bU = Ub4 + rb_readlane<uint32_t>(iu - len, sl), bQ = Qb4 + rb_readlane<uint32_t>(iq - ql, sl), bR = Rb4 + rb_readlane<uint32_t>(ir - rl, sl);
+        return true;
+    };
+    auto refine_end = [&](uint32_t c0, uint32_t ql, uint32_t Qb4) {
+        const uint32_t iq = rb_wave_scan_incl(ql);
+        const uint64_t mk = __ballot(ql != 0u && Qb4 + iq - ql <= xb && xb < Qb4 + iq);
+        const uint32_t lb = mk ? (uint32_t)__builtin_ctzll(mk) : 63u;
+        i1 = c0 + lb + 17u < v.n ? c0 + lb + 17u : v.n;
+    };
+    if (backwards) {
+        uint32_t Ua = 0, Qa = 0, Ra = 0; // sums over the steps BEHIND the current one
+        bool have_b = false, have_a = false;
+        for (int64_t c0 = (int64_t)((v.n - 1u) / 64u) * 64; c0 >= 0; c0 -= 64) {
+            const uint32_t i = (uint32_t)c0 + (uint32_t)lane;
+            const uint32_t w = i < v.n ? v.ops[i] : 0u;
+            const uint32_t opc = rb_opc(w), len = i < v.n ? rb_len(w) : 0u;
+            const uint32_t ql = rb_in(RB_QRY_MASK, opc) ? len : 0u, rl = rb_in(RB_REF_MASK, opc) ? len : 0u;
+            const uint32_t tu = rb_wave_sum_u32(len), tq = rb_wave_sum_u32(ql), tr = rb_wave_sum_u32(rl);
+            const uint32_t qb4 = v.Qtot - Qa - tq; // query bases in front of this step
+            if (have_a) { // the step in front of the one that holds xa: the region starts here
+                i0 = (uint32_t)c0, bU = v.N - Ua - tu, bQ = qb4, bR = v.Rtot - Ra - tr;
+                found = true;
+                break;
+            }
+            if (!have_b && qb4 <= xb) have_b = true, refine_end((uint32_t)c0, ql, qb4);
+            if (have_b && qb4 <= xa) {
+                have_a = true;
+                if (refine_start((uint32_t)c0, len, ql, rl, v.N - Ua - tu, qb4, v.Rtot - Ra - tr)) {
+                    found = true;
+                    break;
+                }
+                if (c0 == 0) { // (the record's first step: nothing in front of it)
+                    i0 = 0, bU = bQ = bR = 0;
+                    found = true;
+                    break;
+                }
+            }
+            Ua += tu, Qa += tq, Ra += tr;
+        }
+    }
+    bool found_a = false;
     for (uint32_t c0 = 0; c0 < v.n && !found; c0 += 64) {
         const uint32_t i = c0 + (uint32_t)lane;
         const uint32_t w = i < v.n ? v.ops[i] : 0u;
         const uint32_t opc = rb_opc(w), len = i < v.n ? rb_len(w) : 0u;
-        const uint32_t tu = rb_wave_sum_u32(len), tq = rb_wave_sum_u32(rb_in(RB_QRY_MASK, opc) ? len : 0u), tr = rb_wave_sum_u32(rb_in(RB_REF_MASK, opc) ? len : 0u);
-        if (!found && Qb + tq > xa) {
-            found = true;
-            if (c0 >= 64u) i0 = c0 - 64u, bU = pU, bQ = pQ, bR = pR;
+        const uint32_t ql = rb_in(RB_QRY_MASK, opc) ? len : 0u, rl = rb_in(RB_REF_MASK, opc) ? len : 0u;
+        const uint32_t tu = rb_wave_sum_u32(len), tq = rb_wave_sum_u32(ql), tr = rb_wave_sum_u32(rl);
+        if (!found_a && Qb + tq > xa) {
+            found_a = true;
+            if (!refine_start(c0, len, ql, rl, Ub, Qb, Rb) && c0 >= 64u) i0 = c0 - 64u, bU = pU, bQ = pQ, bR = pR;
         }
-        if (found && Qb + tq > xb) {
-            i1 = c0 + 128u < v.n ? c0 + 128u : v.n;
+        if (found_a && Qb + tq > xb) {
+            refine_end(c0, ql, Qb);
+            found = true;
             break;
         }
         pU = Ub, pQ = Qb, pR = Rb;
         Ub += tu, Qb += tq, Rb += tr;
     }
+    if (found_a && !found) found = true, i1 = v.n; // (xb behind the last query base: the region runs to the record's end)
     if (!found || i1 - i0 > (uint32_t)CAP) return false;
     const uint32_t m = i1 - i0;
     v.i0 = i0, v.m = m;
@@ -672,28 +734,32 @@ __device__ uint32_t rb_tw_clip(rb_wrec &v, uint64_t new_q_st, uint64_t new_q_en,
     const uint64_t nt_st = t0, nt_en = t1 + 1; // :802-803
     // subset_cigar + collapse (:807-808): ops ia..ib with the first / last length cut; adjacent ops differ, nothing merges; both
     // ends are match-type units, so the strip of :819-822 removes nothing
+    // Round 3: the copy is only a copy.  check_integrity of the clipped record (:819-822) compares the sums of its ops with
+    // coordinates that were derived from those very prefixes: for a regular record it cannot fail, and nmatch follows from the spans
+    // (a match-type op counts in reference, query and units, an I in query and units, a D / N in reference and units, so
+    // matches = ref + query - units: the clip kernel's identity).  Round 2 summed three 64-bit totals over every copied op: 470 of a
+    // pair's 2640 vector instructions.
     const uint32_t ia = A.o.i, ib = B.o.i, cnt = ib - ia + 1;
-    uint64_t R = 0, Q = 0, M = 0;
     for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) {
-        const uint32_t wv = v.ops[ia + j], opc = rb_opc(wv);
+        const uint32_t wv = v.ops[ia + j];
         uint32_t len = rb_len(wv);
         if (cnt == 1) len = B.k - A.k + 1u;
         else if (j == 0) len = A.o.pre + len - A.k;
         else if (j == cnt - 1) len = B.k - B.o.pre + 1u;
-        out[j] = (len << 4) | opc;
-        if (rb_in(RB_REF_MASK, opc)) R += len;
-        if (rb_in(RB_QRY_MASK, opc)) Q += len;
-        if (rb_in(RB_MATCH_MASK, opc)) M += len;
+        out[j] = (len << 4) | rb_opc(wv);
     }
-    R = rb_wave_sum_u64(R), Q = rb_wave_sum_u64(Q), M = rb_wave_sum_u64(M);
-    if (nt_en < nt_st || nt_en - nt_st != R) return RB_ST_PANIC_INTEGRITY_T;
-    if (nq_en < nq_st || nq_en - nq_st != Q) return RB_ST_PANIC_INTEGRITY_Q;
+    // (what CAN fail is the query side: the new start and end are resolved independently -- up and down --, and when the end lands on
+    //  a lower query position than the start the coordinates say end + 1 - start while the ops between the two units still hold
+    //  |end - start| + 1 query bases: check_integrity's unwrap panics)
+    if (nt_en < nt_st) return RB_ST_PANIC_INTEGRITY_T;
+    if (qp_en < qp_st) return RB_ST_PANIC_INTEGRITY_Q;
+    const uint32_t units = B.k - A.k + 1u;
     row->t_st[s] = nt_st;
     row->t_en[s] = nt_en;
     row->q_st[s] = nq_st;
     row->q_en[s] = nq_en;
-    row->nmatch[s] = (uint32_t)M;
-    row->aln_len[s] = B.k - A.k + 1u;
+    row->nmatch[s] = (uint32_t)((nt_en - nt_st) + (nq_en - nq_st) - units);
+    row->aln_len[s] = units;
     row->out_off[s] = out_base;
     row->out_n[s] = cnt;
     return RB_ST_OK;
