@@ -225,7 +225,16 @@ def main():
         return torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).to(dev)
 
     d_off = dev_u64(op_off)
-    d_ops = torch.empty(total_ops + 64, dtype=torch.int32, device=dev)
+    from rustybam_amd import capi as capi_mod
+    lib_alloc = os.environ.get("RB_BENCH_TORCH_ALLOC") != "1"  # (diagnostics: the batch in torch's own allocations, as rounds 1 and 2)
+
+    def big(n, dtype):  # -> (tensor, owner): the batch's large buffers
+        if lib_alloc:
+            b_ = capi_mod.DevBuf(eng, torch, n, dtype)
+            return b_.t, b_
+        return torch.empty(n, dtype=dtype, device=dev), None
+
+    d_ops, own_ops = big(total_ops + 64, torch.int32)
     eng.dev_synth_fill_ops(seed, first, n_rec, d_off.data_ptr(), d_ops.data_ptr())
     if args.workload == "irregular" or args.irregular_frac > 0:
         # op 1 (the first event) becomes an '=': three adjacent '=' ops that the reference's collapse merges (paf.rs:602-620); a third of
@@ -296,21 +305,23 @@ def main():
         out_cap = 4 * rows_cap + total_ops // 8 + 65536
     tz = time.perf_counter()
     for _ in range(6):
-        d_ws = torch.empty(eng.plan_workspace_bytes(plan, rows_cap), dtype=torch.uint8, device=dev)
-        d_rows = torch.empty((rows_cap + 1) * 64, dtype=torch.uint8, device=dev)
-        d_out = torch.empty(out_cap + 64, dtype=torch.int32, device=dev)
+        d_ws, own_ws = big(eng.plan_workspace_bytes(plan, rows_cap), torch.uint8)
+        d_rows, own_rows = big((rows_cap + 1) * 64, torch.uint8)
+        d_out, own_out = big(out_cap + 64, torch.int32)
         run_op(d_ws, d_rows, d_out)
         torch.cuda.synchronize()
         cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
         if cnt["redo_two_walk"] and (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK):
             brk_policy[0] &= ~rustybam_amd.BREAK_ONE_WALK
             del d_ws, d_rows, d_out
+            [o.free() for o in (own_ws, own_rows, own_out) if o]
             continue
         if not cnt["overflow"]:
             break
         rows_cap = max(rows_cap, int(cnt["n_hits"]) + 64)
         out_cap = max(out_cap * 2, int(int(cnt["out_ops_needed"]) * 1.25) + 4096)
         del d_ws, d_rows, d_out
+        [o.free() for o in (own_ws, own_rows, own_out) if o]
     assert not cnt["overflow"], "could not size the output buffers"
     n_hits = int(cnt["n_hits"])
     sizing_ms = (time.perf_counter() - tz) * 1e3  # the calls that find rows_cap / out_cap (allocation included); once per batch shape
@@ -443,6 +454,7 @@ def main():
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
+                   "batch_memory": "rb_dev_alloc (2 MB physical chunks)" if lib_alloc else "torch allocator (hipMalloc)",
                    **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {}),
                    **({"irregular_frac": args.irregular_frac} if args.irregular_frac > 0 else {})},
         "paf_records_per_s": job_recs * args.steps / elapsed,
@@ -551,6 +563,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
+    d_ops = d_ws = d_rows = d_out = rows_t = None
+    [o.free() for o in (own_ops, own_ws, own_rows, own_out) if o]
     eng.plan_destroy(plan)
     if use_dist:
         dist.destroy_process_group()

@@ -184,6 +184,15 @@ class Engine:
         self._chk(self.L.rb_dev_gather_records(self.ctx, C.c_uint64(n_rec), C.c_void_p(ops_ptr), C.c_void_p(op_off_ptr), C.c_void_p(norm_ptr),
                                                C.c_void_p(new_off_ptr), C.c_void_p(new_ops_ptr or 0), C.c_void_p(scratch_ptr)), "rb_dev_gather_records")
 
+    def dev_alloc(self, n_bytes):
+        """device memory from the library's allocator (large requests: physically contiguous VRAM); -> address"""
+        d = C.c_void_p()
+        self._chk(self.L.rb_dev_alloc(self.ctx, C.c_size_t(n_bytes), C.byref(d)), "rb_dev_alloc")
+        return int(d.value)
+
+    def dev_free(self, ptr):
+        self._chk(self.L.rb_dev_free(self.ctx, C.c_void_p(ptr)), "rb_dev_free")
+
     def text_scratch_bytes(self, n):
         f = self.L.rb_text_scratch_bytes
         f.restype = C.c_size_t
@@ -401,3 +410,23 @@ def synth_fill_ops_host(seed, first_record, op_off):
     L.rb_synth_fill_ops_host(C.c_uint64(seed), C.c_uint64(first_record), C.c_uint64(len(op_off) - 1), _p(op_off),
                              _p(ops))
     return ops
+
+
+class DevBuf:
+    """Device memory from the LIBRARY's allocator (rb_dev_alloc: what a host of the C ABI is told to use for a resident batch --
+    requests of 1 GB and more are pieced together from 2 MB physical chunks, which decides 10-15 % of the streaming kernels' time,
+    DESIGN.md section 3), seen by torch through the CUDA array interface without a copy: `.t` is the tensor.  free() gives the
+    memory back (before the engine is closed)."""
+
+    def __init__(self, eng, torch, n, dtype):
+        self.eng, self.n, self.dtype = eng, int(n), dtype
+        self.item = torch.empty(0, dtype=dtype).element_size()
+        self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
+        self.__cuda_array_interface__ = {"shape": (self.n * self.item,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+        self.t = torch.as_tensor(self, device="cuda").view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.t = None
+            self.eng.dev_free(self.ptr)
+            self.ptr = 0

@@ -15,6 +15,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <map>
+#include <mutex>
 
 #include "../../include/rustybam_amd.h"
 #include "rb_lift.h" // rb_lift_params (the device helpers in it are unused here)
@@ -299,15 +301,114 @@ extern "C" int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_ou
     return RB_OK;
 }
 
+// A large buffer as separately created 2 MB physical chunks (hipMemCreate) mapped into one virtual range, in the order they were
+// created or (RB_ALLOC_MODE=scatter) in a pseudo-random one; rb_dev_free unmaps and releases them (rb_dev_alloc says why).
+struct rb_vmm_alloc {
+    size_t bytes, chunk;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+static std::map<void *, rb_vmm_alloc> g_vmm;
+static std::mutex g_vmm_mu;
+static bool rb_free_vmm(void *p) {
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    auto it = g_vmm.find(p);
+    if (it == g_vmm.end()) return false;
+    (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(p, it->second.bytes);
+    for (auto &h : it->second.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(p, it->second.bytes);
+    g_vmm.erase(it);
+    return true;
+}
+static void *rb_alloc_vmm(int device, size_t bytes, bool shuffle) {
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || !gran) return nullptr;
+    // (2 MB: chunks of 4 MB measured 2 % slower, and with 8 MB and 32 MB chunks the first kernel on the buffer took a memory access
+    //  fault on this ROCm -- not understood, not used)
+    size_t chunk = (size_t)2 << 20;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t n = (bytes + chunk - 1) / chunk;
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0) != hipSuccess || !va) return nullptr;
+    std::vector<hipMemGenericAllocationHandle_t> h;
+    h.reserve(n);
+    size_t mapped = 0;
+    bool ok = true;
+    for (size_t k = 0; k < n && ok; k++) {
+        hipMemGenericAllocationHandle_t hk;
+        ok = hipMemCreate(&hk, chunk, &prop, 0) == hipSuccess;
+        if (ok) h.push_back(hk);
+    }
+    std::vector<size_t> order(n);
+    for (size_t k = 0; k < n; k++) order[k] = k;
+    if (shuffle) {
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (size_t k = n; k > 1; k--) {
+            x ^= x << 13, x ^= x >> 7, x ^= x << 17;
+            std::swap(order[k - 1], order[(size_t)(x % k)]);
+        }
+    }
+    for (size_t k = 0; k < n && ok; k++) {
+        ok = hipMemMap((char *)va + k * chunk, chunk, 0, h[order[k]], 0) == hipSuccess;
+        if (ok) mapped = k + 1;
+    }
+    if (ok) {
+        hipMemAccessDesc acc;
+        memset(&acc, 0, sizeof acc);
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        ok = hipMemSetAccess(va, n * chunk, &acc, 1) == hipSuccess;
+    }
+    if (!ok) { // give everything back: the caller falls back to hipMalloc
+        (void)hipGetLastError();
+        if (mapped) (void)hipMemUnmap(va, mapped * chunk);
+        for (auto &hk : h) (void)hipMemRelease(hk);
+        (void)hipMemAddressFree(va, n * chunk);
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        g_vmm[va] = rb_vmm_alloc{n * chunk, chunk, h};
+    }
+    return va;
+}
 extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
     if (!ctx || !dev_ptr) return RB_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipError_t e = hipMalloc(dev_ptr, bytes ? ((bytes + 255) & ~(size_t)255) : 256);
+    const size_t want = bytes ? ((bytes + 255) & ~(size_t)255) : 256;
+    // How a large buffer is pieced together physically decides the streaming kernels' time: the same clip kernel on the same virtual
+    // addresses takes 10.2-11.9 ms in plain hipMalloc memory depending on the allocation (tools/layout_probe.py), 18-20 ms in
+    // physically contiguous memory (hipDeviceMallocContiguous), and 9.4 ms -- every time -- when the buffer is made of separately
+    // created 2 MB physical chunks mapped side by side (hipMemCreate / hipMemMap; tools/contig_probe.py, round 3).  So requests of
+    // 1 GB and more -- a resident batch and its outputs -- are built that way (about 14 us per chunk: 1 s for 75 GB, once per batch);
+    // smaller ones, and everything under RB_ALLOC_MODE=default, come from hipMalloc.  RB_ALLOC_MODE=chunks / scatter (the chunks in
+    // pseudo-random order: no different) / contiguous force a mode for the probe.
+    const char *mode = getenv("RB_ALLOC_MODE");
+    const bool chunks = mode ? (!strcmp(mode, "scatter") || !strcmp(mode, "chunks")) : want >= ((size_t)1 << 30);
+    if (want >= ((size_t)64 << 20) && chunks) {
+        void *q = rb_alloc_vmm(ctx->device, want, mode && !strcmp(mode, "scatter"));
+        if (q) {
+            *dev_ptr = q;
+            return RB_OK;
+        }
+        (void)hipGetLastError();
+    }
+    if (want >= ((size_t)64 << 20) && mode && !strcmp(mode, "contiguous")) {
+        if (hipExtMallocWithFlags(dev_ptr, want, hipDeviceMallocContiguous) == hipSuccess) return RB_OK;
+        (void)hipGetLastError();
+    }
+    hipError_t e = hipMalloc(dev_ptr, want);
     if (e != hipSuccess) return fail(ctx, RB_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     return RB_OK;
 }
 extern "C" int rb_dev_free(rb_ctx *ctx, void *dev_ptr) {
     if (!ctx) return RB_E_INVALID;
+    if (dev_ptr && rb_free_vmm(dev_ptr)) return RB_OK;
     if (dev_ptr) HIPCHK(ctx, hipFree(dev_ptr));
     return RB_OK;
 }

@@ -769,6 +769,10 @@ static int regroup(const std::string &path, bool by_query, bool largest_) {
 int main(int argc, char **argv) {
     g_t_main = now_s();
     setvbuf(stdout, g_obuf, _IOFBF, sizeof g_obuf);
+    // a one-shot command runs every kernel once over buffers it allocates and frees: plain hipMalloc.  (The library builds buffers of
+    // 1 GB and more from 2 MB physical chunks -- 10-15 % on the streaming kernels of a RESIDENT batch, about 14 us per chunk to make:
+    // a second per 75 GB, which this front end would pay for 50 ms of kernels.)
+    setenv("RB_ALLOC_MODE", "default", 0);
     int a = 1, device = 0, policy = RB_BSEARCH_MODERN, gpus = 1;
     while (a + 1 < argc && argv[a][0] == '-') {
         if (!strcmp(argv[a], "--bsearch")) policy = !strcmp(argv[a + 1], "legacy") ? RB_BSEARCH_LEGACY : RB_BSEARCH_MODERN;

@@ -145,7 +145,9 @@ class ResidentTrim:
         n_ops = int(op_off[-1])
         self.n_ops0 = n_ops
         cap = int(n_ops * (1.0 + room_factor)) + 4096
-        self.d_ops = torch.zeros(cap + 64, dtype=torch.int32, device=dev)   # [original ops | room for the clips of the passes]
+        self._own = capi.DevBuf(eng, torch, cap + 64, torch.int32)          # [original ops | room for the clips of the passes], from the
+        self.d_ops = self._own.t                                             # library's allocator (2 MB physical chunks: DESIGN.md section 3)
+        self.d_ops[n_ops:].zero_()
         if isinstance(ops, np.ndarray):
             self.d_ops[:n_ops] = torch.from_numpy(np.ascontiguousarray(ops, dtype=np.uint32).view(np.int32)).to(dev)
         else:
@@ -230,6 +232,11 @@ class ResidentTrim:
             self.contained = d_cont[:self.n].cpu().numpy().astype(bool)
             return self
         raise RuntimeError("trim-paf did not converge")
+
+    def release(self):
+        """give the ops arena back (after gather(): the dense copy is what goes on)"""
+        self.d_ops = None
+        self._own.free()
 
     def gather(self):
         """The current records as a dense batch: (d_new_ops, new_op_off host, norm rows host)."""

@@ -379,7 +379,7 @@ def test_full_size_config4_trim_paf_then_break_paf(oracle, tmp_path):
     # ---- break-paf --max-size 100 on the trimmed batch ----
     d_c = [torch.from_numpy(np.ascontiguousarray(norm[k]).view(np.int64)).to(dev) for k in ("t_st", "t_en", "q_st", "q_en")]
     B = DevBatch.from_device(torch, eng, dev, d_new, int(new_off[-1]), new_off, d_c, torch.from_numpy(strand).to(dev))
-    T.d_ops = None
+    T.release()
     torch.cuda.empty_cache()
     rows, out, cnt = B.run(None, max_size=100, rows_cap=4 * n)
     rows_ok = _check_break_rows(torch, dev, rows, out, n)
@@ -494,7 +494,7 @@ def test_config4_25_contigs_deep_recursion(oracle, tmp_path):
     del fake, dn
     d_c = [torch.from_numpy(np.ascontiguousarray(norm[k]).view(np.int64)).to(dev) for k in ("t_st", "t_en", "q_st", "q_en")]
     B = DevBatch.from_device(torch, eng, dev, d_new, int(new_off[-1]), new_off, d_c, torch.from_numpy(strand).to(dev))
-    T.d_ops = None
+    T.release()
     torch.cuda.empty_cache()
     rows, out, cnt = B.run(None, max_size=100, rows_cap=4 * n)
     rows_ok = _check_break_rows(torch, dev, rows, out, n)

@@ -89,7 +89,7 @@ def main():
     # ---- break-paf --max-size 100 on the trimmed batch ----
     d_c = [torch.from_numpy(np.ascontiguousarray(norm[k]).view(np.int64)).to(dev) for k in ("t_st", "t_en", "q_st", "q_en")]
     B = DevBatch.from_device(torch, eng, dev, d_new, int(new_off[-1]), new_off, d_c, torch.from_numpy(strand).to(dev))
-    T.d_ops = None
+    T.release()
     torch.cuda.empty_cache()
     B.run(None, max_size=100, rows_cap=4 * n, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN | rustybam_amd.BREAK_ONE_WALK)  # sizing
     torch.cuda.synchronize()

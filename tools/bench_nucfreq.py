@@ -66,8 +66,11 @@ def main():
     g.manual_seed(SEED)
     lut = torch.tensor([(1 << (k >> 2)) << 4 | (1 << (k & 3)) for k in range(16)], dtype=torch.uint8, device=dev)
     d_seq = lut[torch.randint(0, 16, (n * bytes_per_read + 64,), dtype=torch.uint8, device=dev, generator=g).long()] if n * bytes_per_read < (1 << 28) else None
+    from rustybam_amd import capi
+    lib_alloc = os.environ.get("RB_BENCH_TORCH_ALLOC") != "1"  # the big arrays from the library's allocator (2 MB physical chunks)
     if d_seq is None:  # in pieces: the index tensor of a one-shot gather would be 8x the sequence
-        d_seq = torch.empty(n * bytes_per_read + 64, dtype=torch.uint8, device=dev)
+        own_seq = capi.DevBuf(eng, torch, n * bytes_per_read + 64, torch.uint8) if lib_alloc else None
+        d_seq = own_seq.t if lib_alloc else torch.empty(n * bytes_per_read + 64, dtype=torch.uint8, device=dev)
         step = 1 << 27
         for o in range(0, d_seq.numel(), step):
             m = min(step, d_seq.numel() - o)
@@ -83,7 +86,8 @@ def main():
     d_rgst = torch.zeros(1, dtype=torch.int64, device=dev)
     d_rgen = torch.full((1,), a.contig, dtype=torch.int64, device=dev)
     d_outoff = torch.tensor([0, a.contig], dtype=torch.int64, device=dev)
-    d_counts = torch.empty(a.contig * 4 + 16, dtype=torch.int32, device=dev)
+    own_counts = capi.DevBuf(eng, torch, a.contig * 4 + 16, torch.int32) if lib_alloc else None
+    d_counts = own_counts.t if lib_alloc else torch.empty(a.contig * 4 + 16, dtype=torch.int32, device=dev)
     d_status = torch.empty(n + 1, dtype=torch.int32, device=dev)
     d_ctr = torch.zeros(6, dtype=torch.int64, device=dev)
     wsb = eng.nucfreq_workspace_bytes(n, 1, a.contig)
@@ -129,7 +133,7 @@ def main():
         "positions_per_s": a.contig / (ms * 1e-3), "max_depth": int(ctr[0]), "covered": int(ctr[1]),
         "roofline": {"bound": "hbm", "kernel": "rb_k_nf_tiles (whole call)", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic, "algorithmic_bytes": alg,
-                     "note": "bound by LDS atomics and instruction issue, not by HBM (profiles/r02_nf_summary.md)"},
+                     "note": "bound by instruction issue, not by HBM (profiles/r03_nf_summary.md)"},
         "setup_s": round(setup, 2)}))
 
 
