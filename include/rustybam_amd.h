@@ -207,7 +207,14 @@ void *rb_ctx_stream(rb_ctx *ctx);
 int rb_ctx_set_timing(rb_ctx *ctx, int enabled);
 int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_out);
 
-/* device memory helpers for hosts without their own allocator (the C++ host and ctypes tests) */
+/* Device memory.  Hosts that keep a batch resident across calls should take the batch, workspace, rows and
+ * output arenas from here: requests of 1 GB and more are built from 2 MB physical chunks (hipMemCreate)
+ * mapped into one virtual range, which spreads a multi-GB array evenly over the HBM channels whatever the
+ * driver's free list looks like.  On the headline batch the clip kernel takes 9.3-9.4 ms per launch on such
+ * memory against 10.2-11.9 ms on plain hipMalloc memory and 18-20 ms on one physically contiguous block
+ * (profiles/r03_alloc_summary.md).  Smaller requests are plain hipMalloc.  RB_ALLOC_MODE in the environment
+ * overrides: default (hipMalloc always) | chunks | scatter (chunks in shuffled order) | contiguous.
+ * Pointers are 2 MB aligned when chunked, 256 B otherwise; free only with rb_dev_free. */
 int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr);
 int rb_dev_free(rb_ctx *ctx, void *dev_ptr);
 /* Transfers of 8 MB and more go through the context's pinned staging ring (two page-locked 32 MB chunks, hipHostMalloc): the

@@ -421,7 +421,11 @@ class DevBuf:
     def __init__(self, eng, torch, n, dtype):
         self.eng, self.n, self.dtype = eng, int(n), dtype
         self.item = torch.empty(0, dtype=dtype).element_size()
-        self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
+        try:
+            self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
+        except Exception:
+            torch.cuda.empty_cache()                # (memory torch's caching allocator holds but does not use is not free to the driver)
+            self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
         self.__cuda_array_interface__ = {"shape": (self.n * self.item,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
         self.t = torch.as_tensor(self, device="cuda").view(dtype)
 

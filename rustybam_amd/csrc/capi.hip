@@ -403,7 +403,10 @@ extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
         (void)hipGetLastError();
     }
     hipError_t e = hipMalloc(dev_ptr, want);
-    if (e != hipSuccess) return fail(ctx, RB_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    if (e != hipSuccess) {
+        (void)hipGetLastError(); // reported through the return code: not left behind for the caller's next HIP call to trip over
+        return fail(ctx, RB_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    }
     return RB_OK;
 }
 extern "C" int rb_dev_free(rb_ctx *ctx, void *dev_ptr) {
