@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 #define STEPS 10
@@ -57,11 +58,37 @@ static float timeit(F f, int reps = 5) {
     hipEventElapsedTime(&ms, a, b);
     return ms / reps;
 }
-int main() {
+// `st_probe chunks`: the buffers from 2 MB physical chunks mapped side by side (what rb_dev_alloc does for a resident batch) instead of hipMalloc
+static bool g_chunks = false;
+static hipError_t alloc(char **p, size_t bytes) {
+    if (!g_chunks) return hipMalloc((void **)p, bytes);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = 0;
+    const size_t chunk = (size_t)2 << 20, n = (bytes + chunk - 1) / chunk;
+    void *va = nullptr;
+    hipError_t e = hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0);
+    if (e != hipSuccess) return e;
+    for (size_t k = 0; k < n; k++) {
+        hipMemGenericAllocationHandle_t h;
+        if ((e = hipMemCreate(&h, chunk, &prop, 0)) != hipSuccess) return e;
+        if ((e = hipMemMap((char *)va + k * chunk, chunk, 0, h, 0)) != hipSuccess) return e;
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(va, n * chunk, &acc, 1)) != hipSuccess) return e;
+    *p = (char *)va;
+    return hipSuccess;
+}
+int main(int argc, char **argv) {
+    g_chunks = argc > 1 && !strcmp(argv[1], "chunks");
+    printf("buffers: %s\n", g_chunks ? "2 MB physical chunks" : "hipMalloc");
     const size_t n_rec = 1000000, bytes = n_rec * (size_t)(STEPS * 2048) + 4096;
     char *src, *d0, *d1;
     uint32_t *sink;
-    CK(hipMalloc(&src, bytes)); CK(hipMalloc(&d0, 2 * bytes)); CK(hipMalloc(&d1, bytes)); CK(hipMalloc(&sink, 64));
+    CK(alloc(&src, bytes)); CK(alloc(&d0, 2 * bytes)); CK(alloc(&d1, bytes)); CK(hipMalloc(&sink, 64));
     CK(hipMemset(src, 1, bytes)); CK(hipMemset(d0, 0, bytes)); CK(hipMemset(d1, 0, bytes));
     const unsigned g = (unsigned)((n_rec + 3) / 4);
     const double gb = (double)n_rec * STEPS * 2048 / 1e9;
