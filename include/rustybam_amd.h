@@ -33,8 +33,15 @@
  *     entry point fails with RB_E_NO_DEVICE.
  *
  * Data model (all little-endian, in HBM):
- *   ops[]      u32  packed BAM encoding  len << 4 | op   (M0 I1 D2 N3 S4 H5 P6 =7 X8); len < 2^28; 16-byte aligned (128 is
- *              faster), and readable -- contents ignored -- up to the next multiple of 32 ops behind the last one
+ *   ops[]      u32  packed BAM encoding  len << 4 | op   (M0 I1 D2 N3 S4 H5 P6 =7 X8); 16-byte aligned (128 is faster), and
+ *              readable -- contents ignored -- up to the next multiple of 32 ops behind the last one.
+ *              A length of 2^28 and more (rust-htslib's Cigar holds a u32; a chromosome-long `=` of a plant genome aligned to
+ *              itself has one) takes TWO words: (len & (2^28 - 1)) << 4 | op, then the CONTINUATION word
+ *              (len >> 28) << 4 | RB_OP_CONT.  Inputs may hold such pairs and outputs (out_ops) hold them wherever a clipped
+ *              or merged op is that long; every count of "ops" in this interface (op_off, first_op, n_ops, lead_ops,
+ *              trail_ops, out_n) counts WORDS.  A record with a continuation word is not "regular": it takes the general
+ *              kernels (same results, slower).  A continuation word with no op in front of it is a word of an unknown code:
+ *              it consumes nothing.
  *   op_off[]   u64  [n_rec + 1] exclusive prefix of ops-per-record
  *   t_st,t_en,q_st,q_en u64 [n_rec];  strand u8 ('+' / '-');  contig u32 (dense ids, host keeps names)
  *   windows: contig u32, st u64, en u64   [n_win]  in BED file order
@@ -51,7 +58,8 @@ extern "C" {
 
 #define RB_ABI_VERSION 1
 
-enum rb_op { RB_OP_M = 0, RB_OP_I = 1, RB_OP_D = 2, RB_OP_N = 3, RB_OP_S = 4, RB_OP_H = 5, RB_OP_P = 6, RB_OP_EQ = 7, RB_OP_X = 8 };
+enum rb_op { RB_OP_M = 0, RB_OP_I = 1, RB_OP_D = 2, RB_OP_N = 3, RB_OP_S = 4, RB_OP_H = 5, RB_OP_P = 6, RB_OP_EQ = 7, RB_OP_X = 8,
+             RB_OP_CONT = 14 /* continuation word: bits 28..31 of the length of the op in front of it (see "ops[]" above) */ };
 
 typedef enum rb_error {
     RB_OK = 0,

@@ -50,21 +50,21 @@ void rbo_free(void *p) { free(p); }
 static const char OPCHARS[] = "MIDNSHP=X";
 
 /* paf.rs:946-951 */
-int rbo_consumes_reference(uint32_t op) {
+int rbo_consumes_reference(rbo_cig op) {
     op &= 15;
     return op == RBO_M || op == RBO_D || op == RBO_N || op == RBO_X || op == RBO_EQ;
 }
 /* paf.rs:958-963 */
-int rbo_consumes_query(uint32_t op) {
+int rbo_consumes_query(rbo_cig op) {
     op &= 15;
     return op == RBO_M || op == RBO_I || op == RBO_S || op == RBO_X || op == RBO_EQ;
 }
 /* paf.rs:973-975 */
-int rbo_is_match(uint32_t op) {
+int rbo_is_match(rbo_cig op) {
     op &= 15;
     return op == RBO_M || op == RBO_X || op == RBO_EQ;
 }
-static int is_indel(uint32_t op) {
+static int is_indel(rbo_cig op) {
     op &= 15;
     return op == RBO_I || op == RBO_D;
 }
@@ -104,7 +104,7 @@ void rbo_rec_clone(rbo_rec *dst, const rbo_rec *src) {
     dst->q_name = xstrdup(src->q_name);
     dst->t_name = xstrdup(src->t_name);
     dst->id = xstrdup(src->id);
-    dst->cigar = (uint32_t *)memdup(src->cigar, src->n_cigar * sizeof(uint32_t));
+    dst->cigar = (rbo_cig *)memdup(src->cigar, src->n_cigar * sizeof(rbo_cig));
     dst->tpos_aln = (uint64_t *)memdup(src->tpos_aln, src->n_aln * sizeof(uint64_t));
     dst->qpos_aln = (uint64_t *)memdup(src->qpos_aln, src->n_aln * sizeof(uint64_t));
     dst->long_cigar = (uint8_t *)memdup(src->long_cigar, src->n_aln);
@@ -147,9 +147,10 @@ void rbo_bed_free(rbo_bed *b) {
 /* rust-htslib 0.44.1 CigarString::try_from(&[u8]) as used at paf.rs:398-399:
  * decimal u32 length then one op char of MIDNSHP=X.  Any violation makes the reference
  * panic via .expect(); we return -1. (Missing digits / overflow: parity unpinned.) */
-int rbo_parse_cigar(const char *s, size_t n, uint32_t **ops, size_t *n_ops) {
+/* rust-htslib CigarString::try_from (paf.rs:398-399): decimal u32 length, one op character */
+static int parse_cigar64(const char *s, size_t n, rbo_cig **ops, size_t *n_ops) {
     size_t cap = 16, cnt = 0;
-    uint32_t *v = (uint32_t *)xmalloc(cap * sizeof(uint32_t));
+    rbo_cig *v = (rbo_cig *)xmalloc(cap * sizeof(rbo_cig));
     size_t i = 0;
     while (i < n) {
         size_t j = i;
@@ -171,28 +172,87 @@ int rbo_parse_cigar(const char *s, size_t n, uint32_t **ops, size_t *n_ops) {
             free(v);
             return -1;
         }
-        if (len >= (1ull << 28)) { /* cannot be packed; the product ABI documents the same limit */
-            free(v);
-            return -1;
-        }
         if (cnt == cap) {
             cap *= 2;
-            v = (uint32_t *)xrealloc(v, cap * sizeof(uint32_t));
+            v = (rbo_cig *)xrealloc(v, cap * sizeof(rbo_cig));
         }
-        v[cnt++] = ((uint32_t)len << 4) | (uint32_t)(p - OPCHARS);
+        v[cnt++] = (len << 4) | (uint64_t)(p - OPCHARS);
         i = j + 1;
     }
     *ops = v;
     *n_ops = cnt;
     return 0;
 }
-
-size_t rbo_cigar_to_string(const uint32_t *ops, size_t n, char **out) {
-    size_t cap = n * 11 + 1, k = 0;
+static size_t cigar64_to_string(const rbo_cig *ops, size_t n, char **out) {
+    size_t cap = n * 12 + 1, k = 0;
     char *b = (char *)xmalloc(cap);
-    for (size_t i = 0; i < n; i++) k += (size_t)sprintf(b + k, "%u%c", ops[i] >> 4, OPCHARS[ops[i] & 15]);
+    for (size_t i = 0; i < n; i++) k += (size_t)sprintf(b + k, "%llu%c", (unsigned long long)(ops[i] >> 4), OPCHARS[ops[i] & 15]);
     b[k] = 0;
     *out = b;
+    return k;
+}
+
+/* ---- the 32-bit word form of the product's ABI (rb_oracle.h, rbo_cig) ---- */
+size_t rbo_words_of(const rbo_cig *ops, size_t n) {
+    size_t w = n;
+    for (size_t i = 0; i < n; i++) w += (ops[i] >> 4) >> RBO_WORD_LEN_BITS ? 1 : 0;
+    return w;
+}
+size_t rbo_cig_to_words(const rbo_cig *ops, size_t n, uint32_t *out) {
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t len = ops[i] >> 4;
+        if (out) out[k] = (uint32_t)((len & ((1u << RBO_WORD_LEN_BITS) - 1u)) << 4) | (uint32_t)(ops[i] & 15);
+        k++;
+        if (len >> RBO_WORD_LEN_BITS) {
+            if (out) out[k] = (uint32_t)((len >> RBO_WORD_LEN_BITS) << 4) | RBO_CONT;
+            k++;
+        }
+    }
+    return k;
+}
+int rbo_words_to_cig(const uint32_t *w, size_t n_words, rbo_cig **ops, size_t *n_ops) {
+    rbo_cig *v = (rbo_cig *)xmalloc((n_words ? n_words : 1) * sizeof(rbo_cig));
+    size_t cnt = 0;
+    int fresh = 0; /* the op in front may still take a continuation word */
+    for (size_t i = 0; i < n_words; i++) {
+        if ((w[i] & 15) == RBO_CONT) {
+            if (!fresh || (w[i] >> 4) > 15 || (w[i] >> 4) == 0) {
+                free(v);
+                return -1;
+            }
+            v[cnt - 1] += ((uint64_t)(w[i] >> 4) << RBO_WORD_LEN_BITS) << 4;
+            fresh = 0;
+        } else {
+            v[cnt++] = w[i]; /* len << 4 | code as it stands */
+            fresh = 1;
+        }
+    }
+    *ops = v;
+    *n_ops = cnt;
+    return 0;
+}
+int rbo_parse_cigar(const char *s, size_t n, uint32_t **ops, size_t *n_ops) {
+    rbo_cig *v = NULL;
+    size_t cnt = 0;
+    if (parse_cigar64(s, n, &v, &cnt)) return -1;
+    const size_t nw = rbo_cig_to_words(v, cnt, NULL);
+    uint32_t *w = (uint32_t *)xmalloc((nw ? nw : 1) * sizeof(uint32_t));
+    rbo_cig_to_words(v, cnt, w);
+    free(v);
+    *ops = w;
+    *n_ops = nw;
+    return 0;
+}
+size_t rbo_cigar_to_string(const uint32_t *words, size_t n, char **out) {
+    rbo_cig *v = NULL;
+    size_t cnt = 0;
+    if (rbo_words_to_cig(words, n, &v, &cnt)) {
+        *out = xstrdup("");
+        return 0;
+    }
+    const size_t k = cigar64_to_string(v, cnt, out);
+    free(v);
     return k;
 }
 
@@ -239,7 +299,7 @@ int rbo_rec_from_line(const char *line, rbo_rec *out) {
         p = q;
     }
     int rc = 0;
-    uint32_t *cigar = NULL;
+    rbo_cig *cigar = NULL;
     size_t n_cigar = 0;
     if (ntok < 12) {
         rc = -1;
@@ -263,7 +323,7 @@ int rbo_rec_from_line(const char *line, rbo_rec *out) {
         if (t[m] == 'c' && t[m + 1] == 'g' && n_cigar == 0) { /* paf.rs:395 */
             free(cigar);
             cigar = NULL;
-            if (rbo_parse_cigar(t + m + 5, n - (m + 5), &cigar, &n_cigar)) {
+            if (parse_cigar64(t + m + 5, n - (m + 5), &cigar, &n_cigar)) {
                 rc = -1;
                 goto done;
             }
@@ -312,7 +372,7 @@ done:
 /* paf.rs:923-944 Display */
 void rbo_rec_print(const rbo_rec *r, FILE *f) {
     char *cg = NULL;
-    rbo_cigar_to_string(r->cigar, r->n_cigar, &cg);
+    cigar64_to_string(r->cigar, r->n_cigar, &cg);
     fprintf(f, "%s\t%llu\t%llu\t%llu\t%c\t%s\t%llu\t%llu\t%llu\t%llu\t%llu\t%llu\tid:Z:%s\tcg:Z:%s\n", r->q_name,
             (unsigned long long)r->q_len, (unsigned long long)r->q_st, (unsigned long long)r->q_en, r->strand,
             r->t_name, (unsigned long long)r->t_len, (unsigned long long)r->t_st, (unsigned long long)r->t_en,
@@ -436,7 +496,8 @@ int rbo_bed_from_file(const char *path, rbo_bed *out) {
 int rbo_infer_n_bases(const rbo_rec *r, uint64_t o[4]) {
     uint64_t t = 0, q = 0, m = 0, a = 0;
     for (size_t i = 0; i < r->n_cigar; i++) {
-        uint32_t op = r->cigar[i], len = op >> 4;
+        const rbo_cig op = r->cigar[i];
+        const uint64_t len = op >> 4;
         if (rbo_consumes_reference(op)) t += len;
         if (rbo_consumes_query(op)) q += len;
         if (rbo_is_match(op)) m += len;
@@ -461,10 +522,10 @@ int rbo_check_integrity(rbo_rec *r) {
     return RBO_OK;
 }
 
-static void id_append_TO(rbo_rec *r, const uint32_t *st, size_t nst, const uint32_t *en, size_t nen) {
+static void id_append_TO(rbo_rec *r, const rbo_cig *st, size_t nst, const rbo_cig *en, size_t nen) {
     char *a = NULL, *b = NULL;
-    rbo_cigar_to_string(st, nst, &a);
-    rbo_cigar_to_string(en, nen, &b);
+    cigar64_to_string(st, nst, &a);
+    cigar64_to_string(en, nen, &b);
     size_t n = strlen(r->id) + strlen(a) + strlen(b) + 6;
     char *s = (char *)xmalloc(n);
     snprintf(s, n, "%s_TO.%s.%s", r->id, a, b);
@@ -478,16 +539,16 @@ static void id_append_TO(rbo_rec *r, const uint32_t *st, size_t nst, const uint3
 int rbo_remove_trailing_indels(rbo_rec *r) {
     size_t cigar_len = r->n_cigar;
     if (cigar_len == 0) return RBO_PANIC_EMPTY_CIGAR; /* :663 */
-    uint32_t st_opt = r->cigar[0];
+    rbo_cig st_opt = r->cigar[0];
     int64_t remove_st_t = 0, remove_st_q = 0;
     size_t remove_st_opts = 0;
-    uint32_t *removed_st = (uint32_t *)xmalloc(cigar_len * sizeof(uint32_t));
+    rbo_cig *removed_st = (rbo_cig *)xmalloc(cigar_len * sizeof(rbo_cig));
     while (is_indel(st_opt)) { /* :668-687 */
         if ((st_opt & 15) == RBO_D) {
-            remove_st_t += st_opt >> 4;
+            remove_st_t += (int64_t)(st_opt >> 4);
             remove_st_q += 1;
         } else {
-            remove_st_q += st_opt >> 4;
+            remove_st_q += (int64_t)(st_opt >> 4);
         }
         removed_st[remove_st_opts++] = st_opt;
         if (remove_st_opts < cigar_len)
@@ -497,22 +558,22 @@ int rbo_remove_trailing_indels(rbo_rec *r) {
     }
     if (remove_st_opts > 1) { /* :690-701 */
         for (size_t i = 0; i + 1 < remove_st_opts; i++) {
-            uint32_t pre = removed_st[i] & 15, cur = removed_st[i + 1] & 15;
+            const unsigned pre = (unsigned)(removed_st[i] & 15), cur = (unsigned)(removed_st[i + 1] & 15);
             if ((pre == RBO_D && cur == RBO_I) || (pre == RBO_I && cur == RBO_D)) {
                 remove_st_t += 1;
                 remove_st_q -= 1;
             }
         }
     }
-    uint32_t en_opt = r->cigar[cigar_len - 1]; /* :704-723 */
+    rbo_cig en_opt = r->cigar[cigar_len - 1]; /* :704-723 */
     int64_t remove_en_t = 0, remove_en_q = 0;
     size_t remove_en_opts = 0;
-    uint32_t *removed_en = (uint32_t *)xmalloc(cigar_len * sizeof(uint32_t));
+    rbo_cig *removed_en = (rbo_cig *)xmalloc(cigar_len * sizeof(rbo_cig));
     while (is_indel(en_opt)) {
         if ((en_opt & 15) == RBO_D)
-            remove_en_t += en_opt >> 4;
+            remove_en_t += (int64_t)(en_opt >> 4);
         else
-            remove_en_q += en_opt >> 4;
+            remove_en_q += (int64_t)(en_opt >> 4);
         removed_en[remove_en_opts++] = en_opt;
         if (cigar_len - remove_en_opts > 0)
             en_opt = r->cigar[cigar_len - 1 - remove_en_opts];
@@ -526,7 +587,7 @@ int rbo_remove_trailing_indels(rbo_rec *r) {
     /* :756-757 */
     if (remove_st_opts + remove_en_opts > cigar_len) return RBO_PANIC_ALL_INDEL;
     size_t new_len = cigar_len - remove_st_opts - remove_en_opts;
-    memmove(r->cigar, r->cigar + remove_st_opts, (cigar_len - remove_st_opts) * sizeof(uint32_t));
+    memmove(r->cigar, r->cigar + remove_st_opts, (cigar_len - remove_st_opts) * sizeof(rbo_cig));
     r->n_cigar = new_len;
     /* :760-769 */
     r->t_st += (uint64_t)remove_st_t;
@@ -558,10 +619,10 @@ int rbo_aligned_pairs(rbo_rec *r) {
     if (r->strand == '-') q_pos = (int64_t)r->q_en;
     size_t k = 0;
     for (size_t i = 0; i < r->n_cigar; i++) {
-        uint32_t op = r->cigar[i];
+        const rbo_cig op = r->cigar[i];
         int moves_t = rbo_consumes_reference(op), moves_q = rbo_consumes_query(op);
-        uint32_t len = op >> 4;
-        for (uint32_t j = 0; j < len; j++) {
+        const uint64_t len = op >> 4;
+        for (uint64_t j = 0; j < len; j++) {
             r->long_cigar[k] = (uint8_t)(op & 15);
             if (moves_t) t_pos += 1;
             if (moves_q && r->strand == '+') q_pos += 1;
@@ -582,7 +643,7 @@ static void make_long_cigar(rbo_rec *r) {
     r->long_cigar = (uint8_t *)xmalloc(total);
     size_t k = 0;
     for (size_t i = 0; i < r->n_cigar; i++)
-        for (uint32_t j = 0; j < (r->cigar[i] >> 4); j++) r->long_cigar[k++] = (uint8_t)(r->cigar[i] & 15);
+        for (uint64_t j = 0; j < (r->cigar[i] >> 4); j++) r->long_cigar[k++] = (uint8_t)(r->cigar[i] & 15);
     /* NB the reference does not touch tpos_aln/qpos_aln here; long_cigar.len() may differ from
      * n_aln only if the caller let them go stale; we keep n_aln tied to the position arrays. */
 }
@@ -685,29 +746,29 @@ int rbo_qpos_to_idx_match(const rbo_rec *r, uint64_t qpos, int right, int policy
 }
 
 /* paf.rs:593-620 subset_cigar + collapse_long_cigar */
-static void subset_collapse(const uint8_t *lc, size_t a, size_t b, uint32_t **ops, size_t *n_ops) {
+static void subset_collapse(const uint8_t *lc, size_t a, size_t b, rbo_cig **ops, size_t *n_ops) {
     size_t cap = 16, cnt = 0;
-    uint32_t *v = (uint32_t *)xmalloc(cap * sizeof(uint32_t));
+    rbo_cig *v = (rbo_cig *)xmalloc(cap * sizeof(rbo_cig));
     uint8_t pre = lc[a];
-    uint32_t pre_len = 1;
+    uint32_t pre_len = 1; /* (u32 in the reference: paf.rs:606) */
     for (size_t i = a + 1; i <= b; i++) {
         if (lc[i] == pre) {
             pre_len++;
         } else {
             if (cnt == cap) {
                 cap *= 2;
-                v = (uint32_t *)xrealloc(v, cap * sizeof(uint32_t));
+                v = (rbo_cig *)xrealloc(v, cap * sizeof(rbo_cig));
             }
-            v[cnt++] = (pre_len << 4) | pre;
+            v[cnt++] = ((rbo_cig)pre_len << 4) | pre;
             pre = lc[i];
             pre_len = 1;
         }
     }
     if (cnt == cap) {
         cap += 1;
-        v = (uint32_t *)xrealloc(v, cap * sizeof(uint32_t));
+        v = (rbo_cig *)xrealloc(v, cap * sizeof(rbo_cig));
     }
-    v[cnt++] = (pre_len << 4) | pre;
+    v[cnt++] = ((rbo_cig)pre_len << 4) | pre;
     *ops = v;
     *n_ops = cnt;
 }
@@ -748,7 +809,7 @@ int rbo_trim_paf_rec_to_rgn(const rbo_region *rgn, const rbo_rec *paf, int polic
     memset(out, 0, sizeof(*out));
     if (paf->t_st > rgn->st && paf->t_en < rgn->en) { /* :23-25 paf.clone(), own id */
         rec_small_copy(out, paf);
-        out->cigar = (uint32_t *)memdup(paf->cigar, paf->n_cigar * sizeof(uint32_t));
+        out->cigar = (rbo_cig *)memdup(paf->cigar, paf->n_cigar * sizeof(rbo_cig));
         out->n_cigar = paf->n_cigar;
         return RBO_OK;
     }
@@ -831,7 +892,8 @@ void rbo_paf_swap_query_and_target(const rbo_rec *paf, rbo_rec *fl) {
     fl->q_st = paf->t_st;
     fl->q_en = paf->t_en;
     for (size_t i = 0; i < fl->n_cigar; i++) {
-        uint32_t op = fl->cigar[i] & 15, len = fl->cigar[i] >> 4;
+        rbo_cig op = fl->cigar[i] & 15;
+        const rbo_cig len = fl->cigar[i] >> 4;
         if (op == RBO_I)
             op = RBO_D;
         else if (op == RBO_D)
@@ -840,7 +902,7 @@ void rbo_paf_swap_query_and_target(const rbo_rec *paf, rbo_rec *fl) {
     }
     if (paf->strand == '-')
         for (size_t i = 0, j = fl->n_cigar; i + 1 < j; i++, j--) {
-            uint32_t t = fl->cigar[i];
+            rbo_cig t = fl->cigar[i];
             fl->cigar[i] = fl->cigar[j - 1];
             fl->cigar[j - 1] = t;
         }
@@ -925,7 +987,8 @@ static int break_impl(const rbo_rec *paf, uint32_t break_length, int policy, rbo
     int rc = 0;
     for (size_t i = 0; i <= paf->n_cigar; i++) {
         int last = (i == paf->n_cigar);
-        uint32_t opt = last ? 0 : paf->cigar[i], opt_len = opt >> 4;
+        const rbo_cig opt = last ? 0 : paf->cigar[i];
+        const uint64_t opt_len = opt >> 4;
         int big = !last && opt_len > break_length && is_indel(opt);
         if (big || last) {
             if (cur_tpos > pre_tpos) {
@@ -984,7 +1047,7 @@ int rbo_truncate_record_by_query(rbo_rec *r, uint64_t new_q_st, uint64_t new_q_e
     }
     uint64_t new_t_st = r->tpos_aln[aln_st];
     uint64_t new_t_en = r->tpos_aln[aln_en] + 1;
-    uint32_t *ops;
+    rbo_cig *ops;
     size_t n_ops;
     subset_collapse(r->long_cigar, aln_st, aln_en, &ops, &n_ops);
     free(r->cigar);
@@ -1397,10 +1460,10 @@ void rbo_paf_scaffold(rbo_paf *paf, uint64_t *orders, uint64_t spacer) {
 }
 
 /* ------------------------------------------------------------------ bamstats.rs:107-154 (md = None) */
-void rbo_stats_from_cigar(const uint32_t *ops, size_t n, rbo_stats *s) {
+void rbo_stats_from_cigar(const rbo_cig *ops, size_t n, rbo_stats *s) {
     memset(s, 0, sizeof(*s));
     for (size_t i = 0; i < n; i++) {
-        uint32_t op = ops[i] & 15, val = ops[i] >> 4;
+        const uint32_t op = (uint32_t)(ops[i] & 15), val = (uint32_t)(ops[i] >> 4); /* (a Cigar length is u32) */
         switch (op) {
         case RBO_D:
             s->del_events += 1;
@@ -1784,7 +1847,12 @@ int rbo_bam_stats(const char *path, int qbed, FILE *out) {
             q_en = q_len - t;
         }
         rbo_stats s;
-        rbo_stats_from_cigar(cig, n, &s);
+        {   /* (BAM words are 28-bit lengths already: widened as they stand) */
+            rbo_cig *wide = (rbo_cig *)xmalloc((n ? n : 1) * sizeof(rbo_cig));
+            for (size_t k = 0; k < (size_t)n; k++) wide[k] = cig[k];
+            rbo_stats_from_cigar(wide, n, &s);
+            free(wide);
+        }
         if (s.equal == 0 && s.matches > 0 && md) { /* bamstats.rs:129-135 */
             uint32_t m4[4];
             rbo_parse_md_for_stats(md, m4);
@@ -2210,12 +2278,25 @@ int rbo_bam_nucfreq(const char *path, const char *region, const char *bed_path, 
 /* ==================================================================================
  * Flat-array API
  * ================================================================================== */
+/* the words of one record -> r->cigar (a continuation word with no op in front of it stays an op of its own: code 14, consumes
+ * nothing -- what the product makes of it too) */
+static void cig_from_words(rbo_rec *r, const uint32_t *w, size_t n_words) {
+    free(r->cigar);
+    r->cigar = NULL;
+    r->n_cigar = 0;
+    if (rbo_words_to_cig(w, n_words, &r->cigar, &r->n_cigar)) {
+        r->cigar = (rbo_cig *)xmalloc((n_words ? n_words : 1) * sizeof(rbo_cig));
+        for (size_t k = 0; k < n_words; k++) r->cigar[k] = w[k];
+        r->n_cigar = n_words;
+    }
+}
+/* ops [0, k) of a cigar take this many words */
+static size_t words_before(const rbo_cig *c, size_t k) { return rbo_words_of(c, k); }
 static void rec_from_arrays(rbo_rec *r, uint64_t i, const uint32_t *ops, const uint64_t *op_off,
                             const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
                             const uint8_t *strand) {
     rbo_rec_init(r);
-    r->n_cigar = (size_t)(op_off[i + 1] - op_off[i]);
-    r->cigar = (uint32_t *)memdup(ops + op_off[i], r->n_cigar * sizeof(uint32_t));
+    cig_from_words(r, ops + op_off[i], (size_t)(op_off[i + 1] - op_off[i]));
     r->t_st = t_st[i];
     r->t_en = t_en[i];
     r->q_st = q_st[i];
@@ -2267,17 +2348,19 @@ int rbo_normalize_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op
         size_t lead = 0, trail = 0;
         while (lead < n0 && is_indel(r.cigar[lead])) lead++;
         while (trail < n0 && is_indel(r.cigar[n0 - 1 - trail])) trail++;
+        const size_t lead_w = words_before(r.cigar, lead < n0 ? lead : n0);                                   /* (words at the boundary) */
+        const size_t trail_w = rbo_words_of(r.cigar + (n0 - (trail < n0 ? trail : n0)), trail < n0 ? trail : n0);
         int st = rbo_remove_trailing_indels(&r);
         w->status = (uint32_t)st;
-        w->lead_ops = (uint32_t)lead;
-        w->trail_ops = (uint32_t)trail;
+        w->lead_ops = (uint32_t)lead_w;
+        w->trail_ops = (uint32_t)trail_w;
         if (st == RBO_OK) {
             w->t_st = r.t_st;
             w->t_en = r.t_en;
             w->q_st = r.q_st;
             w->q_en = r.q_en;
-            w->first_op = (uint32_t)lead;
-            w->n_ops = (uint32_t)r.n_cigar;
+            w->first_op = (uint32_t)lead_w;
+            w->n_ops = (uint32_t)rbo_words_of(r.cigar, r.n_cigar);
             w->nmatch = (uint32_t)r.nmatch;
             w->aln_len = (uint32_t)r.aln_len;
         }
@@ -2292,7 +2375,8 @@ typedef struct {
     uint32_t *ops;
     size_t n_ops, cap_ops;
 } hit_buf;
-static void hb_push(hit_buf *b, const rbo_hit_row *row, const uint32_t *ops, size_t n) {
+static void hb_push(hit_buf *b, const rbo_hit_row *row, const rbo_cig *cig, size_t n_cig) {
+    const size_t n = rbo_cig_to_words(cig, n_cig, NULL);
     if (b->n_rows == b->cap_rows) {
         b->cap_rows = b->cap_rows ? b->cap_rows * 2 : 8;
         b->rows = (rbo_hit_row *)xrealloc(b->rows, b->cap_rows * sizeof(rbo_hit_row));
@@ -2305,7 +2389,7 @@ static void hb_push(hit_buf *b, const rbo_hit_row *row, const uint32_t *ops, siz
     b->rows[b->n_rows].out_off = b->n_ops;
     b->rows[b->n_rows].out_n = (uint32_t)n;
     b->n_rows++;
-    if (n) memcpy(b->ops + b->n_ops, ops, n * sizeof(uint32_t));
+    if (n) rbo_cig_to_words(cig, n_cig, b->ops + b->n_ops);
     b->n_ops += n;
 }
 static void row_from_rec(rbo_hit_row *row, const rbo_rec *t) {
@@ -2489,13 +2573,14 @@ int rbo_overlap_split_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t
                 w->nmatch[s] = (uint32_t)rr[s]->nmatch;
                 w->aln_len[s] = (uint32_t)rr[s]->aln_len;
                 w->out_off[s] = no;
-                w->out_n[s] = (uint32_t)rr[s]->n_cigar;
-                if (no + rr[s]->n_cigar > cap) {
-                    while (no + rr[s]->n_cigar > cap) cap = cap ? cap * 2 : 1024;
+                const size_t nw = rbo_cig_to_words(rr[s]->cigar, rr[s]->n_cigar, NULL);
+                w->out_n[s] = (uint32_t)nw;
+                if (no + nw > cap) {
+                    while (no + nw > cap) cap = cap ? cap * 2 : 1024;
                     O = (uint32_t *)xrealloc(O, cap * sizeof(uint32_t));
                 }
-                memcpy(O + no, rr[s]->cigar, rr[s]->n_cigar * sizeof(uint32_t));
-                no += rr[s]->n_cigar;
+                rbo_cig_to_words(rr[s]->cigar, rr[s]->n_cigar, O + no);
+                no += nw;
             }
         }
         rbo_rec_free(&L);
@@ -2512,12 +2597,11 @@ int rbo_swap_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off,
         rbo_rec r, f;
         uint64_t z = 0;
         rbo_rec_init(&r);
-        r.n_cigar = (size_t)(op_off[i + 1] - op_off[i]);
-        r.cigar = (uint32_t *)memdup(ops + op_off[i], r.n_cigar * sizeof(uint32_t));
+        cig_from_words(&r, ops + op_off[i], (size_t)(op_off[i + 1] - op_off[i]));
         r.strand = (char)strand[i];
         (void)z;
         rbo_paf_swap_query_and_target(&r, &f);
-        memcpy(out_ops + op_off[i], f.cigar, f.n_cigar * sizeof(uint32_t));
+        rbo_cig_to_words(f.cigar, f.n_cigar, out_ops + op_off[i]); /* (as many words as came in) */
         rbo_rec_free(&r);
         rbo_rec_free(&f);
     }

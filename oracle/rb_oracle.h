@@ -40,8 +40,19 @@
 extern "C" {
 #endif
 
-/* BAM op codes, packed op = len << 4 | code (rust_htslib Cigar enum; paf.rs:946-996) */
+/* BAM op codes (rust_htslib Cigar enum; paf.rs:946-996) */
 enum { RBO_M = 0, RBO_I = 1, RBO_D = 2, RBO_N = 3, RBO_S = 4, RBO_H = 5, RBO_P = 6, RBO_EQ = 7, RBO_X = 8 };
+/* One CIGAR op INSIDE the oracle: Cigar(op, u32 len) as len << 4 | code in 64 bits, so every u32 length the reference can hold
+ * has a place.  At the array / word boundaries (rbo_*_arrays, rbo_parse_cigar, rbo_cigar_to_string) the product's 32-bit words are
+ * spoken: len << 4 | code with len < 2^28, and a length of 2^28 or more as TWO words -- (len & (2^28 - 1)) << 4 | code followed by
+ * the continuation word (len >> 28) << 4 | RBO_CONT (include/rustybam_amd.h, "packed ops").  Counts of ops that cross that boundary
+ * (first_op, n_ops, lead_ops, trail_ops, out_n) are counts of WORDS there. */
+typedef uint64_t rbo_cig;
+enum { RBO_CONT = 14 };
+#define RBO_WORD_LEN_BITS 28
+size_t rbo_words_of(const rbo_cig *ops, size_t n);                        /* words the ops take */
+size_t rbo_cig_to_words(const rbo_cig *ops, size_t n, uint32_t *out);     /* returns the word count; out may be NULL */
+int rbo_words_to_cig(const uint32_t *w, size_t n_words, rbo_cig **ops, size_t *n_ops); /* <0: a misplaced continuation word */
 
 enum { RBO_BSEARCH_MODERN = 0, RBO_BSEARCH_LEGACY = 1 };
 
@@ -69,7 +80,7 @@ typedef struct {
     char *t_name;
     uint64_t t_len, t_st, t_en;
     uint64_t nmatch, aln_len, mapq;
-    uint32_t *cigar; /* packed len<<4|op */
+    rbo_cig *cigar; /* len << 4 | op, 64-bit (see rbo_cig) */
     size_t n_cigar;
     char *id;
     /* per-base expansion (paf.rs:362-364) */
@@ -114,9 +125,9 @@ int rbo_bed_from_file(const char *path, rbo_bed *out);
 void rbo_region_default_id(rbo_region *r);
 
 /* --- primitives --- */
-int rbo_consumes_reference(uint32_t op);
-int rbo_consumes_query(uint32_t op);
-int rbo_is_match(uint32_t op);
+int rbo_consumes_reference(rbo_cig op);
+int rbo_consumes_query(rbo_cig op);
+int rbo_is_match(rbo_cig op);
 int rbo_infer_n_bases(const rbo_rec *r, uint64_t out4[4]);       /* paf.rs:631-654 */
 int rbo_check_integrity(rbo_rec *r);                             /* paf.rs:825-857 */
 int rbo_remove_trailing_indels(rbo_rec *r);                      /* paf.rs:656-783 */
@@ -175,7 +186,7 @@ typedef struct {
     uint32_t equal, diff, ins, del, matches, ins_events, del_events;
     float id_by_all, id_by_events, id_by_matches;
 } rbo_stats;
-void rbo_stats_from_cigar(const uint32_t *ops, size_t n, rbo_stats *s);
+void rbo_stats_from_cigar(const rbo_cig *ops, size_t n, rbo_stats *s);
 size_t rbo_f32_display(float v, char *buf, size_t cap); /* Rust `{}` for f32 */
 void rbo_print_stats_header(int qbed, FILE *f);
 void rbo_print_stats(const rbo_rec *r, const rbo_stats *s, int qbed, FILE *f);

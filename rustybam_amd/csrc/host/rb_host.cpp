@@ -70,6 +70,20 @@ static void lap(const char *what, double &t) {
 unsigned parallel_chunk_count(size_t n) { return (unsigned)std::min<size_t>(host_threads(), n ? n : 1); }
 
 static const char OPCH[] = "MIDNSHP=X";
+// Display of packed words (impl Display for CigarString): a continuation word (RB_OP_CONT, rustybam_amd.h) is bits 28.. of the
+// length of the op in front of it
+template <typename Out>
+static inline void append_ops(Out &o, const uint32_t *w, size_t n) {
+    char nb[24];
+    for (size_t i = 0; i < n; i++) {
+        uint64_t len = w[i] >> 4;
+        const uint32_t code = w[i] & 15u;
+        if (code != RB_OP_CONT && i + 1 < n && (w[i + 1] & 15u) == RB_OP_CONT) len += (uint64_t)((w[++i] >> 4) & 15u) << 28;
+        auto r = std::to_chars(nb, nb + sizeof nb, len);
+        o.append(nb, r.ptr);
+        o.push_back(code < 9u ? OPCH[code] : '?');
+    }
+}
 
 Engine::Engine(int device) {
     int rc = rb_ctx_create(device, nullptr, &ctx_);
@@ -83,12 +97,7 @@ void Engine::check(int rc, const char *what) const {
 std::string cigar_to_string(const std::vector<uint32_t> &cigar) {
     std::string s;
     s.reserve(cigar.size() * 5);
-    char buf[16];
-    for (uint32_t v : cigar) {
-        auto r = std::to_chars(buf, buf + sizeof buf, v >> 4);
-        s.append(buf, r.ptr);
-        s.push_back(OPCH[v & 15u]);
-    }
+    append_ops(s, cigar.data(), cigar.size());
     return s;
 }
 
@@ -136,8 +145,8 @@ static void parse_cigar(const char *s, size_t n, std::vector<uint32_t> &out) {
         if (j == i || j >= n) throw Panic("Unable to parse cigar string.");
         const char *p = (const char *)memchr(OPCH, s[j], 9);
         if (!p) throw Panic("Unable to parse cigar string.");
-        if (len >= (1ull << 28)) throw Panic("cigar length does not fit the packed form (>= 2^28)");
-        out.push_back(((uint32_t)len << 4) | (uint32_t)(p - OPCH));
+        out.push_back(((uint32_t)(len & 0x0FFFFFFFull) << 4) | (uint32_t)(p - OPCH));
+        if (len >> 28) out.push_back(((uint32_t)(len >> 28) << 4) | (uint32_t)RB_OP_CONT); // (rustybam_amd.h: lengths of 2^28 and more)
         i = j + 1;
     }
 }
@@ -767,7 +776,7 @@ static std::vector<std::string> rows_to_text(const std::vector<PafRecord> &src, 
                 const uint32_t *c = s.cigar.data() + d[0];
                 const uint32_t n = d[1];
                 if (h.flags & RB_HIT_INSIDE) {
-                    for (uint32_t i = 0; i < n; i++) op(c[i]);
+                    append_ops(o, c, n);
                 } else if (n == 1) {
                     op((h.aln_len << 4) | (c[0] & 15u));
                 } else {
@@ -776,7 +785,7 @@ static std::vector<std::string> rows_to_text(const std::vector<PafRecord> &src, 
                     op((d[3] << 4) | (c[n - 1] & 15u));
                 }
             } else {
-                for (uint32_t i = 0; i < h.out_n; i++) op(out[h.out_off + i]);
+                append_ops(o, out + h.out_off, h.out_n);
             }
             o += '\n';
         }
@@ -1004,7 +1013,10 @@ struct TextFile {
                 unusual = true;
                 continue;
             }
-            if (cig_status[i] == RB_TEXT_TOO_LONG) throw Panic("cigar length does not fit the packed form (>= 2^28)");
+            if (cig_status[i] == RB_TEXT_TOO_LONG) { // a length of 2^28 and more: two words per op, made by the line-by-line parser
+                unusual = true;
+                continue;
+            }
             if (cig_status[i] != RB_TEXT_OK) throw Panic("Unable to parse cigar string.");
         }
         if (unusual) return false;

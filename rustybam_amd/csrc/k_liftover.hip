@@ -1049,7 +1049,7 @@ __device__ uint64_t rb_unit_tpos(const uint32_t *ops, uint32_t n, uint64_t t_st,
     int64_t tpos = (int64_t)t_st - 1;
     uint64_t U = 0;
     for (uint32_t i = 0; i < n; i++) {
-        const uint32_t opc = rb_opc(ops[i]), len = rb_len(ops[i]);
+        const uint32_t opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
         const bool isref = opc <= 8 && rb_in(RB_REF_MASK, opc);
         if (unit < U + len) return (uint64_t)(isref ? tpos + (int64_t)(unit - U) + 1 : tpos); // (-1 wraps to u64::MAX)
         U += len;
@@ -1151,7 +1151,7 @@ __device__ void rb_generic_serial_hit(const rb_lift_params &p, const uint64_t g)
         {
             int64_t tpos = (int64_t)t_st - 1;
             for (uint32_t i = 0; i < n; i++) {
-                const uint32_t opc = rb_opc(ops[i]), len = rb_len(ops[i]);
+                const uint32_t opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 if (len == 0) continue;
                 if (opc <= 8 && rb_in(RB_REF_MASK, opc)) {
                     // units N..N+len-1 hold tpos+1 .. tpos+len
@@ -1184,8 +1184,8 @@ __device__ void rb_generic_serial_hit(const rb_lift_params &p, const uint64_t g)
         bool wrapped = false;
         if (t_st == 0)
             for (uint32_t i = 0; i < n; i++) {
-                if (rb_len(ops[i]) == 0) continue; // (a zero-length op adds no unit)
-                const uint32_t opc = rb_opc(ops[i]);
+                if (rb_wlen(ops, i) == 0) continue; // (a zero-length op adds no unit)
+                const uint32_t opc = rb_wopc(ops, i);
                 wrapped = !(opc <= 8 && rb_in(RB_REF_MASK, opc));
                 break;
             }
@@ -1212,7 +1212,7 @@ __device__ void rb_generic_serial_hit(const rb_lift_params &p, const uint64_t g)
             uint64_t U = 0, R = 0, Q = 0, M = 0;
             bool a_set = false;
             for (uint32_t i = 0; i < n; i++) {
-                const uint32_t opc = rb_opc(ops[i]), len = rb_len(ops[i]);
+                const uint32_t opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 if (len == 0) continue;
                 const bool isref = opc <= 8 && rb_in(RB_REF_MASK, opc), isq = opc <= 8 && rb_in(RB_QRY_MASK, opc);
                 const bool ism = opc <= 8 && rb_in(RB_MATCH_MASK, opc);
@@ -1245,20 +1245,26 @@ __device__ void rb_generic_serial_hit(const rb_lift_params &p, const uint64_t g)
             continue;
         }
         // pass 3: count run-length-merged ops of units [a, b] (paf.rs:602-620)
-        uint32_t out_n = 0;
+        uint32_t out_n = 0; // (in words: a merged run of 2^28 bases and more takes two)
         {
             uint64_t U = 0;
-            uint32_t prev = RB_NULL_OP;
+            uint32_t prev = RB_NULL_OP, run = 0;
             for (uint32_t i = 0; i < n; i++) {
-                const uint32_t opc = rb_opc(ops[i]), len = rb_len(ops[i]);
+                const uint32_t opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 if (len == 0) continue;
                 const uint64_t u0 = U, u1 = U + len - 1;
                 U += len;
                 if (u1 < a) continue;
                 if (u0 > b) break;
-                if (opc != prev) out_n++;
+                const uint64_t c0 = u0 > a ? u0 : a, c1 = u1 < b ? u1 : b;
+                if (opc != prev) {
+                    if (prev != RB_NULL_OP) out_n += 1u + ((run >> RB_LEN_BITS_WORD) ? 1u : 0u);
+                    run = 0;
+                }
+                run += (uint32_t)(c1 - c0 + 1);
                 prev = opc;
             }
+            if (prev != RB_NULL_OP) out_n += 1u + ((run >> RB_LEN_BITS_WORD) ? 1u : 0u);
         }
         w.t_st = t_st + Ra; // liftover.rs:57-60, :77-82 (a and b are match-type units)
         w.t_en = t_st + nRb;
@@ -1285,7 +1291,7 @@ __device__ void rb_generic_serial_hit(const rb_lift_params &p, const uint64_t g)
             uint32_t prev = RB_NULL_OP, run = 0;
             uint64_t o = w.out_off;
             for (uint32_t i = 0; i < n; i++) {
-                const uint32_t opc = rb_opc(ops[i]), len = rb_len(ops[i]);
+                const uint32_t opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 if (len == 0) continue;
                 const uint64_t u0 = U, u1 = U + len - 1;
                 U += len;
@@ -1294,14 +1300,14 @@ __device__ void rb_generic_serial_hit(const rb_lift_params &p, const uint64_t g)
                 const uint64_t c0 = u0 > a ? u0 : a, c1 = u1 < b ? u1 : b;
                 const uint32_t piece = (uint32_t)(c1 - c0 + 1);
                 if (opc != prev) {
-                    if (prev != RB_NULL_OP) p.out_ops[o++] = (run << 4) | prev;
+                    if (prev != RB_NULL_OP) o += rb_emit_run(p.out_ops + o, run, prev);
                     prev = opc;
                     run = piece;
                 } else {
                     run += piece;
                 }
             }
-            if (prev != RB_NULL_OP) p.out_ops[o++] = (run << 4) | prev;
+            if (prev != RB_NULL_OP) o += rb_emit_run(p.out_ops + o, run, prev);
         }
         *row = w;
     }
@@ -1403,7 +1409,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
             const uint32_t wv = i < n ? ops[i] : 0u;
-            const uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
+            uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
+            if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i); // (walk form: one more op of its owner's type)
             const bool isref = opc <= 8u && rb_in(RB_REF_MASK, opc);
             const uint32_t iu = rb_wave_scan_incl(len), ir = rb_wave_scan_incl(isref ? len : 0u);
             if (!first_seen) {
@@ -1457,7 +1464,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
                 if (a_set && U0 > ke) break; // (nothing behind this can be <= ke)
                 const uint32_t i = c0 + (uint32_t)lane;
                 const uint32_t wv = i < n ? ops[i] : 0u;
-                const uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
+                uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
+                if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 const bool okc = opc <= 8u;
                 const bool isref = okc && rb_in(RB_REF_MASK, opc), isq = okc && rb_in(RB_QRY_MASK, opc), ism = okc && rb_in(RB_MATCH_MASK, opc);
                 const uint32_t iu = rb_wave_scan_incl(len), ir = rb_wave_scan_incl(isref ? len : 0u), iq = rb_wave_scan_incl(isq ? len : 0u),
@@ -1504,7 +1512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         w.aln_len = (uint32_t)(b - a + 1);
         // ---- pass 3: ops ia .. ib, zero lengths dropped, first / last cut, runs of one type merged ----
         uint64_t off;
-        if (!reserve((ib - ia + 1u + 3u) & ~3u, &off)) { // (at least as many slots as the merge leaves)
+        if (!reserve((ib - ia + 2u + 3u) & ~3u, &off)) { // (at least as many slots as the merge leaves; + 1: a clip that begins in the bases of a continuation word)
             if (lane == 0) *row = w;
             continue;
         }
@@ -1513,7 +1521,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         for (uint32_t c0 = ia & ~63u; c0 <= ib; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
             const uint32_t wv = (i >= ia && i <= ib) ? ops[i] : 0u;
-            const uint32_t opc = rb_opc(wv), len = rb_len(wv);
+            uint32_t opc = rb_opc(wv), len = rb_len(wv);
+            if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
             const bool in = i >= ia && i <= ib && len != 0u;
             uint32_t piece = len;
             if (i == ia) piece = ia == ib ? (uint32_t)(b - a + 1) : (uint32_t)(Ua_op + len_a - a);
@@ -1536,21 +1545,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             c_tot += rb_wave_sum_u32((in && ridx < 0) ? piece : 0u);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (nstarts) {
+            if (nstarts) { // (runs of 2^28 bases and more leave as two words: rb_emit_run)
                 if (has_carry) {
-                    if (lane == 0) p.out_ops[off + out_pos] = (c_tot << 4) | c_opc;
-                    out_pos++;
+                    const uint32_t cw = 1u + ((c_tot >> RB_LEN_BITS_WORD) ? 1u : 0u);
+                    if (lane == 0) rb_emit_run(p.out_ops + off + out_pos, c_tot, c_opc);
+                    out_pos += cw;
                 }
-                if ((uint32_t)lane + 1u < nstarts) p.out_ops[off + out_pos + (uint32_t)lane] = (run_tot[lane] << 4) | run_opc[lane];
-                out_pos += nstarts - 1u;
+                const bool mine_out = (uint32_t)lane + 1u < nstarts;
+                const uint32_t my_tot = mine_out ? run_tot[lane] : 0u;
+                const uint32_t my_words = mine_out ? 1u + ((my_tot >> RB_LEN_BITS_WORD) ? 1u : 0u) : 0u;
+                const uint32_t wincl = rb_wave_scan_incl(my_words);
+                if (mine_out) rb_emit_run(p.out_ops + off + out_pos + (wincl - my_words), my_tot, run_opc[lane]);
+                out_pos += rb_readlane<uint32_t>(wincl, 63);
                 c_tot = run_tot[nstarts - 1u], c_opc = run_opc[nstarts - 1u];
                 has_carry = true;
             }
             __builtin_amdgcn_wave_barrier();
         }
         if (has_carry) {
-            if (lane == 0) p.out_ops[off + out_pos] = (c_tot << 4) | c_opc;
-            out_pos++;
+            if (lane == 0) rb_emit_run(p.out_ops + off + out_pos, c_tot, c_opc);
+            out_pos += 1u + ((c_tot >> RB_LEN_BITS_WORD) ? 1u : 0u);
         }
         w.out_n = out_pos;
         w.out_off = off;

@@ -77,6 +77,7 @@ __device__ void rb_break_pieces_record(const rb_break_params &p, uint64_t wave, 
         return *reinterpret_cast<const uint4 *>(gbase + off);
     };
     uint32_t Rb = 0, pre = 0, cnt = 0; // ref bases so far, end of the last big indel, pieces so far
+    uint32_t carry_last = RB_NULL_OP;  // last word of the step before
     uint4 pf[2][2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -96,12 +97,42 @@ __device__ void rb_break_pieces_record(const rb_break_params &p, uint64_t wave, 
                 uint32_t rl[8], Rx[8];
                 bool big[8];
                 uint32_t sr = 0;
+                bool cont_here = false;
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const bool valid = !edge || (uint32_t)(idx0 + q) < n;
                     const uint32_t opc = valid ? rb_opc(raw[q]) : RB_NULL_OP, len = valid ? rb_len(raw[q]) : 0u;
                     rl[q] = (opc <= 8u && rb_in(RB_REF_MASK, opc)) ? len : 0u;
                     big[q] = valid && (opc == RB_OP_I || opc == RB_OP_D) && len > p.max_size;
+                    cont_here |= opc == RB_OP_CONT;
+                }
+                // continuation words (lengths of 2^28 and more, rb_device.h): the word walks as `hi << 28` more bases of its owner's
+                // type, and an indel is long by its WHOLE length (liftover.rs:187-188) -- owner and continuation are marked together.
+                // The word behind this step's last one is the first of the step already waiting in the ring.
+                const uint32_t next_step_first = rb_readlane<uint32_t>(pf[ring ^ 1][0].x, 0);
+                const uint32_t step_last = rb_readlane<uint32_t>(raw[7], 63);
+                if (__ballot(cont_here) != 0ull || rb_opc(next_step_first) == RB_OP_CONT) {
+                    const uint32_t prev_last = rb_prev_lane(raw[7], carry_last);
+                    uint32_t next_first = (uint32_t)__shfl_down((int)raw[0], 1, 64);
+                    if (lane == 63) next_first = next_step_first;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const uint32_t i = (uint32_t)(idx0 + q);
+                        const bool valid = i < n;
+                        const uint32_t w = raw[q], c = rb_opc(w);
+                        const uint32_t pw = q ? raw[q > 0 ? q - 1 : 0] : prev_last, nw = q < 7 ? raw[q < 7 ? q + 1 : 7] : next_first;
+                        if (valid && c == RB_OP_CONT && i >= 1u && rb_opc(pw) <= 8u) {
+                            const uint32_t type = rb_opc(pw), hi = (rb_len(w) & 15u) << RB_LEN_BITS_WORD;
+                            rl[q] = rb_in(RB_REF_MASK, type) ? hi : 0u;
+                            big[q] = (type == RB_OP_I || type == RB_OP_D) && rb_len(pw) + hi > p.max_size;
+                        } else if (valid && (c == RB_OP_I || c == RB_OP_D) && i + 1u < n && rb_opc(nw) == RB_OP_CONT) {
+                            big[q] = rb_len(w) + ((rb_len(nw) & 15u) << RB_LEN_BITS_WORD) > p.max_size;
+                        }
+                    }
+                }
+                carry_last = step_last;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
                     Rx[q] = sr;
                     sr += rl[q];
                 }
@@ -246,7 +277,15 @@ __global__ __launch_bounds__(256) void rb_k_swap(rb_swap_params p) {
     const uint64_t o0 = p.op_off[wave], n = p.op_off[wave + 1] - o0;
     const bool minus = p.strand[wave] == (uint8_t)'-';
     for (uint64_t j = rb_lane(); j < n; j += 64) {
-        uint32_t v = p.ops[o0 + (minus ? n - 1 - j : j)];
+        const uint64_t src = minus ? n - 1 - j : j;
+        uint32_t v = p.ops[o0 + src];
+        if (minus) { // an op and its continuation word (rb_device.h) keep their order when the ops are reversed
+            if (rb_opc(v) == RB_OP_CONT) {
+                if (src > 0 && rb_opc(p.ops[o0 + src - 1]) != RB_OP_CONT) v = p.ops[o0 + src - 1];
+            } else if (src + 1 < n && rb_opc(p.ops[o0 + src + 1]) == RB_OP_CONT) {
+                v = p.ops[o0 + src + 1];
+            }
+        }
         const uint32_t opc = rb_opc(v);
         if (opc == RB_OP_I) v = (v & ~15u) | RB_OP_D;
         else if (opc == RB_OP_D) v = (v & ~15u) | RB_OP_I;

@@ -40,8 +40,10 @@ __device__ __forceinline__ rb_strip rb_strip_ends(const uint32_t *ops, uint64_t 
     uint64_t lead = 0, rm_st_t = 0, rm_st_q = 0;
     uint32_t prev = RB_NULL_OP;
     o.dR = o.dQ = 0;
-    while (lead < n && rb_in(RB_INDEL_MASK, rb_opc(ops[lead]))) { // paf.rs:663-701 leading run
-        const uint32_t opc = rb_opc(ops[lead]), len = rb_len(ops[lead]);
+    while (lead < n) { // paf.rs:663-701 leading run (an op with its continuation word is ONE op here: the quirks count ops)
+        uint32_t opc, len;
+        const uint32_t words = rb_op_fwd(ops, n, lead, &opc, &len);
+        if (!rb_in(RB_INDEL_MASK, opc)) break;
         if (opc == RB_OP_D) {
             rm_st_t += len;
             rm_st_q += 1; // :673
@@ -55,11 +57,13 @@ __device__ __forceinline__ rb_strip rb_strip_ends(const uint32_t *ops, uint64_t 
             rm_st_q -= 1;
         }
         prev = opc;
-        lead++;
+        lead += words;
     }
     uint64_t trail = 0, rm_en_t = 0, rm_en_q = 0;
-    while (trail < n && rb_in(RB_INDEL_MASK, rb_opc(ops[n - 1 - trail]))) { // :704-723
-        const uint32_t opc = rb_opc(ops[n - 1 - trail]), len = rb_len(ops[n - 1 - trail]);
+    while (trail < n) { // :704-723
+        uint32_t opc, len;
+        const uint32_t words = rb_op_bwd(ops, n - 1 - trail, &opc, &len);
+        if (!rb_in(RB_INDEL_MASK, opc)) break;
         if (opc == RB_OP_D) {
             rm_en_t += len;
             if (lead + trail < n) o.dR += len; // (an all-indel record is reported, its sums are not used)
@@ -67,7 +71,7 @@ __device__ __forceinline__ rb_strip rb_strip_ends(const uint32_t *ops, uint64_t 
             rm_en_q += len;
             if (lead + trail < n) o.dQ += len;
         }
-        trail++;
+        trail += words;
     }
     o.lead = (uint32_t)lead;
     o.trail = (uint32_t)trail;
@@ -192,6 +196,10 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
                             } else {
                                 v_big |= 8u;
+                                // a continuation word: bits 28.. of the length of the op in front of it (no event of its own)
+                                if (opc == RB_OP_CONT && (prevw & 15u) <= 8u)
+                                    __hip_atomic_fetch_add(&hist[prevw & 15u][my_hist], (unsigned long long)(len & 15u) << RB_LEN_BITS_WORD, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WORKGROUP);
                             }
                             v_reg &= (uint32_t)__builtin_amdgcn_sbfe((int)0x018F018Fu, w, 1u); // M I D N = X
                             v_minlen = v_minlen < len ? v_minlen : len;

@@ -46,15 +46,15 @@ struct rb_qstream {
     __device__ int32_t score_of(uint32_t opc) const { // trim_overlap.rs:14-18
         return opc == RB_OP_EQ ? ms : ((opc == RB_OP_I || opc == RB_OP_D) ? -is : -ds);
     }
-    __device__ bool is_q(int32_t j) const { return rb_len(v.ops[j]) != 0 && rb_s_qry(rb_opc(v.ops[j])); }
+    __device__ bool is_q(int32_t j) const { return rb_wlen(v.ops, (uint32_t)j) != 0 && rb_s_qry(rb_wopc(v.ops, (uint32_t)j)); }
 
     // op code of the unit that qpos_to_idx returns for the LAST unit (in op order) of op i
     __device__ uint32_t special_type() const {
-        const uint32_t own = rb_opc(v.ops[i]);
+        const uint32_t own = rb_wopc(v.ops, (uint32_t)i);
         uint64_t runU = 0;
         uint32_t last = own;
         for (uint32_t j = (uint32_t)i + 1; j < v.n; j++) {
-            const uint32_t opc = rb_opc(v.ops[j]), len = rb_len(v.ops[j]);
+            const uint32_t opc = rb_wopc(v.ops, (uint32_t)j), len = rb_wlen(v.ops, (uint32_t)j);
             if (len == 0) continue;
             if (rb_s_qry(opc)) break;
             runU += len;
@@ -62,12 +62,12 @@ struct rb_qstream {
         }
         if (runU == 0) return own;
         if (policy != RB_BSEARCH_LEGACY) return last; // modern: last equal element
-        const uint64_t klo = U + rb_len(v.ops[i]) - 1;
+        const uint64_t klo = U + rb_wlen(v.ops, (uint32_t)i) - 1;
         const uint64_t k = rb_s_legacy_probe(N, klo, klo + runU);
         if (k == klo) return own;
         uint64_t u = klo + 1;
         for (uint32_t j = (uint32_t)i + 1; j < v.n; j++) {
-            const uint32_t opc = rb_opc(v.ops[j]), len = rb_len(v.ops[j]);
+            const uint32_t opc = rb_wopc(v.ops, (uint32_t)j), len = rb_wlen(v.ops, (uint32_t)j);
             if (len == 0) continue;
             if (k < u + len) return opc;
             u += len;
@@ -78,24 +78,24 @@ struct rb_qstream {
     __device__ void next_op() { // move to the op with the next higher query positions
         const uint64_t base = hi + 1;
         if (!v.minus) {
-            U += rb_len(v.ops[i]);
+            U += rb_wlen(v.ops, (uint32_t)i);
             i++;
             while (i < (int32_t)v.n && !is_q(i)) {
-                U += rb_len(v.ops[i]);
+                U += rb_wlen(v.ops, (uint32_t)i);
                 i++;
             }
             if (i >= (int32_t)v.n) return;
         } else {
             i--;
             while (i >= 0 && !is_q(i)) {
-                U -= rb_len(v.ops[i]);
+                U -= rb_wlen(v.ops, (uint32_t)i);
                 i--;
             }
             if (i < 0) return;
-            U -= rb_len(v.ops[i]);
+            U -= rb_wlen(v.ops, (uint32_t)i);
         }
         lo = base;
-        hi = base + rb_len(v.ops[i]) - 1;
+        hi = base + rb_wlen(v.ops, (uint32_t)i) - 1;
     }
 
     __device__ void seek(uint64_t p) {
@@ -103,21 +103,21 @@ struct rb_qstream {
             i = 0;
             U = 0;
             while (i < (int32_t)v.n && !is_q(i)) {
-                U += rb_len(v.ops[i]);
+                U += rb_wlen(v.ops, (uint32_t)i);
                 i++;
             }
         } else {
             i = (int32_t)v.n - 1;
             U = N;
             while (i >= 0 && !is_q(i)) {
-                U -= rb_len(v.ops[i]);
+                U -= rb_wlen(v.ops, (uint32_t)i);
                 i--;
             }
-            if (i >= 0) U -= rb_len(v.ops[i]);
+            if (i >= 0) U -= rb_wlen(v.ops, (uint32_t)i);
         }
         if (i < 0 || i >= (int32_t)v.n) return;
         lo = v.q_st;
-        hi = lo + rb_len(v.ops[i]) - 1;
+        hi = lo + rb_wlen(v.ops, (uint32_t)i) - 1;
         while (p > hi && i >= 0 && i < (int32_t)v.n) next_op();
         pos = p;
     }
@@ -126,7 +126,7 @@ struct rb_qstream {
 
     // current run of equal scores starting at pos
     __device__ void run(uint64_t *count, int32_t *score) const {
-        const uint32_t own = rb_opc(v.ops[i]);
+        const uint32_t own = rb_wopc(v.ops, (uint32_t)i);
         if (!v.minus) {
             if (pos < hi) {
                 *count = hi - pos;

@@ -20,6 +20,52 @@ __device__ __forceinline__ uint32_t rb_opc(uint32_t v) { return v & 15u; }
 __device__ __forceinline__ uint32_t rb_len(uint32_t v) { return v >> 4; }
 __device__ __forceinline__ bool rb_in(uint32_t mask, uint32_t opc) { return (mask >> opc) & 1u; }
 
+// Lengths of 2^28 and more (a rust-htslib Cigar holds a u32) take TWO words: (len & (2^28 - 1)) << 4 | op, then the continuation
+// word (len >> 28) << 4 | RB_OP_CONT (include/rustybam_amd.h, "packed ops").  A record that holds one is not "regular": only the
+// general kernels ever see the word, and they WALK it as one more op of its owner's type with the length payload << 28 -- to the
+// reference's per-base arrays an op and the same op cut in two are the same thing, and every general kernel merges neighbours of
+// one type on the way out anyway (paf.rs:602-620).  Where the op itself counts and not its bases (the end-indel strip and its
+// quirks, the indel events of stats, the long indels of break-paf, invert) the owner and its continuation are taken together.
+#define RB_LEN_BITS_WORD 28
+#define RB_LEN_MASK_WORD 0x0FFFFFFFu
+// walk form of word i of a record's op array (i counts from the array's first word; a continuation word has an owner in front)
+__device__ __forceinline__ uint32_t rb_wopc(const uint32_t *ops, uint32_t i) {
+    const uint32_t c = ops[i] & 15u;
+    return c == RB_OP_CONT ? (i ? ops[i - 1u] & 15u : RB_NULL_OP) : c;
+}
+__device__ __forceinline__ uint32_t rb_wlen(const uint32_t *ops, uint32_t i) {
+    const uint32_t w = ops[i];
+    return (w & 15u) == RB_OP_CONT ? ((w >> 4) & 15u) << RB_LEN_BITS_WORD : w >> 4;
+}
+// the op that STARTS at word i of ops[0 .. n) / that ENDS at word i: code, whole length; returns the words it takes (1 or 2)
+__device__ __forceinline__ uint32_t rb_op_fwd(const uint32_t *ops, uint64_t n, uint64_t i, uint32_t *opc, uint32_t *len) {
+    const uint32_t w = ops[i];
+    *opc = w & 15u, *len = w >> 4;
+    if (*opc != RB_OP_CONT && i + 1 < n && (ops[i + 1] & 15u) == RB_OP_CONT) {
+        *len += ((ops[i + 1] >> 4) & 15u) << RB_LEN_BITS_WORD;
+        return 2u;
+    }
+    return 1u;
+}
+__device__ __forceinline__ uint32_t rb_op_bwd(const uint32_t *ops, uint64_t i, uint32_t *opc, uint32_t *len) {
+    const uint32_t w = ops[i];
+    if ((w & 15u) == RB_OP_CONT && i > 0 && (ops[i - 1] & 15u) != RB_OP_CONT) {
+        *opc = ops[i - 1] & 15u, *len = (ops[i - 1] >> 4) + (((w >> 4) & 15u) << RB_LEN_BITS_WORD);
+        return 2u;
+    }
+    *opc = w & 15u, *len = w >> 4;
+    return 1u;
+}
+// a run of `len` bases of type `opc` as words at out[0..]: returns how many (1 or 2)
+__device__ __forceinline__ uint32_t rb_emit_run(uint32_t *out, uint32_t len, uint32_t opc) {
+    out[0] = ((len & RB_LEN_MASK_WORD) << 4) | opc;
+    if (len >> RB_LEN_BITS_WORD) {
+        out[1] = ((len >> RB_LEN_BITS_WORD) << 4) | RB_OP_CONT;
+        return 2u;
+    }
+    return 1u;
+}
+
 __device__ __forceinline__ int rb_lane() { return (int)(threadIdx.x & 63u); }
 
 template <typename T>

@@ -21,7 +21,7 @@ __device__ __forceinline__ bool rb_s_match(uint32_t opc) { return opc <= 8u && r
 
 __device__ inline uint64_t rb_s_units(const rb_sview &v) {
     uint64_t N = 0;
-    for (uint32_t i = 0; i < v.n; i++) N += rb_len(v.ops[i]);
+    for (uint32_t i = 0; i < v.n; i++) N += rb_wlen(v.ops, i);
     return N;
 }
 
@@ -49,7 +49,7 @@ __device__ inline bool rb_s_qrange(const rb_sview &v, uint64_t p, uint64_t *klo,
     int64_t qpos = v.minus ? (int64_t)v.q_en : (int64_t)v.q_st - 1;
     const int64_t pp = (int64_t)p;
     for (uint32_t i = 0; i < v.n; i++) {
-        const uint32_t opc = rb_opc(v.ops[i]), len = rb_len(v.ops[i]);
+        const uint32_t opc = rb_wopc(v.ops, i), len = rb_wlen(v.ops, i);
         if (len == 0) continue;
         if (rb_s_qry(opc)) {
             if (!v.minus) {
@@ -85,7 +85,7 @@ __device__ inline void rb_s_unit(const rb_sview &v, uint64_t k, uint32_t *opc_ou
     int64_t tpos = (int64_t)v.t_st - 1;
     int64_t qpos = v.minus ? (int64_t)v.q_en : (int64_t)v.q_st - 1;
     for (uint32_t i = 0; i < v.n; i++) {
-        const uint32_t opc = rb_opc(v.ops[i]), len = rb_len(v.ops[i]);
+        const uint32_t opc = rb_wopc(v.ops, i), len = rb_wlen(v.ops, i);
         if (len == 0) continue;
         const bool r = rb_s_ref(opc), q = rb_s_qry(opc);
         if (k < U + len) {
@@ -110,8 +110,8 @@ __device__ inline void rb_s_unit(const rb_sview &v, uint64_t k, uint32_t *opc_ou
 __device__ inline bool rb_s_wrapped_q(const rb_sview &v) {
     if (v.minus || v.q_st != 0) return false;
     for (uint32_t i = 0; i < v.n; i++) {
-        if (rb_len(v.ops[i]) == 0) continue;
-        return !rb_s_qry(rb_opc(v.ops[i]));
+        if (rb_wlen(v.ops, i) == 0) continue;
+        return !rb_s_qry(rb_wopc(v.ops, i));
     }
     return false;
 }
@@ -154,7 +154,7 @@ __device__ inline bool rb_s_bsearch_q(const rb_sview &v, uint64_t N, uint64_t ke
 __device__ inline uint64_t rb_s_match_ge(const rb_sview &v, uint64_t k, uint64_t N) {
     uint64_t U = 0;
     for (uint32_t i = 0; i < v.n; i++) {
-        const uint32_t opc = rb_opc(v.ops[i]), len = rb_len(v.ops[i]);
+        const uint32_t opc = rb_wopc(v.ops, i), len = rb_wlen(v.ops, i);
         if (len == 0) continue;
         if (rb_s_match(opc) && U + len > k) return k > U ? k : U;
         U += len;
@@ -165,7 +165,7 @@ __device__ inline uint64_t rb_s_match_ge(const rb_sview &v, uint64_t k, uint64_t
 __device__ inline uint64_t rb_s_match_le(const rb_sview &v, uint64_t k) {
     uint64_t U = 0, best = 0;
     for (uint32_t i = 0; i < v.n; i++) {
-        const uint32_t opc = rb_opc(v.ops[i]), len = rb_len(v.ops[i]);
+        const uint32_t opc = rb_wopc(v.ops, i), len = rb_wlen(v.ops, i);
         if (len == 0) continue;
         if (U > k) break;
         if (rb_s_match(opc)) best = (U + len - 1) < k ? (U + len - 1) : k;
@@ -181,7 +181,7 @@ __device__ inline uint32_t rb_s_emit_units(const rb_sview &v, uint64_t a, uint64
     uint32_t prev = RB_NULL_OP, run = 0, cnt = 0;
     sums[0] = sums[1] = sums[2] = sums[3] = 0;
     for (uint32_t i = 0; i < v.n; i++) {
-        const uint32_t opc = rb_opc(v.ops[i]), len = rb_len(v.ops[i]);
+        const uint32_t opc = rb_wopc(v.ops, i), len = rb_wlen(v.ops, i);
         if (len == 0) continue;
         const uint64_t u0 = U, u1 = U + len - 1;
         U += len;
@@ -194,14 +194,14 @@ __device__ inline uint32_t rb_s_emit_units(const rb_sview &v, uint64_t a, uint64
         if (rb_s_match(opc)) sums[2] += piece;
         sums[3] += piece;
         if (opc != prev) {
-            if (prev != RB_NULL_OP) out[cnt++] = (run << 4) | prev;
+            if (prev != RB_NULL_OP) cnt += rb_emit_run(out + cnt, run, prev);
             prev = opc;
             run = piece;
         } else {
             run += piece;
         }
     }
-    if (prev != RB_NULL_OP) out[cnt++] = (run << 4) | prev;
+    if (prev != RB_NULL_OP) cnt += rb_emit_run(out + cnt, run, prev);
     return cnt;
 }
 
@@ -212,8 +212,10 @@ __device__ inline uint32_t rb_s_strip_indels(const uint32_t *ops, uint32_t n, bo
     if (n == 0) return RB_ST_PANIC_EMPTY_CIGAR;
     uint64_t lead = 0, rm_st_t = 0, rm_st_q = 0;
     uint32_t prev = RB_NULL_OP;
-    while (lead < n && rb_in(RB_INDEL_MASK, rb_opc(ops[lead]))) {
-        const uint32_t opc = rb_opc(ops[lead]), len = rb_len(ops[lead]);
+    while (lead < n) {
+        uint32_t opc, len;
+        const uint32_t words = rb_op_fwd(ops, n, lead, &opc, &len);
+        if (!rb_in(RB_INDEL_MASK, opc)) break;
         if (opc == RB_OP_D) {
             rm_st_t += len;
             rm_st_q += 1;
@@ -225,13 +227,15 @@ __device__ inline uint32_t rb_s_strip_indels(const uint32_t *ops, uint32_t n, bo
             rm_st_q -= 1;
         }
         prev = opc;
-        lead++;
+        lead += words;
     }
     uint64_t trail = 0, rm_en_t = 0, rm_en_q = 0;
-    while (trail < n && rb_in(RB_INDEL_MASK, rb_opc(ops[n - 1 - trail]))) {
-        const uint32_t opc = rb_opc(ops[n - 1 - trail]), len = rb_len(ops[n - 1 - trail]);
+    while (trail < n) {
+        uint32_t opc, len;
+        const uint32_t words = rb_op_bwd(ops, n - 1 - trail, &opc, &len);
+        if (!rb_in(RB_INDEL_MASK, opc)) break;
         if (opc == RB_OP_D) rm_en_t += len; else rm_en_q += len;
-        trail++;
+        trail += words;
     }
     if (lead + trail > n) return RB_ST_PANIC_ALL_INDEL;
     *t_st += rm_st_t;
@@ -245,7 +249,7 @@ __device__ inline uint32_t rb_s_strip_indels(const uint32_t *ops, uint32_t n, bo
     *q_en -= rm_en_q;
     uint64_t R = 0, Q = 0, M = 0, U = 0;
     for (uint64_t i = lead; i < n - trail; i++) {
-        const uint32_t opc = rb_opc(ops[i]), len = rb_len(ops[i]);
+        const uint32_t opc = rb_wopc(ops, (uint32_t)i), len = rb_wlen(ops, (uint32_t)i);
         if (rb_s_ref(opc)) R += len;
         if (rb_s_qry(opc)) Q += len;
         if (rb_s_match(opc)) M += len;

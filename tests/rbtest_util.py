@@ -10,15 +10,33 @@ QRY = {0, 1, 4, 7, 8}
 CG_RE = re.compile(rb"(\d+)([MIDNSHP=X])")
 
 
+CONT = 14  # continuation word (include/rustybam_amd.h): bits 28.. of the length of the op in front of it
+
+
 def pack(cigar):
-    """'4M1I' -> uint32 array"""
+    """'4M1I' -> uint32 array of packed words (a length of 2^28 and more takes two)"""
     if isinstance(cigar, str):
         cigar = cigar.encode()
-    return np.array([(int(n) << 4) | OPC[c.decode()] for n, c in CG_RE.findall(cigar)], dtype=np.uint32)
+    out = []
+    for n, c in CG_RE.findall(cigar):
+        n = int(n)
+        out.append(((n & 0x0FFFFFFF) << 4) | OPC[c.decode()])
+        if n >> 28:
+            out.append(((n >> 28) << 4) | CONT)
+    return np.array(out, dtype=np.uint32)
 
 
 def unpack(ops):
-    return "".join(f"{int(v) >> 4}{OPCH[int(v) & 15]}" for v in ops)
+    out, i, n = [], 0, len(ops)
+    while i < n:
+        v = int(ops[i])
+        ln = v >> 4
+        if i + 1 < n and (int(ops[i + 1]) & 15) == CONT and (v & 15) != CONT:
+            ln += ((int(ops[i + 1]) >> 4) & 15) << 28
+            i += 1
+        out.append(f"{ln}{OPCH[v & 15] if (v & 15) < 9 else '?'}")
+        i += 1
+    return "".join(out)
 
 
 class Recs:
