@@ -217,12 +217,13 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
     }
 }
 
-// decimal digits of v (v < 2^28: at most 9)
+// decimal digits of v (at most 10; ten only for an op with a continuation word)
 __device__ __forceinline__ uint32_t rb_ndigits(uint32_t v) {
-    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u);
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) +
+           (v >= 1000000000u);
 }
 
-#define RB_FMT_STAGE (256 * 10 + 48) // bytes of text one step of 256 ops can make (9 digits + the op character each) + the 16-byte phase + 16 bytes of slack in front
+#define RB_FMT_STAGE (256 * 10 + 48) // bytes of text one step of 256 words can make (9 digits + the op character each; an op with a continuation word: 11 bytes for its two words) + the 16-byte phase + 16 bytes of slack in front
 // the four low decimal digits of x < 10000, least significant first, as one byte each of a dword: multiplications by constants that
 // fit 24 bits (v_mul_u32_u24: full rate; the per-digit x / 10 of round 2 was a v_mul_hi_u32 -- quarter rate -- per digit)
 __device__ __forceinline__ uint32_t rb_digits4(uint32_t x) {
@@ -270,17 +271,33 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
             for (int q = 0; q < 4; q++)
                 if (ib + (uint32_t)q < n) vv[q] = src[f0 + ib + (uint32_t)q];
         }
+        // continuation words (rb_device.h; only in what the general kernels wrote, never together with first_len / last_len): the
+        // word prints nothing, its owner prints the whole length.  The word behind this step's last one comes by a scalar load.
+        const uint32_t next_step_first = i0 + 256u < n ? src[f0 + i0 + 256u] : 0u;
+        bool cont_here = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) cont_here |= (vv[q] & 15u) == RB_OP_CONT;
+        uint32_t hi_of[4] = {0u, 0u, 0u, 0u}; // bits 28.. of my ops' lengths
+        if (__ballot(cont_here) != 0ull || (next_step_first & 15u) == RB_OP_CONT) {
+            uint32_t nxt = (uint32_t)__shfl_down((int)vv[0], 1, 64);
+            if (lane == 63) nxt = next_step_first;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t nw = q < 3 ? vv[q < 3 ? q + 1 : 3] : nxt;
+                if ((vv[q] & 15u) != RB_OP_CONT && ib + (uint32_t)q + 1u < n && (nw & 15u) == RB_OP_CONT) hi_of[q] = ((nw >> 4) & 15u) << RB_LEN_BITS_WORD;
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t i = i0 + (uint32_t)lane * 4u + (uint32_t)q;
             uint32_t v = vv[q];
-            uint32_t l = v >> 4;
+            uint32_t l = (v >> 4) + hi_of[q];
             if (n == 1u && fl && ll) l = fl + ll - l; // the middle of one op (liftover.rs via subset_cigar, paf.rs:593-620)
             else if (i == 0u && fl) l = fl;             // first op keeps its tail
             else if (i + 1u == n && ll) l = ll;         // last op keeps its head
             len[q] = l;
             opc[q] = v & 15u;
-            nb[q] = i < n ? rb_ndigits(l) + 1u : 0u;
+            nb[q] = (i < n && opc[q] != RB_OP_CONT) ? rb_ndigits(l) + 1u : 0u;
             mine += nb[q];
         }
         const uint32_t incl = rb_wave_scan_incl(mine);
@@ -308,14 +325,16 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
                     if (nd > 1u) tail[7] = (uint8_t)(d4 >> 8);
                     if (nd > 2u) tail[6] = (uint8_t)(d4 >> 16);
                     if (nd > 3u) tail[5] = (uint8_t)(d4 >> 24);
-                    if (big) { // digits 4..8 (rest < 26844)
-                        const uint32_t top = (uint32_t)(((uint64_t)rest * 3518437209ull) >> 45); // rest / 10000: the ninth digit (0..2)
+                    if (big) { // digits 4..9 (rest < 429497)
+                        const uint32_t top = (uint32_t)(((uint64_t)rest * 3518437209ull) >> 45); // rest / 10000: the ninth and tenth digit (0..42)
                         const uint32_t e4 = rb_digits4(rest - top * 10000u) | 0x30303030u;
                         tail[4] = (uint8_t)e4;
                         if (nd > 5u) tail[3] = (uint8_t)(e4 >> 8);
                         if (nd > 6u) tail[2] = (uint8_t)(e4 >> 16);
                         if (nd > 7u) tail[1] = (uint8_t)(e4 >> 24);
-                        if (nd > 8u) tail[0] = (uint8_t)(48u + top);
+                        const uint32_t t10 = (top * 103u) >> 10; // top / 10 (exact below 179)
+                        if (nd > 8u) tail[0] = (uint8_t)(48u + top - t10 * 10u);
+                        if (nd > 9u) stg[o] = (uint8_t)(48u + t10); // (the tenth digit: lengths of 10^9 and more)
                     }
                     o += nb[q];
                 }
