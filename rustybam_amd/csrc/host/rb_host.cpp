@@ -283,11 +283,27 @@ static void panic_on(uint32_t status, const char *what, size_t i) {
 }
 
 // the record after remove_trailing_indels: id gains _TO.<lead>.<trail> (paf.rs:726-732)
+// the last `count` words of a cigar, last OP first (the order remove_trailing_indels pops them in, paf.rs:704-723); an op and its
+// continuation word stay together
+static std::vector<uint32_t> popped_trail(const std::vector<uint32_t> &cig, uint32_t count) {
+    std::vector<uint32_t> t;
+    size_t i = cig.size(), left = count;
+    while (left > 0 && i > 0) {
+        if ((cig[i - 1] & 15u) == RB_OP_CONT && i >= 2 && left >= 2) {
+            t.push_back(cig[i - 2]);
+            t.push_back(cig[i - 1]);
+            i -= 2, left -= 2;
+        } else {
+            t.push_back(cig[i - 1]);
+            i--, left--;
+        }
+    }
+    return t;
+}
 static std::string stripped_id(const PafRecord &r, const rb_norm_row &nr) {
     if (!(nr.flags & RB_F_STRIPPED)) return r.id;
-    std::vector<uint32_t> lead(r.cigar.begin(), r.cigar.begin() + nr.lead_ops), trail;
-    for (uint32_t k = 0; k < nr.trail_ops; k++) trail.push_back(r.cigar[r.cigar.size() - 1 - k]);
-    return r.id + "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
+    std::vector<uint32_t> lead(r.cigar.begin(), r.cigar.begin() + nr.lead_ops);
+    return r.id + "_TO." + cigar_to_string(lead) + "." + cigar_to_string(popped_trail(r.cigar, nr.trail_ops));
 }
 
 // `rb --gpus N`: a worker process reads only its own lines of the (plain) input file -- bytes [begin, end), cut at line starts
@@ -1029,9 +1045,8 @@ struct TextFile {
         if (!(nr.flags & RB_F_STRIPPED)) return std::string();
         std::vector<uint32_t> cig;
         parse_cigar(all.data() + recs[r].cg, recs[r].cg_n, cig);
-        std::vector<uint32_t> lead(cig.begin(), cig.begin() + nr.lead_ops), trail;
-        for (uint32_t k = 0; k < nr.trail_ops; k++) trail.push_back(cig[cig.size() - 1 - k]);
-        return "_TO." + cigar_to_string(lead) + "." + cigar_to_string(trail);
+        std::vector<uint32_t> lead(cig.begin(), cig.begin() + nr.lead_ops);
+        return "_TO." + cigar_to_string(lead) + "." + cigar_to_string(popped_trail(cig, nr.trail_ops));
     }
 };
 } // namespace
@@ -1215,7 +1230,10 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
     }
     std::vector<uint64_t> cut{begin};
     std::vector<char> probe(1 << 16);
-    for (uint64_t at = begin + chunk; at < end; at += chunk) { // the first line start at or behind every multiple of the chunk size
+    // (RB_FIRST_CHUNK_MB: a smaller first chunk -- the writer has something to do sooner; measured, not the default: see profiles/r03_e2e.md)
+    const char *fe = getenv("RB_FIRST_CHUNK_MB");
+    const uint64_t first = fe ? std::min<uint64_t>(chunk, (uint64_t)std::max(1, atoi(fe)) << 20) : chunk;
+    for (uint64_t at = begin + first; at < end; at += chunk) { // the first line start at or behind every multiple of the chunk size
         uint64_t a = std::max(at, cut.back()) - 1;
         bool found = false;
         while (a < end && !found) {

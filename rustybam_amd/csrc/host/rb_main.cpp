@@ -72,6 +72,13 @@ static char g_obuf[1 << 22];
 // process that owns the end -- a single run, or the parent of `--gpus` before its workers write), the byte range is mapped, and
 // the segments are copied in by up to 32 threads.  The descriptor of a shell redirection is write-only, so the file is reopened
 // read-write through /proc/self/fd; false = not possible here (the caller falls back to pwrite).
+// writers of one regular file: ONE by default.  tools/shm_write_probe.c on the GPU box (16 GB into /dev/shm): 1 thread 5.85 GB/s,
+// 2: 4.5, 4: 6.0, 8: 3.3, 16: 4.4, 32: 4.2 (what this used to run with), 64: 4.9 -- a buffered write holds the inode lock, more
+// writers only queue for it.  RB_WRITE_THREADS overrides (a file system that does scale).
+static unsigned write_threads(size_t segments) {
+    static const unsigned want = getenv("RB_WRITE_THREADS") ? (unsigned)std::max(1, atoi(getenv("RB_WRITE_THREADS"))) : 1u;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(segments, want));
+}
 struct WSeg { const char *p; size_t n; off_t at; };
 static bool write_segments_mapped(const std::vector<WSeg> &segs, bool grow) {
     // MEASURED AND SHELVED (round 3, 19 GB into /dev/shm): the mapped route is 2x SLOWER than pwrite there (11.7 s against 5.3 s for the
@@ -96,7 +103,7 @@ static bool write_segments_mapped(const std::vector<WSeg> &segs, bool grow) {
     char *base = (char *)mmap(nullptr, (size_t)(hi - m0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, m0);
     close(fd);
     if (base == MAP_FAILED) return false;
-    const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 32));
+    const unsigned T = write_threads(segs.size());
     std::atomic<size_t> next{0};
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; t++)
@@ -124,8 +131,7 @@ static void put(const std::vector<std::string> &chunks, bool direct = false) { /
     off_t at = -1;
     if (fstat(1, &st) == 0 && S_ISREG(st.st_mode) && fl >= 0 && !(fl & O_APPEND)) at = lseek(1, 0, SEEK_CUR);
     if (at >= 0) {
-        // segments of at most 16 MB, up to 32 threads: what bounds the write of gigabytes into a page cache (tmpfs, or a file that is
-        // not on disk yet) is the kernel making the pages, which scales with the threads asking for them (8 threads: 5 GB/s)
+        // segments of at most 16 MB (write_threads() says by how many writers)
         std::vector<WSeg> segs;
         off_t o = at;
         for (const std::string &c : chunks)
@@ -138,7 +144,7 @@ static void put(const std::vector<std::string> &chunks, bool direct = false) { /
             lseek(1, o, SEEK_SET);
             return;
         }
-        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 32));
+        const unsigned T = write_threads(segs.size());
         std::vector<std::thread> th;
         std::vector<int> bad(T, 0);
         std::atomic<size_t> next{0};
@@ -366,7 +372,7 @@ bool recv_msg(int fd, MsgIn &m) {
         mapped = write_segments_mapped(ws, false);
     }
     if (g_worker.to_file && !mapped) {
-        const unsigned T = (unsigned)std::max<size_t>(1, std::min<size_t>(segs.size(), 32)); // (the page cache scales with the writers)
+        const unsigned T = write_threads(segs.size()); // (the page cache scales with the writers)
         std::vector<std::thread> th;
         std::vector<int> bad(T, 0);
         for (unsigned t = 0; t < T; t++)
@@ -680,13 +686,32 @@ static bool try_pipelined(int device, int policy, bool is_break, uint32_t max_si
         if (streaming && rb::pipeline_started())
             if (ftruncate(1, base) != 0 || lseek(1, base, SEEK_SET) != base) { perror("rb: cannot rewind the output"); _exit(1); }
     };
+    // MEASURED AND SHELVED (round 3): the pages of the output file made ahead of the writes (fallocate beyond the end of the file while
+    // the first chunk is still being computed: making the pages is a third of the cost of a write into a page cache -- fallocate 17 GB/s,
+    // pwrite into pages that exist 9 GB/s, pwrite that has to make them 5.9 GB/s, tools/shm_write_probe.c).  At the headline size the
+    // run got SLOWER, 5.5 s against 4.7 s: fallocate holds the inode lock the first writes then wait for.  Only with RB_PREALLOC=1.
+    off_t pre_len = 0;
+    std::thread pre;
+    struct stat si;
+    if (streaming && getenv("RB_PREALLOC") && stat(paf_path.c_str(), &si) == 0 && S_ISREG(si.st_mode) && si.st_size >= ((off_t)1 << 30)) {
+        pre_len = (off_t)((double)si.st_size * 1.35);
+        pre = std::thread([base, pre_len]() { (void)fallocate(1, FALLOC_FL_KEEP_SIZE, base, pre_len); });
+    }
+    auto give_back = [&]() { // (after the last write: the pages behind the end of the output)
+        if (pre.joinable()) pre.join();
+        if (pre_len <= 0) return;
+        const off_t end = lseek(1, 0, SEEK_CUR);
+        if (end >= 0 && end < base + pre_len) (void)fallocate(1, FALLOC_FL_PUNCH_HOLE | FALLOC_FL_KEEP_SIZE, end, base + pre_len - end);
+    };
     bool ok = false;
     try {
         ok = rb::lift_file_text_pipelined(device, policy, is_break, max_size, paf_path, rgns, sink);
     } catch (...) { // (a reference panic in a later chunk: the single run panics before it prints anything)
         rewind();
+        give_back();
         throw;
     }
+    give_back();
     if (ok && !violated) {
         if (!streaming) {
             if (acc.contigs.empty()) acc.contigs.push_back(std::string());

@@ -16,6 +16,7 @@ echo "synth: $(awk "BEGIN{print $t1 - $t0}") s, $(stat -c %s $d/w.paf) bytes" | 
 run() { # name, env..., -- args
   name=$1; shift
   for rep in 1 2; do
+    rm -f $d/out_$name.paf   # (the shell truncating 19 GB of an earlier run would be timed as part of this one)
     s=$(date +%s.%N)
     env RB_TIMING=1 "$@" > $d/out_$name.paf 2> gpurun_out/$tag/${name}_$rep.err
     rc=$?
@@ -25,6 +26,12 @@ run() { # name, env..., -- args
 }
 run pipelined $RB liftover --bed $d/w.bed $d/w.paf
 run whole RB_NO_PIPELINE=1 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_prealloc RB_PREALLOC=1 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_wr32 RB_WRITE_THREADS=32 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_w4_512 RB_PIPE_WORKERS=4 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_w5_512 RB_PIPE_WORKERS=5 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_w6_384 RB_PIPE_WORKERS=6 RB_CHUNK_MB=384 $RB liftover --bed $d/w.bed $d/w.paf
+run pipe_w4_first RB_PIPE_WORKERS=4 RB_FIRST_CHUNK_MB=64 $RB liftover --bed $d/w.bed $d/w.paf
 run pipe_w2 RB_PIPE_WORKERS=2 $RB liftover --bed $d/w.bed $d/w.paf
 run pipe_w4 RB_PIPE_WORKERS=4 RB_CHUNK_MB=256 $RB liftover --bed $d/w.bed $d/w.paf
 run gpus2_same RB_GPUS_SAME_DEVICE=1 $RB --gpus 2 liftover --bed $d/w.bed $d/w.paf
