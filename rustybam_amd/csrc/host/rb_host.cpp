@@ -1223,7 +1223,7 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
     uint64_t begin = 0, end = (uint64_t)st.st_size;
     if (g_sliced) begin = std::min<uint64_t>(g_slice_begin, end), end = std::min<uint64_t>(g_slice_end, end);
     const char *ce = getenv("RB_CHUNK_MB"), *ck = getenv("RB_CHUNK_KB"); // (KB: tests on the 2 MB fixture)
-    const uint64_t chunk = ck ? (uint64_t)std::max(1, atoi(ck)) << 10 : (uint64_t)std::max(1, ce ? atoi(ce) : 512) << 20;
+    const uint64_t chunk = ck ? (uint64_t)std::max(1, atoi(ck)) << 10 : (uint64_t)std::max(1, ce ? atoi(ce) : 384) << 20;
     if (end - begin < 2 * chunk) {
         close(fd);
         return false;
@@ -1261,7 +1261,9 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
     std::atomic<size_t> next{0};
     std::atomic<bool> stop{false};
     const char *we = getenv("RB_PIPE_WORKERS");
-    const unsigned W = (unsigned)std::min<size_t>(n_chunks, (size_t)std::max(1, we ? atoi(we) : 3));
+    // (2 workers: the run is bound by the ONE writer of the output file; the sweep of profiles/r03_e2e.md -- 1 to 6 workers, chunks of
+    //  256 MB to 1 GB -- ends within the noise of the box for everything from 1 worker up, and more workers only load the host)
+    const unsigned W = (unsigned)std::min<size_t>(n_chunks, (size_t)std::max(1, we ? atoi(we) : 2));
     std::vector<std::thread> workers;
     for (unsigned w = 0; w < W; w++)
         workers.emplace_back([&]() {
