@@ -230,10 +230,15 @@ def main():
     from rustybam_amd import capi as capi_mod
     lib_alloc = os.environ.get("RB_BENCH_TORCH_ALLOC") != "1"  # (diagnostics: the batch in torch's own allocations, as rounds 1 and 2)
 
+    alloc_note = []
+
     def big(n, dtype):  # -> (tensor, owner): the batch's large buffers
-        if lib_alloc:
-            b_ = capi_mod.DevBuf(eng, torch, n, dtype)
-            return b_.t, b_
+        if lib_alloc and not alloc_note:
+            try:
+                b_ = capi_mod.DevBuf(eng, torch, n, dtype, device=dev)
+                return b_.t, b_
+            except Exception as e:  # (torch could not take the library's memory for a tensor of this device: its own allocator then)
+                alloc_note.append(f"{type(e).__name__}: {e}")
         return torch.empty(n, dtype=dtype, device=dev), None
 
     d_ops, own_ops = big(total_ops + 64, torch.int32)
@@ -456,7 +461,8 @@ def main():
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
-                   "batch_memory": "rb_dev_alloc (2 MB physical chunks)" if lib_alloc else "torch allocator (hipMalloc)",
+                   "batch_memory": ("rb_dev_alloc (2 MB physical chunks)" if lib_alloc and not alloc_note else
+                                    "torch allocator (hipMalloc)" + (f"; rb_dev_alloc memory not usable as a tensor here: {alloc_note[0]}" if alloc_note else "")),
                    **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {}),
                    **({"irregular_frac": args.irregular_frac} if args.irregular_frac > 0 else {})},
         "paf_records_per_s": job_recs * args.steps / elapsed,

@@ -418,7 +418,7 @@ class DevBuf:
     DESIGN.md section 3), seen by torch through the CUDA array interface without a copy: `.t` is the tensor.  free() gives the
     memory back (before the engine is closed)."""
 
-    def __init__(self, eng, torch, n, dtype):
+    def __init__(self, eng, torch, n, dtype, device=None):
         self.eng, self.n, self.dtype = eng, int(n), dtype
         self.item = torch.empty(0, dtype=dtype).element_size()
         try:
@@ -427,7 +427,15 @@ class DevBuf:
             torch.cuda.empty_cache()                # (memory torch's caching allocator holds but does not use is not free to the driver)
             self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
         self.__cuda_array_interface__ = {"shape": (self.n * self.item,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
-        self.t = torch.as_tensor(self, device="cuda").view(dtype)
+        try:
+            self.t = torch.as_tensor(self, device=device if device is not None else "cuda").view(dtype)
+            if device is not None and self.t.device != torch.device(device):
+                raise RuntimeError(f"the buffer was taken for {self.t.device}, not {device}")
+        except Exception:
+            self.t = None
+            eng.dev_free(self.ptr)
+            self.ptr = 0
+            raise
 
     def free(self):
         if self.ptr:

@@ -145,7 +145,7 @@ class ResidentTrim:
         n_ops = int(op_off[-1])
         self.n_ops0 = n_ops
         cap = int(n_ops * (1.0 + room_factor)) + 4096
-        self._own = capi.DevBuf(eng, torch, cap + 64, torch.int32)          # [original ops | room for the clips of the passes], from the
+        self._own = capi.DevBuf(eng, torch, cap + 64, torch.int32, device=dev)         # [original ops | room for the clips of the passes], from the
         self.d_ops = self._own.t                                             # library's allocator (2 MB physical chunks: DESIGN.md section 3)
         self.d_ops[n_ops:].zero_()
         if isinstance(ops, np.ndarray):
