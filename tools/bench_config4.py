@@ -92,6 +92,7 @@ def main():
     T.release()
     torch.cuda.empty_cache()
     B.run(None, max_size=100, rows_cap=4 * n, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN | rustybam_amd.BREAK_ONE_WALK)  # sizing
+    B.last = None  # (the sizing run's buffers go back to torch's allocator: the timed run reuses them instead of asking the driver for 45 GB)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     rows, out, cnt = B.run(None, max_size=100, rows_cap=4 * n, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN | rustybam_amd.BREAK_ONE_WALK)
