@@ -103,6 +103,7 @@ struct rb_format_params {
     uint64_t *text_off;
     uint8_t *text;
     uint64_t text_cap;
+    int plain_ops;
 };
 extern "C" hipError_t rb_launch_parse_cigars(const rb_parse_params *p, bool fill, hipStream_t stream);
 extern "C" hipError_t rb_launch_format_cigars(const rb_format_params *p, bool fill, hipStream_t stream);
@@ -1067,9 +1068,10 @@ extern "C" int rb_dev_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint6
 // offsets_ready: text_off already holds the prefix of a sizes-only call on the same items (the host wrappers size, allocate, fill)
 static int format_cigars_impl(rb_ctx *ctx, const uint32_t *ops, const uint32_t *ops_alt, uint64_t n_items, const uint64_t *first,
                               const uint32_t *count, const uint32_t *first_len, const uint32_t *last_len, uint64_t *text_off,
-                              uint8_t *text, uint64_t text_cap, void *scratch, bool offsets_ready) {
+                              uint8_t *text, uint64_t text_cap, void *scratch, bool offsets_ready, bool plain_ops = false) {
     if (!ctx || !text_off || !scratch || (n_items && (!ops || !first || !count))) return RB_E_INVALID;
     rb_format_params p;
+    p.plain_ops = plain_ops ? 1 : 0; // (the caller knows that ops[] came out of rb_k_parse_cigars: no continuation words to look for)
     p.n_items = n_items;
     p.ops = ops;
     p.ops_alt = ops_alt;
@@ -1572,11 +1574,11 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
         if (!rc && nr) rc = rb_dev_upload(ctx, d_first, first.data(), (size_t)nr * 8);
         if (!rc && nr) rc = rb_dev_upload(ctx, d_cnt3, c3.data(), (size_t)nr * 12);
         if (!rc) rc = rb_ctx_sync(ctx);
-        if (!rc) rc = rb_dev_format_cigars(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, nullptr, 0, d_scr2);
+        if (!rc) rc = format_cigars_impl(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, nullptr, 0, d_scr2, false, true);
         if (!rc) rc = rb_dev_download(ctx, *row_text_off, d_toff, ((size_t)nr + 1) * 8);
         const uint64_t bytes = rc ? 0 : (*row_text_off)[nr];
         if (!rc) rc = b.alloc((size_t)bytes + 16, &d_rtext);
-        if (!rc) rc = format_cigars_impl(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, d_rtext, bytes, d_scr2, true);
+        if (!rc) rc = format_cigars_impl(ctx, d_ops, d_out, nr, d_first, d_cnt3, d_cnt3 + nr, d_cnt3 + 2 * nr, d_toff, d_rtext, bytes, d_scr2, true, true);
         if (!rc) {
             *row_text = (uint8_t *)malloc((size_t)bytes + 16);
             if (!*row_text) rc = fail(ctx, RB_E_NOMEM, "malloc(%llu text bytes)", (unsigned long long)bytes);

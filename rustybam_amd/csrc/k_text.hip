@@ -41,6 +41,7 @@ struct rb_format_params {
     uint64_t *text_off;        // [n_items + 1] counts / offsets
     uint8_t *text;
     uint64_t text_cap;
+    int plain_ops;             // != 0: the items of ops[] hold no continuation words (a batch the device parsed: rb_k_parse_cigars makes none)
 };
 
 // op character -> code (MIDNSHP=X -> 0..8), 255 = not an op.  Branch-free: the nine characters lie in '=' (61) .. 'X' (88),
@@ -217,10 +218,9 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
     }
 }
 
-// decimal digits of v (at most 10; ten only for an op with a continuation word)
+// decimal digits of v, at most 9 (an op with a continuation word may have ten: its caller adds the tenth)
 __device__ __forceinline__ uint32_t rb_ndigits(uint32_t v) {
-    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u) +
-           (v >= 1000000000u);
+    return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u);
 }
 
 #define RB_FMT_STAGE (256 * 10 + 48) // bytes of text one step of 256 words can make (9 digits + the op character each; an op with a continuation word: 11 bytes for its two words) + the 16-byte phase + 16 bytes of slack in front
@@ -251,15 +251,19 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
     const uint64_t f_raw = rb_first64(f_v);
     const uint32_t *__restrict__ src = (f_raw >> 63) ? p.ops_alt : p.ops;
     const uint64_t f0 = f_raw & ~(1ull << 63);
+    const bool look_for_cont = !p.plain_ops || (f_raw >> 63) != 0;
     const uint32_t n = rb_first(n_v);
     const uint32_t fl = rb_first(fl_v);
     const uint32_t ll = rb_first(ll_v);
     uint64_t out = rb_first64(out_v);
     uint64_t bytes = 0;
     uint8_t *stg = stage_all[wib] + (FILL ? 16 : 0); // (16 bytes in front: the digit stores below address from nine bytes before an op's text)
-    for (uint32_t i0 = 0; i0 < n; i0 += 256u) {
+    // A step loads 256 words and prints 255 of them: the last one is only looked at (is it a continuation word? then the word in
+    // front of it prints the whole length) and printed by the next step -- unless the item ends inside the step.
+    for (uint32_t i0 = 0, lim = 0; i0 < n; i0 = lim) {
         uint32_t len[4], opc[4], nb[4];
         uint32_t mine = 0;
+        lim = n - i0 <= 256u ? n : i0 + 255u; // words [i0, lim) are this step's
         // my four ops: one 16-byte load where all four exist (the array may end with the item: no reading past it)
         const uint32_t ib = i0 + (uint32_t)lane * 4u;
         uint32_t vv[4] = {0u, 0u, 0u, 0u};
@@ -271,35 +275,40 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
             for (int q = 0; q < 4; q++)
                 if (ib + (uint32_t)q < n) vv[q] = src[f0 + ib + (uint32_t)q];
         }
-        // continuation words (rb_device.h; only in what the general kernels wrote, never together with first_len / last_len): the
-        // word prints nothing, its owner prints the whole length.  The word behind this step's last one comes by a scalar load.
-        const uint32_t next_step_first = i0 + 256u < n ? src[f0 + i0 + 256u] : 0u;
-        bool cont_here = false;
-#pragma unroll
-        for (int q = 0; q < 4; q++) cont_here |= (vv[q] & 15u) == RB_OP_CONT;
-        uint32_t hi_of[4] = {0u, 0u, 0u, 0u}; // bits 28.. of my ops' lengths
-        if (__ballot(cont_here) != 0ull || (next_step_first & 15u) == RB_OP_CONT) {
-            uint32_t nxt = (uint32_t)__shfl_down((int)vv[0], 1, 64);
-            if (lane == 63) nxt = next_step_first;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t nw = q < 3 ? vv[q < 3 ? q + 1 : 3] : nxt;
-                if ((vv[q] & 15u) != RB_OP_CONT && ib + (uint32_t)q + 1u < n && (nw & 15u) == RB_OP_CONT) hi_of[q] = ((nw >> 4) & 15u) << RB_LEN_BITS_WORD;
-            }
-        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t i = i0 + (uint32_t)lane * 4u + (uint32_t)q;
             uint32_t v = vv[q];
-            uint32_t l = (v >> 4) + hi_of[q];
+            uint32_t l = v >> 4;
             if (n == 1u && fl && ll) l = fl + ll - l; // the middle of one op (liftover.rs via subset_cigar, paf.rs:593-620)
             else if (i == 0u && fl) l = fl;             // first op keeps its tail
             else if (i + 1u == n && ll) l = ll;         // last op keeps its head
             len[q] = l;
             opc[q] = v & 15u;
-            nb[q] = (i < n && opc[q] != RB_OP_CONT) ? rb_ndigits(l) + 1u : 0u;
-            mine += nb[q];
+            nb[q] = i < lim ? rb_ndigits(l) + 1u : 0u;
         }
+        // continuation words (rb_device.h; only in what the general kernels wrote, never together with first_len / last_len): the
+        // word prints nothing, its owner prints the whole length.  Rare: everything about them sits behind one ballot.
+        auto b13 = [](uint32_t w) { return __builtin_amdgcn_ubfe(w, 1u, 3u); }; // bits 1..3 of the code: 7 only for 14 (and 15, which no op has)
+        bool cont_here = false;
+        if (look_for_cont) { // (wave-uniform: not for the clips of a device-parsed batch, which are runs of the records' own ops)
+            const uint32_t m01 = b13(vv[0]) > b13(vv[1]) ? b13(vv[0]) : b13(vv[1]), m23 = b13(vv[2]) > b13(vv[3]) ? b13(vv[2]) : b13(vv[3]);
+            cont_here = (m01 > m23 ? m01 : m23) == 7u;
+        }
+        if (look_for_cont && __ballot(cont_here) != 0ull) {
+            const uint32_t nxt = (uint32_t)__shfl_down((int)vv[0], 1, 64); // (lane 63's last word is never printed by this step unless the item ends with it)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t nw = q < 3 ? vv[q < 3 ? q + 1 : 3] : nxt;
+                if (opc[q] == RB_OP_CONT) {
+                    nb[q] = 0u;
+                } else if (ib + (uint32_t)q < lim && ib + (uint32_t)q + 1u < n && (nw & 15u) == RB_OP_CONT) {
+                    len[q] += ((nw >> 4) & 15u) << RB_LEN_BITS_WORD;
+                    nb[q] = rb_ndigits(len[q]) + (len[q] >= 1000000000u ? 1u : 0u) + 1u;
+                }
+            }
+        }
+        mine = nb[0] + nb[1] + nb[2] + nb[3];
         const uint32_t incl = rb_wave_scan_incl(mine);
         const uint32_t step_bytes = rb_readlane<uint32_t>(incl, 63);
         if (FILL) {

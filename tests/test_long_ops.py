@@ -225,3 +225,19 @@ def test_format_kernel_prints_continuation_words(engine):
     toff, text = engine.format_cigars(ops, first, count)
     for i, c in enumerate(cigs):
         assert bytes(text[int(toff[i]):int(toff[i + 1])]).decode() == c, (i, c[:40])
+
+
+@gpu
+def test_text_route_prints_runs_that_merge_past_2_28(oracle, tmp_path):
+    """no length in the FILE reaches 2^28, so the device parses it and the text route stays on; two neighbours of one type merge into a
+    run that does (paf.rs:602-620), the generic kernel writes it as two words and rb_k_format_cigars prints them as one op"""
+    paf = tmp_path / "merge.paf"
+    paf.write_text("\n".join([line("qE", "200000000=100000000=5X10="), line("qG", "100=2X50="), line("qK", "7=3I268435455=268435455=9X4=", strand="-")]) + "\n")
+    bed = tmp_path / "w.bed"
+    bed.write_text("chrBig\t2\t268435470\nchrBig\t150\t600000000\nchrBig\t0\t700000000\nchrBig\t120\t200\n")
+    for args in (["liftover", "--bed", bed, paf], ["break-paf", "--max-size", "2", paf]):
+        rc, out = _rb(*args)
+        orc, oout = oracle.cli(*args)
+        assert (rc, orc) == (0, 0), args
+        assert out == oout, args
+    assert b"cg:Z:268435370=" in _rb("liftover", "--bed", bed, paf)[1]
