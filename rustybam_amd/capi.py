@@ -185,7 +185,7 @@ class Engine:
                                                C.c_void_p(new_off_ptr), C.c_void_p(new_ops_ptr or 0), C.c_void_p(scratch_ptr)), "rb_dev_gather_records")
 
     def dev_alloc(self, n_bytes):
-        """device memory from the library's allocator (large requests: physically contiguous VRAM); -> address"""
+        """device memory from the library's allocator (requests of 1 GB and more: 2 MB physical chunks mapped side by side); -> address"""
         d = C.c_void_p()
         self._chk(self.L.rb_dev_alloc(self.ctx, C.c_size_t(n_bytes), C.byref(d)), "rb_dev_alloc")
         return int(d.value)
