@@ -199,6 +199,10 @@ def test_rb_front_end_with_long_ops(oracle, tmp_path):
         orc, oout = oracle.cli(*args)
         assert (rc, orc) == (0, 0), args
         assert out == oout, args
+    # two worker processes (both on the one GPU here), their outputs put together by the parent
+    r = subprocess.run([RB, "--gpus", "2", "liftover", "--bed", str(bed), str(paf)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       env={**os.environ, "RB_GPUS_SAME_DEVICE": "1"})
+    assert r.returncode == 0 and r.stdout == oracle.cli("liftover", "--bed", bed, paf)[1]
     panics = tmp_path / "panics.paf"
     panics.write_text("\n".join(CASES) + "\n")
     assert _rb("liftover", "--bed", bed, panics)[0] == 101 and oracle.cli("liftover", "--bed", bed, panics)[0] == 101
