@@ -653,9 +653,9 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, decl_count, decl_list, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, decl_count, decl_list, gen_cp, total;
 };
-static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
+static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap, uint64_t n_ops) {
     ws_layout w;
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -681,12 +681,13 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap) {
     w.copy_list = take((rows_cap + 1) * 16);
     w.decl_count = take(256);
     w.decl_list = take((n_rec + 1) * 4); // break-paf in one walk: the records its clip kernel declined
+    w.gen_cp = take((size_t)(n_ops / RB_GCP + n_rec + 2) * sizeof(uint4)); // checkpoints of the records the generic kernel works on
     w.total = o;
     return w;
 }
 extern "C" size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap) {
     if (!plan) return 0;
-    return ws_of(plan->n_rec, rows_cap).total;
+    return ws_of(plan->n_rec, rows_cap, plan->n_ops).total;
 }
 
 // ops per output slot: the batch's op index space, 32 ops (one 128-byte line) of room per record (records that share a line in the
@@ -713,7 +714,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     if (((uintptr_t)b->ops & 15u) || ((uintptr_t)out_ops & 15u)) return fail(ctx, RB_E_INVALID, "ops/out_ops must be 16-byte aligned");
     if (rows_cap >= 0xFFFFFFFFull) return fail(ctx, RB_E_INVALID, "rows_cap too large");
     if ((uintptr_t)workspace & 255u) return fail(ctx, RB_E_INVALID, "workspace must be 256-byte aligned");
-    const ws_layout w = ws_of(plan->n_rec, rows_cap);
+    const ws_layout w = ws_of(plan->n_rec, rows_cap, plan->n_ops);
     char *ws = (char *)workspace;
     rb_lift_params p;
     memset(&p, 0, sizeof p);
@@ -761,6 +762,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.copy_list = (uint4 *)(ws + w.copy_list);
     p.copy_count = (unsigned long long *)(ws + w.copy_count);
     p.gen_list = (uint32_t *)(ws + w.gen_list);
+    p.gen_cp = getenv("RB_DEBUG_NO_GEN_CP") ? nullptr : (uint4 *)(ws + w.gen_cp); // (diagnostics: every generic walk from the record's first op, as before round 3)
     p.jobs = (rb_job *)(ws + w.jobs);
     p.fused = (policy & RB_LIFT_FUSED_SCAN) ? 1 : 0;
     p.norm_w = const_cast<rb_norm_row *>(norm);

@@ -1324,6 +1324,54 @@ __global__ __launch_bounds__(256) void rb_k_liftover_generic(rb_lift_params p) {
 //   pass 3  the ops between them, first / last length cut, adjacent ops of one type merged (paf.rs:602-620), zero lengths dropped
 // A tpos_aln that is not sorted (units at position -1, see rb_bsearch_units) goes to the serial code above.
 // ------------------------------------------------------------------------------------------------
+// Checkpoints for the generic kernel (rb_lift_params::gen_cp): one wavefront per entry of the generic list walks the entry's record
+// once and leaves, before every RB_GCP-th kept op, the units / reference / query / match bases so far.  The hits of a record follow
+// each other in the list: only the first of a run builds (a record that appears in two runs is built twice, with the same values).
+__device__ __forceinline__ uint4 *rb_gen_cp_of(const rb_lift_params &p, uint32_t r, uint32_t first_op) {
+    return p.gen_cp + ((p.op_off[r] + first_op) / RB_GCP + r);
+}
+__global__ __launch_bounds__(256) void rb_k_generic_checkpoints(rb_lift_params p) {
+    static_assert(RB_GCP == 256u, "one 16-byte load per lane covers a checkpoint interval");
+    const uint32_t wib = threadIdx.x >> 6;
+    const int lane = rb_lane();
+    const uint64_t n_gen = p.counters->n_generic;
+    for (uint64_t g = (uint64_t)blockIdx.x * 4u + wib; g < n_gen; g += (uint64_t)gridDim.x * 4u) {
+        const uint32_t r = p.rows[p.gen_list[g]].rec;
+        if (g > 0 && p.rows[p.gen_list[g - 1]].rec == r) continue;
+        const rb_norm_row *nr = &p.norm[r];
+        if (nr->status != RB_ST_OK) continue;
+        const uint32_t n = nr->n_ops;
+        if (n <= RB_GCP) continue; // (one checkpoint, the record's start: nothing to look up)
+        const uint32_t *ops = p.ops + p.op_off[r] + nr->first_op;
+        uint4 *cp = rb_gen_cp_of(p, r, nr->first_op);
+        auto load = [&](uint32_t c0) -> uint4 { // my four ops of the interval that starts at c0 (past the record: zero-length M ops)
+            const uint32_t i = c0 + 4u * (uint32_t)lane;
+            if (i + 3u < n) return rb_load4_unaligned(ops + i);
+            return make_uint4(i < n ? ops[i] : 0u, i + 1u < n ? ops[i + 1u] : 0u, i + 2u < n ? ops[i + 2u] : 0u, 0u);
+        };
+        uint32_t U = 0, R = 0, Q = 0, M = 0;
+        uint4 nxt = load(0u);
+        for (uint32_t c0 = 0; c0 < n; c0 += RB_GCP) {
+            if (lane == 0) cp[c0 / RB_GCP] = make_uint4(U, R, Q, M);
+            const uint4 cur = nxt;
+            if (c0 + RB_GCP < n) nxt = load(c0 + RB_GCP); // (in flight while this interval is summed)
+            const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
+            uint32_t u = 0, rr = 0, q = 0, m = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t i = c0 + 4u * (uint32_t)lane + (uint32_t)k;
+                uint32_t opc = rb_opc(w4[k]), len = rb_len(w4[k]);
+                if (opc == RB_OP_CONT && i < n) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
+                const bool okc = opc <= 8u;
+                u += len;
+                rr += okc && rb_in(RB_REF_MASK, opc) ? len : 0u;
+                q += okc && rb_in(RB_QRY_MASK, opc) ? len : 0u;
+                m += okc && rb_in(RB_MATCH_MASK, opc) ? len : 0u;
+            }
+            U += rb_wave_sum_u32(u), R += rb_wave_sum_u32(rr), Q += rb_wave_sum_u32(q), M += rb_wave_sum_u32(m);
+        }
+    }
+}
 __device__ __forceinline__ uint64_t rb_wave_min_u64(uint64_t v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -1402,11 +1450,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         }
         const int64_t ps = (int64_t)(wst > t_st ? wst : t_st); // positions to look up (liftover.rs:28, :38-40)
         const int64_t pe = (int64_t)(wen < t_en ? wen : t_en) - 1;
+        // ---- where the walks start: the last checkpoint with at most ps - t_st reference bases in front of it (every unit at
+        //      position ps, and everything behind it, lies at or behind that op).  The question pass 1 answers with the record's
+        //      first ops -- do units at position -1 come first? -- is asked of them directly then. ----
+        uint32_t c_start = 0, c_end1 = 0;               // c_end1: where the walk for the window's END may resume (pass 1)
+        uint4 cp0 = make_uint4(0u, 0u, 0u, 0u), cp_e1 = cp0;
+        bool first_seen = false, wrapped = false;
+        const uint4 *gcp = (p.gen_cp && n > RB_GCP) ? rb_gen_cp_of(p, r, nr->first_op) : nullptr;
+        const uint32_t ncp = (n + RB_GCP - 1u) / RB_GCP;
+        // the last checkpoint whose field (1: reference bases, 0: units) is <= target (checkpoint 0 holds zeros); the fields never decrease
+        auto cp_search = [&](int field, uint64_t target) -> uint32_t {
+            uint32_t k1 = 0;
+            for (uint32_t kb = 0; kb < ncp; kb += 64u) {
+                const uint32_t k = kb + (uint32_t)lane;
+                const uint4 c = gcp[k < ncp ? k : 0u];
+                const uint64_t m = __ballot(k < ncp && (uint64_t)(field ? c.y : c.x) <= target);
+                if (!m) break;
+                k1 = kb + (uint32_t)__builtin_popcountll(m) - 1u; // (m is a run of low bits)
+                if (m != ~0ull) break;
+            }
+            return k1;
+        };
+        if (gcp) {
+            const uint32_t k1 = cp_search(1, (uint64_t)ps - t_st);
+            const uint32_t k2 = pe >= ps ? cp_search(1, (uint64_t)pe - t_st) : 0u;
+            if (k2 > k1 + 1u) c_end1 = k2 * RB_GCP, cp_e1 = gcp[k2];
+            if (k1) {
+                c_start = k1 * RB_GCP;
+                cp0 = gcp[k1];
+                if (t_st == 0) { // (only then can a unit sit at position -1)
+                    for (uint32_t c0 = 0; c0 < n && !first_seen; c0 += 64u) {
+                        const uint32_t i = c0 + (uint32_t)lane;
+                        uint32_t opc = RB_NULL_OP, len = 0u;
+                        if (i < n) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
+                        const uint64_t m = __ballot(len != 0u);
+                        if (m) {
+                            first_seen = true;
+                            wrapped = !((__ballot(opc <= 8u && rb_in(RB_REF_MASK, opc)) >> __builtin_ctzll(m)) & 1ull);
+                        }
+                    }
+                }
+                first_seen = true;
+            }
+        }
         // ---- pass 1 ----
         uint64_t s_lo = ~0ull, s_hi = 0, e_lo = ~0ull, e_hi = 0;
-        uint64_t Ub = 0, Rb = 0;
-        bool first_seen = false, wrapped = false;
-        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+        uint64_t Ub = cp0.x, Rb = cp0.y;
+        for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
             const uint32_t wv = i < n ? ops[i] : 0u;
             uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
@@ -1440,6 +1530,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             Ub += rb_readlane<uint32_t>(iu, 63);
             Rb += rb_readlane<uint32_t>(ir, 63);
             if ((int64_t)t_st - 1 + (int64_t)Rb > pe) break; // every unit behind this step lies behind the window's last base
+            // every unit at position ps is behind us: on to the checkpoint in front of the units at pe (a long window is not walked)
+            if (c_end1 > c0 + 64u && (int64_t)t_st - 1 + (int64_t)Rb > ps) {
+                c0 = c_end1 - 64u;
+                Ub = cp_e1.x, Rb = cp_e1.y;
+                c_end1 = 0;
+            }
         }
         if (wrapped) { // an unsorted tpos_aln: binary_search returns what its probe sequence leads to (serial replay)
             if (lane == 0) rb_generic_serial_hit(p, g);
@@ -1459,8 +1555,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         uint32_t ia = 0, ib = 0, len_a = 0, len_b = 0;
         bool a_set = false, b_set = false;
         {
-            uint64_t U0 = 0, R0 = 0, Q0 = 0, M0 = 0;
-            for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+            uint64_t U0 = cp0.x, R0 = cp0.y, Q0 = cp0.z, M0 = cp0.w; // (ks, the unit the start resolves to, lies behind the checkpoint too)
+            // b is looked for from the checkpoint in front of unit ke; if the stretch from there to ke holds no match-type unit, the
+            // walk is done again without the jump (jump2 = 0)
+            uint32_t c_end2 = 0;
+            uint4 cp_e2 = cp0;
+            if (gcp && ke >= ks) {
+                const uint32_t k3 = cp_search(0, ke);
+                if (k3 * RB_GCP > c_start + RB_GCP) c_end2 = k3 * RB_GCP, cp_e2 = gcp[k3];
+            }
+          for (int attempt = 0; attempt < 2; attempt++) {
+            bool jumped = false;
+            if (attempt) U0 = cp0.x, R0 = cp0.y, Q0 = cp0.z, M0 = cp0.w, a_set = false, b_set = false, a = N, b = 0, c_end2 = 0;
+            for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
                 if (a_set && U0 > ke) break; // (nothing behind this can be <= ke)
                 const uint32_t i = c0 + (uint32_t)lane;
                 const uint32_t wv = i < n ? ops[i] : 0u;
@@ -1497,7 +1604,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
                     }
                 }
                 U0 += rb_readlane<uint32_t>(iu, 63), R0 += rb_readlane<uint32_t>(ir, 63), Q0 += rb_readlane<uint32_t>(iq, 63), M0 += rb_readlane<uint32_t>(im, 63);
+                if (a_set && c_end2 > c0 + 64u) { // a is known: straight to the checkpoint in front of unit ke
+                    c0 = c_end2 - 64u;
+                    U0 = cp_e2.x, R0 = cp_e2.y, Q0 = cp_e2.z, M0 = cp_e2.w;
+                    c_end2 = 0, jumped = true, b_set = false;
+                }
             }
+            if (!jumped || b_set) break; // (jumped and found nothing behind the jump: the last match-type unit <= ke lies in what was skipped)
+          }
         }
         if (a > b || a >= N || !a_set || !b_set) { // liftover.rs:52-54
             w.status = RB_ST_NONE_INDEL;
@@ -1652,6 +1766,7 @@ __global__ __launch_bounds__(256) void rb_k_break_declined_rows(rb_lift_params p
 extern "C" hipError_t rb_launch_break_declined(const rb_lift_params *p, hipStream_t stream) {
     if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_break_declined_rows, dim3((unsigned)std::min<uint64_t>((p->n_rec + 255) / 256, 256)), dim3(256), 0, stream, *p);
+    if (p->gen_cp) hipLaunchKernelGGL(rb_k_generic_checkpoints, dim3(2048), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_liftover_generic_wave, dim3(2048), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
     return hipGetLastError();
@@ -1693,8 +1808,12 @@ extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream
     if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_copy_clips, dim3(2048), dim3(256), 0, stream, *p);
     static const bool serial_generic = getenv("RB_DEBUG_GENERIC_SERIAL") != nullptr; // diagnostics: one thread per hit, as in round 1
-    if (serial_generic) hipLaunchKernelGGL(rb_k_liftover_generic, dim3(1024), dim3(256), 0, stream, *p);
-    else hipLaunchKernelGGL(rb_k_liftover_generic_wave, dim3(2048), dim3(256), 0, stream, *p);
+    if (serial_generic) {
+        hipLaunchKernelGGL(rb_k_liftover_generic, dim3(1024), dim3(256), 0, stream, *p);
+    } else {
+        if (p->gen_cp) hipLaunchKernelGGL(rb_k_generic_checkpoints, dim3(2048), dim3(256), 0, stream, *p);
+        hipLaunchKernelGGL(rb_k_liftover_generic_wave, dim3(2048), dim3(256), 0, stream, *p);
+    }
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
     return hipGetLastError();
 }

@@ -97,7 +97,12 @@ struct rb_lift_params {
     // generic kernel, everybody else's rows stay (round 2 redid the whole batch with two walks when one record declined)
     uint32_t *brk_decl_list;       // [n_rec]
     unsigned long long *brk_decl_count;
+    // checkpoints of the records the generic kernel works on: before kept op RB_GCP * k of record r, at gen_cp[(op_off[r] + first_op)
+    // / RB_GCP + r + k], the units / reference / query / match bases of the record so far (rb_k_generic_checkpoints): a hit starts its
+    // walks at the checkpoint in front of its window instead of at the record's first op.  NULL: every walk starts at the first op.
+    uint4 *gen_cp;
 };
+#define RB_GCP 256u
 
 // the kernel-argument segment of a kernel whose one argument is an rb_lift_params, read with scalar loads where a field is used
 // (rb_k_liftover_stream); rb_kp_here makes a copy of the pointer the compiler cannot see through, so that a load through it is
