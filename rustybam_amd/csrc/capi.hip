@@ -681,7 +681,8 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap, uint64_t n_ops) {
     w.copy_list = take((rows_cap + 1) * 16);
     w.decl_count = take(256);
     w.decl_list = take((n_rec + 1) * 4); // break-paf in one walk: the records its clip kernel declined
-    w.gen_cp = take((size_t)(n_ops / RB_GCP + n_rec + 2) * sizeof(uint4)); // checkpoints of the records the generic kernel works on
+    static const bool no_gen_cp = getenv("RB_DEBUG_NO_GEN_CP") != nullptr; // (diagnostics: no checkpoints, no room for them)
+    w.gen_cp = take(no_gen_cp ? 256 : (size_t)(n_ops / RB_GCP + n_rec + 2) * sizeof(uint4)); // checkpoints of the records the generic kernel works on
     w.total = o;
     return w;
 }
