@@ -26,13 +26,25 @@ d_rows = torch.empty((rows_cap + 1) * 64, dtype=torch.uint8, device=dev)
 d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
 d_norm = torch.empty(n_rec * 64, dtype=torch.uint8, device=dev)
 hdr = None
+# LAYOUT_ARENA=contiguous: the arena from rb_dev_alloc under RB_ALLOC_MODE=contiguous (one physical block: offsets inside it ARE physical
+# offsets); chunks: 2 MB physical chunks; default: torch's allocator (hipMalloc)
+arena_mode = os.environ.get("LAYOUT_ARENA", "torch")
+from rustybam_amd import capi
 for arena_no in range(2):
-    arena = torch.empty(ops_bytes + out_bytes + (6 << 30), dtype=torch.uint8, device=dev)
+    own = None
+    if arena_mode == "torch":
+        arena = torch.empty(ops_bytes + out_bytes + (6 << 30), dtype=torch.uint8, device=dev)
+    else:
+        os.environ["RB_ALLOC_MODE"] = arena_mode
+        own = capi.DevBuf(eng, torch, ops_bytes + out_bytes + (6 << 30), torch.uint8, device=dev)
+        arena = own.t
     base = arena.data_ptr()
     base_al = (base + (1 << 21) - 1) & ~((1 << 21) - 1)  # 2 MB aligned
     for name, a_off, gap in [("gap 0", 0, 0), ("gap 128 B", 0, 128), ("gap 4 KB", 0, 4096), ("gap 64 KB", 0, 65536), ("gap 1 MB", 0, 1 << 20),
                              ("gap 2 MB", 0, 2 << 20), ("gap 2 MB + 4 KB", 0, (2 << 20) + 4096), ("gap 1 GB", 0, 1 << 30), ("gap 1 GB + 68 KB", 0, (1 << 30) + 69632),
-                             ("ops + 4 KB, gap 0", 4096, 0), ("ops + 1 MB, gap 512 KB", 1 << 20, 1 << 19), ("out first", -1, 0)]:
+                             ("ops + 4 KB, gap 0", 4096, 0), ("ops + 1 MB, gap 512 KB", 1 << 20, 1 << 19), ("out first", -1, 0),
+                             ("gap 8 KB", 0, 8192), ("gap 32 KB", 0, 32768), ("gap 256 KB", 0, 1 << 18), ("gap 683 KB", 0, 699392), ("gap 16 MB", 0, 16 << 20),
+                             ("gap 256 MB", 0, 256 << 20), ("gap 3 GB + 1364 KB", 0, (3 << 30) + 1396736)]:
         if a_off >= 0:
             p_ops = base_al + a_off
             p_out = (p_ops + ops_bytes + gap + 127) & ~127
@@ -67,4 +79,6 @@ for arena_no in range(2):
         cnt = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
         print(f"arena {arena_no} (0x{base:x}) {name:24s}: kernel ms min {ks[0]:.3f} median {ks[2]:.3f} max {ks[-1]:.3f}  overflow {int(cnt['overflow'])}", flush=True)
     del arena, d_ops, d_out
+    if own is not None:
+        own.free()
     torch.cuda.empty_cache()
