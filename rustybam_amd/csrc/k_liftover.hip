@@ -1496,9 +1496,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         // ---- pass 1 ----
         uint64_t s_lo = ~0ull, s_hi = 0, e_lo = ~0ull, e_hi = 0;
         uint64_t Ub = cp0.x, Rb = cp0.y;
+        // (the next step's ops are asked for before this step's are looked at: a hit is a chain of dependent steps, and the load is the
+        //  longest link of each)
+        auto ld = [&](uint32_t c0_) -> uint32_t { return c0_ + (uint32_t)lane < n ? ops[c0_ + (uint32_t)lane] : 0u; };
+        uint32_t pf_at = c_start, pf_w = ld(c_start);
         for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
-            const uint32_t wv = i < n ? ops[i] : 0u;
+            if (pf_at != c0) pf_w = ld(c0); // (behind a jump)
+            const uint32_t wv = pf_w;
+            pf_at = c0 + 64u, pf_w = ld(c0 + 64u);
             uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
             if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i); // (walk form: one more op of its owner's type)
             const bool isref = opc <= 8u && rb_in(RB_REF_MASK, opc);
@@ -1567,10 +1573,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
           for (int attempt = 0; attempt < 2; attempt++) {
             bool jumped = false;
             if (attempt) U0 = cp0.x, R0 = cp0.y, Q0 = cp0.z, M0 = cp0.w, a_set = false, b_set = false, a = N, b = 0, c_end2 = 0;
+            pf_at = c_start, pf_w = ld(c_start);
             for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
                 if (a_set && U0 > ke) break; // (nothing behind this can be <= ke)
                 const uint32_t i = c0 + (uint32_t)lane;
-                const uint32_t wv = i < n ? ops[i] : 0u;
+                if (pf_at != c0) pf_w = ld(c0);
+                const uint32_t wv = pf_w;
+                pf_at = c0 + 64u, pf_w = ld(c0 + 64u);
                 uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
                 if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 const bool okc = opc <= 8u;
@@ -1632,9 +1641,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         }
         uint32_t out_pos = 0, c_tot = 0, c_opc = 0;
         bool has_carry = false;
+        auto ld3 = [&](uint32_t c0_) -> uint32_t {
+            const uint32_t i_ = c0_ + (uint32_t)lane;
+            return (i_ >= ia && i_ <= ib) ? ops[i_] : 0u;
+        };
+        uint32_t pf3 = ld3(ia & ~63u);
         for (uint32_t c0 = ia & ~63u; c0 <= ib; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
-            const uint32_t wv = (i >= ia && i <= ib) ? ops[i] : 0u;
+            const uint32_t wv = pf3;
+            pf3 = ld3(c0 + 64u);
             uint32_t opc = rb_opc(wv), len = rb_len(wv);
             if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
             const bool in = i >= ia && i <= ib && len != 0u;
