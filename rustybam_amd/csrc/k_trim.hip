@@ -673,14 +673,19 @@ __device__ uint32_t rb_tw_clip(rb_wrec &v, uint64_t new_q_st, uint64_t new_q_en,
         const rb_wpos o = rb_tw_find<false>(v, x, lane);
         if (o.i >= n) return false;
         const uint32_t j = x - o.pre, len = rb_len(o.w);
-        uint32_t u = rb_tw_before<0>(v, o.i, lane) + j;
+        const uint32_t ub = rb_tw_before<0>(v, o.i, lane);
+        uint32_t u = ub + j;
+        bool moved = false; // the unit left the op that holds the base
         if (j + 1u == len) { // last base of the op: the D / N units behind it repeat its position
             uint32_t k2 = o.i - v.i0 + 1u;
-            for (; k2 < v.m && !rb_in(RB_QRY_MASK, rb_opc(v.w[k2])); k2++) u += rb_len(v.w[k2]);
+            for (; k2 < v.m && !rb_in(RB_QRY_MASK, rb_opc(v.w[k2])); k2++) u += rb_len(v.w[k2]), moved = true;
             if (k2 >= v.m && v.i0 + v.m < n) return false; // (the run leaves the region)
         }
-        // nearest match-type unit, up (paf.rs:581-583) or down (:585-587)
-        rb_wpos om = rb_tw_find<true>(v, u, lane);
+        // nearest match-type unit, up (paf.rs:581-583) or down (:585-587); the op that holds unit u is the one just found unless the
+        // unit moved into the run behind it (round 3: the second search is skipped then -- it was a tenth of a pair's instructions)
+        rb_wpos om;
+        if (!moved) om.i = o.i, om.w = o.w, om.pre = ub;
+        else om = rb_tw_find<true>(v, u, lane);
         if (om.i >= n) return false;
         uint32_t km = u;
         if (!rb_in(RB_MATCH_MASK, rb_opc(om.w))) {
@@ -826,8 +831,30 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
     }
     int64_t best = 0;
     uint64_t best_idx = 0;
+    // the ops that hold the first and the last overlapped query base of each record, searched ONCE (round 3: the scores at the ends
+    // of the overlap and the candidate ranges below each searched them again -- seven wave searches of a pair's instructions)
+    const rb_wpos La = rb_tw_find<false>(L, lxa, lane), Lb = rb_tw_find<false>(L, lxb, lane), Ra = rb_tw_find<false>(R, rxa, lane), Rb = rb_tw_find<false>(R, rxb, lane);
+    if (La.i >= L.n || Lb.i >= L.n || Ra.i >= R.n || Rb.i >= R.n) {
+        pending(4);
+        return;
+    }
+    // W (score of the query bases in front of offset x, op order) at x = xa and at x = xb + 1, from those ops
+    auto W_at_first = [&](const rb_wrec &v, const rb_wpos &o, uint32_t xa) -> int64_t {
+        return (int64_t)v.SP[o.i - v.i0] + (int64_t)(xa - o.pre) * rb_tw_score(rb_opc(o.w), ms, ds, is);
+    };
+    auto W_behind_last = [&](const rb_wrec &v, const rb_wpos &o, uint32_t xb) -> int64_t {
+        const uint32_t k = o.i - v.i0;
+        return xb + 1u < o.pre + rb_len(o.w) ? (int64_t)v.SP[k] + (int64_t)(xb + 1u - o.pre) * rb_tw_score(rb_opc(o.w), ms, ds, is) : (int64_t)v.SP[k + 1u];
+    };
+    // G(p) = W(p - q_st) on '+', -W(q_en - p) on '-': st_ovl is offset xa on '+' and xb + 1 on '-', en_ovl the other way round
+    auto G_st = [&](const rb_wrec &v, const rb_wpos &oa, const rb_wpos &ob, uint32_t xa, uint32_t xb) -> int64_t {
+        return !v.minus ? W_at_first(v, oa, xa) : -W_behind_last(v, ob, xb);
+    };
+    auto G_en = [&](const rb_wrec &v, const rb_wpos &oa, const rb_wpos &ob, uint32_t xa, uint32_t xb) -> int64_t {
+        return !v.minus ? W_behind_last(v, ob, xb) : -W_at_first(v, oa, xa);
+    };
     {
-        const int64_t gl0 = rb_tw_G(L, st_ovl, lane, ms, ds, is), gr0 = rb_tw_G(R, st_ovl, lane, ms, ds, is), gr1 = rb_tw_G(R, en_ovl, lane, ms, ds, is);
+        const int64_t gl0 = G_st(L, La, Lb, lxa, lxb), gr0 = G_st(R, Ra, Rb, rxa, rxb), gr1 = G_en(R, Ra, Rb, rxa, rxb);
         const int64_t rsum = gr1 - gr0; // f(0)
         if (rsum > best) best = rsum;   // (index stays 0)
         int64_t cb = INT64_MIN;         // best f over the candidates k > 0 of this lane; ties: the smaller k
@@ -842,13 +869,8 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
             const uint64_t k = pos - st_ovl;
             if (f > cb || (f == cb && k < ck)) cb = f, ck = k;
         };
-        auto candidates = [&](rb_wrec &v, const rb_wrec &other, bool is_left, uint32_t xa, uint32_t xb) {
-            // ops whose query bases intersect the overlap: a contiguous op range
-            const uint32_t ia = rb_tw_find<false>(v, xa, lane).i, ib = rb_tw_find<false>(v, xb, lane).i;
-            if (ia >= v.n || ib >= v.n) {
-                v.bad = true;
-                return;
-            }
+        auto candidates = [&](rb_wrec &v, const rb_wrec &other, bool is_left, uint32_t ia, uint32_t ib) {
+            // ops whose query bases intersect the overlap: a contiguous op range [ia, ib]
             for (uint32_t i = ia + (uint32_t)lane; i <= ib; i += 64) {
                 const uint32_t k = i - v.i0;
                 const uint32_t wv = v.w[k];
@@ -873,9 +895,9 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
                 }
             }
         };
-        candidates(L, R, true, lxa, lxb);
-        candidates(R, L, false, rxa, rxb);
-        if (lane == 0) consider(en_ovl, R, true, rb_tw_G_lane(L, en_ovl, ms, ds, is));
+        candidates(L, R, true, La.i, Lb.i);
+        candidates(R, L, false, Ra.i, Rb.i);
+        if (lane == 0) consider(en_ovl, R, true, G_en(L, La, Lb, lxa, lxb));
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             const int64_t ob = __shfl_xor(cb, off, 64);
