@@ -284,7 +284,13 @@ int rb_dev_swap(rb_ctx *ctx, const rb_batch_view *batch, uint32_t *out_ops);
  * split point = first arg-max of prefix(left scores) + suffix(right scores) over the overlapped query
  * bases (trim_overlap.rs:50-76), then both records are clipped by query range.  pair_out_off[i] = first
  * op of pair i's output in out_ops; the pair needs room for n_ops(left) + n_ops(right) ops.  norm_rows
- * come from rb_dev_scan_records on the same batch. */
+ * come from rb_dev_scan_records on the same batch.
+ * RB_TRIM_IN_PLACE OR-ed into bsearch_policy (out_ops must then be batch->ops, the resident-batch set-up of rb_dev_apply_pairs):
+ * a clip by query range keeps a RUN of the record's ops and changes only the lengths of the run's first and last op, so a pair of
+ * regular records is not copied -- the two end words are rewritten where they are and rows[].out_off points at the run inside the
+ * array (out_n = its length).  The record's ops outside the run stay where they were, no longer part of it; the batch's original
+ * CIGARs are gone after the call.  Pairs with an irregular record still write their clips at pair_out_off. */
+enum { RB_TRIM_IN_PLACE = 256 };
 int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *batch, const rb_norm_row *norm_rows, uint64_t n_pairs,
                          const uint32_t *left, const uint32_t *right, const uint64_t *pair_out_off, int match_score,
                          int diff_score, int indel_score, int bsearch_policy, rb_pair_row *rows, uint32_t *out_ops);

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "rustybam_amd.h")
 
 BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, LIFT_DESCRIPTORS, LIFT_FUSED_SCAN = 0, 1, 16, 32, 64
+TRIM_IN_PLACE = 256  # rb_dev_overlap_split on a resident batch (out_ops = the batch's ops): regular records are cut where they are, not copied
 BREAK_ONE_WALK = 128  # rb_dev_break: the clip kernel finds the long indels itself; look at counters redo_two_walk afterwards
 HIT_INSIDE, HIT_GENERIC, HIT_DESCRIPTOR = 1, 2, 4
 NF_COVERED = 0x80000000

@@ -70,6 +70,7 @@ struct rb_trim_params {
     uint32_t scratch_blocks;
     unsigned long long *pend;
     uint32_t *pend_list;
+    int in_place;
 };
 struct rb_swap_params {
     uint64_t n_rec;
@@ -936,6 +937,8 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     p.rows = rows;
     p.out_ops = out_ops;
     p.only_pending = 0;
+    p.in_place = (policy & RB_TRIM_IN_PLACE) ? 1 : 0;
+    if (p.in_place && out_ops != b->ops) return fail(ctx, RB_E_INVALID, "RB_TRIM_IN_PLACE: out_ops must be the batch's own ops array");
     if (!ctx->trim_scratch) { // (40 MB, once per context; without it those pairs simply stay with the serial kernel)
         const uint32_t blocks = 48;
         if (hipMalloc(&ctx->trim_scratch, rb_trim_scratch_bytes(blocks)) == hipSuccess) ctx->trim_scratch_blocks = blocks;

@@ -1480,7 +1480,9 @@ bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, i
         eng.check(rb_dev_download(ctx, &hp, d_pass, sizeof hp), "rb_dev_download");
         if (hp.ops_end + 64 > ops_cap) return false; // (nothing has been printed: the record-based path starts over)
         if (hp.n_pairs) {
-            eng.check(rb_dev_overlap_split(ctx, &v, d_norm, hp.n_pairs, d_left, d_right, d_poff, match_score, diff_score, indel_score, eng.bsearch_policy,
+            // (regular records are cut where they are -- two words a record -- instead of being copied behind the ops in use; RB_TRIM_COPY=1: the copy)
+            static const int in_place = getenv("RB_TRIM_COPY") ? 0 : RB_TRIM_IN_PLACE;
+            eng.check(rb_dev_overlap_split(ctx, &v, d_norm, hp.n_pairs, d_left, d_right, d_poff, match_score, diff_score, indel_score, eng.bsearch_policy | in_place,
                                            d_rows, d_ops),
                       "rb_dev_overlap_split");
             eng.check(rb_dev_apply_pairs(ctx, hp.n_pairs, d_left, d_right, d_rows, d_opoff, d_norm), "rb_dev_apply_pairs");

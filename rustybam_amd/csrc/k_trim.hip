@@ -31,6 +31,11 @@ struct rb_trim_params {
     // pend_list[0 .. n_pairs) their indices (NULL: every row is looked at)
     unsigned long long *pend;
     uint32_t *pend_list;
+    // RB_TRIM_IN_PLACE (out_ops is the batch's own ops array): a regular record the wave kernel clips is not copied -- a clip by query
+    // keeps a run of the record's ops and changes the lengths of the run's first and last op only, so those two words are rewritten
+    // where they are and the row points at the run (out_off = its place in the array).  Pairs the serial kernel does still write
+    // their clips at pair_out_off.
+    int in_place;
 };
 
 struct rb_qstream {
@@ -369,6 +374,10 @@ __device__ void rb_serial_pair(const rb_trim_params &p, const uint64_t pi) {
 #define RB_TW_CAP3 32768 // third attempt: the same arrays in device memory (whole-chromosome alignments that overlap by hundreds of kilobases)
 #define RB_TW_SLAB_WORDS(CAP) (2u * 3u * ((CAP) + 1u) + 2u * 3u * ((CAP) / 16u + 2u))
 #define RB_ST_PENDING_INTERNAL 0x7FFF0001u
+#ifndef RB_TW_STOP
+#define RB_TW_STOP 0 // diagnostics (tools/prof_c4_decomp.sh): != 0 ends a pair early -- 1 behind the left record's staging, 2 behind both, 3 behind the
+                     // searches of the overlap's end ops, 4 behind the split, 5 behind the left clip; the rows are wrong then, only the time is of interest
+#endif
 
 // A record of a pair as the wave kernel sees it.  Only the REGION of the record that the overlap can touch is staged in LDS --
 // the ops that hold the overlapped query bases plus a 64-op step on either side -- with prefixes that are absolute (counted from
@@ -640,8 +649,12 @@ struct rb_wend { // a unit of the record: its index, the op that holds it, and t
     rb_wpos o;    // op, its word, units before it
     uint32_t R, Q; // reference / query bases before the op
 };
+struct rb_wcut { // in-place clip: the two words to rewrite (absolute indices into the ops array) once BOTH clips of the pair stand
+    uint64_t at_first, at_last;
+    uint32_t w_first, w_last;
+};
 __device__ uint32_t rb_tw_clip(rb_wrec &v, uint64_t new_q_st, uint64_t new_q_en, uint32_t *out, rb_pair_row *row, int s, uint64_t out_base,
-                               int lane) {
+                               int lane, rb_wcut *cut = nullptr, uint64_t rec_base = 0) {
     if (!(new_q_st >= v.q_st) || !(new_q_en <= v.q_en) || new_q_en == 0) return RB_ST_PANIC_ASSERT; // :787-788
     if (new_q_en <= new_q_st) { // an empty range: the serial kernel says what the reference does with it
         v.bad = true;
@@ -745,13 +758,20 @@ __device__ uint32_t rb_tw_clip(rb_wrec &v, uint64_t new_q_st, uint64_t new_q_en,
     // matches = ref + query - units: the clip kernel's identity).  Round 2 summed three 64-bit totals over every copied op: 470 of a
     // pair's 2640 vector instructions.
     const uint32_t ia = A.o.i, ib = B.o.i, cnt = ib - ia + 1;
-    for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) {
-        const uint32_t wv = v.ops[ia + j];
-        uint32_t len = rb_len(wv);
-        if (cnt == 1) len = B.k - A.k + 1u;
-        else if (j == 0) len = A.o.pre + len - A.k;
-        else if (j == cnt - 1) len = B.k - B.o.pre + 1u;
-        out[j] = (len << 4) | rb_opc(wv);
+    if (cut) { // (in place: nothing is copied; rec_base = where the record's kept ops begin in the ops array)
+        const uint32_t lf = cnt == 1 ? B.k - A.k + 1u : A.o.pre + rb_len(A.o.w) - A.k, ll = cnt == 1 ? lf : B.k - B.o.pre + 1u;
+        cut->at_first = rec_base + ia, cut->at_last = rec_base + ib;
+        cut->w_first = (lf << 4) | rb_opc(A.o.w), cut->w_last = (ll << 4) | rb_opc(B.o.w);
+        out_base = rec_base + ia;
+    } else {
+        for (uint32_t j = (uint32_t)lane; j < cnt; j += 64) {
+            const uint32_t wv = v.ops[ia + j];
+            uint32_t len = rb_len(wv);
+            if (cnt == 1) len = B.k - A.k + 1u;
+            else if (j == 0) len = A.o.pre + len - A.k;
+            else if (j == cnt - 1) len = B.k - B.o.pre + 1u;
+            out[j] = (len << 4) | rb_opc(wv);
+        }
     }
     // (what CAN fail is the query side: the new start and end are resolved independently -- up and down --, and when the end lands on
     //  a lower query position than the start the coordinates say end + 1 - start while the ops between the two units still hold
@@ -825,10 +845,19 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
     uint32_t lxa, lxb, rxa, rxb;
     span(L, &lxa, &lxb);
     span(R, &rxa, &rxb);
+#if RB_TW_STOP == 1
+    if (!rb_tw_stage<CAP>(L, lane, ms, ds, is, lxa, lxb)) pending(3);
+    if (lane == 0) p.rows[pi].split_idx = L.m;
+    return;
+#endif
     if (!rb_tw_stage<CAP>(L, lane, ms, ds, is, lxa, lxb) || !rb_tw_stage<CAP>(R, lane, ms, ds, is, rxa, rxb)) { // an overlap of more ops than the region holds
         pending(3);
         return;
     }
+#if RB_TW_STOP == 2
+    if (lane == 0) p.rows[pi].split_idx = L.m + R.m;
+    return;
+#endif
     int64_t best = 0;
     uint64_t best_idx = 0;
     // the ops that hold the first and the last overlapped query base of each record, searched ONCE (round 3: the scores at the ends
@@ -838,6 +867,10 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
         pending(4);
         return;
     }
+#if RB_TW_STOP == 3
+    if (lane == 0) p.rows[pi].split_idx = La.i + Lb.i + Ra.i + Rb.i;
+    return;
+#endif
     // W (score of the query bases in front of offset x, op order) at x = xa and at x = xb + 1, from those ops
     auto W_at_first = [&](const rb_wrec &v, const rb_wpos &o, uint32_t xa) -> int64_t {
         return (int64_t)v.SP[o.i - v.i0] + (int64_t)(xa - o.pre) * rb_tw_score(rb_opc(o.w), ms, ds, is);
@@ -912,16 +945,30 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
     }
     w.split_idx = best_idx;
     w.split_score = (int32_t)best;
+#if RB_TW_STOP == 4
+    if (lane == 0) p.rows[pi] = w;
+    return;
+#endif
     const uint64_t split = st_ovl + best_idx;
     const uint64_t ob = p.pair_out_off[pi];
-    uint32_t st = rb_tw_clip(L, L.q_st, split, p.out_ops + ob, &w, 0, ob, lane); // trim_overlap.rs:77
+    rb_wcut cutL, cutR;
+    const bool inpl = p.in_place != 0;
+    uint32_t st = rb_tw_clip(L, L.q_st, split, p.out_ops + ob, &w, 0, ob, lane, inpl ? &cutL : nullptr, (uint64_t)(L.ops - p.ops)); // trim_overlap.rs:77
+#if RB_TW_STOP == 5
+    if (lane == 0) p.rows[pi] = w;
+    return;
+#endif
     if (st == RB_ST_OK && !L.bad) {
         const uint64_t ob2 = ob + L.n;
-        st = rb_tw_clip(R, split, R.q_en, p.out_ops + ob2, &w, 1, ob2, lane); // :78
+        st = rb_tw_clip(R, split, R.q_en, p.out_ops + ob2, &w, 1, ob2, lane, inpl ? &cutR : nullptr, (uint64_t)(R.ops - p.ops)); // :78
     }
     if (L.bad || R.bad) { // a boundary the region cannot answer: the serial kernel does the pair (it rewrites both clips)
         pending(L.bad ? 5 : 6);
         return;
+    }
+    if (inpl && st == RB_ST_OK && lane == 0) { // both clips stand: their end words, where they are (first before last: one op -> the same word twice)
+        p.out_ops[cutL.at_first] = cutL.w_first, p.out_ops[cutL.at_last] = cutL.w_last;
+        p.out_ops[cutR.at_first] = cutR.w_first, p.out_ops[cutR.at_last] = cutR.w_last;
     }
     w.status = st;
     w._pad = 1; // (diagnostic: done by the wave kernel; the serial kernel leaves 0)

@@ -3,6 +3,8 @@
 Plumbing for tests: record bookkeeping (stable sort by query name, pair scan, one pair per query per pass,
 recursion as a loop, contained flags) happens here exactly as in the reference; every pass's independent
 pairs go to the GPU in one rb_host_overlap_split call."""
+import os
+
 import numpy as np
 
 from . import capi
@@ -213,7 +215,8 @@ class ResidentTrim:
             if k:
                 if end > self.cap:
                     raise RuntimeError("ResidentTrim: out of room for the clips (raise room_factor)")
-                eng.dev_overlap_split(self.view, self.d_norm.data_ptr(), k, d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), scores, policy,
+                eng.dev_overlap_split(self.view, self.d_norm.data_ptr(), k, d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), scores,
+                                      policy | (0 if os.environ.get("RB_TRIM_COPY") else capi.TRIM_IN_PLACE),   # regular records are cut where they are
                                       d_rows.data_ptr(), self.d_ops.data_ptr())
                 eng.dev_apply_pairs(k, d_l.data_ptr(), d_r.data_ptr(), d_rows.data_ptr(), self.d_off.data_ptr(), self.d_norm.data_ptr())
                 eng.dev_trim_check(k, d_rows.data_ptr(), d_pass.data_ptr())

@@ -569,3 +569,19 @@ def test_pipelined_text_route_equals_the_whole_file_route(golden, args, tmp_path
     rc0, out0 = rb(*a, env={"RB_NO_PIPELINE": "1"})
     rc1, out1 = rb(*a, env={"RB_CHUNK_KB": "200"})
     assert rc0 == 101 and rc1 == 101 and out0 == b""
+
+
+def test_trim_paf_in_place_and_copied_clips_print_the_same(oracle, tmp_path):
+    """rb trim-paf cuts regular records where they are (RB_TRIM_IN_PLACE: two words a record) and copies the clips of the others behind
+    the ops in use; RB_TRIM_COPY=1 copies all of them as rounds 1 and 2 did.  Same bytes, and the oracle's on the first queries."""
+    paf = tmp_path / "c4.paf"
+    with open(paf, "wb") as f:
+        subprocess.check_call(["python3", os.path.join(ROOT, "tools", "gen_config4_paf.py"), "4000"], stdout=f)
+    rc, out = rb("trim-paf", paf)
+    rc2, out2 = rb("trim-paf", paf, env={"RB_TRIM_COPY": "1"})
+    assert (rc, rc2) == (0, 0) and out == out2 and out.count(b"\n") == 4000
+    head = tmp_path / "head.paf"
+    head.write_bytes(b"".join(open(paf, "rb").readlines()[:400]))
+    rc3, out3 = rb("trim-paf", head)
+    orc, oout = oracle.cli("trim-paf", head)
+    assert (rc3, orc) == (0, 0) and out3 == oout

@@ -73,6 +73,14 @@ def main():
     eng.set_timing(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if os.environ.get("RB_C4_ONE_PASS"):  # (diagnostics, tools/prof_c4_decomp.sh: one pass of a library variant whose rows are wrong, then out)
+        try:
+            T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN, max_passes=1)
+        except Exception as e:  # (more passes wanted, or rows a stopped variant left unfinished)
+            print(f"one pass: {e}", file=sys.stderr)
+        torch.cuda.synchronize()
+        print(json.dumps({"one_pass": True}))
+        return
     T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN)
     torch.cuda.synchronize()
     t_trim = time.perf_counter() - t0
