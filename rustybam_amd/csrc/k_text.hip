@@ -223,6 +223,9 @@ __device__ __forceinline__ uint32_t rb_ndigits(uint32_t v) {
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u);
 }
 
+#ifndef RB_FMT_STOP
+#define RB_FMT_STOP 0 // diagnostics (timing only, wrong text): 1 = the fill pass stops behind the byte counts of a step, 2 = behind the digits in LDS
+#endif
 #define RB_FMT_STAGE (256 * 10 + 48) // bytes of text one step of 256 words can make (9 digits + the op character each; an op with a continuation word: 11 bytes for its two words) + the 16-byte phase + 16 bytes of slack in front
 // the four low decimal digits of x < 10000, least significant first, as one byte each of a dword: multiplications by constants that
 // fit 24 bits (v_mul_u32_u24: full rate; the per-digit x / 10 of round 2 was a v_mul_hi_u32 -- quarter rate -- per digit)
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
         mine = nb[0] + nb[1] + nb[2] + nb[3];
         const uint32_t incl = rb_wave_scan_incl(mine);
         const uint32_t step_bytes = rb_readlane<uint32_t>(incl, 63);
-        if (FILL) {
+        if (FILL && RB_FMT_STOP != 1) {
             const uint32_t phase = (uint32_t)(out & 15u);
             uint32_t o = phase + (incl - mine); // place in the stage buffer: byte k of the buffer is byte (out - phase + k) of the text
 #pragma unroll
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
             const uint32_t end = phase + step_bytes;                 // buffer bytes [phase, end) are this step's
             const uint32_t a16 = (phase + 15u) & ~15u, b16 = end & ~15u; // whole 16-byte groups [a16, b16)
             uint8_t *__restrict__ dst = p.text + (out - phase);      // 16-byte aligned (text is, by contract)
-            if (out + step_bytes <= cap_end) {
+            if (RB_FMT_STOP != 2 && out + step_bytes <= cap_end) {
                 if (a16 < b16) {
                     for (uint32_t k = a16 + 16u * (uint32_t)lane; k < b16; k += 1024u)
                         *reinterpret_cast<uint4 *>(dst + k) = *reinterpret_cast<const uint4 *>(stg + k);
