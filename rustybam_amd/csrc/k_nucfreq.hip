@@ -396,6 +396,9 @@ __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { return ((v & 0
 // LDS and memory latency, and the third workgroup is worth 20 % (4.43 -> 3.6 ms on config 5).  The other build takes the tiles
 // crowded with reads (16-bit counters, 32-bit differences: 77 KB).  Both are launched over all tiles and leave the other's alone.
 #define NF_CNT8_DW (10 * ((NF_TILE + 16) / 8))
+#ifndef NF_STOP
+#define NF_STOP 0 // diagnostics (timing only, wrong counts): 1 = no output written, 2 = no LDS atomics (bases staged and decoded, nothing added), 3 = no read touched
+#endif
 template <bool U8T>
 __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + 128) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
@@ -449,6 +452,9 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     auto read_by_wave = [&](auto U8, const nf_read &h, uint32_t w_first, uint64_t i) {
         const int64_t pos = h.pos;
         const uint64_t rend = h.end;
+#if NF_STOP == 3
+        return;
+#endif
         if (h.tid != T.tid || (uint64_t)pos >= T.en || rend <= T.st) return; // hts_itr_next: pos < en && endpos > st (end = 0: not in the pileup)
         if (nf_dropped(drop, i)) return;
         const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = rend < T.en ? rend : T.en;
@@ -526,6 +532,10 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
                     uint32_t x = __builtin_amdgcn_alignbit(d1, d0, shift4); // (d0, d1: nibbles already in base order)
                     const uint32_t width = (uint32_t)(j1 - j0) * 4u;
                     x &= width >= 32u ? 0xFFFFFFFFu : (((1u << width) - 1u) << ((uint32_t)j0 * 4u)); // bases outside [ia, ib) become code 0: add nothing
+#if NF_STOP == 2
+                    if (x == 0x12345678u) cnt[(uint32_t)P & 1023u] = x; // (keeps x alive)
+                    return;
+#endif
                     uint32_t inc[8]; // (the table reads first, all eight in flight, then the atomics)
                     if constexpr (decltype(U8)::value) {
                         unsigned long long *g = reinterpret_cast<unsigned long long *>(&cnt[10u * ((uint32_t)P >> 3)]);
@@ -685,11 +695,16 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
         atomicAdd(&blk_cov, cov);
     }
     __syncthreads();
+#if NF_STOP != 4
     if (threadIdx.x == 0) {
         atomicMax((unsigned long long *)&p.counters->max_depth, (unsigned long long)blk_max);
         atomicAdd((unsigned long long *)&p.counters->n_covered, (unsigned long long)blk_cov);
     }
+#endif
     uint4 *__restrict__ out = reinterpret_cast<uint4 *>(p.counts + 4ull * T.out);
+#if NF_STOP == 1
+    if (blk_max != 0x7FFFFFFFu) return;
+#endif
     if constexpr (U8T) {
         static_assert(NF_PER_THREAD <= 8, "one byte of coverage flags per thread");
         for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
