@@ -20,6 +20,10 @@
 // format = 4 B per op read twice + text bytes written.
 #include "rb_device.h"
 
+#ifndef RB_PARSE_STOP
+#define RB_PARSE_STOP 0 // diagnostics (timing only): 1 = the fill pass of the parser stops behind the values of a step, 2 = behind the ops in LDS
+#endif
+
 struct rb_parse_params {
     uint64_t n_rec;
     const uint8_t *text;      // all CIGAR strings, any layout
@@ -177,6 +181,17 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) mx = mx > slen[j] ? mx : slen[j];
             if (mx >= (1u << 28)) err |= 2u; // not representable in the packed form
+#if RB_PARSE_STOP == 1
+            { // (diagnostics: the step ends behind the values; a dependency on every one of them keeps them computed)
+                uint32_t chk = fixed_first;
+#pragma unroll
+                for (int j = 0; j < 8; j++) chk ^= slen[j];
+                if (chk == 0x9E3779B9u) err |= 8u;
+                const uint32_t tot_ = rb_wave_sum_u32(cnt);
+                out_base += tot_, total += tot_;
+                continue;
+            }
+#endif
             // the ops of this step go through LDS: every lane drops its (at most 8) ops at their rank -- absent slots go to a scrap
             // word -- and the wave then writes the step's ops out side by side
             const uint32_t incl0 = rb_wave_scan_incl(cnt);
@@ -199,8 +214,12 @@ __global__ __launch_bounds__(256) void rb_k_parse_cigars(rb_parse_params p) {
             const uint32_t step_total_f = rb_readlane<uint32_t>(incl0, 63);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+#if RB_PARSE_STOP != 2
             for (uint32_t k = (uint32_t)lane; k < step_total_f; k += 64u)
                 if (out_base + k < p.ops_cap) p.ops[out_base + k] = stg[k];
+#else
+            if (step_total_f == 0x7FFFFFFFu) p.ops[out_base] = stg[lane]; // (diagnostics: nothing leaves LDS)
+#endif
             __builtin_amdgcn_wave_barrier();
             out_base += step_total_f;
             total += step_total_f;
