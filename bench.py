@@ -40,12 +40,19 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=int, default=1_000_000, help="records per GPU")
     ap.add_argument("--windows", type=int, default=3000)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "irregular"],
-                    help="config3: the headline; config2: one 1 Mbp window; irregular: config 3's records made irregular (adjacent ops of one "
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config2-lognormal", "irregular"],
+                    help="config3: the headline; config2: one 1 Mbp window; config2-lognormal: SURVEY 8(d)'s imbalance shape of config 2 "
+                         "(op counts log-normal(ln 2000, 1.35) clipped to [31, 80000], the fixture's own range; --records defaults to 1e5 x "
+                         "mean 4.1k ops); irregular: config 3's records made irregular (adjacent ops of one "
                          "type at the start, an N / H op at an end of two thirds of them) so that every hit takes the generic wave-per-hit kernel")
     ap.add_argument("--irregular-frac", type=float, default=0.0,
                     help="config3 / --op break: this fraction of the records made irregular as in --workload irregular (0.01: what the "
                          "one-walk break path must take record by record instead of redoing the batch)")
+    ap.add_argument("--placement", default="default", choices=["default", "uniform", "overlap"],
+                    help="where the records lie on the target: config 3 = uniform; config 2 = overlap (every record overlaps the window); "
+                         "`--workload config2 --placement uniform` is SURVEY 8(d)'s second imbalance case: about 0.8 %% of the records overlap "
+                         "the window, every record is still walked (liftover.rs:119-121)")
+    ap.add_argument("--no-box", action="store_true", help="skip the `box` block (memory-mix probe, in-kernel clock, tail of the launch)")
     ap.add_argument("--legacy", action="store_true", help="RB_BSEARCH_LEGACY (rustc 1.52 .. 1.81 binary search): duplicates resolved by probe replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -154,6 +161,29 @@ def e2e_leg(n_rec, n_win, gpus=1):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def smi_facts():
+    """Partition modes, power cap and clocks of GPU 0 as rocm-smi reports them -- run as a child process BEFORE this process touches the
+    GPU (a process that has must not fork + exec).  None when rocm-smi is absent or says nothing parsable."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--showmemorypartition", "--showcomputepartition", "--showmaxpower", "--showpower", "--showclocks", "--json"],
+                             capture_output=True, text=True, timeout=60).stdout
+        j = json.loads(out[out.index("{"):])
+        c = j.get("card0") or next(iter(j.values()))
+        pick = {}
+        for k_, v in c.items():
+            lk = k_.lower()
+            if "partition" in lk or "power" in lk or lk.startswith("sclk") or lk.startswith("mclk") or lk.startswith("fclk"):
+                pick[k_] = v
+        return pick or None
+    except Exception as e:  # (diagnostics only: never in the way of the bench)
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -170,6 +200,7 @@ def main():
                           "port": os.environ.get("MASTER_PORT"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
         return
     e2e = None
+    smi = smi_facts() if (rank == 0 and not args.no_box) else None
     if rank == 0 and args.e2e_records > 0 and args.workload == "config3" and args.op == "liftover" and not args.no_cpu_baseline:
         # (child processes, before this one initialises the GPU; with N ranks: `rb --gpus N` on the same file while the other ranks
         #  wait for rank 0 at the rendezvous)
@@ -203,9 +234,12 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream  # handle is NULL, which rb_ctx_create reads as "make a private stream")
     eng = rustybam_amd.Engine(dev_index, stream)
 
+    if args.workload.startswith("config2") and "--records" not in sys.argv:
+        args.records = 100_000  # BASELINE.json configs[1]: 1e5 records x one 1 Mbp window
     if args.scaling == "strong":  # one batch of --records, one op-balanced contiguous record range per rank
-        seed_ = wl.SEED_CONFIG2 if args.workload == "config2" else wl.SEED_CONFIG3
-        bounds = shard.shard_bounds(wl.op_offsets(wl.n_ops(seed_, 0, args.records)), world)
+        seed_ = wl.SEED_CONFIG2 if args.workload.startswith("config2") else wl.SEED_CONFIG3
+        bounds = shard.shard_bounds(wl.op_offsets(wl.n_ops_lognormal(seed_, 0, args.records) if args.workload == "config2-lognormal"
+                                                  else wl.n_ops(seed_, 0, args.records)), world)
         first, n_rec = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
     else:
         n_rec = args.records
@@ -216,10 +250,13 @@ def main():
     else:
         seed, placement = wl.SEED_CONFIG2, "overlap"
         w_c, w_st, w_en = np.zeros(1, np.uint32), np.array([12_000_000], np.uint64), np.array([13_000_000], np.uint64)
+    if args.placement != "default":
+        placement = args.placement
+    lognormal = args.workload == "config2-lognormal"
 
     # ---- generate the shard in HBM ----
     t0 = time.time()
-    nops = wl.n_ops(seed, first, n_rec)
+    nops = wl.n_ops_lognormal(seed, first, n_rec) if lognormal else wl.n_ops(seed, first, n_rec)
     op_off = wl.op_offsets(nops)
     total_ops = int(op_off[-1])
 
@@ -434,16 +471,21 @@ def main():
             break
     except Exception:
         pass
+    ks_ = np.sort(np.asarray(kern_ms[-args.steps:], dtype=np.float64)) if kern_ms else np.zeros(0)
     roofline = {"bound": "hbm", "kernel": ("rb_k_liftover_generic_wave (whole step: the streaming kernel only verifies and defers)" if irregular else "rb_k_liftover_stream") if args.op == "liftover"
                 else "rb_dev_break (rb_k_break_pieces + rb_k_liftover_stream)", "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
+                # the clip kernel's own launches of the timed steps (HIP events on the launch stream): min / median / max
+                "kernel_ms_steps": ({"min": round(float(ks_[0]), 4), "median": round(float(ks_[len(ks_) // 2]), 4), "max": round(float(ks_[-1]), 4),
+                                     "n": int(len(ks_))} if len(ks_) else None),
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)}
 
     result = {
         "metric": (("CIGAR-ops/s, liftover over 100 kb sliding windows (whole pass, inputs resident in HBM)" if args.workload == "config3" else
                     f"CIGAR-ops/s, liftover over 100 kb sliding windows, irregular CIGARs{', legacy binary search' if args.legacy else ''} (generic kernel; whole pass, inputs resident in HBM)" if irregular else
-                    "CIGAR-ops/s, liftover over one 1 Mbp window (whole pass, inputs resident in HBM)") if args.op == "liftover"
+                    "CIGAR-ops/s, liftover over one 1 Mbp window" + (", log-normal op counts" if lognormal else "") +
+                    (", records placed uniformly on the target" if placement == "uniform" else "") + " (whole pass, inputs resident in HBM)") if args.op == "liftover"
                    else "CIGAR-ops/s, break-paf --max-size 100 (whole pass, inputs resident in HBM)"),
         "value": job_ops * args.steps / elapsed,
         "unit": "CIGAR-ops/s",
@@ -456,8 +498,8 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE.json {args.workload}: {n_rec} records/GPU (uniform 1000-9000 ops, "
-                               f"{total_ops} ops on rank 0) x {len(w_st)} windows, seed {seed:#x}",
+        "config": {"workload": f"BASELINE.json {args.workload}: {n_rec} records/GPU ({'log-normal(ln 2000, 1.35) in [31, 80000]' if lognormal else 'uniform 1000-9000'} ops, "
+                               f"{total_ops} ops on rank 0) x {len(w_st)} windows, placement {placement}, seed {seed:#x}",
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
@@ -569,6 +611,51 @@ def main():
                 "by_threads": {str(nt): {"value": os_ops / dt, "seconds": round(dt, 2)} for nt, dt in sorted(os_runs.items())}}
             del ops_host, ob
 
+    # ---- the box: why this line reads what it reads on THIS machine (rank 0, outside the timed region, after every check: the probe
+    #      overwrites the output arena).  (a) the clock the clip kernel holds: its diagnostics build (same code + s_memtime /
+    #      s_memrealtime stamps around the streaming loop of every 16th record, written to a counter block nothing reads) after >= 2 s
+    #      of back-to-back launches; the same run leaves the time each wave was done, hence how long the launch ran on after 95 % of
+    #      them had retired.  (b) the library's memory-mix probe on these very buffers: the kernel's bytes in its access shape without
+    #      its instructions -- a box that is slow at moving bytes shows here, a box that holds a lower clock shows in (a).
+    if rank == 0 and not args.no_box and args.op == "liftover" and not args.descriptors and not irregular:
+        box = {"smi_before_start": smi}
+        try:
+            dpol = policy | ((128 | 256) << 8)
+            eng.set_timing(True)
+            tb0, n_diag = time.perf_counter(), 0
+            while n_diag < 10 or time.perf_counter() - tb0 < 2.0:
+                eng.dev_liftover(plan, view, d_norm.data_ptr(), dpol, d_ws.data_ptr(), d_rows.data_ptr(), rows_cap, d_out.data_ptr(), out_cap, d_cnt.data_ptr())
+                n_diag += 1
+                if n_diag % 10 == 0:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            dms = eng.get_timing()
+            eng.set_timing(False)
+            dc = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
+            ph = [int(x) for x in dc["phase"]]
+            if ph[1]:
+                box["kernel_clock_mhz"] = round(ph[0] * 64.0 / ph[1] * 100.0, 1)
+                box["kernel_clock_note"] = (f"diagnostics build of rb_k_liftover_stream, {n_diag} launches back to back ({time.perf_counter() - tb0:.1f} s), "
+                                            f"stamps of {ph[2]} records of the last launch; that build's launches took {float(np.mean(dms[-10:])):.3f} ms")
+            off = eng.plan_diag_stamps_offset(plan, rows_cap)
+            st_ = d_ws[off: off + 4 * n_rec].view(torch.int32).cpu().numpy().view(np.uint32)
+            rel = np.sort((st_ - st_.min()).astype(np.uint32))  # (mod 2^32: a launch is far shorter than the counter's 43 s)
+            box["launch_tail"] = {"ms_after_95pct_of_waves_done": round(float(rel[-1] - rel[int(0.95 * (len(rel) - 1))]) * 1e-5, 4),
+                                  "ms_after_99pct": round(float(rel[-1] - rel[int(0.99 * (len(rel) - 1))]) * 1e-5, 4),
+                                  "ms_first_to_last_wave_done": round(float(rel[-1]) * 1e-5, 4)}
+            src_bytes = (total_ops * 4) // 20480 * 20480
+            if out_cap * 4 >= 2 * src_bytes:
+                pms, pmhz = eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10)
+                box["probe_ms"] = round(pms, 4)
+                box["probe_clock_mhz"] = round(pmhz, 1)
+                box["probe_gb_s"] = round(2.2 * src_bytes / (pms * 1e-3) / 1e9, 1)
+                box["probe_note"] = (f"rb_dev_box_probe on this run's buffers: {src_bytes} B read from the ops array, 1.2 x that written to the output "
+                                     "arena in the clip kernel's access shape (32 contiguous bytes per lane, two slots), no other instructions")
+                if k_ms == k_ms:
+                    box["kernel_over_probe"] = round(k_ms / (pms * algo_bytes / (2.2 * src_bytes)), 4)  # (probe scaled to the kernel's algorithmic bytes)
+        except Exception as e:  # (diagnostics: never in the way of the line)
+            box["error"] = f"{type(e).__name__}: {e}"
+        result["box"] = box
     if rank == 0:
         print(json.dumps(result))
     d_ops = d_ws = d_rows = d_out = rows_t = None

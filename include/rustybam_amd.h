@@ -250,6 +250,10 @@ void rb_plan_destroy(rb_plan *plan);
 /* bytes of device workspace rb_dev_liftover / rb_dev_break need for this plan and row capacity (the workspace must be
  * 256-byte aligned, as rb_dev_alloc returns it) */
 size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap);
+/* diagnostics (bench.py's box block): byte offset, inside that workspace, of [n_rec] u32 words in which the diagnostics build of the
+ * clip kernel leaves the 100 MHz clock (low 32 bits) at which the wave of schedule slot w was done.  Written only by calls whose
+ * policy carries the undocumented debug bits; the product's kernels never touch the area. */
+size_t rb_plan_diag_stamps_offset(const rb_plan *plan, uint64_t rows_cap);
 /* out_ops capacity (in ops) with which rb_dev_liftover (for_break = 0) / rb_dev_break (1) can emit every clip while the record
  * streams past: the clipped cigars go to up to 4 positional copies of the batch's op index space (as many as the sorted window
  * lists overlap deep; two for break-paf), and only rows' out_off says where a clip is.  A smaller out_cap still works -- clips
@@ -471,10 +475,19 @@ int rb_host_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t n_regions,
 int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const rb_hit_row *rows, uint64_t n_rows, const uint32_t *out_ops,
                        uint64_t row_base, uint64_t rec_base, uint64_t *digest);
 
+/* ---- diagnostics: the box (bench.py's `box` block; not a reference function) ------------------------------------------- *
+ * Moves the clip kernel's memory mix without its instructions: every wave reads a 20 KiB stretch of src[0 .. src_bytes) in the clip
+ * kernel's access shape and writes it to dst0 (all of it) and dst1 (a fifth of it); both need src_bytes of room.  reps launches
+ * back to back; *ms_out = mean time of one, *mhz_out (may be NULL) = the shader clock held meanwhile, from s_memtime / s_memrealtime
+ * stamps around each wave's loop. */
+int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, double *ms_out, double *mhz_out);
+
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and
  * device versions produce identical bytes.  n_ops per record comes from rb_synth_n_ops. */
 uint32_t rb_synth_n_ops(uint64_t seed, uint64_t record, uint32_t lo, uint32_t hi);
+/* the "imbalance" shape of SURVEY.md 8(d): log-normal (mu = ln 2000, sigma = 1.35) clipped to [31, 80000] ops, forced odd */
+uint32_t rb_synth_n_ops_lognormal(uint64_t seed, uint64_t record);
 void rb_synth_fill_ops_host(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops);
 int rb_dev_synth_fill_ops(rb_ctx *ctx, uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off_dev,
                           uint32_t *ops_dev);

@@ -62,6 +62,7 @@ def lib():
         _lib.rb_ctx_last_error.restype = C.c_char_p
         _lib.rb_ctx_stream.restype = C.c_void_p
         _lib.rb_plan_workspace_bytes.restype = C.c_size_t
+        _lib.rb_plan_diag_stamps_offset.restype = C.c_size_t
         _lib.rb_plan_out_capacity.restype = C.c_uint64
         _lib.rb_synth_n_ops.restype = C.c_uint32
         _lib.rb_synth_n_ops.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
@@ -218,6 +219,16 @@ class Engine:
 
     def plan_workspace_bytes(self, plan, rows_cap):
         return int(self.L.rb_plan_workspace_bytes(plan, C.c_uint64(rows_cap)))
+
+    def dev_box_probe(self, src_ptr, src_bytes, dst0_ptr, dst1_ptr, reps=10):
+        """-> (ms per launch, shader MHz held): the clip kernel's memory mix without its instructions (diagnostics)."""
+        ms, mhz = C.c_double(0), C.c_double(0)
+        self._chk(self.L.rb_dev_box_probe(self.ctx, C.c_void_p(src_ptr), C.c_uint64(src_bytes), C.c_void_p(dst0_ptr), C.c_void_p(dst1_ptr),
+                                          C.c_int(reps), C.byref(ms), C.byref(mhz)), "rb_dev_box_probe")
+        return ms.value, mhz.value
+
+    def plan_diag_stamps_offset(self, plan, rows_cap):
+        return int(self.L.rb_plan_diag_stamps_offset(plan, C.c_uint64(rows_cap)))
 
     def dev_liftover(self, plan, view, norm_ptr, policy, ws_ptr, rows_ptr, rows_cap, out_ptr, out_cap, counters_ptr):
         self._chk(self.L.rb_dev_liftover(self.ctx, plan, C.byref(view), C.c_void_p(norm_ptr), C.c_int(policy),

@@ -311,16 +311,26 @@ struct rb_vmm_alloc {
 };
 static std::map<void *, rb_vmm_alloc> g_vmm;
 static std::mutex g_vmm_mu;
-static bool rb_free_vmm(void *p) {
+// -> 0: not one of ours; 1: released; -1: a HIP call failed (*err names it; the pieces that could be given back have been)
+static int rb_free_vmm(void *p, int device, hipError_t *err) {
     std::lock_guard<std::mutex> lk(g_vmm_mu);
     auto it = g_vmm.find(p);
-    if (it == g_vmm.end()) return false;
-    (void)hipDeviceSynchronize();
-    (void)hipMemUnmap(p, it->second.bytes);
-    for (auto &h : it->second.handles) (void)hipMemRelease(h);
-    (void)hipMemAddressFree(p, it->second.bytes);
+    if (it == g_vmm.end()) return 0;
+    hipError_t first = hipSuccess;
+    auto note = [&](hipError_t e) {
+        if (e != hipSuccess && first == hipSuccess) first = e;
+    };
+    note(hipSetDevice(device));       // (the buffer's device, not whatever is current: kernels on it must have drained)
+    note(hipDeviceSynchronize());
+    // every chunk is a mapping of its own: HIP promises the unmapping of whole mappings, not of a range that spans several
+    const size_t chunk = it->second.chunk, n = it->second.handles.size();
+    for (size_t k = 0; k < n; k++) note(hipMemUnmap((char *)p + k * chunk, chunk));
+    for (auto &h : it->second.handles) note(hipMemRelease(h));
+    note(hipMemAddressFree(p, it->second.bytes));
     g_vmm.erase(it);
-    return true;
+    if (first != hipSuccess) (void)hipGetLastError();
+    *err = first;
+    return first == hipSuccess ? 1 : -1;
 }
 static void *rb_alloc_vmm(int device, size_t bytes, bool shuffle) {
     hipMemAllocationProp prop;
@@ -368,7 +378,7 @@ static void *rb_alloc_vmm(int device, size_t bytes, bool shuffle) {
     }
     if (!ok) { // give everything back: the caller falls back to hipMalloc
         (void)hipGetLastError();
-        if (mapped) (void)hipMemUnmap(va, mapped * chunk);
+        for (size_t k = 0; k < mapped; k++) (void)hipMemUnmap((char *)va + k * chunk, chunk);
         for (auto &hk : h) (void)hipMemRelease(hk);
         (void)hipMemAddressFree(va, n * chunk);
         return nullptr;
@@ -413,8 +423,13 @@ extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
 }
 extern "C" int rb_dev_free(rb_ctx *ctx, void *dev_ptr) {
     if (!ctx) return RB_E_INVALID;
-    if (dev_ptr && rb_free_vmm(dev_ptr)) return RB_OK;
-    if (dev_ptr) HIPCHK(ctx, hipFree(dev_ptr));
+    if (!dev_ptr) return RB_OK;
+    hipError_t e = hipSuccess;
+    const int mine = rb_free_vmm(dev_ptr, ctx->device, &e);
+    if (mine < 0) return fail(ctx, RB_E_HIP, "rb_dev_free (chunked buffer): %s", hipGetErrorString(e));
+    if (mine > 0) return RB_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipFree(dev_ptr));
     return RB_OK;
 }
 static bool pin_ready(rb_ctx *ctx) {
@@ -654,8 +669,14 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, decl_count, decl_list, gen_cp, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, decl_count, decl_list, gen_cp, diag_stamps, total;
 };
+// RB_DEBUG_NO_GEN_CP (diagnostics: the generic kernel walks every record from its first op, no room for checkpoints): read ONCE per
+// process -- the workspace layout and the kernel parameter must agree on it
+static bool rb_no_gen_cp() {
+    static const bool v = getenv("RB_DEBUG_NO_GEN_CP") != nullptr;
+    return v;
+}
 static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap, uint64_t n_ops) {
     ws_layout w;
     size_t o = 0;
@@ -682,14 +703,18 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap, uint64_t n_ops) {
     w.copy_list = take((rows_cap + 1) * 16);
     w.decl_count = take(256);
     w.decl_list = take((n_rec + 1) * 4); // break-paf in one walk: the records its clip kernel declined
-    static const bool no_gen_cp = getenv("RB_DEBUG_NO_GEN_CP") != nullptr; // (diagnostics: no checkpoints, no room for them)
-    w.gen_cp = take(no_gen_cp ? 256 : (size_t)(n_ops / RB_GCP + n_rec + 2) * sizeof(uint4)); // checkpoints of the records the generic kernel works on
+    w.gen_cp = take(rb_no_gen_cp() ? 256 : (size_t)(n_ops / RB_GCP + n_rec + 2) * sizeof(uint4)); // checkpoints of the records the generic kernel works on
+    w.diag_stamps = take((n_rec + 1) * 4); // diagnostics build of the clip kernel: when each record's wave was done
     w.total = o;
     return w;
 }
 extern "C" size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap) {
     if (!plan) return 0;
     return ws_of(plan->n_rec, rows_cap, plan->n_ops).total;
+}
+extern "C" size_t rb_plan_diag_stamps_offset(const rb_plan *plan, uint64_t rows_cap) {
+    if (!plan) return 0;
+    return ws_of(plan->n_rec, rows_cap, plan->n_ops).diag_stamps;
 }
 
 // ops per output slot: the batch's op index space, 32 ops (one 128-byte line) of room per record (records that share a line in the
@@ -764,7 +789,8 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.copy_list = (uint4 *)(ws + w.copy_list);
     p.copy_count = (unsigned long long *)(ws + w.copy_count);
     p.gen_list = (uint32_t *)(ws + w.gen_list);
-    p.gen_cp = getenv("RB_DEBUG_NO_GEN_CP") ? nullptr : (uint4 *)(ws + w.gen_cp); // (diagnostics: every generic walk from the record's first op, as before round 3)
+    p.gen_cp = rb_no_gen_cp() ? nullptr : (uint4 *)(ws + w.gen_cp);
+    p.diag_stamps = (uint32_t *)(ws + w.diag_stamps); // (diagnostics: every generic walk from the record's first op, as before round 3)
     p.jobs = (rb_job *)(ws + w.jobs);
     p.fused = (policy & RB_LIFT_FUSED_SCAN) ? 1 : 0;
     p.norm_w = const_cast<rb_norm_row *>(norm);
@@ -1022,6 +1048,7 @@ extern "C" int rb_dev_trim_select(rb_ctx *ctx, uint64_t n_rec, uint64_t n_groups
 }
 extern "C" int rb_dev_trim_check(rb_ctx *ctx, uint64_t n_pairs, const rb_pair_row *rows, rb_trim_pass *pass) {
     if (!ctx || !pass || (n_pairs && !rows)) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, rb_launch_trim_check(rows, n_pairs, pass, ctx->stream));
     return RB_OK;
 }
@@ -1736,6 +1763,7 @@ extern "C" int rb_host_overlap_split(rb_ctx *ctx, uint64_t n_rec, const uint32_t
 // ---- synthetic workload --------------------------------------------------------------------------
 #include "synth.h"
 extern "C" uint32_t rb_synth_n_ops(uint64_t seed, uint64_t record, uint32_t lo, uint32_t hi) { return rb_synth_n_ops_impl(seed, record, lo, hi); }
+extern "C" uint32_t rb_synth_n_ops_lognormal(uint64_t seed, uint64_t record) { return rb_synth_n_ops_lognormal_impl(seed, record); }
 extern "C" void rb_synth_fill_ops_host(uint64_t seed, uint64_t first_record, uint64_t n_rec, const uint64_t *op_off, uint32_t *ops) {
     for (uint64_t r = 0; r < n_rec; r++) {
         const uint64_t n = op_off[r + 1] - op_off[r];
@@ -1774,6 +1802,40 @@ extern "C" int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const
     p.digest = (unsigned long long *)digest;
     HIPCHK(ctx, rb_launch_digest_rows(&p, ctx->stream));
     return RB_OK;
+}
+
+// ---- the box: what this GPU moves at the clip kernel's memory mix, and the clock it holds meanwhile (diagnostics for bench.py) ----
+extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, hipStream_t stream);
+extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, double *ms_out, double *mhz_out) {
+    if (!ctx || !src || !dst0 || !dst1 || !ms_out || reps < 1) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_stretch = src_bytes / (10 * 2048);
+    if (n_stretch == 0) return RB_E_INVALID;
+    uint32_t *stamps = nullptr;
+    HIPCHK(ctx, hipMalloc((void **)&stamps, 64));
+    hipEvent_t a = nullptr, b = nullptr;
+    int rc = RB_OK;
+    auto chk = [&](hipError_t e) {
+        if (e != hipSuccess && rc == RB_OK) rc = fail(ctx, RB_E_HIP, "rb_dev_box_probe: %s", hipGetErrorString(e));
+    };
+    chk(hipEventCreate(&a));
+    chk(hipEventCreate(&b));
+    chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, ctx->stream)); // (untimed: first touch)
+    chk(hipMemsetAsync(stamps, 0, 64, ctx->stream));
+    chk(hipEventRecord(a, ctx->stream));
+    for (int i = 0; i < reps && rc == RB_OK; i++) chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, ctx->stream));
+    chk(hipEventRecord(b, ctx->stream));
+    chk(hipEventSynchronize(b));
+    float ms = 0;
+    if (rc == RB_OK) chk(hipEventElapsedTime(&ms, a, b));
+    uint32_t h[4] = {0, 0, 0, 0};
+    if (rc == RB_OK) chk(hipMemcpy(h, stamps, 16, hipMemcpyDeviceToHost));
+    *ms_out = ms / reps;
+    if (mhz_out) *mhz_out = h[1] ? (double)h[0] * 64.0 / (double)h[1] * 100.0 : 0.0; // cycles per 10 ns tick x 100 MHz
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(stamps);
+    return rc;
 }
 
 // ---- nucfreq ----------------------------------------------------------------------------------------------------------

@@ -213,9 +213,24 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 // v[RB_RING_BASE .. RB_RING_BASE + 8 RB_PF), named literally in the asm statements that load, store and copy it out.  A ring the
 // compiler can see gets copied between registers where two code paths meet (phi copies) -- harmless for ordinary values, fatal
 // for registers with a load in flight, which no s_waitcnt of the compiler's covers.
+#define RB_STR2(x) #x
+#define RB_STR(x) RB_STR2(x)
 #ifndef RB_RING_BASE
 #define RB_RING_BASE 80
-#define RB_RING_TOP "v95" // the last register of the ring (RB_RING_BASE + 8 RB_PF - 1): named as a clobber so that the kernel's register count covers it
+#endif
+#if RB_RING_BASE == 80
+#define RB_RING_TOP_N 95
+#elif RB_RING_BASE == 88
+#define RB_RING_TOP_N 103
+#elif RB_RING_BASE == 96
+#define RB_RING_TOP_N 111
+#elif RB_RING_BASE == 104
+#define RB_RING_TOP_N 119
+#else
+#error "RB_RING_BASE: 80, 88, 96 or 104"
+#endif
+#ifndef RB_RING_TOP
+#define RB_RING_TOP "v" RB_STR(RB_RING_TOP_N) // the last register of the ring (RB_RING_BASE + 8 RB_PF - 1): named as a clobber so that the kernel's register count covers it
 // (NOT all sixteen: a register named as clobbered is one the compiler may use for its own temporaries between two asm statements --
 //  tried, it did.  What keeps the compiler out of the ring is amdgpu_num_vgpr, with one gap: the VGPRs it spills scalar registers into
 //  are placed behind its own allocation, and one build of this kernel had them at v78 v79 v80.  tests/test_ring_registers.py
@@ -224,30 +239,29 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef RB_SPILL_ROOM
 #define RB_SPILL_ROOM 0 // registers between the compiler's allocation and the ring, for the VGPRs it parks spilled scalar registers in
 #endif
-#define RB_STR2(x) #x
-#define RB_STR(x) RB_STR2(x)
 // registers OFF .. OFF + W of the ring, as the assembler reads them (it evaluates the sums)
 #define RB_RREG(OFF, W) "v[" RB_STR(RB_RING_BASE) "+" #OFF ":" RB_STR(RB_RING_BASE) "+" #OFF "+" #W "]"
 static_assert(RB_PF == 2, "the ring's asm statements are written out for two slots");
 // BRK: break-paf in one walk (rb_lift.h, brk_max): the windows of a record are not given, they are the stretches between the indels
 // longer than brk_max, found while the record streams; 32 pieces a pass.  The liftover build has none of that code.
-template <bool BRK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), amdgpu_num_vgpr(RB_RING_BASE - RB_SPILL_ROOM))) void rb_k_liftover_stream(rb_lift_params p_) {
+// DIAG: the diagnostics build of the same kernel (bench.py --debug-skip: phases switched off, phase timers, clock stamps); the product
+// launches DIAG = false, in which no stamp executes and no debug bit is looked at.
+template <bool BRK, bool DIAG>
+__device__ __forceinline__ void rb_stream_record() {
     // The 408 bytes of parameters are NOT read through `p_`: the compiler loads every by-value kernel argument a kernel uses in
     // its entry block and then carries -- spills -- those hundred scalar registers through the whole record (round 2: 233 SGPR
     // spills, parked in VGPRs right under the load ring).  `p.field` below reads the field from the kernel-argument segment where
     // it is used, through a pointer the compiler cannot see through (one s_load at that place); what the streaming loop needs is
     // copied into locals in front of it.
-    (void)p_;
+#ifdef RB_RING_FENCE
+    asm volatile("" ::: "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+#endif
     const rb_kparams kp = (rb_kparams)__builtin_amdgcn_kernarg_segment_ptr();
     rb_kparams kq = rb_kp_here(kp); // the pointer of the current phase (set-up / after the stream of a pass): loads through it stay inside the phase
 #define p (*kq)
-    // diagnostics (bench.py --debug-skip: phases of the kernel switched off, phase timers) only in builds made with -DRB_DIAG=1
-    // (tools/mkvariant.sh): every tested bit is a wave-uniform boolean, i.e. two scalar registers held through the whole record
-#ifndef RB_DIAG
-#define RB_DIAG 0
-#endif
-    const int dbg = RB_DIAG ? p.debug_skip : 0;
+    // diagnostics (bench.py --debug-skip: phases of the kernel switched off, phase timers, clock stamps) only in the DIAG
+    // instantiation: every tested bit is a wave-uniform boolean, i.e. two scalar registers held through the whole record
+    const int dbg = DIAG ? p.debug_skip : 0;
     // checkpoints: exclusive (R,Q,U) prefixes every 16 ops, SoA so that R can be binary-searched
     __shared__ uint32_t cp_all[4][3][RB_SMAX * RB_CP_PER_STEP];
     __shared__ uint32_t wx_all[4][RB_HMAX + 1]; // window indices of one pass over a window list that is not sorted
@@ -420,6 +434,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         uint32_t v_carry = 0xFu;       // last op word of the previous step (code 15: equals nothing)
         unsigned long long v_utot = 0; // 64-bit sum of all lengths
         const bool streams = BRK || ((__ballot(need) != 0 || validate || (spec && any_inside)) && !(dbg & 4));
+        // diagnostics (dbg & 128): the clock this kernel holds while it streams -- s_memtime counts shader cycles, s_memrealtime a
+        // constant 100 MHz -- stamped around the streaming loop of every 16th record, summed into counters->phase[0] (64 cycles) and
+        // phase[1] (10 ns); phase[2] counts the stamped records.  Nothing reads these words on the device.
+        unsigned long long ck_c0 = 0, ck_r0 = 0;
+        if (dbg & 128) ck_c0 = __builtin_amdgcn_s_memtime(), ck_r0 = __builtin_amdgcn_s_memrealtime();
         if (streams) {
             // The load ring and the speculative stores are written by hand.  vmcnt retires in issue order on gfx9 and counts
             // loads and stores together; left to the compiler, the wait for a step's loads would also wait for the stores of
@@ -460,12 +479,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
             RB_RING_LOAD(0, seg_first * RB_SMAX)
             { RB_RING_NOSTORES }
             RB_RING_LOAD(1, seg_first * RB_SMAX + 1u)
-            uint32_t j_lo = 0, j_hi = 0, k_lo = (uint32_t)(jb % (n_slots ? n_slots : 1u)); // clips that can touch the current step: [j_lo, j_hi); class of j_lo
+            // Speculative emission, per slot ("class") q: the CURRENT clip of the class -- its index among the pass's clips and its span in
+            // reference offsets [c_ds, c_de) --, wave-uniform.  The clips of a class follow one another along the record (sorted windows),
+            // so a step looks at the current clip and moves on only when that clip ends inside the step (round 3 kept a window [j_lo, j_hi)
+            // over all classes and ran a scalar loop over it in every step: 60 of the step's 140 scalar instructions).
+            uint32_t c_j[RB_MS], c_ds[RB_MS], c_de[RB_MS];
+            auto clip_fetch = [&](const int q) { // (D lives in lanes: lane j the start of clip j, lane 32 + j its end)
+                const bool ok = c_j[q] < nb;
+                const uint32_t jj = ok ? c_j[q] : 0u;
+                const uint32_t ds_ = rb_readlane<uint32_t>(D, (int)jj), de_ = rb_readlane<uint32_t>(D, (int)(32u + jj));
+                c_ds[q] = ok ? ds_ : 0xFFFFFFFFu; // (no clip: a span no chunk reaches)
+                c_de[q] = ok ? de_ : 0xFFFFFFFFu;
+            };
+#pragma unroll
+            for (int q = 0; q < RB_MS; q++) { // clip j of the pass is of class (jb + j) mod n_slots
+                const uint32_t ns_ = n_slots ? n_slots : 1u;
+                c_j[q] = (uint32_t)q < n_slots ? ((uint32_t)q + ns_ - (uint32_t)(jb % ns_)) % ns_ : 0x7FFFFFFFu;
+                clip_fetch(q);
+            }
             uint32_t Rseg = 0, Qseg = 0, Useg = 0, seg0 = 0;
             // one step of the stream; EDGE = the record's first or last step (ops of the neighbours around it)
-            auto step = [&](auto ring_c, auto edge_c, const uint32_t st, const uint32_t seg1) {
+            // FAST = what nearly every step is, told to the compiler as constants: an interior step (no op of a neighbouring record in
+            // it, inside its segment) of a record's first pass with the fused verification and the speculative stores on.  The
+            // general form tests each of these per step; where the two forms met in one loop body the compiler moved two dozen
+            // values from one set of registers to another between steps.
+            auto step = [&](auto ring_c, auto edge_c, auto fast_c, const uint32_t st, const uint32_t seg1) {
                 constexpr int ring = decltype(ring_c)::value;
                 constexpr bool edge = decltype(edge_c)::value;
+                constexpr bool fast = decltype(fast_c)::value;
+                static_assert(!(fast && edge), "a fast step is an interior step");
+                const bool validate_s = fast ? true : validate, spec_s = fast ? true : spec, later_s = fast ? false : (jb != 0);
                 // the step's 8 ops leave the ring for registers of the compiler's choosing once they have landed
                 // (no memory clobber: the compiler takes an asm that may load for a load still in flight and waits vmcnt(0) at the first use of its outputs)
                 unsigned long long a0, a1, a2, a3;
@@ -480,7 +523,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 unsigned long long msk[RB_MS];
 #pragma unroll
                 for (int q = 0; q < RB_MS; q++) msk[q] = 0ull;
-                if (st < seg1) { // (no break: the ring must be in the same state on every path)
+                if (fast || st < seg1) { // (no break: the ring must be in the same state on every path)
                     uint32_t w[8] = {(uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32),
                                      (uint32_t)a2, (uint32_t)(a2 >> 32), (uint32_t)a3, (uint32_t)(a3 >> 32)};
                     uint32_t c[8]; // what the verification looks at
@@ -497,7 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                             w[q] = ok ? w[q] : 0u;
                         }
                     }
-                    if (validate) {
+                    if (validate_s) {
                         const uint32_t prevw = rb_prev_lane(c[7], v_carry); // previous lane's last op; lane 0: the previous step's
                         v_carry = rb_readlane<uint32_t>(c[7], 63);
                         uint32_t rg[8], x[8];
@@ -542,7 +585,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                     Rb += rb_readlane<uint32_t>(ir, 63);
                     Qb += rb_readlane<uint32_t>(iq, 63);
                     Ub += rb_readlane<uint32_t>(iu, 63);
-                    if (validate) {
+                    if (validate_s) {
                         v_maxsu = v_maxsu > su ? v_maxsu : su;
                         v_utot += rb_readlane<uint32_t>(iu, 63);
                     }
@@ -556,6 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                             lane_big |= (cq == RB_OP_I || cq == RB_OP_D) && rb_len(w[q]) > brk_max_;
                         }
                         unsigned long long cm = __ballot(lane_big);
+                        const bool had_big = cm != 0ull;
                         const uint32_t lane_r0 = R0 + ir - sr; // reference offset of my first op
                         while (cm) {
                             const int l = __builtin_ctzll(cm);
@@ -591,27 +635,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                             }
                         }
                         nb = brk_cnt < brk_j0 ? 0u : (brk_cnt - brk_j0 + 1u < 32u ? brk_cnt - brk_j0 + 1u : 32u);
+                        if (had_big) { // pieces were closed / opened: the classes' current clips are read again
+#pragma unroll
+                            for (int q = 0; q < RB_MS; q++) clip_fetch(q);
+                        }
                     }
-                    if (spec) {
+                    if (spec_s) {
                         // Which of this lane's 8 ops a clip keeps is not known yet (boundaries are resolved per segment),
                         // but which 8-op chunks can hold ops of clip j is: those whose reference span [cR, cE) reaches
                         // from the clip's first base (D_start - 1) to its last one (D_end - 1); walking to the next /
                         // previous match op only shrinks a clip.  Those chunks are stored as they are -- what lies
                         // outside the clip is never read, and the two end groups are rewritten with the clipped
                         // lengths once the boundaries are resolved.
-                        while (j_hi < nb && rb_readlane<uint32_t>(D, (int)j_hi) <= Rb) j_hi++;
-                        while (j_lo < j_hi && rb_readlane<uint32_t>(D, (int)(32u + j_lo)) <= R0) {
-                            j_lo++;
-                            k_lo = (k_lo + 1u == n_slots) ? 0u : k_lo + 1u;
-                        }
                         const uint32_t cR = R0 + ir - sr, cE = R0 + ir;
-                        uint32_t k = k_lo;
-                        for (uint32_t j = j_lo; j < j_hi; j++) {
-                            const uint32_t ds = rb_readlane<uint32_t>(D, (int)j), de = rb_readlane<uint32_t>(D, (int)(32u + j));
-                            const unsigned long long mk = __ballot(cR < de && cE >= ds);
 #pragma unroll
-                            for (int q = 0; q < RB_MS; q++) msk[q] |= (k == (uint32_t)q) ? mk : 0ull;
-                            k = (k + 1u == n_slots) ? 0u : k + 1u;
+                        for (int q = 0; q < RB_MS; q++) {
+                            unsigned long long mk = 0ull;
+                            for (;;) {
+                                mk |= rb_ballot(cR < c_de[q] && cE >= c_ds[q]);
+                                if (c_de[q] > Rb) break; // the clip reaches past this step (or there is none): it stays the current one
+                                c_j[q] += n_slots;       // it ends in this step: the class's next clip may begin in it
+                                clip_fetch(q);
+                                if (c_j[q] >= nb) break;
+                            }
+                            msk[q] = mk;
                         }
                     }
                 }
@@ -621,16 +668,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                     const unsigned long long sv_st = sv_exec;
                     unsigned long long v0 = sv_st, v1 = sv_st;
                     if (edge) { // groups in front of the record's first and behind its last one are not this record's to write
-                        v0 = __ballot(so + 16u > first_boff && so <= last_boff);
-                        v1 = __ballot(so + 32u > first_boff && so + 16u <= last_boff);
+                        v0 = rb_ballot(so + 16u > first_boff && so <= last_boff);
+                        v1 = rb_ballot(so + 32u > first_boff && so + 16u <= last_boff);
                     }
 #pragma unroll
                     for (int q = 0; q < RB_MS; q++) {
                         unsigned long long m0 = msk[q] & v0, m1 = msk[q] & v1;
-                        if (jb != 0 && msk[q] != 0ull) { // later passes stay clear of the end groups earlier passes have patched
+                        if (later_s && msk[q] != 0ull) { // later passes stay clear of the end groups earlier passes have patched
                             const uint32_t c0 = (st << RB_STEP_SHIFT) + (uint32_t)lane * 8u;
-                            m0 &= __ballot(c0 >= carry[q]);
-                            m1 &= __ballot(c0 + 4u >= carry[q]);
+                            m0 &= rb_ballot(c0 >= carry[q]);
+                            m1 &= rb_ballot(c0 + 4u >= carry[q]);
                         }
 #ifdef RB_LINE_ROUND
                         { // whole 128-byte lines (4 lanes): a partly written line costs a read of the rest
@@ -661,6 +708,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 }
                 RB_RING_LOAD(ring, st + RB_PF)
             };
+#ifndef RB_FAST
+#define RB_FAST 0 // (1 needs more vector registers than the ring at v80 leaves: tools/check_ring.py)
+#endif
+            const bool fast_ok = RB_FAST && validate && spec && jb == 0 && !DIAG;
             for (seg0 = seg_first * RB_SMAX; seg0 < n_steps; seg0 += RB_SMAX) {
                 const uint32_t seg1 = (seg0 + RB_SMAX < n_steps) ? seg0 + RB_SMAX : n_steps;
                 Rseg = Rb, Qseg = Qb, Useg = Ub;
@@ -668,14 +719,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
                 // the ring is indexed statically (unrolled by RB_PF): rotating it with register moves would make
                 // every step wait for ALL loads in flight (the moves read their destination registers)
                 for (uint32_t st0 = seg0; st0 < seg1; st0 += RB_PF) {
+#ifndef RB_DBG_ALL_EDGE
+                    if (fast_ok && st0 != 0u && st0 + RB_PF < n_steps) { // every step of the turn is interior (and inside the segment: RB_SMAX is whole turns)
+                        rb_static_for<RB_PF>([&](auto ring_c) { step(ring_c, std::false_type{}, std::true_type{}, st0 + (uint32_t)decltype(ring_c)::value, seg1); });
+                        continue;
+                    }
+#endif
                     rb_static_for<RB_PF>([&](auto ring_c) {
                         const uint32_t st = st0 + (uint32_t)decltype(ring_c)::value;
 #ifdef RB_DBG_ALL_EDGE
-                        if (true) step(ring_c, std::true_type{}, st, seg1);
+                        if (true) step(ring_c, std::true_type{}, std::false_type{}, st, seg1);
 #else
-                        if (st == 0 || st + 1 >= n_steps) step(ring_c, std::true_type{}, st, seg1);
+                        if (st == 0 || st + 1 >= n_steps) step(ring_c, std::true_type{}, std::false_type{}, st, seg1);
 #endif
-                        else step(ring_c, std::false_type{}, st, seg1);
+                        else step(ring_c, std::false_type{}, std::false_type{}, st, seg1);
                     });
                 }
                 // ---- lane-parallel resolution of the boundaries that fall in this segment ----
@@ -734,6 +791,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
 #undef RB_RING_LOAD
 #undef RB_RING_LOAD_ASM
 #undef RB_RING_NOSTORES
+        }
+        if (dbg & 128) {
+            const unsigned long long ck_c1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
+            if (lane == 0 && (wave & 15) == 0) {
+                atomicAdd(&p.counters->phase[0], (uint32_t)((ck_c1 - ck_c0) >> 6));
+                atomicAdd(&p.counters->phase[1], (uint32_t)(ck_r1 - ck_r0));
+                atomicAdd(&p.counters->phase[2], 1u);
+            }
         }
         resume_seg = next_seg, resume_R = next_R, resume_Q = next_Q, resume_U = next_U;
         kq = rb_kp_here(kp); // (what the rows, patches and lists below need is loaded from here on, not carried through the stream)
@@ -976,8 +1041,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), am
         RB_PHASE(4)
         } // (behind the stream)
     }
+    if ((dbg & 256) && lane == 0) p.diag_stamps[wave] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 }
 #undef p
+// the builds of the kernel (an attribute cannot depend on a template parameter): liftover, break-paf in one walk, and the
+// diagnostics build of the liftover form
+#define RB_STREAM_KERNEL(NAME, BRK, DIAG, ROOM)                                                                                   \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), amdgpu_num_vgpr(RB_RING_BASE - (ROOM)))) void NAME(rb_lift_params p_) { \
+        (void)p_; /* (read through the kernel-argument segment, see the top of rb_stream_record) */                                \
+        rb_stream_record<BRK, DIAG>();                                                                                            \
+    }
+RB_STREAM_KERNEL(rb_k_liftover_stream, false, false, RB_SPILL_ROOM)
+RB_STREAM_KERNEL(rb_k_liftover_stream_brk, true, false, RB_SPILL_ROOM)
+RB_STREAM_KERNEL(rb_k_liftover_stream_diag, false, true, 4)
+// (no diagnostics build of the break form: its spilled scalar registers land in the ring -- tools/check_ring.py --, and nothing asks for it)
 
 // ------------------------------------------------------------------------------------------------
 // clips that found no place of their own in a slot (windows overlapping deeper than the slots, window lists that are
@@ -1815,8 +1892,14 @@ extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStre
     const unsigned blocks = (unsigned)(((uint64_t)(p->wave_end - p->wave0) + 3) / 4);
     // diagnostics: RB_DEBUG_DYN_LDS=<bytes> adds unused dynamic LDS to lower the occupancy
     static const unsigned dyn = getenv("RB_DEBUG_DYN_LDS") ? (unsigned)atoi(getenv("RB_DEBUG_DYN_LDS")) : 0u;
-    if (p->brk_mode) hipLaunchKernelGGL(rb_k_liftover_stream<true>, dim3(blocks), dim3(256), dyn, stream, *p);
-    else hipLaunchKernelGGL(rb_k_liftover_stream<false>, dim3(blocks), dim3(256), dyn, stream, *p);
+    if (p->debug_skip) { // diagnostics only (bench.py --debug-skip, the box block's clock stamps)
+        if (!p->brk_mode) {
+            hipLaunchKernelGGL(rb_k_liftover_stream_diag, dim3(blocks), dim3(256), dyn, stream, *p);
+            return hipGetLastError();
+        }
+    }
+    if (p->brk_mode) hipLaunchKernelGGL(rb_k_liftover_stream_brk, dim3(blocks), dim3(256), dyn, stream, *p);
+    else hipLaunchKernelGGL(rb_k_liftover_stream, dim3(blocks), dim3(256), dyn, stream, *p);
     return hipGetLastError();
 }
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream) {

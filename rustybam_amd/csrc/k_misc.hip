@@ -429,3 +429,45 @@ extern "C" hipError_t rb_launch_compact_clips(const rb_compact_params *p, hipStr
     else hipLaunchKernelGGL(rb_k_compact_clips, dim3((unsigned)((p->n_rows + 3) / 4)), dim3(256), 0, stream, *p);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------
+// rb_dev_box_probe: what THIS box moves at the clip kernel's memory mix, without the clip kernel's instructions.  Every wave owns a
+// 20 KiB stretch of `src` (a 5120-op record) and walks it in ten 2 KiB steps in the clip kernel's shape -- 32 contiguous bytes per lane as
+// two 16-byte loads --, storing every step into slot 0 and every fifth one into slot 1 as well (about 1.2 bytes written per byte read:
+// config 3's ratio).  Around the loop the wave stamps s_memtime (shader cycles) and s_memrealtime (100 MHz): the clock the chip holds
+// under this memory load comes out with the time (bench.py's `box` block; tools/st_probe.hip is the stand-alone form of it).
+// ------------------------------------------------------------------------------------------------
+typedef uint32_t rb_bp_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ src, char *__restrict__ d0, char *__restrict__ d1, uint64_t n_stretch,
+                                                      uint32_t *stamps /* [3]: sum of cycles >> 6, sum of 10 ns ticks, stamped waves */) {
+    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_stretch) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const uint64_t base = w * (uint64_t)(10 * 2048) + (uint64_t)lane * 32;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t acc = 0;
+#pragma unroll 2
+    for (int s = 0; s < 10; s++) {
+        const uint64_t o = base + (uint64_t)s * 2048;
+        const rb_bp_u32x4 a = *(const rb_bp_u32x4 *)(src + o), b = *(const rb_bp_u32x4 *)(src + o + 16);
+        acc += a.x ^ b.y;
+        *(rb_bp_u32x4 *)(d0 + o) = a;
+        *(rb_bp_u32x4 *)(d0 + o + 16) = b;
+        if (s % 5 == 0) {
+            *(rb_bp_u32x4 *)(d1 + o) = a;
+            *(rb_bp_u32x4 *)(d1 + o + 16) = b;
+        }
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && (w & 15) == 0) {
+        atomicAdd(&stamps[0], (uint32_t)((c1 - c0) >> 6));
+        atomicAdd(&stamps[1], (uint32_t)(r1 - r0));
+        atomicAdd(&stamps[2], 1u);
+    }
+    if (acc == 0x12345678u) stamps[3] = acc; // (keeps the loads)
+}
+extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, hipStream_t stream) {
+    if (n_stretch == 0) return hipSuccess;
+    hipLaunchKernelGGL(rb_k_box_probe, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    return hipGetLastError();
+}

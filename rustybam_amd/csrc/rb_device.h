@@ -84,6 +84,8 @@ __device__ __forceinline__ uint64_t rb_readlane<uint64_t>(uint64_t v, int lane) 
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
     return ((uint64_t)hi << 32) | lo;
 }
+// wave64 ballot straight from the comparison (HIP's __ballot goes through an i32: v_cndmask + v_cmp_ne on top of the v_cmp)
+#define rb_ballot(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64(pred))
 __device__ __forceinline__ uint32_t rb_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t rb_first64(uint64_t v) {
     uint32_t lo = rb_first((uint32_t)v), hi = rb_first((uint32_t)(v >> 32));

@@ -101,6 +101,9 @@ struct rb_lift_params {
     // / RB_GCP + r + k], the units / reference / query / match bases of the record so far (rb_k_generic_checkpoints): a hit starts its
     // walks at the checkpoint in front of its window instead of at the record's first op.  NULL: every walk starts at the first op.
     uint4 *gen_cp;
+    // diagnostics build of the clip kernel only (debug_skip & 256): [n_rec] the 100 MHz clock (low 32 bits) at which schedule slot w's
+    // wave was done with its record -- how long a launch runs on after most of its waves have retired
+    uint32_t *diag_stamps;
 };
 #define RB_GCP 256u
 

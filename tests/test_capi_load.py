@@ -51,3 +51,18 @@ def test_synth_host_generator_shape():
     # counter based: regenerating a sub-range gives the same bytes
     sub = capi.synth_fill_ops_host(0x5EED0002, 5, off[5:8] - off[5])
     assert np.array_equal(sub, ops[int(off[5]):int(off[7])])
+
+
+def test_lognormal_op_counts_c_and_numpy_twins_agree():
+    """SURVEY 8(d)'s imbalance shape (log-normal(ln 2000, 1.35) clipped to [31, 80000], odd): the C generator (csrc/synth.h, what
+    `rb synth-paf` and the tests use) and the numpy twin (workload.n_ops_lognormal, what bench.py shards with) give the same counts."""
+    import ctypes as C
+    from rustybam_amd import workload as wl
+    L = capi.lib()
+    L.rb_synth_n_ops_lognormal.restype = C.c_uint32
+    L.rb_synth_n_ops_lognormal.argtypes = [C.c_uint64, C.c_uint64]
+    a = np.array([L.rb_synth_n_ops_lognormal(wl.SEED_CONFIG2, 1000 + i) for i in range(5000)], dtype=np.uint64)
+    b = wl.n_ops_lognormal(wl.SEED_CONFIG2, 1000, 5000)
+    assert np.array_equal(a, b)
+    assert (a % 2 == 1).all() and a.min() >= 31 and a.max() <= 80000
+    assert 1800 < np.median(a) < 2200 and 4000 < a.mean() < 5600  # median e^mu = 2000, mean ~ e^(mu + sigma^2 / 2) less the clipped tail

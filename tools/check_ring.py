@@ -24,10 +24,10 @@ def ring_uses(line, ring=RING):
     return bad
 
 
-def check_assembly(text, expect_kernels=2):
+def check_assembly(text, expect_kernels=3, ring=RING):
     """-> list of (kernel, line) offences; raises if the expected kernels are not in the assembly."""
     found, offences = 0, []
-    for m in re.finditer(r"^(_Z20rb_k_liftover_streamILb[01]E\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_Z\d+rb_k_liftover_stream\w*):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         found += 1
         in_asm = False
         for ln in m.group(2).splitlines():
@@ -35,7 +35,7 @@ def check_assembly(text, expect_kernels=2):
                 in_asm = True
             elif "#ASMEND" in ln:
                 in_asm = False
-            elif not in_asm and ring_uses(ln.split(";")[0]):
+            elif not in_asm and ring_uses(ln.split(";")[0], ring):
                 offences.append((m.group(1), ln.strip()))
     if found != expect_kernels:
         raise RuntimeError(f"{found} builds of rb_k_liftover_stream in the assembly, {expect_kernels} expected")
@@ -45,7 +45,7 @@ def check_assembly(text, expect_kernels=2):
 def spills(text):
     """-> {kernel: (sgpr_spill_count, vgpr_spill_count, vgpr_count)} from the code-object metadata at the end of the assembly."""
     out = {}
-    for m in re.finditer(r"\.name: +(_Z20rb_k_liftover_stream\w*)\n(.*?)\.wavefront_size", text, re.S):
+    for m in re.finditer(r"\.name: +(_Z\d+rb_k_liftover_stream\w*)\n(.*?)\.wavefront_size", text, re.S):
         f = dict(re.findall(r"\.(sgpr_spill_count|vgpr_spill_count|vgpr_count): +(\d+)", m.group(2)))
         out[m.group(1)] = (int(f.get("sgpr_spill_count", -1)), int(f.get("vgpr_spill_count", -1)), int(f.get("vgpr_count", -1)))
     return out
@@ -60,10 +60,19 @@ def compile_to_asm(hipcc, extra=()):
         return open(out).read()
 
 
+def ring_of(flags):
+    """The ring a build uses: v80..v95 unless -DRB_RING_BASE=<n> moves it."""
+    for f in flags:
+        m = re.match(r"-DRB_RING_BASE=(\d+)$", f)
+        if m:
+            return (int(m.group(1)), int(m.group(1)) + 15)
+    return RING
+
+
 if __name__ == "__main__":
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     text = compile_to_asm(hipcc, sys.argv[1:])
-    bad = check_assembly(text)
+    bad = check_assembly(text, ring=ring_of(sys.argv[1:]))
     for k, ln in bad[:10]:
         print(f"ring register used by the compiler in {k}: {ln}", file=sys.stderr)
     print(f"check_ring: {'FAILED' if bad else 'ok'}; spills (sgpr, vgpr) = {spills(text)}")
