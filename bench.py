@@ -598,6 +598,28 @@ def main():
                         okm = orows["status"] == 0 if key not in ("rec", "win", "status") else slice(None)
                         assert np.array_equal(srows[key][okm], orows[key][okm]), f"op-space baseline vs per-base oracle: {key}"
                     n_os_rows = len(got[0])
+                    if k_os == n_rec:
+                        # ---- parity on 100 % of the job: every GPU row against the op-space port's (which the sample above ties to the
+                        #      per-base oracle), field by field, and the digest of every clipped CIGAR -- the device digest kernel over
+                        #      the GPU's rows and clips against the same kernel over the port's rows and clips ----
+                        tpf = time.perf_counter()
+                        assert n_os_rows == n_hits, f"full parity: {n_hits} GPU rows vs {n_os_rows} rows of the op-space port"
+                        grows_all = d_rows[: n_hits * 64].cpu().numpy().view(rustybam_amd.HIT_DT)
+                        for key in ("rec", "win", "status", "out_n", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len"):
+                            nbad = int((grows_all[key].astype(np.uint64) != got[0][key].astype(np.uint64)).sum())
+                            assert nbad == 0, f"full parity: {key} differs in {nbad} of {n_hits} rows"
+                        del grows_all
+                        d_or = torch.from_numpy(got[0].view(np.uint8).reshape(-1)).to(dev)
+                        d_oo = torch.from_numpy(got[1].view(np.int32)).to(dev)
+                        d_dg = torch.zeros(1, dtype=torch.int64, device=dev)
+                        torch.cuda.synchronize()
+                        eng.dev_digest_rows(view, d_or.data_ptr(), n_hits, d_oo.data_ptr(), row_base, first, d_dg.data_ptr())
+                        torch.cuda.synchronize()
+                        odig = int(d_dg.item()) & mask64
+                        del d_or, d_oo
+                        assert world > 1 or odig == digest, f"full parity: digest of the port's clips {odig:#x} != the GPU's {digest:#x}"
+                        result["parity_full"] = (f"ok: all {n_hits} rows of all {n_rec} records equal the op-space CPU port's, and the digest of "
+                                                 f"all {n_out_ops} clipped ops equals the digest of the port's ({time.perf_counter() - tpf:.1f} s)")
                 del got
             best_os = min(os_runs, key=os_runs.get)
             os_ops = int(op_off[k_os])

@@ -143,6 +143,18 @@ def liftover_opspace(b, w_contig, w_st, w_en, n_threads=1):
     return _take(hits, nh.value, HIT_DT), _take(ops, no.value, np.uint32)
 
 
+def break_opspace(b, max_size, n_threads=1):
+    """break-paf in op space on the CPU (rb_opspace.c): same rows as break_paf() for regular records, modern policy; None if unsupported"""
+    hits, ops = C.c_void_p(), C.c_void_p()
+    nh, no = C.c_uint64(), C.c_uint64()
+    f = lib().rbo_break_opspace_arrays
+    f.restype = C.c_int
+    rc = f(*b.args(True), C.c_uint32(max_size), C.c_int(n_threads), C.byref(hits), C.byref(nh), C.byref(ops), C.byref(no))
+    if rc != 0:
+        return None
+    return _take(hits, nh.value, HIT_DT), _take(ops, no.value, np.uint32)
+
+
 def break_paf(b, max_size, policy=MODERN, n_threads=1):
     hits, ops = C.c_void_p(), C.c_void_p()
     nh, no = C.c_uint64(), C.c_uint64()

@@ -201,3 +201,107 @@ int rbo_liftover_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint6
     }
     return 0;
 }
+
+/* ---- break-paf (liftover.rs:182-226) in op space: the windows of a record are the stretches of target between its indels longer than
+ * max_size -- [pre_tpos, cur_tpos) wherever cur_tpos > pre_tpos (:190-201, :213-224) --, each clipped exactly as a BED window is
+ * (trim_paf_rec_to_rgn, :17-105; a piece never strictly contains its record, so the clone of :23-25 does not occur).  Rows in record
+ * order, then piece order; win = the piece's ordinal among the record's candidate windows, as rbo_break_arrays.  Same scope as above
+ * (regular records, modern policy); held to the per-base oracle by tests/test_oracle_opspace.py. */
+int rbo_break_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st, const uint64_t *t_en,
+                             const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand, uint32_t max_size, int n_threads,
+                             rbo_hit_row **hits, uint64_t *n_hits, uint32_t **out_ops, uint64_t *n_out) {
+    *hits = NULL, *out_ops = NULL, *n_hits = 0, *n_out = 0;
+    uint64_t *hcount = calloc(n_rec + 1, 8), *ocount = calloc(n_rec + 1, 8);
+    int bad = 0;
+    if (n_threads < 1) n_threads = 1;
+    for (int pass = 0; pass < 2 && !bad; pass++) {
+        if (pass == 1) {
+            uint64_t h = 0, o = 0;
+            for (uint64_t k = 0; k < n_rec; k++) {
+                const uint64_t a = hcount[k], b = ocount[k];
+                hcount[k] = h, ocount[k] = o;
+                h += a, o += b;
+            }
+            *hits = calloc(h + 1, sizeof(rbo_hit_row));
+            *out_ops = malloc((o + 1) * 4);
+            *n_hits = h, *n_out = o;
+        }
+#pragma omp parallel for schedule(dynamic, 64) num_threads(n_threads)
+        for (uint64_t r = 0; r < n_rec; r++) {
+            if (bad) continue;
+            const uint32_t *c = ops + op_off[r];
+            const uint64_t n64 = op_off[r + 1] - op_off[r];
+            const uint32_t n = (uint32_t)n64;
+            int ok = n64 > 0 && n64 < 0xFFFFFFFFull && o_ism(c[0]) && o_ism(c[n - 1]);
+            uint32_t *pR = malloc(((size_t)n + 1) * 12), *pQ = pR + n + 1, *pU = pQ + n + 1;
+            uint64_t R = 0, Q = 0, U = 0;
+            for (uint32_t i = 0; i < n && ok; i++) {
+                const uint32_t v = c[i];
+                ok = o_regular(v) && o_len(v) >= 1 && (i == 0 || o_opc(v) != o_opc(c[i - 1]));
+                pR[i] = (uint32_t)R, pQ[i] = (uint32_t)Q, pU[i] = (uint32_t)U;
+                R += o_rl(v), Q += o_ql(v), U += o_len(v);
+            }
+            ok = ok && U <= 0xFFFFFFFFull && t_en[r] >= t_st[r] && q_en[r] >= q_st[r] && R == t_en[r] - t_st[r] && Q == q_en[r] - q_st[r];
+            if (!ok) {
+                bad = 1;
+                free(pR);
+                continue;
+            }
+            pR[n] = (uint32_t)R, pQ[n] = (uint32_t)Q, pU[n] = (uint32_t)U;
+            const int minus = strand[r] == '-';
+            uint64_t nh = 0, no = 0;
+            uint64_t pre = 0; /* pre_tpos - t_st; cur_tpos - t_st = pR[i] */
+            for (uint32_t i = 0; i <= n; i++) {
+                const int last = i == n;
+                const uint32_t v = last ? 0u : c[i];
+                const int big = !last && (o_opc(v) == 1u || o_opc(v) == 2u) && o_len(v) > max_size; /* liftover.rs:188: Del | Ins */
+                if (!big && !last) continue;
+                const uint64_t cur = pR[i];
+                if (cur > pre) { /* :191, :213 */
+                    rbo_hit_row row;
+                    memset(&row, 0, sizeof row);
+                    row.rec = (uint32_t)r, row.win = (uint32_t)nh;
+                    const uint64_t wst = t_st[r] + pre, wen = t_st[r] + cur;
+                    const uint32_t Ds = (uint32_t)((wst > t_st[r] ? wst : t_st[r]) - t_st[r]) + 1u; /* liftover.rs:28 */
+                    const uint32_t De = (uint32_t)((wen < t_en[r] ? wen : t_en[r]) - t_st[r]);      /* :38-40 */
+                    const bres A = resolve(c, n, pR, pQ, pU, Ds, 1), B = resolve(c, n, pR, pQ, pU, De, 0);
+                    uint32_t a_op = 0, cnt_ops = 0, pa = 0, pb = 0;
+                    if (A.st != 1 || B.st != 1 || A.U >= B.U) {
+                        row.status = 1; /* RBO_ST_NONE_INDEL: liftover.rs:52-54 */
+                    } else {
+                        a_op = A.op, cnt_ops = B.op - A.op + 1, pa = A.part, pb = B.part;
+                        row.t_st = t_st[r] + A.R, row.t_en = t_st[r] + B.R;
+                        if (!minus) row.q_st = q_st[r] + A.Q, row.q_en = q_st[r] + B.Q;
+                        else row.q_st = q_en[r] - B.Q, row.q_en = q_en[r] - A.Q;
+                        row.aln_len = B.U - A.U;
+                        row.nmatch = (B.R + B.Q - B.U) - (A.R + A.Q - A.U);
+                    }
+                    if (pass == 1) {
+                        row.out_n = row.status ? 0 : cnt_ops;
+                        row.out_off = ocount[r] + no;
+                        if (!row.status) {
+                            uint32_t *dst = *out_ops + row.out_off;
+                            memcpy(dst, c + a_op, (size_t)cnt_ops * 4);
+                            if (cnt_ops == 1) dst[0] = ((pa + pb - o_len(dst[0])) << 4) | o_opc(dst[0]);
+                            else dst[0] = (pa << 4) | o_opc(dst[0]), dst[cnt_ops - 1] = (pb << 4) | o_opc(dst[cnt_ops - 1]);
+                        }
+                        (*hits)[hcount[r] + nh] = row;
+                    }
+                    nh++;
+                    no += row.status ? 0 : cnt_ops;
+                }
+                if (last) break;
+                pre = cur + o_rl(v); /* :203-206: behind the indel (a deletion's bases are skipped) */
+            }
+            if (pass == 0) hcount[r] = nh, ocount[r] = no;
+            free(pR);
+        }
+    }
+    free(hcount), free(ocount);
+    if (bad) {
+        free(*hits), free(*out_ops);
+        *hits = NULL, *out_ops = NULL, *n_hits = 0, *n_out = 0;
+        return RBO_OPSPACE_UNSUPPORTED;
+    }
+    return 0;
+}

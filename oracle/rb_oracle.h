@@ -249,6 +249,10 @@ int rbo_liftover_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint6
                                 const uint32_t *contig, uint64_t n_win, const uint32_t *w_contig, const uint64_t *w_st,
                                 const uint64_t *w_en, int n_threads, rbo_hit_row **hits, uint64_t *n_hits,
                                 uint32_t **out_ops, uint64_t *n_out);
+/* break-paf in op space (rb_opspace.c): rows as rbo_break_arrays for regular records under the modern policy, else RBO_OPSPACE_UNSUPPORTED (7) */
+int rbo_break_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st, const uint64_t *t_en,
+                             const uint64_t *q_st, const uint64_t *q_en, const uint8_t *strand, uint32_t max_size, int n_threads,
+                             rbo_hit_row **hits, uint64_t *n_hits, uint32_t **out_ops, uint64_t *n_out);
 
 /* break-paf: every record, record order; win field = piece ordinal within the record */
 int rbo_break_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint64_t *t_st,

@@ -367,6 +367,45 @@ __device__ __forceinline__ void rb_stream_record() {
     // where a later pass may start streaming: the segment in which the previous pass resolved the start of its last window
     // (windows are sorted, so nothing of the next pass lies before it), with the running totals at that point
     uint32_t resume_seg = 0, resume_R = 0, resume_Q = 0, resume_U = 0;
+    unsigned long long sv_exec;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(sv_exec));
+    const uint32_t lane_boff = (uint32_t)lane * 32u;
+    // (chunks past the record's end are not loaded: lanes behind the last chunk re-read it, and the loads of steps
+    //  behind the last one run with an empty exec mask)
+#define RB_RING_LOAD_ASM(RA, RB_)                                                                                               \
+    asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
+         "global_load_dwordx4 " RA ", %[o], %[sb]\n\t"                                                                  \
+         "global_load_dwordx4 " RB_ ", %[o], %[sb] offset:16\n\t"                                                       \
+         "s_mov_b64 exec, %[sv]"                                                                                        \
+         :                                                                                                              \
+         : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
+         : "memory", RB_RING_TOP);
+#define RB_RING_LOAD(RING, STP)                                                                                                 \
+    {                                                                                                                           \
+        const uint32_t stp_ = (STP);                                                                                            \
+        uint32_t lo_ = (stp_ << (RB_STEP_SHIFT + 2)) + lane_boff;                                                               \
+        lo_ = lo_ < last_cboff ? lo_ : last_cboff;                                                                              \
+        const uint32_t *const gb_ = gbase0; /* (named copies: a generic lambda does not capture what only an asm operand uses) */ \
+        const unsigned long long sv_ = sv_exec;                                                                                 \
+        const unsigned long long lm_ = stp_ < n_steps ? sv_ : 0ull;                                                             \
+        if constexpr ((RING) == 0) { RB_RING_LOAD_ASM(RB_RREG(0, 3), RB_RREG(4, 3)) }                                           \
+        else { RB_RING_LOAD_ASM(RB_RREG(8, 3), RB_RREG(12, 3)) }                                                                \
+    }
+#define RB_RING_NOSTORES                                                                                                        \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2 * RB_MS; q_++)                                                                    \
+        asm volatile("s_mov_b64 exec, 0\n\tglobal_store_dword %0, %0, %1\n\ts_mov_b64 exec, %2" ::"v"(0u), "s"(gbase0), "s"(sv_exec) : "memory");
+    // The first pass of a record streams it from its first step: the ring's first loads go out HERE, in front of the pass's window loads
+    // (a chain of dependent loads of its own), not behind them -- one memory latency per record instead of two in front of the first step.
+#ifndef RB_PRELOAD
+#define RB_PRELOAD 1
+#endif
+    const bool preloaded = RB_PRELOAD && !(dbg & 4);
+    if (preloaded) {
+        __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0) (see the stream)
+        RB_RING_LOAD(0, 0u)
+        { RB_RING_NOSTORES }
+        RB_RING_LOAD(1, 1u)
+    }
     for (uint64_t jb = 0; jb < n_items; jb += RB_HMAX) {
         uint32_t nb = BRK ? 0u : (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX); // (BRK: pieces of this pass known so far, the open one included)
         const bool validate = fused && jb == 0;
@@ -446,39 +485,14 @@ __device__ __forceinline__ void rb_stream_record() {
             // RB_STEP_VMEM vector-memory instructions (stores of an empty mask and loads past the record's end are issued
             // with an empty exec mask), so "all but the youngest (RB_PF - 1) * RB_STEP_VMEM" is exactly "this step's loads
             // have landed".  Store data is read when the store issues: a ring slot is reloaded right behind its stores.
-            unsigned long long sv_exec;
-            asm volatile("s_mov_b64 %0, exec" : "=s"(sv_exec));
             // (a wait the compiler knows about: whatever load it still tracks as pending on a register the ring is about to
             //  take would otherwise cost an s_waitcnt vmcnt(0) inside the loop, on every step)
             __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0)
-            const uint32_t lane_boff = (uint32_t)lane * 32u;
-            // (chunks past the record's end are not loaded: lanes behind the last chunk re-read it, and the loads of steps
-            //  behind the last one run with an empty exec mask)
-#define RB_RING_LOAD_ASM(RA, RB_)                                                                                               \
-    asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
-                 "global_load_dwordx4 " RA ", %[o], %[sb]\n\t"                                                                  \
-                 "global_load_dwordx4 " RB_ ", %[o], %[sb] offset:16\n\t"                                                       \
-                 "s_mov_b64 exec, %[sv]"                                                                                        \
-                 :                                                                                                              \
-                 : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
-                 : "memory", RB_RING_TOP);
-#define RB_RING_LOAD(RING, STP)                                                                                                 \
-    {                                                                                                                           \
-        const uint32_t stp_ = (STP);                                                                                            \
-        uint32_t lo_ = (stp_ << (RB_STEP_SHIFT + 2)) + lane_boff;                                                               \
-        lo_ = lo_ < last_cboff ? lo_ : last_cboff;                                                                              \
-        const uint32_t *const gb_ = gbase0; /* (named copies: a generic lambda does not capture what only an asm operand uses) */ \
-        const unsigned long long sv_ = sv_exec;                                                                                 \
-        const unsigned long long lm_ = stp_ < n_steps ? sv_ : 0ull;                                                             \
-        if constexpr ((RING) == 0) { RB_RING_LOAD_ASM(RB_RREG(0, 3), RB_RREG(4, 3)) }                                           \
-        else { RB_RING_LOAD_ASM(RB_RREG(8, 3), RB_RREG(12, 3)) }                                                                \
-    }
-#define RB_RING_NOSTORES                                                                                                        \
-    _Pragma("unroll") for (int q_ = 0; q_ < 2 * RB_MS; q_++)                                                                    \
-        asm volatile("s_mov_b64 exec, 0\n\tglobal_store_dword %0, %0, %1\n\ts_mov_b64 exec, %2" ::"v"(0u), "s"(gbase0), "s"(sv_exec) : "memory");
+            if (!(preloaded && jb == 0)) {
             RB_RING_LOAD(0, seg_first * RB_SMAX)
             { RB_RING_NOSTORES }
             RB_RING_LOAD(1, seg_first * RB_SMAX + 1u)
+            }
             // Speculative emission, per slot ("class") q: the CURRENT clip of the class -- its index among the pass's clips and its span in
             // reference offsets [c_ds, c_de) --, wave-uniform.  The clips of a class follow one another along the record (sorted windows),
             // so a step looks at the current clip and moves on only when that clip ends inside the step (round 3 kept a window [j_lo, j_hi)
@@ -792,6 +806,7 @@ __device__ __forceinline__ void rb_stream_record() {
 #undef RB_RING_LOAD_ASM
 #undef RB_RING_NOSTORES
         }
+        if (!streams && preloaded && jb == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the ring's loads are out: nothing of them may be in flight when the registers are the compiler's again)
         if (dbg & 128) {
             const unsigned long long ck_c1 = __builtin_amdgcn_s_memtime(), ck_r1 = __builtin_amdgcn_s_memrealtime();
             if (lane == 0 && (wave & 15) == 0) {
@@ -1022,8 +1037,13 @@ __device__ __forceinline__ void rb_stream_record() {
                 q1[q] = (c1 > eg_last) ? 0u : w1;
             }
             const rb_u32x4 s0 = {q0[0], q0[1], q0[2], q0[3]}, s1 = {q1[0], q1[1], q1[2], q1[3]};
+#ifdef RB_PATCH_PLAIN
+            *reinterpret_cast<rb_u32x4 *>(dst) = s0;
+            if (eg_l != eg_f) *reinterpret_cast<rb_u32x4 *>(dst + (eg_l - eg_f)) = s1;
+#else
             __builtin_nontemporal_store(s0, reinterpret_cast<rb_u32x4 *>(dst));
             if (eg_l != eg_f) __builtin_nontemporal_store(s1, reinterpret_cast<rb_u32x4 *>(dst + (eg_l - eg_f)));
+#endif
         }
         // ---- clips without a place of their own: one list entry each, copied by rb_k_copy_clips ----
         {

@@ -65,3 +65,20 @@ def test_torch_sees_library_memory(engine):
     assert int(t.sum().item()) == 7 * ((1 << 28) + 5) + 4
     buf.free()
     assert buf.ptr == 0 and buf.t is None
+
+
+def test_chunked_buffers_give_their_memory_back(engine):
+    """A chunked buffer is many mappings; rb_dev_free unmaps them one by one and releases every chunk (a spanning hipMemUnmap is not
+    promised to).  Ten rounds of 1.5 GB: the device's free memory comes back to within a few chunks every time."""
+    torch = pytest.importorskip("torch")
+    size = (3 << 29) + 12345
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(10):
+        p = engine.dev_alloc(size)
+        assert engine.L.rb_dev_memset(engine.ctx, C.c_void_p(p), 1, C.c_size_t(size)) == 0
+        free_mid, _ = torch.cuda.mem_get_info()
+        assert free0 - free_mid >= size - 64 * MB
+        engine.dev_free(p)
+        free1, _ = torch.cuda.mem_get_info()
+        assert abs(free0 - free1) <= 16 * MB, (free0, free1)

@@ -158,6 +158,54 @@ def test_full_size_liftover_integrity_and_descriptor_checksums():
     eng.close()
 
 
+def test_full_size_liftover_every_row_equals_the_opspace_oracle(oracle):
+    """Parity on 100 % of the full-size job: all ~12.6 M hit rows of config 3 against the op-space CPU port (oracle/rb_opspace.c, itself
+    held to the per-base oracle by tests/test_oracle_opspace.py) on all 1e6 records, field by field; and the order-sensitive digest
+    of every clipped CIGAR: rb_dev_digest_rows (= its numpy twin, tests/test_gpu_digest.py) over the GPU's rows and clips against the
+    same kernel over the oracle's rows and clips.  Needs the host memory for 20 GB of ops and 25 GB of clipped CIGARs."""
+    try:
+        avail_gb = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1]) / 1e6
+    except Exception:
+        avail_gb = 0.0
+    n_full = int(os.environ.get("RB_FULLSIZE_RECORDS", "1000000"))
+    if avail_gb < 70 * n_full / 1e6 + 8:
+        pytest.skip(f"host has {avail_gb:.0f} GB available: not enough for the full-size op-space oracle")
+    C = _config3()
+    torch, dev, eng, run, n_rec, total_ops, d_ops = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops", "d_ops"))
+    H = C["host"]
+    rows_g, out_g = run(rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN, 16 * n_rec, int(1.6 * total_ops))
+    n = rows_g.shape[0]
+    ops_host = d_ops[:total_ops].cpu().numpy().view(np.uint32)
+    ob = oracle.Batch(ops_host, H["op_off"], H["t_st"], H["t_en"], H["q_st"], H["q_en"], H["strand"], np.zeros(n_rec, np.uint32))
+    got = oracle.liftover_opspace(ob, *H["windows"], n_threads=min(64, os.cpu_count() or 1))
+    assert got is not None, "the op-space port refused the synthetic records"
+    orows, oops = got
+    assert len(orows) == n, f"{n} GPU rows, {len(orows)} oracle rows"
+    grows = rows_g.cpu().numpy().view(np.uint8).reshape(n, 64).view(rustybam_amd.HIT_DT).reshape(n)
+    for key in ("rec", "win", "status", "out_n", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len"):
+        bad = int((grows[key].astype(np.uint64) != orows[key].astype(np.uint64)).sum())
+        assert bad == 0, f"{key}: {bad} of {n} rows differ from the op-space oracle"
+    assert int(((grows["flags"] & 1) != (orows["flags"] & 1)).sum()) == 0            # "strictly inside" clones (liftover.rs:23-25)
+    # ---- every clipped CIGAR: one digest kernel, two inputs ----
+    d_dig = torch.zeros(2, dtype=torch.int64, device=dev)
+    view = C["view"]
+    d_rows_g = rows_g.contiguous()
+    torch.cuda.synchronize()
+    eng.dev_digest_rows(view, d_rows_g.data_ptr(), n, out_g.data_ptr(), 0, 0, d_dig[0:].data_ptr())
+    torch.cuda.synchronize()
+    del out_g
+    torch.cuda.empty_cache()
+    d_orows = torch.from_numpy(orows.view(np.uint8).reshape(-1)).to(dev)
+    d_oops = torch.from_numpy(oops.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    eng.dev_digest_rows(view, d_orows.data_ptr(), n, d_oops.data_ptr(), 0, 0, d_dig[1:].data_ptr())
+    torch.cuda.synchronize()
+    dg = d_dig.cpu().numpy().view(np.uint64)
+    assert dg[0] == dg[1], f"digest of the GPU's clips {int(dg[0]):#x} != digest of the oracle's {int(dg[1]):#x}"
+    assert int(orows["out_n"].astype(np.int64).sum()) == len(oops) or len(oops) >= int(orows["out_n"].astype(np.int64).sum())
+    eng.close()
+
+
 def test_full_size_config2_one_window_every_record_overlaps(oracle):
     """BASELINE.json configs[1] at full size: 1e5 records of 1000-9000 ops, each placed so that it overlaps the one
     window chr1:12,000,000-13,000,000.  Properties that need no oracle: one hit per record, in record order; every clip passes the

@@ -140,10 +140,12 @@ def test_ka11_bed(oracle, ka, golden, tmp_path):
     assert _parse_out(out)[0]["id"] == "T:14-18"  # bed.rs:150-153 default id = name:st+1-en
 
 
-def test_ka12_gz_same_as_plain(oracle, golden):
+def test_ka12_gz_and_bgz_same_as_plain(oracle, golden):
+    """src/myio.rs:38-46: reader() on the plain file, its .bgz and its .gz yields the same lines (all three legs of the doc test)"""
     a = oracle.cli("stats", "--paf", os.path.join(golden, "asm_small.paf"))
     b = oracle.cli("stats", "--paf", os.path.join(golden, "asm_small.paf.gz"))
-    assert a == b and a[0] == 0
+    c = oracle.cli("stats", "--paf", os.path.join(golden, "asm_small.paf.bgz"))
+    assert a == b and a == c and a[0] == 0
 
 
 def test_f32_display(oracle):

@@ -6,8 +6,12 @@ cd $GRAFT_REPO_ROOT
 cp rustybam_amd/librustybam_amd.so /tmp/keep.so
 rounds=${AB_ROUNDS:-4}
 rm -f /tmp/ab_times.txt
+# (odd rounds run the variants in the order given, even rounds in reverse: a box whose times creep from process to process -- some
+#  do, by 10 % over a dozen processes -- then favours nobody)
+fwd="$*"; rev=""; for n in "$@"; do rev="$n $rev"; done
 for round in $(seq $rounds); do
-  for n in "$@"; do
+  if [ $((round % 2)) -eq 1 ]; then order="$fwd"; else order="$rev"; fi
+  for n in $order; do
     cp rustybam_amd/variants/$n.so rustybam_amd/librustybam_amd.so
     python bench.py --steps 10 --no-cpu-baseline $AB_ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$n', 'step %.3f' % d['ms_per_step'], 'kernel %.3f' % d['roofline']['kernel_ms'], d.get('output_digest'))" | tee -a /tmp/ab_times.txt
