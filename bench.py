@@ -503,6 +503,7 @@ def main():
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
+                   "batch_buffers_chunked": {k_: (bool(o_.chunked) if o_ else None) for k_, o_ in (("ops", own_ops), ("workspace", own_ws), ("rows", own_rows), ("out_ops", own_out))},
                    "batch_memory": ("rb_dev_alloc (2 MB physical chunks)" if lib_alloc and not alloc_note else
                                     "torch allocator (hipMalloc)" + (f"; rb_dev_alloc memory not usable as a tensor here: {alloc_note[0]}" if alloc_note else "")),
                    **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {}),
@@ -609,7 +610,7 @@ def main():
                             nbad = int((grows_all[key].astype(np.uint64) != got[0][key].astype(np.uint64)).sum())
                             assert nbad == 0, f"full parity: {key} differs in {nbad} of {n_hits} rows"
                         del grows_all
-                        d_or = torch.from_numpy(got[0].view(np.uint8).reshape(-1)).to(dev)
+                        d_or = torch.from_numpy(capi.hit_rows_from(got[0]).view(np.uint8).reshape(-1)).to(dev)  # (the port's rows are 72 bytes, rb_hit_row 64)
                         d_oo = torch.from_numpy(got[1].view(np.int32)).to(dev)
                         d_dg = torch.zeros(1, dtype=torch.int64, device=dev)
                         torch.cuda.synchronize()
@@ -660,7 +661,12 @@ def main():
                 box["kernel_clock_note"] = (f"diagnostics build of rb_k_liftover_stream, {n_diag} launches back to back ({time.perf_counter() - tb0:.1f} s), "
                                             f"stamps of {ph[2]} records of the last launch; that build's launches took {float(np.mean(dms[-10:])):.3f} ms")
             off = eng.plan_diag_stamps_offset(plan, rows_cap)
+            d_ws[off: off + 4 * n_rec].zero_()
+            torch.cuda.synchronize()
+            eng.dev_liftover(plan, view, d_norm.data_ptr(), dpol, d_ws.data_ptr(), d_rows.data_ptr(), rows_cap, d_out.data_ptr(), out_cap, d_cnt.data_ptr())
+            torch.cuda.synchronize()
             st_ = d_ws[off: off + 4 * n_rec].view(torch.int32).cpu().numpy().view(np.uint32)
+            st_ = st_[st_ != 0]  # (a wave that left without a stamp -- a record the kernel handed to the general path -- has none)
             rel = np.sort((st_ - st_.min()).astype(np.uint32))  # (mod 2^32: a launch is far shorter than the counter's 43 s)
             box["launch_tail"] = {"ms_after_95pct_of_waves_done": round(float(rel[-1] - rel[int(0.95 * (len(rel) - 1))]) * 1e-5, 4),
                                   "ms_after_99pct": round(float(rel[-1] - rel[int(0.99 * (len(rel) - 1))]) * 1e-5, 4),
@@ -671,6 +677,8 @@ def main():
                 box["probe_ms"] = round(pms, 4)
                 box["probe_clock_mhz"] = round(pmhz, 1)
                 box["probe_gb_s"] = round(2.2 * src_bytes / (pms * 1e-3) / 1e9, 1)
+                sms, smhz = eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=True)
+                box["probe_scattered_ms"] = round(sms, 4)  # (the same bytes, the concurrently running waves spread over the whole arrays)
                 box["probe_note"] = (f"rb_dev_box_probe on this run's buffers: {src_bytes} B read from the ops array, 1.2 x that written to the output "
                                      "arena in the clip kernel's access shape (32 contiguous bytes per lane, two slots), no other instructions")
                 if k_ms == k_ms:

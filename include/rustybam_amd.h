@@ -216,7 +216,7 @@ int rb_ctx_set_timing(rb_ctx *ctx, int enabled);
 int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_out);
 
 /* Device memory.  Hosts that keep a batch resident across calls should take the batch, workspace, rows and
- * output arenas from here: requests of 1 GB and more are built from 2 MB physical chunks (hipMemCreate)
+ * output arenas from here: requests of 256 MB and more are built from 2 MB physical chunks (hipMemCreate)
  * mapped into one virtual range, which spreads a multi-GB array evenly over the HBM channels whatever the
  * driver's free list looks like.  On the headline batch the clip kernel takes 9.3-9.4 ms per launch on such
  * memory against 10.2-11.9 ms on plain hipMalloc memory and 18-20 ms on one physically contiguous block
@@ -225,6 +225,9 @@ int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_out);
  * Pointers are 2 MB aligned when chunked, 256 B otherwise; free only with rb_dev_free. */
 int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr);
 int rb_dev_free(rb_ctx *ctx, void *dev_ptr);
+/* which route a buffer of rb_dev_alloc took: 1 = 2 MB physical chunks, 0 = plain hipMalloc (a small request, or the fallback when the
+ * chunked route failed -- the two routes differ by 10-20 % in the clip kernel's time, so bench.py reports it) */
+int rb_dev_alloc_mode(rb_ctx *ctx, const void *dev_ptr);
 /* Transfers of 8 MB and more go through the context's pinned staging ring (two page-locked 32 MB chunks, hipHostMalloc): the
  * host side of a chunk is copied on several host threads while the DMA of the other chunk runs, so pageable caller memory moves
  * at the link's rate and host_src may be reused as soon as rb_dev_upload returns (the DMAs are queued on the context's stream).
@@ -479,8 +482,9 @@ int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const rb_hit_row
  * Moves the clip kernel's memory mix without its instructions: every wave reads a 20 KiB stretch of src[0 .. src_bytes) in the clip
  * kernel's access shape and writes it to dst0 (all of it) and dst1 (a fifth of it); both need src_bytes of room.  reps launches
  * back to back; *ms_out = mean time of one, *mhz_out (may be NULL) = the shader clock held meanwhile, from s_memtime / s_memrealtime
- * stamps around each wave's loop. */
-int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, double *ms_out, double *mhz_out);
+ * stamps around each wave's loop.  scatter != 0: the waves that run at the same time work 5 MB apart, all over the array (as the clip
+ * kernel's do: its records run longest first), instead of side by side. */
+int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, int scatter, double *ms_out, double *mhz_out);
 
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and

@@ -40,6 +40,17 @@ assert REDUCE_DT.itemsize == 72 and NORM_DT.itemsize == 64 and HIT_DT.itemsize =
 assert PAIR_DT.itemsize == 128
 
 
+def hit_rows_from(rows):
+    """Rows of another layout with the same field names (the oracle's 72-byte rows) as rb_hit_row records (HIT_DT, 64 bytes): what
+    rb_dev_digest_rows reads.  flags keeps bit 0 only (HIT_INSIDE)."""
+    out = np.zeros(len(rows), dtype=HIT_DT)
+    for k in ("rec", "win", "out_n", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_off"):
+        out[k] = rows[k]
+    out["status"] = rows["status"].astype(np.uint16)
+    out["flags"] = (rows["flags"] & 1).astype(np.uint16)
+    return out
+
+
 class RbError(RuntimeError):
     pass
 
@@ -187,7 +198,7 @@ class Engine:
                                                C.c_void_p(new_off_ptr), C.c_void_p(new_ops_ptr or 0), C.c_void_p(scratch_ptr)), "rb_dev_gather_records")
 
     def dev_alloc(self, n_bytes):
-        """device memory from the library's allocator (requests of 1 GB and more: 2 MB physical chunks mapped side by side); -> address"""
+        """device memory from the library's allocator (requests of 256 MB and more: 2 MB physical chunks mapped side by side); -> address"""
         d = C.c_void_p()
         self._chk(self.L.rb_dev_alloc(self.ctx, C.c_size_t(n_bytes), C.byref(d)), "rb_dev_alloc")
         return int(d.value)
@@ -220,11 +231,11 @@ class Engine:
     def plan_workspace_bytes(self, plan, rows_cap):
         return int(self.L.rb_plan_workspace_bytes(plan, C.c_uint64(rows_cap)))
 
-    def dev_box_probe(self, src_ptr, src_bytes, dst0_ptr, dst1_ptr, reps=10):
+    def dev_box_probe(self, src_ptr, src_bytes, dst0_ptr, dst1_ptr, reps=10, scatter=False):
         """-> (ms per launch, shader MHz held): the clip kernel's memory mix without its instructions (diagnostics)."""
         ms, mhz = C.c_double(0), C.c_double(0)
         self._chk(self.L.rb_dev_box_probe(self.ctx, C.c_void_p(src_ptr), C.c_uint64(src_bytes), C.c_void_p(dst0_ptr), C.c_void_p(dst1_ptr),
-                                          C.c_int(reps), C.byref(ms), C.byref(mhz)), "rb_dev_box_probe")
+                                          C.c_int(reps), C.c_int(1 if scatter else 0), C.byref(ms), C.byref(mhz)), "rb_dev_box_probe")
         return ms.value, mhz.value
 
     def plan_diag_stamps_offset(self, plan, rows_cap):
@@ -426,7 +437,7 @@ def synth_fill_ops_host(seed, first_record, op_off):
 
 class DevBuf:
     """Device memory from the LIBRARY's allocator (rb_dev_alloc: what a host of the C ABI is told to use for a resident batch --
-    requests of 1 GB and more are pieced together from 2 MB physical chunks, which decides 10-15 % of the streaming kernels' time,
+    requests of 256 MB and more are pieced together from 2 MB physical chunks, which decides 10-15 % of the streaming kernels' time,
     DESIGN.md section 3), seen by torch through the CUDA array interface without a copy: `.t` is the tensor.  free() gives the
     memory back (before the engine is closed)."""
 
@@ -438,6 +449,7 @@ class DevBuf:
         except Exception:
             torch.cuda.empty_cache()                # (memory torch's caching allocator holds but does not use is not free to the driver)
             self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
+        self.chunked = eng.L.rb_dev_alloc_mode(eng.ctx, C.c_void_p(self.ptr)) == 1  # (False: plain hipMalloc memory -- small, or the fallback)
         self.__cuda_array_interface__ = {"shape": (self.n * self.item,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
         try:
             self.t = torch.as_tensor(self, device=device if device is not None else "cuda").view(dtype)

@@ -150,6 +150,7 @@ struct rb_nf_params {
     uint64_t drop_words;
     uint32_t *deep_list;
     uint32_t flags;
+    void *tdesc;
 };
 extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *p, hipStream_t stream);
 struct rb_compact_params {
@@ -186,6 +187,7 @@ struct rb_ctx {
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
+    uint64_t alloc_fallbacks = 0; // rb_dev_alloc requests that wanted the chunked route and got plain hipMalloc
 };
 #define RB_PIN_CHUNK ((size_t)32 << 20)
 #define RB_PIN_MIN ((size_t)8 << 20) // smaller transfers take the runtime's own pageable path
@@ -401,14 +403,19 @@ extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
     // smaller ones, and everything under RB_ALLOC_MODE=default, come from hipMalloc.  RB_ALLOC_MODE=chunks / scatter (the chunks in
     // pseudo-random order: no different) / contiguous force a mode for the probe.
     const char *mode = getenv("RB_ALLOC_MODE");
-    const bool chunks = mode ? (!strcmp(mode, "scatter") || !strcmp(mode, "chunks")) : want >= ((size_t)1 << 30);
+    // (round 4: from 256 MB up, not 1 GB -- the row arena of the headline batch, 1.02e9 bytes, fell just short of the old threshold and sat
+    //  in plain hipMalloc memory beside a chunked batch; RB_ALLOC_CHUNK_MIN_MB moves the threshold for experiments)
+    static const size_t chunk_min = (size_t)(getenv("RB_ALLOC_CHUNK_MIN_MB") ? atol(getenv("RB_ALLOC_CHUNK_MIN_MB")) : 256) << 20;
+    const bool chunks = mode ? (!strcmp(mode, "scatter") || !strcmp(mode, "chunks")) : want >= chunk_min;
     if (want >= ((size_t)64 << 20) && chunks) {
         void *q = rb_alloc_vmm(ctx->device, want, mode && !strcmp(mode, "scatter"));
         if (q) {
             *dev_ptr = q;
             return RB_OK;
         }
-        (void)hipGetLastError();
+        const hipError_t why = hipGetLastError();
+        ctx->alloc_fallbacks++; // (rb_dev_alloc_mode tells the caller which route a buffer took: the two differ by 10-20 % in the clip kernel's time)
+        if (getenv("RB_ALLOC_LOG")) fprintf(stderr, "[rb_dev_alloc] %zu bytes: the chunked route failed (%s), plain hipMalloc instead\n", want, hipGetErrorString(why));
     }
     if (want >= ((size_t)64 << 20) && mode && !strcmp(mode, "contiguous")) {
         if (hipExtMallocWithFlags(dev_ptr, want, hipDeviceMallocContiguous) == hipSuccess) return RB_OK;
@@ -420,6 +427,13 @@ extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
         return fail(ctx, RB_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
     return RB_OK;
+}
+// which route a buffer of rb_dev_alloc took: 1 = separately created 2 MB physical chunks, 0 = plain hipMalloc (a small request, a forced
+// mode, or the fallback when the chunked route failed), -1 = not a pointer rb_dev_alloc's chunked route knows (plain, or foreign)
+extern "C" int rb_dev_alloc_mode(rb_ctx *ctx, const void *dev_ptr) {
+    if (!ctx || !dev_ptr) return RB_E_INVALID;
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    return g_vmm.count(const_cast<void *>(dev_ptr)) ? 1 : 0;
 }
 extern "C" int rb_dev_free(rb_ctx *ctx, void *dev_ptr) {
     if (!ctx) return RB_E_INVALID;
@@ -606,6 +620,22 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
             a.swap(b);
         }
         sched = a;
+        // RB_SCHED=chunk:<N> (experiments): records in MEMORY order by chunks of N, longest first inside a chunk.  The waves that run at
+        // the same time then work on neighbouring records -- a few hundred MB of the ops array and of each output slot -- instead of
+        // on records scattered over all of them, and the four waves of a workgroup still get records of one length.
+        if (const char *e = getenv("RB_SCHED")) {
+            uint64_t N = 0;
+            if (!strncmp(e, "chunk:", 6)) N = strtoull(e + 6, nullptr, 10);
+            else if (!strcmp(e, "memory")) N = 1;
+            if (N >= 1) {
+                std::iota(sched.begin(), sched.end(), 0u);
+                if (N > 1)
+                    for (uint64_t c0 = 0; c0 < n_rec; c0 += N) {
+                        const uint64_t c1 = std::min<uint64_t>(n_rec, c0 + N);
+                        std::stable_sort(sched.begin() + c0, sched.begin() + c1, [&](uint32_t x, uint32_t y) { return key[x] > key[y]; });
+                    }
+            }
+        }
     }
     // windows grouped by contig, BED order kept inside a contig
     std::vector<uint64_t> cw_off(n_contig + 1, 0), g_st(n_win), g_en(n_win), o_st(n_win), o_en(n_win);
@@ -1805,8 +1835,8 @@ extern "C" int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const
 }
 
 // ---- the box: what this GPU moves at the clip kernel's memory mix, and the clock it holds meanwhile (diagnostics for bench.py) ----
-extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, hipStream_t stream);
-extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, double *ms_out, double *mhz_out) {
+extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, int scatter, hipStream_t stream);
+extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, int scatter, double *ms_out, double *mhz_out) {
     if (!ctx || !src || !dst0 || !dst1 || !ms_out || reps < 1) return RB_E_INVALID;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t n_stretch = src_bytes / (10 * 2048);
@@ -1820,10 +1850,10 @@ extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes
     };
     chk(hipEventCreate(&a));
     chk(hipEventCreate(&b));
-    chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, ctx->stream)); // (untimed: first touch)
+    chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, scatter, ctx->stream)); // (untimed: first touch)
     chk(hipMemsetAsync(stamps, 0, 64, ctx->stream));
     chk(hipEventRecord(a, ctx->stream));
-    for (int i = 0; i < reps && rc == RB_OK; i++) chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, ctx->stream));
+    for (int i = 0; i < reps && rc == RB_OK; i++) chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, scatter, ctx->stream));
     chk(hipEventRecord(b, ctx->stream));
     chk(hipEventSynchronize(b));
     float ms = 0;
@@ -1841,7 +1871,7 @@ extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes
 // ---- nucfreq ----------------------------------------------------------------------------------------------------------
 namespace {
 struct nf_layout {
-    size_t end_key, rd_end, tile_off, blk, tile_lo, tile_hi, drop_off, deep_list, drop_pool, total;
+    size_t end_key, rd_end, tile_off, blk, tile_lo, tile_hi, drop_off, deep_list, drop_pool, tdesc, total;
     uint64_t max_tiles, drop_words;
 };
 nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_positions) {
@@ -1860,6 +1890,7 @@ nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_position
     L.deep_list = o, o = up(o + ((size_t)n_regions + 2) * 4);
     L.drop_words = n_reads + 1024;
     L.drop_pool = o, o = up(o + ((size_t)L.drop_words + 1) * 8); // (word 0: the pool's cursor)
+    L.tdesc = o, o = up(o + ((size_t)L.max_tiles + 1) * 64);     // one 64-byte descriptor per tile (rb_k_nf_tile_desc)
     L.total = o;
     return L;
 }
@@ -1896,6 +1927,7 @@ extern "C" int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t 
     p.drop_bits = (uint64_t *)(w + L.drop_pool) + 1, p.drop_words = L.drop_words;
     static const bool all_atomic = getenv("RB_DEBUG_NF_ATOMIC") != nullptr; // (diagnostic: every tile through the LDS-atomic kernel)
     p.flags = all_atomic ? 1u : 0u;
+    p.tdesc = (void *)(w + L.tdesc);
     HIPCHK(ctx, hipMemsetAsync(p.drop_bits - 1, 0, 8, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(p.deep_list + n_regions, 0, 8, ctx->stream)); // (how many deep regions; can the cap be reached at all)
     HIPCHK(ctx, rb_launch_nucfreq(&p, ctx->stream));

@@ -231,6 +231,86 @@ static int synth_paf(uint64_t seed, uint64_t first, uint64_t n_rec, bool overlap
     fflush(stdout);
     return 0;
 }
+// `rb synth-paf config4 <n_records>`: SURVEY.md 8(d) config 4 as text -- records over the 25 contigs of .test/asm_small.bam's header in
+// proportion to their lengths (the 16.5 kb chrM gets none that fit), 300..700 ops a record (mean 500: 5e9 ops at 1e7 records), queries
+// q<k> of four records whose consecutive query spans overlap by U[100, 10000] bases with none contained, '+' strand, seed 0x5EED0004.
+// Counter-based (a query's four records depend on (seed, k) only), all host threads, printed in order.
+static int synth_paf_config4(uint64_t n_rec) {
+    static const struct { const char *name; uint64_t len; } C4[25] = {
+        {"chr1", 248387497}, {"chr2", 242696747}, {"chr3", 201106605}, {"chr4", 193575430}, {"chr5", 182045437}, {"chr6", 172126870},
+        {"chr7", 160567423}, {"chr8", 146259322}, {"chr9", 150617274}, {"chr10", 134758122}, {"chr11", 135127772}, {"chr12", 133324781},
+        {"chr13", 114240146}, {"chr14", 101219177}, {"chr15", 100338308}, {"chr16", 96330493}, {"chr17", 84277185}, {"chr18", 80542536},
+        {"chr19", 61707359}, {"chr20", 66210247}, {"chr21", 45827691}, {"chr22", 51353906}, {"chrX", 154259625}, {"chrM", 16569}, {"chrY", 57227415}};
+    const uint64_t seed = 0x5EED0004ull;
+    uint64_t cum[26];
+    cum[0] = 0;
+    for (int c = 0; c < 25; c++) cum[c + 1] = cum[c] + C4[c].len;
+    n_rec = n_rec / 4 * 4;
+    const uint64_t n_q = n_rec / 4;
+    const unsigned T = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 64u));
+    const uint64_t slice = 256; // queries per work item
+    std::vector<std::string> buf(T);
+    auto put_u = [](std::string &o, uint64_t v) {
+        char tmp[24];
+        int k = 24;
+        do { tmp[--k] = (char)('0' + v % 10); v /= 10; } while (v);
+        o.append(tmp + k, (size_t)(24 - k));
+    };
+    for (uint64_t base = 0; base < n_q; base += slice * T) {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < T; t++) {
+            th.emplace_back([&, t]() {
+                std::string &o = buf[t];
+                o.clear();
+                const uint64_t lo = base + t * slice, hi = std::min(n_q, lo + slice);
+                std::string cg[4];
+                for (uint64_t k = lo; k < hi; k++) {
+                    uint64_t R[4], Q[4], q_st[4];
+                    for (int j = 0; j < 4; j++) {
+                        const uint64_t r = 4 * k + j;
+                        const uint32_t n = rb_synth_n_ops_impl(seed, r, 300, 700);
+                        R[j] = Q[j] = 0;
+                        cg[j].clear();
+                        for (uint32_t i = 0; i < n; i++) {
+                            const uint32_t v = rb_synth_op(seed, r, i), op = v & 15u, len = v >> 4;
+                            if (op != 1) R[j] += len;
+                            if (op != 2) Q[j] += len;
+                            put_u(cg[j], len);
+                            cg[j].push_back("MIDNSHP=X"[op]);
+                        }
+                    }
+                    q_st[0] = 0;
+                    for (int j = 1; j < 4; j++) { // the next span starts inside the previous one, U[100, 10000] bases before its end; never contained
+                        const uint64_t h = rb_splitmix64(seed ^ rb_splitmix64((4 * k + j) ^ 0x2222222222222222ull));
+                        const uint64_t ov = std::min<uint64_t>(100 + h % 9901, std::min(Q[j - 1], Q[j]) / 2);
+                        q_st[j] = q_st[j - 1] + Q[j - 1] - ov;
+                    }
+                    const uint64_t q_len = q_st[3] + Q[3] + 1000;
+                    for (int j = 0; j < 4; j++) {
+                        const uint64_t r = 4 * k + j;
+                        const uint64_t h1 = rb_splitmix64(seed ^ rb_splitmix64(r ^ 0x1111111111111111ull)), h2 = rb_splitmix64(h1);
+                        int c = 0;
+                        for (int tries = 0; tries < 8; tries++) { // a contig in proportion to its length, long enough for the record
+                            const uint64_t x = rb_splitmix64(h1 + (uint64_t)tries) % cum[25];
+                            c = 0;
+                            while (cum[c + 1] <= x) c++;
+                            if (C4[c].len > R[j]) break;
+                            c = 0; // (chr1 takes whatever fits nowhere else)
+                        }
+                        const uint64_t t_st = h2 % (C4[c].len - R[j] + 1);
+                        o.push_back('q'); put_u(o, k); o.push_back('\t'); put_u(o, q_len); o.push_back('\t'); put_u(o, q_st[j]); o.push_back('\t');
+                        put_u(o, q_st[j] + Q[j]); o.append("\t+\t"); o.append(C4[c].name); o.push_back('\t'); put_u(o, C4[c].len); o.push_back('\t');
+                        put_u(o, t_st); o.push_back('\t'); put_u(o, t_st + R[j]); o.append("\t0\t0\t60\ttp:A:P\tcg:Z:"); o.append(cg[j]); o.push_back('\n');
+                    }
+                }
+            });
+        }
+        for (auto &x : th) x.join();
+        for (unsigned t = 0; t < T; t++) fwrite(buf[t].data(), 1, buf[t].size(), stdout);
+    }
+    fflush(stdout);
+    return 0;
+}
 static int synth_bed(uint64_t n_win) {
     for (uint64_t i = 0; i < n_win; i++) {
         const uint64_t st = i * 82796ull, en = st + 100000ull < 248387497ull ? st + 100000ull : 248387497ull;
@@ -811,6 +891,7 @@ int main(int argc, char **argv) {
     const std::string cmd = argv[a++];
     if (cmd == "synth-paf" || cmd == "synth-bed") { // rb synth-paf <seed> <first_record> <n_records> [overlap] | rb synth-bed <n_windows>
         if (cmd == "synth-bed") return synth_bed(a < argc ? strtoull(argv[a], nullptr, 0) : 3000);
+        if (a + 1 < argc && !strcmp(argv[a], "config4")) return synth_paf_config4(strtoull(argv[a + 1], nullptr, 0)); // rb synth-paf config4 <n_records>
         if (a + 2 >= argc) return usage();
         return synth_paf(strtoull(argv[a], nullptr, 0), strtoull(argv[a + 1], nullptr, 0), strtoull(argv[a + 2], nullptr, 0),
                          a + 3 < argc && !strcmp(argv[a + 3], "overlap"));

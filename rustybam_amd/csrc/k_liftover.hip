@@ -253,9 +253,6 @@ __device__ __forceinline__ void rb_stream_record() {
     // spills, parked in VGPRs right under the load ring).  `p.field` below reads the field from the kernel-argument segment where
     // it is used, through a pointer the compiler cannot see through (one s_load at that place); what the streaming loop needs is
     // copied into locals in front of it.
-#ifdef RB_RING_FENCE
-    asm volatile("" ::: "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
-#endif
     const rb_kparams kp = (rb_kparams)__builtin_amdgcn_kernarg_segment_ptr();
     rb_kparams kq = rb_kp_here(kp); // the pointer of the current phase (set-up / after the stream of a pass): loads through it stay inside the phase
 #define p (*kq)
@@ -723,7 +720,8 @@ __device__ __forceinline__ void rb_stream_record() {
                 RB_RING_LOAD(ring, st + RB_PF)
             };
 #ifndef RB_FAST
-#define RB_FAST 0 // (1 needs more vector registers than the ring at v80 leaves: tools/check_ring.py)
+#define RB_FAST 0 // (1 takes 84 vector registers: the ring then has to sit at v96 -- 4 waves per SIMD instead of 5 --, and on one box the two
+                  //  builds ran 9.81 and 9.74 ms: profiles/r04_stream_summary.md.  Kept as a build switch, not the product)
 #endif
             const bool fast_ok = RB_FAST && validate && spec && jb == 0 && !DIAG;
             for (seg0 = seg_first * RB_SMAX; seg0 < n_steps; seg0 += RB_SMAX) {
@@ -868,7 +866,10 @@ __device__ __forceinline__ void rb_stream_record() {
                 w->aln_len = rec_aln_len;
                 w->flags = (nr->flags & RB_F_STRIPPED) | RB_F_REGULAR;
             }
-            if (!BRK && nh == 0) return;
+            if (!BRK && nh == 0) { // (no window overlaps the record: it has been walked and verified, liftover.rs:119-121, and that is all)
+                if ((dbg & 256) && lane == 0) p.diag_stamps[wave] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+                return;
+            }
         }
         if constexpr (BRK) {
             brk_cnt = rb_first(brk_cnt), brk_nx_cnt = rb_first(brk_nx_cnt), brk_nx_pre = rb_first(brk_nx_pre);

@@ -438,10 +438,17 @@ extern "C" hipError_t rb_launch_compact_clips(const rb_compact_params *p, hipStr
 // under this memory load comes out with the time (bench.py's `box` block; tools/st_probe.hip is the stand-alone form of it).
 // ------------------------------------------------------------------------------------------------
 typedef uint32_t rb_bp_u32x4 __attribute__((ext_vector_type(4)));
+// SCATTER: wave w takes stretch (w mod 4096) * (n / 4096) + w / 4096 -- the waves that run at the same time are then spread over the
+// whole array, 5 MB apart, as the clip kernel's are (its records run longest first, i.e. in no memory order), instead of side by side.
+template <bool SCATTER>
 __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ src, char *__restrict__ d0, char *__restrict__ d1, uint64_t n_stretch,
                                                       uint32_t *stamps /* [3]: sum of cycles >> 6, sum of 10 ns ticks, stamped waves */) {
-    const uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_stretch) return;
+    if (SCATTER) {
+        const uint64_t per = n_stretch / 4096u;
+        if (per && w < per * 4096u) w = (w % 4096u) * per + w / 4096u;
+    }
     const int lane = (int)(threadIdx.x & 63);
     const uint64_t base = w * (uint64_t)(10 * 2048) + (uint64_t)lane * 32;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
@@ -466,8 +473,9 @@ __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ s
     }
     if (acc == 0x12345678u) stamps[3] = acc; // (keeps the loads)
 }
-extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, hipStream_t stream) {
+extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, int scatter, hipStream_t stream) {
     if (n_stretch == 0) return hipSuccess;
-    hipLaunchKernelGGL(rb_k_box_probe, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    if (scatter) hipLaunchKernelGGL(rb_k_box_probe<true>, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    else hipLaunchKernelGGL(rb_k_box_probe<false>, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
     return hipGetLastError();
 }

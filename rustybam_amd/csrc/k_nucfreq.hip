@@ -25,6 +25,7 @@
 // HBM traffic: each read's packed bases once per tile it overlaps (4 bits / base), its CIGAR likewise, 16 B written per
 // position.  Bound: HBM (the counters never leave LDS).
 #include "rb_device.h"
+#include <algorithm>
 
 #ifndef NF_TILE
 #define NF_TILE 4096
@@ -67,6 +68,7 @@ struct rb_nf_params {
     uint64_t drop_words;
     uint32_t *deep_list;  // [n_regions + 1] regions whose fetch holds more reads than the cap; [n_regions] = how many
     uint32_t flags;       // bit 0: 16-bit counters for every tile (diagnostic)
+    struct nf_tdesc *tdesc; // [max_tiles] what a workgroup needs to know about a tile, in one 64-byte record (rb_k_nf_tile_desc)
 };
 
 // one read as the tile kernel sees it: a single 48-byte record (one scalar load) instead of eight arrays
@@ -384,6 +386,40 @@ __device__ __forceinline__ bool nf_dropped(const nf_drop &d, uint64_t i) { // di
 #define NF_U8_MAX_READS 255u
 __device__ __forceinline__ bool nf_u8_tile(const rb_nf_params &p, uint64_t lo, uint64_t hi) { return !(p.flags & 1u) && hi - lo <= NF_U8_MAX_READS; }
 
+// everything a workgroup needs about a tile in ONE 64-byte record at a wave-uniform address (a scalar load), instead of the chain tile_off ->
+// region (a binary search) -> region arrays -> drop_off -> tile_lo of the region's first tile that rb_k_nf_tiles walks at its start
+struct __attribute__((aligned(64))) nf_tdesc {
+    uint64_t st, out, lo, hi, drop_off, drop_rlo; // first position, first output position, reads [lo, hi), the region's dropped-read bitmap
+    uint32_t n_pos;
+    int32_t tid;
+    uint32_t r, u8; // region; 1: the byte-counter build takes the tile
+};
+// a record loaded at a wave-uniform address, told to the compiler as the wave-uniform value it is
+__device__ __forceinline__ uint64_t nf_first64(uint64_t v) { return rb_first64(v); }
+__device__ __forceinline__ nf_tdesc nf_uniform(const nf_tdesc &d) {
+    nf_tdesc o;
+    o.st = nf_first64(d.st), o.out = nf_first64(d.out), o.lo = nf_first64(d.lo), o.hi = nf_first64(d.hi);
+    o.drop_off = nf_first64(d.drop_off), o.drop_rlo = nf_first64(d.drop_rlo);
+    o.n_pos = rb_first(d.n_pos), o.tid = (int32_t)rb_first((uint32_t)d.tid), o.r = rb_first(d.r), o.u8 = rb_first(d.u8);
+    return o;
+}
+__device__ __forceinline__ nf_read nf_uniform(const nf_read &h) {
+    nf_read o;
+    o.pos = rb_first(h.pos), o.end = rb_first(h.end), o.tid = (int32_t)rb_first((uint32_t)h.tid), o.l_seq = rb_first(h.l_seq);
+    o.op_off = nf_first64(h.op_off), o.n_ops = rb_first(h.n_ops), o.pad0 = 0, o.nib0 = nf_first64(h.nib0), o.pad1 = 0;
+    return o;
+}
+__global__ __launch_bounds__(256) void rb_k_nf_tile_desc(rb_nf_params p) {
+    const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (t >= p.tile_off[p.n_regions]) return;
+    const nf_tile T = nf_tile_of(p, t);
+    const nf_drop d = nf_drop_of(p, T);
+    nf_tdesc D;
+    D.st = T.st, D.out = T.out, D.lo = p.tile_lo[t], D.hi = p.tile_hi[t], D.drop_off = d.off, D.drop_rlo = d.rlo;
+    D.n_pos = (uint32_t)(T.en - T.st), D.tid = T.tid, D.r = (uint32_t)T.r, D.u8 = nf_u8_tile(p, D.lo, D.hi) ? 1u : 0u;
+    p.tdesc[t] = D;
+}
+
 // LDS place of tile position i: two dwords (A | C << 16, G | T << 16); 8 guard positions in front (a lane's group of 8 may start
 // before the tile), and one dword skipped after every 8 positions so that the lanes of an atomic -- lane l adds to position
 // 8 l + k -- are 17 dwords apart and fall on different banks
@@ -422,10 +458,15 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     __shared__ __attribute__((aligned(16))) uint32_t stage_all[NF_WAVES][STG + 8]; // per wave: the bases one read lays over the tile (4 zero dwords in front)
     const uint64_t t = blockIdx.x;
     if (t >= p.tile_off[p.n_regions]) return;
-    if (nf_u8_tile(p, p.tile_lo[t], p.tile_hi[t]) != U8T) return; // the other build's
-    const nf_tile T = nf_tile_of(p, t);
-    const nf_drop drop = nf_drop_of(p, T);
-    const uint32_t n_pos = (uint32_t)(T.en - T.st);
+    // (round 4: the tile's facts come as ONE 64-byte record at a wave-uniform address -- rb_k_nf_tile_desc -- instead of a binary search
+    //  for the region followed by dependent loads of its arrays, of the region's first tile and of its dropped-read bitmap's place)
+    const nf_tdesc D = nf_uniform(p.tdesc[t]);
+    if ((D.u8 != 0u) != U8T) return; // the other build's
+    nf_tile T;
+    T.r = D.r, T.st = D.st, T.en = D.st + D.n_pos, T.out = D.out, T.tid = D.tid;
+    nf_drop drop;
+    drop.off = D.drop_off, drop.rlo = D.drop_rlo, drop.bits = p.drop_bits;
+    const uint32_t n_pos = D.n_pos;
     for (uint32_t k = threadIdx.x; k < (U8T ? NF_CNT8_DW : NF_CNT_DW); k += NF_THREADS) cnt[k] = 0;
     if ((threadIdx.x & 63u) < 4u) stage_all[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
     for (uint32_t k = threadIdx.x; k < (U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8); k += NF_THREADS) diff[k] = 0;
@@ -442,7 +483,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     __syncthreads();
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const int lane = rb_lane();
-    const uint64_t lo = p.tile_lo[t], hi = p.tile_hi[t];
+    const uint64_t lo = D.lo, hi = D.hi;
     // U8 tiles (at most 255 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
     // per 8 positions (lane l of an add is 10 l dwords on: all of a half-wave's 8-byte accesses on different banks), and one
     // ds_add_u64 covers two positions -- half the atomics of the 16-bit layout and no choice of word per base
@@ -720,6 +761,7 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     }
 }
 
+
 extern "C" size_t rb_nf_tile_positions(void) { return NF_TILE; }
 extern "C" size_t rb_nf_scan_blocks(uint64_t n) { return (size_t)((n + NF_SCAN_PER_BLOCK - 1) / NF_SCAN_PER_BLOCK); }
 
@@ -742,6 +784,7 @@ extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stre
     if (p.n_reads > RB_NF_DEPTH_CAP) hipLaunchKernelGGL(rb_k_nf_crowded, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_deep_regions, dim3((unsigned)((p.n_regions + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_admit, dim3(512), dim3(64), 0, stream, p);
+    hipLaunchKernelGGL(rb_k_nf_tile_desc, dim3((unsigned)((p.max_tiles + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_tiles<true>, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_tiles<false>, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
     return hipGetLastError();

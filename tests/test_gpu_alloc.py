@@ -1,4 +1,4 @@
-"""rb_dev_alloc / rb_dev_free (include/rustybam_amd.h): requests of 1 GB and more are built from 2 MB physical chunks mapped into one
+"""rb_dev_alloc / rb_dev_free (include/rustybam_amd.h): requests of 256 MB and more are built from 2 MB physical chunks mapped into one
 virtual range ("Where the batch lives"); every mode of RB_ALLOC_MODE must behave like plain device memory."""
 import ctypes as C
 import os

@@ -195,7 +195,8 @@ def test_full_size_liftover_every_row_equals_the_opspace_oracle(oracle):
     torch.cuda.synchronize()
     del out_g
     torch.cuda.empty_cache()
-    d_orows = torch.from_numpy(orows.view(np.uint8).reshape(-1)).to(dev)
+    from rustybam_amd import capi
+    d_orows = torch.from_numpy(capi.hit_rows_from(orows).view(np.uint8).reshape(-1)).to(dev)   # (the oracle's rows are 72 bytes, rb_hit_row 64)
     d_oops = torch.from_numpy(oops.view(np.int32)).to(dev)
     torch.cuda.synchronize()
     eng.dev_digest_rows(view, d_orows.data_ptr(), n, d_oops.data_ptr(), 0, 0, d_dig[1:].data_ptr())

@@ -94,6 +94,10 @@ def main():
     pair_in = int((nops64[left] + nops64[left + 1]).sum())        # (upper bound: the middle records have been cut once already in later passes)
     pair_out = int(2 * norm["n_ops"].astype(np.int64).sum() - norm["n_ops"][0::4].astype(np.int64).sum() - norm["n_ops"][3::4].astype(np.int64).sum())
     pair_bytes = 4 * pair_in + 128 * pairs + 4 * pair_out
+    # ... and what MOVES on a resident batch (RB_TRIM_IN_PLACE): the kept run of a regular record stays where it is -- only the two end
+    # words of each clip are rewritten --, so the clips are not written: ops read + rows + 2 words per clip (round-3 review: the figure
+    # above prices 4 B per emitted op that this route no longer emits)
+    pair_bytes_moved = 4 * pair_in + 128 * pairs + 2 * 2 * 4 * pairs
     # ---- break-paf --max-size 100 on the trimmed batch ----
     d_c = [torch.from_numpy(np.ascontiguousarray(norm[k]).view(np.int64)).to(dev) for k in ("t_st", "t_en", "q_st", "q_en")]
     B = DevBatch.from_device(torch, eng, dev, d_new, int(new_off[-1]), new_off, d_c, torch.from_numpy(strand).to(dev))
@@ -113,6 +117,10 @@ def main():
            "trim_roofline_on_wall": {"bound": "hbm", "achieved": round(pair_bytes / t_trim / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                      "frac": round(pair_bytes / t_trim / 8e12, 4),
                                      "note": "whole trim-paf stage (selection + pair kernels + apply + the host's reads) over the pair passes' algorithmic bytes"},
+           "trim_pair_pass_moved_bytes": pair_bytes_moved,
+           "trim_roofline_moved_on_wall": {"bound": "hbm", "achieved": round(pair_bytes_moved / t_trim / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                           "frac": round(pair_bytes_moved / t_trim / 8e12, 4),
+                                           "note": "the same time over the bytes the in-place route really moves (ops read + rows + two words per clip): the honest fraction"},
            "pairs_by_wave_kernel": T.pairs_by_wave,
            "break_pieces": int(rows.shape[0]), "break_wall_s": round(t_break, 4), "break_records_per_s_wall": n / t_break,
            "break_one_walk": not bool(cnt["redo_two_walk"]), "setup_s": round(gen, 2)}

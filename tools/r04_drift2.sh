@@ -10,7 +10,7 @@ import json,sys
 t,i=sys.argv[1],sys.argv[2]
 try:
     d=json.load(open(f"gpurun_out/{t}/b_{i}.json")); b=d.get("box",{})
-    print(i, "kernel", d["roofline"]["kernel_ms"], d["roofline"]["kernel_ms_steps"], "clock", b.get("kernel_clock_mhz"), "probe", b.get("probe_ms"), b.get("probe_clock_mhz"), "k/p", b.get("kernel_over_probe"), "tail", b.get("launch_tail"), b.get("error"))
+    print(i, "kernel", d["roofline"]["kernel_ms"], d["roofline"]["kernel_ms_steps"], "clock", b.get("kernel_clock_mhz"), "probe", b.get("probe_ms"), b.get("probe_scattered_ms"), "k/p", b.get("kernel_over_probe"), "chunked", d["config"].get("batch_buffers_chunked"), b.get("error"))
 except Exception as e:
     print(i, "failed", e, open(f"gpurun_out/{t}/err_{i}.txt").read()[-800:])
 PY
