@@ -348,10 +348,42 @@ static void keep_query_lines(const char *a, const char *e, std::vector<char> &ou
     if (run) out.insert(out.end(), run, e);
 }
 
+// stdin can be read once: what came out of it is kept, so that a command's text route and -- when a line needs the general parser --
+// the route it falls back to both see the input (round 4: `rb trim-paf x | rb break-paf -` took the line-by-line route for 15 GB)
+static const std::string &stdin_text() {
+    static std::string all;
+    static bool done = false;
+    if (!done) {
+        done = true;
+        gzFile f = gzdopen(0, "rb"); // (plain text passes through; gzip and BGZF are inflated)
+        if (!f) throw Panic("Failed to open -");
+        gzbuffer(f, 1 << 22);
+        size_t cap = (size_t)256 << 20, n = 0;
+        all.resize(cap);
+        for (;;) {
+            if (cap - n < ((size_t)16 << 20)) all.resize(cap *= 2);
+            const int r = gzread(f, &all[n], (unsigned)std::min<size_t>(cap - n, (size_t)1 << 30));
+            if (r <= 0) break;
+            n += (size_t)r;
+        }
+        gzclose(f);
+        all.resize(n);
+    }
+    return all;
+}
 // the whole (decompressed) text of a PAF file or stdin
 static std::string read_all(const std::string &file_name) {
     std::string all;
     bool plain = false;
+    if (file_name == "-") {
+        all = stdin_text();
+        if (g_qrange) {
+            std::vector<char> kept;
+            keep_query_lines(all.data(), all.data() + all.size(), kept);
+            all.assign(kept.data(), kept.size());
+        }
+        return all;
+    }
     if (file_name != "-") { // uncompressed regular file: read it directly (zlib's pass-through mode is 3x slower)
         FILE *fp = fopen(file_name.c_str(), "rb");
         if (!fp) throw Panic("Failed to open " + file_name);

@@ -944,7 +944,7 @@ int main(int argc, char **argv) {
         double tl = now_s();
         // text in -> text out (CIGAR text parsed / printed on the device) for regular files; stdin and RB_GENERAL_PATH=1 take the
         // record-based path, which every other arm uses anyway
-        const bool text_path = paf_path != "-" && !getenv("RB_GENERAL_PATH");
+        const bool text_path = !getenv("RB_GENERAL_PATH"); // (also for stdin: its text is kept, rb_host.cpp stdin_text)
         rb::Engine eng(device);
         lap("device context", tl);
         eng.bsearch_policy = policy;

@@ -218,16 +218,20 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef RB_RING_BASE
 #define RB_RING_BASE 80
 #endif
-#if RB_RING_BASE == 80
+#if RB_RING_BASE == 80 && RB_PF == 2
 #define RB_RING_TOP_N 95
-#elif RB_RING_BASE == 88
+#elif RB_RING_BASE == 88 && RB_PF == 2
 #define RB_RING_TOP_N 103
-#elif RB_RING_BASE == 96
+#elif RB_RING_BASE == 96 && RB_PF == 2
 #define RB_RING_TOP_N 111
-#elif RB_RING_BASE == 104
+#elif RB_RING_BASE == 104 && RB_PF == 2
 #define RB_RING_TOP_N 119
+#elif RB_RING_BASE == 96 && RB_PF == 3
+#define RB_RING_TOP_N 119
+#elif RB_RING_BASE == 104 && RB_PF == 3
+#define RB_RING_TOP_N 127
 #else
-#error "RB_RING_BASE: 80, 88, 96 or 104"
+#error "RB_RING_BASE / RB_PF: 80, 88, 96 or 104 with two slots; 96 or 104 with three"
 #endif
 #ifndef RB_RING_TOP
 #define RB_RING_TOP "v" RB_STR(RB_RING_TOP_N) // the last register of the ring (RB_RING_BASE + 8 RB_PF - 1): named as a clobber so that the kernel's register count covers it
@@ -241,7 +245,7 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 // registers OFF .. OFF + W of the ring, as the assembler reads them (it evaluates the sums)
 #define RB_RREG(OFF, W) "v[" RB_STR(RB_RING_BASE) "+" #OFF ":" RB_STR(RB_RING_BASE) "+" #OFF "+" #W "]"
-static_assert(RB_PF == 2, "the ring's asm statements are written out for two slots");
+static_assert(RB_PF == 2 || RB_PF == 3, "the ring's asm statements are written out for two or three slots");
 // BRK: break-paf in one walk (rb_lift.h, brk_max): the windows of a record are not given, they are the stretches between the indels
 // longer than brk_max, found while the record streams; 32 pieces a pass.  The liftover build has none of that code.
 // DIAG: the diagnostics build of the same kernel (bench.py --debug-skip: phases switched off, phase timers, clock stamps); the product
@@ -386,7 +390,8 @@ __device__ __forceinline__ void rb_stream_record() {
         const unsigned long long sv_ = sv_exec;                                                                                 \
         const unsigned long long lm_ = stp_ < n_steps ? sv_ : 0ull;                                                             \
         if constexpr ((RING) == 0) { RB_RING_LOAD_ASM(RB_RREG(0, 3), RB_RREG(4, 3)) }                                           \
-        else { RB_RING_LOAD_ASM(RB_RREG(8, 3), RB_RREG(12, 3)) }                                                                \
+        else if constexpr ((RING) == 1) { RB_RING_LOAD_ASM(RB_RREG(8, 3), RB_RREG(12, 3)) }                                     \
+        else { RB_RING_LOAD_ASM(RB_RREG(16, 3), RB_RREG(20, 3)) }                                                               \
     }
 #define RB_RING_NOSTORES                                                                                                        \
     _Pragma("unroll") for (int q_ = 0; q_ < 2 * RB_MS; q_++)                                                                    \
@@ -402,6 +407,10 @@ __device__ __forceinline__ void rb_stream_record() {
         RB_RING_LOAD(0, 0u)
         { RB_RING_NOSTORES }
         RB_RING_LOAD(1, 1u)
+#if RB_PF == 3
+        { RB_RING_NOSTORES }
+        RB_RING_LOAD(2, 2u)
+#endif
     }
     for (uint64_t jb = 0; jb < n_items; jb += RB_HMAX) {
         uint32_t nb = BRK ? 0u : (uint32_t)((nh - jb) < RB_HMAX ? (nh - jb) : RB_HMAX); // (BRK: pieces of this pass known so far, the open one included)
@@ -489,6 +498,10 @@ __device__ __forceinline__ void rb_stream_record() {
             RB_RING_LOAD(0, seg_first * RB_SMAX)
             { RB_RING_NOSTORES }
             RB_RING_LOAD(1, seg_first * RB_SMAX + 1u)
+#if RB_PF == 3
+            { RB_RING_NOSTORES }
+            RB_RING_LOAD(2, seg_first * RB_SMAX + 2u)
+#endif
             }
             // Speculative emission, per slot ("class") q: the CURRENT clip of the class -- its index among the pass's clips and its span in
             // reference offsets [c_ds, c_de) --, wave-uniform.  The clips of a class follow one another along the record (sorted windows),
@@ -529,7 +542,8 @@ __device__ __forceinline__ void rb_stream_record() {
                  : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3)                                                                       \
                  : "n"(RB_RING_WAIT));
                 if constexpr (ring == 0) { RB_RING_TAKE(RB_RREG(0, 1), RB_RREG(2, 1), RB_RREG(4, 1), RB_RREG(6, 1)) }
-                else { RB_RING_TAKE(RB_RREG(8, 1), RB_RREG(10, 1), RB_RREG(12, 1), RB_RREG(14, 1)) }
+                else if constexpr (ring == 1) { RB_RING_TAKE(RB_RREG(8, 1), RB_RREG(10, 1), RB_RREG(12, 1), RB_RREG(14, 1)) }
+                else { RB_RING_TAKE(RB_RREG(16, 1), RB_RREG(18, 1), RB_RREG(20, 1), RB_RREG(22, 1)) }
 #undef RB_RING_TAKE
                 unsigned long long msk[RB_MS];
 #pragma unroll
@@ -713,7 +727,8 @@ __device__ __forceinline__ void rb_stream_record() {
                  : [m0] "s"(m0), [m1] "s"(m1), [o] "v"(so), [sb] "s"(sb), [sv] "s"(sv_st)                                       \
                  : "memory");
                         if constexpr (ring == 0) { RB_RING_STORE(RB_RREG(0, 3), RB_RREG(4, 3)) }
-                        else { RB_RING_STORE(RB_RREG(8, 3), RB_RREG(12, 3)) }
+                        else if constexpr (ring == 1) { RB_RING_STORE(RB_RREG(8, 3), RB_RREG(12, 3)) }
+                        else { RB_RING_STORE(RB_RREG(16, 3), RB_RREG(20, 3)) }
 #undef RB_RING_STORE
                     }
                 }

@@ -522,6 +522,24 @@ def test_gpus_flag_stdin_general_path_and_refusals(golden):
         assert r.returncode == 2 and not r.stdout
 
 
+def test_stdin_takes_the_text_route_and_prints_what_the_file_prints(golden):
+    """`rb trim-paf x | rb break-paf -` (README.md:22-23): a command that reads stdin keeps the text and takes the device text route like
+    a file (round 3 sent stdin down the line-by-line route); same bytes as the file run for every hot-path command."""
+    paf = open(f"{golden}/asm_small.paf", "rb").read()
+    for a in (["break-paf", "--max-size", "100"], ["trim-paf"], ["stats", "--paf"], ["invert"], ["liftover", "--bed", f"{golden}/asm_small.bed"]):
+        rc_f, out_f = rb(*a, f"{golden}/asm_small.paf")
+        r = subprocess.run([RB, *a, "-"], input=paf, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert rc_f == 0 and r.returncode == 0 and r.stdout == out_f and len(out_f) > 500, a
+    # the README pipeline, through a real pipe
+    p1 = subprocess.Popen([RB, "trim-paf", f"{golden}/asm_small.paf"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    p2 = subprocess.run([RB, "break-paf", "--max-size", "100", "-"], stdin=p1.stdout, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    p1.stdout.close()
+    assert p1.wait() == 0 and p2.returncode == 0
+    rc_t, trimmed = rb("trim-paf", f"{golden}/asm_small.paf")
+    want = subprocess.run([RB, "break-paf", "--max-size", "100", "-"], input=trimmed, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    assert p2.stdout == want.stdout and p2.stdout.count(b"\n") > 2000
+
+
 def test_gpus_flag_panic_in_one_shard(golden, tmp_path):
     """a line the reference panics on, in the second shard: what the single run printed before the panic (the stats header, nothing
     for the other commands), exit code 101"""

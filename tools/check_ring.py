@@ -62,11 +62,15 @@ def compile_to_asm(hipcc, extra=()):
 
 def ring_of(flags):
     """The ring a build uses: v80..v95 unless -DRB_RING_BASE=<n> moves it."""
+    base, pf = RING[0], 2
     for f in flags:
         m = re.match(r"-DRB_RING_BASE=(\d+)$", f)
         if m:
-            return (int(m.group(1)), int(m.group(1)) + 15)
-    return RING
+            base = int(m.group(1))
+        m = re.match(r"-DRB_PF=(\d+)$", f)
+        if m:
+            pf = int(m.group(1))
+    return (base, base + 8 * pf - 1)
 
 
 if __name__ == "__main__":
