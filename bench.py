@@ -679,6 +679,8 @@ def main():
                 box["probe_gb_s"] = round(2.2 * src_bytes / (pms * 1e-3) / 1e9, 1)
                 sms, smhz = eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=True)
                 box["probe_scattered_ms"] = round(sms, 4)  # (the same bytes, the concurrently running waves spread over the whole arrays)
+                box["probe_flat_ms"] = round(eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=2)[0], 4)
+                box["probe_flat_scattered_ms"] = round(eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=3)[0], 4)
                 box["probe_note"] = (f"rb_dev_box_probe on this run's buffers: {src_bytes} B read from the ops array, 1.2 x that written to the output "
                                      "arena in the clip kernel's access shape (32 contiguous bytes per lane, two slots), no other instructions")
                 if k_ms == k_ms:

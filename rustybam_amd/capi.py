@@ -235,7 +235,7 @@ class Engine:
         """-> (ms per launch, shader MHz held): the clip kernel's memory mix without its instructions (diagnostics)."""
         ms, mhz = C.c_double(0), C.c_double(0)
         self._chk(self.L.rb_dev_box_probe(self.ctx, C.c_void_p(src_ptr), C.c_uint64(src_bytes), C.c_void_p(dst0_ptr), C.c_void_p(dst1_ptr),
-                                          C.c_int(reps), C.c_int(1 if scatter else 0), C.byref(ms), C.byref(mhz)), "rb_dev_box_probe")
+                                          C.c_int(reps), C.c_int(int(scatter)), C.byref(ms), C.byref(mhz)), "rb_dev_box_probe")
         return ms.value, mhz.value
 
     def plan_diag_stamps_offset(self, plan, rows_cap):

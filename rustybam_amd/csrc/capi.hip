@@ -168,6 +168,28 @@ extern "C" size_t rb_nf_scan_blocks(uint64_t n);
 #define RB_MAX_ARENA 256
 
 #define RB_TIMING_RING 256
+// Filling device memory is done by a kernel of the library (plain 16-byte stores; the runtime's hipMemsetAsync is a kernel too).
+// Round 4 wrote it while hunting a fill that "ran" and changed nothing; the cause turned out to be elsewhere -- a virtual range
+// given back and taken again, rb_free_vmm -- and the kernel stayed: one code path less that is not the library's own.
+__global__ __launch_bounds__(256) void rb_k_fill_bytes(uint8_t *dst, uint32_t v4, size_t n) {
+    const uintptr_t a = (uintptr_t)dst;
+    const size_t head = n < 16 ? n : (size_t)((16 - (a & 15)) & 15); // bytes in front of the first 16-byte boundary
+    const size_t body = (n - head) / 16;                             // whole 16-byte groups
+    const size_t tail0 = head + body * 16;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < body; k += stride) *reinterpret_cast<uint4 *>(dst + head + k * 16) = make_uint4(v4, v4, v4, v4);
+    if (i < head) dst[i] = (uint8_t)v4;
+    if (i < n - tail0) dst[tail0 + i] = (uint8_t)v4;
+}
+extern "C" hipError_t rb_fill_async(void *dst, int value, size_t bytes, hipStream_t stream) {
+    if (!bytes) return hipSuccess;
+    const uint32_t b = (uint32_t)value & 255u, v4 = b | (b << 8) | (b << 16) | (b << 24);
+    const size_t groups = bytes / 16 + 1;
+    const unsigned blocks = (unsigned)std::min<size_t>((groups + 255) / 256, 65536);
+    hipLaunchKernelGGL(rb_k_fill_bytes, dim3(blocks ? blocks : 1), dim3(256), 0, stream, (uint8_t *)dst, v4, bytes);
+    return hipGetLastError();
+}
+
 struct rb_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -190,7 +212,7 @@ struct rb_ctx {
     uint64_t alloc_fallbacks = 0; // rb_dev_alloc requests that wanted the chunked route and got plain hipMalloc
 };
 #define RB_PIN_CHUNK ((size_t)32 << 20)
-#define RB_PIN_MIN ((size_t)8 << 20) // smaller transfers take the runtime's own pageable path
+#define RB_PIN_MIN ((size_t)8 << 20) // (round 3: smaller transfers took the runtime's own pageable path; round 4: nothing does, rb_dev_upload says why)
 
 struct rb_plan {
     rb_ctx *ctx = nullptr;
@@ -328,7 +350,12 @@ static int rb_free_vmm(void *p, int device, hipError_t *err) {
     const size_t chunk = it->second.chunk, n = it->second.handles.size();
     for (size_t k = 0; k < n; k++) note(hipMemUnmap((char *)p + k * chunk, chunk));
     for (auto &h : it->second.handles) note(hipMemRelease(h));
-    note(hipMemAddressFree(p, it->second.bytes));
+    // The virtual range is NOT given back (hipMemAddressFree): a later reservation would get it again, and a kernel's stores into a
+    // buffer mapped at addresses this process had mapped before went to the OLD physical pages -- a fill kernel that "ran" and changed
+    // nothing that three different readers could see (tools/alloc_probe2.py: a 300 MB buffer taken right after a 1 GB one was freed;
+    // copies, which do not go through the compute units' translation caches, read and wrote the new pages).  Addresses are not
+    // scarce (a batch of 75 GB takes 2^-11 of the 47-bit range); memory is what is returned, chunk by chunk, above.
+    if (getenv("RB_ALLOC_FREE_VA")) note(hipMemAddressFree(p, it->second.bytes)); // (the probe's switch)
     g_vmm.erase(it);
     if (first != hipSuccess) (void)hipGetLastError();
     *err = first;
@@ -482,8 +509,10 @@ static void par_memcpy(void *dst, const void *src, size_t n) { // a chunk of the
 extern "C" int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, size_t bytes) {
     if (!ctx) return RB_E_INVALID;
     if (!bytes) return RB_OK;
-    if (bytes < RB_PIN_MIN || !pin_ready(ctx)) {
-        HIPCHK(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    // Every transfer goes through the context's own page-locked chunks (round 4; small ones used to be handed to the runtime as
+    // pageable memory): one path, and the caller's buffer is never pinned behind its back.
+    if (!pin_ready(ctx)) { // (no page-locked memory to be had: the runtime's path, synchronously)
+        HIPCHK(ctx, hipMemcpy(dev_dst, host_src, bytes, hipMemcpyHostToDevice));
         return RB_OK;
     }
     // host_src is consumed chunk by chunk into page-locked memory; when the call returns the caller may reuse it, the DMAs are
@@ -501,9 +530,13 @@ extern "C" int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, s
 }
 extern "C" int rb_dev_download(rb_ctx *ctx, void *host_dst, const void *dev_src, size_t bytes) {
     if (!ctx) return RB_E_INVALID;
-    if (bytes < RB_PIN_MIN || !pin_ready(ctx)) {
-        if (bytes) HIPCHK(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (!bytes) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        return RB_OK;
+    }
+    if (!pin_ready(ctx)) { // (see rb_dev_upload)
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipMemcpy(host_dst, dev_src, bytes, hipMemcpyDeviceToHost));
         return RB_OK;
     }
     // chunk k + 1 is in flight into one page-locked slot while chunk k leaves the other for host_dst
@@ -533,7 +566,7 @@ extern "C" int rb_dev_download(rb_ctx *ctx, void *host_dst, const void *dev_src,
 }
 extern "C" int rb_dev_memset(rb_ctx *ctx, void *dev_dst, int value, size_t bytes) {
     if (!ctx) return RB_E_INVALID;
-    if (bytes) HIPCHK(ctx, hipMemsetAsync(dev_dst, value, bytes, ctx->stream));
+    if (bytes) HIPCHK(ctx, rb_fill_async(dev_dst, value, bytes, ctx->stream));
     return RB_OK;
 }
 
@@ -563,8 +596,10 @@ template <typename T>
 static int upload_vec(rb_ctx *ctx, const std::vector<T> &v, T **dev) {
     int rc = rb_dev_alloc(ctx, v.size() * sizeof(T) + 16, (void **)dev);
     if (rc) return rc;
-    if (!v.empty()) {
-        hipError_t e = hipMemcpy(*dev, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    if (!v.empty()) { // (through the context's page-locked chunks, like every host transfer of the library: rb_dev_upload says why)
+        rc = rb_dev_upload(ctx, *dev, v.data(), v.size() * sizeof(T));
+        if (rc) return rc;
+        hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) return fail(ctx, RB_E_HIP, "plan upload: %s", hipGetErrorString(e));
     }
     return RB_OK;
@@ -835,7 +870,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
         sp.t_st = b->t_st, sp.t_en = b->t_en, sp.q_st = b->q_st, sp.q_en = b->q_en;
         sp.strand = b->strand;
         sp.norm_rows = p.norm_w;
-        HIPCHK(ctx, hipMemsetAsync(p.pend_count, 0, 8, ctx->stream));
+        HIPCHK(ctx, rb_fill_async(p.pend_count, 0, 8, ctx->stream));
         HIPCHK(ctx, rb_launch_peek_norm(&sp, ctx->stream)); // provisional rows from the records' ends
     }
     p.counters = counters;
@@ -843,9 +878,9 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.early_exit = (policy & RB_LIFT_EARLY_EXIT) ? 1 : 0;
     p.debug_skip = (policy >> 8) & 0xFFF; // diagnostics only, undocumented on purpose
     uint64_t *block_sums = (uint64_t *)(ws + w.block_sums);
-    HIPCHK(ctx, hipMemsetAsync(counters, 0, sizeof(rb_counters), ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(p.copy_count, 0, 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(p.arena_cur, 0, (size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8, ctx->stream));
+    HIPCHK(ctx, rb_fill_async(counters, 0, sizeof(rb_counters), ctx->stream));
+    HIPCHK(ctx, rb_fill_async(p.copy_count, 0, 8, ctx->stream));
+    HIPCHK(ctx, rb_fill_async(p.arena_cur, 0, (size_t)RB_MAX_ARENA * RB_ARENA_STRIDE * 8, ctx->stream));
     if (b->n_rec == 0) return RB_OK;
     const bool one_walk = is_break && (policy & RB_BREAK_ONE_WALK) && !p.desc_mode;
     if (one_walk) {
@@ -860,10 +895,10 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
         p.brk_arena_cap = rows_cap / p.brk_n_arena;
         p.brk_decl_list = (uint32_t *)(ws + w.decl_list);
         p.brk_decl_count = (unsigned long long *)(ws + w.decl_count);
-        HIPCHK(ctx, hipMemsetAsync(p.brk_decl_count, 0, 8, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(p.brk_cursor, 0, (size_t)RB_MAX_ARENA * 128, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(p.hit_off, 0, (size_t)(b->n_rec + 2) * 8, ctx->stream));
-        HIPCHK(ctx, hipMemsetAsync(p.brk_off, 0xFF, (size_t)(b->n_rec + 1) * 8, ctx->stream));
+        HIPCHK(ctx, rb_fill_async(p.brk_decl_count, 0, 8, ctx->stream));
+        HIPCHK(ctx, rb_fill_async(p.brk_cursor, 0, (size_t)RB_MAX_ARENA * 128, ctx->stream));
+        HIPCHK(ctx, rb_fill_async(p.hit_off, 0, (size_t)(b->n_rec + 2) * 8, ctx->stream));
+        HIPCHK(ctx, rb_fill_async(p.brk_off, 0xFF, (size_t)(b->n_rec + 1) * 8, ctx->stream));
         HIPCHK(ctx, rb_launch_make_jobs(&p, ctx->stream));
         const size_t slot1 = (size_t)(ctx->timed_calls % RB_TIMING_RING);
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_a[slot1], ctx->stream));
@@ -919,7 +954,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
         bp.tmp_cursor = (unsigned long long *)(ws + w.bp_cur);
         bp.n_arena = pick_arenas(b->n_rec);
         bp.arena_cap = rows_cap / bp.n_arena;
-        HIPCHK(ctx, hipMemsetAsync(bp.tmp_cursor, 0, (size_t)RB_MAX_ARENA * 128, ctx->stream));
+        HIPCHK(ctx, rb_fill_async(bp.tmp_cursor, 0, (size_t)RB_MAX_ARENA * 128, ctx->stream));
         bp.fill = 2, bp.redo_only = 0;
         HIPCHK(ctx, rb_launch_break_pieces(&bp, ctx->stream));
         HIPCHK(ctx, rb_launch_count_and_scan(&p, block_sums, false, ctx->stream));
@@ -1014,7 +1049,7 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     if (ctx->trim_pend) {
         p.pend = (unsigned long long *)ctx->trim_pend;
         p.pend_list = (uint32_t *)((char *)ctx->trim_pend + 256);
-        HIPCHK(ctx, hipMemsetAsync(p.pend, 0, 8, ctx->stream));
+        HIPCHK(ctx, rb_fill_async(p.pend, 0, 8, ctx->stream));
     }
     HIPCHK(ctx, rb_launch_overlap_split(&p, ctx->stream));
     return RB_OK;
@@ -1095,7 +1130,7 @@ extern "C" int rb_dev_gather_records(rb_ctx *ctx, uint64_t n_rec, const uint32_t
                                      uint64_t *new_op_off, uint32_t *new_ops, void *scratch) {
     if (!ctx || !new_op_off || !scratch || (n_rec && (!ops || !op_off || !norm_rows))) return RB_E_INVALID;
     rb_gather_params p{n_rec, ops, op_off, norm_rows, new_op_off, new_ops, 0};
-    HIPCHK(ctx, hipMemsetAsync(new_op_off + n_rec, 0, 8, ctx->stream));
+    HIPCHK(ctx, rb_fill_async(new_op_off + n_rec, 0, 8, ctx->stream));
     if (n_rec == 0) return RB_OK;
     HIPCHK(ctx, rb_launch_gather_records(&p, ctx->stream));
     HIPCHK(ctx, rb_launch_exclusive_scan(new_op_off, n_rec, (uint64_t *)scratch, nullptr, ctx->stream));
@@ -1121,7 +1156,7 @@ extern "C" int rb_dev_parse_cigars(rb_ctx *ctx, const uint8_t *text, const uint6
     p.ops = ops;
     p.ops_cap = ops_cap;
     p.status = status;
-    HIPCHK(ctx, hipMemsetAsync(op_off + n_rec, 0, 8, ctx->stream));
+    HIPCHK(ctx, rb_fill_async(op_off + n_rec, 0, 8, ctx->stream));
     if (n_rec == 0) return RB_OK;
     HIPCHK(ctx, rb_launch_parse_cigars(&p, false, ctx->stream));
     HIPCHK(ctx, rb_launch_exclusive_scan(op_off, n_rec, (uint64_t *)scratch, nullptr, ctx->stream));
@@ -1145,7 +1180,7 @@ static int format_cigars_impl(rb_ctx *ctx, const uint32_t *ops, const uint32_t *
     p.text_off = text_off;
     p.text = text;
     p.text_cap = text_cap;
-    if (!offsets_ready) HIPCHK(ctx, hipMemsetAsync(text_off + n_items, 0, 8, ctx->stream));
+    if (!offsets_ready) HIPCHK(ctx, rb_fill_async(text_off + n_items, 0, 8, ctx->stream));
     if (n_items == 0) return RB_OK;
     if (!offsets_ready) {
         HIPCHK(ctx, rb_launch_format_cigars(&p, false, ctx->stream));
@@ -1851,7 +1886,7 @@ extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes
     chk(hipEventCreate(&a));
     chk(hipEventCreate(&b));
     chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, scatter, ctx->stream)); // (untimed: first touch)
-    chk(hipMemsetAsync(stamps, 0, 64, ctx->stream));
+    chk(rb_fill_async(stamps, 0, 64, ctx->stream));
     chk(hipEventRecord(a, ctx->stream));
     for (int i = 0; i < reps && rc == RB_OK; i++) chk(rb_launch_box_probe(src, dst0, dst1, n_stretch, stamps, scatter, ctx->stream));
     chk(hipEventRecord(b, ctx->stream));
@@ -1911,7 +1946,7 @@ extern "C" int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t 
     if (!ws || ((uintptr_t)ws & 255) || ws_bytes < L.total) return fail(ctx, RB_E_INVALID, "nucfreq workspace: %zu bytes, 256-byte aligned, needed", L.total);
     if (L.max_tiles >= 0x7FFFFFFFull) return fail(ctx, RB_E_INVALID, "nucfreq: too many positions for one call");
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    HIPCHK(ctx, hipMemsetAsync(counters, 0, sizeof(rb_nucfreq_counters), ctx->stream));
+    HIPCHK(ctx, rb_fill_async(counters, 0, sizeof(rb_nucfreq_counters), ctx->stream));
     uint8_t *w = (uint8_t *)ws;
     rb_nf_params p{};
     p.n_reads = reads->n_reads;
@@ -1928,8 +1963,8 @@ extern "C" int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t 
     static const bool all_atomic = getenv("RB_DEBUG_NF_ATOMIC") != nullptr; // (diagnostic: every tile through the LDS-atomic kernel)
     p.flags = all_atomic ? 1u : 0u;
     p.tdesc = (void *)(w + L.tdesc);
-    HIPCHK(ctx, hipMemsetAsync(p.drop_bits - 1, 0, 8, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(p.deep_list + n_regions, 0, 8, ctx->stream)); // (how many deep regions; can the cap be reached at all)
+    HIPCHK(ctx, rb_fill_async(p.drop_bits - 1, 0, 8, ctx->stream));
+    HIPCHK(ctx, rb_fill_async(p.deep_list + n_regions, 0, 8, ctx->stream)); // (how many deep regions; can the cap be reached at all)
     HIPCHK(ctx, rb_launch_nucfreq(&p, ctx->stream));
     return RB_OK;
 }

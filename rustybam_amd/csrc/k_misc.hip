@@ -440,7 +440,9 @@ extern "C" hipError_t rb_launch_compact_clips(const rb_compact_params *p, hipStr
 typedef uint32_t rb_bp_u32x4 __attribute__((ext_vector_type(4)));
 // SCATTER: wave w takes stretch (w mod 4096) * (n / 4096) + w / 4096 -- the waves that run at the same time are then spread over the
 // whole array, 5 MB apart, as the clip kernel's are (its records run longest first, i.e. in no memory order), instead of side by side.
-template <bool SCATTER>
+// FLAT (scatter code 2 / 3): lane l takes bytes [16 l, 16 l + 16) and [1024 + 16 l, ...) of a 2 KiB step -- every instruction covers 1 KiB of
+// whole lines -- instead of the clip kernel's 32 contiguous bytes per lane: what the other load shape would be worth on these buffers.
+template <bool SCATTER, bool FLAT = false>
 __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ src, char *__restrict__ d0, char *__restrict__ d1, uint64_t n_stretch,
                                                       uint32_t *stamps /* [3]: sum of cycles >> 6, sum of 10 ns ticks, stamped waves */) {
     uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -450,19 +452,20 @@ __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ s
         if (per && w < per * 4096u) w = (w % 4096u) * per + w / 4096u;
     }
     const int lane = (int)(threadIdx.x & 63);
-    const uint64_t base = w * (uint64_t)(10 * 2048) + (uint64_t)lane * 32;
+    const uint64_t base = w * (uint64_t)(10 * 2048) + (uint64_t)lane * (FLAT ? 16 : 32);
+    constexpr uint64_t second = FLAT ? 1024 : 16;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     uint32_t acc = 0;
 #pragma unroll 2
     for (int s = 0; s < 10; s++) {
         const uint64_t o = base + (uint64_t)s * 2048;
-        const rb_bp_u32x4 a = *(const rb_bp_u32x4 *)(src + o), b = *(const rb_bp_u32x4 *)(src + o + 16);
+        const rb_bp_u32x4 a = *(const rb_bp_u32x4 *)(src + o), b = *(const rb_bp_u32x4 *)(src + o + second);
         acc += a.x ^ b.y;
         *(rb_bp_u32x4 *)(d0 + o) = a;
-        *(rb_bp_u32x4 *)(d0 + o + 16) = b;
+        *(rb_bp_u32x4 *)(d0 + o + second) = b;
         if (s % 5 == 0) {
             *(rb_bp_u32x4 *)(d1 + o) = a;
-            *(rb_bp_u32x4 *)(d1 + o + 16) = b;
+            *(rb_bp_u32x4 *)(d1 + o + second) = b;
         }
     }
     const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
@@ -475,7 +478,10 @@ __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ s
 }
 extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, int scatter, hipStream_t stream) {
     if (n_stretch == 0) return hipSuccess;
-    if (scatter) hipLaunchKernelGGL(rb_k_box_probe<true>, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
-    else hipLaunchKernelGGL(rb_k_box_probe<false>, dim3((unsigned)((n_stretch + 3) / 4)), dim3(256), 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    const dim3 g((unsigned)((n_stretch + 3) / 4)), b(256);
+    if (scatter == 3) hipLaunchKernelGGL((rb_k_box_probe<true, true>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    else if (scatter == 2) hipLaunchKernelGGL((rb_k_box_probe<false, true>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    else if (scatter) hipLaunchKernelGGL((rb_k_box_probe<true, false>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    else hipLaunchKernelGGL((rb_k_box_probe<false, false>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
     return hipGetLastError();
 }

@@ -1209,8 +1209,9 @@ __global__ __launch_bounds__(256) void rb_k_trim_check(const rb_pair_row *rows, 
     if (k < n_pairs && rows[k].status != RB_ST_OK) atomicMax(&pass->bad_status, rows[k].status);
 }
 extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t *block_sums, uint64_t *total_out, hipStream_t stream);
+extern "C" hipError_t rb_fill_async(void *dst, int value, size_t bytes, hipStream_t stream);
 extern "C" hipError_t rb_launch_trim_select(const rb_tsel_params *p, uint64_t *block_sums, hipStream_t stream) {
-    hipError_t e = hipMemsetAsync(p->pass, 0, sizeof(rb_trim_pass), stream);
+    hipError_t e = rb_fill_async(p->pass, 0, sizeof(rb_trim_pass), stream); // (the library's own fill kernel: capi.hip says why)
     if (e != hipSuccess) return e;
     if (p->n_groups == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((p->n_groups + 255) / 256);

@@ -346,14 +346,48 @@ def _check_break_rows(torch, dev, rows, out, n_rec):
     return rows
 
 
-def test_full_size_break_paf_integrity():
+def test_full_size_break_paf_integrity(oracle):
     """break-paf --max-size 100 on the same 1e6 records: every piece passes check_integrity, pieces of a record come in target order
-    and do not overlap, and no piece contains an insertion or deletion longer than the limit"""
+    and do not overlap, and no piece contains an insertion or deletion longer than the limit -- and (round 4) ALL pieces equal the
+    op-space CPU port's (oracle/rb_opspace.c rbo_break_opspace_arrays, held to the per-base oracle by tests/test_oracle_opspace.py):
+    every row field by field, every clipped CIGAR through the device digest over both outputs."""
     C = _config3(is_break=True)
-    torch, dev, eng, run, n_rec, total_ops = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops"))
-    rows, out = run(rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN, 8 * n_rec, int(1.4 * total_ops))
+    torch, dev, eng, run, n_rec, total_ops, d_ops = (C[k] for k in ("torch", "dev", "eng", "run", "n_rec", "total_ops", "d_ops"))
+    rows, out = run(rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN | rustybam_amd.BREAK_ONE_WALK, 8 * n_rec, int(1.4 * total_ops))
     assert rows.shape[0] > 2 * n_rec
     _check_break_rows(torch, dev, rows, out, n_rec)
+    try:
+        avail_gb = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1]) / 1e6
+    except Exception:
+        avail_gb = 0.0
+    if avail_gb >= 60 * n_rec / 1e6 + 8:
+        from rustybam_amd import capi
+        H = C["host"]
+        n = rows.shape[0]
+        ops_host = d_ops[:total_ops].cpu().numpy().view(np.uint32)
+        ob = oracle.Batch(ops_host, H["op_off"], H["t_st"], H["t_en"], H["q_st"], H["q_en"], H["strand"], np.zeros(n_rec, np.uint32))
+        got = oracle.break_opspace(ob, 100, n_threads=min(64, os.cpu_count() or 1))
+        assert got is not None
+        orows, oops = got
+        assert len(orows) == n, f"{n} GPU pieces, {len(orows)} of the op-space port"
+        grows = rows.cpu().numpy().view(np.uint8).reshape(n, 64).view(rustybam_amd.HIT_DT).reshape(n)
+        for key in ("rec", "win", "status", "out_n", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len"):
+            bad = int((grows[key].astype(np.uint64) != orows[key].astype(np.uint64)).sum())
+            assert bad == 0, f"{key}: {bad} of {n} pieces differ from the op-space port"
+        d_dig = torch.zeros(2, dtype=torch.int64, device=dev)
+        d_rows_g = rows.contiguous()
+        torch.cuda.synchronize()
+        eng.dev_digest_rows(C["view"], d_rows_g.data_ptr(), n, out.data_ptr(), 0, 0, d_dig[0:].data_ptr())
+        torch.cuda.synchronize()
+        del out
+        torch.cuda.empty_cache()
+        d_orows = torch.from_numpy(capi.hit_rows_from(orows).view(np.uint8).reshape(-1)).to(dev)
+        d_oops = torch.from_numpy(oops.view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        eng.dev_digest_rows(C["view"], d_orows.data_ptr(), n, d_oops.data_ptr(), 0, 0, d_dig[1:].data_ptr())
+        torch.cuda.synchronize()
+        dg = d_dig.cpu().numpy().view(np.uint64)
+        assert dg[0] == dg[1], f"digest of the GPU's pieces {int(dg[0]):#x} != digest of the port's {int(dg[1]):#x}"
     eng.close()
 
 
