@@ -184,6 +184,75 @@ def smi_facts():
         return {"error": f"{type(e).__name__}: {e}"}
 
 
+class SmiSampler:
+    """`rocm-smi` in a loop as a child process, started BEFORE this process touches the GPU (a process that has must not fork + exec) and
+    stopped by its pid at the end: what the clocks (sclk / mclk / fclk), the temperatures and the package power read WHILE the clip
+    kernel runs.  One JSON document per sample, each stamped with the wall clock."""
+
+    def __init__(self):
+        import shutil
+        import subprocess
+        import tempfile
+        self.proc, self.path = None, None
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        if not os.path.exists(exe):
+            return
+        fd, self.path = tempfile.mkstemp(prefix="rb_smi_", suffix=".txt")
+        os.close(fd)
+        # (it samples only once `<path>.go` exists: nothing polls the chip's management unit during the timed region)
+        loop = (f'while [ ! -e {self.path}.go ]; do sleep 0.05; done; '
+                f'while true; do echo "@@ $(date +%s.%N)"; {exe} --showclocks --showpower --showtemp --json 2>/dev/null; sleep 0.1; done')
+        try:
+            self.proc = subprocess.Popen(["bash", "-c", loop], stdout=open(self.path, "w"), stderr=subprocess.DEVNULL, start_new_session=True)
+        except Exception:
+            self.proc = None
+
+    def go(self):
+        if self.proc:
+            open(self.path + ".go", "w").close()
+
+    def stop(self, t_from, t_to):
+        """-> {field: [min, max]} over the samples taken in [t_from, t_to] (time.time() stamps), or None"""
+        if not self.proc:
+            return None
+        try:
+            import signal
+            os.killpg(self.proc.pid, signal.SIGTERM)  # (the exact process group this object started)
+            self.proc.wait(timeout=5)
+        except Exception:
+            pass
+        out = {}
+        try:
+            n = 0
+            for chunk in open(self.path).read().split("@@ ")[1:]:
+                head, _, body = chunk.partition("\n")
+                ts = float(head.strip())
+                if not (t_from <= ts <= t_to) or "{" not in body:
+                    continue
+                try:
+                    j = json.loads(body[body.index("{"):body.rindex("}") + 1])
+                except Exception:
+                    continue
+                c = j.get("card0") or next(iter(j.values()))
+                n += 1
+                for k_, v in c.items():
+                    lk = k_.lower()
+                    if not ("clock speed" in lk or "temperature" in lk or "power" in lk):
+                        continue
+                    try:
+                        x = float(str(v).strip("()").lower().replace("mhz", "").replace("c", "").replace("w", ""))
+                    except Exception:
+                        continue
+                    lo, hi = out.get(k_, (x, x))
+                    out[k_] = (min(lo, x), max(hi, x))
+            os.unlink(self.path)
+            if os.path.exists(self.path + ".go"):
+                os.unlink(self.path + ".go")
+            return {"samples": n, **{k_: [v[0], v[1]] for k_, v in sorted(out.items())}} if n else {"samples": 0}
+        except Exception as e:
+            return {"error": f"{type(e).__name__}: {e}"}
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -201,6 +270,7 @@ def main():
         return
     e2e = None
     smi = smi_facts() if (rank == 0 and not args.no_box) else None
+    sampler = SmiSampler() if (rank == 0 and not args.no_box) else None  # (a child process, started before this one touches the GPU)
     if rank == 0 and args.e2e_records > 0 and args.workload == "config3" and args.op == "liftover" and not args.no_cpu_baseline:
         # (child processes, before this one initialises the GPU; with N ranks: `rb --gpus N` on the same file while the other ranks
         #  wait for rank 0 at the rendezvous)
@@ -636,7 +706,7 @@ def main():
 
     # ---- the box: why this line reads what it reads on THIS machine (rank 0, outside the timed region, after every check: the probe
     #      overwrites the output arena).  (a) the clock the clip kernel holds: its diagnostics build (same code + s_memtime /
-    #      s_memrealtime stamps around the streaming loop of every 16th record, written to a counter block nothing reads) after >= 2 s
+    #      s_memrealtime stamps around the streaming loop of every 16th record, written to a counter block nothing reads) after >= 3 s
     #      of back-to-back launches; the same run leaves the time each wave was done, hence how long the launch ran on after 95 % of
     #      them had retired.  (b) the library's memory-mix probe on these very buffers: the kernel's bytes in its access shape without
     #      its instructions -- a box that is slow at moving bytes shows here, a box that holds a lower clock shows in (a).
@@ -645,13 +715,19 @@ def main():
         try:
             dpol = policy | ((128 | 256) << 8)
             eng.set_timing(True)
-            tb0, n_diag = time.perf_counter(), 0
-            while n_diag < 10 or time.perf_counter() - tb0 < 2.0:
+            if sampler:
+                sampler.go()
+            tb0, n_diag, wall0 = time.perf_counter(), 0, time.time()
+            while n_diag < 10 or time.perf_counter() - tb0 < 3.0:
                 eng.dev_liftover(plan, view, d_norm.data_ptr(), dpol, d_ws.data_ptr(), d_rows.data_ptr(), rows_cap, d_out.data_ptr(), out_cap, d_cnt.data_ptr())
                 n_diag += 1
                 if n_diag % 10 == 0:
                     torch.cuda.synchronize()
             torch.cuda.synchronize()
+            wall1 = time.time()
+            if sampler:  # rocm-smi's view of the chip while the clip kernel ran back to back (clocks incl. memory and fabric, temperatures, power)
+                box["smi_under_load"] = sampler.stop(wall0 + 0.3, wall1)
+                sampler = None
             dms = eng.get_timing()
             eng.set_timing(False)
             dc = d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]
@@ -688,6 +764,8 @@ def main():
         except Exception as e:  # (diagnostics: never in the way of the line)
             box["error"] = f"{type(e).__name__}: {e}"
         result["box"] = box
+    if sampler:
+        sampler.stop(0, 0)
     if rank == 0:
         print(json.dumps(result))
     d_ops = d_ws = d_rows = d_out = rows_t = None

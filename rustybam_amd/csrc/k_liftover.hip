@@ -182,13 +182,23 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
 // ------------------------------------------------------------------------------------------------
 // streaming kernel
 // ------------------------------------------------------------------------------------------------
-#define RB_STEP_SHIFT 9  // a step is 512 ops: 8 ops (two 16-byte loads, 32 contiguous bytes) per lane
-#define RB_CP_PER_STEP (512 / RB_CP_OPS) // one checkpoint per RB_CP_OPS ops (16: every second lane; 8: every lane)
+// RB_OPL: ops per lane and step.  8 ("pair", the product): a step is 512 ops, two 16-byte loads of 32 contiguous bytes per lane.
+// 4 ("flat", a build switch): a step is 256 ops, ONE 16-byte load per lane -- every load and store instruction covers 1 KiB of whole
+// 128-byte lines, which the memory-mix probe prices 6 % under the pair shape (bench.py box.probe_flat_ms) -- at twice the steps,
+// i.e. twice the wave scans and scalar bookkeeping per op.
+#ifndef RB_OPL
+#define RB_OPL 8
+#endif
+static_assert(RB_OPL == 8 || RB_OPL == 4, "ops per lane and step: 8 or 4");
+#define RB_GRP (RB_OPL / 4)                    // 16-byte groups per lane and step
+#define RB_STEP_SHIFT (RB_OPL == 8 ? 9 : 8)    // log2 of the ops of a step
+#define RB_CP_PER_STEP ((64 * RB_OPL) / RB_CP_OPS) // one checkpoint per RB_CP_OPS ops
+#define RB_CP_LANES (RB_CP_OPS / RB_OPL)       // lanes that share a checkpoint (the first of them leaves it)
 #ifndef RB_PF
-#define RB_PF 2 // steps (2 KiB each) of stream loads in flight per wave
+#define RB_PF (RB_OPL == 8 ? 2 : 4) // steps of stream loads in flight per wave (4 KiB either way)
 #endif
 #ifndef RB_SEG
-#define RB_SEG 10
+#define RB_SEG (RB_OPL == 8 ? 10 : 20)
 #endif
 #define RB_SMAX ((RB_SEG / RB_PF) * RB_PF) // steps whose checkpoints fit in LDS at once; whole turns of the load ring
 #ifndef RB_WPE
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
 #endif
 // vector-memory instructions a step of the streaming loop issues, always (stores whose mask is empty are issued with an empty
 // exec mask: they move nothing but they count, tools/vmcnt_probe.hip, which keeps every s_waitcnt immediate exact)
-#define RB_STEP_VMEM (2 * RB_MS + 2)
+#define RB_STEP_VMEM (RB_GRP * RB_MS + RB_GRP)
 #ifndef RB_RING_WAIT
 #define RB_RING_WAIT ((RB_PF - 1) * RB_STEP_VMEM)
 #endif
@@ -218,7 +228,7 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #ifndef RB_RING_BASE
 #define RB_RING_BASE 80
 #endif
-#if RB_RING_BASE == 80 && RB_PF == 2
+#if RB_RING_BASE == 80 && RB_PF == 2 && RB_OPL == 8
 #define RB_RING_TOP_N 95
 #elif RB_RING_BASE == 88 && RB_PF == 2
 #define RB_RING_TOP_N 103
@@ -226,6 +236,10 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #define RB_RING_TOP_N 111
 #elif RB_RING_BASE == 104 && RB_PF == 2
 #define RB_RING_TOP_N 119
+#elif RB_RING_BASE == 80 && RB_PF == 4 && RB_OPL == 4
+#define RB_RING_TOP_N 95
+#elif RB_RING_BASE == 96 && RB_PF == 4 && RB_OPL == 4
+#define RB_RING_TOP_N 111
 #elif RB_RING_BASE == 96 && RB_PF == 3
 #define RB_RING_TOP_N 119
 #elif RB_RING_BASE == 104 && RB_PF == 3
@@ -245,7 +259,15 @@ typedef uint32_t rb_u32x4 __attribute__((ext_vector_type(4)));
 #endif
 // registers OFF .. OFF + W of the ring, as the assembler reads them (it evaluates the sums)
 #define RB_RREG(OFF, W) "v[" RB_STR(RB_RING_BASE) "+" #OFF ":" RB_STR(RB_RING_BASE) "+" #OFF "+" #W "]"
-static_assert(RB_PF == 2 || RB_PF == 3, "the ring's asm statements are written out for two or three slots");
+// RB_RING_CASE(ring, M): M(<the slot's registers>) for the ring slot `ring` (a compile-time constant)
+#if RB_OPL == 8
+#define RB_RING_CASE(RING, M)                                                                                                   \
+    if constexpr ((RING) == 0) { M(0, 2, 4, 6) } else if constexpr ((RING) == 1) { M(8, 10, 12, 14) } else { M(16, 18, 20, 22) }
+#else
+#define RB_RING_CASE(RING, M)                                                                                                   \
+    if constexpr ((RING) == 0) { M(0, 2, 0, 0) } else if constexpr ((RING) == 1) { M(4, 6, 0, 0) } else if constexpr ((RING) == 2) { M(8, 10, 0, 0) } else { M(12, 14, 0, 0) }
+#endif
+static_assert((RB_OPL == 8 && (RB_PF == 2 || RB_PF == 3)) || (RB_OPL == 4 && RB_PF == 4), "the ring's asm statements are written out for two or three slots of eight registers, or four of four");
 // BRK: break-paf in one walk (rb_lift.h, brk_max): the windows of a record are not given, they are the stretches between the indels
 // longer than brk_max, found while the record streams; 32 pieces a pass.  The liftover build has none of that code.
 // DIAG: the diagnostics build of the same kernel (bench.py --debug-skip: phases switched off, phase timers, clock stamps); the product
@@ -338,7 +360,7 @@ __device__ __forceinline__ void rb_stream_record() {
     const uint32_t *__restrict__ gbase0 = p.ops + g0;
     const uint32_t first_boff = (uint32_t)head * 4u;                          // byte offset (from g0) of the record's first op
     const uint32_t last_boff = (uint32_t)(((gend - 1u) & ~3ull) - g0) * 4u;   // ... of the last 16-byte group that holds an op of it
-    const uint32_t last_cboff = last_boff & ~31u;                             // ... of the 32-byte chunk (8 ops, one lane) with that group
+    const uint32_t last_cboff = last_boff & ~(4u * RB_OPL - 1u);              // ... of the chunk (RB_OPL ops, one lane) with that group
 
     // ---- where clips go.  Output copy ("slot") k of the batch mirrors the input positions: the op at coordinate c of this
     //      record (c counted from g0, the first op of the record's first 128-byte line) lives at
@@ -370,17 +392,27 @@ __device__ __forceinline__ void rb_stream_record() {
     uint32_t resume_seg = 0, resume_R = 0, resume_Q = 0, resume_U = 0;
     unsigned long long sv_exec;
     asm volatile("s_mov_b64 %0, exec" : "=s"(sv_exec));
-    const uint32_t lane_boff = (uint32_t)lane * 32u;
+    const uint32_t lane_boff = (uint32_t)lane * (4u * RB_OPL);
     // (chunks past the record's end are not loaded: lanes behind the last chunk re-read it, and the loads of steps
     //  behind the last one run with an empty exec mask)
-#define RB_RING_LOAD_ASM(RA, RB_)                                                                                               \
+#if RB_OPL == 8
+#define RB_RING_LOAD_ASM(A, B_, C_, D_)                                                                                         \
     asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
-         "global_load_dwordx4 " RA ", %[o], %[sb]\n\t"                                                                  \
-         "global_load_dwordx4 " RB_ ", %[o], %[sb] offset:16\n\t"                                                       \
+         "global_load_dwordx4 " RB_RREG(A, 3) ", %[o], %[sb]\n\t"                                                       \
+         "global_load_dwordx4 " RB_RREG(C_, 3) ", %[o], %[sb] offset:16\n\t"                                            \
          "s_mov_b64 exec, %[sv]"                                                                                        \
          :                                                                                                              \
          : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
          : "memory", RB_RING_TOP);
+#else
+#define RB_RING_LOAD_ASM(A, B_, C_, D_)                                                                                         \
+    asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
+         "global_load_dwordx4 " RB_RREG(A, 3) ", %[o], %[sb]\n\t"                                                       \
+         "s_mov_b64 exec, %[sv]"                                                                                        \
+         :                                                                                                              \
+         : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
+         : "memory", RB_RING_TOP);
+#endif
 #define RB_RING_LOAD(RING, STP)                                                                                                 \
     {                                                                                                                           \
         const uint32_t stp_ = (STP);                                                                                            \
@@ -389,12 +421,10 @@ __device__ __forceinline__ void rb_stream_record() {
         const uint32_t *const gb_ = gbase0; /* (named copies: a generic lambda does not capture what only an asm operand uses) */ \
         const unsigned long long sv_ = sv_exec;                                                                                 \
         const unsigned long long lm_ = stp_ < n_steps ? sv_ : 0ull;                                                             \
-        if constexpr ((RING) == 0) { RB_RING_LOAD_ASM(RB_RREG(0, 3), RB_RREG(4, 3)) }                                           \
-        else if constexpr ((RING) == 1) { RB_RING_LOAD_ASM(RB_RREG(8, 3), RB_RREG(12, 3)) }                                     \
-        else { RB_RING_LOAD_ASM(RB_RREG(16, 3), RB_RREG(20, 3)) }                                                               \
+        RB_RING_CASE(RING, RB_RING_LOAD_ASM)                                                                                    \
     }
 #define RB_RING_NOSTORES                                                                                                        \
-    _Pragma("unroll") for (int q_ = 0; q_ < 2 * RB_MS; q_++)                                                                    \
+    _Pragma("unroll") for (int q_ = 0; q_ < RB_GRP * RB_MS; q_++)                                                               \
         asm volatile("s_mov_b64 exec, 0\n\tglobal_store_dword %0, %0, %1\n\ts_mov_b64 exec, %2" ::"v"(0u), "s"(gbase0), "s"(sv_exec) : "memory");
     // The first pass of a record streams it from its first step: the ring's first loads go out HERE, in front of the pass's window loads
     // (a chain of dependent loads of its own), not behind them -- one memory latency per record instead of two in front of the first step.
@@ -407,9 +437,13 @@ __device__ __forceinline__ void rb_stream_record() {
         RB_RING_LOAD(0, 0u)
         { RB_RING_NOSTORES }
         RB_RING_LOAD(1, 1u)
-#if RB_PF == 3
+#if RB_PF >= 3
         { RB_RING_NOSTORES }
         RB_RING_LOAD(2, 2u)
+#endif
+#if RB_PF >= 4
+        { RB_RING_NOSTORES }
+        RB_RING_LOAD(3, 3u)
 #endif
     }
     for (uint64_t jb = 0; jb < n_items; jb += RB_HMAX) {
@@ -498,9 +532,13 @@ __device__ __forceinline__ void rb_stream_record() {
             RB_RING_LOAD(0, seg_first * RB_SMAX)
             { RB_RING_NOSTORES }
             RB_RING_LOAD(1, seg_first * RB_SMAX + 1u)
-#if RB_PF == 3
+#if RB_PF >= 3
             { RB_RING_NOSTORES }
             RB_RING_LOAD(2, seg_first * RB_SMAX + 2u)
+#endif
+#if RB_PF >= 4
+            { RB_RING_NOSTORES }
+            RB_RING_LOAD(3, seg_first * RB_SMAX + 3u)
 #endif
             }
             // Speculative emission, per slot ("class") q: the CURRENT clip of the class -- its index among the pass's clips and its span in
@@ -535,73 +573,73 @@ __device__ __forceinline__ void rb_stream_record() {
                 const bool validate_s = fast ? true : validate, spec_s = fast ? true : spec, later_s = fast ? false : (jb != 0);
                 // the step's 8 ops leave the ring for registers of the compiler's choosing once they have landed
                 // (no memory clobber: the compiler takes an asm that may load for a load still in flight and waits vmcnt(0) at the first use of its outputs)
-                unsigned long long a0, a1, a2, a3;
-#define RB_RING_TAKE(R0, R1, R2, R3)                                                                                            \
+                unsigned long long a0, a1, a2 = 0, a3 = 0;
+#if RB_OPL == 8
+#define RB_RING_TAKE(A, B_, C_, D_)                                                                                             \
     asm volatile("s_waitcnt vmcnt(%4)\n\t"                                                                                      \
-                 "v_mov_b64 %0, " R0 "\n\tv_mov_b64 %1, " R1 "\n\tv_mov_b64 %2, " R2 "\n\tv_mov_b64 %3, " R3                      \
+                 "v_mov_b64 %0, " RB_RREG(A, 1) "\n\tv_mov_b64 %1, " RB_RREG(B_, 1) "\n\tv_mov_b64 %2, " RB_RREG(C_, 1) "\n\tv_mov_b64 %3, " RB_RREG(D_, 1) \
                  : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3)                                                                       \
                  : "n"(RB_RING_WAIT));
-                if constexpr (ring == 0) { RB_RING_TAKE(RB_RREG(0, 1), RB_RREG(2, 1), RB_RREG(4, 1), RB_RREG(6, 1)) }
-                else if constexpr (ring == 1) { RB_RING_TAKE(RB_RREG(8, 1), RB_RREG(10, 1), RB_RREG(12, 1), RB_RREG(14, 1)) }
-                else { RB_RING_TAKE(RB_RREG(16, 1), RB_RREG(18, 1), RB_RREG(20, 1), RB_RREG(22, 1)) }
+#else
+#define RB_RING_TAKE(A, B_, C_, D_)                                                                                             \
+    asm volatile("s_waitcnt vmcnt(%2)\n\t"                                                                                      \
+                 "v_mov_b64 %0, " RB_RREG(A, 1) "\n\tv_mov_b64 %1, " RB_RREG(B_, 1)                                             \
+                 : "=v"(a0), "=v"(a1)                                                                                           \
+                 : "n"(RB_RING_WAIT));
+#endif
+                RB_RING_CASE(ring, RB_RING_TAKE)
 #undef RB_RING_TAKE
                 unsigned long long msk[RB_MS];
 #pragma unroll
                 for (int q = 0; q < RB_MS; q++) msk[q] = 0ull;
                 if (fast || st < seg1) { // (no break: the ring must be in the same state on every path)
-                    uint32_t w[8] = {(uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32),
-                                     (uint32_t)a2, (uint32_t)(a2 >> 32), (uint32_t)a3, (uint32_t)(a3 >> 32)};
-                    uint32_t c[8]; // what the verification looks at
+                    const uint32_t w_all[8] = {(uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32),
+                                               (uint32_t)a2, (uint32_t)(a2 >> 32), (uint32_t)a3, (uint32_t)(a3 >> 32)};
+                    uint32_t w[RB_OPL], c[RB_OPL]; // the lane's ops; what the verification looks at
 #pragma unroll
-                    for (int q = 0; q < 8; q++) c[q] = w[q];
+                    for (int q = 0; q < RB_OPL; q++) w[q] = c[q] = w_all[q];
                     if (edge) {
                         // ops of the neighbouring records: zero for the sums (a 0-length M); for the verification an I / D of length
                         // 1 by position parity -- regular, alternating, and never equal to the match op a normalised record ends on
-                        const int32_t idx0 = (int32_t)(st << RB_STEP_SHIFT) + lane * 8 - head;
+                        const int32_t idx0 = (int32_t)(st << RB_STEP_SHIFT) + lane * RB_OPL - head;
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
+                        for (int q = 0; q < RB_OPL; q++) {
                             const bool ok = (uint32_t)(idx0 + q) < n; // (also the negative head indices)
                             c[q] = ok ? w[q] : ((q & 1) ? 0x12u : 0x11u);
                             w[q] = ok ? w[q] : 0u;
                         }
                     }
                     if (validate_s) {
-                        const uint32_t prevw = rb_prev_lane(c[7], v_carry); // previous lane's last op; lane 0: the previous step's
-                        v_carry = rb_readlane<uint32_t>(c[7], 63);
-                        uint32_t rg[8], x[8];
+                        const uint32_t prevw = rb_prev_lane(c[RB_OPL - 1], v_carry); // previous lane's last op; lane 0: the previous step's
+                        v_carry = rb_readlane<uint32_t>(c[RB_OPL - 1], 63);
+                        uint32_t rg[RB_OPL], x[RB_OPL];
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
+                        for (int q = 0; q < RB_OPL; q++) {
                             rg[q] = (uint32_t)__builtin_amdgcn_sbfe((int)0x018F018Fu, c[q], 1u); // M I D N = X
                             x[q] = (c[q] ^ (q ? c[q - 1] : prevw)) & 15u;
                         }
-                        v_reg &= rg[0] & rg[1];
-                        v_reg &= rg[2] & rg[3];
-                        v_reg &= rg[4] & rg[5];
-                        v_reg &= rg[6] & rg[7];
                         auto min3 = [](uint32_t a, uint32_t b, uint32_t d) { const uint32_t t = a < b ? a : b; return t < d ? t : d; };
-                        v_minw = min3(v_minw, c[0], c[1]);
-                        v_minw = min3(v_minw, c[2], c[3]);
-                        v_minw = min3(v_minw, c[4], c[5]);
-                        v_minw = min3(v_minw, c[6], c[7]);
-                        v_adj = min3(v_adj, x[0], x[1]);
-                        v_adj = min3(v_adj, x[2], x[3]);
-                        v_adj = min3(v_adj, x[4], x[5]);
-                        v_adj = min3(v_adj, x[6], x[7]);
+#pragma unroll
+                        for (int q = 0; q < RB_OPL; q += 2) {
+                            v_reg &= rg[q] & rg[q + 1];
+                            v_minw = min3(v_minw, c[q], c[q + 1]);
+                            v_adj = min3(v_adj, x[q], x[q + 1]);
+                        }
                     }
                     // per-lane sums of the reference / query / unit lengths of 8 ops; regular records hold only
                     // M I D N = X, so "consumes the reference" = not I and "consumes the query" = not D / N: one
                     // v_bfe_i32 per class turns the op code (low bits of the word) into an all-ones / zero mask
                     uint32_t sr = 0, sq = 0, su = 0;
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
+                    for (int q = 0; q < RB_OPL; q++) {
                         const uint32_t len = rb_len(w[q]);
                         sr += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFDFFFDu, w[q], 1u);
                         sq += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFF3FFF3u, w[q], 1u); // not D, not N
                         su += len;
                     }
                     const uint32_t ir = rb_wave_scan_incl(sr), iq = rb_wave_scan_incl(sq), iu = rb_wave_scan_incl(su);
-                    if (RB_CP_OPS == 8 || (lane & 1) == 0) { // checkpoint every RB_CP_OPS ops
-                        const uint32_t t = (st - seg0) * RB_CP_PER_STEP + (RB_CP_OPS == 8 ? (uint32_t)lane : ((uint32_t)lane >> 1));
+                    if (RB_CP_LANES == 1 || ((uint32_t)lane & (RB_CP_LANES - 1u)) == 0u) { // checkpoint every RB_CP_OPS ops: the first of the lanes that share it
+                        const uint32_t t = (st - seg0) * RB_CP_PER_STEP + (uint32_t)lane / RB_CP_LANES;
                         cpR[t] = Rb + ir - sr;
                         cpQ[t] = Qb + iq - sq;
                         cpU[t] = Ub + iu - su;
@@ -619,7 +657,7 @@ __device__ __forceinline__ void rb_stream_record() {
                         // rare -- one step in six has one -- and are taken one by one, in op order, with wave-uniform arithmetic
                         bool lane_big = false;
 #pragma unroll
-                        for (int q = 0; q < 8; q++) {
+                        for (int q = 0; q < RB_OPL; q++) {
                             const uint32_t cq = w[q] & 15u;
                             lane_big |= (cq == RB_OP_I || cq == RB_OP_D) && rb_len(w[q]) > brk_max_;
                         }
@@ -631,7 +669,7 @@ __device__ __forceinline__ void rb_stream_record() {
                             cm &= cm - 1ull;
                             uint32_t rx = rb_readlane<uint32_t>(lane_r0, l);
 #pragma unroll
-                            for (int q = 0; q < 8; q++) {
+                            for (int q = 0; q < RB_OPL; q++) {
                                 const uint32_t wq = rb_readlane<uint32_t>(w[q], l);
                                 const uint32_t cq = wq & 15u, lq = rb_len(wq);
                                 const uint32_t rlq = cq == RB_OP_I ? 0u : lq; // (regular records: M I D N = X)
@@ -694,17 +732,18 @@ __device__ __forceinline__ void rb_stream_record() {
                     unsigned long long v0 = sv_st, v1 = sv_st;
                     if (edge) { // groups in front of the record's first and behind its last one are not this record's to write
                         v0 = rb_ballot(so + 16u > first_boff && so <= last_boff);
-                        v1 = rb_ballot(so + 32u > first_boff && so + 16u <= last_boff);
+                        if (RB_GRP == 2) v1 = rb_ballot(so + 32u > first_boff && so + 16u <= last_boff);
                     }
 #pragma unroll
                     for (int q = 0; q < RB_MS; q++) {
                         unsigned long long m0 = msk[q] & v0, m1 = msk[q] & v1;
                         if (later_s && msk[q] != 0ull) { // later passes stay clear of the end groups earlier passes have patched
-                            const uint32_t c0 = (st << RB_STEP_SHIFT) + (uint32_t)lane * 8u;
+                            const uint32_t c0 = (st << RB_STEP_SHIFT) + (uint32_t)lane * (uint32_t)RB_OPL;
                             m0 &= rb_ballot(c0 >= carry[q]);
                             m1 &= rb_ballot(c0 + 4u >= carry[q]);
                         }
 #ifdef RB_LINE_ROUND
+                        static_assert(RB_OPL == 8, "RB_LINE_ROUND is written for four lanes per line");
                         { // whole 128-byte lines (4 lanes): a partly written line costs a read of the rest
                             unsigned long long q4 = (m0 | m1);
                             q4 = (q4 | (q4 >> 1) | (q4 >> 2) | (q4 >> 3)) & 0x1111111111111111ull;
@@ -717,18 +756,26 @@ __device__ __forceinline__ void rb_stream_record() {
 #endif
                         if (dbg & 64) m0 = m1 = 0ull; // diagnostics: everything but the stores themselves
                         const uint32_t *sb = out_ops_ + slot_row0 + (uint64_t)q * slot_stride_;
-#define RB_RING_STORE(RA, RB_)                                                                                                  \
+#if RB_OPL == 8
+#define RB_RING_STORE(A, B_, C_, D_)                                                                                            \
     asm volatile("s_mov_b64 exec, %[m0]\n\t"                                                                                    \
-                 "global_store_dwordx4 %[o], " RA ", %[sb]" RB_ST_NT "\n\t"                                                     \
+                 "global_store_dwordx4 %[o], " RB_RREG(A, 3) ", %[sb]" RB_ST_NT "\n\t"                                          \
                  "s_mov_b64 exec, %[m1]\n\t"                                                                                    \
-                 "global_store_dwordx4 %[o], " RB_ ", %[sb] offset:16" RB_ST_NT "\n\t"                                          \
+                 "global_store_dwordx4 %[o], " RB_RREG(C_, 3) ", %[sb] offset:16" RB_ST_NT "\n\t"                               \
                  "s_mov_b64 exec, %[sv]"                                                                                        \
                  :                                                                                                              \
                  : [m0] "s"(m0), [m1] "s"(m1), [o] "v"(so), [sb] "s"(sb), [sv] "s"(sv_st)                                       \
                  : "memory");
-                        if constexpr (ring == 0) { RB_RING_STORE(RB_RREG(0, 3), RB_RREG(4, 3)) }
-                        else if constexpr (ring == 1) { RB_RING_STORE(RB_RREG(8, 3), RB_RREG(12, 3)) }
-                        else { RB_RING_STORE(RB_RREG(16, 3), RB_RREG(20, 3)) }
+#else
+#define RB_RING_STORE(A, B_, C_, D_)                                                                                            \
+    asm volatile("s_mov_b64 exec, %[m0]\n\t"                                                                                    \
+                 "global_store_dwordx4 %[o], " RB_RREG(A, 3) ", %[sb]" RB_ST_NT "\n\t"                                          \
+                 "s_mov_b64 exec, %[sv]"                                                                                        \
+                 :                                                                                                              \
+                 : [m0] "s"(m0), [o] "v"(so), [sb] "s"(sb), [sv] "s"(sv_st)                                                     \
+                 : "memory");
+#endif
+                        RB_RING_CASE(ring, RB_RING_STORE)
 #undef RB_RING_STORE
                     }
                 }
