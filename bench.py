@@ -747,6 +747,12 @@ def main():
             box["launch_tail"] = {"ms_after_95pct_of_waves_done": round(float(rel[-1] - rel[int(0.95 * (len(rel) - 1))]) * 1e-5, 4),
                                   "ms_after_99pct": round(float(rel[-1] - rel[int(0.99 * (len(rel) - 1))]) * 1e-5, 4),
                                   "ms_first_to_last_wave_done": round(float(rel[-1]) * 1e-5, 4)}
+            # where a record's cycles go on this box: one launch of the diagnostics build with its per-phase clock sums on (every 16th record)
+            eng.dev_liftover(plan, view, d_norm.data_ptr(), policy | (32 << 8), d_ws.data_ptr(), d_rows.data_ptr(), rows_cap, d_out.data_ptr(), out_cap, d_cnt.data_ptr())
+            torch.cuda.synchronize()
+            pc = [int(x) * 256 for x in d_cnt.cpu().numpy().view(rustybam_amd.COUNTERS_DT)[0]["phase"]][:5]
+            box["phase_cycles_per_record"] = dict(zip(["job_and_windows", "stream_and_resolve", "verdict_and_finalize", "reservation", "rows_and_end_groups"],
+                                                      [round(v / max(1, n_rec)) for v in pc]))
             src_bytes = (total_ops * 4) // 20480 * 20480
             if out_cap * 4 >= 2 * src_bytes:
                 pms, pmhz = eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10)
@@ -757,6 +763,17 @@ def main():
                 box["probe_scattered_ms"] = round(sms, 4)  # (the same bytes, the concurrently running waves spread over the whole arrays)
                 box["probe_flat_ms"] = round(eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=2)[0], 4)
                 box["probe_flat_scattered_ms"] = round(eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=3)[0], 4)
+                # the two sides of the mix alone, and the clip kernel's diagnostics build without its speculative stores / without any
+                # store of clipped ops: on this memory system the mix costs about what its reads and its writes cost one after the other
+                box["probe_read_only_ms"] = round(eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=1 | 4)[0], 4)
+                box["probe_write_only_ms"] = round(eng.dev_box_probe(d_ops.data_ptr(), src_bytes, d_out.data_ptr(), d_out.data_ptr() + src_bytes, 10, scatter=1 | 8)[0], 4)
+                for key, bits in (("kernel_without_speculative_stores_ms", 64), ("kernel_reads_only_ms", 64 | 512)):
+                    eng.set_timing(True)
+                    for _ in range(6):
+                        eng.dev_liftover(plan, view, d_norm.data_ptr(), policy | (bits << 8), d_ws.data_ptr(), d_rows.data_ptr(), rows_cap, d_out.data_ptr(), out_cap, d_cnt.data_ptr())
+                    torch.cuda.synchronize()
+                    box[key] = round(float(np.mean(eng.get_timing()[-4:])), 4)
+                    eng.set_timing(False)
                 box["probe_note"] = (f"rb_dev_box_probe on this run's buffers: {src_bytes} B read from the ops array, 1.2 x that written to the output "
                                      "arena in the clip kernel's access shape (32 contiguous bytes per lane, two slots), no other instructions")
                 if k_ms == k_ms:

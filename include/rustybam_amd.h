@@ -484,7 +484,8 @@ int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const rb_hit_row
  * back to back; *ms_out = mean time of one, *mhz_out (may be NULL) = the shader clock held meanwhile, from s_memtime / s_memrealtime
  * stamps around each wave's loop.  scatter != 0: the waves that run at the same time work 5 MB apart, all over the array (as the clip
  * kernel's do: its records run longest first), instead of side by side; 2 / 3: the same two orders with the other load shape (every
- * instruction covering 1 KiB of whole lines instead of 32 contiguous bytes per lane). */
+ * instruction covering 1 KiB of whole lines instead of 32 contiguous bytes per lane); + 4: the read side alone (no stores), + 8: the
+ * write side alone (no loads). */
 int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, int scatter, double *ms_out, double *mhz_out);
 
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *

@@ -294,8 +294,18 @@ __device__ __forceinline__ void rb_stream_record() {
     const int lane = rb_lane();
     long long t_prev = (dbg & 32) ? clock64() : 0;
     uint32_t *cpR = cp_all[wib][0], *cpQ = cp_all[wib][1], *cpU = cp_all[wib][2];
+#ifndef RB_JOB_AHEAD
+#define RB_JOB_AHEAD 0 // (build switch: touch the job of the wave that starts RB_JOB_AHEAD waves from now -- a multiple of 32, i.e. a workgroup of the same XCD)
+#endif
+#if RB_JOB_AHEAD
+    uint32_t job_touch = 0; // (a load whose value nobody wants: the register stays reserved until the job's own load, issued behind it, has landed)
+    if (wave + RB_JOB_AHEAD < p.wave_end) asm volatile("global_load_dword %0, %1, off" : "=v"(job_touch) : "v"(&p.jobs[wave + RB_JOB_AHEAD]) : "memory");
+#endif
     const rb_job jb_ = p.jobs[wave]; // (uniform address: one 64-byte request)
     const uint32_t jflags = rb_first(jb_.flags);
+#if RB_JOB_AHEAD
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(job_touch) : : "memory");
+#endif
     if (jflags & RB_JOB_ROWS_OVERFLOW) { // rows do not fit: flag and leave (host retries with more room)
         if (lane == 0) p.counters->overflow = 1;
         return;
@@ -395,11 +405,23 @@ __device__ __forceinline__ void rb_stream_record() {
     const uint32_t lane_boff = (uint32_t)lane * (4u * RB_OPL);
     // (chunks past the record's end are not loaded: lanes behind the last chunk re-read it, and the loads of steps
     //  behind the last one run with an empty exec mask)
+// RB_LINE_ROUND (lanes of 32 bytes per granule: 2 = 64 bytes, 4 = 128 bytes): nothing of a slot is ever PARTLY written.  The speculative
+// stores of a step are widened to whole granules and the end groups of a clip -- the patches of its first and last op -- are whole
+// granules too (RB_GRAN ops each) instead of 16-byte groups.  A granule that is written in part costs a read-modify-write somewhere
+// behind L2 (profiles/r04_stream_summary.md: 8 - 11 % of the launch on the boxes where this kernel is slow).
+#ifdef RB_LINE_ROUND
+#define RB_GRAN (8 * RB_LINE_ROUND)
+#else
+#define RB_GRAN 4
+#endif
+#ifndef RB_LD_NT
+#define RB_LD_NT "" // (build switch: " nt" marks the stream's loads non-temporal -- what is read once should not push the jobs, windows and rows out of L2)
+#endif
 #if RB_OPL == 8
 #define RB_RING_LOAD_ASM(A, B_, C_, D_)                                                                                         \
     asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
-         "global_load_dwordx4 " RB_RREG(A, 3) ", %[o], %[sb]\n\t"                                                       \
-         "global_load_dwordx4 " RB_RREG(C_, 3) ", %[o], %[sb] offset:16\n\t"                                            \
+         "global_load_dwordx4 " RB_RREG(A, 3) ", %[o], %[sb]" RB_LD_NT "\n\t"                                             \
+         "global_load_dwordx4 " RB_RREG(C_, 3) ", %[o], %[sb] offset:16" RB_LD_NT "\n\t"                                  \
          "s_mov_b64 exec, %[sv]"                                                                                        \
          :                                                                                                              \
          : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
@@ -407,7 +429,7 @@ __device__ __forceinline__ void rb_stream_record() {
 #else
 #define RB_RING_LOAD_ASM(A, B_, C_, D_)                                                                                         \
     asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
-         "global_load_dwordx4 " RB_RREG(A, 3) ", %[o], %[sb]\n\t"                                                       \
+         "global_load_dwordx4 " RB_RREG(A, 3) ", %[o], %[sb]" RB_LD_NT "\n\t"                                             \
          "s_mov_b64 exec, %[sv]"                                                                                        \
          :                                                                                                              \
          : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
@@ -743,15 +765,18 @@ __device__ __forceinline__ void rb_stream_record() {
                             m1 &= rb_ballot(c0 + 4u >= carry[q]);
                         }
 #ifdef RB_LINE_ROUND
-                        static_assert(RB_OPL == 8, "RB_LINE_ROUND is written for four lanes per line");
-                        { // whole 128-byte lines (4 lanes): a partly written line costs a read of the rest
+                        static_assert(RB_OPL == 8 && (RB_LINE_ROUND == 2 || RB_LINE_ROUND == 4), "RB_LINE_ROUND: lanes (of 32 bytes) per granule, 64 or 128 bytes");
+                        { // whole granules of 32 / 64 / 128 bytes (1 / 2 / 4 lanes): a partly written one costs a read-modify-write somewhere behind L2
                             unsigned long long q4 = (m0 | m1);
-                            q4 = (q4 | (q4 >> 1) | (q4 >> 2) | (q4 >> 3)) & 0x1111111111111111ull;
-                            q4 |= q4 << 1;
-                            q4 |= q4 << 2;
+                            if (RB_LINE_ROUND >= 2) q4 = (q4 | (q4 >> 1)), q4 &= RB_LINE_ROUND == 2 ? 0x5555555555555555ull : ~0ull;
+                            if (RB_LINE_ROUND == 4) q4 = (q4 | (q4 >> 2)) & 0x1111111111111111ull;
+                            if (RB_LINE_ROUND >= 2) q4 |= q4 << 1;
+                            if (RB_LINE_ROUND == 4) q4 |= q4 << 2;
                             const unsigned long long keep0 = m0 | ~msk[q], keep1 = m1 | ~msk[q]; // (what the edge / carry filters took away stays away)
-                            m0 = q4 & v0 & keep0;
-                            m1 = q4 & v1 & keep1;
+                            // (a line of a slot belongs to one record -- slot_row0 --: lanes in front of the record's first op or behind its last
+                            //  one, in a granule that holds an op of a clip, write what they loaded: a neighbour's ops, nobody's to read)
+                            m0 = q4 & keep0;
+                            m1 = q4 & keep1;
                         }
 #endif
                         if (dbg & 64) m0 = m1 = 0ull; // diagnostics: everything but the stores themselves
@@ -834,8 +859,8 @@ __device__ __forceinline__ void rb_stream_record() {
                         if (D == Rb) { // boundary on the record's last base; the last op is match-type
                             const uint32_t lv = rec_ops[n - 1];
                             O.st = RB_S_OK, O.op = n - 1;
-                            if (is_start) O.part = 1u, O.R = Rb - 1, O.Q = Qb - 1, O.U = Ub - 1;
-                            else O.part = rb_len(lv), O.R = Rb, O.Q = Qb, O.U = Ub;
+                            if (is_start) O.part = rb_part_pack(1u, lv), O.R = Rb - 1, O.Q = Qb - 1, O.U = Ub - 1;
+                            else O.part = rb_part_pack(rb_len(lv), lv), O.R = Rb, O.Q = Qb, O.U = Ub;
                         } else {
                             // last checkpoint with R <= D (R is non-decreasing)
                             uint32_t lo_t = 0, hi_t = n_cp;
@@ -1003,14 +1028,14 @@ __device__ __forceinline__ void rb_stream_record() {
         const uint32_t e_first = (uint32_t)head + a_op; // coordinate (op index + head, counted from the aligned g0) of the first op
         const uint32_t e_cnt = emits ? out_n : 0u;
         const uint32_t eg_last = e_first + e_cnt - 1u;
-        const uint32_t eg_f = e_first & ~3u, eg_l = e_cnt ? (eg_last & ~3u) : eg_f;
+        const uint32_t eg_f = e_first & ~(uint32_t)(RB_GRAN - 1), eg_l = e_cnt ? (eg_last & ~(uint32_t)(RB_GRAN - 1)) : eg_f;
         // ---- which clips own their place in a slot.  Clip j (class j mod n_slots) does when it starts behind the last group
         //      of every earlier clip of its class: then no two clips of a slot share a 16-byte group, and the groups a clip
         //      rewrites (its first and last) are nobody else's.  With windows that overlap at most n_slots deep that is every
         //      clip; the others are copied to the arena area by rb_k_copy_clips. ----
         const uint32_t ns1 = n_slots ? n_slots : 1u;
         const uint32_t cls = (uint32_t)((jb + hl) % ns1);
-        const uint32_t lgp = (emits && e_cnt) ? eg_l + 4u : 0u; // first coordinate behind my clip (0: no clip)
+        const uint32_t lgp = (emits && e_cnt) ? eg_l + (uint32_t)RB_GRAN : 0u; // first coordinate behind my clip's last group (0: no clip)
         uint32_t pm = lane < 32 ? lgp : 0u;                      // inclusive prefix maximum over the lanes of my class
         for (uint32_t d = ns1; d < 32u; d <<= 1) {
             const uint32_t t = (uint32_t)__shfl_up((int)pm, d, 64);
@@ -1038,10 +1063,18 @@ __device__ __forceinline__ void rb_stream_record() {
         }
         // the two end groups are re-read (the record has just been streamed: L2 or Infinity Cache)
         // (unconditional: a conditional load is sunk to its use; the ops array is padded, a quad may reach past the record)
-        const uint32_t *__restrict__ gsrc = rec_ops - head; // coordinate c -> gsrc[c]; 16-byte aligned at c % 4 == 0
-        uint4 eg_q0 = *reinterpret_cast<const uint4 *>(gsrc + eg_f);
-        uint4 eg_q1 = *reinterpret_cast<const uint4 *>(gsrc + eg_l);
+        [[maybe_unused]] const uint32_t *__restrict__ gsrc = rec_ops - head; // coordinate c -> gsrc[c]; 16-byte aligned at c % 4 == 0
+        // (diagnostics, dbg & 512: what the end groups cost -- their loads go to the record's first line, their stores are left out)
+#ifndef RB_PATCH_WORDS
+#define RB_PATCH_WORDS 1 // the clip's first and last op are written as two words made from what the resolution left in registers (0: the
+                         // round-2 form -- their 16-byte groups read again from the record, patched, written back)
+#endif
+#if !RB_PATCH_WORDS && !(RB_GRAN > 4 && RB_GRAN_PATCH)
+        static_assert(RB_GRAN == 4, "the 16-byte end groups are the geometry of RB_GRAN = 4");
+        uint4 eg_q0 = *reinterpret_cast<const uint4 *>(gsrc + ((dbg & 512) ? 0u : eg_f));
+        uint4 eg_q1 = *reinterpret_cast<const uint4 *>(gsrc + ((dbg & 512) ? 0u : eg_l));
         __builtin_amdgcn_sched_barrier(0);
+#endif
         RB_PHASE(2)
         const uint64_t my_off = (uint64_t)cls * slot_stride_ + slot_row0 + e_first; // out_ops index of my clip's first op
         // (the row index is formed from an opaque copy of the lane id: otherwise the compiler hoists the row addresses above
@@ -1074,13 +1107,71 @@ __device__ __forceinline__ void rb_stream_record() {
                 *row = w;
                 if (desc_mode_ && status == RB_ST_OK) // which ops of the ORIGINAL cigar the clip keeps
                     *reinterpret_cast<uint4 *>(out_ops_ + 4ull * my_row) =
-                        make_uint4(nr->first_op + a_op, out_n, inside ? 0u : A.part, inside ? 0u : B.part);
+                        make_uint4(nr->first_op + a_op, out_n, inside ? 0u : rb_part(A.part), inside ? 0u : rb_part(B.part));
             }
         }
         RB_PHASE(3)
         // ---- the end groups: the lane that owns a clip writes the group(s) holding its first and last op with the clipped
         //      lengths patched in; slots of those groups outside the clip are written as zeros ----
-        if (in_slot && !(dbg & 1)) {
+#ifndef RB_GRAN_PATCH
+#define RB_GRAN_PATCH 0 // (1, with RB_LINE_ROUND: the end ops are patched by rewriting their whole granules -- measured: the bigger the
+                        //  patch, the slower, 9.5 / 10.3 / 11.6 ms for 16 / 64 / 128 bytes on one box; kept for the record)
+#endif
+#if RB_GRAN > 4 && RB_GRAN_PATCH
+        // whole granules: the granule that holds the clip's first op and the one that holds its last op are read again in full and
+        // written in full, the two ops patched; what lies in them outside the clip is written as it was read (the slot's lines are
+        // this record's alone, and nobody reads a slot outside a clip)
+        if (in_slot && !(dbg & (1 | 512))) {
+            uint32_t *__restrict__ dst = out_ops_ + (uint64_t)cls * slot_stride_ + slot_row0; // coordinate 0
+            const uint32_t c_lastq = ((uint32_t)head + n - 1u) & ~3u; // the last group that holds an op of the record (nothing behind it is read)
+            auto granule = [&](const uint32_t gc0) {
+#pragma nounroll // (64 bytes at a time: a 128-byte granule in one go takes 32 registers, and the compiler then reaches into the ring)
+                for (uint32_t gc = gc0; gc < gc0 + (uint32_t)RB_GRAN; gc += 16u) {
+                    rb_u32x4 v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t c = gc + 4u * (uint32_t)k;
+                        v[k] = *reinterpret_cast<const rb_u32x4 *>(gsrc + (c < c_lastq ? c : c_lastq));
+                    }
+                    if (!inside) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const uint32_t c = gc + 4u * (uint32_t)k + (uint32_t)q;
+                                uint32_t w = v[k][q];
+                                if (e_cnt == 1u) { // the middle of one op
+                                    if (c == e_first) w = ((rb_part(A.part) + rb_part(B.part) - rb_len(w)) << 4) | rb_opc(w);
+                                } else {
+                                    if (c == e_first) w = (rb_part(A.part) << 4) | rb_opc(w); // first op keeps its tail
+                                    if (c == eg_last) w = (rb_part(B.part) << 4) | rb_opc(w); // last op keeps its head
+                                }
+                                v[k][q] = w;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) __builtin_nontemporal_store(v[k], reinterpret_cast<rb_u32x4 *>(dst + gc + 4u * (uint32_t)k));
+                }
+            };
+            granule(eg_f);
+            if (eg_l != eg_f) granule(eg_l);
+        }
+#elif RB_PATCH_WORDS
+        // ---- the end ops: the speculative stores put the record's ops there as they are; the clip's first op keeps its tail, its last op
+        //      its head.  Both words are made from what the resolution of the two boundaries left in registers (clipped length and op code:
+        //      rb_bres.part) -- nothing is read again.  A clip that is the middle of ONE op holds B.U - A.U units of it. ----
+        if (in_slot && !inside && !(dbg & (1 | 512))) {
+            uint32_t *__restrict__ dst = out_ops_ + (uint64_t)cls * slot_stride_ + slot_row0; // coordinate 0
+            if (e_cnt == 1u) {
+                __builtin_nontemporal_store(((B.U - A.U) << 4) | (A.part >> 28), dst + e_first);
+            } else {
+                __builtin_nontemporal_store(rb_part_word(A.part), dst + e_first);
+                __builtin_nontemporal_store(rb_part_word(B.part), dst + eg_last);
+            }
+        }
+#else
+        if (in_slot && !(dbg & (1 | 512))) {
             uint32_t *__restrict__ dst = out_ops_ + (uint64_t)cls * slot_stride_ + slot_row0 + eg_f; // the group holding coordinate eg_f
             uint32_t q0[4] = {eg_q0.x, eg_q0.y, eg_q0.z, eg_q0.w}, q1[4] = {eg_q1.x, eg_q1.y, eg_q1.z, eg_q1.w};
 #pragma unroll
@@ -1089,11 +1180,11 @@ __device__ __forceinline__ void rb_stream_record() {
                 uint32_t w0 = q0[q], w1 = q1[q];
                 if (!inside) {
                     if (e_cnt == 1u) { // the middle of one op
-                        if (c0 == e_first) w0 = ((A.part + B.part - rb_len(w0)) << 4) | rb_opc(w0);
+                        if (c0 == e_first) w0 = ((rb_part(A.part) + rb_part(B.part) - rb_len(w0)) << 4) | rb_opc(w0);
                     } else {
-                        if (c0 == e_first) w0 = (A.part << 4) | rb_opc(w0); // first op keeps its tail
-                        if (c0 == eg_last) w0 = (B.part << 4) | rb_opc(w0); // (clips of 2..4 ops inside one group)
-                        if (c1 == eg_last) w1 = (B.part << 4) | rb_opc(w1); // last op keeps its head
+                        if (c0 == e_first) w0 = (rb_part(A.part) << 4) | rb_opc(w0); // first op keeps its tail
+                        if (c0 == eg_last) w0 = (rb_part(B.part) << 4) | rb_opc(w0); // (clips of 2..4 ops inside one group)
+                        if (c1 == eg_last) w1 = (rb_part(B.part) << 4) | rb_opc(w1); // last op keeps its head
                     }
                 }
                 q0[q] = (c0 < e_first || c0 > eg_last) ? 0u : w0;
@@ -1108,6 +1199,7 @@ __device__ __forceinline__ void rb_stream_record() {
             if (eg_l != eg_f) __builtin_nontemporal_store(s1, reinterpret_cast<rb_u32x4 *>(dst + (eg_l - eg_f)));
 #endif
         }
+#endif
         // ---- clips without a place of their own: one list entry each, copied by rb_k_copy_clips ----
         {
             const unsigned long long cm = __ballot(copied);
@@ -1117,7 +1209,7 @@ __device__ __forceinline__ void rb_stream_record() {
                 c0 = rb_first64(c0);
                 if (copied) {
                     const uint64_t at = c0 + (uint64_t)__popcll(cm & ((1ull << lane) - 1ull));
-                    p.copy_list[at] = make_uint4((uint32_t)my_row, a_op, inside ? 0u : A.part, inside ? 0u : B.part);
+                    p.copy_list[at] = make_uint4((uint32_t)my_row, a_op, inside ? 0u : rb_part(A.part), inside ? 0u : rb_part(B.part));
                 }
             }
         }

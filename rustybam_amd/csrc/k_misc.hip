@@ -444,7 +444,8 @@ typedef uint32_t rb_bp_u32x4 __attribute__((ext_vector_type(4)));
 // whole lines -- instead of the clip kernel's 32 contiguous bytes per lane: what the other load shape would be worth on these buffers.
 template <bool SCATTER, bool FLAT = false>
 __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ src, char *__restrict__ d0, char *__restrict__ d1, uint64_t n_stretch,
-                                                      uint32_t *stamps /* [3]: sum of cycles >> 6, sum of 10 ns ticks, stamped waves */) {
+                                                      uint32_t *stamps /* [3]: sum of cycles >> 6, sum of 10 ns ticks, stamped waves */,
+                                                      int no_stores, int no_loads /* the read side / the write side of the mix alone */) {
     uint64_t w = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_stretch) return;
     if (SCATTER) {
@@ -459,8 +460,10 @@ __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ s
 #pragma unroll 2
     for (int s = 0; s < 10; s++) {
         const uint64_t o = base + (uint64_t)s * 2048;
-        const rb_bp_u32x4 a = *(const rb_bp_u32x4 *)(src + o), b = *(const rb_bp_u32x4 *)(src + o + second);
+        rb_bp_u32x4 a = {(uint32_t)s, (uint32_t)lane, 0u, 0u}, b = a;
+        if (!no_loads) a = *(const rb_bp_u32x4 *)(src + o), b = *(const rb_bp_u32x4 *)(src + o + second);
         acc += a.x ^ b.y;
+        if (no_stores) continue;
         *(rb_bp_u32x4 *)(d0 + o) = a;
         *(rb_bp_u32x4 *)(d0 + o + second) = b;
         if (s % 5 == 0) {
@@ -479,9 +482,11 @@ __global__ __launch_bounds__(256) void rb_k_box_probe(const char *__restrict__ s
 extern "C" hipError_t rb_launch_box_probe(const void *src, void *d0, void *d1, uint64_t n_stretch, uint32_t *stamps, int scatter, hipStream_t stream) {
     if (n_stretch == 0) return hipSuccess;
     const dim3 g((unsigned)((n_stretch + 3) / 4)), b(256);
-    if (scatter == 3) hipLaunchKernelGGL((rb_k_box_probe<true, true>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
-    else if (scatter == 2) hipLaunchKernelGGL((rb_k_box_probe<false, true>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
-    else if (scatter) hipLaunchKernelGGL((rb_k_box_probe<true, false>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
-    else hipLaunchKernelGGL((rb_k_box_probe<false, false>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps);
+    const int no_stores = (scatter & 4) != 0, no_loads = (scatter & 8) != 0; // (codes 4 .. 15: the read side / the write side alone)
+    scatter &= 3;
+    if (scatter == 3) hipLaunchKernelGGL((rb_k_box_probe<true, true>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps, no_stores, no_loads);
+    else if (scatter == 2) hipLaunchKernelGGL((rb_k_box_probe<false, true>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps, no_stores, no_loads);
+    else if (scatter) hipLaunchKernelGGL((rb_k_box_probe<true, false>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps, no_stores, no_loads);
+    else hipLaunchKernelGGL((rb_k_box_probe<false, false>), g, b, 0, stream, (const char *)src, (char *)d0, (char *)d1, n_stretch, stamps, no_stores, no_loads);
     return hipGetLastError();
 }

@@ -197,9 +197,15 @@ __device__ inline void rb_defer_record(rb_kparams kp, uint32_t r, const rb_norm_
 // tpos_to_idx + walk-to-match rules (paf.rs:541-561) with short look-ahead / look-back loads.
 struct rb_bres {
     uint32_t st;            // RB_S_OK / NONE / DEFER
-    uint32_t op, part;      // op index; start: ops' remaining length (len - off), end: used length (off + 1)
+    uint32_t op, part;      // op index; start: ops' remaining length (len - off), end: used length (off + 1) -- with the op's code in
+                            // the top four bits (a length has 28): rb_part() / rb_part_word() below
     uint32_t R, Q, U;       // start: exclusive counts at the unit; end: inclusive counts
 };
+
+// rb_bres.part: the clipped length of the boundary op and the op's code; rb_part_word = the op as the clip holds it
+__device__ __forceinline__ uint32_t rb_part_pack(uint32_t part, uint32_t op_word) { return part | (op_word << 28); }
+__device__ __forceinline__ uint32_t rb_part(uint32_t packed) { return packed & 0x0FFFFFFFu; }
+__device__ __forceinline__ uint32_t rb_part_word(uint32_t packed) { return (packed << 4) | (packed >> 28); }
 
 #define RB_WALK_MAX 24
 
@@ -264,13 +270,13 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
         int32_t X; // first match-type op with index >= X
         if (off > 0) { // the boundary base and the next base share op f
             if (rb_ism(fv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = rb_len(fv) - (off - 1), o.R = fR + off - 1, o.Q = fQ + off - 1, o.U = fU + off - 1;
+                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = rb_part_pack(rb_len(fv) - (off - 1), fv), o.R = fR + off - 1, o.Q = fQ + off - 1, o.U = fU + off - 1;
                 return o;
             }
             X = fi + 1;
         } else { // boundary base is the last unit before op f: the last equal element is the unit before f
             if (fi > 0 && rb_ism(pv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = 1u, o.R = fR - 1, o.Q = fQ - 1, o.U = fU - 1;
+                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = rb_part_pack(1u, pv), o.R = fR - 1, o.Q = fQ - 1, o.U = fU - 1;
                 return o;
             }
             // duplicates in tpos_aln (units of an insertion share the boundary's tpos): which one
@@ -285,7 +291,7 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
 #pragma nounroll // (unrolled 24-fold, each level of the nest parks an exec mask in scalar registers: 100 spills)
         for (int t = 0; t < RB_WALK_MAX; t++) {
             if (i >= X && rb_ism(v)) {
-                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
+                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_part_pack(rb_len(v), v), o.R = R, o.Q = Q, o.U = U;
                 return o;
             }
             R += rb_rl(v);
@@ -303,13 +309,13 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
         int32_t Y; // last match-type op with index <= Y
         if (off > 0) {
             if (rb_ism(fv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = off, o.R = D, o.Q = fQ + off, o.U = fU + off;
+                o.st = RB_S_OK, o.op = (uint32_t)fi, o.part = rb_part_pack(off, fv), o.R = D, o.Q = fQ + off, o.U = fU + off;
                 return o;
             }
             Y = fi - 1;
         } else {
             if (fi > 0 && rb_ism(pv)) {
-                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = rb_len(pv), o.R = fR, o.Q = fQ, o.U = fU;
+                o.st = RB_S_OK, o.op = (uint32_t)(fi - 1), o.part = rb_part_pack(rb_len(pv), pv), o.R = fR, o.Q = fQ, o.U = fU;
                 return o;
             }
             Y = fi - 2;
@@ -325,7 +331,7 @@ __device__ __forceinline__ rb_bres rb_resolve(const uint32_t *__restrict__ ops, 
             }
             const uint32_t v = ops[i];
             if (i <= Y && rb_ism(v)) {
-                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_len(v), o.R = R, o.Q = Q, o.U = U;
+                o.st = RB_S_OK, o.op = (uint32_t)i, o.part = rb_part_pack(rb_len(v), v), o.R = R, o.Q = Q, o.U = U;
                 return o;
             }
             R -= rb_rl(v);
