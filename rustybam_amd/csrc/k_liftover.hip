@@ -766,7 +766,7 @@ __device__ __forceinline__ void rb_stream_record() {
                         }
 #ifdef RB_LINE_ROUND
                         static_assert(RB_OPL == 8 && (RB_LINE_ROUND == 2 || RB_LINE_ROUND == 4), "RB_LINE_ROUND: lanes (of 32 bytes) per granule, 64 or 128 bytes");
-                        { // whole granules of 32 / 64 / 128 bytes (1 / 2 / 4 lanes): a partly written one costs a read-modify-write somewhere behind L2
+                        if constexpr (!BRK) { // whole granules of 64 / 128 bytes (2 / 4 lanes); break-paf's pieces lie op to op: its groups stay 16 bytes
                             unsigned long long q4 = (m0 | m1);
                             if (RB_LINE_ROUND >= 2) q4 = (q4 | (q4 >> 1)), q4 &= RB_LINE_ROUND == 2 ? 0x5555555555555555ull : ~0ull;
                             if (RB_LINE_ROUND == 4) q4 = (q4 | (q4 >> 2)) & 0x1111111111111111ull;
@@ -1028,14 +1028,15 @@ __device__ __forceinline__ void rb_stream_record() {
         const uint32_t e_first = (uint32_t)head + a_op; // coordinate (op index + head, counted from the aligned g0) of the first op
         const uint32_t e_cnt = emits ? out_n : 0u;
         const uint32_t eg_last = e_first + e_cnt - 1u;
-        const uint32_t eg_f = e_first & ~(uint32_t)(RB_GRAN - 1), eg_l = e_cnt ? (eg_last & ~(uint32_t)(RB_GRAN - 1)) : eg_f;
+        constexpr uint32_t gran = BRK ? 4u : (uint32_t)RB_GRAN; // ops per group no two clips of a slot may share
+        const uint32_t eg_f = e_first & ~(gran - 1u), eg_l = e_cnt ? (eg_last & ~(gran - 1u)) : eg_f;
         // ---- which clips own their place in a slot.  Clip j (class j mod n_slots) does when it starts behind the last group
         //      of every earlier clip of its class: then no two clips of a slot share a 16-byte group, and the groups a clip
         //      rewrites (its first and last) are nobody else's.  With windows that overlap at most n_slots deep that is every
         //      clip; the others are copied to the arena area by rb_k_copy_clips. ----
         const uint32_t ns1 = n_slots ? n_slots : 1u;
         const uint32_t cls = (uint32_t)((jb + hl) % ns1);
-        const uint32_t lgp = (emits && e_cnt) ? eg_l + (uint32_t)RB_GRAN : 0u; // first coordinate behind my clip's last group (0: no clip)
+        const uint32_t lgp = (emits && e_cnt) ? eg_l + gran : 0u; // first coordinate behind my clip's last group (0: no clip)
         uint32_t pm = lane < 32 ? lgp : 0u;                      // inclusive prefix maximum over the lanes of my class
         for (uint32_t d = ns1; d < 32u; d <<= 1) {
             const uint32_t t = (uint32_t)__shfl_up((int)pm, d, 64);
