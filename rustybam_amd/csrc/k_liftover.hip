@@ -405,11 +405,15 @@ __device__ __forceinline__ void rb_stream_record() {
     const uint32_t lane_boff = (uint32_t)lane * (4u * RB_OPL);
     // (chunks past the record's end are not loaded: lanes behind the last chunk re-read it, and the loads of steps
     //  behind the last one run with an empty exec mask)
-// RB_LINE_ROUND (lanes of 32 bytes per granule: 2 = 64 bytes, 4 = 128 bytes): nothing of a slot is ever PARTLY written.  The speculative
-// stores of a step are widened to whole granules and the end groups of a clip -- the patches of its first and last op -- are whole
-// granules too (RB_GRAN ops each) instead of 16-byte groups.  A granule that is written in part costs a read-modify-write somewhere
-// behind L2 (profiles/r04_stream_summary.md: 8 - 11 % of the launch on the boxes where this kernel is slow).
-#ifdef RB_LINE_ROUND
+// RB_LINE_ROUND (lanes of 32 bytes per granule: 2 = 64 bytes, 4 = 128 bytes, 0 = off): the speculative stores of a step are widened to
+// whole granules -- a lane in front of a clip's first chunk or behind its last one, in the same granule, stores what it loaded too
+// (the record's own neighbouring ops; a slot's lines are this record's alone and nobody reads a slot outside a clip) --, and no two
+// clips of a slot may share a granule (RB_GRAN ops) instead of a 16-byte group.  Fewer lines written in part: a launch that writes
+// none at all (diagnostics: this + no end ops) is 5 % shorter on a fast box and 11 % on a slow one, profiles/r04_stream_summary.md.
+#ifndef RB_LINE_ROUND
+#define RB_LINE_ROUND (RB_OPL == 8 ? 2 : 0) // 64-byte granules: -0.6 % on a fast box, -1.7 % on a slow one (r04_ab7, r04_hs8); 128 bytes: nothing
+#endif
+#if RB_LINE_ROUND
 #define RB_GRAN (8 * RB_LINE_ROUND)
 #else
 #define RB_GRAN 4
@@ -764,7 +768,7 @@ __device__ __forceinline__ void rb_stream_record() {
                             m0 &= rb_ballot(c0 >= carry[q]);
                             m1 &= rb_ballot(c0 + 4u >= carry[q]);
                         }
-#ifdef RB_LINE_ROUND
+#if RB_LINE_ROUND
                         static_assert(RB_OPL == 8 && (RB_LINE_ROUND == 2 || RB_LINE_ROUND == 4), "RB_LINE_ROUND: lanes (of 32 bytes) per granule, 64 or 128 bytes");
                         if constexpr (!BRK) { // whole granules of 64 / 128 bytes (2 / 4 lanes); break-paf's pieces lie op to op: its groups stay 16 bytes
                             unsigned long long q4 = (m0 | m1);
