@@ -1240,7 +1240,7 @@ std::atomic<bool> g_pipeline_started{false};
 }
 bool pipeline_started() { return g_pipeline_started.load(); }
 bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uint32_t break_length, const std::string &paf_path,
-                              const std::vector<Region> &rgns, const std::function<void(std::vector<std::string> &, TextRuns &)> &sink) {
+                              const std::vector<Region> &rgns, const std::function<bool(std::vector<std::string> &, TextRuns &)> &sink) {
     g_pipeline_started = false;
     if (paf_path == "-" || g_qrange) return false;
     const int fd = open(paf_path.c_str(), O_RDONLY);
@@ -1286,6 +1286,7 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
         TextRuns runs;
         std::string panic;
         bool general = false, done = false;
+        bool late_panic = false; // the panic came from the liftover stage, not from loading / parsing the chunk
     };
     std::vector<Result> res(n_chunks);
     std::mutex mu;
@@ -1308,6 +1309,7 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
                     cv.wait(lk, [&] { return stop || k < W + 1 || (res[k - W - 1].done && res[k - W - 1].text.empty()); });
                 }
                 Result R;
+                bool loaded = false;
                 try {
                     if (!eng) {
                         eng.reset(new Engine(device));
@@ -1348,6 +1350,7 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
                         if (!f.check_loaded(cig_status, red)) {
                             R.general = true;
                         } else {
+                            loaded = true;
                             for (size_t i = 0; i < n; i++) panic_on(norm[i].status, "aligned_pairs", i);
                             RunMarks marks;
                             R.text = assemble_lines(f, norm, TR, is_break ? nullptr : &rgns, &marks);
@@ -1363,6 +1366,7 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
                 } catch (const Panic &e) {
                     R.panic = e.what();
                     if (R.panic.empty()) R.panic = "panic";
+                    R.late_panic = loaded;
                 } catch (const std::exception &e) {
                     R.panic = std::string("\x01") + e.what(); // (not a reference panic: the caller rethrows it as a runtime error)
                 }
@@ -1386,10 +1390,13 @@ bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uin
             res[k].done = true;
         }
         cv.notify_all();
+        // A panic of the liftover stage in chunk k must not win over a load / parse panic in a later chunk: the reference reads the whole
+        // file (Paf::from_file, paf.rs:70) before it lifts anything.  The whole-file route keeps that order: it takes over.
+        if (!R.panic.empty() && R.late_panic) { ok = false; break; }
         if (!R.panic.empty()) { panic = R.panic; ok = false; break; }
         if (R.general) { ok = false; break; }
         g_pipeline_started = true;
-        sink(R.text, R.runs);
+        if (!sink(R.text, R.runs)) { ok = false; break; } // (the output so far is not the reference's: no point in computing the rest)
     }
     stop = true;
     cv.notify_all();

@@ -111,7 +111,7 @@ bool liftover_file_text(Engine &eng, const std::string &paf_path, const std::vec
 // is contig-major within the chunk (runs); false = not applicable or a line needs the general parser (pipeline_started(): the
 // sink has already been given chunks)
 bool lift_file_text_pipelined(int device, int bsearch_policy, bool is_break, uint32_t break_length, const std::string &paf_path,
-                              const std::vector<Region> &rgns, const std::function<void(std::vector<std::string> &, TextRuns &)> &sink);
+                              const std::vector<Region> &rgns, const std::function<bool(std::vector<std::string> &, TextRuns &)> &sink); // sink: false = stop, the caller takes the whole-file route
 bool pipeline_started();
 bool break_file_text(Engine &eng, const std::string &paf_path, uint32_t break_length, std::vector<std::string> &out_text); // main.rs:271-281
 bool trim_file_text(Engine &eng, const std::string &paf_path, int match_score, int diff_score, int indel_score, bool remove_contained,

@@ -738,22 +738,22 @@ static bool try_pipelined(int device, int policy, bool is_break, uint32_t max_si
     std::unordered_map<std::string, uint32_t> rank; // contig -> first-appearance rank over the chunks so far
     int64_t last_rank = -1;
     bool violated = false;
-    auto sink = [&](std::vector<std::string> &text, rb::TextRuns &runs) {
+    auto sink = [&](std::vector<std::string> &text, rb::TextRuns &runs) -> bool {
         std::vector<uint32_t> gid(runs.contigs.size());
         for (size_t c = 0; c < runs.contigs.size(); c++) {
             auto it = rank.emplace(runs.contigs[c], (uint32_t)rank.size());
             if (it.second) acc.contigs.push_back(runs.contigs[c]);
             gid[c] = it.first->second;
         }
-        if (violated) return;
+        if (violated) return false;
         if (streaming) {
             for (const auto &r : runs.runs) {
-                if ((int64_t)gid[r.first] < last_rank) { violated = true; return; }
+                if ((int64_t)gid[r.first] < last_rank) { violated = true; return false; }
                 last_rank = gid[r.first];
             }
             put(text, true); // (straight to the file: a rewind must not find earlier chunks waiting in stdio's buffer)
             std::vector<std::string>().swap(text);
-            return;
+            return true;
         }
         for (const auto &r : runs.runs) {
             Piece pc;
@@ -761,6 +761,7 @@ static bool try_pipelined(int device, int policy, bool is_break, uint32_t max_si
             acc.pieces.push_back(pc);
         }
         for (std::string &t : text) acc.chunks.push_back(std::move(t));
+        return true;
     };
     auto rewind = [&]() { // what was written is not the reference's output: back to where it began
         if (streaming && rb::pipeline_started())

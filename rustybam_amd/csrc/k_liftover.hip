@@ -1606,14 +1606,23 @@ __global__ __launch_bounds__(256) void rb_k_generic_checkpoints(rb_lift_params p
             if (i + 3u < n) return rb_load4_unaligned(ops + i);
             return make_uint4(i < n ? ops[i] : 0u, i + 1u < n ? ops[i + 1u] : 0u, i + 2u < n ? ops[i + 2u] : 0u, 0u);
         };
-        uint32_t U = 0, R = 0, Q = 0, M = 0;
+        // The fields are 32 bits wide.  A record whose units in front of a checkpoint reach 2^32 (continuation words: up to 15 * 2^28
+        // bases a word) gets none: checkpoint 0 -- zeros otherwise -- says so, and rb_k_liftover_generic_wave walks such a record
+        // from its first op with its own 64-bit sums, as it does without checkpoints.
+        uint64_t U = 0;
+        uint32_t R = 0, Q = 0, M = 0;
         uint4 nxt = load(0u);
         for (uint32_t c0 = 0; c0 < n; c0 += RB_GCP) {
-            if (lane == 0) cp[c0 / RB_GCP] = make_uint4(U, R, Q, M);
+            if (U >> 32) {
+                if (lane == 0) cp[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                break;
+            }
+            if (lane == 0) cp[c0 / RB_GCP] = make_uint4((uint32_t)U, R, Q, M);
             const uint4 cur = nxt;
             if (c0 + RB_GCP < n) nxt = load(c0 + RB_GCP); // (in flight while this interval is summed)
             const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
-            uint32_t u = 0, rr = 0, q = 0, m = 0;
+            uint64_t u = 0; // (the reference / query / match sums are parts of it: they stay below 2^32 wherever a checkpoint is written)
+            uint32_t rr = 0, q = 0, m = 0;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t i = c0 + 4u * (uint32_t)lane + (uint32_t)k;
@@ -1625,7 +1634,7 @@ __global__ __launch_bounds__(256) void rb_k_generic_checkpoints(rb_lift_params p
                 q += okc && rb_in(RB_QRY_MASK, opc) ? len : 0u;
                 m += okc && rb_in(RB_MATCH_MASK, opc) ? len : 0u;
             }
-            U += rb_wave_sum_u32(u), R += rb_wave_sum_u32(rr), Q += rb_wave_sum_u32(q), M += rb_wave_sum_u32(m);
+            U += rb_wave_sum_u64(u), R += rb_wave_sum_u32(rr), Q += rb_wave_sum_u32(q), M += rb_wave_sum_u32(m);
         }
     }
 }
@@ -1714,6 +1723,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         uint4 cp0 = make_uint4(0u, 0u, 0u, 0u), cp_e1 = cp0;
         bool first_seen = false, wrapped = false;
         const uint4 *gcp = (p.gen_cp && n > RB_GCP) ? rb_gen_cp_of(p, r, nr->first_op) : nullptr;
+        if (gcp && rb_first(gcp[0].x) == 0xFFFFFFFFu) gcp = nullptr; // (a record of 2^32 units and more has no checkpoints: rb_k_generic_checkpoints)
         const uint32_t ncp = (n + RB_GCP - 1u) / RB_GCP;
         // the last checkpoint whose field (1: reference bases, 0: units) is <= target (checkpoint 0 holds zeros); the fields never decrease
         auto cp_search = [&](int field, uint64_t target) -> uint32_t {

@@ -590,6 +590,29 @@ def test_pipelined_text_route_equals_the_whole_file_route(golden, args, tmp_path
     assert rc0 == 101 and rc1 == 101 and out0 == b""
 
 
+def test_pipelined_route_reports_the_panic_the_reference_reports(golden, tmp_path):
+    """A record that loads but panics in the liftover stage (a leading deletion at t_st = 0: remove_trailing_indels, paf.rs:656-783,
+    then unwrap) in an EARLY chunk, and a line Paf::from_file panics on (paf.rs:381: fewer than 12 columns) in a LATE one.  The
+    reference reads the whole file before it lifts anything, so the parse panic is the one it dies of; the pipelined route must say
+    what the whole-file route says (it reported the first panic in chunk order)."""
+    lines = [l for l in open(f"{golden}/asm_small.paf", "rb").read().split(b"\n") if l]
+    late = b"q\t200\t0\t100\t+\t" + lines[0].split(b"\t")[5] + b"\t100000000\t0\t105\t100\t205\t60\tcg:Z:5D100="
+    bad = tmp_path / "two_panics.paf"
+    bad.write_bytes(b"\n".join(lines[:40] + [late] + lines[40:-2] + [b"short\tline"] + lines[-2:]) + b"\n")
+    for a in (["liftover", "--bed", f"{golden}/asm_small.bed", str(bad)], ["break-paf", "--max-size", "100", str(bad)]):
+        whole = subprocess.run([RB, *a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "RB_NO_PIPELINE": "1"})
+        piped = subprocess.run([RB, *a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "RB_CHUNK_KB": "200"})
+        assert whole.returncode == 101 and piped.returncode == 101, a
+        assert piped.stderr == whole.stderr and piped.stdout == whole.stdout == b"", (a, piped.stderr, whole.stderr)
+    # the early record alone: the liftover-stage panic is what both routes report
+    only = tmp_path / "one_panic.paf"
+    only.write_bytes(b"\n".join(lines[:40] + [late] + lines[40:]) + b"\n")
+    a = ["liftover", "--bed", f"{golden}/asm_small.bed", str(only)]
+    whole = subprocess.run([RB, *a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "RB_NO_PIPELINE": "1"})
+    piped = subprocess.run([RB, *a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env={**os.environ, "RB_CHUNK_KB": "200"})
+    assert whole.returncode == 101 and piped.returncode == 101 and piped.stderr == whole.stderr and piped.stdout == b""
+
+
 def test_trim_paf_in_place_and_copied_clips_print_the_same(oracle, tmp_path):
     """rb trim-paf cuts regular records where they are (RB_TRIM_IN_PLACE: two words a record) and copies the clips of the others behind
     the ops in use; RB_TRIM_COPY=1 copies all of them as rounds 1 and 2 did.  Same bytes, and the oracle's on the first queries."""

@@ -245,3 +245,63 @@ def test_text_route_prints_runs_that_merge_past_2_28(oracle, tmp_path):
         assert (rc, orc) == (0, 0), args
         assert out == oout, args
     assert b"cg:Z:268435370=" in _rb("liftover", "--bed", bed, paf)[1]
+
+
+# Records of nearly 2^32 and of more than 2^32 units.  The reference sums a record's lengths in u32 (infer_n_bases, paf.rs:632-647): a
+# record of 2^32 units and more is PANIC_OVERFLOW at the scan and never reaches a walk -- which is what keeps the 32-bit checkpoints of
+# the general kernel (units / reference / query / match bases in front of every 256th op) from wrapping; rb_k_generic_checkpoints sums
+# in 64 bits and leaves such a record without checkpoints all the same.  A record just under 2^32 units has checkpoint
+# values up to 4.29e9.  Neither fits the per-base oracle (73 GB): the expectation is worked out here -- a record of = and X only maps
+# reference to query base by base, a clip is the run of ops under the window with its first and last op cut.
+def _big_record(head_len):
+    head = f"{head_len}=1X" * 3
+    tail = "5=1X" * 400
+    return line("qBig", head + tail, t_st=1000, q_st=7, t_len=9_000_000_000), 3 * (head_len + 1)
+
+
+def _clip_of_match_only(cg, t0, ws, we):
+    out, pos = [], t0
+    for n, o in ((int(a), b) for a, b in re.findall(r"(\d+)([=X])", cg)):
+        lo, hi = max(pos, ws), min(pos + n, we)
+        if lo < hi:
+            out.append(f"{hi - lo}{o}")
+        pos += n
+    return "".join(out)
+
+
+def _big_batch(head_len):
+    ln, big = _big_record(head_len)
+    r = recs_from_lines([ln])
+    b = dict(ops=r.ops, op_off=r.op_off, t_st=r.t_st, t_en=r.t_en, q_st=r.q_st, q_en=r.q_en, strand=r.strand, contig=r.contig)
+    t0 = 1000
+    wins = [(t0 + big + 100, t0 + big + 163), (t0 + big + 1200, t0 + big + 1207), (t0 + head_len - 5, t0 + head_len + 9),
+            (t0 + big - 3, t0 + big + 14), (t0 + big + 2395, t0 + big + 2400)]
+    w = (np.zeros(len(wins), np.uint32), np.array([a for a, _ in wins], np.uint64), np.array([e for _, e in wins], np.uint64))
+    return ln, b, wins, w
+
+
+def test_oracle_scan_of_records_around_2_32_units(oracle):
+    for head_len, status in ((1431654000, 0), (2147483648, oracle.PANIC_OVERFLOW)):
+        ln, b, _, _ = _big_batch(head_len)
+        ob = oracle.Batch(b["ops"], b["op_off"], b["t_st"], b["t_en"], b["q_st"], b["q_en"], b["strand"])
+        assert int(oracle.normalize(ob)["status"][0]) == status and int(oracle.reduce(ob)["status"][0]) == status
+
+
+@gpu
+@pytest.mark.parametrize("policy", [0, 1])
+def test_records_around_2_32_units_through_the_checkpointed_walk(engine, policy):
+    # just under 2^32 units: checkpoint values up to 4.29e9
+    ln, b, wins, w = _big_batch(1431654000)
+    rows, ops, norm, cnt = engine.liftover(*batch_args(b), b["contig"], *w, policy=policy)
+    assert int(norm["status"][0]) == 0 and len(rows) == len(wins) and (rows["status"] == 0).all()
+    cg, t0 = ln.split("cg:Z:")[1], 1000
+    for h in rows:
+        ws, we = wins[int(h["win"])]
+        text = unpack(ops[int(h["out_off"]):int(h["out_off"]) + int(h["out_n"])])
+        assert text == _clip_of_match_only(cg, t0, ws, we), (ws, we, text)
+        assert (int(h["t_st"]), int(h["t_en"])) == (ws, we)
+        assert (int(h["q_st"]), int(h["q_en"])) == (7 + ws - t0, 7 + we - t0)
+    # 2^32 units and more: the scan's verdict, no rows
+    ln, b, wins, w = _big_batch(2147483648)
+    rows, ops, norm, cnt = engine.liftover(*batch_args(b), b["contig"], *w, policy=policy)
+    assert int(norm["status"][0]) == 22 and len(rows) == 0
