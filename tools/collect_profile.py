@@ -43,6 +43,18 @@ traffic = {"_comment": "PMC traffic of rb_k_liftover_stream per full-size launch
            "traffic_bytes_per_launch": fetch + write, "kernel": "rb_k_liftover_stream", "build": f"profile {tag}",
            "kernel_source_sha": kernel_source_sha(), "git_head": os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()}
 json.dump(traffic, open(os.path.join(dst, f"traffic_{rnd}.json"), "w"), indent=1)
+extra_rows = ""
+if B.get("e2e", {}).get("records"):
+    extra_rows += f"| end to end (`rb liftover`, text in -> text out, {B['e2e']['records']} records) | {B.get('e2e_paf_records_per_s', 0):.0f} PAF-records/s ({B['e2e'].get('seconds', 0)} s) |\n"
+if B.get("cpu_baseline"):
+    extra_rows += (f"| cpu_baseline (the oracle: a per-base restatement, not the Rust binary) | {B['cpu_baseline'].get('value', 0):.3e} CIGAR-ops/s on "
+                   f"{B['cpu_baseline'].get('cores', 0)} threads; -t 8: {B['cpu_baseline'].get('t8', {}).get('value', 0):.3e} |\n")
+bx = B.get("box", {})
+if bx:
+    extra_rows += (f"| the box (`box` block of the same line) | in-kernel clock {bx.get('kernel_clock_mhz')} MHz; probe {bx.get('probe_ms')} ms side by side, "
+                   f"{bx.get('probe_scattered_ms')} scattered, reads / writes alone {bx.get('probe_read_only_ms')} / {bx.get('probe_write_only_ms')}; the kernel's read side "
+                   f"{bx.get('kernel_reads_only_ms')} ms, without speculative stores {bx.get('kernel_without_speculative_stores_ms')} ms; cycles of a record by phase "
+                   f"{bx.get('phase_cycles_per_record')} |\n")
 md = f"""# Profile {tag} -- the headline step (config 3: 1e6 records, 5e9 ops, 3000 sliding 100 kb windows, 1 MI355X)
 
 `tools/prof_round.sh {tag}` (kernel trace + stats; FETCH_SIZE / WRITE_SIZE / SQ counters in separate `--pmc` passes), then an unprofiled
@@ -58,9 +70,7 @@ md = f"""# Profile {tag} -- the headline step (config 3: 1e6 records, 5e9 ops, 3
 | traffic | **{(fetch + write) / 1e9:.1f} GB = {(fetch + write) / algo:.3f} x the {algo / 1e9:.2f} GB of algorithmic bytes** (round 2: 51.8 GB, 1.143 x; round 1: 70.9 GB, 1.56 x) |
 | SQ_INSTS_VALU / SALU per full launch | {best.get('SQ_INSTS_VALU', 0):.3g} / {best.get('SQ_INSTS_SALU', 0):.3g} ({best.get('SQ_INSTS_VALU', 0) / 1e6:.0f} / {best.get('SQ_INSTS_SALU', 0) / 1e6:.0f} per record) |
 | SQ_INSTS_VMEM_RD / VMEM_WR / LDS per full launch | {best.get('SQ_INSTS_VMEM_RD', 0):.3g} / {best.get('SQ_INSTS_VMEM_WR', 0):.3g} / {best.get('SQ_INSTS_LDS', 0):.3g} |
-| end to end (`rb liftover`, text in -> text out, {B.get('e2e', {}).get('records', 0)} records) | {B.get('e2e_paf_records_per_s', 0):.0f} PAF-records/s ({B.get('e2e', {}).get('seconds', 0)} s) |
-| cpu_baseline (the oracle: a per-base restatement, not the Rust binary) | {B.get('cpu_baseline', {}).get('value', 0):.3e} CIGAR-ops/s on {B.get('cpu_baseline', {}).get('cores', 0)} threads; -t 8: {B.get('cpu_baseline', {}).get('t8', {}).get('value', 0):.3e} |
-| parity | {B.get('parity_sample', '-')}; output digest {B.get('output_digest', '-')} |
+{extra_rows}| parity | {B.get('parity_sample', '-')}; output digest {B.get('output_digest', '-')} |
 """
 open(os.path.join(dst, f"{tag}_summary.md"), "w").write(md)
 print(md)
