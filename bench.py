@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--early-exit", action="store_true", help="allow the kernel to stop a record early (off: full walk)")
     ap.add_argument("--unfused", action="store_true", help="run rb_dev_scan_records as its own pass inside the step instead of the fused scan")
+    ap.add_argument("--placement-tries", type=int, default=4,
+                    help="candidates rb_dev_alloc_placed may allocate for the output arena (a store sweep over each, the fastest kept: set-up, "
+                         "not timed); 1 = plain rb_dev_alloc")
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: skip kernel phases (invalid results)")
     ap.add_argument("--op", default="liftover", choices=["liftover", "break"],
                     help="liftover (headline) or break-paf --max-size 100 on the same records (secondary measurement)")
@@ -339,10 +342,10 @@ def main():
 
     alloc_note = []
 
-    def big(n, dtype):  # -> (tensor, owner): the batch's large buffers
+    def big(n, dtype, placed=1):  # -> (tensor, owner): the batch's large buffers (placed > 1: the output arena, rb_dev_alloc_placed)
         if lib_alloc and not alloc_note:
             try:
-                b_ = capi_mod.DevBuf(eng, torch, n, dtype, device=dev)
+                b_ = capi_mod.DevBuf(eng, torch, n, dtype, device=dev, placed_tries=placed)
                 return b_.t, b_
             except Exception as e:  # (torch could not take the library's memory for a tensor of this device: its own allocator then)
                 alloc_note.append(f"{type(e).__name__}: {e}")
@@ -439,6 +442,18 @@ def main():
     assert not cnt["overflow"], "could not size the output buffers"
     n_hits = int(cnt["n_hits"])
     sizing_ms = (time.perf_counter() - tz) * 1e3  # the calls that find rows_cap / out_cap (allocation included); once per batch shape
+    # The output arena, placed by measurement (rb_dev_alloc_placed; set-up, like the sizing above): which physical pages the arena has
+    # decides up to 20 % of the clip kernel's time on this part, reads do not care (profiles/r04_alloc_summary.md).  The library
+    # allocates up to --placement-tries candidates, times a store sweep over each, keeps the fastest and gives the others back.
+    placement_ms = 0.0
+    if args.placement_tries > 1 and own_out is not None:
+        tp = time.perf_counter()
+        del d_out
+        own_out.free()
+        d_out, own_out = big(out_cap + 64, torch.int32, placed=args.placement_tries)
+        run_op(d_ws, d_rows, d_out)
+        torch.cuda.synchronize()
+        placement_ms = (time.perf_counter() - tp) * 1e3
 
     def step():
         # the whole hot path from the packed ops.  liftover: one fused call -- remove_trailing_indels + check_integrity (which the
@@ -466,6 +481,33 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = eng.get_timing()
     eng.set_timing(False)
+    if os.environ.get("RB_BENCH_PLACEMENTS") and rank == 0 and args.op == "liftover":
+        # experiment: the same launch with the output arena in OTHER physical pages of this process (earlier arenas stay allocated), and
+        # the probe's write side alone on each: is the time of a launch a property of where its output lies?
+        held = []
+        src_b = (total_ops * 4) // 20480 * 20480
+        for k_ in range(int(os.environ["RB_BENCH_PLACEMENTS"])):
+            t_out, own_t = (d_out, None) if k_ == 0 else big(out_cap + 64, torch.int32)
+            held.append((t_out, own_t))
+            eng.set_timing(True)
+            for _ in range(6):
+                run_op(d_ws, d_rows, t_out)
+            torch.cuda.synchronize()
+            k_ms_ = float(np.mean(eng.get_timing()[-4:]))
+            eng.set_timing(False)
+            w_ms_ = eng.dev_box_probe(d_ops.data_ptr(), src_b, t_out.data_ptr(), t_out.data_ptr() + src_b, 5, scatter=1 | 8)[0] if out_cap * 4 >= 2 * src_b else float("nan")
+            parts = []
+            if out_cap * 4 >= 2 * src_b:  # (the write side on sixteenths of the arena: is a slow arena slow everywhere?)
+                pb = src_b // 16 // 20480 * 20480
+                for j_ in range(16):
+                    parts.append(round(eng.dev_box_probe(d_ops.data_ptr(), pb, t_out.data_ptr() + j_ * pb * 2, t_out.data_ptr() + j_ * pb * 2 + pb, 5, scatter=1 | 8)[0] * 16, 2))
+            print(f"[placement {k_}] kernel {k_ms_:.3f} ms  probe writes alone {w_ms_:.3f} ms  arena at 0x{t_out.data_ptr():x}  by sixteenth (x 16): {parts}", file=sys.stderr)
+        for t_out, own_t in held[1:]:
+            del t_out
+            if own_t:
+                own_t.free()
+        run_op(d_ws, d_rows, d_out)  # (the probe overwrote the arena: the checks below read this launch's output)
+        torch.cuda.synchronize()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -574,6 +616,10 @@ def main():
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
                    "batch_buffers_chunked": {k_: (bool(o_.chunked) if o_ else None) for k_, o_ in (("ops", own_ops), ("workspace", own_ws), ("rows", own_rows), ("out_ops", own_out))},
+                   "out_arena_placement": ({"tries_allowed": args.placement_tries, **own_out.placement, "seconds": round(placement_ms / 1e3, 2),
+                                            "note": "rb_dev_alloc_placed, part of the set-up: candidates of the output arena, a store sweep over each (ms), "
+                                                    "the fastest kept; which physical pages the arena has decides up to 20 % of the clip kernel's time"}
+                                           if (own_out is not None and own_out.placement) else None),
                    "batch_memory": ("rb_dev_alloc (2 MB physical chunks)" if lib_alloc and not alloc_note else
                                     "torch allocator (hipMalloc)" + (f"; rb_dev_alloc memory not usable as a tensor here: {alloc_note[0]}" if alloc_note else "")),
                    **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {}),

@@ -488,6 +488,14 @@ int rb_dev_digest_rows(rb_ctx *ctx, const rb_batch_view *batch, const rb_hit_row
  * write side alone (no loads). */
 int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst0, void *dst1, int reps, int scatter, double *ms_out, double *mhz_out);
 
+/* A buffer that will be WRITTEN at streaming rate (an output arena), placed by measurement: on MI355X the time of a launch that streams
+ * its output into a buffer depends on which physical pages the buffer has (same process, same launch, the arena allocated four times
+ * over: 9.10 / 9.17 / 9.25 / 11.04 ms; reads do not care).  Allocates up to `tries` candidates of `bytes` with rb_dev_alloc -- fewer
+ * when the device lacks the room --, times a store sweep over each, returns the fastest in *out (free it with rb_dev_free) and gives
+ * the others back.  sweep_ms (NULL or room for `tries` doubles): the time of each candidate's sweep, -1 where none was made;
+ * *kept (may be NULL): the index of the one returned.  tries = 1 is rb_dev_alloc. */
+int rb_dev_alloc_placed(rb_ctx *ctx, uint64_t bytes, int tries, void **out, double *sweep_ms, int *kept);
+
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and
  * device versions produce identical bytes.  n_ops per record comes from rb_synth_n_ops. */

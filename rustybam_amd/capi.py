@@ -203,6 +203,14 @@ class Engine:
         self._chk(self.L.rb_dev_alloc(self.ctx, C.c_size_t(n_bytes), C.byref(d)), "rb_dev_alloc")
         return int(d.value)
 
+    def dev_alloc_placed(self, n_bytes, tries):
+        """a buffer that will be written at streaming rate, placed by measurement (rb_dev_alloc_placed: up to `tries` candidates, a store
+        sweep over each, the fastest kept); -> (address, [sweep ms per candidate], index kept)"""
+        d, kept = C.c_void_p(), C.c_int(-1)
+        ms = (C.c_double * max(1, tries))()
+        self._chk(self.L.rb_dev_alloc_placed(self.ctx, C.c_uint64(n_bytes), C.c_int(tries), C.byref(d), ms, C.byref(kept)), "rb_dev_alloc_placed")
+        return int(d.value), [round(ms[i], 4) for i in range(tries) if ms[i] >= 0], int(kept.value)
+
     def dev_free(self, ptr):
         self._chk(self.L.rb_dev_free(self.ctx, C.c_void_p(ptr)), "rb_dev_free")
 
@@ -441,14 +449,22 @@ class DevBuf:
     DESIGN.md section 3), seen by torch through the CUDA array interface without a copy: `.t` is the tensor.  free() gives the
     memory back (before the engine is closed)."""
 
-    def __init__(self, eng, torch, n, dtype, device=None):
+    def __init__(self, eng, torch, n, dtype, device=None, placed_tries=1):
         self.eng, self.n, self.dtype = eng, int(n), dtype
         self.item = torch.empty(0, dtype=dtype).element_size()
+        self.placement = None                       # (placed_tries > 1: {"sweep_ms": [...], "kept": i} of rb_dev_alloc_placed)
+
+        def take():
+            if placed_tries > 1:
+                ptr, ms, kept = eng.dev_alloc_placed(max(self.n * self.item, 256), placed_tries)
+                self.placement = {"sweep_ms": ms, "kept": kept}
+                return ptr
+            return eng.dev_alloc(max(self.n * self.item, 256))
         try:
-            self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
+            self.ptr = take()
         except Exception:
             torch.cuda.empty_cache()                # (memory torch's caching allocator holds but does not use is not free to the driver)
-            self.ptr = eng.dev_alloc(max(self.n * self.item, 256))
+            self.ptr = take()
         self.chunked = eng.L.rb_dev_alloc_mode(eng.ctx, C.c_void_p(self.ptr)) == 1  # (False: plain hipMalloc memory -- small, or the fallback)
         self.__cuda_array_interface__ = {"shape": (self.n * self.item,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
         try:

@@ -15,6 +15,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
 #include <map>
 #include <mutex>
 
@@ -784,7 +785,11 @@ extern "C" size_t rb_plan_diag_stamps_offset(const rb_plan *plan, uint64_t rows_
 
 // ops per output slot: the batch's op index space, 32 ops (one 128-byte line) of room per record (records that share a line in the
 // input must not share one in the output), a multiple of 32
-static uint64_t slot_stride_of(uint64_t n_ops, uint64_t n_rec) { return ((n_ops + 31) & ~(uint64_t)31) + 32 * n_rec + 64; }
+static uint64_t slot_pad() { // (experiment, RB_SLOT_PAD=<ops>: where slot 1 lies relative to slot 0 below the 2 MB of a physical chunk)
+    static const uint64_t v = [] { const char *e = getenv("RB_SLOT_PAD"); return e ? (uint64_t)strtoull(e, nullptr, 10) & ~(uint64_t)31 : 0ull; }();
+    return v;
+}
+static uint64_t slot_stride_of(uint64_t n_ops, uint64_t n_rec) { return ((n_ops + 31) & ~(uint64_t)31) + 32 * n_rec + 64 + slot_pad(); }
 extern "C" uint64_t rb_plan_out_capacity(const rb_plan *plan, int for_break) {
     if (!plan) return 0;
     const uint64_t slots = for_break ? std::min<uint32_t>(2u, RB_MS) : std::min<uint32_t>(plan->depth, RB_MS);
@@ -1901,6 +1906,69 @@ extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes
     if (b) (void)hipEventDestroy(b);
     (void)hipFree(stamps);
     return rc;
+}
+
+// ---- a buffer that will be WRITTEN at the clip kernel's rate, placed by measurement ----
+// On MI355X the time of a launch that streams its output into a buffer depends on WHICH physical pages the buffer has: the same
+// process, the same launch, the output arena allocated four times over -- 9.10, 9.17, 9.25 and 11.04 ms (profiles/r04_alloc_summary.md).
+// Reads do not care; writes do, and the library's store sweep (the box probe's write side alone, over the whole buffer) sees most of
+// it.  rb_dev_alloc_placed allocates up to `tries` candidates of `bytes` (fewer when the device has not the room: a candidate is only
+// taken while twice its size stays free), times the sweep on each, keeps the fastest and gives the others back.  sweep_ms[i] (may be
+// NULL, room for `tries`) = what candidate i took, -1 where none was made; *kept = the index of the one returned.
+extern "C" int rb_dev_alloc_placed(rb_ctx *ctx, uint64_t bytes, int tries, void **out, double *sweep_ms, int *kept) {
+    if (!ctx || !out || tries < 1) return RB_E_INVALID;
+    *out = nullptr;
+    if (kept) *kept = -1;
+    for (int i = 0; sweep_ms && i < tries; i++) sweep_ms[i] = -1.0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<void *> cand;
+    std::vector<double> ms;
+    const uint64_t half = bytes / 2 / 20480 * 20480; // (the sweep writes 20 KiB stretches: the buffer as two halves, each one fully written once)
+    int rc = RB_OK, best = -1;
+    for (int i = 0; i < tries && rc == RB_OK; i++) {
+        if (i > 0) { // (never the last of the memory: the winner's neighbours -- workspace, rows -- still have to fit)
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess || (uint64_t)fr < 2 * bytes + ((uint64_t)8 << 30)) break;
+        }
+        void *q = nullptr;
+        const auto t_a = std::chrono::steady_clock::now();
+        const int r1 = rb_dev_alloc(ctx, bytes, &q);
+        if (r1 != RB_OK) {
+            if (i == 0) rc = r1;
+            break;
+        }
+        if (getenv("RB_ALLOC_LOG"))
+            fprintf(stderr, "[rb_dev_alloc_placed] candidate %d: %.2f s to allocate\n", i, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count());
+        cand.push_back(q);
+        double t = 0;
+        if (half >= 20480 && tries > 1) {
+            double a = 0, b = 0;
+            char *p0 = (char *)q, *p1 = (char *)q + half;
+            int r2 = rb_dev_box_probe(ctx, p0, half, p0, p1, 3, 1 | 8, &a, nullptr); // (8: no loads -- src is not read)
+            if (r2 == RB_OK) r2 = rb_dev_box_probe(ctx, p1, half, p1, p0, 3, 1 | 8, &b, nullptr);
+            if (r2 != RB_OK) {
+                rc = r2;
+                break;
+            }
+            t = a + b;
+        }
+        ms.push_back(t);
+        if (sweep_ms) sweep_ms[i] = t;
+        if (best < 0 || t < ms[(size_t)best]) best = i;
+    }
+    const auto t_f = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < cand.size(); i++)
+        if ((int)i != best || rc != RB_OK) {
+            const int r3 = rb_dev_free(ctx, cand[i]);
+            if (r3 != RB_OK && rc == RB_OK) rc = r3;
+        }
+    if (getenv("RB_ALLOC_LOG"))
+        fprintf(stderr, "[rb_dev_alloc_placed] %zu candidates, kept %d, %.2f s to give the others back\n", cand.size(), best,
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f).count());
+    if (rc != RB_OK) return rc;
+    *out = cand[(size_t)best];
+    if (kept) *kept = best;
+    return RB_OK;
 }
 
 // ---- nucfreq ----------------------------------------------------------------------------------------------------------

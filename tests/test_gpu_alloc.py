@@ -82,3 +82,24 @@ def test_chunked_buffers_give_their_memory_back(engine):
         engine.dev_free(p)
         free1, _ = torch.cuda.mem_get_info()
         assert abs(free0 - free1) <= 16 * MB, (free0, free1)
+
+
+def test_placed_allocation_keeps_one_candidate_and_gives_the_others_back(engine):
+    """rb_dev_alloc_placed: up to `tries` candidates, a store sweep over each, the fastest kept, the others freed; the buffer it returns
+    is ordinary library memory."""
+    torch = pytest.importorskip("torch")
+    size = (3 << 29) + 4096                                                  # 1.5 GB: the chunked route
+    free0 = torch.cuda.mem_get_info()[0]
+    ptr, sweeps, kept = engine.dev_alloc_placed(size, 3)
+    assert len(sweeps) == 3 and 0 <= kept < 3 and all(s > 0 for s in sweeps) and sweeps[kept] == min(sweeps)
+    assert engine.L.rb_dev_alloc_mode(engine.ctx, C.c_void_p(ptr)) == 1
+    assert free0 - torch.cuda.mem_get_info()[0] < size + 64 * MB           # one candidate's worth is held, not three
+    rng = np.random.default_rng(7)
+    blob = rng.integers(0, 256, 5 * MB + 77, dtype=np.uint8)
+    for at in (0, 2 * MB - 1000, size - blob.nbytes):
+        _roundtrip(engine, ptr, at, blob)
+    engine.dev_free(ptr)
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 * MB
+    ptr, sweeps, kept = engine.dev_alloc_placed(size, 1)                     # one try = rb_dev_alloc (no sweep)
+    assert kept == 0 and len(sweeps) == 1
+    engine.dev_free(ptr)
