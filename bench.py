@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--placement-tries", type=int, default=4,
                     help="candidates rb_dev_alloc_placed may allocate for the output arena (a store sweep over each, the fastest kept: set-up, "
                          "not timed); 1 = plain rb_dev_alloc")
+    ap.add_argument("--placement-by", default="launch", choices=["launch", "sweep"],
+                    help="what ranks the candidates: the step itself on each (rb_dev_alloc_placed_by) or the library's store sweep (rb_dev_alloc_placed)")
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: skip kernel phases (invalid results)")
     ap.add_argument("--op", default="liftover", choices=["liftover", "break"],
                     help="liftover (headline) or break-paf --max-size 100 on the same records (secondary measurement)")
@@ -342,10 +344,10 @@ def main():
 
     alloc_note = []
 
-    def big(n, dtype, placed=1):  # -> (tensor, owner): the batch's large buffers (placed > 1: the output arena, rb_dev_alloc_placed)
+    def big(n, dtype, placed=1, score=None):  # -> (tensor, owner): the batch's large buffers (placed > 1: the output arena, rb_dev_alloc_placed[_by])
         if lib_alloc and not alloc_note:
             try:
-                b_ = capi_mod.DevBuf(eng, torch, n, dtype, device=dev, placed_tries=placed)
+                b_ = capi_mod.DevBuf(eng, torch, n, dtype, device=dev, placed_tries=placed, score=score)
                 return b_.t, b_
             except Exception as e:  # (torch could not take the library's memory for a tensor of this device: its own allocator then)
                 alloc_note.append(f"{type(e).__name__}: {e}")
@@ -411,11 +413,12 @@ def main():
     brk_policy = [policy | (rustybam_amd.BREAK_ONE_WALK if (args.op == "break" and not args.descriptors and not args.two_walk) else 0)]
 
     def run_op(ws, rows, out):
+        out_ptr = out if isinstance(out, int) else out.data_ptr()  # (a raw address: a candidate of the arena's placement)
         if args.op == "break":
-            eng.dev_break(plan, view, d_norm.data_ptr(), 100, brk_policy[0], ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(),
+            eng.dev_break(plan, view, d_norm.data_ptr(), 100, brk_policy[0], ws.data_ptr(), rows.data_ptr(), rows_cap, out_ptr,
                           out_cap, d_cnt.data_ptr())
         else:
-            eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out.data_ptr(),
+            eng.dev_liftover(plan, view, d_norm.data_ptr(), policy, ws.data_ptr(), rows.data_ptr(), rows_cap, out_ptr,
                              out_cap, d_cnt.data_ptr())
     if args.descriptors:
         rows_cap = max(rows_cap, 16 * n_rec)
@@ -444,13 +447,26 @@ def main():
     sizing_ms = (time.perf_counter() - tz) * 1e3  # the calls that find rows_cap / out_cap (allocation included); once per batch shape
     # The output arena, placed by measurement (rb_dev_alloc_placed; set-up, like the sizing above): which physical pages the arena has
     # decides up to 20 % of the clip kernel's time on this part, reads do not care (profiles/r04_alloc_summary.md).  The library
-    # allocates up to --placement-tries candidates, times a store sweep over each, keeps the fastest and gives the others back.
+    # allocates up to --placement-tries candidates, measures each, keeps the fastest and gives the others back.  The measure
+    # (--placement-by): "launch" = this step on the candidate, three times under a timer (rb_dev_alloc_placed_by: what the arena is for);
+    # "sweep" = the library's own store sweep (rb_dev_alloc_placed), which tells an 11 ms arena from a 9.2 ms one but not always
+    # a 10.1 ms one from a 9.9 ms one.
     placement_ms = 0.0
     if args.placement_tries > 1 and own_out is not None:
         tp = time.perf_counter()
         del d_out
         own_out.free()
-        d_out, own_out = big(out_cap + 64, torch.int32, placed=args.placement_tries)
+
+        def launch_score(ptr):
+            run_op(d_ws, d_rows, ptr)  # (first touch of the candidate's pages)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(3):
+                run_op(d_ws, d_rows, ptr)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t_) * 1e3 / 3
+
+        d_out, own_out = big(out_cap + 64, torch.int32, placed=args.placement_tries, score=launch_score if args.placement_by == "launch" else None)
         run_op(d_ws, d_rows, d_out)
         torch.cuda.synchronize()
         placement_ms = (time.perf_counter() - tp) * 1e3
@@ -496,12 +512,9 @@ def main():
             k_ms_ = float(np.mean(eng.get_timing()[-4:]))
             eng.set_timing(False)
             w_ms_ = eng.dev_box_probe(d_ops.data_ptr(), src_b, t_out.data_ptr(), t_out.data_ptr() + src_b, 5, scatter=1 | 8)[0] if out_cap * 4 >= 2 * src_b else float("nan")
-            parts = []
-            if out_cap * 4 >= 2 * src_b:  # (the write side on sixteenths of the arena: is a slow arena slow everywhere?)
-                pb = src_b // 16 // 20480 * 20480
-                for j_ in range(16):
-                    parts.append(round(eng.dev_box_probe(d_ops.data_ptr(), pb, t_out.data_ptr() + j_ * pb * 2, t_out.data_ptr() + j_ * pb * 2 + pb, 5, scatter=1 | 8)[0] * 16, 2))
-            print(f"[placement {k_}] kernel {k_ms_:.3f} ms  probe writes alone {w_ms_:.3f} ms  arena at 0x{t_out.data_ptr():x}  by sixteenth (x 16): {parts}", file=sys.stderr)
+            prof = eng.dev_store_sweep_profile(t_out.data_ptr(), out_cap * 4, 32)
+            print(f"[placement {k_}] kernel {k_ms_:.3f} ms  probe writes alone {w_ms_:.3f} ms  arena at 0x{t_out.data_ptr():x}  "
+                  f"us per wave's 20 KiB by 32nd of the arena: {[round(x, 1) for x in prof]}", file=sys.stderr)
         for t_out, own_t in held[1:]:
             del t_out
             if own_t:
@@ -617,8 +630,10 @@ def main():
                    "full_walk": not args.early_exit, "clip_output": "descriptors" if args.descriptors else "copied ops",
                    "batch_buffers_chunked": {k_: (bool(o_.chunked) if o_ else None) for k_, o_ in (("ops", own_ops), ("workspace", own_ws), ("rows", own_rows), ("out_ops", own_out))},
                    "out_arena_placement": ({"tries_allowed": args.placement_tries, **own_out.placement, "seconds": round(placement_ms / 1e3, 2),
-                                            "note": "rb_dev_alloc_placed, part of the set-up: candidates of the output arena, a store sweep over each (ms), "
-                                                    "the fastest kept; which physical pages the arena has decides up to 20 % of the clip kernel's time"}
+                                            "by": args.placement_by,
+                                            "note": "rb_dev_alloc_placed[_by], part of the set-up: candidates of the output arena, each measured (ms: the step itself "
+                                                    "on the candidate, or the library's store sweep), the fastest kept; which physical pages the arena has decides "
+                                                    "up to 20 % of the clip kernel's time"}
                                            if (own_out is not None and own_out.placement) else None),
                    "batch_memory": ("rb_dev_alloc (2 MB physical chunks)" if lib_alloc and not alloc_note else
                                     "torch allocator (hipMalloc)" + (f"; rb_dev_alloc memory not usable as a tensor here: {alloc_note[0]}" if alloc_note else "")),

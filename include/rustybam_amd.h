@@ -495,6 +495,12 @@ int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes, void *dst
  * the others back.  sweep_ms (NULL or room for `tries` doubles): the time of each candidate's sweep, -1 where none was made;
  * *kept (may be NULL): the index of the one returned.  tries = 1 is rb_dev_alloc. */
 int rb_dev_alloc_placed(rb_ctx *ctx, uint64_t bytes, int tries, void **out, double *sweep_ms, int *kept);
+/* The same with the caller's own measure instead of the store sweep: score(candidate, user) is called once per candidate (nothing of
+ * the library is locked meanwhile; it may launch on the context and must leave the device idle or its work ordered on the context's
+ * stream) and returns a time -- the lowest wins, a negative one ends the search with RB_E_INVALID.  The measure that counts is the
+ * launch the buffer is for: the sweep tells a 9.2 ms arena from an 11 ms one, not always a 9.9 ms one from a 10.1 ms one. */
+int rb_dev_alloc_placed_by(rb_ctx *ctx, uint64_t bytes, int tries, double (*score)(void *candidate, void *user), void *user, void **out,
+                           double *scores, int *kept);
 
 /* ---- synthetic workload generator (bench and tests, not a reference function) -- *
  * Counter-based: ops of record r depend only on (seed, first_record + r, op index).  The host and

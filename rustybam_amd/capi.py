@@ -203,12 +203,30 @@ class Engine:
         self._chk(self.L.rb_dev_alloc(self.ctx, C.c_size_t(n_bytes), C.byref(d)), "rb_dev_alloc")
         return int(d.value)
 
-    def dev_alloc_placed(self, n_bytes, tries):
+    SCORE_CB = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_void_p)
+
+    def dev_alloc_placed(self, n_bytes, tries, score=None):
         """a buffer that will be written at streaming rate, placed by measurement (rb_dev_alloc_placed: up to `tries` candidates, a store
-        sweep over each, the fastest kept); -> (address, [sweep ms per candidate], index kept)"""
+        sweep over each -- or score(address) -> time, the caller's own launch (rb_dev_alloc_placed_by) --, the fastest kept);
+        -> (address, [score per candidate], index kept)"""
         d, kept = C.c_void_p(), C.c_int(-1)
         ms = (C.c_double * max(1, tries))()
-        self._chk(self.L.rb_dev_alloc_placed(self.ctx, C.c_uint64(n_bytes), C.c_int(tries), C.byref(d), ms, C.byref(kept)), "rb_dev_alloc_placed")
+        if score is None:
+            self._chk(self.L.rb_dev_alloc_placed(self.ctx, C.c_uint64(n_bytes), C.c_int(tries), C.byref(d), ms, C.byref(kept)), "rb_dev_alloc_placed")
+        else:
+            err = []
+
+            def cb(ptr, _user):
+                try:
+                    return float(score(int(ptr)))
+                except Exception as e:  # (no exception may cross the C frames: the search ends, the caller hears about it below)
+                    err.append(e)
+                    return -1.0
+            fn = self.SCORE_CB(cb)
+            rc = self.L.rb_dev_alloc_placed_by(self.ctx, C.c_uint64(n_bytes), C.c_int(tries), fn, None, C.byref(d), ms, C.byref(kept))
+            if err:
+                raise err[0]
+            self._chk(rc, "rb_dev_alloc_placed_by")
         return int(d.value), [round(ms[i], 4) for i in range(tries) if ms[i] >= 0], int(kept.value)
 
     def dev_free(self, ptr):
@@ -449,15 +467,15 @@ class DevBuf:
     DESIGN.md section 3), seen by torch through the CUDA array interface without a copy: `.t` is the tensor.  free() gives the
     memory back (before the engine is closed)."""
 
-    def __init__(self, eng, torch, n, dtype, device=None, placed_tries=1):
+    def __init__(self, eng, torch, n, dtype, device=None, placed_tries=1, score=None):
         self.eng, self.n, self.dtype = eng, int(n), dtype
         self.item = torch.empty(0, dtype=dtype).element_size()
         self.placement = None                       # (placed_tries > 1: {"sweep_ms": [...], "kept": i} of rb_dev_alloc_placed)
 
         def take():
             if placed_tries > 1:
-                ptr, ms, kept = eng.dev_alloc_placed(max(self.n * self.item, 256), placed_tries)
-                self.placement = {"sweep_ms": ms, "kept": kept}
+                ptr, ms, kept = eng.dev_alloc_placed(max(self.n * self.item, 256), placed_tries, score)
+                self.placement = {("launch_ms" if score else "sweep_ms"): ms, "kept": kept}
                 return ptr
             return eng.dev_alloc(max(self.n * self.item, 256))
         try:

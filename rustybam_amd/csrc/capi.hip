@@ -1915,7 +1915,37 @@ extern "C" int rb_dev_box_probe(rb_ctx *ctx, const void *src, uint64_t src_bytes
 // it.  rb_dev_alloc_placed allocates up to `tries` candidates of `bytes` (fewer when the device has not the room: a candidate is only
 // taken while twice its size stays free), times the sweep on each, keeps the fastest and gives the others back.  sweep_ms[i] (may be
 // NULL, room for `tries`) = what candidate i took, -1 where none was made; *kept = the index of the one returned.
+// rb_dev_alloc_placed_by: the same with the caller's own measure -- score(candidate, user) is called once per candidate, with nothing
+// of the library locked, and may launch on the context (bench.py: the clip kernel itself on its batch, which is what the placement
+// is for; the store sweep ranks a 9.9 ms arena behind a 10.1 ms one now and then).  The lowest score wins; a negative score ends the
+// search with RB_E_INVALID.
+extern "C" int rb_dev_alloc_placed_by(rb_ctx *ctx, uint64_t bytes, int tries, double (*score)(void *candidate, void *user), void *user, void **out,
+                                      double *scores, int *kept);
+namespace {
+struct sweep_arg { rb_ctx *ctx; uint64_t half; int rc; };
+double sweep_score(void *q, void *user) {
+    sweep_arg *a = (sweep_arg *)user;
+    double t0 = 0, t1 = 0;
+    char *p0 = (char *)q, *p1 = (char *)q + a->half;
+    int r = rb_dev_box_probe(a->ctx, p0, a->half, p0, p1, 3, 1 | 8, &t0, nullptr); // (8: no loads -- src is not read)
+    if (r == RB_OK) r = rb_dev_box_probe(a->ctx, p1, a->half, p1, p0, 3, 1 | 8, &t1, nullptr);
+    if (r != RB_OK) {
+        a->rc = r;
+        return -1.0;
+    }
+    return t0 + t1;
+}
+} // namespace
 extern "C" int rb_dev_alloc_placed(rb_ctx *ctx, uint64_t bytes, int tries, void **out, double *sweep_ms, int *kept) {
+    if (!ctx || !out || tries < 1) return RB_E_INVALID;
+    sweep_arg a{ctx, bytes / 2 / 20480 * 20480, RB_OK}; // (the sweep writes 20 KiB stretches: the buffer as two halves, each one fully written once)
+    const bool sweep = a.half >= 20480 && tries > 1;
+    const int rc = rb_dev_alloc_placed_by(ctx, bytes, sweep ? tries : 1, sweep ? sweep_score : nullptr, &a, out, sweep_ms, kept);
+    for (int i = 1; sweep_ms && !sweep && i < tries; i++) sweep_ms[i] = -1.0;
+    return (rc != RB_OK && a.rc != RB_OK) ? a.rc : rc;
+}
+extern "C" int rb_dev_alloc_placed_by(rb_ctx *ctx, uint64_t bytes, int tries, double (*score)(void *candidate, void *user), void *user, void **out,
+                                      double *sweep_ms, int *kept) {
     if (!ctx || !out || tries < 1) return RB_E_INVALID;
     *out = nullptr;
     if (kept) *kept = -1;
@@ -1923,7 +1953,6 @@ extern "C" int rb_dev_alloc_placed(rb_ctx *ctx, uint64_t bytes, int tries, void 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<void *> cand;
     std::vector<double> ms;
-    const uint64_t half = bytes / 2 / 20480 * 20480; // (the sweep writes 20 KiB stretches: the buffer as two halves, each one fully written once)
     int rc = RB_OK, best = -1;
     for (int i = 0; i < tries && rc == RB_OK; i++) {
         if (i > 0) { // (never the last of the memory: the winner's neighbours -- workspace, rows -- still have to fit)
@@ -1941,16 +1970,12 @@ extern "C" int rb_dev_alloc_placed(rb_ctx *ctx, uint64_t bytes, int tries, void 
             fprintf(stderr, "[rb_dev_alloc_placed] candidate %d: %.2f s to allocate\n", i, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_a).count());
         cand.push_back(q);
         double t = 0;
-        if (half >= 20480 && tries > 1) {
-            double a = 0, b = 0;
-            char *p0 = (char *)q, *p1 = (char *)q + half;
-            int r2 = rb_dev_box_probe(ctx, p0, half, p0, p1, 3, 1 | 8, &a, nullptr); // (8: no loads -- src is not read)
-            if (r2 == RB_OK) r2 = rb_dev_box_probe(ctx, p1, half, p1, p0, 3, 1 | 8, &b, nullptr);
-            if (r2 != RB_OK) {
-                rc = r2;
+        if (score && tries > 1) {
+            t = score(q, user);
+            if (!(t >= 0)) {
+                rc = fail(ctx, RB_E_INVALID, "rb_dev_alloc_placed_by: the score of candidate %d is negative", i);
                 break;
             }
-            t = a + b;
         }
         ms.push_back(t);
         if (sweep_ms) sweep_ms[i] = t;

@@ -103,3 +103,28 @@ def test_placed_allocation_keeps_one_candidate_and_gives_the_others_back(engine)
     ptr, sweeps, kept = engine.dev_alloc_placed(size, 1)                     # one try = rb_dev_alloc (no sweep)
     assert kept == 0 and len(sweeps) == 1
     engine.dev_free(ptr)
+
+
+def test_placed_allocation_by_the_callers_own_measure(engine):
+    """rb_dev_alloc_placed_by: the caller scores every candidate (here: a list of made-up times, and a launch of the library on the
+    candidate); the lowest score is kept, an exception in the score ends the search and gives everything back"""
+    torch = pytest.importorskip("torch")
+    size = (3 << 29) + 4096
+    free0 = torch.cuda.mem_get_info()[0]
+    seen = []
+
+    def score(ptr):
+        seen.append(ptr)
+        assert engine.L.rb_dev_memset(engine.ctx, C.c_void_p(ptr), 0x11, C.c_size_t(4 * MB)) == 0     # (it may launch on the context)
+        return [5.0, 2.0, 9.0][len(seen) - 1]
+    ptr, scores, kept = engine.dev_alloc_placed(size, 3, score)
+    assert kept == 1 and scores == [5.0, 2.0, 9.0] and ptr == seen[1] and len(set(seen)) == 3
+    back = np.zeros(4 * MB, np.uint8)
+    assert engine.L.rb_dev_download(engine.ctx, C.c_void_p(back.ctypes.data), C.c_void_p(ptr), C.c_size_t(4 * MB)) == 0 and (back == 0x11).all()
+    engine.dev_free(ptr)
+
+    def bad(ptr):
+        raise ValueError("no")
+    with pytest.raises(ValueError):
+        engine.dev_alloc_placed(size, 3, bad)
+    assert free0 - torch.cuda.mem_get_info()[0] < 64 * MB
