@@ -242,6 +242,10 @@ __device__ __forceinline__ uint32_t rb_ndigits(uint32_t v) {
     return 1u + (v >= 10u) + (v >= 100u) + (v >= 1000u) + (v >= 10000u) + (v >= 100000u) + (v >= 1000000u) + (v >= 10000000u) + (v >= 100000000u);
 }
 
+#ifndef RB_FMT_WORDS
+#define RB_FMT_WORDS 0 // 1: an op's text as one 8-byte LDS store instead of a byte store per digit -- bit-exact (133 tests), and 2 % SLOWER
+                       // (1.85 against 1.81 ms, profiles/r04_text_summary.md): kept as a switch, not the product
+#endif
 #ifndef RB_FMT_STOP
 #define RB_FMT_STOP 0 // diagnostics (timing only, wrong text): 1 = the fill pass stops behind the byte counts of a step, 2 = behind the digits in LDS
 #endif
@@ -336,6 +340,39 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
         if (FILL && RB_FMT_STOP != 1) {
             const uint32_t phase = (uint32_t)(out & 15u);
             uint32_t o = phase + (incl - mine); // place in the stage buffer: byte k of the buffer is byte (out - phase + k) of the text
+            // Round 4: where no op of the step has more than four digits (nearly every step), an op's text leaves for LDS as ONE
+            // 8-byte store that ENDS at the op's last byte: its digits and character in the top bytes, the text in front of it -- the
+            // lane's earlier ops, or the tail of the lane before -- in the bytes below.  Every byte a store carries is the byte that
+            // belongs there, so stores may overlap in any order.  (Rounds 2 - 3: one predicated byte store per digit.)
+            const bool small_ops = nb[0] <= 5u && nb[1] <= 5u && nb[2] <= 5u && nb[3] <= 5u;
+            if (RB_FMT_WORDS && __ballot(!small_ops) == 0ull) {
+                unsigned long long S = 0ull, W[4];
+                uint32_t e[4], cum[4], c_ = 0u;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t n_ = nb[q];
+                    const uint32_t d4 = rb_digits4(len[q]) | 0x30303030u; // digit j of the length in byte j
+                    const uint32_t ch = (uint32_t)(uint8_t)("MIDNSHP=X??????"[opc[q] < 9u ? opc[q] : 9u]);
+                    const uint32_t hi = __builtin_amdgcn_perm(ch, d4, 0x04000102u);   // bytes: digit 2, digit 1, digit 0, the character
+                    const unsigned long long T = ((unsigned long long)hi << 32) | (unsigned long long)(d4 & 0xFF000000u); // ... digit 3 below them
+                    const uint32_t sh = 8u * n_;
+                    const unsigned long long keep = ~0ull << ((64u - sh) & 63u);       // the top n_ bytes (n_ = 0: not used)
+                    S = n_ ? ((S >> sh) | (T & keep)) : S;
+                    W[q] = S;
+                    c_ += n_, o += n_;
+                    cum[q] = c_, e[q] = o;
+                }
+                // the tail of the lane in front (a lane that has an op is behind a lane with four: at least eight bytes, all its own)
+                const uint32_t p_lo = rb_prev_lane((uint32_t)S, 0u), p_hi = rb_prev_lane((uint32_t)(S >> 32), 0u);
+                const unsigned long long prevS = ((unsigned long long)p_hi << 32) | p_lo;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (nb[q]) {
+                        const unsigned long long w = W[q] | (cum[q] < 8u ? (prevS >> (8u * cum[q])) : 0ull);
+                        __builtin_memcpy(stg + e[q] - 8u, &w, 8); // (one ds_write_b64 at a byte address: gfx950 takes it)
+                    }
+                }
+            } else {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (nb[q]) {
@@ -369,6 +406,7 @@ __global__ __launch_bounds__(256) void rb_k_format_cigars(rb_format_params p) {
                     }
                     o += nb[q];
                 }
+            }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();

@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=15000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--placement-tries", type=int, default=1, help="candidates rb_dev_alloc_placed may take for the counts array (store sweep)")
     a = ap.parse_args()
     import torch
     import rustybam_amd
@@ -86,7 +87,7 @@ def main():
     d_rgst = torch.zeros(1, dtype=torch.int64, device=dev)
     d_rgen = torch.full((1,), a.contig, dtype=torch.int64, device=dev)
     d_outoff = torch.tensor([0, a.contig], dtype=torch.int64, device=dev)
-    own_counts = capi.DevBuf(eng, torch, a.contig * 4 + 16, torch.int32) if lib_alloc else None
+    own_counts = capi.DevBuf(eng, torch, a.contig * 4 + 16, torch.int32, placed_tries=a.placement_tries) if lib_alloc else None
     d_counts = own_counts.t if lib_alloc else torch.empty(a.contig * 4 + 16, dtype=torch.int32, device=dev)
     d_status = torch.empty(n + 1, dtype=torch.int32, device=dev)
     d_ctr = torch.zeros(6, dtype=torch.int64, device=dev)
