@@ -385,6 +385,8 @@ def main():
     d_strand = torch.from_numpy(strand).to(dev)
     view = eng.batch_view(n_rec, total_ops, d_ops.data_ptr(), d_off.data_ptr(), d_tst.data_ptr(), d_ten.data_ptr(),
                           d_qst.data_ptr(), d_qen.data_ptr(), d_strand.data_ptr(), d_contig.data_ptr())
+    def view_now():  # (the batch view of the moment: the ops array may move once, when it is placed)
+        return view
     # upload-time pass of the reference (Paf::from_file -> check_integrity) + remove_trailing_indels
     eng.dev_scan_records(view, d_red.data_ptr(), d_norm.data_ptr())
     torch.cuda.synchronize()
@@ -412,8 +414,12 @@ def main():
     # counters and is done with the collect pass in front (two walks) -- decided once, by the sizing call below
     brk_policy = [policy | (rustybam_amd.BREAK_ONE_WALK if (args.op == "break" and not args.descriptors and not args.two_walk) else 0)]
 
+    nonlocal_view = [None]  # (set while a candidate of the ops array is being measured)
+    ops_placement = None
+
     def run_op(ws, rows, out):
         out_ptr = out if isinstance(out, int) else out.data_ptr()  # (a raw address: a candidate of the arena's placement)
+        view = nonlocal_view[0] or view_now()
         if args.op == "break":
             eng.dev_break(plan, view, d_norm.data_ptr(), 100, brk_policy[0], ws.data_ptr(), rows.data_ptr(), rows_cap, out_ptr,
                           out_cap, d_cnt.data_ptr())
@@ -467,6 +473,33 @@ def main():
             return (time.perf_counter() - t_) * 1e3 / 3
 
         d_out, own_out = big(out_cap + 64, torch.int32, placed=args.placement_tries, score=launch_score if args.placement_by == "launch" else None)
+        # ... and the INPUT: with the arena fixed, the same launch reading its ops from other pages differs by up to 8 % as well (9.23 /
+        # 9.38 / 10.02 ms, profiles/r04_alloc_summary.md).  Candidates of the ops array, each filled with a copy of the ops and measured by
+        # the step itself; rows and workspace do not care where they lie (9.42 - 9.48 ms).
+        if args.placement_by == "launch" and own_ops is not None:
+            class _Raw:  # (a candidate's address as a tensor, for the copy)
+                def __init__(self, ptr, nbytes):
+                    self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+            ops_bytes = (total_ops + 64) * 4
+            views = {}
+
+            def ops_score(ptr):
+                torch.as_tensor(_Raw(ptr, ops_bytes), device=dev).copy_(d_ops.view(torch.uint8)[:ops_bytes])
+                views[ptr] = eng.batch_view(n_rec, total_ops, ptr, d_off.data_ptr(), d_tst.data_ptr(), d_ten.data_ptr(),
+                                            d_qst.data_ptr(), d_qen.data_ptr(), d_strand.data_ptr(), d_contig.data_ptr())
+                nonlocal_view[0] = views[ptr]
+                try:
+                    return launch_score(d_out)
+                finally:
+                    nonlocal_view[0] = None
+            new_ops, new_own = big(total_ops + 64, torch.int32, placed=args.placement_tries, score=ops_score)
+            if new_own is not None and new_own.placement:
+                ops_placement = new_own.placement
+                old_t, old_own = d_ops, own_ops
+                d_ops, own_ops = new_ops, new_own
+                view = views[d_ops.data_ptr()]
+                del old_t
+                old_own.free()
         run_op(d_ws, d_rows, d_out)
         torch.cuda.synchronize()
         placement_ms = (time.perf_counter() - tp) * 1e3
@@ -512,13 +545,43 @@ def main():
             k_ms_ = float(np.mean(eng.get_timing()[-4:]))
             eng.set_timing(False)
             w_ms_ = eng.dev_box_probe(d_ops.data_ptr(), src_b, t_out.data_ptr(), t_out.data_ptr() + src_b, 5, scatter=1 | 8)[0] if out_cap * 4 >= 2 * src_b else float("nan")
-            prof = eng.dev_store_sweep_profile(t_out.data_ptr(), out_cap * 4, 32)
-            print(f"[placement {k_}] kernel {k_ms_:.3f} ms  probe writes alone {w_ms_:.3f} ms  arena at 0x{t_out.data_ptr():x}  "
-                  f"us per wave's 20 KiB by 32nd of the arena: {[round(x, 1) for x in prof]}", file=sys.stderr)
+            print(f"[placement {k_}] kernel {k_ms_:.3f} ms  probe writes alone {w_ms_:.3f} ms  arena at 0x{t_out.data_ptr():x}", file=sys.stderr)
         for t_out, own_t in held[1:]:
             del t_out
             if own_t:
                 own_t.free()
+        # ... and the other buffers, the arena fixed: the INPUT ops in other pages, then rows + workspace in other pages
+        held = []
+        for k_ in range(int(os.environ["RB_BENCH_PLACEMENTS"]) - 1):
+            t_ops, own_t = big(total_ops + 64, torch.int32)
+            t_ops.copy_(d_ops)
+            held.append((t_ops, own_t))
+            view_k = eng.batch_view(n_rec, total_ops, t_ops.data_ptr(), d_off.data_ptr(), d_tst.data_ptr(), d_ten.data_ptr(),
+                                    d_qst.data_ptr(), d_qen.data_ptr(), d_strand.data_ptr(), d_contig.data_ptr())
+            eng.set_timing(True)
+            for _ in range(6):
+                eng.dev_liftover(plan, view_k, d_norm.data_ptr(), policy, d_ws.data_ptr(), d_rows.data_ptr(), rows_cap, d_out.data_ptr(), out_cap, d_cnt.data_ptr())
+            torch.cuda.synchronize()
+            print(f"[ops placement {k_ + 1}] kernel {float(np.mean(eng.get_timing()[-4:])):.3f} ms  ops at 0x{t_ops.data_ptr():x}", file=sys.stderr)
+            eng.set_timing(False)
+        for t_ops, own_t in held:
+            del t_ops
+            if own_t:
+                own_t.free()
+        held = []
+        for k_ in range(int(os.environ["RB_BENCH_PLACEMENTS"]) - 1):
+            t_ws, own_a = big(eng.plan_workspace_bytes(plan, rows_cap), torch.uint8)
+            t_rows, own_b = big((rows_cap + 1) * 64, torch.uint8)
+            held.append((t_ws, own_a, t_rows, own_b))
+            eng.set_timing(True)
+            for _ in range(6):
+                run_op(t_ws, t_rows, d_out)
+            torch.cuda.synchronize()
+            print(f"[rows + workspace placement {k_ + 1}] kernel {float(np.mean(eng.get_timing()[-4:])):.3f} ms", file=sys.stderr)
+            eng.set_timing(False)
+        for t_ws, own_a, t_rows, own_b in held:
+            del t_ws, t_rows
+            [o_.free() for o_ in (own_a, own_b) if o_]
         run_op(d_ws, d_rows, d_out)  # (the probe overwrote the arena: the checks below read this launch's output)
         torch.cuda.synchronize()
     if use_dist:
@@ -635,6 +698,8 @@ def main():
                                                     "on the candidate, or the library's store sweep), the fastest kept; which physical pages the arena has decides "
                                                     "up to 20 % of the clip kernel's time"}
                                            if (own_out is not None and own_out.placement) else None),
+                   "ops_placement": ({"launch_ms": ops_placement["launch_ms"], "kept": ops_placement["kept"],
+                                      "note": "the input ops array placed the same way, arena fixed: the step itself on every candidate"} if ops_placement else None),
                    "batch_memory": ("rb_dev_alloc (2 MB physical chunks)" if lib_alloc and not alloc_note else
                                     "torch allocator (hipMalloc)" + (f"; rb_dev_alloc memory not usable as a tensor here: {alloc_note[0]}" if alloc_note else "")),
                    **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {}),
