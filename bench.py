@@ -492,14 +492,20 @@ def main():
                     return launch_score(d_out)
                 finally:
                     nonlocal_view[0] = None
+            incumbent_ms = launch_score(d_out)  # (the ops array as it lies: a candidate like the others -- the pages the arena's losers gave back may be the slow ones)
             new_ops, new_own = big(total_ops + 64, torch.int32, placed=args.placement_tries, score=ops_score)
             if new_own is not None and new_own.placement:
-                ops_placement = new_own.placement
-                old_t, old_own = d_ops, own_ops
-                d_ops, own_ops = new_ops, new_own
-                view = views[d_ops.data_ptr()]
-                del old_t
-                old_own.free()
+                ops_placement = dict(new_own.placement, incumbent_ms=round(incumbent_ms, 4))
+                if min(new_own.placement["launch_ms"]) < incumbent_ms:
+                    old_t, old_own = d_ops, own_ops
+                    d_ops, own_ops = new_ops, new_own
+                    view = views[d_ops.data_ptr()]
+                    del old_t
+                    old_own.free()
+                else:
+                    ops_placement["kept"] = "incumbent"
+                    del new_ops
+                    new_own.free()
         run_op(d_ws, d_rows, d_out)
         torch.cuda.synchronize()
         placement_ms = (time.perf_counter() - tp) * 1e3
@@ -698,8 +704,9 @@ def main():
                                                     "on the candidate, or the library's store sweep), the fastest kept; which physical pages the arena has decides "
                                                     "up to 20 % of the clip kernel's time"}
                                            if (own_out is not None and own_out.placement) else None),
-                   "ops_placement": ({"launch_ms": ops_placement["launch_ms"], "kept": ops_placement["kept"],
-                                      "note": "the input ops array placed the same way, arena fixed: the step itself on every candidate"} if ops_placement else None),
+                   "ops_placement": ({"incumbent_ms": ops_placement["incumbent_ms"], "launch_ms": ops_placement["launch_ms"], "kept": ops_placement["kept"],
+                                      "note": "the input ops array placed the same way, arena fixed: the step itself on the array as it lies (incumbent) and on "
+                                              "every candidate (a copy of the ops); the array moves only to a faster candidate"} if ops_placement else None),
                    "batch_memory": ("rb_dev_alloc (2 MB physical chunks)" if lib_alloc and not alloc_note else
                                     "torch allocator (hipMalloc)" + (f"; rb_dev_alloc memory not usable as a tensor here: {alloc_note[0]}" if alloc_note else "")),
                    **({"break_walks": 1 if (brk_policy[0] & rustybam_amd.BREAK_ONE_WALK) else 2} if args.op == "break" else {}),

@@ -33,7 +33,10 @@ def test_strong_scaling_digest_is_the_same_for_every_gpu_count():
     # the output arena and the ops array are placed by measurement (set-up): every candidate's time is in the line, and which one was kept
     for key in ("out_arena_placement", "ops_placement"):
         pl = one["config"][key]
-        assert len(pl["launch_ms"]) >= 1 and 0 <= pl["kept"] < len(pl["launch_ms"]) and pl["launch_ms"][pl["kept"]] == min(pl["launch_ms"]), key
+        if pl["kept"] == "incumbent":                       # (the ops array stays where it is unless a candidate is faster)
+            assert key == "ops_placement" and pl["incumbent_ms"] <= min(pl["launch_ms"])
+        else:
+            assert len(pl["launch_ms"]) >= 1 and 0 <= pl["kept"] < len(pl["launch_ms"]) and pl["launch_ms"][pl["kept"]] == min(pl["launch_ms"]), key
     forced = _bench(1, {"RB_BENCH_FORCE_DIST": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533", "RANK": "0", "WORLD_SIZE": "1",
                         "LOCAL_RANK": "0"})   # the RCCL init / barrier / gather path with a world of one
     assert forced["output_digest"] == one["output_digest"]

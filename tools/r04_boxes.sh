@@ -7,5 +7,5 @@ python bench.py --steps 10 --no-cpu-baseline --e2e-records 0 --no-box 2>/dev/nul
 python - $tag <<'PY'
 import json,sys
 d=json.load(open(f"gpurun_out/{sys.argv[1]}/b.json")); c=d["config"]
-print("kernel", d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"], "arena", c["out_arena_placement"]["launch_ms"], c["out_arena_placement"]["kept"], "ops", c["ops_placement"] and (c["ops_placement"]["launch_ms"], c["ops_placement"]["kept"]))
+print("kernel", d["roofline"]["kernel_ms"], "frac", d["roofline"]["frac"], "arena", c["out_arena_placement"]["launch_ms"], c["out_arena_placement"]["kept"], "ops", c["ops_placement"] and (c["ops_placement"].get("incumbent_ms"), c["ops_placement"]["launch_ms"], c["ops_placement"]["kept"]))
 PY
