@@ -43,6 +43,17 @@ traffic = {"_comment": "PMC traffic of rb_k_liftover_stream per full-size launch
            "traffic_bytes_per_launch": fetch + write, "kernel": "rb_k_liftover_stream", "build": f"profile {tag}",
            "kernel_source_sha": kernel_source_sha(), "git_head": os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()}
 json.dump(traffic, open(os.path.join(dst, f"traffic_{rnd}.json"), "w"), indent=1)
+timed_row = f"max {float(ks['MaxNs']) / 1e6:.2f} ms"
+try:  # the timed steps = the last launches of the kernel in the trace
+    import csv as _csv
+    tr = [r for r in _csv.DictReader(open(os.path.join(ROOT, "gpurun_out", tag, "kt_kernel_trace.csv"))) if r["Kernel_Name"].startswith("rb_k_liftover_stream(")]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr]
+    last = dur[-10:]
+    timed_row = (f"the last 10 launches (the timed steps): {min(last):.2f} - {max(last):.2f} ms, mean {sum(last) / len(last):.3f} ms; all {len(dur)} launches "
+                 f"{min(dur):.2f} - {max(dur):.2f} ms (the slow ones are candidates the placement turned down)")
+except Exception:
+    pass
 extra_rows = ""
 if B.get("e2e", {}).get("records"):
     extra_rows += f"| end to end (`rb liftover`, text in -> text out, {B['e2e']['records']} records) | {B.get('e2e_paf_records_per_s', 0):.0f} PAF-records/s ({B['e2e'].get('seconds', 0)} s) |\n"
@@ -64,7 +75,7 @@ md = f"""# Profile {tag} -- the headline step (config 3: 1e6 records, 5e9 ops, 3
 |---|---|
 | `ms_per_step` (bench.py, unprofiled) | {B['ms_per_step']:.2f} -> {B['value']:.3e} CIGAR-ops/s, {B['paf_records_per_s']:.3e} PAF-records/s |
 | `rb_k_liftover_stream`, HIP events inside bench.py | {B['roofline']['kernel_ms']:.2f} ms -> {B['roofline']['achieved']:.0f} GB/s of algorithmic bytes = **{B['roofline']['frac']:.3f} of 8 TB/s** |
-| the same kernel in `profiles/{tag}_kernel_stats.csv` (full-size launches = the maximum; the average mixes in sizing / parity-sample launches) | max {float(ks['MaxNs']) / 1e6:.2f} ms over {ks['Calls']} calls |
+| the same kernel in the profiled run (`profiles/{tag}_kernel_stats.csv`: {ks['Calls']} calls -- sizing, the candidates of the two placements, warm-up, the timed steps) | {timed_row} |
 | FETCH_SIZE per full launch | {best['FETCH_SIZE']:.4g} KB raw x2 (gfx950 correction) = {fetch / 1e9:.2f} GB |
 | WRITE_SIZE per full launch | {best['WRITE_SIZE']:.4g} KB = {write / 1e9:.2f} GB |
 | traffic | **{(fetch + write) / 1e9:.1f} GB = {(fetch + write) / algo:.3f} x the {algo / 1e9:.2f} GB of algorithmic bytes** (round 2: 51.8 GB, 1.143 x; round 1: 70.9 GB, 1.56 x) |
