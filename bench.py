@@ -40,11 +40,15 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--records", type=int, default=1_000_000, help="records per GPU")
     ap.add_argument("--windows", type=int, default=3000)
-    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config2-lognormal", "irregular"],
+    ap.add_argument("--workload", default="config3", choices=["config3", "config2", "config2-lognormal", "irregular", "config4-shape"],
                     help="config3: the headline; config2: one 1 Mbp window; config2-lognormal: SURVEY 8(d)'s imbalance shape of config 2 "
                          "(op counts log-normal(ln 2000, 1.35) clipped to [31, 80000], the fixture's own range; --records defaults to 1e5 x "
                          "mean 4.1k ops); irregular: config 3's records made irregular (adjacent ops of one "
-                         "type at the start, an N / H op at an end of two thirds of them) so that every hit takes the generic wave-per-hit kernel")
+                         "type at the start, an N / H op at an end of two thirds of them) so that every hit takes the generic wave-per-hit kernel; "
+                         "config4-shape: BASELINE config 4's record shape through the same two ops (--records defaults to 1e7 records of 300-700 "
+                         "ops, seed 0x5EED0004, placed uniformly under the 3000 sliding windows; --op liftover | break): the short-record regime")
+    ap.add_argument("--ops-lo", type=int, default=0, help="config4-shape: op counts uniform in [--ops-lo, --ops-hi] (default 300 .. 700)")
+    ap.add_argument("--ops-hi", type=int, default=0)
     ap.add_argument("--irregular-frac", type=float, default=0.0,
                     help="config3 / --op break: this fraction of the records made irregular as in --workload irregular (0.01: what the "
                          "one-walk break path must take record by record instead of redoing the batch)")
@@ -53,6 +57,8 @@ def parse():
                          "`--workload config2 --placement uniform` is SURVEY 8(d)'s second imbalance case: about 0.8 %% of the records overlap "
                          "the window, every record is still walked (liftover.rs:119-121)")
     ap.add_argument("--no-box", action="store_true", help="skip the `box` block (memory-mix probe, in-kernel clock, tail of the launch)")
+    ap.add_argument("--box-smi", action="store_true",
+                    help="the `box` block also asks rocm-smi (two child processes, started before this one touches the GPU; never under a profiler)")
     ap.add_argument("--legacy", action="store_true", help="RB_BSEARCH_LEGACY (rustc 1.52 .. 1.81 binary search): duplicates resolved by probe replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
@@ -258,10 +264,27 @@ class SmiSampler:
             return {"error": f"{type(e).__name__}: {e}"}
 
 
+def under_profiler():
+    """True when a profiler's tool library rides in this process (rocprofv3 / rocprof preload theirs, and with --pmc it has initialised
+    the GPU before python's first line runs).  Such a process must not start ANY child: no rocm-smi, no `rb`, no ranks."""
+    e = os.environ
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in e):
+        return True
+    pre = e.get("LD_PRELOAD", "")
+    return any(t in pre for t in ("rocprof", "roctracer", "rocprofiler", "libkineto"))
+
+
 def main():
     args = parse()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    profiled = under_profiler()
+    if profiled:  # (no child process of any kind: see under_profiler)
+        args.box_smi = False
+        args.e2e_records = 0
+        if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+            raise SystemExit("bench.py: --gpus N under a profiler would start the ranks from a process whose GPU is already initialised; "
+                             "profile one rank (--gpus 1) or start the ranks with torch.distributed.run outside the profiler")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args))  # (before torch / HIP are even imported)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -274,9 +297,10 @@ def main():
                           "port": os.environ.get("MASTER_PORT"), "ipc_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}), flush=True)
         return
     e2e = None
-    smi = smi_facts() if (rank == 0 and not args.no_box) else None
-    sampler = SmiSampler() if (rank == 0 and not args.no_box) else None  # (a child process, started before this one touches the GPU)
-    if rank == 0 and args.e2e_records > 0 and args.workload == "config3" and args.op == "liftover" and not args.no_cpu_baseline:
+    want_smi = rank == 0 and args.box_smi and not args.no_box and not profiled
+    smi = smi_facts() if want_smi else None
+    sampler = SmiSampler() if want_smi else None  # (a child process, started before this one touches the GPU)
+    if rank == 0 and args.e2e_records > 0 and args.workload == "config3" and args.op == "liftover" and not args.no_cpu_baseline and not profiled:
         # (child processes, before this one initialises the GPU; with N ranks: `rb --gpus N` on the same file while the other ranks
         #  wait for rank 0 at the rendezvous)
         e2e = e2e_leg(args.e2e_records, args.windows, world)
@@ -311,16 +335,20 @@ def main():
 
     if args.workload.startswith("config2") and "--records" not in sys.argv:
         args.records = 100_000  # BASELINE.json configs[1]: 1e5 records x one 1 Mbp window
+    c4 = args.workload == "config4-shape"
+    if c4 and "--records" not in sys.argv:
+        args.records = 10_000_000  # BASELINE.json configs[3]: 1e7 records of 300 - 700 ops
+    ops_lo, ops_hi = (args.ops_lo or 300, args.ops_hi or 700) if c4 else (1000, 9000)
     if args.scaling == "strong":  # one batch of --records, one op-balanced contiguous record range per rank
-        seed_ = wl.SEED_CONFIG2 if args.workload.startswith("config2") else wl.SEED_CONFIG3
+        seed_ = wl.SEED_CONFIG2 if args.workload.startswith("config2") else (wl.SEED_CONFIG4 if c4 else wl.SEED_CONFIG3)
         bounds = shard.shard_bounds(wl.op_offsets(wl.n_ops_lognormal(seed_, 0, args.records) if args.workload == "config2-lognormal"
-                                                  else wl.n_ops(seed_, 0, args.records)), world)
+                                                  else wl.n_ops(seed_, 0, args.records, ops_lo, ops_hi)), world)
         first, n_rec = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
     else:
         n_rec = args.records
         first = rank * n_rec
-    if args.workload in ("config3", "irregular"):
-        seed, placement = wl.SEED_CONFIG3, "uniform"
+    if args.workload in ("config3", "irregular", "config4-shape"):
+        seed, placement = (wl.SEED_CONFIG4 if c4 else wl.SEED_CONFIG3), "uniform"
         w_c, w_st, w_en = wl.sliding_windows(args.windows)
     else:
         seed, placement = wl.SEED_CONFIG2, "overlap"
@@ -331,7 +359,7 @@ def main():
 
     # ---- generate the shard in HBM ----
     t0 = time.time()
-    nops = wl.n_ops_lognormal(seed, first, n_rec) if lognormal else wl.n_ops(seed, first, n_rec)
+    nops = wl.n_ops_lognormal(seed, first, n_rec) if lognormal else wl.n_ops(seed, first, n_rec, ops_lo, ops_hi)
     op_off = wl.op_offsets(nops)
     total_ops = int(op_off[-1])
 
@@ -458,7 +486,17 @@ def main():
     # "sweep" = the library's own store sweep (rb_dev_alloc_placed), which tells an 11 ms arena from a 9.2 ms one but not always
     # a 10.1 ms one from a 9.9 ms one.
     placement_ms = 0.0
+    unplaced_ms = None  # the clip kernel (HIP events) on the buffers as rb_dev_alloc first returned them: what a caller that places nothing gets
     if args.placement_tries > 1 and own_out is not None:
+        run_op(d_ws, d_rows, d_out)
+        torch.cuda.synchronize()
+        eng.set_timing(True)
+        for _ in range(5):
+            run_op(d_ws, d_rows, d_out)
+        torch.cuda.synchronize()
+        u_ = eng.get_timing()[-5:]
+        eng.set_timing(False)
+        unplaced_ms = float(np.mean(u_)) if len(u_) else None
         tp = time.perf_counter()
         del d_out
         own_out.free()
@@ -645,7 +683,8 @@ def main():
         ks = np.sort(np.asarray(kern_ms[-args.steps:]))
         print(f"[kernel ms] min {ks[0]:.3f}  median {ks[len(ks) // 2]:.3f}  mean {ks.mean():.3f}  max {ks[-1]:.3f}"
               f"  | out_cap {out_cap} rows_cap {rows_cap} d_out 0x{d_out.data_ptr():x} d_ops 0x{d_ops.data_ptr():x}", file=sys.stderr)
-    if args.op == "break" or irregular:  # (no single dominant kernel under HIP events: the rate is taken over the whole step)
+    one_walk = args.op == "break" and bool(brk_policy[0] & rustybam_amd.BREAK_ONE_WALK)
+    if (args.op == "break" and not one_walk) or irregular or not (k_ms == k_ms):  # (no single dominant kernel under HIP events: the rate is taken over the whole step)
         k_ms = elapsed / args.steps * 1e3
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     # HBM-side bytes per launch from the committed PMC run of this same workload (bench.py is not run under --pmc).  The file names the
@@ -667,20 +706,27 @@ def main():
         pass
     ks_ = np.sort(np.asarray(kern_ms[-args.steps:], dtype=np.float64)) if kern_ms else np.zeros(0)
     roofline = {"bound": "hbm", "kernel": ("rb_k_liftover_generic_wave (whole step: the streaming kernel only verifies and defers)" if irregular else "rb_k_liftover_stream") if args.op == "liftover"
-                else "rb_dev_break (rb_k_break_pieces + rb_k_liftover_stream)", "achieved": round(achieved, 1), "peak": 8000.0,
+                else ("rb_k_liftover_stream_brk" if one_walk else "rb_dev_break (rb_k_break_pieces + rb_k_liftover_stream)"), "achieved": round(achieved, 1), "peak": 8000.0,
                 "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_note,
                 "kernel_ms": round(k_ms, 4), "algorithmic_bytes": algo_bytes,
                 # the clip kernel's own launches of the timed steps (HIP events on the launch stream): min / median / max
                 "kernel_ms_steps": ({"min": round(float(ks_[0]), 4), "median": round(float(ks_[len(ks_) // 2]), 4), "max": round(float(ks_[-1]), 4),
                                      "n": int(len(ks_))} if len(ks_) else None),
                 "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)}
+    # ... and the same kernel on the buffers as first allocated (arena candidate 0, the ops array where it lay): five launches under HIP
+    # events before any placement.  With --placement-tries 1 nothing is placed and the line's own figure is that number.
+    if unplaced_ms is None and args.placement_tries <= 1 and k_ms == k_ms:
+        unplaced_ms = k_ms
+    roofline["unplaced"] = ({"kernel_ms": round(unplaced_ms, 4), "frac": round(algo_bytes / (unplaced_ms * 1e-3) / 8e12, 4),
+                             "note": "arena and ops array as rb_dev_alloc first returned them (no rb_dev_alloc_placed)"} if unplaced_ms else None)
 
     result = {
         "metric": (("CIGAR-ops/s, liftover over 100 kb sliding windows (whole pass, inputs resident in HBM)" if args.workload == "config3" else
+                    f"CIGAR-ops/s, liftover over 100 kb sliding windows, records of {ops_lo}-{ops_hi} ops (config 4's shape; whole pass, inputs resident in HBM)" if c4 else
                     f"CIGAR-ops/s, liftover over 100 kb sliding windows, irregular CIGARs{', legacy binary search' if args.legacy else ''} (generic kernel; whole pass, inputs resident in HBM)" if irregular else
                     "CIGAR-ops/s, liftover over one 1 Mbp window" + (", log-normal op counts" if lognormal else "") +
                     (", records placed uniformly on the target" if placement == "uniform" else "") + " (whole pass, inputs resident in HBM)") if args.op == "liftover"
-                   else "CIGAR-ops/s, break-paf --max-size 100 (whole pass, inputs resident in HBM)"),
+                   else "CIGAR-ops/s, break-paf --max-size 100" + (f", records of {ops_lo}-{ops_hi} ops (config 4's shape)" if c4 else "") + " (whole pass, inputs resident in HBM)"),
         "value": job_ops * args.steps / elapsed,
         "unit": "CIGAR-ops/s",
         "n_gpus": world,
@@ -692,7 +738,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": f"BASELINE.json {args.workload}: {n_rec} records/GPU ({'log-normal(ln 2000, 1.35) in [31, 80000]' if lognormal else 'uniform 1000-9000'} ops, "
+        "config": {"workload": f"BASELINE.json {args.workload}: {n_rec} records/GPU ({'log-normal(ln 2000, 1.35) in [31, 80000]' if lognormal else f'uniform {ops_lo}-{ops_hi}'} ops, "
                                f"{total_ops} ops on rank 0) x {len(w_st)} windows, placement {placement}, seed {seed:#x}",
                    "records_per_gpu": n_rec, "windows": int(len(w_st)), "parallelism": f"record-range shard x{world} ({args.scaling}: "
                                    + (f"{args.records} records in all, cut on the op-count prefix" if args.scaling == "strong" else f"{args.records} records per GPU") + ")",

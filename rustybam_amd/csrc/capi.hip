@@ -113,6 +113,13 @@ extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t
 extern "C" hipError_t rb_launch_make_jobs(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_stream(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_liftover_tiles(const rb_lift_params *p, hipStream_t stream);       // k_tile.hip
+extern "C" hipError_t rb_launch_liftover_stream_list(const rb_lift_params *p, hipStream_t stream);
+extern "C" uint32_t rb_tile_max_ops(void);
+extern "C" uint32_t rb_tile_max_records(void);
+#ifndef RB_SHORT_MAX_DEFAULT
+#define RB_SHORT_MAX_DEFAULT 2048 // records of up to this many ops go through the tile kernel (profiles/r05_reclen_summary.md)
+#endif
 extern "C" hipError_t rb_launch_break_gather(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_break_declined(const rb_lift_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_break_list_declined(const rb_lift_params *p, hipStream_t stream);
@@ -224,6 +231,10 @@ struct rb_plan {
     uint32_t *sched = nullptr, *slot_of = nullptr, *canon_pos = nullptr, *w_orig = nullptr, *ident = nullptr;
     uint64_t *w_st = nullptr, *w_en = nullptr, *wo_st = nullptr, *wo_en = nullptr, *cw_off = nullptr;
     uint8_t *cw_mono = nullptr;
+    // short records (k_tile.hip): tiles of consecutive records, two words each {first record | passthrough << 31, records}; the schedule's
+    // slots [0, stream_end) hold the records longer than the tiles take (it is sorted by length)
+    uint32_t *tiles = nullptr;
+    uint32_t n_tiles = 0, stream_end = 0;
 };
 
 static int fail(rb_ctx *ctx, int code, const char *fmt, ...) {
@@ -704,6 +715,43 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
             pl->depth = std::max<uint32_t>(pl->depth, (uint32_t)std::min<uint64_t>(i - lo + 1, 1u << 20));
         }
     }
+    // tiles of short records (k_tile.hip): consecutive records of 8 .. short_max ops, at most rb_tile_max_records() of them and
+    // rb_tile_max_ops() ops together; runs of records below 8 ops become pass-through tiles (the per-record kernel takes them).
+    // RB_TILE=0 switches the tile kernel off, RB_SHORT_MAX=<ops> moves the line between the two kernels (experiments).
+    std::vector<uint32_t> tiles;
+    pl->stream_end = (uint32_t)n_rec;
+    {
+        const char *e = getenv("RB_TILE");
+        const bool on = !(e && !strcmp(e, "0")) && !getenv("RB_SCHED");
+        uint64_t short_max = RB_SHORT_MAX_DEFAULT;
+        if (const char *m = getenv("RB_SHORT_MAX")) short_max = strtoull(m, nullptr, 10);
+        short_max = std::min<uint64_t>(short_max, rb_tile_max_ops());
+        if (on && short_max >= 8 && n_rec) {
+            const uint64_t max_ops = rb_tile_max_ops(), max_rec = rb_tile_max_records();
+            uint64_t first = 0, cnt = 0, ops = 0, n_long = 0, n_tiled = 0;
+            bool tiny = false;
+            auto close = [&]() {
+                if (cnt) tiles.push_back((uint32_t)first | (tiny ? 0x80000000u : 0u)), tiles.push_back((uint32_t)cnt), n_tiled += tiny ? 0 : cnt;
+                cnt = 0, ops = 0;
+            };
+            for (uint64_t r = 0; r < n_rec; r++) {
+                const uint64_t n = op_off[r + 1] - op_off[r];
+                if (n > short_max) {
+                    close();
+                    n_long++;
+                    continue;
+                }
+                const bool t = n < 8;
+                if (cnt && (t != tiny || cnt >= max_rec || (!t && ops + n > max_ops))) close();
+                if (!cnt) first = r, tiny = t;
+                cnt++, ops += n;
+            }
+            close();
+            if (n_tiled == 0) tiles.clear(); // (nothing for the tile kernel: the schedule stays whole)
+            else pl->stream_end = (uint32_t)n_long;
+        }
+        pl->n_tiles = (uint32_t)(tiles.size() / 2);
+    }
     int rc = RB_OK;
     std::vector<uint32_t> slot_of(n_rec);
     for (uint64_t w = 0; w < n_rec; w++) slot_of[sched[w]] = (uint32_t)w;
@@ -718,6 +766,7 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
     if (!rc) rc = upload_vec(ctx, o_en, &pl->wo_en);
     if (!rc) rc = upload_vec(ctx, cw_off, &pl->cw_off);
     if (!rc) rc = upload_vec(ctx, mono, &pl->cw_mono);
+    if (!rc && pl->n_tiles) rc = upload_vec(ctx, tiles, &pl->tiles);
     if (rc) {
         rb_plan_destroy(pl);
         return rc;
@@ -727,7 +776,7 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
 }
 extern "C" void rb_plan_destroy(rb_plan *pl) {
     if (!pl) return;
-    void *ptrs[] = {pl->sched, pl->slot_of, pl->ident, pl->canon_pos, pl->w_st, pl->w_en, pl->w_orig, pl->wo_st, pl->wo_en, pl->cw_off, pl->cw_mono};
+    void *ptrs[] = {pl->sched, pl->slot_of, pl->ident, pl->canon_pos, pl->w_st, pl->w_en, pl->w_orig, pl->wo_st, pl->wo_en, pl->cw_off, pl->cw_mono, pl->tiles};
     for (void *q : ptrs)
         if (q) hipFree(q);
     delete pl;
@@ -735,7 +784,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
 
 // workspace layout: [hit_off (n_rec+1) u64][win_lo][block sums][arena cursors][jobs n_rec x 64 B][gen_list rows_cap u32][x_st rows_cap u64][x_en rows_cap u64]
 struct ws_layout {
-    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, decl_count, decl_list, gen_cp, diag_stamps, total;
+    size_t hit_off, win_lo, block_sums, arena, pend_count, pend_list, jobs, gen_list, x_st, x_en, bp_tmp, bp_off, bp_cur, brk_rows, copy_count, copy_list, decl_count, decl_list, gen_cp, diag_stamps, fb_count, fb_list, total;
 };
 // RB_DEBUG_NO_GEN_CP (diagnostics: the generic kernel walks every record from its first op, no room for checkpoints): read ONCE per
 // process -- the workspace layout and the kernel parameter must agree on it
@@ -771,6 +820,8 @@ static ws_layout ws_of(uint64_t n_rec, uint64_t rows_cap, uint64_t n_ops) {
     w.decl_list = take((n_rec + 1) * 4); // break-paf in one walk: the records its clip kernel declined
     w.gen_cp = take(rb_no_gen_cp() ? 256 : (size_t)(n_ops / RB_GCP + n_rec + 2) * sizeof(uint4)); // checkpoints of the records the generic kernel works on
     w.diag_stamps = take((n_rec + 1) * 4); // diagnostics build of the clip kernel: when each record's wave was done
+    w.fb_count = take(256);
+    w.fb_list = take((n_rec + 1) * 4); // the records of the tiles the tile kernel handed to the per-record kernel
     w.total = o;
     return w;
 }
@@ -866,6 +917,13 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.norm_w = const_cast<rb_norm_row *>(norm);
     p.pend_list = (uint32_t *)(ws + w.pend_list);
     p.pend_count = (unsigned long long *)(ws + w.pend_count);
+    // short records go through the tile kernel (k_tile.hip); the diagnostics builds keep every record on the per-record kernel
+    const bool use_tiles = plan->n_tiles != 0 && ((policy >> 8) & 0xFFF) == 0 && !getenv("RB_DEBUG_NO_TILES");
+    p.tile_first = use_tiles ? plan->tiles : nullptr;
+    p.n_tiles = use_tiles ? plan->n_tiles : 0;
+    p.fb_list = (uint32_t *)(ws + w.fb_list);
+    p.fb_count = (unsigned long long *)(ws + w.fb_count);
+    const uint32_t stream_end = use_tiles ? plan->stream_end : (uint32_t)b->n_rec;
     rb_scan_params sp;
     memset(&sp, 0, sizeof sp);
     if (p.fused) {
@@ -908,8 +966,13 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
         const size_t slot1 = (size_t)(ctx->timed_calls % RB_TIMING_RING);
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_a[slot1], ctx->stream));
         p.wave0 = 0;
-        p.wave_end = (uint32_t)b->n_rec;
+        p.wave_end = stream_end;
         HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
+        if (use_tiles) {
+            HIPCHK(ctx, rb_fill_async(p.fb_count, 0, 8, ctx->stream));
+            HIPCHK(ctx, rb_launch_liftover_tiles(&p, ctx->stream));
+            HIPCHK(ctx, rb_launch_liftover_stream_list(&p, ctx->stream));
+        }
         if (p.fused) {
             sp.list = p.pend_list;
             sp.n_list = (const uint64_t *)p.pend_count;
@@ -975,8 +1038,13 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     const size_t slot = (size_t)(ctx->timed_calls % RB_TIMING_RING);
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev_a[slot], ctx->stream));
     p.wave0 = 0;
-    p.wave_end = (uint32_t)b->n_rec;
+    p.wave_end = stream_end;
     HIPCHK(ctx, rb_launch_liftover_stream(&p, ctx->stream));
+    if (use_tiles) {
+        HIPCHK(ctx, rb_fill_async(p.fb_count, 0, 8, ctx->stream));
+        HIPCHK(ctx, rb_launch_liftover_tiles(&p, ctx->stream));
+        HIPCHK(ctx, rb_launch_liftover_stream_list(&p, ctx->stream));
+    }
     if (p.fused) { // the full record scan for the records the clip kernel handed back (usually none)
         sp.list = p.pend_list;
         sp.n_list = (const uint64_t *)p.pend_count;

@@ -46,6 +46,7 @@
         t_prev = t_now;                                                                                              \
     }
 
+#ifndef RB_LIST_TU // (k_liftover_list.hip compiles only the per-record kernel's list form out of this file)
 __global__ __launch_bounds__(256) void rb_k_count_hits(rb_lift_params p) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.n_rec) return;
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(256) void rb_k_make_jobs(rb_lift_params p) {
     p.jobs[w] = j;
 }
 
+#endif // !RB_LIST_TU
 // ------------------------------------------------------------------------------------------------
 // streaming kernel
 // ------------------------------------------------------------------------------------------------
@@ -272,8 +274,9 @@ static_assert((RB_OPL == 8 && (RB_PF == 2 || RB_PF == 3)) || (RB_OPL == 4 && RB_
 // longer than brk_max, found while the record streams; 32 pieces a pass.  The liftover build has none of that code.
 // DIAG: the diagnostics build of the same kernel (bench.py --debug-skip: phases switched off, phase timers, clock stamps); the product
 // launches DIAG = false, in which no stamp executes and no debug bit is looked at.
-template <bool BRK, bool DIAG>
-__device__ __forceinline__ void rb_stream_record() {
+// LIST_WAVE: the schedule slot comes from the caller (rb_k_liftover_stream_list: the records the tile kernel handed back, k_tile.hip)
+template <bool BRK, bool DIAG, bool LIST = false>
+__device__ __forceinline__ void rb_stream_record(const uint64_t list_wave = 0) {
     // The 408 bytes of parameters are NOT read through `p_`: the compiler loads every by-value kernel argument a kernel uses in
     // its entry block and then carries -- spills -- those hundred scalar registers through the whole record (round 2: 233 SGPR
     // spills, parked in VGPRs right under the load ring).  `p.field` below reads the field from the kernel-argument segment where
@@ -289,8 +292,13 @@ __device__ __forceinline__ void rb_stream_record() {
     __shared__ uint32_t cp_all[4][3][RB_SMAX * RB_CP_PER_STEP];
     __shared__ uint32_t wx_all[4][RB_HMAX + 1]; // window indices of one pass over a window list that is not sorted
     const uint32_t wib = rb_first(threadIdx.x >> 6); // wave in block (told to the compiler as the wave-uniform value it is)
-    const uint64_t wave = (uint64_t)p.wave0 + (uint64_t)blockIdx.x * 4u + wib;
-    if (wave >= p.wave_end) return;
+    uint64_t wave;
+    if constexpr (LIST) {
+        wave = list_wave;
+    } else {
+        wave = (uint64_t)p.wave0 + (uint64_t)blockIdx.x * 4u + wib;
+        if (wave >= p.wave_end) return;
+    }
     const int lane = rb_lane();
     long long t_prev = (dbg & 32) ? clock64() : 0;
     uint32_t *cpR = cp_all[wib][0], *cpQ = cp_all[wib][1], *cpU = cp_all[wib][2];
@@ -1231,9 +1239,41 @@ __device__ __forceinline__ void rb_stream_record() {
         (void)p_; /* (read through the kernel-argument segment, see the top of rb_stream_record) */                                \
         rb_stream_record<BRK, DIAG>();                                                                                            \
     }
+#ifndef RB_LIST_TU
 RB_STREAM_KERNEL(rb_k_liftover_stream, false, false, RB_SPILL_ROOM)
 RB_STREAM_KERNEL(rb_k_liftover_stream_brk, true, false, RB_SPILL_ROOM)
 RB_STREAM_KERNEL(rb_k_liftover_stream_diag, false, true, 4)
+#endif
+#ifdef RB_LIST_TU
+// ... and over a LIST of records (fb_list: the records of the tiles k_tile.hip did not take), workgroups that stay and take entry after entry
+#define RB_LIST_BLOCKS 2560u // workgroups of the list form (twice what the chip holds at five per CU: entries differ in length)
+// (the loop's state is ONE vector register -- the entry index, kept opaque --: everything else is read again from the kernel-argument
+//  segment per entry.  Scalar registers carried around the record's body are spilled, and this build's spills reached into the ring)
+#define RB_STREAM_LIST_KERNEL(NAME, BRK)                                                                                          \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_WPE), amdgpu_num_vgpr(RB_RING_BASE - RB_SPILL_ROOM))) void NAME(rb_lift_params p_) { \
+        (void)p_;                                                                                                                 \
+        const rb_kparams kp_ = (rb_kparams)__builtin_amdgcn_kernarg_segment_ptr();                                                \
+        uint32_t i_v = blockIdx.x * 4u + (threadIdx.x >> 6);                                                                      \
+        for (;;) {                                                                                                                \
+            asm volatile("" : "+v"(i_v));                                                                                         \
+            const rb_kparams kl_ = rb_kp_here(kp_);                                                                               \
+            const uint32_t i_ = rb_first(i_v);                                                                                    \
+            if ((unsigned long long)i_ >= *kl_->fb_count) break;                                                                  \
+            const uint64_t w_ = rb_first(kl_->slot_of[rb_first(kl_->fb_list[i_])]);                                               \
+            rb_stream_record<BRK, false, true>(w_);                                                                               \
+            i_v += RB_LIST_BLOCKS * 4u;                                                                                           \
+        }                                                                                                                         \
+    }
+RB_STREAM_LIST_KERNEL(rb_k_liftover_stream_list, false)
+RB_STREAM_LIST_KERNEL(rb_k_liftover_stream_brk_list, true)
+extern "C" hipError_t rb_launch_liftover_stream_list(const rb_lift_params *p, hipStream_t stream) {
+    if (p->n_rec == 0 || p->n_tiles == 0) return hipSuccess;
+    if (p->brk_mode) hipLaunchKernelGGL(rb_k_liftover_stream_brk_list, dim3(RB_LIST_BLOCKS), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL(rb_k_liftover_stream_list, dim3(RB_LIST_BLOCKS), dim3(256), 0, stream, *p);
+    return hipGetLastError();
+}
+#endif // RB_LIST_TU
+#ifndef RB_LIST_TU
 // (no diagnostics build of the break form: its spilled scalar registers land in the ring -- tools/check_ring.py --, and nothing asks for it)
 
 // ------------------------------------------------------------------------------------------------
@@ -2107,3 +2147,4 @@ extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream
 }
 
 extern "C" size_t rb_scan_block_sums_count(uint64_t n_rec) { return (size_t)((n_rec + RB_SCAN_PER_BLOCK - 1) / RB_SCAN_PER_BLOCK + 2); }
+#endif // !RB_LIST_TU

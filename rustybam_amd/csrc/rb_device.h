@@ -84,6 +84,11 @@ __device__ __forceinline__ uint64_t rb_readlane<uint64_t>(uint64_t v, int lane) 
     uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
     return ((uint64_t)hi << 32) | lo;
 }
+// v_writelane_b32: lane `lane` of `old` becomes the wave-uniform `val` (this clang has no builtin for it; the intrinsic is there)
+extern "C" __device__ int rb_llvm_writelane(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+__device__ __forceinline__ uint32_t rb_writelane(uint32_t val, uint32_t lane, uint32_t old) {
+    return (uint32_t)rb_llvm_writelane((int)val, (int)lane, (int)old);
+}
 // wave64 ballot straight from the comparison (HIP's __ballot goes through an i32: v_cndmask + v_cmp_ne on top of the v_cmp)
 #define rb_ballot(pred) ((unsigned long long)__builtin_amdgcn_ballot_w64(pred))
 __device__ __forceinline__ uint32_t rb_first(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }

@@ -104,6 +104,15 @@ struct rb_lift_params {
     // diagnostics build of the clip kernel only (debug_skip & 256): [n_rec] the 100 MHz clock (low 32 bits) at which schedule slot w's
     // wave was done with its record -- how long a launch runs on after most of its waves have retired
     uint32_t *diag_stamps;
+    // short records (k_tile.hip): tile t = records [tile_first[t], tile_first[t + 1]) -- consecutive in memory, each of 8 .. short_max
+    // ops, at most RBT_REC of them and RBT_OPS - 32 ops together -- streamed by ONE wave as if they were one record (bit 31 of
+    // tile_first[t]: a run of records too small for a tile, handed to the per-record kernel as they are).  A tile the tile kernel does
+    // not take (a record that is not regular or was stripped, too many hits, a record its verification does not pass, ...) lists its
+    // records in fb_list; the per-record kernel then runs over that list (rb_k_liftover_stream_list).
+    const uint32_t *tile_first;    // [2 n_tiles]: {first record | pass-through << 31, records}
+    uint32_t n_tiles;
+    uint32_t *fb_list;             // [n_rec]
+    unsigned long long *fb_count;
 };
 #define RB_GCP 256u
 

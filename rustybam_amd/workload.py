@@ -10,6 +10,7 @@ import numpy as np
 CHR1_LEN = 248_387_497
 SEED_CONFIG2 = 0x5EED0002
 SEED_CONFIG3 = 0x5EED0003
+SEED_CONFIG4 = 0x5EED0004
 M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 
 

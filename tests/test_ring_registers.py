@@ -28,3 +28,20 @@ def test_compiler_stays_out_of_the_ring_registers():
     text = check_ring.compile_to_asm(HIPCC)
     bad = check_ring.check_assembly(text)  # raises unless both builds (liftover, break-paf in one walk) are in the assembly
     assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not present")
+def test_compiler_stays_out_of_the_tile_kernels_ring():
+    """k_tile.hip (short records, one wave per tile of records): the same invisible ring, liftover and break-paf builds."""
+    text = check_ring.compile_to_asm(HIPCC, source="k_tile.hip")
+    bad = check_ring.check_assembly(text, 2, check_ring.RING, "rb_k_liftover_tile")
+    assert not bad, bad[:5]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not present")
+def test_compiler_stays_out_of_the_list_forms_ring():
+    """k_liftover_list.hip: the per-record kernel over the tile kernel's hand-backs; its ring sits at v88..v103 because the loop's spilled
+    scalar registers are parked at v80.. (this check found them there)."""
+    text = check_ring.compile_to_asm(HIPCC, source="k_liftover_list.hip")
+    bad = check_ring.check_assembly(text, 2, (88, 103))
+    assert not bad, bad[:5]

@@ -11,7 +11,7 @@ mkdir -p ../variants /tmp/rbvar_$name
 obj=${src%.hip}.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-value -Wno-unused-function -ffp-contract=off "$@" -c $src -o /tmp/rbvar_$name/$obj
 objs=""
-for o in capi.o k_records.o k_liftover.o k_misc.o k_trim.o k_text.o k_nucfreq.o; do
+for o in capi.o k_records.o k_liftover.o k_liftover_list.o k_tile.o k_misc.o k_trim.o k_text.o k_nucfreq.o; do
   if [ "$o" = "$obj" ]; then objs="$objs /tmp/rbvar_$name/$obj"; else objs="$objs $o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/$name.so $objs
