@@ -775,10 +775,17 @@ def main():
         from rustybam_amd import capi
         threads = os.cpu_count() or 1
 
+        def sample_idx(k):  # k records spread over the WHOLE batch (every n_rec // k-th one), not its first k
+            stride = max(1, n_rec // max(1, k))
+            return np.arange(0, n_rec, stride, dtype=np.int64)[:k]
+
         def sample(k):
-            so = wl.op_offsets(nops[:k])
-            sops = capi.synth_fill_ops_host(seed, first, so)
-            return pyoracle.Batch(sops, so, t_st[:k], t_en[:k], q_st[:k], q_en[:k], strand[:k], np.zeros(k, np.uint32))
+            idx = sample_idx(k)
+            so = wl.op_offsets(nops[idx])
+            sops = np.empty(int(so[-1]), np.uint32)
+            for j, r_ in enumerate(idx):  # (the generator is counter based: record r alone is record r of the batch)
+                sops[int(so[j]):int(so[j + 1])] = capi.synth_fill_ops_host(seed, first + int(r_), np.array([0, nops[r_]], np.uint64))
+            return pyoracle.Batch(sops, so, t_st[idx], t_en[idx], q_st[idx], q_en[idx], strand[idx], np.zeros(len(idx), np.uint32))
 
         def timed(sb_, nt):
             tb_ = time.perf_counter()
@@ -801,7 +808,7 @@ def main():
         best = min(runs, key=runs.get)
         cpu_s = runs[best]
         result["cpu_baseline"] = {"value": sample_ops / cpu_s, "unit": "CIGAR-ops/s", "cores": best, "kind": "port",
-                                  "sample": f"first {k} records of the same workload ({sample_ops} ops) x {len(w_st)} "
+                                  "sample": f"{k} records of the same workload, every {max(1, n_rec // max(1, k))}th of the batch ({sample_ops} ops) x {len(w_st)} "
                                             f"windows, per-base oracle (aligned_pairs expansion) with OpenMP over "
                                             f"records, {cpu_s:.1f} s; the fastest of the thread counts tried",
                                   "records_per_s": k / cpu_s, "host_cores": threads,
@@ -809,12 +816,17 @@ def main():
                                                  for nt, dt in sorted(runs.items())},
                                   "t8": {"value": sample_ops / runs[t8], "records_per_s": k / runs[t8], "cores": t8,
                                          "sample": "the same sample on the reference's default pool (-t 8, cli.rs:18-19)"}}
-        # parity of the sample at full size: GPU rows of records 0..k-1 vs the oracle, bit for bit
-        hit_off = d_ws[: 8 * (n_rec + 1)].view(torch.int64)
-        nrow = int(hit_off[k].item())
-        grows = d_rows[: nrow * 64].cpu().numpy().view(rustybam_amd.HIT_DT)
+        # parity of the sample at full size: the GPU's rows of the sampled records (one contig: canonical order is record order, the rows
+        # of record r are hit_off[r] .. hit_off[r + 1]) vs the oracle, bit for bit
+        idx = sample_idx(k)
+        hit_off_h = d_ws[: 8 * (n_rec + 1)].view(torch.int64).cpu().numpy()
+        sel_rows = np.concatenate([np.arange(hit_off_h[r_], hit_off_h[r_ + 1]) for r_ in idx]) if len(idx) else np.zeros(0, np.int64)
+        nrow = len(sel_rows)
+        d_sel = torch.from_numpy(sel_rows).to(dev)
+        grows = d_rows[: n_hits * 64].view(n_hits, 64)[d_sel].cpu().numpy().view(rustybam_amd.HIT_DT).reshape(-1)
         assert nrow == len(orows), f"sample parity: {nrow} GPU rows vs {len(orows)} oracle rows"
-        for key in ("rec", "win", "status", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
+        assert np.array_equal(grows["rec"].astype(np.int64), idx[orows["rec"].astype(np.int64)]), "sample parity: rec"
+        for key in ("win", "status", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
             ok = orows["status"] == 0 if key not in ("rec", "win", "status") else slice(None)
             assert np.array_equal(grows[key][ok].astype(np.uint64), orows[key][ok].astype(np.uint64)), f"sample parity: {key}"
         okrows = np.nonzero(orows["status"] == 0)[0]
@@ -823,7 +835,8 @@ def main():
             a = d_out[int(grows["out_off"][i]): int(grows["out_off"][i]) + int(grows["out_n"][i])].cpu().numpy().view(np.uint32)
             b = oops[int(orows["out_off"][i]): int(orows["out_off"][i]) + int(orows["out_n"][i])]
             assert np.array_equal(a, b), f"sample parity: cigar of row {i}"
-        result["parity_sample"] = f"ok: {nrow} rows of {k} records identical to the oracle, {len(pick)} cigars compared"
+        result["parity_sample"] = (f"ok: {nrow} rows of {k} records (every {max(1, n_rec // max(1, k))}th record of the batch) identical to the "
+                                   f"per-base oracle, {len(pick)} cigars compared")
         # ---- "also time the op-space CPU path on the full input" -- oracle/rb_opspace.c, a CPU port of the op-space
         #      formulation (no per-base expansion), OpenMP over records, on ALL records of rank 0's batch when the host has the
         #      memory for them (20 GB of ops + 25 GB of clipped CIGARs), else on a fifth of them.  Its rows for the sample above
@@ -843,10 +856,14 @@ def main():
                 os_runs[nt] = time.perf_counter() - tb_
                 assert got is not None, "the op-space baseline refused the synthetic records"
                 if nt == min(64, threads):
-                    srows = got[0][: len(orows)]
-                    for key in ("rec", "win", "status", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
-                        okm = orows["status"] == 0 if key not in ("rec", "win", "status") else slice(None)
-                        assert np.array_equal(srows[key][okm], orows[key][okm]), f"op-space baseline vs per-base oracle: {key}"
+                    # the port's rows of the sampled records (record order, the same row ranges) against the per-base oracle's
+                    in_os = sel_rows < (hit_off_h[k_os] if k_os < n_rec else len(got[0]))
+                    srows = got[0][sel_rows[in_os]]
+                    oro = orows[in_os]
+                    assert np.array_equal(srows["rec"].astype(np.int64), idx[oro["rec"].astype(np.int64)]), "op-space baseline vs per-base oracle: rec"
+                    for key in ("win", "status", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len", "out_n"):
+                        okm = oro["status"] == 0 if key not in ("rec", "win", "status") else slice(None)
+                        assert np.array_equal(srows[key][okm], oro[key][okm]), f"op-space baseline vs per-base oracle: {key}"
                     n_os_rows = len(got[0])
                     if k_os == n_rec:
                         # ---- parity on 100 % of the job: every GPU row against the op-space port's (which the sample above ties to the

@@ -171,7 +171,9 @@ typedef struct rb_counters { /* device-written job summary, 64 bytes */
     uint64_t out_ops_used;       /* highest op index written + 1                                  */
     uint64_t n_generic;          /* hits routed to the generic kernel                             */
     uint32_t overflow;           /* != 0: rows or out_ops capacity exceeded, results incomplete   */
-    uint32_t phase[5];           /* diagnostics (debug_skip & 32): shader-clock sums per phase of the clip kernel, units of 16 cycles */
+    uint32_t phase[5];           /* diagnostics (debug_skip & 32): shader-clock sums per phase of the clip kernel, units of 16 cycles;
+                                    without debug_skip: phase[3] = tiles of short records the call ran (0: none), phase[4] = records of
+                                    those tiles that the tile kernel handed back to the per-record kernel (informational) */
     uint32_t brk_scratch_short;  /* RB_BREAK_ONE_WALK only: != 0: a scratch-row cursor ran out before the rows did; n_hits then asks for more */
     uint32_t redo_two_walk;      /* RB_BREAK_ONE_WALK only: != 0: the batch holds what the one-walk path does not take (irregular
                                     records, boundaries only the generic kernel resolves): results incomplete, call again without the flag */

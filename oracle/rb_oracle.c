@@ -745,6 +745,9 @@ int rbo_qpos_to_idx_match(const rbo_rec *r, uint64_t qpos, int right, int policy
     return 0;
 }
 
+/* paf.rs:984-998 update_cigar_opt_len: the same op with a new length (every arm of the match keeps the variant) */
+rbo_cig rbo_update_cigar_opt_len(rbo_cig op, uint32_t new_opt_len) { return ((rbo_cig)new_opt_len << 4) | (op & 15u); }
+
 /* paf.rs:593-620 subset_cigar + collapse_long_cigar */
 static void subset_collapse(const uint8_t *lc, size_t a, size_t b, rbo_cig **ops, size_t *n_ops) {
     size_t cap = 16, cnt = 0;
@@ -759,7 +762,7 @@ static void subset_collapse(const uint8_t *lc, size_t a, size_t b, rbo_cig **ops
                 cap *= 2;
                 v = (rbo_cig *)xrealloc(v, cap * sizeof(rbo_cig));
             }
-            v[cnt++] = ((rbo_cig)pre_len << 4) | pre;
+            v[cnt++] = rbo_update_cigar_opt_len(pre, pre_len); /* paf.rs:612 */
             pre = lc[i];
             pre_len = 1;
         }
@@ -768,7 +771,7 @@ static void subset_collapse(const uint8_t *lc, size_t a, size_t b, rbo_cig **ops
         cap += 1;
         v = (rbo_cig *)xrealloc(v, cap * sizeof(rbo_cig));
     }
-    v[cnt++] = ((rbo_cig)pre_len << 4) | pre;
+    v[cnt++] = rbo_update_cigar_opt_len(pre, pre_len); /* paf.rs:618 */
     *ops = v;
     *n_ops = cnt;
 }

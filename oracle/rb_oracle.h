@@ -128,6 +128,7 @@ void rbo_region_default_id(rbo_region *r);
 int rbo_consumes_reference(rbo_cig op);
 int rbo_consumes_query(rbo_cig op);
 int rbo_is_match(rbo_cig op);
+rbo_cig rbo_update_cigar_opt_len(rbo_cig op, uint32_t new_opt_len); /* paf.rs:984-998 */
 int rbo_infer_n_bases(const rbo_rec *r, uint64_t out4[4]);       /* paf.rs:631-654 */
 int rbo_check_integrity(rbo_rec *r);                             /* paf.rs:825-857 */
 int rbo_remove_trailing_indels(rbo_rec *r);                      /* paf.rs:656-783 */

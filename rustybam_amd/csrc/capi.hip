@@ -231,8 +231,8 @@ struct rb_plan {
     uint32_t *sched = nullptr, *slot_of = nullptr, *canon_pos = nullptr, *w_orig = nullptr, *ident = nullptr;
     uint64_t *w_st = nullptr, *w_en = nullptr, *wo_st = nullptr, *wo_en = nullptr, *cw_off = nullptr;
     uint8_t *cw_mono = nullptr;
-    // short records (k_tile.hip): tiles of consecutive records, two words each {first record | passthrough << 31, records}; the schedule's
-    // slots [0, stream_end) hold the records longer than the tiles take (it is sorted by length)
+    // short records (k_tile.hip): tiles of consecutive records, three words each {first record | passthrough << 31, records, schedule slot of
+    // the first record}; the schedule's slots [0, stream_end) hold the records longer than the tiles take, longest first, the others follow in memory order
     uint32_t *tiles = nullptr;
     uint32_t n_tiles = 0, stream_end = 0;
 };
@@ -747,10 +747,28 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
                 cnt++, ops += n;
             }
             close();
-            if (n_tiled == 0) tiles.clear(); // (nothing for the tile kernel: the schedule stays whole)
-            else pl->stream_end = (uint32_t)n_long;
+            if (n_tiled == 0) {
+                tiles.clear(); // (nothing for the tile kernel: the schedule stays whole)
+            } else {
+                // The schedule's slots [0, n_long) keep the long records, longest first; behind them the short ones follow in MEMORY
+                // order: their slots are never launched as waves of their own, they are where the records' jobs lie -- a tile's jobs then
+                // lie side by side (one coalesced read instead of a gather through slot_of), rb_k_make_jobs writes them side by side
+                pl->stream_end = (uint32_t)n_long;
+                std::vector<uint32_t> s2(n_rec);
+                uint64_t a = 0, b = n_long;
+                for (uint64_t w = 0; w < n_rec; w++)
+                    if (op_off[(uint64_t)sched[w] + 1] - op_off[sched[w]] > short_max) s2[a++] = sched[w];
+                std::vector<uint32_t> slot_short(n_rec, 0);
+                for (uint64_t r = 0; r < n_rec; r++)
+                    if (op_off[r + 1] - op_off[r] <= short_max) slot_short[r] = (uint32_t)b, s2[b++] = (uint32_t)r;
+                sched.swap(s2);
+                std::vector<uint32_t> t3;
+                t3.reserve(tiles.size() / 2 * 3);
+                for (size_t t = 0; t + 1 < tiles.size(); t += 2) t3.push_back(tiles[t]), t3.push_back(tiles[t + 1]), t3.push_back(slot_short[tiles[t] & 0x7FFFFFFFu]);
+                tiles.swap(t3);
+            }
         }
-        pl->n_tiles = (uint32_t)(tiles.size() / 2);
+        pl->n_tiles = (uint32_t)(tiles.size() / 3);
     }
     int rc = RB_OK;
     std::vector<uint32_t> slot_of(n_rec);

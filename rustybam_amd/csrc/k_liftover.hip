@@ -2026,6 +2026,10 @@ __global__ __launch_bounds__(64) void rb_k_finish(rb_lift_params p) {
     // what makes the job fit: the slots the window lists ask for, plus every arena as large as the fullest one got
     p.counters->out_ops_needed = p.needed_base + (mx + 3ull) / 4ull * 4ull * p.n_arena + 1024ull * p.n_arena;
     if (p.counters->n_hits > p.rows_cap) p.counters->overflow = 1;
+    if (p.n_tiles && !p.debug_skip) { // (the diagnostics words, outside the diagnostics builds: how the short records went)
+        p.counters->phase[3] = p.n_tiles;
+        p.counters->phase[4] = (uint32_t)*p.fb_count; // records the tile kernel handed to the per-record kernel
+    }
     if (p.brk_mode && p.counters->brk_scratch_short) { // one of the scratch-row cursors ran out before the rows did: ask for a quarter more
         p.counters->overflow = 1;
         const uint64_t have = p.counters->n_hits > p.rows_cap ? p.counters->n_hits : p.rows_cap;

@@ -85,8 +85,9 @@ __device__ __forceinline__ void rb_tile_body() {
     uint32_t *cpR = cp_all[wib][0], *cpQ = cp_all[wib][1], *cpU = cp_all[wib][2];
     uint8_t *bq_s = reinterpret_cast<uint8_t *>(bq_all[wib]);
     uint32_t *hr_s = hr_all[wib];
-    uint32_t ra = rb_first(p.tile_first[2u * tile]);
-    const uint32_t nrec = rb_first(p.tile_first[2u * tile + 1u]);
+    uint32_t ra = rb_first(p.tile_first[3u * tile]);
+    const uint32_t nrec = rb_first(p.tile_first[3u * tile + 1u]);
+    const uint32_t slot0 = rb_first(p.tile_first[3u * tile + 2u]); // (the jobs of a tile's records lie side by side)
     const bool passthrough = (ra >> 31) != 0u;
     ra &= 0x7FFFFFFFu;
     // the tile goes to the per-record kernel as it is
@@ -109,7 +110,7 @@ __device__ __forceinline__ void rb_tile_body() {
     // ---- set-up, lane j = record ra + j ----
     const bool isrec = (uint32_t)lane < nrec;
     const uint32_t r = ra + (isrec ? (uint32_t)lane : 0u);
-    const uint32_t slot = p.slot_of[r];
+    const uint32_t slot = slot0 + (isrec ? (uint32_t)lane : 0u);
     const uint64_t oo0 = p.op_off[r], oo1 = p.op_off[r + 1];
     uint32_t jflags, jn, jnh, jlo, jh0;
     uint64_t jrec0, t_st, t_en;
@@ -148,6 +149,35 @@ __device__ __forceinline__ void rb_tile_body() {
     }
     const uint32_t head = (uint32_t)(g_first - g0);
     const uint32_t rel0 = isrec ? (uint32_t)(jrec0 - g0) : 0u; // the record's first op, counted from g0
+    const uint32_t *__restrict__ gbase0 = p.ops + g0;
+    const uint32_t first_boff = head * 4u;
+    const uint32_t last_boff = (uint32_t)(((gend - 1u) & ~3ull) - g0) * 4u;
+    const uint32_t last_cboff = last_boff & ~31u;
+    unsigned long long sv_exec;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(sv_exec));
+    const uint32_t lane_boff = (uint32_t)lane * 32u;
+#define RBT_RING_LOAD_ASM(A, B_, C_, D_)                                                                                        \
+    asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
+                 "global_load_dwordx4 " RBT_RREG(A, 3) ", %[o], %[sb]\n\t"                                                      \
+                 "global_load_dwordx4 " RBT_RREG(C_, 3) ", %[o], %[sb] offset:16\n\t"                                           \
+                 "s_mov_b64 exec, %[sv]"                                                                                        \
+                 :                                                                                                              \
+                 : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
+                 : "memory", RBT_RING_TOP);
+#define RBT_RING_LOAD(RING, STP)                                                                                                \
+    {                                                                                                                           \
+        const uint32_t stp_ = (STP);                                                                                            \
+        uint32_t lo_ = (stp_ << 11) + lane_boff;                                                                                \
+        lo_ = lo_ < last_cboff ? lo_ : last_cboff;                                                                              \
+        const uint32_t *const gb_ = gbase0;                                                                                     \
+        const unsigned long long sv_ = sv_exec;                                                                                 \
+        const unsigned long long lm_ = stp_ < n_steps ? sv_ : 0ull;                                                             \
+        RBT_RING_CASE(RING, RBT_RING_LOAD_ASM)                                                                                  \
+    }
+#define RBT_RING_NOSTORES                                                                                                       \
+    _Pragma("unroll") for (int q_ = 0; q_ < 2 * RB_MS; q_++)                                                                    \
+        asm volatile("s_mov_b64 exec, 0\n\tglobal_store_dword %0, %0, %1\n\ts_mov_b64 exec, %2" ::"v"(0u), "s"(gbase0), "s"(sv_exec) : "memory");
+
     // hits of the tile, one lane each: the records' hits one behind the other
     const uint32_t nhj = (!BRK && active) ? jnh : 0u;
     const uint32_t hb_incl = rb_wave_scan_incl(nhj);
@@ -157,6 +187,11 @@ __device__ __forceinline__ void rb_tile_body() {
         fallback();
         return;
     }
+    // the ring's first loads go out HERE, in front of the window loads of the hits (a dependent trip of their own), not behind them
+    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the ring's wait counts count from here
+    RBT_RING_LOAD(0, 0u)
+    { RBT_RING_NOSTORES }
+    RBT_RING_LOAD(1, 1u)
     // Dst / Den: the hit's boundaries as offsets in the tile's running reference total, D = (offset of the boundary base) + 1 as in
     // rb_k_liftover_stream; hmeta = record (tile-local) | ordinal of the hit in its record << 8
     uint32_t Dst = 0xFFFFFFFFu, Den = 0xFFFFFFFFu, hmeta = 0u;
@@ -191,41 +226,11 @@ __device__ __forceinline__ void rb_tile_body() {
     for (uint32_t k = (uint32_t)lane; k < RBT_CP / 4; k += 64u) bq_all[wib][k] = 0x08080808u;
     if (isrec && lane != 0) bq_s[rel0 >> 3] = (uint8_t)(rel0 & 7u);
 
-    const uint32_t *__restrict__ gbase0 = p.ops + g0;
-    const uint32_t first_boff = head * 4u;
-    const uint32_t last_boff = (uint32_t)(((gend - 1u) & ~3ull) - g0) * 4u;
-    const uint32_t last_cboff = last_boff & ~31u;
     uint32_t *const out_ops_ = p.out_ops;
     const uint64_t slot_stride_ = p.slot_stride;
     const uint32_t brk_max_ = BRK ? p.brk_max : 0u;
     const uint64_t slot_row0 = 32ull * ra + g0; // out_ops index of coordinate 0 (counted from g0) in slot 0: the lines of the tile's first record
     const bool spec = n_slots != 0u && !desc_mode && (BRK || H != 0u);
-    unsigned long long sv_exec;
-    asm volatile("s_mov_b64 %0, exec" : "=s"(sv_exec));
-    const uint32_t lane_boff = (uint32_t)lane * 32u;
-
-#define RBT_RING_LOAD_ASM(A, B_, C_, D_)                                                                                        \
-    asm volatile("s_mov_b64 exec, %[lm]\n\t"                                                                                    \
-                 "global_load_dwordx4 " RBT_RREG(A, 3) ", %[o], %[sb]\n\t"                                                      \
-                 "global_load_dwordx4 " RBT_RREG(C_, 3) ", %[o], %[sb] offset:16\n\t"                                           \
-                 "s_mov_b64 exec, %[sv]"                                                                                        \
-                 :                                                                                                              \
-                 : [o] "v"(lo_), [sb] "s"(gb_), [lm] "s"(lm_), [sv] "s"(sv_)                                                    \
-                 : "memory", RBT_RING_TOP);
-#define RBT_RING_LOAD(RING, STP)                                                                                                \
-    {                                                                                                                           \
-        const uint32_t stp_ = (STP);                                                                                            \
-        uint32_t lo_ = (stp_ << 11) + lane_boff;                                                                                \
-        lo_ = lo_ < last_cboff ? lo_ : last_cboff;                                                                              \
-        const uint32_t *const gb_ = gbase0;                                                                                     \
-        const unsigned long long sv_ = sv_exec;                                                                                 \
-        const unsigned long long lm_ = stp_ < n_steps ? sv_ : 0ull;                                                             \
-        RBT_RING_CASE(RING, RBT_RING_LOAD_ASM)                                                                                  \
-    }
-#define RBT_RING_NOSTORES                                                                                                       \
-    _Pragma("unroll") for (int q_ = 0; q_ < 2 * RB_MS; q_++)                                                                    \
-        asm volatile("s_mov_b64 exec, 0\n\tglobal_store_dword %0, %0, %1\n\ts_mov_b64 exec, %2" ::"v"(0u), "s"(gbase0), "s"(sv_exec) : "memory");
-
     // ---- the stream ----
     uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals of the tile
     uint32_t v_reg = 0xFFFFFFFFu, v_minw = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_maxsu = 0u, v_carry = 0xFu;
@@ -270,10 +275,6 @@ __device__ __forceinline__ void rb_tile_body() {
 #pragma unroll
     for (int q = 0; q < RB_MS; q++) clip_fetch(q);
 
-    __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the ring's wait counts below count from here
-    RBT_RING_LOAD(0, 0u)
-    { RBT_RING_NOSTORES }
-    RBT_RING_LOAD(1, 1u)
     auto step = [&](auto ring_c, auto edge_c, const uint32_t st) {
         constexpr int ring = decltype(ring_c)::value;
         constexpr bool edge = decltype(edge_c)::value;
@@ -318,9 +319,11 @@ __device__ __forceinline__ void rb_tile_body() {
             }
         }
         uint32_t sr = 0, sq = 0, su = 0;
+        [[maybe_unused]] uint32_t rpre[8]; // break-paf: the reference bases of my ops in front of op q (the partial sums, kept)
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t len = rb_len(w[q]);
+            rpre[q] = sr;
             sr += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFDFFFDu, w[q], 1u); // ref = not I
             sq += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFF3FFF3u, w[q], 1u); // query = not D, not N
             su += len;
@@ -341,25 +344,25 @@ __device__ __forceinline__ void rb_tile_body() {
         if constexpr (BRK) {
             // events of this step in op order, wave-uniform: a record starts (the open piece of the record in front of it closes where
             // that record ends, the cut state begins anew), or an indel longer than brk_max cuts (liftover.rs:187-206)
-            bool lane_big = false;
+            // (per lane a mask of the ops that are events; the wave then visits the event ops only: a step has one or two)
+            uint32_t evm = bqv < 8u ? 1u << bqv : 0u;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const uint32_t cq = w[q] & 15u;
-                lane_big |= (cq == RB_OP_I || cq == RB_OP_D) && rb_len(w[q]) > brk_max_;
+                evm |= ((cq == RB_OP_I || cq == RB_OP_D) && rb_len(w[q]) > brk_max_) ? 1u << q : 0u;
             }
-            unsigned long long cm = rb_ballot(lane_big || bqv < 8u);
+            unsigned long long cm = rb_ballot(evm != 0u);
             const bool had = cm != 0ull;
             const uint32_t lane_r0 = R0 + ir - sr;
             while (cm) {
                 const int l = __builtin_ctzll(cm);
                 cm &= cm - 1ull;
-                uint32_t rx = rb_readlane<uint32_t>(lane_r0, l);
+                const uint32_t r0l = rb_readlane<uint32_t>(lane_r0, l), ml = rb_readlane<uint32_t>(evm, l);
                 const uint32_t bql = rb_readlane<uint32_t>(bqv, l);
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
-                    const uint32_t wq = rb_readlane<uint32_t>(w[q], l);
-                    const uint32_t cq = wq & 15u, lq = rb_len(wq);
-                    const uint32_t rlq = cq == RB_OP_I ? 0u : lq;
+                    if (!(ml & (1u << q))) continue;
+                    const uint32_t rx = r0l + rb_readlane<uint32_t>(rpre[q], l);
                     if (bql == (uint32_t)q) { // the next record starts here
                         brk_close(rx);
                         rcnt = rb_writelane((brk_cnt - brk_p0), cur, rcnt);
@@ -368,12 +371,13 @@ __device__ __forceinline__ void rb_tile_body() {
                         rp0 = rb_writelane(brk_cnt, cur, rp0);
                         brk_open();
                     }
+                    const uint32_t wq = rb_readlane<uint32_t>(w[q], l);
+                    const uint32_t cq = wq & 15u, lq = rb_len(wq);
                     if ((cq == RB_OP_I || cq == RB_OP_D) && lq > brk_max_) {
                         brk_close(rx);
-                        brk_pre = rx + rlq; // :203-206
+                        brk_pre = rx + (cq == RB_OP_I ? 0u : lq); // :203-206
                         brk_open();
                     }
-                    rx += rlq;
                 }
             }
             if (had) {
@@ -541,7 +545,7 @@ __device__ __forceinline__ void rb_tile_body() {
     uint32_t win = jl;
     const uint32_t rec_nm = fused ? hTR + hTQ - hTU : 0u, rec_al = fused ? hTU : 0u;
     if (ish) {
-        const rb_job *jp = &p.jobs[p.slot_of[hr]];
+        const rb_job *jp = &p.jobs[slot0 + hj];
         const uint64_t jt_st = jp->t_st, jt_en = jp->t_en, jq_st = jp->q_st, jq_en = jp->q_en;
         const bool minus = (jp->flags & RB_JOB_MINUS) != 0u;
         h0r = jp->h0;

@@ -109,7 +109,7 @@ struct rb_lift_params {
     // tile_first[t]: a run of records too small for a tile, handed to the per-record kernel as they are).  A tile the tile kernel does
     // not take (a record that is not regular or was stripped, too many hits, a record its verification does not pass, ...) lists its
     // records in fb_list; the per-record kernel then runs over that list (rb_k_liftover_stream_list).
-    const uint32_t *tile_first;    // [2 n_tiles]: {first record | pass-through << 31, records}
+    const uint32_t *tile_first;    // [3 n_tiles]: {first record | pass-through << 31, records, schedule slot of the first record (the others follow)}
     uint32_t n_tiles;
     uint32_t *fb_list;             // [n_rec]
     unsigned long long *fb_count;

@@ -360,7 +360,11 @@ def test_full_size_break_paf_integrity(oracle):
         avail_gb = int([ln for ln in open("/proc/meminfo") if ln.startswith("MemAvailable")][0].split()[1]) / 1e6
     except Exception:
         avail_gb = 0.0
-    if avail_gb >= 60 * n_rec / 1e6 + 8:
+    if avail_gb < 60 * n_rec / 1e6 + 8:  # (loudly: the property checks above have passed, the comparison of all pieces has NOT run)
+        eng.close()
+        pytest.skip(f"host has {avail_gb:.0f} GB available: the integrity properties of all {rows.shape[0]} pieces hold, but the comparison "
+                    f"with the op-space port on all {n_rec} records needs {60 * n_rec / 1e6 + 8:.0f} GB and did not run")
+    if True:
         from rustybam_amd import capi
         H = C["host"]
         n = rows.shape[0]

@@ -285,3 +285,30 @@ def test_ka16_ka17_target_region_and_parse_region(oracle, ka, tmp_path):
         r = Rg()
         assert oracle.lib().rbo_parse_region(text.encode(), C.byref(r)) == 0
         assert (r.name.decode(), r.st, r.en) == (name, st, en)
+
+
+def test_ka18_ka19_doctest_inputs_without_an_assert_of_their_own(oracle, ka):
+    """The two doctest inputs of src/paf.rs that no KA held so far (tests/golden/README.md, "doctest blocks"): PafRecord::new on a line of
+    the twelve mandatory columns without a tag must succeed (paf.rs:374: `.unwrap()`), and update_cigar_opt_len keeps the op and replaces
+    the length (paf.rs:981-982)."""
+    import ctypes as C
+    k = ka["KA18_new_without_tags"]
+
+    class Rec(C.Structure):  # rbo_rec (oracle/rb_oracle.h)
+        _fields_ = [("q_name", C.c_char_p), ("q_len", C.c_uint64), ("q_st", C.c_uint64), ("q_en", C.c_uint64), ("strand", C.c_char),
+                    ("t_name", C.c_char_p), ("t_len", C.c_uint64), ("t_st", C.c_uint64), ("t_en", C.c_uint64), ("nmatch", C.c_uint64),
+                    ("aln_len", C.c_uint64), ("mapq", C.c_uint64), ("cigar", C.c_void_p), ("n_cigar", C.c_size_t), ("id", C.c_char_p),
+                    ("tpos_aln", C.c_void_p), ("qpos_aln", C.c_void_p), ("long_cigar", C.c_void_p), ("n_aln", C.c_size_t), ("contained", C.c_int)]
+    L = oracle.lib()
+    rec = Rec()
+    L.rbo_rec_init(C.byref(rec))
+    assert L.rbo_rec_from_line(k["line"].encode(), C.byref(rec)) == 0
+    got = {"q_name": rec.q_name.decode(), "q_len": rec.q_len, "q_st": rec.q_st, "q_en": rec.q_en, "strand": rec.strand.decode(),
+           "t_name": rec.t_name.decode(), "t_len": rec.t_len, "t_st": rec.t_st, "t_en": rec.t_en, "nmatch": rec.nmatch, "aln_len": rec.aln_len,
+           "mapq": rec.mapq}
+    assert got == k["fields"] and rec.n_cigar == k["n_cigar"]
+    L.rbo_rec_free(C.byref(rec))
+    L.rbo_update_cigar_opt_len.restype = C.c_uint64
+    L.rbo_update_cigar_opt_len.argtypes = [C.c_uint64, C.c_uint32]
+    for before, new_len, after in ka["KA19_update_cigar_opt_len"]["cases"]:
+        assert int(L.rbo_update_cigar_opt_len(int(pack(before)[0]), new_len)) == int(pack(after)[0])

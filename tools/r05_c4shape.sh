@@ -34,7 +34,7 @@ for op in ("break", "liftover"):
     per = collections.defaultdict(dict)
     for f in sorted(glob.glob(f"{out}/sq_{op}/**/*counter_collection.csv", recursive=True)):
         for row in csv.DictReader(open(f)):
-            if "liftover_stream" in row["Kernel_Name"] or "rb_k_short" in row["Kernel_Name"]:
+            if "liftover_stream" in row["Kernel_Name"] or "liftover_tile" in row["Kernel_Name"]:
                 per[(f.split("/")[-1][0], row["Kernel_Name"][:40], row["Dispatch_Id"])][row["Counter_Name"]] = float(row["Counter_Value"])
     # the last dispatch of each file
     last = {}
