@@ -230,6 +230,23 @@ int rb_dev_free(rb_ctx *ctx, void *dev_ptr);
 /* which route a buffer of rb_dev_alloc took: 1 = 2 MB physical chunks, 0 = plain hipMalloc (a small request, or the fallback when the
  * chunked route failed -- the two routes differ by 10-20 % in the clip kernel's time, so bench.py reports it) */
 int rb_dev_alloc_mode(rb_ctx *ctx, const void *dev_ptr);
+/* ADDRESS SPACE.  A chunked buffer that is FREED gives its memory back, not its virtual range: on this ROCm a kernel's stores into a range
+ * the process had mapped before went to the OLD physical pages (tools/alloc_probe2.py), so rb_dev_free retires the range for the life of
+ * the process.  A host that allocates and frees 40-75 GB batches therefore spends that much address space per batch; the library counts it
+ * and stops using the chunked route (plain hipMalloc instead: slower pages, rb_dev_alloc_mode says 0) once live + retired ranges reach
+ * RB_ALLOC_VA_CAP_GB (default 32768 = 32 TB of the 128 TB a process has).  The way around it is not to free:
+ *   rb_dev_release     gives a buffer back to the CONTEXT: it stays mapped, keeps its physical pages (and so what rb_dev_alloc_placed
+ *                      chose them for), and the next rb_dev_alloc / rb_dev_alloc_placed[_by] of exactly the same size on this context
+ *                      returns it -- no address space retired, no 14 us per chunk, no placement measured again (a released PLACED
+ *                      buffer satisfies rb_dev_alloc_placed[_by] at once: *kept = -1, no score).  Buffers below 1 MB are simply freed.
+ *                      The context's stream is synchronised; work on other streams must be finished.  At most RB_ALLOC_CACHE_GB
+ *                      (default 96) gigabytes are held, the oldest are freed first; rb_ctx_destroy frees what is held.
+ *   rb_dev_cache_trim  frees held buffers, oldest first, until at most keep_bytes remain.
+ *   rb_dev_alloc_stats out[0] live chunked bytes (process), out[1] bytes this context holds for reuse, out[2] retired address space
+ *                      (process), out[3] the cap on out[0] + out[2], out[4] requests of this context that fell back to plain hipMalloc. */
+int rb_dev_release(rb_ctx *ctx, void *dev_ptr);
+int rb_dev_cache_trim(rb_ctx *ctx, uint64_t keep_bytes);
+int rb_dev_alloc_stats(rb_ctx *ctx, uint64_t out[5]);
 /* Transfers of 8 MB and more go through the context's pinned staging ring (two page-locked 32 MB chunks, hipHostMalloc): the
  * host side of a chunk is copied on several host threads while the DMA of the other chunk runs, so pageable caller memory moves
  * at the link's rate and host_src may be reused as soon as rb_dev_upload returns (the DMAs are queued on the context's stream).

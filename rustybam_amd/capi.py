@@ -232,6 +232,19 @@ class Engine:
     def dev_free(self, ptr):
         self._chk(self.L.rb_dev_free(self.ctx, C.c_void_p(ptr)), "rb_dev_free")
 
+    def dev_release(self, ptr):
+        """back to the context's cache: still mapped, handed out again by the next dev_alloc / dev_alloc_placed of the same size"""
+        self._chk(self.L.rb_dev_release(self.ctx, C.c_void_p(ptr)), "rb_dev_release")
+
+    def dev_cache_trim(self, keep_bytes=0):
+        self._chk(self.L.rb_dev_cache_trim(self.ctx, C.c_uint64(keep_bytes)), "rb_dev_cache_trim")
+
+    def dev_alloc_stats(self):
+        """-> dict(live, cached, retired_va, va_cap, fallbacks): rb_dev_alloc_stats"""
+        o = (C.c_uint64 * 5)()
+        self._chk(self.L.rb_dev_alloc_stats(self.ctx, o), "rb_dev_alloc_stats")
+        return dict(live=int(o[0]), cached=int(o[1]), retired_va=int(o[2]), va_cap=int(o[3]), fallbacks=int(o[4]))
+
     def text_scratch_bytes(self, n):
         f = self.L.rb_text_scratch_bytes
         f.restype = C.c_size_t
@@ -499,4 +512,11 @@ class DevBuf:
         if self.ptr:
             self.t = None
             self.eng.dev_free(self.ptr)
+            self.ptr = 0
+
+    def release(self):
+        """give the buffer back to the context (rb_dev_release): it stays mapped and keeps its pages for the next DevBuf of this size"""
+        if self.ptr:
+            self.t = None
+            self.eng.dev_release(self.ptr)
             self.ptr = 0

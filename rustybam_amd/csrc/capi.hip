@@ -218,6 +218,11 @@ struct rb_ctx {
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
     uint64_t alloc_fallbacks = 0; // rb_dev_alloc requests that wanted the chunked route and got plain hipMalloc
+    // buffers given back with rb_dev_release: still mapped (a chunked buffer keeps its physical pages, hence its placement), handed out
+    // again by the next rb_dev_alloc / rb_dev_alloc_placed of the same size on this context
+    struct cached_buf { void *p; size_t bytes; bool placed; };
+    std::vector<cached_buf> cache;
+    size_t cache_bytes = 0;
 };
 #define RB_PIN_CHUNK ((size_t)32 << 20)
 #define RB_PIN_MIN ((size_t)8 << 20) // (round 3: smaller transfers took the runtime's own pageable path; round 4: nothing does, rb_dev_upload says why)
@@ -298,6 +303,7 @@ extern "C" void rb_ctx_destroy(rb_ctx *ctx) {
     }
     if (ctx->trim_scratch) hipFree(ctx->trim_scratch);
     if (ctx->trim_pend) hipFree(ctx->trim_pend);
+    (void)rb_dev_cache_trim(ctx, 0);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -344,9 +350,21 @@ extern "C" int rb_ctx_get_timing(rb_ctx *ctx, double *ms_out, int cap, int *n_ou
 struct rb_vmm_alloc {
     size_t bytes, chunk;
     std::vector<hipMemGenericAllocationHandle_t> handles;
+    bool placed = false; // chosen among candidates by measurement (rb_dev_alloc_placed[_by])
 };
 static std::map<void *, rb_vmm_alloc> g_vmm;
 static std::mutex g_vmm_mu;
+// Virtual address space: a freed chunked buffer's range is never given back to the driver (rb_free_vmm says why), so every chunked
+// allocation that is FREED costs its size in address space for the life of the process.  Counted, and capped: beyond the cap (default
+// 32 TB of the 128 TB a process has, RB_ALLOC_VA_CAP_GB) the chunked route is refused and rb_dev_alloc falls back to plain hipMalloc
+// (rb_dev_alloc_mode / rb_dev_alloc_stats say so).  A host that recycles its buffers with rb_dev_release instead of rb_dev_free retires
+// nothing.
+static size_t g_va_live = 0, g_va_retired = 0; // (under g_vmm_mu)
+static std::map<void *, size_t> g_asked;        // (under g_vmm_mu) what rb_dev_alloc was asked for, rounded to 256: buffers of 1 MB and more (the ones rb_dev_release keeps)
+static size_t rb_va_cap() { // (read per call: tests move it)
+    const char *e = getenv("RB_ALLOC_VA_CAP_GB");
+    return (size_t)(e ? strtoull(e, nullptr, 10) : 32768ull) << 30;
+}
 // -> 0: not one of ours; 1: released; -1: a HIP call failed (*err names it; the pieces that could be given back have been)
 static int rb_free_vmm(void *p, int device, hipError_t *err) {
     std::lock_guard<std::mutex> lk(g_vmm_mu);
@@ -367,7 +385,9 @@ static int rb_free_vmm(void *p, int device, hipError_t *err) {
     // nothing that three different readers could see (tools/alloc_probe2.py: a 300 MB buffer taken right after a 1 GB one was freed;
     // copies, which do not go through the compute units' translation caches, read and wrote the new pages).  Addresses are not
     // scarce (a batch of 75 GB takes 2^-11 of the 47-bit range); memory is what is returned, chunk by chunk, above.
+    g_va_live -= it->second.bytes;
     if (getenv("RB_ALLOC_FREE_VA")) note(hipMemAddressFree(p, it->second.bytes)); // (the probe's switch)
+    else g_va_retired += it->second.bytes;
     g_vmm.erase(it);
     if (first != hipSuccess) (void)hipGetLastError();
     *err = first;
@@ -386,6 +406,10 @@ static void *rb_alloc_vmm(int device, size_t bytes, bool shuffle) {
     size_t chunk = (size_t)2 << 20;
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t n = (bytes + chunk - 1) / chunk;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        if (g_va_live + g_va_retired + n * chunk > rb_va_cap()) return nullptr; // (address space used up by freed buffers: the caller takes plain hipMalloc)
+    }
     void *va = nullptr;
     if (hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0) != hipSuccess || !va) return nullptr;
     std::vector<hipMemGenericAllocationHandle_t> h;
@@ -427,6 +451,7 @@ static void *rb_alloc_vmm(int device, size_t bytes, bool shuffle) {
     {
         std::lock_guard<std::mutex> lk(g_vmm_mu);
         g_vmm[va] = rb_vmm_alloc{n * chunk, chunk, h};
+        g_va_live += n * chunk;
     }
     return va;
 }
@@ -441,6 +466,13 @@ extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
     // 1 GB and more -- a resident batch and its outputs -- are built that way (about 14 us per chunk: 1 s for 75 GB, once per batch);
     // smaller ones, and everything under RB_ALLOC_MODE=default, come from hipMalloc.  RB_ALLOC_MODE=chunks / scatter (the chunks in
     // pseudo-random order: no different) / contiguous force a mode for the probe.
+    for (size_t k = 0; k < ctx->cache.size(); k++) // a buffer this context released, of this very size: as it is (still mapped, its pages its own)
+        if (ctx->cache[k].bytes == want) {
+            *dev_ptr = ctx->cache[k].p;
+            ctx->cache_bytes -= want;
+            ctx->cache.erase(ctx->cache.begin() + (long)k);
+            return RB_OK;
+        }
     const char *mode = getenv("RB_ALLOC_MODE");
     // (round 4: from 256 MB up, not 1 GB -- the row arena of the headline batch, 1.02e9 bytes, fell just short of the old threshold and sat
     //  in plain hipMalloc memory beside a chunked batch; RB_ALLOC_CHUNK_MIN_MB moves the threshold for experiments)
@@ -450,14 +482,25 @@ extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
         void *q = rb_alloc_vmm(ctx->device, want, mode && !strcmp(mode, "scatter"));
         if (q) {
             *dev_ptr = q;
+            std::lock_guard<std::mutex> lk(g_vmm_mu);
+            g_asked[q] = want;
             return RB_OK;
         }
         const hipError_t why = hipGetLastError();
         ctx->alloc_fallbacks++; // (rb_dev_alloc_mode tells the caller which route a buffer took: the two differ by 10-20 % in the clip kernel's time)
         if (getenv("RB_ALLOC_LOG")) fprintf(stderr, "[rb_dev_alloc] %zu bytes: the chunked route failed (%s), plain hipMalloc instead\n", want, hipGetErrorString(why));
     }
+    auto remember = [&]() {
+        if (want >= ((size_t)1 << 20)) {
+            std::lock_guard<std::mutex> lk(g_vmm_mu);
+            g_asked[*dev_ptr] = want;
+        }
+    };
     if (want >= ((size_t)64 << 20) && mode && !strcmp(mode, "contiguous")) {
-        if (hipExtMallocWithFlags(dev_ptr, want, hipDeviceMallocContiguous) == hipSuccess) return RB_OK;
+        if (hipExtMallocWithFlags(dev_ptr, want, hipDeviceMallocContiguous) == hipSuccess) {
+            remember();
+            return RB_OK;
+        }
         (void)hipGetLastError();
     }
     hipError_t e = hipMalloc(dev_ptr, want);
@@ -465,24 +508,87 @@ extern "C" int rb_dev_alloc(rb_ctx *ctx, size_t bytes, void **dev_ptr) {
         (void)hipGetLastError(); // reported through the return code: not left behind for the caller's next HIP call to trip over
         return fail(ctx, RB_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
     }
+    remember();
     return RB_OK;
 }
-// which route a buffer of rb_dev_alloc took: 1 = separately created 2 MB physical chunks, 0 = plain hipMalloc (a small request, a forced
-// mode, or the fallback when the chunked route failed), -1 = not a pointer rb_dev_alloc's chunked route knows (plain, or foreign)
+// which route a buffer of rb_dev_alloc took: 1 = separately created 2 MB physical chunks, 0 = anything else (plain hipMalloc: a small
+// request, a forced mode, the fallback when the chunked route failed or the address-space cap was reached; or a foreign pointer)
 extern "C" int rb_dev_alloc_mode(rb_ctx *ctx, const void *dev_ptr) {
     if (!ctx || !dev_ptr) return RB_E_INVALID;
     std::lock_guard<std::mutex> lk(g_vmm_mu);
     return g_vmm.count(const_cast<void *>(dev_ptr)) ? 1 : 0;
 }
+static size_t rb_buf_bytes(rb_ctx *, void *p, bool *placed) {
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    auto it = g_asked.find(p);
+    if (it == g_asked.end()) return 0;
+    auto iv = g_vmm.find(p);
+    *placed = iv != g_vmm.end() && iv->second.placed;
+    return it->second;
+}
 extern "C" int rb_dev_free(rb_ctx *ctx, void *dev_ptr) {
     if (!ctx) return RB_E_INVALID;
     if (!dev_ptr) return RB_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        g_asked.erase(dev_ptr);
+    }
     hipError_t e = hipSuccess;
     const int mine = rb_free_vmm(dev_ptr, ctx->device, &e);
     if (mine < 0) return fail(ctx, RB_E_HIP, "rb_dev_free (chunked buffer): %s", hipGetErrorString(e));
     if (mine > 0) return RB_OK;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipFree(dev_ptr));
+    return RB_OK;
+}
+// rb_dev_release: the buffer goes back to the CONTEXT, not to the device -- it stays mapped, a chunked buffer keeps its physical pages
+// (and with them what rb_dev_alloc_placed chose them for), and the next rb_dev_alloc / rb_dev_alloc_placed of exactly this size on this
+// context returns it.  No address space is retired and nothing is unmapped, so a host that allocates and releases the same shapes batch
+// after batch runs in constant address space and pays the 14 us per chunk once.  The cache holds at most RB_ALLOC_CACHE_GB (default
+// 96) gigabytes: what does not fit is freed (rb_dev_free).  The caller's work on the buffer must have been enqueued on the context's
+// stream (it is synchronised here) or be finished.
+static size_t rb_cache_cap() {
+    static const size_t v = [] { const char *e = getenv("RB_ALLOC_CACHE_GB"); return (size_t)(e ? strtoull(e, nullptr, 10) : 96ull) << 30; }();
+    return v;
+}
+extern "C" int rb_dev_release(rb_ctx *ctx, void *dev_ptr) {
+    if (!ctx) return RB_E_INVALID;
+    if (!dev_ptr) return RB_OK;
+    bool placed = false;
+    const size_t bytes = rb_buf_bytes(ctx, dev_ptr, &placed);
+    if (!bytes || bytes > rb_cache_cap()) return rb_dev_free(ctx, dev_ptr);
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    while (!ctx->cache.empty() && ctx->cache_bytes + bytes > rb_cache_cap()) { // the oldest go first
+        void *q = ctx->cache.front().p;
+        ctx->cache_bytes -= ctx->cache.front().bytes;
+        ctx->cache.erase(ctx->cache.begin());
+        const int rc = rb_dev_free(ctx, q);
+        if (rc) return rc;
+    }
+    ctx->cache.push_back({dev_ptr, bytes, placed});
+    ctx->cache_bytes += bytes;
+    return RB_OK;
+}
+// frees cached buffers, oldest first, until at most keep_bytes are held
+extern "C" int rb_dev_cache_trim(rb_ctx *ctx, uint64_t keep_bytes) {
+    if (!ctx) return RB_E_INVALID;
+    while (!ctx->cache.empty() && ctx->cache_bytes > keep_bytes) {
+        void *q = ctx->cache.front().p;
+        ctx->cache_bytes -= ctx->cache.front().bytes;
+        ctx->cache.erase(ctx->cache.begin());
+        const int rc = rb_dev_free(ctx, q);
+        if (rc) return rc;
+    }
+    return RB_OK;
+}
+// out[0] = bytes of live chunked buffers (this process), out[1] = bytes this context holds for reuse (rb_dev_release), out[2] = address
+// space retired by freed chunked buffers (this process; never returned: rb_free_vmm), out[3] = the cap on out[0] + out[2],
+// out[4] = rb_dev_alloc requests of this context that wanted the chunked route and got plain hipMalloc
+extern "C" int rb_dev_alloc_stats(rb_ctx *ctx, uint64_t out[5]) {
+    if (!ctx || !out) return RB_E_INVALID;
+    std::lock_guard<std::mutex> lk(g_vmm_mu);
+    out[0] = g_va_live, out[1] = ctx->cache_bytes, out[2] = g_va_retired, out[3] = rb_va_cap(), out[4] = ctx->alloc_fallbacks;
     return RB_OK;
 }
 static bool pin_ready(rb_ctx *ctx) {
@@ -796,7 +902,7 @@ extern "C" void rb_plan_destroy(rb_plan *pl) {
     if (!pl) return;
     void *ptrs[] = {pl->sched, pl->slot_of, pl->ident, pl->canon_pos, pl->w_st, pl->w_en, pl->w_orig, pl->wo_st, pl->wo_en, pl->cw_off, pl->cw_mono, pl->tiles};
     for (void *q : ptrs)
-        if (q) hipFree(q);
+        if (q) (void)rb_dev_free(pl->ctx, q); // (rb_dev_alloc memory: a large array is a chunked buffer, which hipFree does not know)
     delete pl;
 }
 
@@ -1301,7 +1407,7 @@ struct DevBatch {
     std::vector<void *> owned;
     explicit DevBatch(rb_ctx *c) : ctx(c) {}
     ~DevBatch() {
-        for (void *q : owned) hipFree(q);
+        for (void *q : owned) (void)rb_dev_free(ctx, q);
     }
     template <typename T>
     int up(const T *host, size_t n, const T **dev) {
@@ -1428,9 +1534,9 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
     uint32_t *d_out = nullptr;
     bool one_walk = is_break && !(policy & RB_LIFT_DESCRIPTORS) && !getenv("RB_BREAK_TWO_WALK"); // (the env: diagnostics)
     for (int attempt = 0; attempt < 6; attempt++) {
-        if (ws) hipFree(ws);
-        if (d_rows) hipFree(d_rows);
-        if (d_out) hipFree(d_out);
+        if (ws) (void)rb_dev_free(ctx, ws);
+        if (d_rows) (void)rb_dev_free(ctx, d_rows);
+        if (d_out) (void)rb_dev_free(ctx, d_out);
         ws = nullptr;
         d_rows = nullptr;
         d_out = nullptr;
@@ -1479,9 +1585,9 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
             if (!rc) rc = rb_dev_download(ctx, *rows, d_rows, (size_t)hc.n_hits * sizeof(rb_hit_row));
             *out_ops = (uint32_t *)malloc((size_t)(o + 1) * 4);
             if (!rc && o) rc = rb_dev_download(ctx, *out_ops, d_dense, (size_t)o * 4);
-            if (d_off) hipFree(d_off);
-            if (d_blk) hipFree(d_blk);
-            if (d_dense) hipFree(d_dense);
+            if (d_off) (void)rb_dev_free(ctx, d_off);
+            if (d_blk) (void)rb_dev_free(ctx, d_blk);
+            if (d_dense) (void)rb_dev_free(ctx, d_dense);
             for (uint64_t i = 0; i < hc.n_hits && !rc; i++) // (rows that carry no clip: the fields the reference has no value for)
                 if ((*rows)[i].status != RB_ST_OK) (*rows)[i].out_off = 0, (*rows)[i].out_n = 0;
         } else {
@@ -1491,9 +1597,9 @@ static int host_lift(rb_ctx *ctx, bool is_break, uint32_t max_size, uint64_t n_r
         if (counters) *counters = hc;
         rb_lap("D2H + compact", tl);
     }
-    if (ws) hipFree(ws);
-    if (d_rows) hipFree(d_rows);
-    if (d_out) hipFree(d_out);
+    if (ws) (void)rb_dev_free(ctx, ws);
+    if (d_rows) (void)rb_dev_free(ctx, d_rows);
+    if (d_out) (void)rb_dev_free(ctx, d_out);
     rb_plan_destroy(plan);
     if (rc) {
         free(*rows);
@@ -1694,9 +1800,9 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
     uint32_t *d_out = nullptr;
     bool one_walk = is_break && !(policy & RB_LIFT_DESCRIPTORS) && !getenv("RB_BREAK_TWO_WALK"); // (the env: diagnostics)
     for (int attempt = 0; attempt < 6; attempt++) {
-        if (ws) hipFree(ws);
-        if (d_rows) hipFree(d_rows);
-        if (d_out) hipFree(d_out);
+        if (ws) (void)rb_dev_free(ctx, ws);
+        if (d_rows) (void)rb_dev_free(ctx, d_rows);
+        if (d_out) (void)rb_dev_free(ctx, d_out);
         ws = nullptr, d_rows = nullptr, d_out = nullptr;
         rc = rb_dev_alloc(ctx, rb_plan_workspace_bytes(plan, rows_cap), &ws);
         if (!rc) rc = rb_dev_alloc(ctx, (rows_cap + 1) * sizeof(rb_hit_row), (void **)&d_rows);
@@ -1800,9 +1906,9 @@ static int host_lift_text(rb_ctx *ctx, bool is_break, uint32_t max_size, bool sc
         free(*row_text);
         *rows = nullptr, *row_text_off = nullptr, *row_text = nullptr;
     }
-    if (ws) hipFree(ws);
-    if (d_rows) hipFree(d_rows);
-    if (d_out) hipFree(d_out);
+    if (ws) (void)rb_dev_free(ctx, ws);
+    if (d_rows) (void)rb_dev_free(ctx, d_rows);
+    if (d_out) (void)rb_dev_free(ctx, d_out);
     rb_plan_destroy(plan);
     return rc;
 }
@@ -2037,6 +2143,16 @@ extern "C" int rb_dev_alloc_placed_by(rb_ctx *ctx, uint64_t bytes, int tries, do
     if (kept) *kept = -1;
     for (int i = 0; sweep_ms && i < tries; i++) sweep_ms[i] = -1.0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (tries > 1) { // a buffer of this size that this context placed before and released (rb_dev_release): as it is, nothing is measured again
+        const size_t want = bytes ? ((bytes + 255) & ~(size_t)255) : 256;
+        for (size_t k = 0; k < ctx->cache.size(); k++)
+            if (ctx->cache[k].bytes == want && ctx->cache[k].placed) {
+                *out = ctx->cache[k].p;
+                ctx->cache_bytes -= want;
+                ctx->cache.erase(ctx->cache.begin() + (long)k);
+                return RB_OK; // (*kept = -1, every score -1: no candidate was made)
+            }
+    }
     std::vector<void *> cand;
     std::vector<double> ms;
     int rc = RB_OK, best = -1;
@@ -2079,6 +2195,11 @@ extern "C" int rb_dev_alloc_placed_by(rb_ctx *ctx, uint64_t bytes, int tries, do
     if (rc != RB_OK) return rc;
     *out = cand[(size_t)best];
     if (kept) *kept = best;
+    if (cand.size() > 1) { // chosen by measurement: the context's cache keeps that in mind (rb_dev_release)
+        std::lock_guard<std::mutex> lk(g_vmm_mu);
+        auto it = g_vmm.find(*out);
+        if (it != g_vmm.end()) it->second.placed = true;
+    }
     return RB_OK;
 }
 

@@ -67,6 +67,13 @@
 #define RBT_STEP_VMEM (2 * RB_MS + 2) // vector-memory instructions a step issues, always
 #define RBT_RING_WAIT ((RBT_PF - 1) * RBT_STEP_VMEM)
 #define RBT_GRAN 16 // speculative stores are widened to whole 64-byte granules (liftover form)
+#ifndef RBT_STOP
+#define RBT_STOP 0 // diagnostics (tools/mkvariant.sh --src k_tile.hip -DRBT_STOP=n; wrong results, only the time is of interest): a tile ends
+                   // 1 behind its set-up, 2 behind its stream, 3 behind the resolution of its boundaries
+#endif
+#ifndef RBT_NOSTORE
+#define RBT_NOSTORE 0 // diagnostics: no speculative store moves anything (the read side alone)
+#endif
 
 typedef uint32_t rbt_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -187,6 +194,7 @@ __device__ __forceinline__ void rb_tile_body() {
         fallback();
         return;
     }
+    if (RBT_STOP == 1) return;
     // the ring's first loads go out HERE, in front of the window loads of the hits (a dependent trip of their own), not behind them
     __builtin_amdgcn_s_waitcnt(0x0F70); // vmcnt(0): the ring's wait counts count from here
     RBT_RING_LOAD(0, 0u)
@@ -422,6 +430,7 @@ __device__ __forceinline__ void rb_tile_body() {
                     m0 = q4 & keep0;
                     m1 = q4 & keep1;
                 }
+                if (RBT_NOSTORE) m0 = m1 = 0ull;
                 const uint32_t *sb = out_ops_ + slot_row0 + (uint64_t)q * slot_stride_;
 #define RBT_RING_STORE(A, B_, C_, D_)                                                                                           \
     asm volatile("s_mov_b64 exec, %[m0]\n\t"                                                                                    \
@@ -449,6 +458,7 @@ __device__ __forceinline__ void rb_tile_body() {
 #undef RBT_RING_LOAD
 #undef RBT_RING_LOAD_ASM
 #undef RBT_RING_NOSTORES
+    if (RBT_STOP == 2) return;
     kq = rb_kp_here(kp);
     if constexpr (BRK) { // what lies behind the last long indel of the last record (liftover.rs:213-224)
         brk_close(Rb);
@@ -535,6 +545,10 @@ __device__ __forceinline__ void rb_tile_body() {
     const rb_bres A = resolve1(Dst, std::true_type{});
     const rb_bres B = resolve1(Den, std::false_type{});
 
+    if (RBT_STOP == 3) {
+        if (ish && (A.st | B.st) == 0x7777u) p.counters->overflow = 1; // (keeps the resolution alive)
+        return;
+    }
     // ---- rows, lane h ----
     const uint32_t hr = ra + hj; // the record
     uint32_t status = RB_ST_OK, out_n = 0, a_op = 0;

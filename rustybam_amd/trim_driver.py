@@ -177,11 +177,14 @@ class ResidentTrim:
         self.grp_sorted = np.cumsum(np.r_[0, gs[1:] != gs[:-1]])
         self.passes, self.pairs_done, self.pairs_by_wave = 0, 0, 0
 
-    def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000, check_host=False):
+    def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000, check_host=False, fetch=True, events=None):
         """the passes of Paf::overlapping_paf_recs (paf.rs:286-288).  Everything of a pass runs on the device: the pair scan and the
         selection (rb_dev_trim_select), the split + clip of the chosen pairs in place (rb_dev_overlap_split, rb_dev_apply_pairs), the
         status check (rb_dev_trim_check); the host reads 64 bytes per pass.  check_host: also run the numpy restatement of the
-        selection (select_pairs) on the coordinates of every pass and compare (tests)."""
+        selection (select_pairs) on the coordinates of every pass and compare (tests).
+        fetch=False: the normalised rows stay on the device when the passes are done (fetch() brings them later: 64 bytes per record,
+        640 MB for config 4 -- a consumer that goes on on the device never needs them).  events: a list that receives, per pass,
+        (pairs, ms of the selection, ms of the pair kernels, ms of apply + check) from HIP events on the engine's stream."""
         torch, eng, dev = self.torch, self.eng, self.dev
         start = np.flatnonzero(np.r_[True, self.grp_sorted[1:] != self.grp_sorted[:-1]]) if self.n else np.zeros(0, np.int64)
         grp_off = np.r_[start, self.n].astype(np.uint64)
@@ -195,12 +198,18 @@ class ResidentTrim:
         d_pass = torch.zeros(64, dtype=torch.uint8, device=dev)
         d_scr = torch.zeros(eng.trim_select_scratch_bytes(n_groups), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
+        ev_log = []
         for _ in range(max_passes):
             if check_host:
                 norm = self.d_norm.cpu().numpy().view(capi.NORM_DT)[:self.n]
                 want = select_pairs(self.order, self.grp_sorted, norm["q_st"].astype(np.uint64), norm["q_en"].astype(np.uint64))
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if events is not None else None
+            if ev:
+                ev[0].record()
             eng.dev_trim_select(self.n, n_groups, d_order.data_ptr(), d_grp.data_ptr(), self.d_norm.data_ptr(), self.cursor, d_cont.data_ptr(),
                                 d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), d_pass.data_ptr(), d_scr.data_ptr())
+            if ev:
+                ev[1].record()
             eng.sync()
             ps = d_pass.cpu().numpy().view(capi.TRIM_PASS_DT)[0]
             k, deferred, end = int(ps["n_pairs"]), int(ps["n_deferred"]), int(ps["ops_end"])
@@ -218,8 +227,13 @@ class ResidentTrim:
                 eng.dev_overlap_split(self.view, self.d_norm.data_ptr(), k, d_l.data_ptr(), d_r.data_ptr(), d_po.data_ptr(), scores,
                                       policy | (0 if os.environ.get("RB_TRIM_COPY") else capi.TRIM_IN_PLACE),   # regular records are cut where they are
                                       d_rows.data_ptr(), self.d_ops.data_ptr())
+                if ev:
+                    ev[2].record()
                 eng.dev_apply_pairs(k, d_l.data_ptr(), d_r.data_ptr(), d_rows.data_ptr(), self.d_off.data_ptr(), self.d_norm.data_ptr())
                 eng.dev_trim_check(k, d_rows.data_ptr(), d_pass.data_ptr())
+                if ev:
+                    ev[3].record()
+                    ev_log.append((k, ev))
                 eng.sync()
                 bad = int(d_pass.cpu().numpy().view(capi.TRIM_PASS_DT)[0]["bad_status"])
                 if bad:
@@ -229,12 +243,23 @@ class ResidentTrim:
                 self.pairs_done += k
             if deferred > 0:
                 continue
-            norm = self.d_norm.cpu().numpy().view(capi.NORM_DT)[:self.n]
-            self.q_st, self.q_en = norm["q_st"].astype(np.uint64), norm["q_en"].astype(np.uint64)
-            self.cur_n = norm["n_ops"].astype(np.uint64)
-            self.contained = d_cont[:self.n].cpu().numpy().astype(bool)
+            self._d_cont = d_cont
+            if events is not None:
+                torch.cuda.synchronize()
+                for k_, e_ in ev_log:
+                    events.append((k_, e_[0].elapsed_time(e_[1]), e_[1].elapsed_time(e_[2]), e_[2].elapsed_time(e_[3])))
+            if fetch:
+                self.fetch()
             return self
         raise RuntimeError("trim-paf did not converge")
+
+    def fetch(self):
+        """the normalised rows and the contained flags of the finished passes, on the host (64 + 1 bytes per record)"""
+        norm = self.d_norm.cpu().numpy().view(capi.NORM_DT)[:self.n]
+        self.q_st, self.q_en = norm["q_st"].astype(np.uint64), norm["q_en"].astype(np.uint64)
+        self.cur_n = norm["n_ops"].astype(np.uint64)
+        self.contained = self._d_cont[:self.n].cpu().numpy().astype(bool)
+        return self
 
     def release(self):
         """give the ops arena back (after gather(): the dense copy is what goes on)"""

@@ -128,3 +128,105 @@ def test_placed_allocation_by_the_callers_own_measure(engine):
     with pytest.raises(ValueError):
         engine.dev_alloc_placed(size, 3, bad)
     assert free0 - torch.cuda.mem_get_info()[0] < 64 * MB
+
+
+def _pattern_check(engine, ptr, size, k):
+    """a kernel of the library writes the buffer's two ends and its middle; the copy engine reads them back"""
+    for at in (0, size // 2 // 4096 * 4096, size - 4 * MB):
+        assert engine.L.rb_dev_memset(engine.ctx, C.c_void_p(ptr + at), (k * 7 + 3) & 255, C.c_size_t(4 * MB)) == 0
+        back = np.zeros(4 * MB, np.uint8)
+        assert engine.L.rb_dev_download(engine.ctx, C.c_void_p(back.ctypes.data), C.c_void_p(ptr + at), C.c_size_t(4 * MB)) == 0
+        assert (back == ((k * 7 + 3) & 255)).all(), (k, at)
+
+
+def test_release_recycles_buffers_in_constant_address_space(engine):
+    """rb_dev_release: 300 rounds of a 1 GB buffer allocated, written by a kernel, read back and released -- the same mapping comes back
+    every time: no address space is retired, no memory moves, and what the kernel wrote is what a copy reads (every round)"""
+    torch = pytest.importorskip("torch")
+    size = (1 << 30) + 4096
+    engine.dev_cache_trim(0)
+    s0 = engine.dev_alloc_stats()
+    first = None
+    for k in range(300):
+        p = engine.dev_alloc(size)
+        first = first or p
+        assert p == first
+        if k % 10 == 0 or k == 299:
+            _pattern_check(engine, p, size, k)
+        else:
+            assert engine.L.rb_dev_memset(engine.ctx, C.c_void_p(p + (k % 200) * 4 * MB), k & 255, C.c_size_t(4 * MB)) == 0
+        engine.dev_release(p)
+    s1 = engine.dev_alloc_stats()
+    assert s1["retired_va"] == s0["retired_va"] and s1["cached"] == (size + 255) // 256 * 256
+    assert s1["live"] - s0["live"] <= size + 2 * MB
+    free_held = torch.cuda.mem_get_info()[0]
+    engine.dev_cache_trim(0)
+    s2 = engine.dev_alloc_stats()
+    assert s2["cached"] == 0 and s2["retired_va"] - s1["retired_va"] >= size and torch.cuda.mem_get_info()[0] - free_held >= size - 64 * MB
+
+
+def test_freed_buffers_retire_a_bounded_amount_of_address_space(engine):
+    """rb_dev_free retires the virtual range of a chunked buffer (a later mapping at the same addresses was seen to take stores into the
+    OLD pages): 300 rounds of 1 GB cost at most 300 x (1 GB + one chunk) of address space, counted by rb_dev_alloc_stats and far below
+    the cap; every round's kernel writes are what a copy reads back; the device's memory comes back every time."""
+    torch = pytest.importorskip("torch")
+    size = (1 << 30) + 4096
+    engine.dev_cache_trim(0)
+    s0 = engine.dev_alloc_stats()
+    free0 = torch.cuda.mem_get_info()[0]
+    seen = set()
+    for k in range(300):
+        p = engine.dev_alloc(size)
+        assert p not in seen
+        seen.add(p)
+        assert engine.L.rb_dev_alloc_mode(engine.ctx, C.c_void_p(p)) == 1
+        if k % 25 == 0 or k == 299:
+            _pattern_check(engine, p, size, k)
+        else:
+            assert engine.L.rb_dev_memset(engine.ctx, C.c_void_p(p), k & 255, C.c_size_t(2 * MB)) == 0
+            back = np.zeros(4096, np.uint8)
+            assert engine.L.rb_dev_download(engine.ctx, C.c_void_p(back.ctypes.data), C.c_void_p(p + MB), C.c_size_t(4096)) == 0 and (back == (k & 255)).all()
+        engine.dev_free(p)
+    s1 = engine.dev_alloc_stats()
+    grown = s1["retired_va"] - s0["retired_va"]
+    assert 300 * size <= grown <= 300 * (size + 2 * MB), grown
+    assert s1["live"] == s0["live"] and s1["live"] + s1["retired_va"] < s1["va_cap"] // 8
+    assert abs(free0 - torch.cuda.mem_get_info()[0]) <= 64 * MB
+
+
+def test_address_space_cap_falls_back_to_plain_memory(engine):
+    """beyond RB_ALLOC_VA_CAP_GB (live + retired ranges) the chunked route is refused: rb_dev_alloc still serves the request, from plain
+    hipMalloc, and says so"""
+    size = (1 << 30) + 4096
+    s0 = engine.dev_alloc_stats()
+    old = os.environ.get("RB_ALLOC_VA_CAP_GB")
+    os.environ["RB_ALLOC_VA_CAP_GB"] = str((s0["live"] + s0["retired_va"]) // (1 << 30) + 1)   # (room for less than one more gigabyte)
+    try:
+        p = engine.dev_alloc(size)
+        assert engine.L.rb_dev_alloc_mode(engine.ctx, C.c_void_p(p)) == 0
+        assert engine.dev_alloc_stats()["fallbacks"] == s0["fallbacks"] + 1
+        _pattern_check(engine, p, size, 5)
+        engine.dev_free(p)
+    finally:
+        if old is None:
+            del os.environ["RB_ALLOC_VA_CAP_GB"]
+        else:
+            os.environ["RB_ALLOC_VA_CAP_GB"] = old
+    p = engine.dev_alloc(size)
+    assert engine.L.rb_dev_alloc_mode(engine.ctx, C.c_void_p(p)) == 1
+    engine.dev_free(p)
+
+
+def test_a_released_placed_buffer_is_not_measured_again(engine):
+    size = (3 << 29) + 4096
+    engine.dev_cache_trim(0)
+    ptr, sweeps, kept = engine.dev_alloc_placed(size, 3)
+    assert kept >= 0 and len([s for s in sweeps if s > 0]) == 3
+    engine.dev_release(ptr)
+    ptr2, sweeps2, kept2 = engine.dev_alloc_placed(size, 3)
+    assert ptr2 == ptr and kept2 == -1 and all(s < 0 for s in sweeps2)
+    engine.dev_release(ptr2)
+    p3 = engine.dev_alloc(size)                       # (a plain request of the size takes it as well)
+    assert p3 == ptr
+    engine.dev_free(p3)
+    assert engine.dev_alloc_stats()["cached"] == 0

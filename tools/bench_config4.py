@@ -81,10 +81,13 @@ def main():
         torch.cuda.synchronize()
         print(json.dumps({"one_pass": True}))
         return
-    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN)
+    ev = []
+    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN, fetch=False, events=ev)  # (the batch goes on on the device: nothing of it is fetched inside the stage)
     torch.cuda.synchronize()
     t_trim = time.perf_counter() - t0
     eng.set_timing(False)
+    T.fetch()  # (the rows the checks below read: outside the stage)
+    k_sel, k_pair, k_apply = sum(e[1] for e in ev), sum(e[2] for e in ev), sum(e[3] for e in ev)
     # algorithmic bytes of the pair passes: every pair reads both of its records as they are at that pass (bounded by their original
     # lengths: counted from the ops in use), writes a 128-byte row and the two clipped records
     pairs = T.pairs_done
@@ -121,6 +124,14 @@ def main():
            "trim_roofline_moved_on_wall": {"bound": "hbm", "achieved": round(pair_bytes_moved / t_trim / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                            "frac": round(pair_bytes_moved / t_trim / 8e12, 4),
                                            "note": "the same time over the bytes the in-place route really moves (ops read + rows + two words per clip): the honest fraction"},
+           "trim_kernels_ms": {"selection": round(k_sel, 3), "pair_kernels": round(k_pair, 3), "apply_and_check": round(k_apply, 3),
+                               "per_pass": [[int(e[0]), round(e[1], 3), round(e[2], 3), round(e[3], 3)] for e in ev],
+                               "note": "HIP events on the engine's stream around every pass: pairs, ms of rb_dev_trim_select, of rb_dev_overlap_split "
+                                       "(the wave-per-pair kernel and its retries), of rb_dev_apply_pairs + rb_dev_trim_check"},
+           "trim_wall_over_kernels": round(t_trim * 1e3 / max(1e-9, k_sel + k_pair + k_apply), 2),
+           "trim_roofline_moved_on_pair_kernels": {"bound": "hbm", "achieved": round(pair_bytes_moved / max(1e-9, k_pair * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                                   "frac": round(pair_bytes_moved / max(1e-9, k_pair * 1e-3) / 8e12, 4),
+                                                   "note": "the bytes the in-place route moves over the pair kernels' own time (HIP events)"},
            "pairs_by_wave_kernel": T.pairs_by_wave,
            "break_pieces": int(rows.shape[0]), "break_wall_s": round(t_break, 4), "break_records_per_s_wall": n / t_break,
            "break_one_walk": not bool(cnt["redo_two_walk"]), "setup_s": round(gen, 2)}
