@@ -217,6 +217,7 @@ struct rb_ctx {
     void *pin[2] = {nullptr, nullptr};
     hipEvent_t pin_ev[2] = {nullptr, nullptr};
     bool pin_busy[2] = {false, false};
+    unsigned pin_next = 0; // the slot the next upload chunk takes
     uint64_t alloc_fallbacks = 0; // rb_dev_alloc requests that wanted the chunked route and got plain hipMalloc
     // buffers given back with rb_dev_release: still mapped (a chunked buffer keeps its physical pages, hence its placement), handed out
     // again by the next rb_dev_alloc / rb_dev_alloc_placed of the same size on this context
@@ -635,8 +636,10 @@ extern "C" int rb_dev_upload(rb_ctx *ctx, void *dev_dst, const void *host_src, s
     }
     // host_src is consumed chunk by chunk into page-locked memory; when the call returns the caller may reuse it, the DMAs are
     // queued on the context's stream
-    for (size_t off = 0, k = 0; off < bytes; off += RB_PIN_CHUNK, k++) {
-        const int slot = (int)(k & 1);
+    // (the slot cursor runs on ACROSS calls: two small uploads in a row take different slots, so the second does not wait for the DMA --
+    //  and whatever kernel was queued in front of it -- of the first)
+    for (size_t off = 0; off < bytes; off += RB_PIN_CHUNK) {
+        const int slot = (int)(ctx->pin_next++ & 1u);
         const size_t n = std::min(RB_PIN_CHUNK, bytes - off);
         if (ctx->pin_busy[slot]) HIPCHK(ctx, hipEventSynchronize(ctx->pin_ev[slot]));
         par_memcpy(ctx->pin[slot], (const char *)host_src + off, n);
@@ -715,10 +718,8 @@ static int upload_vec(rb_ctx *ctx, const std::vector<T> &v, T **dev) {
     int rc = rb_dev_alloc(ctx, v.size() * sizeof(T) + 16, (void **)dev);
     if (rc) return rc;
     if (!v.empty()) { // (through the context's page-locked chunks, like every host transfer of the library: rb_dev_upload says why)
-        rc = rb_dev_upload(ctx, *dev, v.data(), v.size() * sizeof(T));
+        rc = rb_dev_upload(ctx, *dev, v.data(), v.size() * sizeof(T)); // (the host vector is consumed when this returns; the DMA is queued)
         if (rc) return rc;
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) return fail(ctx, RB_E_HIP, "plan upload: %s", hipGetErrorString(e));
     }
     return RB_OK;
 }
@@ -891,6 +892,7 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
     if (!rc) rc = upload_vec(ctx, cw_off, &pl->cw_off);
     if (!rc) rc = upload_vec(ctx, mono, &pl->cw_mono);
     if (!rc && pl->n_tiles) rc = upload_vec(ctx, tiles, &pl->tiles);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RB_E_HIP, "plan upload: %s", hipGetErrorString(hipGetLastError())); // (once, for all of them)
     if (rc) {
         rb_plan_destroy(pl);
         return rc;

@@ -44,26 +44,35 @@
 #endif
 #define RBT_STR2(x) #x
 #define RBT_STR(x) RBT_STR2(x)
-#if RBT_RING_BASE == 64
+#ifndef RBT_PF
+#define RBT_PF 2 // steps of stream loads in flight per wave (2 KiB each): the ring is 8 RBT_PF registers
+#endif
+#ifndef RBT_SPILL_ROOM
+#define RBT_SPILL_ROOM 0 // registers between the compiler's allocation and the ring (it parks spilled scalar registers right behind its own)
+#endif
+#define RBT_RING_TOP_N (RBT_RING_BASE + 8 * RBT_PF - 1)
+#if RBT_RING_TOP_N == 79
 #define RBT_RING_TOP "v79"
-#elif RBT_RING_BASE == 72
+#elif RBT_RING_TOP_N == 87
 #define RBT_RING_TOP "v87"
-#elif RBT_RING_BASE == 80
+#elif RBT_RING_TOP_N == 95
 #define RBT_RING_TOP "v95"
-#elif RBT_RING_BASE == 88
+#elif RBT_RING_TOP_N == 103
 #define RBT_RING_TOP "v103"
-#elif RBT_RING_BASE == 96
+#elif RBT_RING_TOP_N == 111
 #define RBT_RING_TOP "v111"
-#elif RBT_RING_BASE == 112
+#elif RBT_RING_TOP_N == 119
+#define RBT_RING_TOP "v119"
+#elif RBT_RING_TOP_N == 127
 #define RBT_RING_TOP "v127"
 #else
-#error "RBT_RING_BASE: 64, 72, 80, 88, 96 or 112"
+#error "RBT_RING_BASE + 8 RBT_PF - 1: 79, 87, 95, 103, 111, 119 or 127"
 #endif
-// the load ring: two steps of 8 registers, outside the compiler's allocation (amdgpu_num_vgpr), named literally -- k_liftover.hip says why
+// the load ring: RBT_PF steps of 8 registers, outside the compiler's allocation (amdgpu_num_vgpr), named literally -- k_liftover.hip says why
 #define RBT_RREG(OFF, W) "v[" RBT_STR(RBT_RING_BASE) "+" #OFF ":" RBT_STR(RBT_RING_BASE) "+" #OFF "+" #W "]"
 #define RBT_RING_CASE(RING, M)                                                                                                  \
-    if constexpr ((RING) == 0) { M(0, 2, 4, 6) } else { M(8, 10, 12, 14) }
-#define RBT_PF 2
+    if constexpr ((RING) == 0) { M(0, 2, 4, 6) } else if constexpr ((RING) == 1) { M(8, 10, 12, 14) } else if constexpr ((RING) == 2) { M(16, 18, 20, 22) } else { M(24, 26, 28, 30) }
+static_assert(RBT_PF >= 2 && RBT_PF <= 4, "two to four steps in flight");
 #define RBT_STEP_VMEM (2 * RB_MS + 2) // vector-memory instructions a step issues, always
 #define RBT_RING_WAIT ((RBT_PF - 1) * RBT_STEP_VMEM)
 #define RBT_GRAN 16 // speculative stores are widened to whole 64-byte granules (liftover form)
@@ -200,6 +209,14 @@ __device__ __forceinline__ void rb_tile_body() {
     RBT_RING_LOAD(0, 0u)
     { RBT_RING_NOSTORES }
     RBT_RING_LOAD(1, 1u)
+#if RBT_PF >= 3
+    { RBT_RING_NOSTORES }
+    RBT_RING_LOAD(2, 2u)
+#endif
+#if RBT_PF >= 4
+    { RBT_RING_NOSTORES }
+    RBT_RING_LOAD(3, 3u)
+#endif
     // Dst / Den: the hit's boundaries as offsets in the tile's running reference total, D = (offset of the boundary base) + 1 as in
     // rb_k_liftover_stream; hmeta = record (tile-local) | ordinal of the hit in its record << 8
     uint32_t Dst = 0xFFFFFFFFu, Den = 0xFFFFFFFFu, hmeta = 0u;
@@ -682,7 +699,7 @@ __device__ __forceinline__ void rb_tile_body() {
 }
 
 #define RBT_KERNEL(NAME, BRK)                                                                                                     \
-    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RBT_WPE), amdgpu_num_vgpr(RBT_RING_BASE))) void NAME(rb_lift_params p_) { \
+    __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RBT_WPE), amdgpu_num_vgpr(RBT_RING_BASE - RBT_SPILL_ROOM))) void NAME(rb_lift_params p_) { \
         (void)p_;                                                                                                                 \
         rb_tile_body<BRK>();                                                                                                      \
     }

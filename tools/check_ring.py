@@ -68,7 +68,7 @@ def ring_of(flags, macro="RB_RING_BASE"):
         m = re.match(r"-D" + macro + r"=(\d+)$", f)
         if m:
             base = int(m.group(1))
-        m = re.match(r"-DRB_PF=(\d+)$", f)
+        m = re.match(r"-DRBT?_PF=(\d+)$", f)
         if m:
             pf = int(m.group(1))
     return (base, base + 8 * pf - 1)
