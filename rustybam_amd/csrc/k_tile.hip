@@ -258,7 +258,7 @@ __device__ __forceinline__ void rb_tile_body() {
     const bool spec = n_slots != 0u && !desc_mode && (BRK || H != 0u);
     // ---- the stream ----
     uint32_t Rb = 0, Qb = 0, Ub = 0; // running totals of the tile
-    uint32_t v_reg = 0xFFFFFFFFu, v_minw = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_maxsu = 0u, v_carry = 0xFu;
+    uint32_t v_reg = 0u, v_minw = 0xFFFFFFFFu, v_adj = 0xFFFFFFFFu, v_maxsu = 0u, v_carry = 0xFu;
     unsigned long long v_utot = 0;
     // break-paf: the cut state runs along the tile.  cur = the record being streamed, brk_pre = where its open piece starts (an offset
     // in the tile's running reference total), brk_cnt = pieces closed so far = the lane of the open one, brk_p0 = brk_cnt when the
@@ -328,17 +328,19 @@ __device__ __forceinline__ void rb_tile_body() {
         if (fused) {
             const uint32_t prevw = rb_prev_lane(c[7], v_carry);
             v_carry = rb_readlane<uint32_t>(c[7], 63);
-            uint32_t rg[8], x[8];
+            // v_reg collects the op codes seen as bits (1 << (word & 31): the code, and bit 4 = the length's lowest bit -- either half of
+            // the word means the same code), checked against M I D N = X at the end; the op at which a record starts has nothing in front
+            // of it to be equal to: its nibble of `poison` is ORed into its difference
+            const uint32_t poison = bqv < 8u ? 15u << (4u * bqv) : 0u;
+            uint32_t x[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                rg[q] = (uint32_t)__builtin_amdgcn_sbfe((int)0x018F018Fu, c[q], 1u); // M I D N = X
-                x[q] = (c[q] ^ (q ? c[q - 1] : prevw)) & 15u;
-                x[q] = bqv == (uint32_t)q ? 15u : x[q]; // (the op in front belongs to another record)
+                v_reg |= 1u << (c[q] & 31u);
+                x[q] = ((c[q] ^ (q ? c[q - 1] : prevw)) & 15u) | __builtin_amdgcn_ubfe(poison, 4u * q, 4u);
             }
             auto min3 = [](uint32_t a, uint32_t b, uint32_t d) { const uint32_t t = a < b ? a : b; return t < d ? t : d; };
 #pragma unroll
             for (int q = 0; q < 8; q += 2) {
-                v_reg &= rg[q] & rg[q + 1];
                 v_minw = min3(v_minw, c[q], c[q + 1]);
                 v_adj = min3(v_adj, x[q], x[q + 1]);
             }
@@ -514,7 +516,7 @@ __device__ __forceinline__ void rb_tile_body() {
         // check_integrity (paf.rs:825-857) on every record of the tile and, with the fused scan, the conditions of the fast path over all of
         // its ops.  (v_maxsu: per-lane sums below 2^25 keep the 64-lane scans inside 32 bits; v_utot: the exact total of all lengths.)
         bool lane_bad = (v_maxsu >> 25) != 0u || (isrec && (totR != spanR || totQ != spanQ || PR != PassR));
-        if (fused) lane_bad |= v_reg != 0xFFFFFFFFu || v_minw < 16u || v_adj == 0u;
+        if (fused) lane_bad |= ((v_reg | (v_reg >> 16)) & 0xFFFFu & ~(uint32_t)RB_REGULAR_MASK) != 0u || v_minw < 16u || v_adj == 0u;
         if (rb_ballot(lane_bad) != 0ull || rb_first64(v_utot) > 0xFFFFFFFFull) {
             fallback();
             return;

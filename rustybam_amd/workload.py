@@ -118,6 +118,6 @@ def kernel_source_sha():
     import os
     d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
     h = hashlib.sha256()
-    for f in ("k_liftover.hip", "rb_lift.h", "rb_device.h"):
+    for f in ("k_liftover.hip", "k_tile.hip", "rb_lift.h", "rb_device.h"):
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

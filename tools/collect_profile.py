@@ -22,17 +22,27 @@ bench = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f
 line = [ln for ln in open(bench) if ln.startswith("{")][-1]
 open(os.path.join(dst, f"{tag}_bench.json"), "w").write(line)
 B = json.loads(line)
+# round 5: a step's clips come from THREE launches -- rb_k_liftover_stream (records longer than the tiles take), rb_k_liftover_tile (tiles of
+# short records) and rb_k_liftover_stream_list (what the tile kernel handed back) --, which bench.py times together: the counters of a
+# full-size step are the sums over the three of each one's largest launch
+FAMILIES = ("rb_k_liftover_stream(", "rb_k_liftover_tile(", "rb_k_liftover_stream_list(")
 per = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(src, "*counter_collection.csv"))):
     for row in csv.DictReader(open(f)):
-        if "liftover_stream" in row["Kernel_Name"]:
-            per[(os.path.basename(f), row["Dispatch_Id"])][row["Counter_Name"]] = float(row["Counter_Value"])
-best = {}
-for (_f, _d), c in per.items():
+        fam = next((x for x in FAMILIES if row["Kernel_Name"].startswith(x)), None)
+        if fam:
+            per[(os.path.basename(f), row["Dispatch_Id"], fam)][row["Counter_Name"]] = float(row["Counter_Value"])
+best_f = collections.defaultdict(dict)
+for (_f, _d, fam), c in per.items():
     for k, v in c.items():
-        best[k] = max(best.get(k, 0.0), v)
+        best_f[fam][k] = max(best_f[fam].get(k, 0.0), v)
+best = collections.defaultdict(float)
+for fam, c in best_f.items():
+    for k, v in c.items():
+        best[k] += v
+best = dict(best)
 stats = {r["Name"]: r for r in csv.DictReader(open(os.path.join(src, "kt_kernel_stats.csv")))}
-ks = next(v for k, v in stats.items() if "liftover_stream" in k)
+ks = next(v for k, v in stats.items() if k.startswith("rb_k_liftover_stream("))
 fetch, write = best["FETCH_SIZE"] * 2 * 1024, best["WRITE_SIZE"] * 1024
 algo = B["roofline"]["algorithmic_bytes"]
 traffic = {"_comment": "PMC traffic of rb_k_liftover_stream per full-size launch on the bench.py default workload (config 3, 1e6 records x 3000 "
@@ -40,7 +50,8 @@ traffic = {"_comment": "PMC traffic of rb_k_liftover_stream per full-size launch
                        f"(16 B / lane streaming loads). Source: profiles/{tag}_summary.md",
            "workload": {"records_per_gpu": B["config"]["records_per_gpu"], "windows": B["config"]["windows"], "workload": "config3"},
            "fetch_size_kb_raw": best["FETCH_SIZE"], "write_size_kb_raw": best["WRITE_SIZE"], "fetch_bytes_corrected": fetch, "write_bytes": write,
-           "traffic_bytes_per_launch": fetch + write, "kernel": "rb_k_liftover_stream", "build": f"profile {tag}",
+           "traffic_bytes_per_launch": fetch + write, "kernel": "rb_k_liftover_stream + rb_k_liftover_tile + rb_k_liftover_stream_list (the clip kernels of one step)", "build": f"profile {tag}",
+           "by_kernel": {fam.rstrip("("): {k: v for k, v in c.items() if k in ("FETCH_SIZE", "WRITE_SIZE")} for fam, c in best_f.items()},
            "kernel_source_sha": kernel_source_sha(), "git_head": os.popen(f"git -C {ROOT} rev-parse --short HEAD 2>/dev/null").read().strip()}
 json.dump(traffic, open(os.path.join(dst, f"traffic_{rnd}.json"), "w"), indent=1)
 timed_row = f"max {float(ks['MaxNs']) / 1e6:.2f} ms"

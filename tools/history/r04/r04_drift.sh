@@ -8,7 +8,7 @@ rocprofv3 -L 2>/dev/null | grep -iE "utcl|tlb|latency|TCP_|TCC_EA0_RD|TCC_EA0_WR
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/st_probe tools/st_probe.hip 2>/dev/null
 probe() { /tmp/st_probe chunks 2>&1 | grep -E "read \+ write pair \(1.2x, 2 slots\)|^read  pair|^write pair \(1 slot" | tr '\n' ';'; echo; }
 pmc() { # $1 = label
-  rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_REQUEST TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES --output-format csv -d gpurun_out/$tag/pmc_$1 -o c -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --e2e-records 0 > gpurun_out/$tag/pmc_$1.log 2>&1
+  rocprofv3 --pmc TCP_UTCL1_TRANSLATION_MISS TCP_UTCL1_TRANSLATION_HIT TCP_UTCL1_REQUEST TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_PENDING_STALL_CYCLES --output-format csv -d gpurun_out/$tag/pmc_$1 -o c -- python3 bench.py --no-box --e2e-records 0 --steps 3 --warmup 1 --no-cpu-baseline --e2e-records 0 > gpurun_out/$tag/pmc_$1.log 2>&1
   python3 - "$tag" "$1" <<'PY'
 import csv, glob, sys, collections
 tag, lab = sys.argv[1], sys.argv[2]

@@ -9,7 +9,7 @@ mkdir -p gpurun_out/$tag
 cp rustybam_amd/librustybam_amd.so /tmp/keep_decomp.so
 cp rustybam_amd/variants/diag.so rustybam_amd/librustybam_amd.so
 for skip in 0 2 1 3 4 64; do
-  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d gpurun_out/$tag/s$skip -o sq -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --debug-skip $skip > gpurun_out/$tag/s${skip}.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d gpurun_out/$tag/s$skip -o sq -- python3 bench.py --no-box --e2e-records 0 --steps 2 --warmup 1 --no-cpu-baseline --debug-skip $skip > gpurun_out/$tag/s${skip}.log 2>&1
   python3 - "$tag" "$skip" <<'PY' >> gpurun_out/$tag/summary.txt
 import csv, glob, sys, collections
 tag, skip = sys.argv[1], sys.argv[2]
