@@ -186,18 +186,7 @@ class ResidentTrim:
         640 MB for config 4 -- a consumer that goes on on the device never needs them).  events: a list that receives, per pass,
         (pairs, ms of the selection, ms of the pair kernels, ms of apply + check) from HIP events on the engine's stream."""
         torch, eng, dev = self.torch, self.eng, self.dev
-        start = np.flatnonzero(np.r_[True, self.grp_sorted[1:] != self.grp_sorted[:-1]]) if self.n else np.zeros(0, np.int64)
-        grp_off = np.r_[start, self.n].astype(np.uint64)
-        n_groups = len(grp_off) - 1
-        d_order = torch.from_numpy(np.ascontiguousarray(self.order, dtype=np.uint32).view(np.int32)).to(dev)
-        d_grp = torch.from_numpy(grp_off.view(np.int64)).to(dev)
-        d_cont = torch.zeros(self.n + 1, dtype=torch.uint8, device=dev)
-        d_l, d_r = torch.zeros(n_groups + 1, dtype=torch.int32, device=dev), torch.zeros(n_groups + 1, dtype=torch.int32, device=dev)
-        d_po = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)
-        d_rows = torch.empty((n_groups + 1) * 128, dtype=torch.uint8, device=dev)
-        d_pass = torch.zeros(64, dtype=torch.uint8, device=dev)
-        d_scr = torch.zeros(eng.trim_select_scratch_bytes(n_groups), dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
+        n_groups, d_order, d_grp, d_cont, d_l, d_r, d_po, d_rows, d_pass, d_scr = self._pass_buffers()
         ev_log = []
         for _ in range(max_passes):
             if check_host:
@@ -238,12 +227,16 @@ class ResidentTrim:
                 bad = int(d_pass.cpu().numpy().view(capi.TRIM_PASS_DT)[0]["bad_status"])
                 if bad:
                     raise RuntimeError(f"trim pair status {bad}: the reference panics")
-                self.pairs_by_wave += int((d_rows[: k * 128].view(torch.int64).view(k, 16)[:, 15] == 1).sum().item())  # (diagnostic word: 1 = wave-per-pair kernel)
+                by_wave = (d_rows[: k * 128].view(torch.int64).view(k, 16)[:, 15] == 1).sum()  # (diagnostic word: 1 = wave-per-pair kernel; read at the end)
+                self._by_wave = by_wave if getattr(self, "_by_wave", None) is None else self._by_wave + by_wave
                 self.cursor = (end + 31) // 32 * 32
                 self.pairs_done += k
             if deferred > 0:
                 continue
             self._d_cont = d_cont
+            if getattr(self, "_by_wave", None) is not None:
+                self.pairs_by_wave += int(self._by_wave.item())
+                self._by_wave = None
             if events is not None:
                 torch.cuda.synchronize()
                 for k_, e_ in ev_log:
@@ -252,6 +245,26 @@ class ResidentTrim:
                 self.fetch()
             return self
         raise RuntimeError("trim-paf did not converge")
+
+    def _pass_buffers(self):
+        """the query groups of the batch (host: one pass over the sorted group ids) and the device buffers of the passes, made once -- a
+        resident host has them before the first pass, as it has the batch"""
+        if getattr(self, "_pb", None) is None:
+            torch, eng, dev = self.torch, self.eng, self.dev
+            start = np.flatnonzero(np.r_[True, self.grp_sorted[1:] != self.grp_sorted[:-1]]) if self.n else np.zeros(0, np.int64)
+            grp_off = np.r_[start, self.n].astype(np.uint64)
+            n_groups = len(grp_off) - 1
+            d_order = torch.from_numpy(np.ascontiguousarray(self.order, dtype=np.uint32).view(np.int32)).to(dev)
+            d_grp = torch.from_numpy(grp_off.view(np.int64)).to(dev)
+            d_cont = torch.zeros(self.n + 1, dtype=torch.uint8, device=dev)
+            d_l, d_r = torch.zeros(n_groups + 1, dtype=torch.int32, device=dev), torch.zeros(n_groups + 1, dtype=torch.int32, device=dev)
+            d_po = torch.zeros(n_groups + 1, dtype=torch.int64, device=dev)
+            d_rows = torch.empty((n_groups + 1) * 128, dtype=torch.uint8, device=dev)
+            d_pass = torch.zeros(64, dtype=torch.uint8, device=dev)
+            d_scr = torch.zeros(eng.trim_select_scratch_bytes(n_groups), dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            self._pb = (n_groups, d_order, d_grp, d_cont, d_l, d_r, d_po, d_rows, d_pass, d_scr)
+        return self._pb
 
     def fetch(self):
         """the normalised rows and the contained flags of the finished passes, on the host (64 + 1 bytes per record)"""

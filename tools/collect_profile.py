@@ -65,6 +65,12 @@ try:  # the timed steps = the last launches of the kernel in the trace
                  f"{min(dur):.2f} - {max(dur):.2f} ms (the slow ones are candidates the placement turned down)")
 except Exception:
     pass
+def _avg(prefix):
+    r_ = next((v for k, v in stats.items() if k.startswith(prefix)), None)
+    return f"{float(r_['AverageNs']) / 1e6:.3f} ms x {r_['Calls']}" if r_ else "-"
+
+
+tile_row = f"{_avg('rb_k_liftover_tile(')} / {_avg('rb_k_liftover_stream_list(')}"
 extra_rows = ""
 if B.get("e2e", {}).get("records"):
     extra_rows += f"| end to end (`rb liftover`, text in -> text out, {B['e2e']['records']} records) | {B.get('e2e_paf_records_per_s', 0):.0f} PAF-records/s ({B['e2e'].get('seconds', 0)} s) |\n"
@@ -85,11 +91,12 @@ md = f"""# Profile {tag} -- the headline step (config 3: 1e6 records, 5e9 ops, 3
 | | |
 |---|---|
 | `ms_per_step` (bench.py, unprofiled) | {B['ms_per_step']:.2f} -> {B['value']:.3e} CIGAR-ops/s, {B['paf_records_per_s']:.3e} PAF-records/s |
-| `rb_k_liftover_stream`, HIP events inside bench.py | {B['roofline']['kernel_ms']:.2f} ms -> {B['roofline']['achieved']:.0f} GB/s of algorithmic bytes = **{B['roofline']['frac']:.3f} of 8 TB/s** |
-| the same kernel in the profiled run (`profiles/{tag}_kernel_stats.csv`: {ks['Calls']} calls -- sizing, the candidates of the two placements, warm-up, the timed steps) | {timed_row} |
+| the clip kernels of a step (`rb_k_liftover_stream`: records longer than 2048 ops; `rb_k_liftover_tile`: tiles of the others; `rb_k_liftover_stream_list`: what the tile kernel handed back), HIP events inside bench.py around the three | {B['roofline']['kernel_ms']:.2f} ms -> {B['roofline']['achieved']:.0f} GB/s of algorithmic bytes = **{B['roofline']['frac']:.3f} of 8 TB/s**; as first allocated (`roofline.unplaced`): {(B['roofline'].get('unplaced') or {}).get('kernel_ms', float('nan')):.2f} ms = {(B['roofline'].get('unplaced') or {}).get('frac', float('nan')):.3f} |
+| `rb_k_liftover_tile` / `rb_k_liftover_stream_list` in the profiled run (average of all calls) | {tile_row} |
+| `rb_k_liftover_stream` in the profiled run (`profiles/{tag}_kernel_stats.csv`: {ks['Calls']} calls -- sizing, the candidates of the two placements, warm-up, the timed steps) | {timed_row} |
 | FETCH_SIZE per full launch | {best['FETCH_SIZE']:.4g} KB raw x2 (gfx950 correction) = {fetch / 1e9:.2f} GB |
 | WRITE_SIZE per full launch | {best['WRITE_SIZE']:.4g} KB = {write / 1e9:.2f} GB |
-| traffic | **{(fetch + write) / 1e9:.1f} GB = {(fetch + write) / algo:.3f} x the {algo / 1e9:.2f} GB of algorithmic bytes** (round 2: 51.8 GB, 1.143 x; round 1: 70.9 GB, 1.56 x) |
+| traffic | **{(fetch + write) / 1e9:.1f} GB = {(fetch + write) / algo:.3f} x the {algo / 1e9:.2f} GB of algorithmic bytes** (sums over the three kernels; round 4: 50.5 GB, round 2: 51.8 GB, round 1: 70.9 GB) |
 | SQ_INSTS_VALU / SALU per full launch | {best.get('SQ_INSTS_VALU', 0):.3g} / {best.get('SQ_INSTS_SALU', 0):.3g} ({best.get('SQ_INSTS_VALU', 0) / 1e6:.0f} / {best.get('SQ_INSTS_SALU', 0) / 1e6:.0f} per record) |
 | SQ_INSTS_VMEM_RD / VMEM_WR / LDS per full launch | {best.get('SQ_INSTS_VMEM_RD', 0):.3g} / {best.get('SQ_INSTS_VMEM_WR', 0):.3g} / {best.get('SQ_INSTS_LDS', 0):.3g} |
 {extra_rows}| parity | {B.get('parity_sample', '-')}; output digest {B.get('output_digest', '-')} |
