@@ -264,6 +264,11 @@ int rb_dev_scan_records(rb_ctx *ctx, const rb_batch_view *batch, rb_reduce_row *
  *   - canonical output order: contigs by first appearance, then record order (liftover.rs:151-164)
  *   - longest-first launch order (load balance; does not affect results)
  *   - windows grouped by contig in BED order, with a per-contig "monotone" flag
+ *   - (round 5) TILES of short records: runs of records that lie one behind the other in ops[], 8 .. 2048 ops each, at most 32 of them and
+ *     4064 ops together.  rb_dev_liftover / rb_dev_break stream a tile with ONE wavefront (k_tile.hip) instead of one per record; longer
+ *     records keep the per-record kernel, and a tile the tile kernel does not take (an irregular or stripped record, an integrity failure,
+ *     more than 64 hits, ...) is handed to it record by record.  Same rows, same clips either way; counters.phase[3..4] tell how it went.
+ *     RB_TILE=0 in the environment switches the tiles off, RB_SHORT_MAX=<ops> moves the line (both read here, per plan).
  * `windows` may be NULL (break-paf / stats only).  */
 int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_off_host, const uint32_t *contig_host,
                    uint64_t n_win, const uint32_t *w_contig_host, const uint64_t *w_st_host, const uint64_t *w_en_host,

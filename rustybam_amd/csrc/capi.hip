@@ -159,6 +159,7 @@ struct rb_nf_params {
     uint32_t *deep_list;
     uint32_t flags;
     void *tdesc;
+    uint32_t *wide_list;
 };
 extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *p, hipStream_t stream);
 struct rb_compact_params {
@@ -2208,7 +2209,7 @@ extern "C" int rb_dev_alloc_placed_by(rb_ctx *ctx, uint64_t bytes, int tries, do
 // ---- nucfreq ----------------------------------------------------------------------------------------------------------
 namespace {
 struct nf_layout {
-    size_t end_key, rd_end, tile_off, blk, tile_lo, tile_hi, drop_off, deep_list, drop_pool, tdesc, total;
+    size_t end_key, rd_end, tile_off, blk, tile_lo, tile_hi, drop_off, deep_list, drop_pool, tdesc, wide_list, total;
     uint64_t max_tiles, drop_words;
 };
 nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_positions) {
@@ -2228,6 +2229,7 @@ nf_layout nf_ws_layout(uint64_t n_reads, uint64_t n_regions, uint64_t n_position
     L.drop_words = n_reads + 1024;
     L.drop_pool = o, o = up(o + ((size_t)L.drop_words + 1) * 8); // (word 0: the pool's cursor)
     L.tdesc = o, o = up(o + ((size_t)L.max_tiles + 1) * 64);     // one 64-byte descriptor per tile (rb_k_nf_tile_desc)
+    L.wide_list = o, o = up(o + ((size_t)L.max_tiles + 2) * 4);  // the tiles of the 16-bit build: count, then indices
     L.total = o;
     return L;
 }
@@ -2265,6 +2267,7 @@ extern "C" int rb_dev_nucfreq(rb_ctx *ctx, const rb_reads_view *reads, uint64_t 
     static const bool all_atomic = getenv("RB_DEBUG_NF_ATOMIC") != nullptr; // (diagnostic: every tile through the LDS-atomic kernel)
     p.flags = all_atomic ? 1u : 0u;
     p.tdesc = (void *)(w + L.tdesc);
+    p.wide_list = (uint32_t *)(w + L.wide_list);
     HIPCHK(ctx, rb_fill_async(p.drop_bits - 1, 0, 8, ctx->stream));
     HIPCHK(ctx, rb_fill_async(p.deep_list + n_regions, 0, 8, ctx->stream)); // (how many deep regions; can the cap be reached at all)
     HIPCHK(ctx, rb_launch_nucfreq(&p, ctx->stream));

@@ -69,6 +69,7 @@ struct rb_nf_params {
     uint32_t *deep_list;  // [n_regions + 1] regions whose fetch holds more reads than the cap; [n_regions] = how many
     uint32_t flags;       // bit 0: 16-bit counters for every tile (diagnostic)
     struct nf_tdesc *tdesc; // [max_tiles] what a workgroup needs to know about a tile, in one 64-byte record (rb_k_nf_tile_desc)
+    uint32_t *wide_list;    // [1 + max_tiles] how many tiles take the 16-bit build, then which (rb_k_nf_tile_desc lists them)
 };
 
 // one read as the tile kernel sees it: a single 48-byte record (one scalar load) instead of eight arrays
@@ -418,6 +419,7 @@ __global__ __launch_bounds__(256) void rb_k_nf_tile_desc(rb_nf_params p) {
     D.st = T.st, D.out = T.out, D.lo = p.tile_lo[t], D.hi = p.tile_hi[t], D.drop_off = d.off, D.drop_rlo = d.rlo;
     D.n_pos = (uint32_t)(T.en - T.st), D.tid = T.tid, D.r = (uint32_t)T.r, D.u8 = nf_u8_tile(p, D.lo, D.hi) ? 1u : 0u;
     p.tdesc[t] = D;
+    if (!D.u8) p.wide_list[1u + atomicAdd(&p.wide_list[0], 1u)] = (uint32_t)t; // (the 16-bit build walks this list: round 5 -- it used to be launched over all tiles to find its own)
 }
 
 // LDS place of tile position i: two dwords (A | C << 16, G | T << 16); 8 guard positions in front (a lane's group of 8 may start
@@ -436,7 +438,7 @@ __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { return ((v & 0
 #define NF_STOP 0 // diagnostics (timing only, wrong counts): 1 = no output written, 2 = no LDS atomics (bases staged and decoded, nothing added), 3 = no read touched
 #endif
 template <bool U8T>
-__global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
+__device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_t t) {
     constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + 128) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
     constexpr int STG_IT = (int)((STG + 255u) / 256u);
     __shared__ __attribute__((aligned(16))) uint32_t cnt[U8T ? NF_CNT8_DW : NF_CNT_DW]; // per position: one dword of four byte counters / A | C << 16, G | T << 16
@@ -456,7 +458,6 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     __shared__ int32_t wsum[NF_WAVES];
     __shared__ uint32_t blk_max, blk_cov;
     __shared__ __attribute__((aligned(16))) uint32_t stage_all[NF_WAVES][STG + 8]; // per wave: the bases one read lays over the tile (4 zero dwords in front)
-    const uint64_t t = blockIdx.x;
     if (t >= p.tile_off[p.n_regions]) return;
     // (round 4: the tile's facts come as ONE 64-byte record at a wave-uniform address -- rb_k_nf_tile_desc -- instead of a binary search
     //  for the region followed by dependent loads of its arrays, of the region's first tile and of its dropped-read bitmap's place)
@@ -761,11 +762,26 @@ __global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
     }
 }
 
+// the byte-counter build: a workgroup per tile (it leaves the tiles of the other build alone); the 16-bit build: workgroups that stay and
+// walk the list of ITS tiles -- none on long-read data, where launching it over all 61 k tiles of config 5 to find that out took 0.13 ms a call
+template <bool U8T>
+__global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
+    if constexpr (U8T) {
+        nf_one_tile<true>(p, blockIdx.x);
+    } else {
+        const uint32_t n = p.wide_list[0];
+        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+            nf_one_tile<false>(p, p.wide_list[1u + i]);
+            __syncthreads(); // (the next tile zeroes the counters this one's output loop reads)
+        }
+    }
+}
 
 extern "C" size_t rb_nf_tile_positions(void) { return NF_TILE; }
 extern "C" size_t rb_nf_scan_blocks(uint64_t n) { return (size_t)((n + NF_SCAN_PER_BLOCK - 1) / NF_SCAN_PER_BLOCK); }
 
 extern "C" hipError_t rb_launch_exclusive_scan(uint64_t *v, uint64_t n, uint64_t *block_sums, uint64_t *total_out, hipStream_t stream);
+extern "C" hipError_t rb_fill_async(void *dst, int value, size_t bytes, hipStream_t stream);
 
 extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stream) {
     const rb_nf_params p = *pp;
@@ -784,8 +800,10 @@ extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stre
     if (p.n_reads > RB_NF_DEPTH_CAP) hipLaunchKernelGGL(rb_k_nf_crowded, dim3((unsigned)((p.n_reads + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_deep_regions, dim3((unsigned)((p.n_regions + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_admit, dim3(512), dim3(64), 0, stream, p);
+    e = rb_fill_async(p.wide_list, 0, 4, stream);
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rb_k_nf_tile_desc, dim3((unsigned)((p.max_tiles + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_tiles<true>, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
-    hipLaunchKernelGGL(rb_k_nf_tiles<false>, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
+    hipLaunchKernelGGL(rb_k_nf_tiles<false>, dim3((unsigned)std::min<uint64_t>(p.max_tiles, 1024)), dim3(NF_THREADS), 0, stream, p);
     return hipGetLastError();
 }
