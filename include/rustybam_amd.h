@@ -274,6 +274,12 @@ int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_off_host, con
                    uint64_t n_win, const uint32_t *w_contig_host, const uint64_t *w_st_host, const uint64_t *w_en_host,
                    rb_plan **out);
 void rb_plan_destroy(rb_plan *plan);
+/* How rb_plan_create cuts a batch into tiles and orders its schedule, on plain host arrays (no device, no context): sched_out[n_rec] =
+ * the records longer than short_max (0: the default, 2048) longest first -- *n_long_out of them --, then the others in memory order;
+ * tiles_out[3 t ..] = {first record | pass-through << 31, records, schedule slot of the first record}.  Returns the number of tiles
+ * (all of them are counted, tiles_cap of them written), -1 on bad arguments. */
+int64_t rb_plan_tiles_host(uint64_t n_rec, const uint64_t *op_off_host, uint64_t short_max, uint32_t *sched_out, uint32_t *tiles_out,
+                           uint64_t tiles_cap, uint64_t *n_long_out);
 /* bytes of device workspace rb_dev_liftover / rb_dev_break need for this plan and row capacity (the workspace must be
  * 256-byte aligned, as rb_dev_alloc returns it) */
 size_t rb_plan_workspace_bytes(const rb_plan *plan, uint64_t rows_cap);

@@ -725,6 +725,72 @@ static int upload_vec(rb_ctx *ctx, const std::vector<T> &v, T **dev) {
     return RB_OK;
 }
 
+// Tiles of short records (k_tile.hip): runs of consecutive records of 8 .. short_max ops, at most rb_tile_max_records() of them and
+// rb_tile_max_ops() ops together, three words a tile {first record | pass-through << 31, records, schedule slot of the first record}; runs of
+// records below 8 ops become pass-through tiles (the per-record kernel takes them: a lane's eight ops would hold three records).  `sched` comes
+// in as the longest-first order of all records and leaves as: the records longer than short_max, longest first (*n_long of them: the
+// per-record kernel's launch), then the others in MEMORY order -- their slots are never launched as waves of their own, they are where the
+// records' jobs lie, so a tile's jobs lie side by side (one coalesced read instead of a gather, and rb_k_make_jobs writes them side by side).
+// No tile worth the name (nothing of 8 ops and more below the line): tiles stays empty and sched as it was.
+static void rb_cut_tiles(uint64_t n_rec, const uint64_t *op_off, uint64_t short_max, std::vector<uint32_t> &sched, std::vector<uint32_t> &tiles,
+                         uint64_t *n_long_out) {
+    tiles.clear();
+    *n_long_out = 0;
+    short_max = std::min<uint64_t>(short_max, rb_tile_max_ops());
+    if (short_max < 8 || !n_rec) return;
+    const uint64_t max_ops = rb_tile_max_ops(), max_rec = rb_tile_max_records();
+    std::vector<uint32_t> t2;
+    uint64_t first = 0, cnt = 0, ops = 0, n_long = 0, n_tiled = 0;
+    bool tiny = false;
+    auto close = [&]() {
+        if (cnt) t2.push_back((uint32_t)first | (tiny ? 0x80000000u : 0u)), t2.push_back((uint32_t)cnt), n_tiled += tiny ? 0 : cnt;
+        cnt = 0, ops = 0;
+    };
+    for (uint64_t r = 0; r < n_rec; r++) {
+        const uint64_t n = op_off[r + 1] - op_off[r];
+        if (n > short_max) {
+            close();
+            n_long++;
+            continue;
+        }
+        const bool t = n < 8;
+        if (cnt && (t != tiny || cnt >= max_rec || (!t && ops + n > max_ops))) close();
+        if (!cnt) first = r, tiny = t;
+        cnt++, ops += n;
+    }
+    close();
+    if (n_tiled == 0) return;
+    std::vector<uint32_t> s2(n_rec);
+    uint64_t a = 0, b = n_long;
+    for (uint64_t w = 0; w < n_rec; w++)
+        if (op_off[(uint64_t)sched[w] + 1] - op_off[sched[w]] > short_max) s2[a++] = sched[w];
+    std::vector<uint32_t> slot_short(n_rec, 0);
+    for (uint64_t r = 0; r < n_rec; r++)
+        if (op_off[r + 1] - op_off[r] <= short_max) slot_short[r] = (uint32_t)b, s2[b++] = (uint32_t)r;
+    sched.swap(s2);
+    tiles.reserve(t2.size() / 2 * 3);
+    for (size_t t = 0; t + 1 < t2.size(); t += 2) tiles.push_back(t2[t]), tiles.push_back(t2[t + 1]), tiles.push_back(slot_short[t2[t] & 0x7FFFFFFFu]);
+    *n_long_out = n_long;
+}
+// the same on plain host arrays, no device needed (tests/test_plan_tiles.py; a host that wants to know how a batch will be cut):
+// sched_out [n_rec], tiles_out [3 * tiles_cap]; returns the number of tiles (tiles beyond tiles_cap are counted, not written), -1: bad arguments
+extern "C" int64_t rb_plan_tiles_host(uint64_t n_rec, const uint64_t *op_off, uint64_t short_max, uint32_t *sched_out, uint32_t *tiles_out,
+                                      uint64_t tiles_cap, uint64_t *n_long_out) {
+    if (n_rec && (!op_off || !sched_out)) return -1;
+    if (n_rec >= 0xFFFFFFFFull) return -1;
+    std::vector<uint32_t> sched(n_rec), tiles;
+    std::iota(sched.begin(), sched.end(), 0u);
+    std::stable_sort(sched.begin(), sched.end(), [&](uint32_t x, uint32_t y) { return op_off[(uint64_t)x + 1] - op_off[x] > op_off[(uint64_t)y + 1] - op_off[y]; }); // (what rb_plan_create's radix sort gives)
+    uint64_t n_long = 0;
+    rb_cut_tiles(n_rec, op_off, short_max ? short_max : RB_SHORT_MAX_DEFAULT, sched, tiles, &n_long);
+    for (uint64_t i = 0; i < n_rec; i++) sched_out[i] = sched[i];
+    const uint64_t nt = tiles.size() / 3;
+    for (uint64_t t = 0; t < nt && t < tiles_cap && tiles_out; t++)
+        for (int k = 0; k < 3; k++) tiles_out[3 * t + k] = tiles[3 * t + k];
+    if (n_long_out) *n_long_out = tiles.empty() ? n_rec : n_long;
+    return (int64_t)nt;
+}
+
 extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_off, const uint32_t *contig, uint64_t n_win,
                               const uint32_t *w_contig, const uint64_t *w_st, const uint64_t *w_en, rb_plan **out) {
     if (!ctx || !out || (n_rec && (!op_off || !contig))) return RB_E_INVALID;
@@ -823,9 +889,8 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
             pl->depth = std::max<uint32_t>(pl->depth, (uint32_t)std::min<uint64_t>(i - lo + 1, 1u << 20));
         }
     }
-    // tiles of short records (k_tile.hip): consecutive records of 8 .. short_max ops, at most rb_tile_max_records() of them and
-    // rb_tile_max_ops() ops together; runs of records below 8 ops become pass-through tiles (the per-record kernel takes them).
-    // RB_TILE=0 switches the tile kernel off, RB_SHORT_MAX=<ops> moves the line between the two kernels (experiments).
+    // tiles of short records (k_tile.hip): rb_plan_tiles_host below.  RB_TILE=0 switches the tile kernel off, RB_SHORT_MAX=<ops> moves the
+    // line between the two kernels (experiments; RB_SCHED -- a schedule that is not sorted by length -- switches it off as well).
     std::vector<uint32_t> tiles;
     pl->stream_end = (uint32_t)n_rec;
     {
@@ -833,48 +898,10 @@ extern "C" int rb_plan_create(rb_ctx *ctx, uint64_t n_rec, const uint64_t *op_of
         const bool on = !(e && !strcmp(e, "0")) && !getenv("RB_SCHED");
         uint64_t short_max = RB_SHORT_MAX_DEFAULT;
         if (const char *m = getenv("RB_SHORT_MAX")) short_max = strtoull(m, nullptr, 10);
-        short_max = std::min<uint64_t>(short_max, rb_tile_max_ops());
-        if (on && short_max >= 8 && n_rec) {
-            const uint64_t max_ops = rb_tile_max_ops(), max_rec = rb_tile_max_records();
-            uint64_t first = 0, cnt = 0, ops = 0, n_long = 0, n_tiled = 0;
-            bool tiny = false;
-            auto close = [&]() {
-                if (cnt) tiles.push_back((uint32_t)first | (tiny ? 0x80000000u : 0u)), tiles.push_back((uint32_t)cnt), n_tiled += tiny ? 0 : cnt;
-                cnt = 0, ops = 0;
-            };
-            for (uint64_t r = 0; r < n_rec; r++) {
-                const uint64_t n = op_off[r + 1] - op_off[r];
-                if (n > short_max) {
-                    close();
-                    n_long++;
-                    continue;
-                }
-                const bool t = n < 8;
-                if (cnt && (t != tiny || cnt >= max_rec || (!t && ops + n > max_ops))) close();
-                if (!cnt) first = r, tiny = t;
-                cnt++, ops += n;
-            }
-            close();
-            if (n_tiled == 0) {
-                tiles.clear(); // (nothing for the tile kernel: the schedule stays whole)
-            } else {
-                // The schedule's slots [0, n_long) keep the long records, longest first; behind them the short ones follow in MEMORY
-                // order: their slots are never launched as waves of their own, they are where the records' jobs lie -- a tile's jobs then
-                // lie side by side (one coalesced read instead of a gather through slot_of), rb_k_make_jobs writes them side by side
-                pl->stream_end = (uint32_t)n_long;
-                std::vector<uint32_t> s2(n_rec);
-                uint64_t a = 0, b = n_long;
-                for (uint64_t w = 0; w < n_rec; w++)
-                    if (op_off[(uint64_t)sched[w] + 1] - op_off[sched[w]] > short_max) s2[a++] = sched[w];
-                std::vector<uint32_t> slot_short(n_rec, 0);
-                for (uint64_t r = 0; r < n_rec; r++)
-                    if (op_off[r + 1] - op_off[r] <= short_max) slot_short[r] = (uint32_t)b, s2[b++] = (uint32_t)r;
-                sched.swap(s2);
-                std::vector<uint32_t> t3;
-                t3.reserve(tiles.size() / 2 * 3);
-                for (size_t t = 0; t + 1 < tiles.size(); t += 2) t3.push_back(tiles[t]), t3.push_back(tiles[t + 1]), t3.push_back(slot_short[tiles[t] & 0x7FFFFFFFu]);
-                tiles.swap(t3);
-            }
+        if (on && n_rec) {
+            uint64_t n_long = 0;
+            rb_cut_tiles(n_rec, op_off, short_max, sched, tiles, &n_long);
+            if (!tiles.empty()) pl->stream_end = (uint32_t)n_long;
         }
         pl->n_tiles = (uint32_t)(tiles.size() / 3);
     }

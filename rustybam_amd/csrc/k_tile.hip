@@ -102,7 +102,7 @@ __device__ __forceinline__ void rb_tile_body() {
     uint8_t *bq_s = reinterpret_cast<uint8_t *>(bq_all[wib]);
     uint32_t *hr_s = hr_all[wib];
     uint32_t ra = rb_first(p.tile_first[3u * tile]);
-    const uint32_t nrec = rb_first(p.tile_first[3u * tile + 1u]);
+    uint32_t nrec = rb_first(p.tile_first[3u * tile + 1u]);
     const uint32_t slot0 = rb_first(p.tile_first[3u * tile + 2u]); // (the jobs of a tile's records lie side by side)
     const bool passthrough = (ra >> 31) != 0u;
     ra &= 0x7FFFFFFFu;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void rb_tile_body() {
     const uint32_t ns1 = n_slots ? n_slots : 1u;
 
     // ---- set-up, lane j = record ra + j ----
-    const bool isrec = (uint32_t)lane < nrec;
+    bool isrec = (uint32_t)lane < nrec;
     const uint32_t r = ra + (isrec ? (uint32_t)lane : 0u);
     const uint32_t slot = slot0 + (isrec ? (uint32_t)lane : 0u);
     const uint64_t oo0 = p.op_off[r], oo1 = p.op_off[r + 1];
@@ -134,6 +134,25 @@ __device__ __forceinline__ void rb_tile_body() {
         const rb_job *jp = &p.jobs[slot];
         jrec0 = jp->rec0, jn = jp->n, jflags = jp->flags, jnh = jp->nh, jlo = jp->lo, jh0 = jp->h0;
         t_st = jp->t_st, t_en = jp->t_en;
+    }
+    if constexpr (!BRK) {
+        // more hits than lanes: the tile is cut behind the last record whose hits still fit -- the records behind it go to the per-record
+        // kernel, the tile kernel keeps the front (dense windows over short records: a tile of 31 records with three hits each)
+        const uint32_t nh0 = (isrec && (jflags & RB_JOB_VALID) != 0u) ? jnh : 0u;
+        const uint32_t inc0 = rb_wave_scan_incl(nh0);
+        if (rb_readlane<uint32_t>(inc0, 63) > RBT_HITS) {
+            const uint32_t m = (uint32_t)__builtin_popcountll(rb_ballot(isrec && inc0 <= RBT_HITS)); // (the counts do not decrease: a run of low lanes)
+            if (m == 0u) {
+                fallback();
+                return;
+            }
+            unsigned long long b0 = 0;
+            if (lane == 0) b0 = atomicAdd(p.fb_count, (unsigned long long)(nrec - m));
+            b0 = rb_first64(b0);
+            if ((uint32_t)lane >= m && (uint32_t)lane < nrec) p.fb_list[b0 + ((uint32_t)lane - m)] = ra + (uint32_t)lane;
+            nrec = m;
+            isrec = (uint32_t)lane < nrec;
+        }
     }
     uint32_t spanR, spanQ;
     bool active;

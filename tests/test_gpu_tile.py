@@ -146,6 +146,16 @@ def test_dense_windows_hand_tiles_back(engine, oracle):
     lift_both(engine, oracle, b, w, FUSED, "dense windows", expect_back=100)
 
 
+def test_tiles_are_cut_where_their_hits_fill_the_lanes(engine, oracle):
+    """a tile of 31 records with three hits each holds more hits than the tile kernel has lanes (64): it keeps the records in front whose
+    hits fit and hands the others to the per-record kernel -- a third of the batch, not all of it"""
+    b = synth_batch(engine, 0xC07, 620, 100, 140, span=400_000)          # records of about 23 kb ...
+    w = sliding(span=500_000, step=9_000, width=10_000)                   # ... under windows every 9 kb: about 3.5 hits a record
+    cnt = lift_both(engine, oracle, b, w, FUSED, "tiles cut by hits")
+    back = int(cnt["phase"][4])
+    assert int(cnt["phase"][3]) > 0 and 620 // 8 < back < 620 * 2 // 3, back
+
+
 @pytest.mark.parametrize("mode", ["indel_ends", "wild", "mixed", "spliced"])
 def test_records_the_tile_kernel_hands_back(engine, oracle, mode):
     """stripped end indels, irregular CIGARs, integrity failures inside tiles: the whole tile is handed back, results as before"""
