@@ -1695,7 +1695,9 @@ __device__ __forceinline__ uint64_t rb_wave_max_u64(uint64_t v) {
     return v;
 }
 #ifndef RB_GW_WPE
-#define RB_GW_WPE 8 // (the kernel waits on its three dependent passes over the record: 8 waves per SIMD at 64 VGPRs beat 5 at 83 by 9 %)
+#define RB_GW_WPE 5 // (round 5: with the ops coming in groups of four steps a hit takes 51 us instead of 97, and the window's eight registers do not fit
+                    //  the 64 of eight waves per SIMD without scratch: 5 waves 12.5 ms, 6 waves 16.8, 8 waves 17.0 -- against 15.0 for the round-3 form
+                    //  at 8 waves, which had beaten its own 5-wave build by 9 %; irregular workload, same box, tools/r05_gw_check.sh)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))) void rb_k_liftover_generic_wave(rb_lift_params p) {
     __shared__ uint32_t run_tot_all[4][64], run_opc_all[4][64];
@@ -1806,12 +1808,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         // (the next step's ops are asked for before this step's are looked at: a hit is a chain of dependent steps, and the load is the
         //  longest link of each)
         auto ld = [&](uint32_t c0_) -> uint32_t { return c0_ + (uint32_t)lane < n ? ops[c0_ + (uint32_t)lane] : 0u; };
-        uint32_t pf_at = c_start, pf_w = ld(c_start);
+        // Round 5: the ops come in GROUPS of four steps (256 ops, four loads out at once), and the group behind the one being walked is
+        // asked for when its predecessor is entered: a hit was a chain of some 25 dependent steps of 3.8 us each (one 256-byte load a
+        // step, one step ahead); it is a chain of groups now.  win_take(c0): the 64 ops of the step at c0 (a multiple of 64 from the pass's
+        // start; behind a jump the window is refilled).
+#ifndef RB_GW_GROUP
+#define RB_GW_GROUP 4
+#endif
+        uint32_t wc[RB_GW_GROUP], wx[RB_GW_GROUP];
+        uint32_t wcb = 0xFFFFFFFFu, wxb = 0xFFFFFFFFu; // first op of the current group / of the group ahead (none)
+        auto win_fill = [&](uint32_t base, uint32_t (&dst)[RB_GW_GROUP], auto &&ldf) {
+#pragma unroll
+            for (int k = 0; k < RB_GW_GROUP; k++) dst[k] = ldf(base + 64u * (uint32_t)k);
+        };
+        auto win_take = [&](uint32_t c0_, auto &&ldf) -> uint32_t {
+            const uint32_t d = c0_ - wcb;
+            if (wcb == 0xFFFFFFFFu || d >= 64u * RB_GW_GROUP || (d & 63u)) { // not in the current group
+                if (c0_ == wxb) {
+#pragma unroll
+                    for (int k = 0; k < RB_GW_GROUP; k++) wc[k] = wx[k];
+                } else {
+                    win_fill(c0_, wc, ldf);
+                }
+                wcb = c0_, wxb = c0_ + 64u * RB_GW_GROUP;
+                win_fill(wxb, wx, ldf); // (the group behind it: out now, wanted four steps from now)
+            }
+            const uint32_t k = (c0_ - wcb) >> 6;
+            uint32_t v = wc[0];
+#pragma unroll
+            for (int q = 1; q < RB_GW_GROUP; q++) v = k == (uint32_t)q ? wc[q] : v;
+            return v;
+        };
+        auto win_reset = [&]() { wcb = wxb = 0xFFFFFFFFu; };
         for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
-            if (pf_at != c0) pf_w = ld(c0); // (behind a jump)
-            const uint32_t wv = pf_w;
-            pf_at = c0 + 64u, pf_w = ld(c0 + 64u);
+            const uint32_t wv = win_take(c0, ld);
             uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
             if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i); // (walk form: one more op of its owner's type)
             const bool isref = opc <= 8u && rb_in(RB_REF_MASK, opc);
@@ -1880,13 +1911,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
           for (int attempt = 0; attempt < 2; attempt++) {
             bool jumped = false;
             if (attempt) U0 = cp0.x, R0 = cp0.y, Q0 = cp0.z, M0 = cp0.w, a_set = false, b_set = false, a = N, b = 0, c_end2 = 0;
-            pf_at = c_start, pf_w = ld(c_start);
+            win_reset();
             for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
                 if (a_set && U0 > ke) break; // (nothing behind this can be <= ke)
                 const uint32_t i = c0 + (uint32_t)lane;
-                if (pf_at != c0) pf_w = ld(c0);
-                const uint32_t wv = pf_w;
-                pf_at = c0 + 64u, pf_w = ld(c0 + 64u);
+                const uint32_t wv = win_take(c0, ld);
                 uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
                 if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 const bool okc = opc <= 8u;
@@ -1952,11 +1981,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             const uint32_t i_ = c0_ + (uint32_t)lane;
             return (i_ >= ia && i_ <= ib) ? ops[i_] : 0u;
         };
-        uint32_t pf3 = ld3(ia & ~63u);
+        win_reset();
         for (uint32_t c0 = ia & ~63u; c0 <= ib; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
-            const uint32_t wv = pf3;
-            pf3 = ld3(c0 + 64u);
+            const uint32_t wv = win_take(c0, ld3);
             uint32_t opc = rb_opc(wv), len = rb_len(wv);
             if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
             const bool in = i >= ia && i <= ib && len != 0u;
