@@ -1062,6 +1062,8 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     if (p.desc_mode && out_cap < p.arena_origin + 1024) return fail(ctx, RB_E_CAPACITY, "descriptor mode needs out_cap >= 4 * rows_cap + 1024");
     p.arena_size = out_cap > p.arena_origin ? ((out_cap - p.arena_origin) / p.n_arena) & ~(uint64_t)3 : 0;
     p.copy_list = (uint4 *)(ws + w.copy_list);
+    // the generic kernel's per-hit descriptors take three arrays that are done with by the time it runs (rb_lift.h)
+    p.gj_a = (rb_gja *)(ws + w.brk_rows), p.gj_b = (uint4 *)(ws + w.copy_list), p.gj_c = (uint2 *)(ws + w.bp_tmp);
     p.copy_count = (unsigned long long *)(ws + w.copy_count);
     p.gen_list = (uint32_t *)(ws + w.gen_list);
     p.gen_cp = rb_no_gen_cp() ? nullptr : (uint4 *)(ws + w.gen_cp);

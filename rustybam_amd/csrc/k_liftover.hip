@@ -1694,6 +1694,50 @@ __device__ __forceinline__ uint64_t rb_wave_max_u64(uint64_t v) {
     }
     return v;
 }
+// One thread per generic hit: everything the wave kernel needs to start on it, gathered -- the dependent chain list entry -> row -> record's
+// row, offsets, strand -> windows -> checkpoint searches is walked here by as many threads as there are hits, not by a wave per hit in front
+// of its first op (round 5; the stream kernel got its rb_job the same way in round 1).
+__global__ __launch_bounds__(256) void rb_k_generic_jobs(rb_lift_params p) {
+    const uint64_t n_gen = p.counters->n_generic;
+    for (uint64_t g = (uint64_t)blockIdx.x * 256u + threadIdx.x; g < n_gen; g += (uint64_t)gridDim.x * 256u) {
+        const uint32_t hrow = p.gen_list[g];
+        const rb_hit_row *row = &p.rows[hrow];
+        const uint32_t r = row->rec, win = row->win;
+        const rb_norm_row *nr = &p.norm[r];
+        rb_gja A;
+        A.t_st = nr->t_st, A.t_en = nr->t_en, A.q_st = nr->q_st, A.q_en = nr->q_en;
+        A.n = nr->n_ops;
+        A.ops_off = p.op_off[r] + nr->first_op;
+        A.wst = p.x_st ? p.x_st[hrow] : p.wo_st[win];
+        A.wen = p.x_en ? p.x_en[hrow] : p.wo_en[win];
+        A.k2 = 0;
+        uint32_t k1 = 0, has_cp = 0;
+        const uint32_t status = nr->status;
+        if (status == RB_ST_OK && !(A.t_st > A.wst && A.t_en < A.wen)) {
+            const uint4 *gcp = (p.gen_cp && A.n > RB_GCP) ? rb_gen_cp_of(p, r, nr->first_op) : nullptr;
+            if (gcp && gcp[0].x == 0xFFFFFFFFu) gcp = nullptr; // (a record of 2^32 units and more has no checkpoints)
+            if (gcp) {
+                has_cp = 1;
+                const uint32_t ncp = (A.n + RB_GCP - 1u) / RB_GCP;
+                auto last_le = [&](uint64_t target) -> uint32_t { // the last checkpoint with at most `target` reference bases in front of it (checkpoint 0 holds zeros)
+                    uint32_t lo = 0, hi = ncp;
+                    while (hi - lo > 1u) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint64_t)gcp[mid].y <= target) lo = mid; else hi = mid;
+                    }
+                    return lo;
+                };
+                const int64_t ps = (int64_t)(A.wst > A.t_st ? A.wst : A.t_st), pe = (int64_t)(A.wen < A.t_en ? A.wen : A.t_en) - 1;
+                k1 = last_le((uint64_t)ps - A.t_st);
+                const uint32_t k2 = pe >= ps ? last_le((uint64_t)pe - A.t_st) : 0u;
+                if (k2 > k1 + 1u) A.k2 = k2;
+            }
+        }
+        p.gj_a[g] = A;
+        p.gj_b[g] = make_uint4(hrow, r, win, (status << 16) | (((uint32_t)row->flags & 0xFFu) << 8) | (has_cp << 1) | (p.strand[r] == (uint8_t)'-' ? 1u : 0u));
+        p.gj_c[g] = make_uint2(nr->aln_len, k1);
+    }
+}
 #ifndef RB_GW_WPE
 #define RB_GW_WPE 5 // (round 5: with the ops coming in groups of four steps a hit takes 51 us instead of 97, and the window's eight registers do not fit
                     //  the 64 of eight waves per SIMD without scratch: 5 waves 12.5 ms, 6 waves 16.8, 8 waves 17.0 -- against 15.0 for the round-3 form
@@ -1706,10 +1750,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
     const int lane = rb_lane();
     const uint64_t n_gen = p.counters->n_generic;
     for (uint64_t g = (uint64_t)blockIdx.x * 4u + wib; g < n_gen; g += (uint64_t)gridDim.x * 4u) {
-        const uint64_t hrow = p.gen_list[g];
+        // the hit's descriptor (rb_k_generic_jobs): three loads at addresses the whole wave shares, one trip
+        const rb_gja A_ = p.gj_a[g];
+        const uint4 B_ = p.gj_b[g];
+        const uint2 C_ = p.gj_c[g];
+        const uint64_t hrow = rb_first(B_.x);
+        const uint32_t r = rb_first(B_.y), win = rb_first(B_.z), gfl = rb_first(B_.w);
         rb_hit_row *row = &p.rows[hrow];
-        const uint32_t r = row->rec, win = row->win;
-        const rb_norm_row *nr = &p.norm[r];
         rb_hit_row w;
         w.rec = r;
         w.win = win;
@@ -1719,18 +1766,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         w.out_off = 0;
         w.t_st = w.t_en = w.q_st = w.q_en = 0;
         w.nmatch = w.aln_len = 0;
-        if (nr->status != RB_ST_OK) { // fused scan: the record was handed back and the full scan found the reference would panic on it
-            w.status = (uint16_t)nr->status;
-            w.flags = row->flags;
+        if ((gfl >> 16) != RB_ST_OK) { // fused scan: the record was handed back and the full scan found the reference would panic on it
+            w.status = (uint16_t)(gfl >> 16);
+            w.flags = (uint16_t)((gfl >> 8) & 0xFFu);
             if (lane == 0) *row = w;
             continue;
         }
-        const uint64_t t_st = nr->t_st, t_en = nr->t_en, q_st = nr->q_st, q_en = nr->q_en;
-        const bool minus = p.strand[r] == (uint8_t)'-';
-        const uint32_t n = nr->n_ops;
-        const uint32_t *ops = p.ops + p.op_off[r] + nr->first_op;
-        const uint64_t wst = p.x_st ? p.x_st[hrow] : p.wo_st[win];
-        const uint64_t wen = p.x_en ? p.x_en[hrow] : p.wo_en[win];
+        const uint64_t t_st = rb_first64(A_.t_st), t_en = rb_first64(A_.t_en), q_st = rb_first64(A_.q_st), q_en = rb_first64(A_.q_en);
+        const bool minus = (gfl & 1u) != 0u;
+        const uint32_t n = rb_first(A_.n);
+        const uint64_t ops_off = rb_first64(A_.ops_off);
+        const uint32_t *ops = p.ops + ops_off;
+        const uint64_t wst = rb_first64(A_.wst), wen = rb_first64(A_.wen);
+        const uint32_t rec_units = rb_first(C_.x);
         const uint32_t arena = (uint32_t)(g % p.n_arena);
         auto reserve = [&](uint32_t padded, uint64_t *off) -> bool { // room in an arena, for the whole wave
             unsigned long long b0 = 0;
@@ -1746,7 +1794,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         if (t_st > wst && t_en < wen) { // liftover.rs:23-25: verbatim clone, own id
             w.flags |= RB_HIT_INSIDE;
             w.t_st = t_st, w.t_en = t_en, w.q_st = q_st, w.q_en = q_en;
-            w.nmatch = nr->nmatch, w.aln_len = nr->aln_len;
+            w.nmatch = p.norm[r].nmatch, w.aln_len = rec_units;
             w.out_n = n;
             uint64_t off;
             if (reserve((n + 3u) & ~3u, &off)) {
@@ -1764,8 +1812,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         uint32_t c_start = 0, c_end1 = 0;               // c_end1: where the walk for the window's END may resume (pass 1)
         uint4 cp0 = make_uint4(0u, 0u, 0u, 0u), cp_e1 = cp0;
         bool first_seen = false, wrapped = false;
-        const uint4 *gcp = (p.gen_cp && n > RB_GCP) ? rb_gen_cp_of(p, r, nr->first_op) : nullptr;
-        if (gcp && rb_first(gcp[0].x) == 0xFFFFFFFFu) gcp = nullptr; // (a record of 2^32 units and more has no checkpoints: rb_k_generic_checkpoints)
+        const uint4 *gcp = (gfl & 2u) ? p.gen_cp + (ops_off / RB_GCP + r) : nullptr; // (rb_gen_cp_of; rb_k_generic_jobs has looked: there are checkpoints)
         const uint32_t ncp = (n + RB_GCP - 1u) / RB_GCP;
         // the last checkpoint whose field (1: reference bases, 0: units) is <= target (checkpoint 0 holds zeros); the fields never decrease
         auto cp_search = [&](int field, uint64_t target) -> uint32_t {
@@ -1781,9 +1828,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             return k1;
         };
         if (gcp) {
-            const uint32_t k1 = cp_search(1, (uint64_t)ps - t_st);
-            const uint32_t k2 = pe >= ps ? cp_search(1, (uint64_t)pe - t_st) : 0u;
-            if (k2 > k1 + 1u) c_end1 = k2 * RB_GCP, cp_e1 = gcp[k2];
+            const uint32_t k1 = rb_first(C_.y), k2 = rb_first(A_.k2); // (searched by rb_k_generic_jobs: k2 != 0 means k2 > k1 + 1)
+            if (k2) c_end1 = k2 * RB_GCP, cp_e1 = gcp[k2];
             if (k1) {
                 c_start = k1 * RB_GCP;
                 cp0 = gcp[k1];
@@ -1885,7 +1931,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             if (lane == 0) rb_generic_serial_hit(p, g);
             continue;
         }
-        const uint64_t N = nr->aln_len; // all units of the (normalised) record
+        const uint64_t N = rec_units; // all units of the (normalised) record
         s_lo = rb_wave_min_u64(s_lo), s_hi = rb_wave_max_u64(s_hi), e_lo = rb_wave_min_u64(e_lo), e_hi = rb_wave_max_u64(e_hi);
         if (s_lo == ~0ull || e_lo == ~0ull) { // binary_search Err -> panic (liftover.rs:31, :42)
             w.status = RB_ST_PANIC_NOTFOUND;
@@ -2121,6 +2167,7 @@ extern "C" hipError_t rb_launch_break_declined(const rb_lift_params *p, hipStrea
     if (p->n_rec == 0) return hipSuccess;
     hipLaunchKernelGGL(rb_k_break_declined_rows, dim3((unsigned)std::min<uint64_t>((p->n_rec + 255) / 256, 256)), dim3(256), 0, stream, *p);
     if (p->gen_cp) hipLaunchKernelGGL(rb_k_generic_checkpoints, dim3(2048), dim3(256), 0, stream, *p);
+    hipLaunchKernelGGL(rb_k_generic_jobs, dim3(1024), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_liftover_generic_wave, dim3(2048), dim3(256), 0, stream, *p);
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);
     return hipGetLastError();
@@ -2172,6 +2219,7 @@ extern "C" hipError_t rb_launch_liftover_tail(const rb_lift_params *p, hipStream
         hipLaunchKernelGGL(rb_k_liftover_generic, dim3(1024), dim3(256), 0, stream, *p);
     } else {
         if (p->gen_cp) hipLaunchKernelGGL(rb_k_generic_checkpoints, dim3(2048), dim3(256), 0, stream, *p);
+        hipLaunchKernelGGL(rb_k_generic_jobs, dim3(1024), dim3(256), 0, stream, *p);
         hipLaunchKernelGGL(rb_k_liftover_generic_wave, dim3(2048), dim3(256), 0, stream, *p);
     }
     hipLaunchKernelGGL(rb_k_finish, dim3(1), dim3(64), 0, stream, *p);

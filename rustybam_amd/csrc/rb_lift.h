@@ -109,12 +109,26 @@ struct rb_lift_params {
     // tile_first[t]: a run of records too small for a tile, handed to the per-record kernel as they are).  A tile the tile kernel does
     // not take (a record that is not regular or was stripped, too many hits, a record its verification does not pass, ...) lists its
     // records in fb_list; the per-record kernel then runs over that list (rb_k_liftover_stream_list).
+    // the generic wave kernel's per-hit descriptors (round 5, rb_k_generic_jobs): what a wave needs about hit g in ONE trip instead of seven
+    // (list entry -> row -> record's row and offsets -> windows -> checkpoint searches).  They live in workspace arrays that are free by the
+    // time the generic kernel runs: gj_a = the scratch rows of break-paf's one walk (64 B per row), gj_b = the copy list (16 B), gj_c = the
+    // piece windows' temporary (8 B).
+    struct rb_gja *gj_a;
+    uint4 *gj_b;                   // {row, record, window, status << 16 | row flags << 8 | has checkpoints << 1 | minus strand}
+    uint2 *gj_c;                   // {units of the record (aln_len), checkpoint the walks start at}
     const uint32_t *tile_first;    // [3 n_tiles]: {first record | pass-through << 31, records, schedule slot of the first record (the others follow)}
     uint32_t n_tiles;
     uint32_t *fb_list;             // [n_rec]
     unsigned long long *fb_count;
 };
 #define RB_GCP 256u
+struct __attribute__((aligned(64))) rb_gja { // half A of a generic hit's descriptor
+    uint64_t ops_off;                // the record's first kept op in ops[]
+    uint64_t t_st, t_en, q_st, q_en; // normalised coordinates
+    uint64_t wst, wen;               // the window
+    uint32_t n;                      // kept ops
+    uint32_t k2;                     // checkpoint in front of the units at the window's end (0: no jump)
+};
 
 // the kernel-argument segment of a kernel whose one argument is an rb_lift_params, read with scalar loads where a field is used
 // (rb_k_liftover_stream); rb_kp_here makes a copy of the pointer the compiler cannot see through, so that a load through it is
