@@ -502,13 +502,19 @@ def main():
         own_out.free()
 
         def launch_score(ptr):
+            # the clip kernels' own time on the candidate (HIP events inside the library, three launches), the measure the line reports --
+            # not the wall time of three whole steps (round 4); the wall only where the library timed nothing
             run_op(d_ws, d_rows, ptr)  # (first touch of the candidate's pages)
             torch.cuda.synchronize()
+            eng.set_timing(True)
             t_ = time.perf_counter()
             for _ in range(3):
                 run_op(d_ws, d_rows, ptr)
             torch.cuda.synchronize()
-            return (time.perf_counter() - t_) * 1e3 / 3
+            wall = (time.perf_counter() - t_) * 1e3 / 3
+            ev_ = eng.get_timing()[-3:]
+            eng.set_timing(False)
+            return float(np.mean(ev_)) if len(ev_) == 3 else wall
 
         d_out, own_out = big(out_cap + 64, torch.int32, placed=args.placement_tries, score=launch_score if args.placement_by == "launch" else None)
         # ... and the INPUT: with the arena fixed, the same launch reading its ops from other pages differs by up to 8 % as well (9.23 /
@@ -746,8 +752,8 @@ def main():
                    "batch_buffers_chunked": {k_: (bool(o_.chunked) if o_ else None) for k_, o_ in (("ops", own_ops), ("workspace", own_ws), ("rows", own_rows), ("out_ops", own_out))},
                    "out_arena_placement": ({"tries_allowed": args.placement_tries, **own_out.placement, "seconds": round(placement_ms / 1e3, 2),
                                             "by": args.placement_by,
-                                            "note": "rb_dev_alloc_placed[_by], part of the set-up: candidates of the output arena, each measured (ms: the step itself "
-                                                    "on the candidate, or the library's store sweep), the fastest kept; which physical pages the arena has decides "
+                                            "note": "rb_dev_alloc_placed[_by], part of the set-up: candidates of the output arena, each measured (ms: the clip kernels of the step "
+                                                    "itself on the candidate under HIP events, or the library's store sweep), the fastest kept; which physical pages the arena has decides "
                                                     "up to 20 % of the clip kernel's time"}
                                            if (own_out is not None and own_out.placement) else None),
                    "ops_placement": ({"incumbent_ms": ops_placement["incumbent_ms"], "launch_ms": ops_placement["launch_ms"], "kept": ops_placement["kept"],
