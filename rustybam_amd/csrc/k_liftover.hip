@@ -1628,7 +1628,7 @@ __device__ __forceinline__ uint4 *rb_gen_cp_of(const rb_lift_params &p, uint32_t
     return p.gen_cp + ((p.op_off[r] + first_op) / RB_GCP + r);
 }
 __global__ __launch_bounds__(256) void rb_k_generic_checkpoints(rb_lift_params p) {
-    static_assert(RB_GCP == 256u, "one 16-byte load per lane covers a checkpoint interval");
+    static_assert(RB_GCP == 64u, "one 16-byte load per lane covers four checkpoint intervals: lanes 0, 16, 32, 48 stand at their starts");
     const uint32_t wib = threadIdx.x >> 6;
     const int lane = rb_lane();
     const uint64_t n_gen = p.counters->n_generic;
@@ -1641,7 +1641,7 @@ __global__ __launch_bounds__(256) void rb_k_generic_checkpoints(rb_lift_params p
         if (n <= RB_GCP) continue; // (one checkpoint, the record's start: nothing to look up)
         const uint32_t *ops = p.ops + p.op_off[r] + nr->first_op;
         uint4 *cp = rb_gen_cp_of(p, r, nr->first_op);
-        auto load = [&](uint32_t c0) -> uint4 { // my four ops of the interval that starts at c0 (past the record: zero-length M ops)
+        auto load = [&](uint32_t c0) -> uint4 { // my four ops of the 256 that start at c0 (past the record: zero-length M ops)
             const uint32_t i = c0 + 4u * (uint32_t)lane;
             if (i + 3u < n) return rb_load4_unaligned(ops + i);
             return make_uint4(i < n ? ops[i] : 0u, i + 1u < n ? ops[i + 1u] : 0u, i + 2u < n ? ops[i + 2u] : 0u, 0u);
@@ -1649,17 +1649,15 @@ __global__ __launch_bounds__(256) void rb_k_generic_checkpoints(rb_lift_params p
         // The fields are 32 bits wide.  A record whose units in front of a checkpoint reach 2^32 (continuation words: up to 15 * 2^28
         // bases a word) gets none: checkpoint 0 -- zeros otherwise -- says so, and rb_k_liftover_generic_wave walks such a record
         // from its first op with its own 64-bit sums, as it does without checkpoints.
+        // Round 5: a checkpoint every 64 ops (256 before): a walk of the wave kernel starts in the step that holds what it looks for
+        // instead of up to three steps in front of it -- the kernel is bound by the instructions of its steps.  A lane sums its four
+        // ops, wave scans give every lane the sums in front of it, and the lanes that stand at a multiple of 64 ops write.
         uint64_t U = 0;
         uint32_t R = 0, Q = 0, M = 0;
         uint4 nxt = load(0u);
-        for (uint32_t c0 = 0; c0 < n; c0 += RB_GCP) {
-            if (U >> 32) {
-                if (lane == 0) cp[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                break;
-            }
-            if (lane == 0) cp[c0 / RB_GCP] = make_uint4((uint32_t)U, R, Q, M);
+        for (uint32_t c0 = 0; c0 < n; c0 += 256u) {
             const uint4 cur = nxt;
-            if (c0 + RB_GCP < n) nxt = load(c0 + RB_GCP); // (in flight while this interval is summed)
+            if (c0 + 256u < n) nxt = load(c0 + 256u); // (in flight while these ops are summed)
             const uint32_t w4[4] = {cur.x, cur.y, cur.z, cur.w};
             uint64_t u = 0; // (the reference / query / match sums are parts of it: they stay below 2^32 wherever a checkpoint is written)
             uint32_t rr = 0, q = 0, m = 0;
@@ -1674,7 +1672,17 @@ __global__ __launch_bounds__(256) void rb_k_generic_checkpoints(rb_lift_params p
                 q += okc && rb_in(RB_QRY_MASK, opc) ? len : 0u;
                 m += okc && rb_in(RB_MATCH_MASK, opc) ? len : 0u;
             }
-            U += rb_wave_sum_u64(u), R += rb_wave_sum_u32(rr), Q += rb_wave_sum_u32(q), M += rb_wave_sum_u32(m);
+            // (u < 2^34 a lane: scanned as its low 24 bits and what is above them, neither of which can leave 32 bits over 64 lanes)
+            const uint64_t iu = (uint64_t)rb_wave_scan_incl((uint32_t)u & 0xFFFFFFu) + ((uint64_t)rb_wave_scan_incl((uint32_t)(u >> 24)) << 24);
+            const uint32_t ir = rb_wave_scan_incl(rr), iq = rb_wave_scan_incl(q), im = rb_wave_scan_incl(m);
+            const bool mine = (lane & 15) == 0 && c0 + 4u * (uint32_t)lane < n; // a checkpoint stands in front of my first op
+            const uint64_t Uv = U + iu - u;
+            if (__ballot(mine && (Uv >> 32)) != 0ull) {
+                if (lane == 0) cp[0] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                break;
+            }
+            if (mine) cp[c0 / RB_GCP + ((uint32_t)lane >> 4)] = make_uint4((uint32_t)Uv, R + ir - rr, Q + iq - q, M + im - m);
+            U += rb_readlane<uint64_t>(iu, 63), R += rb_readlane<uint32_t>(ir, 63), Q += rb_readlane<uint32_t>(iq, 63), M += rb_readlane<uint32_t>(im, 63);
         }
     }
 }
@@ -1739,9 +1747,11 @@ __global__ __launch_bounds__(256) void rb_k_generic_jobs(rb_lift_params p) {
     }
 }
 #ifndef RB_GW_WPE
-#define RB_GW_WPE 5 // (round 5: with the ops coming in groups of four steps a hit takes 51 us instead of 97, and the window's eight registers do not fit
-                    //  the 64 of eight waves per SIMD without scratch: 5 waves 12.5 ms, 6 waves 16.8, 8 waves 17.0 -- against 15.0 for the round-3 form
-                    //  at 8 waves, which had beaten its own 5-wave build by 9 %; irregular workload, same box, tools/r05_gw_check.sh)
+#define RB_GW_WPE 4 // (round 5: the kernel wants 127 registers; at five waves per SIMD (96) it spills 74 of them to scratch, at four it spills none:
+                    //  11.58 -> 10.48 ms on the irregular workload, and two, three or four waves take the same time -- the kernel is bound by the
+                    //  vector instructions it issues, not by what it waits for.  Groups of two steps instead of four: 9.41 ms (fewer selects in
+                    //  win_take, fewer loads past the end of a walk); one: 9.68.  tools/r05_gw_ab.sh, same box.  Earlier in the round, at group 4:
+                    //  5 waves 12.5 ms, 6 waves 16.8, 8 waves 17.0 -- against 15.0 for the round-3 form at 8 waves)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))) void rb_k_liftover_generic_wave(rb_lift_params p) {
     __shared__ uint32_t run_tot_all[4][64], run_opc_all[4][64];
@@ -1854,12 +1864,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         // (the next step's ops are asked for before this step's are looked at: a hit is a chain of dependent steps, and the load is the
         //  longest link of each)
         auto ld = [&](uint32_t c0_) -> uint32_t { return c0_ + (uint32_t)lane < n ? ops[c0_ + (uint32_t)lane] : 0u; };
-        // Round 5: the ops come in GROUPS of four steps (256 ops, four loads out at once), and the group behind the one being walked is
+        // Round 5: the ops come in GROUPS of RB_GW_GROUP steps (two: 128 ops, two loads out at once; four were tried first), and the group behind the one being walked is
         // asked for when its predecessor is entered: a hit was a chain of some 25 dependent steps of 3.8 us each (one 256-byte load a
         // step, one step ahead); it is a chain of groups now.  win_take(c0): the 64 ops of the step at c0 (a multiple of 64 from the pass's
         // start; behind a jump the window is refilled).
 #ifndef RB_GW_GROUP
-#define RB_GW_GROUP 4
+#define RB_GW_GROUP 2
 #endif
         uint32_t wc[RB_GW_GROUP], wx[RB_GW_GROUP];
         uint32_t wcb = 0xFFFFFFFFu, wxb = 0xFFFFFFFFu; // first op of the current group / of the group ahead (none)
@@ -2037,6 +2047,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             uint32_t piece = len;
             if (i == ia) piece = ia == ib ? (uint32_t)(b - a + 1) : (uint32_t)(Ua_op + len_a - a);
             else if (i == ib) piece = (uint32_t)(b - Ub_op + 1);
+#ifndef RB_GW_NO_PLAIN_STEP
+            // Round 5: the step that needs none of the machinery below -- every op of the range kept (no zero length), a plain word, no two
+            // neighbours of one type (the run carried over is lane 0's neighbour): the ops leave as they are, cut at the ends, and the
+            // last one is carried.  An irregular record is irregular in a few places; this is the step of all its other ops (the
+            // general step is some 390 vector instructions for 64 ops, and the kernel is bound by them).
+            {
+                const bool inr = i >= ia && i <= ib;
+                const uint32_t ptype = rb_prev_lane(opc, has_carry ? c_opc : 0xFFu);
+                const bool odd = inr && (len == 0u || rb_opc(wv) == RB_OP_CONT || (piece >> RB_LEN_BITS_WORD) != 0u || (ptype == opc && (lane == 0 || i > ia)));
+                if (!__ballot(odd)) {
+                    if (has_carry) {
+                        if (lane == 0) rb_emit_run(p.out_ops + off + out_pos, c_tot, c_opc);
+                        out_pos += 1u + ((c_tot >> RB_LEN_BITS_WORD) ? 1u : 0u);
+                    }
+                    const uint64_t im = __ballot(inr); // (not empty: the loop runs over the steps of ia .. ib)
+                    const uint32_t cnt = (uint32_t)__builtin_popcountll(im), rank = (uint32_t)__builtin_popcountll(im & ((1ull << lane) - 1ull));
+                    if (inr && rank + 1u < cnt) p.out_ops[off + out_pos + rank] = (piece << 4) | opc;
+                    out_pos += cnt - 1u;
+                    const int last = 63 - __builtin_clzll(im);
+                    c_tot = rb_readlane<uint32_t>(piece, last), c_opc = rb_readlane<uint32_t>(opc, last);
+                    has_carry = true;
+                    continue;
+                }
+            }
+#endif
             // code of the last kept op in front of this lane (bit 4: there is one); lane 0 takes the run carried over
             const uint32_t key = in ? ((uint32_t)lane << 5) | 16u | opc : 0u;
             const uint32_t incl = rb_wave_scan_incl_max_u32(key);

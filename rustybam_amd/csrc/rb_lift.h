@@ -121,7 +121,7 @@ struct rb_lift_params {
     uint32_t *fb_list;             // [n_rec]
     unsigned long long *fb_count;
 };
-#define RB_GCP 256u
+#define RB_GCP 64u
 struct __attribute__((aligned(64))) rb_gja { // half A of a generic hit's descriptor
     uint64_t ops_off;                // the record's first kept op in ops[]
     uint64_t t_st, t_en, q_st, q_en; // normalised coordinates
