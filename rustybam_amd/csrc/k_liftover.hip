@@ -1747,11 +1747,10 @@ __global__ __launch_bounds__(256) void rb_k_generic_jobs(rb_lift_params p) {
     }
 }
 #ifndef RB_GW_WPE
-#define RB_GW_WPE 4 // (round 5: the kernel wants 127 registers; at five waves per SIMD (96) it spills 74 of them to scratch, at four it spills none:
+#define RB_GW_WPE 4 // (round 5: the kernel wants 127 registers; at five waves per SIMD (96) it spilled 74 of them to scratch, at four it spills none:
                     //  11.58 -> 10.48 ms on the irregular workload, and two, three or four waves take the same time -- the kernel is bound by the
-                    //  vector instructions it issues, not by what it waits for.  Groups of two steps instead of four: 9.41 ms (fewer selects in
-                    //  win_take, fewer loads past the end of a walk); one: 9.68.  tools/r05_gw_ab.sh, same box.  Earlier in the round, at group 4:
-                    //  5 waves 12.5 ms, 6 waves 16.8, 8 waves 17.0 -- against 15.0 for the round-3 form at 8 waves)
+                    //  instructions it issues, not by what it waits for.  tools/r05_gw_ab.sh, same box.  Earlier in the round, with groups of
+                    //  four steps: 5 waves 12.5 ms, 6 waves 16.8, 8 waves 17.0 -- against 15.0 for the round-3 form at 8 waves)
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))) void rb_k_liftover_generic_wave(rb_lift_params p) {
     __shared__ uint32_t run_tot_all[4][64], run_opc_all[4][64];
@@ -1864,41 +1863,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         // (the next step's ops are asked for before this step's are looked at: a hit is a chain of dependent steps, and the load is the
         //  longest link of each)
         auto ld = [&](uint32_t c0_) -> uint32_t { return c0_ + (uint32_t)lane < n ? ops[c0_ + (uint32_t)lane] : 0u; };
-        // Round 5: the ops come in GROUPS of RB_GW_GROUP steps (two: 128 ops, two loads out at once; four were tried first), and the group behind the one being walked is
-        // asked for when its predecessor is entered: a hit was a chain of some 25 dependent steps of 3.8 us each (one 256-byte load a
-        // step, one step ahead); it is a chain of groups now.  win_take(c0): the 64 ops of the step at c0 (a multiple of 64 from the pass's
-        // start; behind a jump the window is refilled).
+        // Round 5: the ops come in GROUPS of steps (G loads out at once), and the group behind the one being walked is asked for when its
+        // predecessor is entered: a hit was a chain of some 25 dependent steps of 3.8 us each (one 256-byte load a step, one step
+        // ahead); it is a chain of groups now.  win_take(G, c0): the 64 ops of the step at c0 (a multiple of 64 from the pass's start;
+        // behind a jump the window is refilled).
 #ifndef RB_GW_GROUP
-#define RB_GW_GROUP 2
+#define RB_GW_GROUP 1  // passes 1 and 2: with a checkpoint in front of every step they are walks of one or two steps, and every step asked for
+                       // beyond them is a load for nothing (groups of 2 / 3 / 4 in all passes: 7.68 / 8.49 / 8.85 ms on the irregular workload)
 #endif
-        uint32_t wc[RB_GW_GROUP], wx[RB_GW_GROUP];
+#ifndef RB_GW_GROUP3
+#define RB_GW_GROUP3 2 // pass 3 walks ia .. ib, known in advance (eight steps on the bench's windows; past ib no load is issued) -- and still
+                       // does not gain from loads further ahead: groups of 2 / 4 / 8 with passes 1 and 2 at one: 7.64 / 7.82 / 8.28 ms.  What a
+                       // larger group adds is the selects of win_take and the copies between the two groups; the kernel is bound by what it
+                       // issues (its steps are full of wave-uniform decisions: 286 scalar instructions beside 387 vector ones in the
+                       // general step of pass 3), not by its loads -- two, three or four waves per SIMD take the same time
+#endif
+        constexpr int RB_GW_GMAX = RB_GW_GROUP > RB_GW_GROUP3 ? RB_GW_GROUP : RB_GW_GROUP3;
+        using rb_g12 = std::integral_constant<int, RB_GW_GROUP>;
+        using rb_g3 = std::integral_constant<int, RB_GW_GROUP3>;
+        uint32_t wc[RB_GW_GMAX], wx[RB_GW_GMAX];
         uint32_t wcb = 0xFFFFFFFFu, wxb = 0xFFFFFFFFu; // first op of the current group / of the group ahead (none)
-        auto win_fill = [&](uint32_t base, uint32_t (&dst)[RB_GW_GROUP], auto &&ldf) {
+        auto win_fill = [&](auto G_, uint32_t base, uint32_t (&dst)[RB_GW_GMAX], auto &&ldf) {
+            constexpr int G = decltype(G_)::value;
 #pragma unroll
-            for (int k = 0; k < RB_GW_GROUP; k++) dst[k] = ldf(base + 64u * (uint32_t)k);
+            for (int k = 0; k < G; k++) dst[k] = ldf(base + 64u * (uint32_t)k);
         };
-        auto win_take = [&](uint32_t c0_, auto &&ldf) -> uint32_t {
+        auto win_take = [&](auto G_, uint32_t c0_, auto &&ldf) -> uint32_t {
+            constexpr int G = decltype(G_)::value;
             const uint32_t d = c0_ - wcb;
-            if (wcb == 0xFFFFFFFFu || d >= 64u * RB_GW_GROUP || (d & 63u)) { // not in the current group
+            if (wcb == 0xFFFFFFFFu || d >= 64u * G || (d & 63u)) { // not in the current group
                 if (c0_ == wxb) {
 #pragma unroll
-                    for (int k = 0; k < RB_GW_GROUP; k++) wc[k] = wx[k];
+                    for (int k = 0; k < G; k++) wc[k] = wx[k];
                 } else {
-                    win_fill(c0_, wc, ldf);
+                    win_fill(G_, c0_, wc, ldf);
                 }
-                wcb = c0_, wxb = c0_ + 64u * RB_GW_GROUP;
-                win_fill(wxb, wx, ldf); // (the group behind it: out now, wanted four steps from now)
+                wcb = c0_, wxb = c0_ + 64u * G;
+                win_fill(G_, wxb, wx, ldf); // (the group behind it: out now, wanted G steps from now)
             }
             const uint32_t k = (c0_ - wcb) >> 6;
             uint32_t v = wc[0];
 #pragma unroll
-            for (int q = 1; q < RB_GW_GROUP; q++) v = k == (uint32_t)q ? wc[q] : v;
+            for (int q = 1; q < G; q++) v = k == (uint32_t)q ? wc[q] : v;
             return v;
         };
         auto win_reset = [&]() { wcb = wxb = 0xFFFFFFFFu; };
         for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
-            const uint32_t wv = win_take(c0, ld);
+            const uint32_t wv = win_take(rb_g12{}, c0, ld);
             uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
             if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i); // (walk form: one more op of its owner's type)
             const bool isref = opc <= 8u && rb_in(RB_REF_MASK, opc);
@@ -1942,6 +1954,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             continue;
         }
         const uint64_t N = rec_units; // all units of the (normalised) record
+#if defined(RB_GW_STOP) && RB_GW_STOP == 1 // (diagnostics, timing only: the hit ends behind pass 1)
+        if (s_lo != 0x12345ull) { if (lane == 0) row->status = (uint16_t)(s_lo & 1u); continue; }
+#endif
         s_lo = rb_wave_min_u64(s_lo), s_hi = rb_wave_max_u64(s_hi), e_lo = rb_wave_min_u64(e_lo), e_hi = rb_wave_max_u64(e_hi);
         if (s_lo == ~0ull || e_lo == ~0ull) { // binary_search Err -> panic (liftover.rs:31, :42)
             w.status = RB_ST_PANIC_NOTFOUND;
@@ -1971,7 +1986,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             for (uint32_t c0 = c_start; c0 < n; c0 += 64u) {
                 if (a_set && U0 > ke) break; // (nothing behind this can be <= ke)
                 const uint32_t i = c0 + (uint32_t)lane;
-                const uint32_t wv = win_take(c0, ld);
+                const uint32_t wv = win_take(rb_g12{}, c0, ld);
                 uint32_t opc = rb_opc(wv), len = i < n ? rb_len(wv) : 0u;
                 if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
                 const bool okc = opc <= 8u;
@@ -2019,6 +2034,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
             if (lane == 0) *row = w;
             continue;
         }
+#if defined(RB_GW_STOP) && RB_GW_STOP == 2 // (diagnostics, timing only: the hit ends behind pass 2)
+        if (a != 0x12345ull) { if (lane == 0) row->status = (uint16_t)((a + b + Ra + Qa + Ma + nRb + nQb + nMb + ia + ib) & 1u); continue; }
+#endif
         w.t_st = t_st + Ra; // liftover.rs:57-60, :77-82 (a and b are match-type units)
         w.t_en = t_st + nRb;
         if (!minus) w.q_st = q_st + Qa, w.q_en = q_st + nQb;
@@ -2040,7 +2058,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RB_GW_WPE))
         win_reset();
         for (uint32_t c0 = ia & ~63u; c0 <= ib; c0 += 64u) {
             const uint32_t i = c0 + (uint32_t)lane;
-            const uint32_t wv = win_take(c0, ld3);
+            const uint32_t wv = win_take(rb_g3{}, c0, ld3);
             uint32_t opc = rb_opc(wv), len = rb_len(wv);
             if (opc == RB_OP_CONT) opc = rb_wopc(ops, i), len = rb_wlen(ops, i);
             const bool in = i >= ia && i <= ib && len != 0u;
