@@ -692,6 +692,8 @@ def main():
     one_walk = args.op == "break" and bool(brk_policy[0] & rustybam_amd.BREAK_ONE_WALK)
     if (args.op == "break" and not one_walk) or irregular or not (k_ms == k_ms):  # (no single dominant kernel under HIP events: the rate is taken over the whole step)
         k_ms = elapsed / args.steps * 1e3
+        if args.placement_tries > 1:
+            unplaced_ms = None  # (measured on the clip kernels' events: not the basis of this line's rate)
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
     # HBM-side bytes per launch from the committed PMC run of this same workload (bench.py is not run under --pmc).  The file names the
     # hash of the kernel sources it was measured on: a figure measured on other sources is refused (null + a note), not reported
