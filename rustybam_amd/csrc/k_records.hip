@@ -220,7 +220,31 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
     if (n_steps) bad = (v_reg != 0xFFFFFFFFu ? 1u : 0u) | (v_minlen == 0u ? 2u : 0u) | (v_adj == 0u ? 4u : 0u) | v_big;
 
     // ---- cross-lane reduction ----
+    // Round 5: DPP sums only -- a code's length in two 20-bit pieces (a lane's length sum stays below 2^40, as the LDS counters assume)
+    // instead of a 64-bit sum through twelve ds_bpermute; the op counts of I and D alone (the events of bamstats.rs:112-117: nothing asks
+    // for the others); H and P, which only the unit total sees, as one sum; the flags by ballot.  18 wave sums where there were 9 through
+    // the LDS crossbar and 9 by DPP: 14.4 -> 10.0 ms per 1e7 records of 500 ops with the first of these changes alone
+    // (tools/r05_scan_ab.sh, same box, rows equal); -DRB_SCAN_SHFL_SUMS is the old form.
     uint64_t L[9];
+#ifndef RB_SCAN_SHFL_SUMS
+    auto sum40 = [&](unsigned long long v) -> uint64_t {
+        const uint32_t s_lo = rb_wave_sum_u32((uint32_t)v & 0xFFFFFu), s_hi = rb_wave_sum_u32((uint32_t)(v >> 20) & 0xFFFFFu);
+        return (uint64_t)s_lo + ((uint64_t)s_hi << 20);
+    };
+#pragma unroll
+    for (int t = 0; t < 9; t++)
+        if (t != RB_OP_H && t != RB_OP_P) L[t] = sum40(hist[t][lane]);
+    {
+        const unsigned long long h = hist[RB_OP_H][lane], q = hist[RB_OP_P][lane]; // piece by piece (a piece of the two together takes 21 bits)
+        const uint32_t s_lo = rb_wave_sum_u32(((uint32_t)h & 0xFFFFFu) + ((uint32_t)q & 0xFFFFFu));
+        const uint32_t s_hi = rb_wave_sum_u32(((uint32_t)(h >> 20) & 0xFFFFFu) + ((uint32_t)(q >> 20) & 0xFFFFFu));
+        L[RB_OP_H] = (uint64_t)s_lo + ((uint64_t)s_hi << 20);
+        L[RB_OP_P] = 0;
+    }
+    const uint32_t ins_events = rb_wave_sum_u32((uint32_t)(hist[RB_OP_I][lane] >> RB_LEN_BITS));
+    const uint32_t del_events = rb_wave_sum_u32((uint32_t)(hist[RB_OP_D][lane] >> RB_LEN_BITS));
+    bad = (__ballot(bad & 1u) ? 1u : 0u) | (__ballot(bad & 2u) ? 2u : 0u) | (__ballot(bad & 4u) ? 4u : 0u) | (__ballot(bad & 8u) ? 8u : 0u);
+#else
     uint32_t C[9];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
@@ -231,6 +255,7 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
     const uint32_t ins_events = C[RB_OP_I];
     const uint32_t del_events = C[RB_OP_D];
     bad = rb_wave_or_u32(bad);
+#endif
     if (lane != 0) continue;
 
     const uint64_t R = L[RB_OP_M] + L[RB_OP_D] + L[RB_OP_N] + L[RB_OP_EQ] + L[RB_OP_X];
