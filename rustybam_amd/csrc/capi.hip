@@ -21,6 +21,7 @@
 
 #include "../../include/rustybam_amd.h"
 #include "rb_lift.h" // rb_lift_params (the device helpers in it are unused here)
+#include "rb_trim.h" // rb_trim_params
 
 // ---- kernel-side parameter blocks (must match the .hip files) ----------------------------------
 struct rb_scan_params {
@@ -54,25 +55,7 @@ struct rb_break_params {
     const uint32_t *list;
     const unsigned long long *n_list;
 };
-struct rb_trim_params {
-    uint64_t n_pairs;
-    const uint32_t *ops;
-    const uint64_t *op_off;
-    const uint8_t *strand;
-    const rb_norm_row *norm;
-    const uint32_t *left, *right;
-    const uint64_t *pair_out_off;
-    int match_score, diff_score, indel_score;
-    int policy;
-    rb_pair_row *rows;
-    uint32_t *out_ops;
-    int only_pending;
-    uint32_t *scratch;
-    uint32_t scratch_blocks;
-    unsigned long long *pend;
-    uint32_t *pend_list;
-    int in_place;
-};
+// (rb_trim_params: rb_trim.h)
 struct rb_swap_params {
     uint64_t n_rec;
     const uint32_t *ops;

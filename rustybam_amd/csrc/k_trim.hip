@@ -9,34 +9,9 @@
 // (trim_overlap.rs:69-76) is found from run ends.  One thread per pair, serial: the pairs of one pass are
 // independent (one pair per query name and pass, paf.rs:264-284); the pass/recursion driver stays on the
 // host.  Fully general (all op codes, both binary-search policies).
-#include "rb_serial.h"
+#include "rb_trim.h"
 #include <algorithm>
 
-struct rb_trim_params {
-    uint64_t n_pairs;
-    const uint32_t *ops;
-    const uint64_t *op_off;
-    const uint8_t *strand;
-    const rb_norm_row *norm;
-    const uint32_t *left, *right;
-    const uint64_t *pair_out_off; // [n_pairs] first output op of each pair (room for n_left + n_right ops)
-    int match_score, diff_score, indel_score;
-    int policy;
-    rb_pair_row *rows;
-    uint32_t *out_ops;
-    int only_pending;
-    uint32_t *scratch;       // device memory for the third attempt of the wave kernel (regions too large for LDS), or NULL
-    uint32_t scratch_blocks; // slabs in it
-    // pairs the first wave kernel declines, so that the attempts behind it do not have to look at every row: pend[0] = how many,
-    // pend_list[0 .. n_pairs) their indices (NULL: every row is looked at)
-    unsigned long long *pend;
-    uint32_t *pend_list;
-    // RB_TRIM_IN_PLACE (out_ops is the batch's own ops array): a regular record the wave kernel clips is not copied -- a clip by query
-    // keeps a run of the record's ops and changes the lengths of the run's first and last op only, so those two words are rewritten
-    // where they are and the row points at the run (out_off = its place in the array).  Pairs the serial kernel does still write
-    // their clips at pair_out_off.
-    int in_place;
-};
 
 struct rb_qstream {
     rb_sview v;
@@ -373,7 +348,6 @@ __device__ void rb_serial_pair(const rb_trim_params &p, const uint64_t pi) {
 #define RB_TW_CAP2 6144 // second attempt for the pairs whose overlap spans more ops (one pair per CU at a time; such overlaps are rare)
 #define RB_TW_CAP3 32768 // third attempt: the same arrays in device memory (whole-chromosome alignments that overlap by hundreds of kilobases)
 #define RB_TW_SLAB_WORDS(CAP) (2u * 3u * ((CAP) + 1u) + 2u * 3u * ((CAP) / 16u + 2u))
-#define RB_ST_PENDING_INTERNAL 0x7FFF0001u
 #ifndef RB_TW_STOP
 #define RB_TW_STOP 0 // diagnostics (tools/prof_c4_decomp.sh): != 0 ends a pair early -- 1 behind the left record's staging, 2 behind both, 3 behind the
                      // searches of the overlap's end ops, 4 behind the split, 5 behind the left clip; the rows are wrong then, only the time is of interest
@@ -400,9 +374,6 @@ struct rb_wpos { // an op (i = n: none) and the exclusive prefix of the searched
     uint32_t i, w, pre;
 };
 
-__device__ __forceinline__ int32_t rb_tw_score(uint32_t opc, int32_t ms, int32_t ds, int32_t is) {
-    return opc == RB_OP_EQ ? ms : ((opc == RB_OP_I || opc == RB_OP_D) ? -is : -ds);
-}
 
 // Stage the region of v that holds the query offsets [xa, xb] (op order).  false: it does not fit RB_TW_CAP ops.
 template <int CAP>
@@ -1016,6 +987,7 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_wave_pending(rb_trim_pa
         __builtin_amdgcn_wave_barrier();
     }
 }
+extern "C" hipError_t rb_launch_overlap_split_quad(const rb_trim_params *p, int t, hipStream_t stream); // k_trim4.hip
 extern "C" size_t rb_trim_scratch_bytes(uint32_t blocks) { return (size_t)blocks * RB_TW_SLAB_WORDS(RB_TW_CAP3) * 4u; }
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream) {
     if (p->n_pairs == 0) return hipSuccess;
@@ -1023,7 +995,19 @@ extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream
     static const bool serial_only = getenv("RB_DEBUG_TRIM_SERIAL") != nullptr; // diagnostics: the general kernel for every pair
     if (!serial_only) {
         q.only_pending = 0;
-        hipLaunchKernelGGL(rb_k_overlap_split_wave<RB_TW_CAP>, dim3((unsigned)p->n_pairs), dim3(64), 0, stream, q);
+        // first attempt: four pairs per wavefront (k_trim4.hip); what it lists goes to the wave-per-pair kernel.  Without a list (its
+        // allocation failed) the wave-per-pair kernel looks at every pair, as it did before round 6.
+        static const char *quad_env = getenv("RB_TRIM_QUAD"); // diagnostics: 0 = off, 4 / 8 = ops per lane of a region (default 8)
+        const int quad_t = quad_env ? atoi(quad_env) : 8;
+        if (q.pend_list && quad_t) {
+            hipError_t e = rb_launch_overlap_split_quad(&q, quad_t, stream);
+            if (e != hipSuccess) return e;
+            q.only_pending = 2;
+            const unsigned g0 = (unsigned)(p->n_pairs < 65536 ? p->n_pairs : 65536);
+            hipLaunchKernelGGL(rb_k_overlap_split_wave_pending<RB_TW_CAP>, dim3(g0), dim3(64), 0, stream, q);
+        } else {
+            hipLaunchKernelGGL(rb_k_overlap_split_wave<RB_TW_CAP>, dim3((unsigned)p->n_pairs), dim3(64), 0, stream, q);
+        }
         q.only_pending = 2; // (the attempts behind the first walk its list; what they decline is listed already)
         const unsigned g1 = (unsigned)(p->n_pairs < 8192 ? p->n_pairs : 8192);
         hipLaunchKernelGGL(rb_k_overlap_split_wave_pending<RB_TW_CAP1>, dim3(g1), dim3(64), 0, stream, q);
