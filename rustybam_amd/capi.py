@@ -1,6 +1,7 @@
 """ctypes binding of include/rustybam_amd.h (plumbing for tests and bench.py)."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -56,6 +57,14 @@ class RbError(RuntimeError):
 
 
 def lib_path():
+    """the product library; RB_VARIANT=<name> (diagnostics only: tools/mkvariant.sh builds rustybam_amd/variants/<name>.so, some of them
+    timing builds with wrong results) loads that one instead and says so -- the A/B scripts select a variant this way and never copy
+    one over the product library"""
+    v = os.environ.get("RB_VARIANT")
+    if v:
+        p = os.path.join(HERE, "variants", v + ".so")
+        print(f"[rustybam_amd] RB_VARIANT: loading {p} instead of the product library", file=sys.stderr)
+        return p
     return os.path.join(HERE, "librustybam_amd.so")
 
 

@@ -945,6 +945,33 @@ __device__ void rb_tw_pair(const rb_trim_params &p, const uint64_t pi, uint32_t 
     w._pad = 1; // (diagnostic: done by the wave kernel; the serial kernel leaves 0)
     if (lane == 0) p.rows[pi] = w;
 }
+// the list (or, without one, every row) as the attempts behind the first walk it: a workgroup looks at 64 entries at a time, one per
+// lane, and does those that are still pending one after the other (round 6; one entry at a time, two dependent loads each, took a
+// 48-workgroup attempt 0.35 ms to find out that a list of 150,000 pairs held nothing for it)
+struct rb_tw_walker {
+    uint64_t n, e0;
+    unsigned long long todo;
+    uint32_t pi; // per lane: the entry this lane looked at
+};
+__device__ __forceinline__ void rb_tw_walk_begin(const rb_trim_params &p, rb_tw_walker &w) {
+    w.n = p.pend_list ? rb_first64(*p.pend) : p.n_pairs;
+    w.e0 = 0, w.todo = 0ull, w.pi = 0u;
+}
+__device__ __forceinline__ bool rb_tw_walk_next(const rb_trim_params &p, rb_tw_walker &w, uint64_t *pi) { // wave-uniform
+    while (!w.todo) {
+        // (workgroup b owns the entries b, b + G, b + 2 G ...: a short list is spread over the workgroups, a long one is looked at 64
+        //  entries at a time)
+        if (w.e0 * gridDim.x + blockIdx.x >= w.n) return false;
+        const uint64_t e = (w.e0 + (uint64_t)rb_lane()) * gridDim.x + blockIdx.x;
+        w.pi = e < w.n ? (p.pend_list ? p.pend_list[e] : (uint32_t)e) : 0u;
+        w.todo = rb_ballot(e < w.n && p.rows[w.pi].status == RB_ST_PENDING_INTERNAL);
+        w.e0 += 64u;
+    }
+    const int l = __builtin_ctzll(w.todo);
+    w.todo &= w.todo - 1ull;
+    *pi = (uint64_t)rb_readlane<uint32_t>(w.pi, l);
+    return true;
+}
 // first attempt: a wavefront per pair
 #ifndef RB_TW_WPE
 #define RB_TW_WPE 8
@@ -964,11 +991,10 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_wave_scratch(rb_trim_pa
     uint32_t *slab = p.scratch + (size_t)blockIdx.x * RB_TW_SLAB_WORDS(CAP);
     auto *aw = reinterpret_cast<uint32_t (*)[3][CAP + 1]>(slab);
     auto *ac = reinterpret_cast<uint32_t (*)[3][CAP / 16 + 2]>(slab + 2u * 3u * (CAP + 1u));
-    const uint64_t n = p.pend_list ? rb_first64(*p.pend) : p.n_pairs;
-    for (uint64_t e = blockIdx.x; e < n; e += gridDim.x) {
-        const uint64_t pi = p.pend_list ? (uint64_t)rb_first(p.pend_list[e]) : e;
-        const uint32_t st = rb_first(p.rows[pi].status);
-        if (st == RB_ST_PENDING_INTERNAL) rb_tw_pair<CAP>(p, pi, aw, ac);
+    rb_tw_walker wk;
+    rb_tw_walk_begin(p, wk);
+    for (uint64_t pi; rb_tw_walk_next(p, wk, &pi);) {
+        rb_tw_pair<CAP>(p, pi, aw, ac);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
@@ -978,16 +1004,15 @@ template <int CAP>
 __global__ __launch_bounds__(64) void rb_k_overlap_split_wave_pending(rb_trim_params p) {
     __shared__ uint32_t lds_w[2][3][CAP + 1];
     __shared__ uint32_t lds_c[2][3][CAP / 16 + 2];
-    const uint64_t n = p.pend_list ? rb_first64(*p.pend) : p.n_pairs;
-    for (uint64_t e = blockIdx.x; e < n; e += gridDim.x) {
-        const uint64_t pi = p.pend_list ? (uint64_t)rb_first(p.pend_list[e]) : e;
-        const uint32_t st = rb_first(p.rows[pi].status);
-        if (st == RB_ST_PENDING_INTERNAL) rb_tw_pair<CAP>(p, pi, lds_w, lds_c);
+    rb_tw_walker wk;
+    rb_tw_walk_begin(p, wk);
+    for (uint64_t pi; rb_tw_walk_next(p, wk, &pi);) {
+        rb_tw_pair<CAP>(p, pi, lds_w, lds_c);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the LDS arrays are reused by the next pair)
         __builtin_amdgcn_wave_barrier();
     }
 }
-extern "C" hipError_t rb_launch_overlap_split_quad(const rb_trim_params *p, int t, hipStream_t stream); // k_trim4.hip
+extern "C" hipError_t rb_launch_overlap_split_quad(const rb_trim_params *p, int t, bool from_list, hipStream_t stream); // k_trim4.hip
 extern "C" size_t rb_trim_scratch_bytes(uint32_t blocks) { return (size_t)blocks * RB_TW_SLAB_WORDS(RB_TW_CAP3) * 4u; }
 extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream_t stream) {
     if (p->n_pairs == 0) return hipSuccess;
@@ -997,13 +1022,17 @@ extern "C" hipError_t rb_launch_overlap_split(const rb_trim_params *p, hipStream
         q.only_pending = 0;
         // first attempt: four pairs per wavefront (k_trim4.hip); what it lists goes to the wave-per-pair kernel.  Without a list (its
         // allocation failed) the wave-per-pair kernel looks at every pair, as it did before round 6.
-        static const char *quad_env = getenv("RB_TRIM_QUAD"); // diagnostics: 0 = off, 4 / 8 = ops per lane of a region (default 8)
-        const int quad_t = quad_env ? atoi(quad_env) : 8;
+        static const char *quad_env = getenv("RB_TRIM_QUAD"); // diagnostics: 0 = off, 4 / 8 = ops per lane of the first attempt's regions
+        const int quad_t = quad_env ? atoi(quad_env) : 4;
         if (q.pend_list && quad_t) {
-            hipError_t e = rb_launch_overlap_split_quad(&q, quad_t, stream);
+            hipError_t e = rb_launch_overlap_split_quad(&q, quad_t, false, stream);
             if (e != hipSuccess) return e;
             q.only_pending = 2;
-            const unsigned g0 = (unsigned)(p->n_pairs < 65536 ? p->n_pairs : 65536);
+            if (quad_t < 8) { // the pairs whose overlap does not fit 64 ops of a record's end: 128
+                e = rb_launch_overlap_split_quad(&q, 8, true, stream);
+                if (e != hipSuccess) return e;
+            }
+            const unsigned g0 = (unsigned)(p->n_pairs < 8192 ? p->n_pairs : 8192);
             hipLaunchKernelGGL(rb_k_overlap_split_wave_pending<RB_TW_CAP>, dim3(g0), dim3(64), 0, stream, q);
         } else {
             hipLaunchKernelGGL(rb_k_overlap_split_wave<RB_TW_CAP>, dim3((unsigned)p->n_pairs), dim3(64), 0, stream, q);

@@ -234,22 +234,6 @@ __device__ __forceinline__ uint32_t rb_q4_before(const rb_qrec &v, const rb_q4_s
     }
     return (KIND == 0 ? S.cU[c] : S.cR[c]) + rb_row_sum(x);
 }
-// score of the region's query bases in front of query offset x (op order), per lane; Qc[0] <= x
-template <int T>
-__device__ __forceinline__ int64_t rb_q4_W_lane(const rb_qrec &v, const rb_q4_slab<T> &S, uint32_t x, int32_t ms, int32_t ds, int32_t is) {
-    if (x >= v.eQ) return S.SP[16 * T];
-    // the last index with Qc <= x (non-query ops share the value of the query op behind them, and that op comes later; the entries
-    // behind the region hold eQ > x)
-    uint32_t lo = 0;
-#pragma unroll
-    for (uint32_t s = 8u * T; s >= 1u; s >>= 1) lo += S.Qc[lo + s] <= x ? s : 0u;
-    return (int64_t)S.SP[lo] + (int64_t)(x - S.Qc[lo]) * rb_tw_score(rb_opc(S.w[lo]), ms, ds, is);
-}
-template <int T>
-__device__ __forceinline__ int64_t rb_q4_G_lane(const rb_qrec &v, const rb_q4_slab<T> &S, uint64_t p, int32_t ms, int32_t ds, int32_t is) {
-    return !v.minus ? rb_q4_W_lane<T>(v, S, (uint32_t)(p - v.q_st), ms, ds, is) : -rb_q4_W_lane<T>(v, S, (uint32_t)(v.q_en - p), ms, ds, is);
-}
-
 // truncate_record_by_query (paf.rs:785-823) on a staged regular record: rb_tw_clip (k_trim.hip) for a row of 16 lanes
 template <int T>
 __device__ __forceinline__ uint32_t rb_q4_clip(rb_qrec &v, const rb_q4_slab<T> &S, uint64_t new_q_st, uint64_t new_q_en, uint32_t *out, rb_pair_row *row,
@@ -376,15 +360,13 @@ __device__ __forceinline__ uint32_t rb_q4_clip(rb_qrec &v, const rb_q4_slab<T> &
     return RB_ST_OK;
 }
 
-#ifndef RB_Q4_WPE
-#define RB_Q4_WPE 4
+#ifndef RB_Q4_STOP
+#define RB_Q4_STOP 0 // diagnostics (tools/r06_quad_decomp.sh): != 0 ends a pair early -- 1 behind the staging of both records, 2 behind the searches
+                     // of the overlap's end ops, 3 behind the split, 4 behind the left clip; the rows are wrong then, only the time is of interest
 #endif
 template <int T>
-__global__ __launch_bounds__(64) void rb_k_overlap_split_quad(rb_trim_params p) {
-    __shared__ __attribute__((aligned(16))) rb_q4_slab<T> lds[4][2];
-    const uint32_t lane = (uint32_t)rb_lane(), gbase = lane & 48u, gl = lane & 15u, g = lane >> 4;
-    const uint64_t pi = (uint64_t)blockIdx.x * 4u + g;
-    if (pi >= p.n_pairs) return;
+__device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64_t pi, const uint32_t gbase, const uint32_t gl, const uint32_t g) {
+    __shared__ __attribute__((aligned(16))) rb_q4_slab<T> lds[4][2]; // (here and not in the kernels: as an argument it would be a generic pointer)
     rb_pair_row w;
     w.split_idx = 0;
     w.split_score = 0;
@@ -405,7 +387,7 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_quad(rb_trim_params p) 
     }
     auto pending = [&](uint32_t why) { // (why: diagnostics, RB_DEBUG_TRIM_NO_SERIAL; whoever does the pair rewrites the whole row)
         if (gl == 0) {
-            p.pend_list[atomicAdd(p.pend, 1ull)] = (uint32_t)pi;
+            if (!p.only_pending) p.pend_list[atomicAdd(p.pend, 1ull)] = (uint32_t)pi; // (listed once: by the first attempt)
             p.rows[pi].status = RB_ST_PENDING_INTERNAL, p.rows[pi].split_idx = why;
         }
     };
@@ -414,6 +396,15 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_quad(rb_trim_params p) 
         return;
     }
     const int32_t ms = p.match_score, ds = p.diff_score, is = p.indel_score;
+    {   // the sums below are 32 bits wide: scores so large that a sum over both records' query bases could leave 2^29 are left to the
+        // wave-per-pair kernel, which sums in 64 bits
+        const uint32_t a = (uint32_t)(ms < 0 ? -ms : ms), b = (uint32_t)(ds < 0 ? -ds : ds), c = (uint32_t)(is < 0 ? -is : is);
+        const uint64_t smax = a > b ? (a > c ? a : c) : (b > c ? b : c);
+        if (smax * ((nl.q_en - nl.q_st) + (nr.q_en - nr.q_st)) >= (1ull << 29)) {
+            pending(8);
+            return;
+        }
+    }
     rb_qrec L, R;
     L.ops = p.ops + p.op_off[rl] + nl.first_op, L.n = nl.n_ops;
     L.t_st = nl.t_st, L.t_en = nl.t_en, L.q_st = nl.q_st, L.q_en = nl.q_en, L.minus = p.strand[rl] == (uint8_t)'-';
@@ -446,8 +437,12 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_quad(rb_trim_params p) 
         pending(3);
         return;
     }
-    int64_t best = 0;
-    uint64_t best_idx = 0;
+#if RB_Q4_STOP == 1
+    if (gl == 0) p.rows[pi].split_idx = L.eQ + R.eQ;
+    return;
+#endif
+    int32_t best = 0;
+    uint32_t best_idx = 0;
     // the ops that hold the first and the last overlapped query base of each record
     const rb_qpos La = rb_q4_find<T>(L, SL, lxa, gl, gbase), Lb = rb_q4_find<T>(L, SL, lxb, gl, gbase);
     const rb_qpos Ra = rb_q4_find<T>(R, SR, rxa, gl, gbase), Rb = rb_q4_find<T>(R, SR, rxb, gl, gbase);
@@ -460,78 +455,132 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_quad(rb_trim_params p) 
         pending(7);
         return;
     }
-    // W (score of the query bases in front of offset x, op order) at x = xa and at x = xb + 1, from those ops
-    auto W_at_first = [&](const rb_qrec &v, const rb_q4_slab<T> &S, const rb_qpos &o, uint32_t xa) -> int64_t {
-        return (int64_t)S.SP[o.i - v.i0] + (int64_t)(xa - o.pre) * rb_tw_score(rb_opc(o.w), ms, ds, is);
-    };
-    auto W_behind_last = [&](const rb_qrec &v, const rb_q4_slab<T> &S, const rb_qpos &o, uint32_t xb) -> int64_t {
-        const uint32_t k = o.i - v.i0;
-        return xb + 1u < o.pre + rb_len(o.w) ? (int64_t)S.SP[k] + (int64_t)(xb + 1u - o.pre) * rb_tw_score(rb_opc(o.w), ms, ds, is) : (int64_t)S.SP[k + 1u];
-    };
-    // G(p) = W(p - q_st) on '+', -W(q_en - p) on '-': st_ovl is offset xa on '+' and xb + 1 on '-', en_ovl the other way round
-    auto G_st = [&](const rb_qrec &v, const rb_q4_slab<T> &S, const rb_qpos &oa, const rb_qpos &ob, uint32_t xa, uint32_t xb) -> int64_t {
-        return !v.minus ? W_at_first(v, S, oa, xa) : -W_behind_last(v, S, ob, xb);
-    };
-    auto G_en = [&](const rb_qrec &v, const rb_q4_slab<T> &S, const rb_qpos &oa, const rb_qpos &ob, uint32_t xa, uint32_t xb) -> int64_t {
-        return !v.minus ? W_behind_last(v, S, ob, xb) : -W_at_first(v, S, oa, xa);
+#if RB_Q4_STOP == 2
+    if (gl == 0) p.rows[pi].split_idx = La.i + Lb.i + Ra.i + Rb.i;
+    return;
+#endif
+    // Everything below works in k = bases behind st_ovl (0 .. n), 32 bits, and on query offsets in op order, so that the two strands
+    // share one instruction stream: the boundary k of the overlap is query offset x = xa + k on '+' and xb + 1 - k on '-' (op order
+    // runs against the positions there), and G(k) = W(x) on '+', -W(x) on '-', W = score of the query bases in front of offset x.
+    const uint32_t n_ovl = (uint32_t)(en_ovl - st_ovl);
+    auto W_ends = [&](const rb_qrec &v, const rb_q4_slab<T> &S, const rb_qpos &oa, const rb_qpos &ob, uint32_t xa, uint32_t xb, int32_t *g0, int32_t *gn) {
+        const int32_t Wa = S.SP[oa.i - v.i0] + (xa - oa.pre) * rb_tw_score(rb_opc(oa.w), ms, ds, is); // W(xa)
+        const uint32_t kb = ob.i - v.i0;
+        const int32_t Wb = xb + 1u < ob.pre + rb_len(ob.w) ? S.SP[kb] + (xb + 1u - ob.pre) * rb_tw_score(rb_opc(ob.w), ms, ds, is)
+                                                            : S.SP[kb + 1u];                                 // W(xb + 1)
+        *g0 = v.minus ? -Wb : Wa, *gn = v.minus ? -Wa : Wb;
     };
     {
-        const int64_t gl0 = G_st(L, SL, La, Lb, lxa, lxb), gr0 = G_st(R, SR, Ra, Rb, rxa, rxb), gr1 = G_en(R, SR, Ra, Rb, rxa, rxb);
-        const int64_t rsum = gr1 - gr0; // f(0)
+        int32_t gl0, gl1, gr0, gr1;
+        W_ends(L, SL, La, Lb, lxa, lxb, &gl0, &gl1);
+        W_ends(R, SR, Ra, Rb, rxa, rxb, &gr0, &gr1);
+        const int32_t rsum = gr1 - gr0; // f(0)
         if (rsum > best) best = rsum;   // (index stays 0)
-        int64_t cb = INT64_MIN;         // best f over the candidates k > 0 of this lane; ties: the smaller k
+        int32_t cb = INT32_MIN;         // best f over the candidates k > 0 of this lane; ties: the smaller k
         uint32_t ck = 0;
-        // a candidate is a position where one record's score changes; that record's own sum up to it comes straight from its
-        // prefix arrays, only the other record is searched
-        auto consider = [&](uint64_t pos, const rb_qrec &other, const rb_q4_slab<T> &SO, bool own_is_left, int64_t g_own) {
-            if (pos <= st_ovl || pos > en_ovl) return;
-            const int64_t g_other = rb_q4_G_lane<T>(other, SO, pos, ms, ds, is);
-            const int64_t gL = own_is_left ? g_own : g_other, gR = own_is_left ? g_other : g_own;
-            const int64_t f = (gL - gl0) + (gr1 - gR);
-            const uint32_t k = (uint32_t)(pos - st_ovl);
-            if (f > cb || (f == cb && k < ck)) cb = f, ck = k;
+        if (gl == 0u) cb = gl1 - gl0, ck = n_ovl; // f(n): the left record's whole overlap
+        // a candidate is a boundary where one record's score changes -- the end of a query op and, where the op's last base scores
+        // differently (a D / N run behind it), the boundary in front of that base; that record's own sum up to it comes straight
+        // from its prefix arrays, only the other record is searched.  Both records' candidates go through ONE loop, free of branches
+        // but for a rare second search, so that the two searches of a step -- chains of dependent LDS reads -- run side by side.
+        struct hit_t { // the other record at ITS offset xo
+            int32_t W;
+            uint32_t j, len;
+            int32_t own;
+            bool inside;
         };
-        auto candidates = [&](const rb_qrec &v, const rb_q4_slab<T> &S, const rb_qrec &other, const rb_q4_slab<T> &SO, bool is_left, uint32_t ia, uint32_t ib) {
-            // ops whose query bases intersect the overlap: a contiguous op range [ia, ib].  The score changes where an op starts and
-            // where its special last base starts (only if that base scores differently: a D / N run behind the op); the end of the
-            // range's last op is the overlap's end or lies behind it (lane 0 below)
-            for (uint32_t i = ia + gl; i <= ib; i += 16u) {
-                const uint32_t k = i - v.i0;
-                const uint32_t wv = S.w[k];
-                if (!rb_in(RB_QRY_MASK, rb_opc(wv))) continue;
-                const uint64_t len = rb_len(wv), Qi = S.Qc[k];
-                const int64_t Si = S.SP[k], mi = (int64_t)S.SP[k + 1] - Si, own = rb_tw_score(rb_opc(wv), ms, ds, is);
-                const int64_t w0 = Si, w1 = Si + (int64_t)(len - 1) * own; // W at offsets Qi, Qi + len - 1
-                const bool special = mi != (int64_t)len * own;
-                if (!v.minus) {
-                    const uint64_t lo = v.q_st + Qi;
-                    consider(lo, other, SO, is_left, w0);
-                    if (special) consider(lo + len - 1, other, SO, is_left, w1); // the special base (the last one in op order) starts
-                } else {
-                    const uint64_t lo = v.q_en - Qi - len; // G(p) = -W(q_en - p); positions fall as the ops go on
-                    consider(lo + len, other, SO, is_left, -w0);
-                    if (special) consider(lo + 1, other, SO, is_left, -w1); // the special base (lowest position) ends
-                }
+        // the last index with Qc <= xo holds xo (the entries behind the region hold eQ): a 4-ary descent, three reads per level
+        auto search = [&](const rb_qrec &o, const rb_q4_slab<T> &SO, uint32_t xo) -> hit_t {
+            uint32_t lo = 0;
+#pragma unroll
+            for (int lv = 0; lv < 3; lv++) { // strides 4 T, T, T / 4
+                const uint32_t st = (4u * T) >> (2 * lv);
+                const uint32_t a = SO.Qc[lo + st], b = SO.Qc[lo + 2u * st], c = SO.Qc[lo + 3u * st];
+                lo += ((a <= xo ? 1u : 0u) + (b <= xo ? 1u : 0u) + (c <= xo ? 1u : 0u)) * st;
             }
+            if constexpr (T == 8) lo += SO.Qc[lo + 1u] <= xo ? 1u : 0u; // (128 = 2 * 4^3)
+            hit_t h;
+            const uint32_t wo = SO.w[lo];
+            h.j = xo - SO.Qc[lo], h.len = rb_len(wo), h.own = rb_tw_score(rb_opc(wo), ms, ds, is), h.inside = xo < o.eQ;
+            h.W = h.inside ? SO.SP[lo] + h.j * h.own : SO.SP[16 * T];
+            return h;
         };
-        candidates(L, SL, R, SR, true, La.i, Lb.i);
-        candidates(R, SR, L, SL, false, Ra.i, Rb.i);
-        if (gl == 0) consider(en_ovl, R, SR, true, G_en(L, SL, La, Lb, lxa, lxb));
+        struct late_t { // a special boundary the end's search did not answer
+            bool need;
+            uint32_t ks;
+            int32_t W_own;
+        };
+        auto eval = [&](const rb_qrec &v, const rb_q4_slab<T> &S, uint32_t vxa, uint32_t vxb, const rb_qrec &o, const rb_q4_slab<T> &SO, uint32_t oxa, uint32_t oxb,
+                        bool is_left, uint32_t i, uint32_t ib) -> late_t {
+            auto update = [&](bool act, uint32_t k, int32_t W_own, int32_t Wo) {
+                const int32_t g_own = v.minus ? -W_own : W_own, g_oth = o.minus ? -Wo : Wo;
+                const int32_t f = is_left ? (g_own - gl0) + (gr1 - g_oth) : (g_oth - gl0) + (gr1 - g_own);
+                const bool better = act && (f > cb || (f == cb && k < ck));
+                cb = better ? f : cb, ck = better ? k : ck;
+            };
+            const bool in = i <= ib;
+            const uint32_t kk = in ? i - v.i0 : 0u;
+            const uint32_t wv = S.w[kk], len = rb_len(wv), xe = S.Qc[kk] + len;
+            const int32_t Si = S.SP[kk], Sn = S.SP[kk + 1u], own = rb_tw_score(rb_opc(wv), ms, ds, is);
+            const bool q = in && rb_in(RB_QRY_MASK, rb_opc(wv));
+            const int32_t body = (int32_t)(len - 1u) * own; // (as the prefixes were built: 32 bits)
+            // the op's end: boundary ke, the other record's offset there
+            const uint32_t ke = v.minus ? vxb + 1u - xe : xe - vxa;
+            const bool e_ok = q && ke - 1u < n_ovl; // 0 < k <= n
+            const hit_t h = search(o, SO, e_ok ? (o.minus ? oxb + 1u - ke : oxa + ke) : o.bQ);
+            update(e_ok, ke, Sn, h.W);
+            // the boundary in front of the op's last base, where that base scores differently: one base towards the op's start,
+            // which is one base down the other record's offsets on the same strand and one base up on the other -- the hit of the
+            // end's search answers it unless the step leaves the other record's op (then it is searched: below)
+            const bool same = v.minus == o.minus;
+            late_t l;
+            l.ks = v.minus ? ke + 1u : ke - 1u;
+            l.W_own = Si + (len - 1u) * own;
+            const bool sp = q && Sn - Si - body != own && l.ks - 1u < n_ovl;
+            const bool easy = e_ok && h.inside && (same ? h.j >= 1u : h.j + 1u < h.len);
+            update(sp && easy, l.ks, l.W_own, same ? h.W - h.own : h.W + h.own);
+            l.need = sp && !easy;
+            return l;
+        };
+        auto late = [&](const late_t &l, const rb_qrec &v, const rb_qrec &o, const rb_q4_slab<T> &SO, uint32_t oxa, uint32_t oxb, bool is_left) {
+            if (!l.need) return;
+            const int32_t Wo = search(o, SO, o.minus ? oxb + 1u - l.ks : oxa + l.ks).W;
+            const int32_t g_own = v.minus ? -l.W_own : l.W_own, g_oth = o.minus ? -Wo : Wo;
+            const int32_t f = is_left ? (g_own - gl0) + (gr1 - g_oth) : (g_oth - gl0) + (gr1 - g_own);
+            if (f > cb || (f == cb && l.ks < ck)) cb = f, ck = l.ks;
+        };
+        {
+            const uint32_t cl = Lb.i - La.i, cr = Rb.i - Ra.i, steps = (cl > cr ? cl : cr) / 16u + 1u;
+            for (uint32_t it = 0, d = gl; it < steps; it++, d += 16u) {
+                const late_t ll = eval(L, SL, lxa, lxb, R, SR, rxa, rxb, true, La.i + d, Lb.i);
+                const late_t lr = eval(R, SR, rxa, rxb, L, SL, lxa, lxb, false, Ra.i + d, Rb.i);
+                late(ll, L, R, SR, rxa, rxb, true);
+                late(lr, R, L, SL, lxa, lxb, false);
+            }
+        }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
-            const uint32_t olo = rb_row_ror((uint32_t)cb, off), ohi = rb_row_ror((uint32_t)((uint64_t)cb >> 32), off), ok = rb_row_ror(ck, off);
-            const int64_t ob = (int64_t)(((uint64_t)ohi << 32) | olo);
+            const int32_t ob = (int32_t)rb_row_ror((uint32_t)cb, off);
+            const uint32_t ok = rb_row_ror(ck, off);
             if (ob > cb || (ob == cb && ok < ck)) cb = ob, ck = ok;
         }
         if (cb > best) best = cb, best_idx = ck;
     }
+#if RB_Q4_STOP == 3
+    if (gl == 0) p.rows[pi].split_idx = best_idx;
+    return;
+#endif
     w.split_idx = best_idx;
-    w.split_score = (int32_t)best;
+    w.split_score = best;
     const uint64_t split = st_ovl + best_idx;
     const bool inpl = p.in_place != 0;
     const uint64_t ob = inpl ? 0ull : p.pair_out_off[pi];
     rb_qcut cutL, cutR;
     uint32_t st = rb_q4_clip<T>(L, SL, L.q_st, split, p.out_ops + ob, &w, 0, ob, gl, gbase, inpl, cutL, (uint64_t)(L.ops - p.ops)); // trim_overlap.rs:77
+#if RB_Q4_STOP == 4
+    if (gl == 0) p.rows[pi] = w;
+    return;
+#endif
     if (st == RB_ST_OK && !L.bad) {
         const uint64_t ob2 = ob + L.n;
         st = rb_q4_clip<T>(R, SR, split, R.q_en, p.out_ops + ob2, &w, 1, ob2, gl, gbase, inpl, cutR, (uint64_t)(R.ops - p.ops)); // :78
@@ -554,10 +603,36 @@ __global__ __launch_bounds__(64) void rb_k_overlap_split_quad(rb_trim_params p) 
     }
 }
 
-extern "C" hipError_t rb_launch_overlap_split_quad(const rb_trim_params *p, int t, hipStream_t stream) {
+// first attempt: pairs 4 b .. 4 b + 3 to workgroup b
+template <int T>
+__global__ __launch_bounds__(64) void rb_k_overlap_split_quad(rb_trim_params p) {
+    const uint32_t lane = (uint32_t)rb_lane(), gbase = lane & 48u, gl = lane & 15u, g = lane >> 4;
+    const uint64_t pi = (uint64_t)blockIdx.x * 4u + g;
+    if (pi < p.n_pairs) rb_q4_pair<T>(p, pi, gbase, gl, g);
+}
+// second attempt, with larger regions, for the pairs the first one listed: the workgroups walk the list, four entries at a time
+template <int T>
+__global__ __launch_bounds__(64) void rb_k_overlap_split_quad_list(rb_trim_params p) {
+    const uint32_t lane = (uint32_t)rb_lane(), gbase = lane & 48u, gl = lane & 15u, g = lane >> 4;
+    const uint64_t n = *p.pend;
+    for (uint64_t e = (uint64_t)blockIdx.x * 4u + g; e < n; e += (uint64_t)gridDim.x * 4u) {
+        const uint64_t pi = p.pend_list[e];
+        if (p.rows[pi].status == RB_ST_PENDING_INTERNAL) rb_q4_pair<T>(p, pi, gbase, gl, g);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the slabs are reused by the next entry)
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+extern "C" hipError_t rb_launch_overlap_split_quad(const rb_trim_params *p, int t, bool from_list, hipStream_t stream) {
     if (p->n_pairs == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((p->n_pairs + 3) / 4);
-    if (t == 4) hipLaunchKernelGGL(rb_k_overlap_split_quad<4>, dim3(blocks), dim3(64), 0, stream, *p);
-    else hipLaunchKernelGGL(rb_k_overlap_split_quad<8>, dim3(blocks), dim3(64), 0, stream, *p);
+    if (from_list) {
+        const unsigned g = blocks < 16384u ? blocks : 16384u;
+        if (t == 4) hipLaunchKernelGGL(rb_k_overlap_split_quad_list<4>, dim3(g), dim3(64), 0, stream, *p);
+        else hipLaunchKernelGGL(rb_k_overlap_split_quad_list<8>, dim3(g), dim3(64), 0, stream, *p);
+    } else if (t == 4) {
+        hipLaunchKernelGGL(rb_k_overlap_split_quad<4>, dim3(blocks), dim3(64), 0, stream, *p);
+    } else {
+        hipLaunchKernelGGL(rb_k_overlap_split_quad<8>, dim3(blocks), dim3(64), 0, stream, *p);
+    }
     return hipGetLastError();
 }
