@@ -65,6 +65,10 @@ struct rb_swap_params {
 };
 
 extern "C" hipError_t rb_launch_scan_records(const rb_scan_params *p, hipStream_t stream);
+extern "C" hipError_t rb_launch_scan_rows(const rb_scan_params *p, void *long_buf, hipStream_t stream);
+#ifndef RB_SCAN_ROWS_MEAN_MAX
+#define RB_SCAN_ROWS_MEAN_MAX 1536 // ops per record, batch mean, up to which rb_dev_scan_records takes the row form (k_records.hip)
+#endif
 extern "C" hipError_t rb_launch_peek_norm(const rb_scan_params *p, hipStream_t stream);
 extern "C" hipError_t rb_launch_count_and_scan(const rb_lift_params *p, uint64_t *block_sums, bool do_count, hipStream_t stream);
 struct rb_parse_params {
@@ -196,6 +200,8 @@ struct rb_ctx {
     uint32_t trim_scratch_blocks = 0;
     void *trim_pend = nullptr; // [count (256 B) | indices of the pairs the first wave kernel declined]
     uint64_t trim_pend_cap = 0;
+    void *scan_list = nullptr; // [count (256 B) | indices of the records the row form of the scan left to the wave-per-record kernel]
+    uint64_t scan_list_cap = 0;
     // pinned staging ring of the host-buffer entry points (rb_dev_upload / rb_dev_download): large transfers go through two
     // page-locked chunks (hipHostMalloc), the copy into / out of a chunk on several host threads while the DMA of the other runs
     void *pin[2] = {nullptr, nullptr};
@@ -288,6 +294,7 @@ extern "C" void rb_ctx_destroy(rb_ctx *ctx) {
     }
     if (ctx->trim_scratch) hipFree(ctx->trim_scratch);
     if (ctx->trim_pend) hipFree(ctx->trim_pend);
+    if (ctx->scan_list) hipFree(ctx->scan_list);
     (void)rb_dev_cache_trim(ctx, 0);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -692,6 +699,24 @@ extern "C" int rb_dev_scan_records(rb_ctx *ctx, const rb_batch_view *b, rb_reduc
     p.norm_rows = norm_rows;
     p.list = nullptr;
     p.n_list = nullptr;
+    // a batch of short records (config 4's shape: a few hundred ops each) goes through the row form, four records per wavefront, and
+    // only what that lists through the wave-per-record kernel; RB_SCAN_ROWS=0 (diagnostics): the wave-per-record kernel for everything
+    static const bool rows_off = getenv("RB_SCAN_ROWS") && atoi(getenv("RB_SCAN_ROWS")) == 0;
+    if (!rows_off && b->n_rec >= 64 && b->n_ops / b->n_rec <= RB_SCAN_ROWS_MEAN_MAX) {
+        if (ctx->scan_list_cap < b->n_rec) { // (grows with the largest batch seen: four bytes per record)
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->scan_list) hipFree(ctx->scan_list);
+            ctx->scan_list = nullptr, ctx->scan_list_cap = 0;
+            const uint64_t cap = b->n_rec + b->n_rec / 4 + 1024;
+            if (hipMalloc(&ctx->scan_list, 256 + cap * 4) == hipSuccess) ctx->scan_list_cap = cap;
+            else (void)hipGetLastError();
+        }
+        if (ctx->scan_list) {
+            HIPCHK(ctx, rb_fill_async(ctx->scan_list, 0, 8, ctx->stream));
+            HIPCHK(ctx, rb_launch_scan_rows(&p, ctx->scan_list, ctx->stream));
+            return RB_OK;
+        }
+    }
     HIPCHK(ctx, rb_launch_scan_records(&p, ctx->stream));
     return RB_OK;
 }
@@ -1252,6 +1277,7 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     if (ctx->trim_pend_cap < n_pairs) { // (grows with the largest pass seen; a few bytes per pair)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->trim_pend) hipFree(ctx->trim_pend);
+    if (ctx->scan_list) hipFree(ctx->scan_list);
         ctx->trim_pend = nullptr, ctx->trim_pend_cap = 0;
         const uint64_t cap = n_pairs + n_pairs / 4 + 1024;
         if (hipMalloc(&ctx->trim_pend, 256 + cap * 4) == hipSuccess) ctx->trim_pend_cap = cap;

@@ -19,50 +19,6 @@
 // behind it: the wave-per-pair kernel with its larger regions, then the serial one.
 #include "rb_trim.h"
 
-#define RB_DPP_ROW_SHL(n) (0x100 + (n))
-#define RB_DPP_ROW_ROR(n) (0x120 + (n))
-
-// ---- a row of 16 lanes ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t rb_row_scan_incl(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(1), 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(2), 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(4), 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHR(8), 0xf, 0xf, false);
-    return v;
-}
-__device__ __forceinline__ uint32_t rb_row_sum(uint32_t v) { // every lane of the row gets the row's sum
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(8), 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(4), 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(2), 0xf, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(1), 0xf, 0xf, false);
-    return v;
-}
-// lane 15 of the row, to every lane of it.  As inline assembly: through the builtin the compiler folds the move into the instruction
-// that uses it (v_subrev_u32_dpp ... row_newbcast:15 bound_ctrl:1), and that form returned the lane's OWN value on the MI355X boxes of
-// round 6 (the plain v_mov_b32_dpp is right).  The s_nop covers the two wait states between a VALU write and a DPP read of a register,
-// which the compiler's hazard pass does not see inside an asm.
-__device__ __forceinline__ uint32_t rb_row_last(uint32_t v) {
-    uint32_t r;
-    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
-    return r;
-}
-__device__ __forceinline__ uint32_t rb_row_next(uint32_t v) { // lane + 1 of the row; lane 15 gets 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_SHL(1), 0xf, 0xf, true);
-}
-__device__ __forceinline__ uint32_t rb_row_ror(uint32_t v, int n) {
-    switch (n) {
-    case 8: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(8), 0xf, 0xf, false);
-    case 4: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(4), 0xf, 0xf, false);
-    case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(2), 0xf, 0xf, false);
-    default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, RB_DPP_ROW_ROR(1), 0xf, 0xf, false);
-    }
-}
-// the row's 16 bits of a wave ballot (lanes of other rows that sit in other branches do not matter: their bits are cut off)
-#define rb_row_ballot(pred, gbase) ((uint32_t)(rb_ballot(pred) >> (gbase)) & 0xFFFFu)
-__device__ __forceinline__ uint32_t rb_row_read(uint32_t v, uint32_t gbase, uint32_t l) { // lane l (row-uniform, 0 .. 15) of the row
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((gbase + l) << 2), (int)v);
-}
-
 // ---- a record's region in LDS -----------------------------------------------------------------------------------------------------
 template <int T>
 struct rb_q4_slab {
