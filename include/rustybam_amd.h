@@ -108,7 +108,16 @@ enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY
         * that collects the pieces first: the ops are read once).  The caller must look at counters->redo_two_walk afterwards: set,
         * the batch holds something this path does not take (an irregular record, a boundary the fast path cannot
         * resolve), the results are incomplete and the call is to be repeated without this flag (rb_host_break does). */
-       RB_BREAK_ONE_WALK = 128 };
+       RB_BREAK_ONE_WALK = 128,
+       /* RB_LIFT_OP_STARTS (rb_dev_liftover, rb_dev_break; not with RB_LIFT_FUSED_SCAN): the batch is one that trim-paf has cut IN PLACE
+        * (rb_dev_overlap_split with RB_TRIM_IN_PLACE + rb_dev_apply_pairs): batch->op_off[r] is where record r starts and says nothing
+        * about where it ends, every extent comes from norm_rows (first_op, n_ops), which must be the finished rows of that batch.
+        * The plan is the one built from the op offsets the batch had BEFORE the passes (records only shrink inside their old
+        * extents, so its tiles still hold).  With it the README pipeline trim-paf | break-paf needs no rb_dev_gather_records
+        * between the two: the clip kernels stream over the gaps the cuts left between the records of a tile.  A record a pass has
+        * MOVED (an irregular record's clip, written behind the ops in use) must lie below batch->n_ops = the plan's op count: if the
+        * passes moved any, gather first. */
+       RB_LIFT_OP_STARTS = 1 << 20 };
 
 /* rb_norm_row.flags / rb_reduce_row.flags */
 enum {

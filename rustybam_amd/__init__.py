@@ -6,4 +6,4 @@ it never falls back to a CPU implementation: if the library or a gfx950 device i
 raise.
 """
 from .capi import (Engine, RbError, lib, lib_path, HIT_DT, NORM_DT, REDUCE_DT, COUNTERS_DT, PAIR_DT,  # noqa: F401
-                   BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, LIFT_DESCRIPTORS, LIFT_FUSED_SCAN, BREAK_ONE_WALK, TRIM_IN_PLACE, HIT_INSIDE, HIT_GENERIC, HIT_DESCRIPTOR, NF_COVERED, RD_OK, RD_FILTERED, RD_BAD_CIGAR, RD_SEQ_SHORT, exported_symbols, declared_symbols)
+                   BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, LIFT_DESCRIPTORS, LIFT_FUSED_SCAN, LIFT_OP_STARTS, BREAK_ONE_WALK, TRIM_IN_PLACE, HIT_INSIDE, HIT_GENERIC, HIT_DESCRIPTOR, NF_COVERED, RD_OK, RD_FILTERED, RD_BAD_CIGAR, RD_SEQ_SHORT, exported_symbols, declared_symbols)

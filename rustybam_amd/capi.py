@@ -12,6 +12,7 @@ HEADER = os.path.join(ROOT, "include", "rustybam_amd.h")
 
 BSEARCH_MODERN, BSEARCH_LEGACY, LIFT_EARLY_EXIT, LIFT_DESCRIPTORS, LIFT_FUSED_SCAN = 0, 1, 16, 32, 64
 TRIM_IN_PLACE = 256  # rb_dev_overlap_split on a resident batch (out_ops = the batch's ops): regular records are cut where they are, not copied
+LIFT_OP_STARTS = 1 << 20  # rb_dev_liftover / rb_dev_break on a batch trim-paf has cut in place: op_off is a table of starts, extents come from the norm rows
 BREAK_ONE_WALK = 128  # rb_dev_break: the clip kernel finds the long indels itself; look at counters redo_two_walk afterwards
 HIT_INSIDE, HIT_GENERIC, HIT_DESCRIPTOR = 1, 2, 4
 NF_COVERED = 0x80000000

@@ -1078,6 +1078,9 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.diag_stamps = (uint32_t *)(ws + w.diag_stamps); // (diagnostics: every generic walk from the record's first op, as before round 3)
     p.jobs = (rb_job *)(ws + w.jobs);
     p.fused = (policy & RB_LIFT_FUSED_SCAN) ? 1 : 0;
+    p.op_starts = (policy & RB_LIFT_OP_STARTS) ? 1 : 0;
+    if (p.op_starts && p.fused) return fail(ctx, RB_E_INVALID, "RB_LIFT_OP_STARTS takes finished norm_rows: not together with RB_LIFT_FUSED_SCAN");
+    if (p.op_starts && b->n_ops > plan->n_ops) return fail(ctx, RB_E_INVALID, "RB_LIFT_OP_STARTS: batch->n_ops exceeds the plan's op count (gather the batch first)");
     p.norm_w = const_cast<rb_norm_row *>(norm);
     p.pend_list = (uint32_t *)(ws + w.pend_list);
     p.pend_count = (unsigned long long *)(ws + w.pend_count);
@@ -1277,7 +1280,6 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     if (ctx->trim_pend_cap < n_pairs) { // (grows with the largest pass seen; a few bytes per pair)
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->trim_pend) hipFree(ctx->trim_pend);
-    if (ctx->scan_list) hipFree(ctx->scan_list);
         ctx->trim_pend = nullptr, ctx->trim_pend_cap = 0;
         const uint64_t cap = n_pairs + n_pairs / 4 + 1024;
         if (hipMalloc(&ctx->trim_pend, 256 + cap * 4) == hipSuccess) ctx->trim_pend_cap = cap;

@@ -36,6 +36,7 @@
 #define RBT_CP (RBT_OPS / 8) // one checkpoint per lane and step
 #define RBT_REC 32           // records per tile at most
 #define RBT_HITS 64          // hits (liftover) / pieces (break-paf) per tile at most: one lane each
+#define RBT_GAP_MAX 1024u    // RB_LIFT_OP_STARTS: ops between two records of a tile at most (more: the per-record kernel takes the tile)
 #ifndef RBT_RING_BASE
 #define RBT_RING_BASE 80
 #endif
@@ -94,6 +95,7 @@ __device__ __forceinline__ void rb_tile_body() {
     __shared__ uint32_t cp_all[4][3][RBT_CP];
     __shared__ uint32_t bq_all[4][RBT_CP / 4];  // per chunk of 8 ops: where in it a record starts (8: nowhere), one byte each
     __shared__ uint32_t hr_all[4][RBT_HITS];    // set-up scratch: the record of every hit
+    __shared__ uint32_t gq_all[4][RBT_CP / 4];  // RB_LIFT_OP_STARTS: per chunk of 8 ops, the ops that lie in a gap between two records, one bit each
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const uint32_t tile = blockIdx.x * 4u + wib;
     if (tile >= p.n_tiles) return;
@@ -101,6 +103,7 @@ __device__ __forceinline__ void rb_tile_body() {
     uint32_t *cpR = cp_all[wib][0], *cpQ = cp_all[wib][1], *cpU = cp_all[wib][2];
     uint8_t *bq_s = reinterpret_cast<uint8_t *>(bq_all[wib]);
     uint32_t *hr_s = hr_all[wib];
+    uint8_t *gq_s = reinterpret_cast<uint8_t *>(gq_all[wib]);
     uint32_t ra = rb_first(p.tile_first[3u * tile]);
     uint32_t nrec = rb_first(p.tile_first[3u * tile + 1u]);
     const uint32_t slot0 = rb_first(p.tile_first[3u * tile + 2u]); // (the jobs of a tile's records lie side by side)
@@ -127,7 +130,10 @@ __device__ __forceinline__ void rb_tile_body() {
     bool isrec = (uint32_t)lane < nrec;
     const uint32_t r = ra + (isrec ? (uint32_t)lane : 0u);
     const uint32_t slot = slot0 + (isrec ? (uint32_t)lane : 0u);
-    const uint64_t oo0 = p.op_off[r], oo1 = p.op_off[r + 1];
+    // RB_LIFT_OP_STARTS (a batch trim-paf has cut in place, include/rustybam_amd.h): op_off is a table of starts, a record's extent is its
+    // row's (the job's), and the records of a tile lie one behind the other with GAPS between them -- what the clips left of their ends
+    const bool starts = p.op_starts != 0;
+    const uint64_t oo0 = p.op_off[r], oo1 = starts ? 0ull : p.op_off[r + 1];
     uint32_t jflags, jn, jnh, jlo, jh0;
     uint64_t jrec0, t_st, t_en;
     {
@@ -163,7 +169,7 @@ __device__ __forceinline__ void rb_tile_body() {
         const bool passive = !BRK && (jflags & (RB_JOB_VALID | RB_JOB_ROWS_OVERFLOW)) == 0u && jnh == 0u; // (no window overlaps it and nothing is to be verified: its ops only run past)
         const uint64_t sR = t_en - t_st, sQ = q_en - q_st;
         bool ok = (active || passive) && (jflags & RB_JOB_REGULAR) != 0u && (BRK || explicit_w || (jflags & RB_JOB_MONO) != 0u) &&
-                  jrec0 == oo0 && (uint64_t)jn == oo1 - oo0 && jn >= 8u && t_en >= t_st && q_en >= q_st && sR < (1ull << 31) && sQ < (1ull << 31);
+                  (starts || (jrec0 == oo0 && (uint64_t)jn == oo1 - oo0)) && jn >= 8u && t_en >= t_st && q_en >= q_st && sR < (1ull << 31) && sQ < (1ull << 31);
         spanR = isrec ? (uint32_t)sR : 0u, spanQ = isrec ? (uint32_t)sQ : 0u;
         if (!isrec) ok = true, active = false;
         const uint64_t tot = rb_wave_sum_u64(isrec ? sR + sQ : 0ull); // (U <= R + Q: below 2^32 every running total of the tile is exact)
@@ -175,7 +181,21 @@ __device__ __forceinline__ void rb_tile_body() {
     const uint32_t PassR = rb_wave_scan_incl(spanR) - spanR; // where record j starts in the tile's running reference total, if its CIGAR sums to its header
     const uint64_t g_first = rb_first64(jrec0);              // (lane 0: the tile's first op)
     const uint64_t g0 = g_first & ~31ull;
-    const uint64_t gend = rb_first64(rb_readlane<uint64_t>(oo1, (int)nrec - 1));
+    const uint64_t gend = rb_first64(rb_readlane<uint64_t>(jrec0 + jn, (int)nrec - 1));
+    // the gap in front of record j (lane j): its ops are streamed like everybody else's and count for nothing
+    uint32_t gap = 0;
+    bool has_gaps = false;
+    if (starts) {
+        const uint64_t end_prev = __shfl_up(jrec0 + jn, 1, 64);
+        const bool mine = isrec && lane != 0;
+        const bool bad_order = mine && (jrec0 < end_prev || jrec0 - end_prev > RBT_GAP_MAX);
+        if (rb_ballot(bad_order) != 0ull || gend < g_first) { // (a record that was moved elsewhere, or an extent nobody should stream)
+            fallback();
+            return;
+        }
+        gap = mine ? (uint32_t)(jrec0 - end_prev) : 0u;
+        has_gaps = rb_ballot(gap != 0u) != 0ull;
+    }
     const uint32_t n_tile = (uint32_t)(gend - g_first);
     const uint32_t n_steps = (uint32_t)((gend - g0 + 511u) >> 9);
     if (n_steps > RBT_STEPS) { // (rb_plan_create does not make such a tile)
@@ -269,6 +289,15 @@ __device__ __forceinline__ void rb_tile_body() {
     // where records start inside a chunk (the first record's start is the tile's: nothing to tell)
     for (uint32_t k = (uint32_t)lane; k < RBT_CP / 4; k += 64u) bq_all[wib][k] = 0x08080808u;
     if (isrec && lane != 0) bq_s[rel0 >> 3] = (uint8_t)(rel0 & 7u);
+    // which ops of a chunk are gap ops, one bit each (a chunk holds ops of one gap at most: records are 8 ops and more)
+    if (has_gaps) {
+        for (uint32_t k = (uint32_t)lane; k < RBT_CP / 4; k += 64u) gq_all[wib][k] = 0u;
+        for (uint32_t a = rel0 - gap; a < rel0;) { // (lanes without a gap: no trip)
+            const uint32_t c = a >> 3, e = (c + 1u) << 3 < rel0 ? (c + 1u) << 3 : rel0;
+            gq_s[c] = (uint8_t)(((1u << (e - (c << 3))) - 1u) & ~((1u << (a & 7u)) - 1u));
+            a = e;
+        }
+    }
 
     uint32_t *const out_ops_ = p.out_ops;
     const uint64_t slot_stride_ = p.slot_stride;
@@ -341,6 +370,17 @@ __device__ __forceinline__ void rb_tile_body() {
                 const bool ok = (uint32_t)(idx0 + q) < n_tile;
                 c[q] = ok ? w[q] : ((q & 1) ? 0x12u : 0x11u);
                 w[q] = ok ? w[q] : 0u;
+            }
+        }
+        if (has_gaps) { // gap ops: zero for the sums, an alternating I / D of length 1 for the verification, like the neighbours' ops at the edges
+            const uint32_t gm = gq_s[(st << 6) + (uint32_t)lane];
+            if (rb_ballot(gm != 0u) != 0ull) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const bool ok = !((gm >> q) & 1u);
+                    c[q] = ok ? c[q] : ((q & 1) ? 0x12u : 0x11u);
+                    w[q] = ok ? w[q] : 0u;
+                }
             }
         }
         const uint32_t bqv = bq_s[(st << 6) + (uint32_t)lane]; // the op of my 8 at which a record starts (8: none)
@@ -517,9 +557,10 @@ __device__ __forceinline__ void rb_tile_body() {
         const uint4 g0_ = gq[0], g1_ = gq[1];
         const uint32_t g[8] = {g0_.x, g0_.y, g0_.z, g0_.w, g1_.x, g1_.y, g1_.z, g1_.w};
         PR = cpR[cj], PQ = cpQ[cj], PU = cpU[cj];
+        const uint32_t gmj = has_gaps ? (uint32_t)gq_s[cj] : 0u; // (the ops in front of it that lie in the gap count for nothing, as in the stream)
 #pragma unroll
         for (int q = 0; q < 7; q++) {
-            const uint32_t len = (uint32_t)q < bqj ? rb_len(g[q]) : 0u;
+            const uint32_t len = ((uint32_t)q < bqj && !((gmj >> q) & 1u)) ? rb_len(g[q]) : 0u;
             PR += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFFDFFFDu, g[q], 1u);
             PQ += len & (uint32_t)__builtin_amdgcn_sbfe((int)0xFFF3FFF3u, g[q], 1u);
             PU += len;

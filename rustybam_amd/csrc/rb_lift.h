@@ -120,6 +120,9 @@ struct rb_lift_params {
     uint32_t n_tiles;
     uint32_t *fb_list;             // [n_rec]
     unsigned long long *fb_count;
+    // RB_LIFT_OP_STARTS: op_off[r] is where record r starts, nothing more (op_off[r + 1] says nothing about its end): a batch that
+    // trim-paf has cut in place.  Extents come from norm[] alone; the tile kernel streams over the gaps between a tile's records.
+    int op_starts;
 };
 #define RB_GCP 64u
 struct __attribute__((aligned(64))) rb_gja { // half A of a generic hit's descriptor

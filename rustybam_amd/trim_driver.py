@@ -146,6 +146,7 @@ class ResidentTrim:
         self.n = len(op_off) - 1
         n_ops = int(op_off[-1])
         self.n_ops0 = n_ops
+        self.op_off_host = np.ascontiguousarray(op_off, dtype=np.uint64)  # (as the batch came: what a plan for RB_LIFT_OP_STARTS is built from)
         cap = int(n_ops * (1.0 + room_factor)) + 4096
         self._own = capi.DevBuf(eng, torch, cap + 64, torch.int32, device=dev)         # [original ops | room for the clips of the passes], from the
         self.d_ops = self._own.t                                             # library's allocator (2 MB physical chunks: DESIGN.md section 3)
@@ -187,6 +188,8 @@ class ResidentTrim:
         (pairs, ms of the selection, ms of the pair kernels, ms of apply + check) from HIP events on the engine's stream."""
         torch, eng, dev = self.torch, self.eng, self.dev
         n_groups, d_order, d_grp, d_cont, d_l, d_r, d_po, d_rows, d_pass, d_scr = self._pass_buffers()
+        d_cont.zero_(), d_pass.zero_()  # (the buffers are kept between calls: a second run() starts from zeros like the first)
+        self._by_wave = None
         ev_log = []
         for _ in range(max_passes):
             if check_host:

@@ -47,11 +47,28 @@ class DevBatch:
         self.d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
         return self
 
+    @classmethod
+    def from_trimmed(cls, torch, eng, dev, T):
+        """the batch of a trim_driver.ResidentTrim as its passes left it -- cut in place, op_off a table of starts, the extents in the norm
+        rows -- for rb_dev_liftover / rb_dev_break with RB_LIFT_OP_STARTS: no rb_dev_gather_records in between.  The plan comes from the
+        op offsets the batch had before the passes.  Only valid while no pass has moved a record (T.pairs_by_wave == T.pairs_done)."""
+        self = cls.__new__(cls)
+        self.torch, self.eng, self.dev = torch, eng, dev
+        self.n_rec, self.n_ops = T.n, T.n_ops0
+        self.op_off_host = np.ascontiguousarray(T.op_off_host, dtype=np.uint64)
+        self.contig_host = np.zeros(self.n_rec, np.uint32)
+        self.d_ops, self.d_off, self.d_c, self.d_strand, self.d_contig, self.d_norm = T.d_ops, T.d_off, T.d_c, T.d_strand, T.d_contig, T.d_norm
+        self.view = eng.batch_view(self.n_rec, self.n_ops, self.d_ops.data_ptr(), self.d_off.data_ptr(), *[x.data_ptr() for x in self.d_c],
+                                   self.d_strand.data_ptr(), self.d_contig.data_ptr())
+        self.d_cnt = torch.zeros(64, dtype=torch.uint8, device=dev)
+        self.norm_ready = True
+        return self
+
     def run(self, windows=None, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN, max_size=None, rows_cap=None, out_cap=None):
         """liftover over `windows` = (w_contig, w_st, w_en), or break-paf when max_size is given.  Returns (rows tensor [n, 16] int32,
         out tensor, counters) with the buffers left on the device."""
         torch, eng, dev = self.torch, self.eng, self.dev
-        if not (policy & rustybam_amd.LIFT_FUSED_SCAN):
+        if not (policy & rustybam_amd.LIFT_FUSED_SCAN) and not getattr(self, "norm_ready", False):
             torch.cuda.synchronize()
             eng.dev_scan_records(self.view, 0, self.d_norm.data_ptr())
         plan = eng.plan_create(self.op_off_host, self.contig_host, *(windows if windows is not None else (None, None, None)))
@@ -104,3 +121,38 @@ class DevBatch:
         words = np.where((r["flags"] & rustybam_amd.HIT_DESCRIPTOR) != 0, 4, r["out_n"]).astype(np.uint64)
         hi = int((r["out_off"][ok] + words[ok]).max()) if ok.any() else 0
         return r, out[:hi].cpu().numpy().view(np.uint32)
+
+
+def config4_resident(torch, eng, dev, n, seed=0x5EED0004, lo=300, hi=700, room_factor=1.6, strands="random"):
+    """SURVEY 8d config 4's shape, resident in HBM: n records (a multiple of 4) of lo..hi synthetic ops, 4 records per query whose
+    consecutive query spans overlap by U[100, 10000] bases (nothing contained).  Returns (ResidentTrim before its passes, host dict of
+    the coordinates / strands / op counts / op offsets)."""
+    from rustybam_amd import workload as wl, trim_driver
+    n = n // 4 * 4
+    nops = wl.n_ops(seed, 0, n, lo, hi)
+    op_off = wl.op_offsets(nops)
+    total_ops = int(op_off[-1])
+    d_off = _i64(torch, dev, op_off)
+    d_ops = torch.empty(total_ops + 64, dtype=torch.int32, device=dev)
+    eng.dev_synth_fill_ops(seed, 0, n, d_off.data_ptr(), d_ops.data_ptr())
+    zeros = torch.zeros(n, dtype=torch.int64, device=dev)
+    d_red = torch.empty(n * 72, dtype=torch.uint8, device=dev)
+    v0 = eng.batch_view(n, total_ops, d_ops.data_ptr(), d_off.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), zeros.data_ptr(), zeros.data_ptr(),
+                        torch.full((n,), ord("+"), dtype=torch.uint8, device=dev).data_ptr(), torch.zeros(n, dtype=torch.int32, device=dev).data_ptr())
+    torch.cuda.synchronize()
+    eng.dev_scan_records(v0, d_red.data_ptr(), 0)
+    torch.cuda.synchronize()
+    red = d_red.cpu().numpy().view(rustybam_amd.REDUCE_DT)
+    tb, qb = red["t_bases"].astype(np.uint64), red["q_bases"].astype(np.uint64)
+    rng = np.random.default_rng(seed)
+    q_st = np.zeros(n, np.uint64)
+    ov = rng.integers(100, 10001, n).astype(np.uint64)
+    for j in range(1, 4):
+        prev_en = q_st[j - 1::4] + qb[j - 1::4]
+        q_st[j::4] = prev_en - np.minimum(ov[j::4], np.minimum(qb[j - 1::4], qb[j::4]) // np.uint64(2))
+    q_en = q_st + qb
+    t_st = rng.integers(0, 200_000_000, n).astype(np.uint64)
+    t_en = t_st + tb
+    strand = (np.where(rng.integers(0, 2, n) == 0, ord("+"), ord("-")) if strands == "random" else np.full(n, ord(strands))).astype(np.uint8)
+    T = trim_driver.ResidentTrim(eng, torch, dev, d_ops, op_off, t_st, t_en, q_st, q_en, strand, np.arange(n) // 4, room_factor=room_factor)
+    return T, dict(n=n, nops=nops, op_off=op_off, total_ops=total_ops, t_st=t_st, t_en=t_en, q_st=q_st, q_en=q_en, strand=strand)

@@ -291,3 +291,45 @@ def test_pass_selection_on_the_device_equals_the_reference_scan(engine):
     need = np.array([int(norm["n_ops"][a]) + int(norm["n_ops"][b]) for a, b in pairs], np.int64)
     poff = d_poff[:k].cpu().numpy()
     assert np.array_equal(poff, 1000 + np.concatenate([[0], np.cumsum(need)[:-1]])) and int(ps["ops_end"]) == 1000 + int(need.sum())
+
+
+@pytest.mark.parametrize("n,lo,hi", [(40_000, 300, 700), (60_000, 40, 120), (8_000, 1500, 2600)])
+def test_break_paf_straight_off_the_trimmed_batch(n, lo, hi):
+    """The README pipeline trim-paf | break-paf on a resident batch WITHOUT rb_dev_gather_records between the two (RB_LIFT_OP_STARTS): the
+    passes cut the records in place, op_off becomes a table of starts, and rb_dev_break takes the batch as it lies -- the tile kernel
+    streams over the gaps the cuts left between the records of a tile.  Same rows and the same clips (digest over every op) as the route
+    through the dense copy, with the one-walk kernel and with the two-walk path; config 4's record shape, short records (several dozen
+    records per tile, gaps as long as records) and records above the tile kernel's length."""
+    import torch
+    from devutil import DevBatch, config4_resident
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    eng = rustybam_amd.Engine(0, torch.cuda.current_stream().cuda_stream)
+    T, h = config4_resident(torch, eng, dev, n, lo=lo, hi=hi)
+    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN)
+    assert T.pairs_done >= 2 * (n // 4) and T.pairs_by_wave == T.pairs_done  # (every clip in place: nothing moved)
+    res = {}
+    for name, pol in (("starts one walk", rustybam_amd.LIFT_OP_STARTS | rustybam_amd.BREAK_ONE_WALK), ("starts two walks", rustybam_amd.LIFT_OP_STARTS)):
+        B = DevBatch.from_trimmed(torch, eng, dev, T)
+        rows, out, cnt = B.run(None, max_size=100, rows_cap=6 * n, policy=rustybam_amd.BSEARCH_MODERN | pol)
+        assert not cnt["redo_two_walk"] and not cnt["overflow"], name
+        hr, _ = B.host_rows(rows, out)
+        res[name] = (hr.copy(), B.digest(rows, out), int(cnt["phase"][3]), int(cnt["phase"][4]))
+    d_new, new_off, norm = T.gather()
+    d_c = [torch.from_numpy(np.ascontiguousarray(norm[k]).view(np.int64)).to(dev) for k in ("t_st", "t_en", "q_st", "q_en")]
+    G = DevBatch.from_device(torch, eng, dev, d_new, int(new_off[-1]), new_off, d_c, torch.from_numpy(h["strand"]).to(dev))
+    rows, out, cnt = G.run(None, max_size=100, rows_cap=6 * n, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_FUSED_SCAN | rustybam_amd.BREAK_ONE_WALK)
+    assert not cnt["redo_two_walk"] and not cnt["overflow"]
+    want, _ = G.host_rows(rows, out)
+    want_digest = G.digest(rows, out)
+    for name, (got, dg, tiles, handed_back) in res.items():
+        assert len(got) == len(want), name
+        for k in ("rec", "win", "status", "out_n", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len"):
+            assert np.array_equal(got[k], want[k]), f"{name}: {k}"
+        assert dg == want_digest, name
+        if hi <= 2048:  # (the short-record shape cuts some records below the 8 ops a tile's record needs: their tiles go back, same rows)
+            assert tiles > 0 and (lo < 300 or handed_back <= n // 50), f"{name}: {tiles} tiles, {handed_back} records handed back to the per-record kernel"
+    del B, G, rows, out
+    T.release()
+    torch.cuda.synchronize()
+    eng.close()
