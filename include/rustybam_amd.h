@@ -341,6 +341,11 @@ int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *batch, const rb_norm_
                          const uint32_t *left, const uint32_t *right, const uint64_t *pair_out_off, int match_score,
                          int diff_score, int indel_score, int bsearch_policy, rb_pair_row *rows, uint32_t *out_ops);
 
+/* rb_dev_trim_reserve (optional): rb_dev_overlap_split keeps, per context, a list of the pairs its first kernel leaves to the ones
+ * behind it; the list grows with the largest n_pairs seen, and growing means a stream synchronisation and an allocation inside that
+ * call.  A host that knows how many pairs a pass can have (one per query group) sizes the list up front with this. */
+int rb_dev_trim_reserve(rb_ctx *ctx, uint64_t n_pairs);
+
 /* ---- trim-paf with the batch resident on the device across the passes of Paf::overlapping_paf_recs (paf.rs:210-305) ----------
  * rb_dev_apply_pairs: the records a pass has cut become the batch's current records.  For every pair k with status RB_ST_OK and
  *     side s (0 = left[k], 1 = right[k]):  op_off[rec] = rows[k].out_off[s] and norm_rows[rec] = the clipped record (coordinates,

@@ -173,6 +173,27 @@ def overlap_split(b, left, right, scores=(1, 1, 1), policy=MODERN):
     return rows, _take(ops, no.value, np.uint32)
 
 
+PAIR_CLIP_DT = np.dtype([("split_idx", "<u8"), ("split_score", "<i4"), ("status", "<u4"), ("t_st", "<u8", (2,)), ("t_en", "<u8", (2,)),
+                         ("q_st", "<u8", (2,)), ("q_en", "<u8", (2,)), ("nmatch", "<u4", (2,)), ("aln_len", "<u4", (2,)), ("first", "<u4", (2,)),
+                         ("count", "<u4", (2,)), ("first_len", "<u4", (2,)), ("last_len", "<u4", (2,))])
+PAIR_UNSUPPORTED = 0xFFFFFFFF
+
+
+def overlap_split_opspace(ops, rec_off, rec_n, first_len, last_len, t_st, t_en, q_st, q_en, strand, left, right, scores=(1, 1, 1), n_threads=1):
+    """trim-paf's pair step in op space on record VIEWS (rb_opspace.c): the cut of every pair as a view (first kept op, count, new end
+    lengths) with its coordinates, nmatch, aln_len.  Regular records, modern policy: (rows, number of pairs outside that scope)."""
+    a32, a64 = (lambda x: _arr(x, np.uint32)), (lambda x: _arr(x, np.uint64))
+    ops, rec_off, rec_n, first_len, last_len = a32(ops), a64(rec_off), a32(rec_n), a32(first_len), a32(last_len)
+    t_st, t_en, q_st, q_en, strand, left, right = a64(t_st), a64(t_en), a64(q_st), a64(q_en), _arr(strand, np.uint8), a32(left), a32(right)
+    rows = np.zeros(len(left), dtype=PAIR_CLIP_DT)
+    assert PAIR_CLIP_DT.itemsize == 128  # (sizeof(rbo_pair_clip_row))
+    f = lib().rbo_overlap_split_opspace_arrays
+    f.restype = C.c_int64
+    bad = f(C.c_uint64(len(rec_off)), _p(ops), _p(rec_off), _p(rec_n), _p(first_len), _p(last_len), _p(t_st), _p(t_en), _p(q_st), _p(q_en), _p(strand),
+            C.c_uint64(len(left)), _p(left), _p(right), C.c_int(scores[0]), C.c_int(scores[1]), C.c_int(scores[2]), C.c_int(n_threads), _p(rows))
+    return rows, int(bad)
+
+
 def swap(b):
     out = np.zeros_like(b.ops)
     lib().rbo_swap_arrays(C.c_uint64(b.n), _p(b.ops), _p(b.op_off), _p(b.strand), _p(out))

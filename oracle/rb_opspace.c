@@ -305,3 +305,198 @@ int rbo_break_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t
     }
     return 0;
 }
+
+/* ---- trim-paf's pair step in op space: trim_overlapping_pafs (trim_overlap.rs:36-86: score_of_qpos :6-19 over the overlapped query
+ * bases, the first maximum of prefix(left) + suffix(right) :69-76) followed by truncate_record_by_query on both records
+ * (paf.rs:785-823).  A record comes as a VIEW -- where its kept ops begin in ops[], how many they are, and the lengths its first and
+ * last op have by now (0: as stored) -- so that a caller can carry the passes of Paf::overlapping_paf_recs over a batch it never
+ * rewrites; the answer is the cut as a view again (first kept op, count, new end lengths) with the coordinates, nmatch and aln_len.
+ * Per-base semantics in op space: query offset d of a record lies in the query op i with pQ[i] <= d < pQ[i] + len; its
+ * unit is pU[i] + (d - pQ[i]), but for the LAST base of the op the last unit in front of the next query op (the D / N run behind it:
+ * modern binary search, the last equal element of qpos_aln); a unit scores by the op it lies in.  Written as runs of equal scores over
+ * the overlap, left and right merged, the sum evaluated where either changes.  Scope as above: regular records, modern policy; a pair
+ * outside it (or one whose cut ends in anything but RB_ST_OK) gets status RBO_PAIR_UNSUPPORTED and is counted in the return value.
+ * tests/test_oracle_opspace.py holds it to the per-base oracle. */
+typedef struct {
+    uint32_t n;
+    uint32_t *c, *pR, *pQ, *pU; /* ops with the end lengths applied; exclusive prefixes, n + 1 entries */
+    uint64_t t_st, t_en, q_st, q_en;
+    int minus;
+} pview;
+static int pv_load(pview *v, uint32_t *buf, const uint32_t *ops, uint64_t off, uint32_t n, uint32_t fl, uint32_t ll, uint64_t t_st, uint64_t t_en,
+                   uint64_t q_st, uint64_t q_en, int minus) {
+    v->n = n, v->c = buf, v->pR = buf + n, v->pQ = v->pR + n + 1, v->pU = v->pQ + n + 1;
+    v->t_st = t_st, v->t_en = t_en, v->q_st = q_st, v->q_en = q_en, v->minus = minus;
+    if (n == 0) return 0;
+    memcpy(v->c, ops + off, (size_t)n * 4);
+    if (fl) v->c[0] = (fl << 4) | o_opc(v->c[0]);
+    if (ll) v->c[n - 1] = (ll << 4) | o_opc(v->c[n - 1]);
+    uint64_t R = 0, Q = 0, U = 0;
+    int ok = o_ism(v->c[0]) && o_ism(v->c[n - 1]);
+    for (uint32_t i = 0; i < n && ok; i++) {
+        const uint32_t w = v->c[i];
+        ok = o_regular(w) && o_len(w) >= 1 && (i == 0 || o_opc(w) != o_opc(v->c[i - 1]));
+        v->pR[i] = (uint32_t)R, v->pQ[i] = (uint32_t)Q, v->pU[i] = (uint32_t)U;
+        R += o_rl(w), Q += o_ql(w), U += o_len(w);
+    }
+    v->pR[n] = (uint32_t)R, v->pQ[n] = (uint32_t)Q, v->pU[n] = (uint32_t)U;
+    return ok && U <= 0xFFFFFFFFull && t_en >= t_st && q_en >= q_st && R == t_en - t_st && Q == q_en - q_st;
+}
+static inline int pv_score(uint32_t opc, int ms, int ds, int is) { return opc == 7u ? ms : ((opc == 1u || opc == 2u) ? -is : -ds); } /* trim_overlap.rs:14-18 */
+static uint32_t pv_qop(const pview *v, uint32_t d) { /* the query op that holds query offset d (d < pQ[n]) */
+    uint32_t lo = 0, hi = v->n; /* first i with pQ[i + 1] > d */
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if (v->pQ[mid + 1] > d) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+/* the op whose type the LAST query base of query op i takes: the last op in front of the next query op */
+static uint32_t pv_special(const pview *v, uint32_t i) {
+    uint32_t j = i;
+    while (j + 1 < v->n && o_ql(v->c[j + 1]) == 0) j++;
+    return j;
+}
+/* scores of the query positions st .. en - 1 in rising position order, as runs: len[] / sc[]; returns how many (cap entries at most) */
+static size_t pv_runs(const pview *v, uint64_t st, uint64_t en, int ms, int ds, int is, uint32_t *len, int *sc, size_t cap) {
+    size_t m = 0;
+    uint64_t left = en - st;
+    if (!v->minus) {
+        uint32_t d = (uint32_t)(st - v->q_st), i = pv_qop(v, d);
+        while (left && i < v->n) {
+            const uint32_t l = o_len(v->c[i]), o = d - v->pQ[i];
+            const int own = pv_score(o_opc(v->c[i]), ms, ds, is), sp = pv_score(o_opc(v->c[pv_special(v, i)]), ms, ds, is);
+            uint64_t body = (uint64_t)(l - 1u) - o; /* offsets o .. l - 2 */
+            if (body > left) body = left;
+            if (body && m < cap) len[m] = (uint32_t)body, sc[m++] = own;
+            left -= body;
+            if (left && m < cap) len[m] = 1, sc[m++] = sp, left--;
+            i++;
+            while (i < v->n && o_ql(v->c[i]) == 0) i++;
+            if (i < v->n) d = v->pQ[i];
+        }
+    } else {
+        uint32_t d = (uint32_t)(v->q_en - 1 - st), i = pv_qop(v, d); /* op order runs against the positions */
+        for (;;) {
+            const uint32_t l = o_len(v->c[i]), o = d - v->pQ[i];
+            const int own = pv_score(o_opc(v->c[i]), ms, ds, is), sp = pv_score(o_opc(v->c[pv_special(v, i)]), ms, ds, is);
+            uint64_t body = (uint64_t)o + 1u; /* offsets o .. 0 */
+            if (o == l - 1u) { /* the op's last base (in op order) comes first */
+                if (left && m < cap) len[m] = 1, sc[m++] = sp, left--;
+                body = l - 1u;
+            }
+            if (body > left) body = left;
+            if (body && m < cap) len[m] = (uint32_t)body, sc[m++] = own;
+            left -= body;
+            if (!left || i == 0) break;
+            uint32_t j = i;
+            while (j > 0 && o_ql(v->c[j - 1]) == 0) j--;
+            if (j == 0) break;
+            i = j - 1;
+            d = v->pQ[i] + o_len(v->c[i]) - 1u;
+        }
+    }
+    return left ? (size_t)-1 : m;
+}
+typedef struct { uint32_t k, j; } punit; /* unit k in op j */
+static int pv_q2u(const pview *v, uint64_t p, punit *u) { /* qpos_to_idx (paf.rs:564-574), modern policy */
+    if (p < v->q_st || p >= v->q_en) return 0;
+    const uint32_t d = (uint32_t)(v->minus ? v->q_en - 1 - p : p - v->q_st), i = pv_qop(v, d);
+    if (d + 1u == v->pQ[i] + o_len(v->c[i])) {
+        u->j = pv_special(v, i), u->k = v->pU[u->j + 1] - 1u;
+    } else {
+        u->j = i, u->k = v->pU[i] + (d - v->pQ[i]);
+    }
+    return 1;
+}
+static int pv_match(const pview *v, punit *u, int up) { /* the nearest match-type unit at or above / at or below u (paf.rs:576-590) */
+    if (o_ism(v->c[u->j])) return 1;
+    if (up) {
+        for (uint32_t j = u->j + 1; j < v->n; j++)
+            if (o_ism(v->c[j])) { u->j = j, u->k = v->pU[j]; return 1; }
+        return 0; /* index past the end: the reference panics */
+    }
+    for (uint32_t j = u->j; j > 0; j--)
+        if (o_ism(v->c[j - 1])) { u->j = j - 1, u->k = v->pU[j] - 1u; return 1; }
+    return 0;
+}
+#define RBO_PAIR_UNSUPPORTED 0xFFFFFFFFu
+static int pv_cut(const pview *v, uint64_t a, uint64_t b, rbo_pair_clip_row *row, int s) { /* truncate_record_by_query (paf.rs:785-823) */
+    if (a < v->q_st || b > v->q_en || b == 0 || b <= a) return 0;
+    punit A, B;
+    if (!pv_q2u(v, a, &A) || !pv_q2u(v, b - 1, &B)) return 0;
+    if (!pv_match(v, &A, !v->minus) || !pv_match(v, &B, v->minus)) return 0; /* :792-796 */
+    const uint32_t oa = A.k - v->pU[A.j], ob = B.k - v->pU[B.j];
+    const uint64_t qa = v->minus ? v->q_en - 1 - v->pQ[A.j] - oa : v->q_st + v->pQ[A.j] + oa;
+    const uint64_t qb = v->minus ? v->q_en - 1 - v->pQ[B.j] - ob : v->q_st + v->pQ[B.j] + ob;
+    const uint64_t nq_st = qa, nq_en = qb + 1;
+    if (A.k > B.k) { const punit t = A; A = B; B = t; } /* :799-801 */
+    const uint64_t nt_st = v->t_st + v->pR[A.j] + (A.k - v->pU[A.j]), nt_en = v->t_st + v->pR[B.j] + (B.k - v->pU[B.j]) + 1; /* :802-803 */
+    const uint32_t cnt = B.j - A.j + 1;
+    const uint32_t fl = cnt == 1 ? B.k - A.k + 1u : v->pU[A.j + 1] - A.k, ll = cnt == 1 ? fl : B.k - v->pU[B.j] + 1u;
+    /* the kept ops, summed one by one (check_integrity, paf.rs:825-857; nmatch = M + = + X) */
+    uint64_t R = 0, Q = 0, M = 0, U = 0;
+    for (uint32_t j = A.j; j <= B.j; j++) {
+        const uint32_t w = v->c[j], l = j == A.j ? fl : (j == B.j ? ll : o_len(w)), t = (l << 4) | o_opc(w);
+        R += o_rl(t), Q += o_ql(t), U += l, M += o_ism(t) ? l : 0;
+    }
+    if (nt_en < nt_st || nq_en < nq_st || R != nt_en - nt_st || Q != nq_en - nq_st) return 0; /* (the reference panics: not this port's business) */
+    row->t_st[s] = nt_st, row->t_en[s] = nt_en, row->q_st[s] = nq_st, row->q_en[s] = nq_en;
+    row->nmatch[s] = (uint32_t)M, row->aln_len[s] = (uint32_t)U;
+    row->first[s] = A.j, row->count[s] = cnt, row->first_len[s] = fl, row->last_len[s] = ll;
+    return 1;
+}
+int64_t rbo_overlap_split_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *rec_off, const uint32_t *rec_n, const uint32_t *first_len,
+                                         const uint32_t *last_len, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
+                                         const uint8_t *strand, uint64_t n_pairs, const uint32_t *left, const uint32_t *right, int match_score,
+                                         int diff_score, int indel_score, int n_threads, rbo_pair_clip_row *rows) {
+    int64_t unsupported = 0;
+    if (n_threads < 1) n_threads = 1;
+#pragma omp parallel for schedule(dynamic, 256) num_threads(n_threads) reduction(+ : unsupported)
+    for (uint64_t k = 0; k < n_pairs; k++) {
+        rbo_pair_clip_row *row = &rows[k];
+        memset(row, 0, sizeof *row);
+        row->status = RBO_PAIR_UNSUPPORTED;
+        const uint32_t rl = left[k], rr = right[k];
+        if (rl >= n_rec || rr >= n_rec) { unsupported++; continue; }
+        const size_t nl = rec_n[rl], nr = rec_n[rr];
+        uint32_t *buf = malloc(((nl + 1) * 4 + (nr + 1) * 4 + 8) * 4 + (nl + nr + 8) * 4 * 8); /* two views, then four run arrays of 2 (nl + nr) + 8 entries */
+        pview L, R;
+        int ok = pv_load(&L, buf, ops, rec_off[rl], (uint32_t)nl, first_len[rl], last_len[rl], t_st[rl], t_en[rl], q_st[rl], q_en[rl], strand[rl] == '-') &&
+                 pv_load(&R, buf + (nl + 1) * 4, ops, rec_off[rr], (uint32_t)nr, first_len[rr], last_len[rr], t_st[rr], t_en[rr], q_st[rr], q_en[rr], strand[rr] == '-');
+        const uint64_t st = ok ? (L.q_st > R.q_st ? L.q_st : R.q_st) : 0, en = ok ? (L.q_en < R.q_en ? L.q_en : R.q_en) : 0; /* trim_overlap.rs:43-44 */
+        ok = ok && en > st;
+        if (ok) {
+            const size_t cap = 2 * (nl + nr) + 8;
+            uint32_t *ll_ = (uint32_t *)(buf + (nl + 1) * 4 + (nr + 1) * 4 + 8), *rl_ = ll_ + cap;
+            int *ls_ = (int *)(rl_ + cap), *rs_ = ls_ + cap;
+            /* (room: cap entries of each of the four arrays fit the allocation above) */
+            const size_t ml = pv_runs(&L, st, en, match_score, diff_score, indel_score, ll_, ls_, cap);
+            const size_t mr = pv_runs(&R, st, en, match_score, diff_score, indel_score, rl_, rs_, cap);
+            ok = ml != (size_t)-1 && mr != (size_t)-1;
+            if (ok) {
+                int64_t rsum = 0;
+                for (size_t i = 0; i < mr; i++) rsum += (int64_t)rs_[i] * rl_[i];
+                int64_t best = 0, P = 0; /* trim_overlap.rs:69-76: first maximum of l[0 .. k) + r[k .. n), starting from (0, index 0) */
+                uint64_t best_idx = 0, pos = 0;
+                if (rsum > best) best = rsum;
+                size_t i = 0, j = 0;
+                uint32_t ci = ml ? ll_[0] : 0, cj = mr ? rl_[0] : 0;
+                while (i < ml && j < mr) {
+                    const uint32_t c = ci < cj ? ci : cj;
+                    P += (int64_t)(ls_[i] - rs_[j]) * c, pos += c;
+                    if (rsum + P > best) best = rsum + P, best_idx = pos;
+                    ci -= c, cj -= c;
+                    if (!ci && ++i < ml) ci = ll_[i];
+                    if (!cj && ++j < mr) cj = rl_[j];
+                }
+                row->split_idx = best_idx, row->split_score = (int32_t)best;
+                const uint64_t split = st + best_idx;
+                ok = pv_cut(&L, L.q_st, split, row, 0) && pv_cut(&R, split, R.q_en, row, 1); /* trim_overlap.rs:77-78 */
+            }
+        }
+        if (ok) row->status = 0; else unsupported++;
+        free(buf);
+    }
+    return unsupported;
+}

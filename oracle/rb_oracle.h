@@ -279,6 +279,22 @@ int rbo_overlap_split_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t
                              int match_score, int diff_score, int indel_score, int policy, rbo_pair_row *rows,
                              uint32_t **out_ops, uint64_t *n_out);
 
+/* the same step in op space (rb_opspace.c), on record VIEWS: a record = ops[rec_off[r] ..][rec_n[r]] with its first / last op's length
+ * replaced by first_len[r] / last_len[r] where those are not 0 -- what a pass of trim-paf that cuts in place has made of it.  The cut
+ * comes back as a view as well.  Regular records, modern policy; returns how many pairs fell outside that (status 0xFFFFFFFF). */
+typedef struct rbo_pair_clip_row {
+    uint64_t split_idx;
+    int32_t split_score;
+    uint32_t status;
+    uint64_t t_st[2], t_en[2], q_st[2], q_en[2];
+    uint32_t nmatch[2], aln_len[2];
+    uint32_t first[2], count[2], first_len[2], last_len[2]; /* kept ops: the view's ops [first, first + count), and their new end lengths */
+} rbo_pair_clip_row;
+int64_t rbo_overlap_split_opspace_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *rec_off, const uint32_t *rec_n, const uint32_t *first_len,
+                                         const uint32_t *last_len, const uint64_t *t_st, const uint64_t *t_en, const uint64_t *q_st, const uint64_t *q_en,
+                                         const uint8_t *strand, uint64_t n_pairs, const uint32_t *left, const uint32_t *right, int match_score,
+                                         int diff_score, int indel_score, int n_threads, rbo_pair_clip_row *rows);
+
 /* swap query/target of each record (paf.rs:1068-1094): I<->D, reverse op order on '-' */
 int rbo_swap_arrays(uint64_t n_rec, const uint32_t *ops, const uint64_t *op_off, const uint8_t *strand,
                     uint32_t *out_ops);

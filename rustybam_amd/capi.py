@@ -153,6 +153,9 @@ class Engine:
         self._chk(self.L.rb_ctx_sync(self.ctx), "rb_ctx_sync")
 
     # ---- device-pointer level (bench.py: buffers are torch tensors already resident in HBM) ----
+    def trim_reserve(self, n_pairs):
+        self._chk(self.L.rb_dev_trim_reserve(self.ctx, C.c_uint64(int(n_pairs))), "rb_dev_trim_reserve")
+
     def set_timing(self, on=True):
         self._chk(self.L.rb_ctx_set_timing(self.ctx, C.c_int(1 if on else 0)), "rb_ctx_set_timing")
 

@@ -1248,6 +1248,22 @@ extern "C" int rb_dev_swap(rb_ctx *ctx, const rb_batch_view *b, uint32_t *out_op
     return RB_OK;
 }
 
+static int trim_pend_reserve(rb_ctx *ctx, uint64_t n_pairs) {
+    if (ctx->trim_pend_cap >= n_pairs) return RB_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->trim_pend) hipFree(ctx->trim_pend);
+    ctx->trim_pend = nullptr, ctx->trim_pend_cap = 0;
+    const uint64_t cap = n_pairs + n_pairs / 4 + 1024;
+    if (hipMalloc(&ctx->trim_pend, 256 + cap * 4) == hipSuccess) ctx->trim_pend_cap = cap;
+    else (void)hipGetLastError(); // (without a list the wave-per-pair kernel looks at every pair: slower, same rows)
+    return RB_OK;
+}
+extern "C" int rb_dev_trim_reserve(rb_ctx *ctx, uint64_t n_pairs) {
+    if (!ctx) return RB_E_INVALID;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return trim_pend_reserve(ctx, n_pairs);
+}
+
 extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const rb_norm_row *norm, uint64_t n_pairs, const uint32_t *left,
                                     const uint32_t *right, const uint64_t *pair_out_off, int match_score, int diff_score,
                                     int indel_score, int policy, rb_pair_row *rows, uint32_t *out_ops) {
@@ -1277,13 +1293,9 @@ extern "C" int rb_dev_overlap_split(rb_ctx *ctx, const rb_batch_view *b, const r
     }
     p.scratch = (uint32_t *)ctx->trim_scratch;
     p.scratch_blocks = ctx->trim_scratch_blocks;
-    if (ctx->trim_pend_cap < n_pairs) { // (grows with the largest pass seen; a few bytes per pair)
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->trim_pend) hipFree(ctx->trim_pend);
-        ctx->trim_pend = nullptr, ctx->trim_pend_cap = 0;
-        const uint64_t cap = n_pairs + n_pairs / 4 + 1024;
-        if (hipMalloc(&ctx->trim_pend, 256 + cap * 4) == hipSuccess) ctx->trim_pend_cap = cap;
-        else (void)hipGetLastError();
+    { // (the list grows with the largest pass seen; a few bytes per pair.  rb_dev_trim_reserve takes the growth out of the first pass)
+        const int rc = trim_pend_reserve(ctx, n_pairs);
+        if (rc) return rc;
     }
     p.pend = nullptr, p.pend_list = nullptr;
     if (ctx->trim_pend) {

@@ -178,14 +178,16 @@ class ResidentTrim:
         self.grp_sorted = np.cumsum(np.r_[0, gs[1:] != gs[:-1]])
         self.passes, self.pairs_done, self.pairs_by_wave = 0, 0, 0
 
-    def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000, check_host=False, fetch=True, events=None):
+    def run(self, scores=(1, 1, 1), policy=capi.BSEARCH_MODERN, max_passes=100000, check_host=False, fetch=True, events=None, on_pass=None):
         """the passes of Paf::overlapping_paf_recs (paf.rs:286-288).  Everything of a pass runs on the device: the pair scan and the
         selection (rb_dev_trim_select), the split + clip of the chosen pairs in place (rb_dev_overlap_split, rb_dev_apply_pairs), the
         status check (rb_dev_trim_check); the host reads 64 bytes per pass.  check_host: also run the numpy restatement of the
         selection (select_pairs) on the coordinates of every pass and compare (tests).
         fetch=False: the normalised rows stay on the device when the passes are done (fetch() brings them later: 64 bytes per record,
         640 MB for config 4 -- a consumer that goes on on the device never needs them).  events: a list that receives, per pass,
-        (pairs, ms of the selection, ms of the pair kernels, ms of apply + check) from HIP events on the engine's stream."""
+        (pairs, ms of the selection, ms of the pair kernels, ms of apply + check) from HIP events on the engine's stream.
+        on_pass(i, k, d_left, d_right, d_rows): called after pass i has cut its k pairs (rows = k * 128 bytes, status checked), before the
+        next selection -- tests compare every pair row of a pass with the op-space CPU port there."""
         torch, eng, dev = self.torch, self.eng, self.dev
         n_groups, d_order, d_grp, d_cont, d_l, d_r, d_po, d_rows, d_pass, d_scr = self._pass_buffers()
         d_cont.zero_(), d_pass.zero_()  # (the buffers are kept between calls: a second run() starts from zeros like the first)
@@ -230,6 +232,8 @@ class ResidentTrim:
                 bad = int(d_pass.cpu().numpy().view(capi.TRIM_PASS_DT)[0]["bad_status"])
                 if bad:
                     raise RuntimeError(f"trim pair status {bad}: the reference panics")
+                if on_pass is not None:
+                    on_pass(self.passes - 1, k, d_l, d_r, d_rows)
                 by_wave = (d_rows[: k * 128].view(torch.int64).view(k, 16)[:, 15] == 1).sum()  # (diagnostic word: 1 = wave-per-pair kernel; read at the end)
                 self._by_wave = by_wave if getattr(self, "_by_wave", None) is None else self._by_wave + by_wave
                 self.cursor = (end + 31) // 32 * 32

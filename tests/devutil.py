@@ -156,3 +156,47 @@ def config4_resident(torch, eng, dev, n, seed=0x5EED0004, lo=300, hi=700, room_f
     strand = (np.where(rng.integers(0, 2, n) == 0, ord("+"), ord("-")) if strands == "random" else np.full(n, ord(strands))).astype(np.uint8)
     T = trim_driver.ResidentTrim(eng, torch, dev, d_ops, op_off, t_st, t_en, q_st, q_en, strand, np.arange(n) // 4, room_factor=room_factor)
     return T, dict(n=n, nops=nops, op_off=op_off, total_ops=total_ops, t_st=t_st, t_en=t_en, q_st=q_st, q_en=q_en, strand=strand)
+
+
+class PairPortCheck:
+    """Every pair row of every pass of a ResidentTrim against the op-space CPU port of the pair step (oracle/rb_opspace.c, held to the
+    per-base oracle by tests/test_oracle_opspace.py): the port carries the passes over the ORIGINAL ops as views (start, count, end
+    lengths) -- so the check is independent of what the device wrote into its batch -- and, pass by pass, compares split index and score,
+    both cuts' coordinates, nmatch, aln_len, the kept range (out_off, out_n) and the two end words the device rewrote in place."""
+
+    def __init__(self, oracle, torch, T, ops_host, h, n_threads=32):
+        self.oracle, self.torch, self.T, self.ops, self.n_threads = oracle, torch, T, ops_host, n_threads
+        self.off = h["op_off"][:-1].astype(np.uint64).copy()
+        self.n = np.diff(h["op_off"]).astype(np.uint32)
+        self.fl, self.ll = np.zeros(len(self.n), np.uint32), np.zeros(len(self.n), np.uint32)
+        self.c = {k: h[k].astype(np.uint64).copy() for k in ("t_st", "t_en", "q_st", "q_en")}
+        self.strand = h["strand"]
+        self.pairs = 0
+
+    def __call__(self, i, k, d_l, d_r, d_rows):
+        torch = self.torch
+        left, right = d_l[:k].cpu().numpy().view(np.uint32), d_r[:k].cpu().numpy().view(np.uint32)
+        rows = d_rows[: k * 128].cpu().numpy().view(rustybam_amd.capi.PAIR_DT)
+        got, bad = self.oracle.overlap_split_opspace(self.ops, self.off, self.n, self.fl, self.ll, self.c["t_st"], self.c["t_en"], self.c["q_st"], self.c["q_en"],
+                                                     self.strand, left, right, (1, 1, 1), n_threads=self.n_threads)
+        assert bad == 0, f"pass {i}: {bad} pairs outside the port's scope"
+        assert (rows["status"] == 0).all()
+        for f in ("split_idx", "split_score", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len"):
+            assert np.array_equal(rows[f], got[f]), f"pass {i}: {f} differs from the op-space port"
+        assert np.array_equal(rows["out_n"], got["count"]), f"pass {i}: out_n"
+        for s, rec in ((0, left), (1, right)):
+            first = self.off[rec] + got["first"][:, s]
+            assert np.array_equal(rows["out_off"][:, s], first), f"pass {i}: out_off (side {s})"
+            last = first + got["count"][:, s].astype(np.uint64) - np.uint64(1)
+            want_first = (got["first_len"][:, s].astype(np.uint32) << np.uint32(4)) | (self.ops[first.astype(np.int64)] & np.uint32(15))
+            want_last = (got["last_len"][:, s].astype(np.uint32) << np.uint32(4)) | (self.ops[last.astype(np.int64)] & np.uint32(15))
+            dev = self.T.d_ops.device
+            g_first = self.T.d_ops[torch.from_numpy(first.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
+            g_last = self.T.d_ops[torch.from_numpy(last.astype(np.int64)).to(dev)].cpu().numpy().view(np.uint32)
+            assert np.array_equal(g_first, want_first) and np.array_equal(g_last, want_last), f"pass {i}: the end words of the clips (side {s})"
+            # the port's state: the records as views
+            self.off[rec] = first
+            self.n[rec], self.fl[rec], self.ll[rec] = got["count"][:, s], got["first_len"][:, s], got["last_len"][:, s]
+            for f in self.c:
+                self.c[f][rec] = got[f][:, s]
+        self.pairs += k

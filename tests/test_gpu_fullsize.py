@@ -399,10 +399,12 @@ def test_full_size_config4_trim_paf_then_break_paf(oracle, tmp_path):
     """BASELINE.json configs[3]: trim-paf (scores 1,1,1) -> break-paf --max-size 100 on 1e7 synthetic records
     (300-700 ops, 5e9 ops; 4 records per query whose consecutive query spans overlap by U[100, 10000] bases).  The batch stays in HBM
     from the first byte to the last: the passes of Paf::overlapping_paf_recs run over it in place (trim_driver.ResidentTrim:
-    rb_dev_overlap_split + rb_dev_apply_pairs), rb_dev_gather_records makes it dense, rb_dev_break cuts it.  Properties that need no
-    oracle: no two records of a query overlap any more, every record still passes check_integrity and lies inside the record it
-    came from, every piece of break-paf passes the checks of the config-3 test; and the oracle CLI on the first query groups,
-    line by line, for both commands."""
+    rb_dev_overlap_split + rb_dev_apply_pairs), then break-paf twice: straight off the batch as the passes left it (RB_LIFT_OP_STARTS, the
+    route tools/bench_config4.py measures) and on the dense copy rb_dev_gather_records makes -- same pieces, same digest.  Checked:
+    EVERY pair row of every pass (split, both cuts' coordinates, nmatch, aln_len, the kept range and its rewritten end words) against the
+    op-space CPU port of the pair step; properties that need no oracle -- no two records of a query overlap any more, every record
+    still passes check_integrity and lies inside the record it came from, every piece of break-paf passes the checks of the config-3
+    test; and the per-base oracle CLI on 120 query groups spread over the whole batch, line by line, for both commands."""
     import torch
     from devutil import DevBatch
     from rbtest_util import unpack
@@ -444,8 +446,23 @@ def test_full_size_config4_trim_paf_then_break_paf(oracle, tmp_path):
     group = np.arange(n) // 4
     T = trim_driver.ResidentTrim(eng, torch, dev, d_ops, op_off, t_st, t_en, q_st, q_en, strand, group, room_factor=1.6)
     del d_ops
-    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN)
+    # EVERY pair row of every pass against the op-space CPU port of the pair step (oracle/rb_opspace.c; tests/test_oracle_opspace.py
+    # ties it to the per-base oracle): the port carries the passes over a host copy of the original ops as views
+    from devutil import PairPortCheck
+    ops_host = capi.synth_fill_ops_host(seed, 0, op_off)
+    port = PairPortCheck(oracle, torch, T, ops_host, dict(op_off=op_off, t_st=t_st, t_en=t_en, q_st=q_st, q_en=q_en, strand=strand),
+                         n_threads=min(64, os.cpu_count() or 1))
+    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN, on_pass=port)
     assert T.passes == 3 and T.pairs_done == 3 * (n // 4)         # (0,1) (1,2) (2,3) of every query, one per pass
+    assert port.pairs == T.pairs_done and T.pairs_by_wave == T.pairs_done
+    # ---- break-paf straight off the batch as the passes left it (RB_LIFT_OP_STARTS: no dense copy): its digest, for the route below ----
+    S = DevBatch.from_trimmed(torch, eng, dev, T)
+    srows, sout, scnt = S.run(None, max_size=100, rows_cap=4 * n, policy=rustybam_amd.BSEARCH_MODERN | rustybam_amd.LIFT_OP_STARTS | rustybam_amd.BREAK_ONE_WALK)
+    assert not scnt["redo_two_walk"] and not scnt["overflow"]
+    starts_pieces, starts_digest = int(srows.shape[0]), S.digest(srows, sout)
+    starts_handed_back = int(scnt["phase"][4])
+    del srows, sout, S
+    torch.cuda.empty_cache()
     # ---- no overlap left inside a query ----
     qs, qe = T.q_st.reshape(-1, 4).astype(np.int64), T.q_en.reshape(-1, 4).astype(np.int64)
     assert (qe[:, :-1] <= qs[:, 1:]).all() and (qs < qe).all()
@@ -470,22 +487,24 @@ def test_full_size_config4_trim_paf_then_break_paf(oracle, tmp_path):
     torch.cuda.empty_cache()
     rows, out, cnt = B.run(None, max_size=100, rows_cap=4 * n)
     rows_ok = _check_break_rows(torch, dev, rows, out, n)
-    # ---- the oracle CLI on the first query groups: trim-paf, then break-paf of its output ----
-    k = 4 * 120
-    so = wl.op_offsets(nops[:k])
-    sops = capi.synth_fill_ops_host(seed, 0, so)
+    # the route without the dense copy cut the same pieces: same count, same digest over every row and every clipped op
+    assert starts_pieces == int(rows.shape[0]) and starts_digest == B.digest(rows, out) and starts_handed_back <= n // 1000
+    # ---- the oracle CLI on 120 query groups spread over the whole batch (every (n / 480)-th group): trim-paf, then break-paf of its output ----
+    step = max(1, (n // 4) // 120)
+    recs = np.concatenate([np.arange(4 * g, 4 * g + 4) for g in range(0, n // 4, step)][:120])
+    k = len(recs)
     paf = tmp_path / "c4.paf"
     with open(paf, "w") as f:
-        for r in range(k):
-            cg = unpack(sops[int(so[r]):int(so[r + 1])])
+        for r in recs:
+            cg = unpack(ops_host[int(op_off[r]):int(op_off[r + 1])])
             f.write(f"q{r // 4:07d}\t{int(q_en[r // 4 * 4 + 3]) + 1000}\t{int(q_st[r])}\t{int(q_en[r])}\t{chr(strand[r])}\tchr1\t250000000\t"
                     f"{int(t_st[r])}\t{int(t_en[r])}\t0\t0\t60\tcg:Z:{cg}\n")
+    del ops_host
     rc, otrim = oracle.cli("trim-paf", paf)
     assert rc == 0
-    new_ops = d_new[:int(new_off[k])].cpu().numpy().view(np.uint32)
     mine = []
-    for r in range(k):                                            # (names sort like the record numbers: q0000000, q0000001, ...)
-        cg = unpack(new_ops[int(new_off[r]):int(new_off[r + 1])])
+    for r in recs:                                                # (names sort like the record numbers: q0000000, q0000001, ...)
+        cg = unpack(d_new[int(new_off[r]):int(new_off[r + 1])].cpu().numpy().view(np.uint32))
         mine.append(f"q{r // 4:07d}\t{int(q_en[r // 4 * 4 + 3]) + 1000}\t{int(norm['q_st'][r])}\t{int(norm['q_en'][r])}\t{chr(strand[r])}\tchr1\t250000000\t"
                     f"{int(norm['t_st'][r])}\t{int(norm['t_en'][r])}\t{int(norm['nmatch'][r])}\t{int(norm['aln_len'][r])}\t60\tid:Z:\tcg:Z:{cg}\n")
     assert "".join(mine).encode() == otrim
@@ -493,8 +512,10 @@ def test_full_size_config4_trim_paf_then_break_paf(oracle, tmp_path):
     trimmed.write_bytes(otrim)
     rc, obreak = oracle.cli("break-paf", "--max-size", "100", trimmed)
     assert rc == 0
-    hr = rows_ok[(rows_ok[:, 0].to(torch.int64) & 0xFFFFFFFF) < k].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
-    allr = rows[(rows[:, 0].to(torch.int64) & 0xFFFFFFFF) < k].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
+    in_sample = torch.zeros(n, dtype=torch.bool, device=dev)
+    in_sample[torch.from_numpy(recs).to(dev)] = True
+    hr = rows_ok[in_sample[rows_ok[:, 0].to(torch.int64) & 0xFFFFFFFF]].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
+    allr = rows[in_sample[rows[:, 0].to(torch.int64) & 0xFFFFFFFF]].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
     assert len(allr) >= len(hr)
     mine = []
     for h in hr:
