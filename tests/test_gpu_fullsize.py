@@ -581,8 +581,13 @@ def test_config4_25_contigs_deep_recursion(oracle, tmp_path):
     strand = np.where(rng.integers(0, 2, n) == 0, ord("+"), ord("-")).astype(np.uint8)
     T = trim_driver.ResidentTrim(eng, torch, dev, d_ops, op_off, t_st, t_en, q_st, q_en, strand, group, room_factor=3.0)
     del d_ops
-    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN, check_host=True)
+    from devutil import PairPortCheck                               # (every pair row of every pass against the op-space CPU port)
+    ops_host = capi.synth_fill_ops_host(seed, 0, op_off)
+    port = PairPortCheck(oracle, torch, T, ops_host, dict(op_off=op_off, t_st=t_st, t_en=t_en, q_st=q_st, q_en=q_en, strand=strand),
+                         n_threads=min(64, os.cpu_count() or 1))
+    T.run((1, 1, 1), rustybam_amd.BSEARCH_MODERN, check_host=True, on_pass=port)
     assert T.passes > 6, T.passes                                   # (a group of 9 with two overlaps per record: many rounds)
+    assert port.pairs == T.pairs_done
     # ---- no overlap left inside a query (any two records of a group) ----
     order = np.lexsort((T.q_st.astype(np.int64), group))
     g_s, qs_s, qe_s = group[order], T.q_st[order].astype(np.int64), T.q_en[order].astype(np.int64)
@@ -606,29 +611,31 @@ def test_config4_25_contigs_deep_recursion(oracle, tmp_path):
     torch.cuda.empty_cache()
     rows, out, cnt = B.run(None, max_size=100, rows_cap=4 * n)
     rows_ok = _check_break_rows(torch, dev, rows, out, n)
-    # ---- the oracle CLI on the first query groups ----
-    k = int(np.cumsum(sizes)[150])
-    so = wl.op_offsets(nops[:k])
-    sops = capi.synth_fill_ops_host(seed, 0, so)
-    q_len = {g: int(q_en[group == g].max()) + 1000 for g in range(151)}
+    # ---- the oracle CLI on 151 query groups spread over the whole batch ----
+    ends = np.cumsum(sizes)
+    pick = np.arange(0, len(sizes), max(1, len(sizes) // 151))[:151]
+    recs = np.concatenate([np.arange(ends[g] - sizes[g], ends[g]) for g in pick])
+    q_len = {int(g): int(q_en[ends[g] - sizes[g]:ends[g]].max()) + 1000 for g in pick}
     line = lambda r, qs_, qe_, ts_, te_, nm, al, cg, with_id: (
         f"q{group[r]:07d}\t{q_len[int(group[r])]}\t{qs_}\t{qe_}\t{chr(strand[r])}\t{contigs[contig[r]][0]}\t{contigs[contig[r]][1]}\t{ts_}\t{te_}\t{nm}\t{al}\t60\t"
         + ("id:Z:\t" if with_id else "") + f"cg:Z:{cg}\n")
     paf = tmp_path / "c4b.paf"
     with open(paf, "w") as f:
-        for r in range(k):
-            f.write(line(r, int(q_st[r]), int(q_en[r]), int(t_st[r]), int(t_en[r]), 0, 0, unpack(sops[int(so[r]):int(so[r + 1])]), False))
+        for r in recs:
+            f.write(line(r, int(q_st[r]), int(q_en[r]), int(t_st[r]), int(t_en[r]), 0, 0, unpack(ops_host[int(op_off[r]):int(op_off[r + 1])]), False))
+    del ops_host
     rc, otrim = oracle.cli("trim-paf", paf)
     assert rc == 0
-    new_ops = d_new[:int(new_off[k])].cpu().numpy().view(np.uint32)
     mine = [line(r, int(norm["q_st"][r]), int(norm["q_en"][r]), int(norm["t_st"][r]), int(norm["t_en"][r]), int(norm["nmatch"][r]), int(norm["aln_len"][r]),
-                 unpack(new_ops[int(new_off[r]):int(new_off[r + 1])]), True) for r in range(k)]
+                 unpack(d_new[int(new_off[r]):int(new_off[r + 1])].cpu().numpy().view(np.uint32)), True) for r in recs]
     assert "".join(mine).encode() == otrim                       # (names sort like the group numbers; file order inside a group)
     trimmed = tmp_path / "c4b_trim.paf"
     trimmed.write_bytes(otrim)
     rc, obreak = oracle.cli("break-paf", "--max-size", "100", trimmed)
     assert rc == 0
-    hr = rows_ok[(rows_ok[:, 0].to(torch.int64) & 0xFFFFFFFF) < k].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
+    in_sample = torch.zeros(n, dtype=torch.bool, device=dev)
+    in_sample[torch.from_numpy(recs).to(dev)] = True
+    hr = rows_ok[in_sample[rows_ok[:, 0].to(torch.int64) & 0xFFFFFFFF]].contiguous().cpu().numpy().view(np.uint8).reshape(-1).view(rustybam_amd.HIT_DT)
     mine = [line(int(h["rec"]), int(h["q_st"]), int(h["q_en"]), int(h["t_st"]), int(h["t_en"]), int(h["nmatch"]), int(h["aln_len"]),
                  unpack(out[int(h["out_off"]):int(h["out_off"]) + int(h["out_n"])].cpu().numpy().view(np.uint32)), True) for h in hr]
     assert "".join(mine).encode() == obreak
