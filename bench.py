@@ -769,6 +769,10 @@ def main():
         "output_digest": f"{digest:#018x}", "job_records": int(job_recs), "job_hits": job_hits,
         "hits_per_gpu": n_hits, "ok_hits_per_gpu": n_ok, "out_ops_per_gpu": n_out_ops,
         "generic_hits_per_gpu": int(cnt["n_generic"]),
+        # short records: tiles the step ran (0: none) and the records of tiles the tile kernel handed back to the per-record kernel (streamed
+        # twice: a fallback storm would show here)
+        **({"tiles_per_gpu": int(cnt["phase"][3]), "tile_records_handed_back_per_gpu": int(cnt["phase"][4]),
+            "tile_records_handed_back_frac": round(int(cnt["phase"][4]) / max(1, n_rec), 5)} if not args.debug_skip else {}),
         "roofline": roofline,
         "setup_s": round(gen_s, 2),
         # once per (batch, windows), outside ms_per_step: the host-built plan and the output-sizing calls

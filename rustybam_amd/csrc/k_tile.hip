@@ -323,13 +323,12 @@ __device__ __forceinline__ void rb_tile_body() {
             const unsigned long long bit = 1ull << brk_cnt;
 #pragma unroll
             for (int q = 0; q < RB_MS; q++) cmask[q] = (cmask[q] & ~bit) | ((jl % ns1) == (uint32_t)q ? bit : 0ull);
-        } else {
-            brk_over = true;
-        }
+        } // (no lane left: only a piece that CLOSES there is one too many -- brk_close; one that turns out to hold no reference base is not a piece)
     };
     auto brk_close = [&](const uint32_t rx) { // liftover.rs:191 / :213-224: the open piece ends in front of offset rx, if it holds reference bases
         if (rx > brk_pre) {
             if (brk_cnt < RBT_HITS) Den = rb_writelane(rx, brk_cnt, Den);
+            else brk_over = true; // a 65th piece: the tile goes to the per-record kernel
             brk_cnt++;
         }
     };

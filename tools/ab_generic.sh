@@ -4,20 +4,19 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 what=$1; shift
-cp rustybam_amd/librustybam_amd.so /tmp/keep_g.so
 if [ "$what" = "text" ]; then
   D=/tmp/rb_ab_text; mkdir -p $D
   rustybam_amd/rb synth-paf 0x5EED0003 0 100000 > $D/w.paf; rustybam_amd/rb synth-bed 3000 > $D/w.bed
 fi
 for round in 1 2 3; do
   for n in "$@"; do
-    cp rustybam_amd/variants/$n.so rustybam_amd/librustybam_amd.so
+    export RB_VARIANT=$n  # (rustybam_amd.capi loads variants/<name>.so; the product library is never overwritten)
     if [ "$what" = "nf" ]; then
       python tools/bench_nucfreq.py --steps 5 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$n', 'ms_per_step %.3f' % d['ms_per_step'])"
     else
       rm -rf gpurun_out/ab_text_$n
-      RB_NO_PIPELINE=1 RB_FULL_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_text_$n -o kt -- rustybam_amd/rb liftover --bed $D/w.bed $D/w.paf > $D/out.paf 2>/dev/null
+      LD_PRELOAD=$GRAFT_REPO_ROOT/rustybam_amd/variants/$n.so RB_NO_PIPELINE=1 RB_FULL_EXIT=1 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_text_$n -o kt -- rustybam_amd/rb liftover --bed $D/w.bed $D/w.paf > $D/out.paf 2>/dev/null
       python - $n <<'PY'
 import csv, sys
 n = sys.argv[1]
@@ -27,4 +26,3 @@ PY
     fi
   done
 done
-cp /tmp/keep_g.so rustybam_amd/librustybam_amd.so

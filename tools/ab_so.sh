@@ -3,7 +3,6 @@
 # interleaved rounds (default 4); the same binary differs by +-0.7 ms between two processes on one box (where the driver places the
 # 20 / 30 GB buffers), so min and median over the rounds are what to compare
 cd $GRAFT_REPO_ROOT
-cp rustybam_amd/librustybam_amd.so /tmp/keep.so
 rounds=${AB_ROUNDS:-4}
 rm -f /tmp/ab_times.txt
 # (odd rounds run the variants in the order given, even rounds in reverse: a box whose times creep from process to process -- some
@@ -12,12 +11,11 @@ fwd="$*"; rev=""; for n in "$@"; do rev="$n $rev"; done
 for round in $(seq $rounds); do
   if [ $((round % 2)) -eq 1 ]; then order="$fwd"; else order="$rev"; fi
   for n in $order; do
-    cp rustybam_amd/variants/$n.so rustybam_amd/librustybam_amd.so
+    export RB_VARIANT=$n  # (rustybam_amd.capi loads variants/<name>.so; the product library is never overwritten)
     python bench.py --steps 10 --no-cpu-baseline $AB_ARGS 2>/dev/null | tail -1 | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$n', 'step %.3f' % d['ms_per_step'], 'kernel %.3f' % d['roofline']['kernel_ms'], d.get('output_digest'))" | tee -a /tmp/ab_times.txt
   done
 done
-cp /tmp/keep.so rustybam_amd/librustybam_amd.so
 python - <<'PY'
 import collections, statistics
 t = collections.defaultdict(list)

@@ -3,9 +3,7 @@
 #   tools/r05_variant_check.sh <name> "<AB args>" [rounds]
 cd $GRAFT_REPO_ROOT
 v=$1
-cp rustybam_amd/librustybam_amd.so /tmp/keep_lib.so
-cp rustybam_amd/variants/$v.so rustybam_amd/librustybam_amd.so
+export RB_VARIANT=$v  # (rustybam_amd.capi loads variants/<name>.so; the product library is never overwritten)
 RB_TILE=0 timeout -k 5 1500 python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_imbalance.py tests/test_gpu_digest.py -x -q -m gpu 2>&1 | tail -6
 timeout -k 5 900 python3 -m pytest tests/test_gpu_tile.py -x -q -m gpu 2>&1 | tail -3
-cp /tmp/keep_lib.so rustybam_amd/librustybam_amd.so
 AB_ROUNDS=${3:-3} AB_ARGS="$2" bash tools/ab_so.sh cur $v 2>&1 | tail -8

@@ -4,9 +4,8 @@
 # are meaningless).  Prints the first launch's duration of rb_k_overlap_split_wave<192>.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-cp rustybam_amd/librustybam_amd.so /tmp/keep_c4d.so
 for n in stop0 stop1 stop2 stop3 stop4 stop5 stop0; do
-  cp rustybam_amd/variants/$n.so rustybam_amd/librustybam_amd.so
+  export RB_VARIANT=$n  # (rustybam_amd.capi loads variants/<name>.so; the product library is never overwritten)
   rm -rf gpurun_out/c4d_$n
   RB_C4_ONE_PASS=1 RB_DEBUG_TRIM_NO_SERIAL=1 timeout 200 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/c4d_$n -o kt -- python3 tools/bench_config4.py --records 4000000 > /dev/null 2>&1
   f=$(find gpurun_out/c4d_$n -name "*kernel_trace.csv" | head -1)
@@ -17,4 +16,3 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 print(sys.argv[1], "first launch ms", round((int(rows[0]["End_Timestamp"]) - int(rows[0]["Start_Timestamp"])) / 1e6, 3) if rows else None, "launches", len(rows))
 PY
 done
-cp /tmp/keep_c4d.so rustybam_amd/librustybam_amd.so

@@ -6,8 +6,7 @@ cd $GRAFT_REPO_ROOT
 tag=${1:-decomp}
 mkdir -p gpurun_out/$tag
 # (the production kernel has its diagnostics compiled out: this script wants the -DRB_DIAG=1 build, tools/mkvariant.sh diag -DRB_DIAG=1)
-cp rustybam_amd/librustybam_amd.so /tmp/keep_decomp.so
-cp rustybam_amd/variants/diag.so rustybam_amd/librustybam_amd.so
+export RB_VARIANT=diag  # (rustybam_amd.capi loads variants/<name>.so; the product library is never overwritten)
 for skip in 0 2 1 3 4 64; do
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES --output-format csv -d gpurun_out/$tag/s$skip -o sq -- python3 bench.py --no-box --e2e-records 0 --steps 2 --warmup 1 --no-cpu-baseline --debug-skip $skip > gpurun_out/$tag/s${skip}.log 2>&1
   python3 - "$tag" "$skip" <<'PY' >> gpurun_out/$tag/summary.txt
@@ -23,5 +22,4 @@ print("debug-skip", skip, {k: f"{v:.4g}" for k, v in sorted(best.items())})
 PY
   rm -rf gpurun_out/$tag/s$skip
 done
-cp /tmp/keep_decomp.so rustybam_amd/librustybam_amd.so
 cat gpurun_out/$tag/summary.txt
