@@ -109,7 +109,7 @@ enum { RB_BSEARCH_MODERN = 0 /* rustc >= 1.82 (and < 1.52) */, RB_BSEARCH_LEGACY
         * the batch holds something this path does not take (an irregular record, a boundary the fast path cannot
         * resolve), the results are incomplete and the call is to be repeated without this flag (rb_host_break does). */
        RB_BREAK_ONE_WALK = 128,
-       /* RB_LIFT_OP_STARTS (rb_dev_liftover, rb_dev_break; not with RB_LIFT_FUSED_SCAN): the batch is one that trim-paf has cut IN PLACE
+       /* RB_LIFT_OP_STARTS (rb_dev_liftover, rb_dev_break; not with RB_LIFT_FUSED_SCAN or RB_LIFT_DESCRIPTORS): the batch is one that trim-paf has cut IN PLACE
         * (rb_dev_overlap_split with RB_TRIM_IN_PLACE + rb_dev_apply_pairs): batch->op_off[r] is where record r starts and says nothing
         * about where it ends, every extent comes from norm_rows (first_op, n_ops), which must be the finished rows of that batch.
         * The plan is the one built from the op offsets the batch had BEFORE the passes (records only shrink inside their old

@@ -1080,6 +1080,7 @@ static int lift_common(rb_ctx *ctx, const rb_plan *plan, const rb_batch_view *b,
     p.fused = (policy & RB_LIFT_FUSED_SCAN) ? 1 : 0;
     p.op_starts = (policy & RB_LIFT_OP_STARTS) ? 1 : 0;
     if (p.op_starts && p.fused) return fail(ctx, RB_E_INVALID, "RB_LIFT_OP_STARTS takes finished norm_rows: not together with RB_LIFT_FUSED_SCAN");
+    if (p.op_starts && (policy & RB_LIFT_DESCRIPTORS)) return fail(ctx, RB_E_INVALID, "RB_LIFT_OP_STARTS with RB_LIFT_DESCRIPTORS: a descriptor indexes the record's ORIGINAL cigar, which a batch cut in place no longer is");
     if (p.op_starts && b->n_ops > plan->n_ops) return fail(ctx, RB_E_INVALID, "RB_LIFT_OP_STARTS: batch->n_ops exceeds the plan's op count (gather the batch first)");
     p.norm_w = const_cast<rb_norm_row *>(norm);
     p.pend_list = (uint32_t *)(ws + w.pend_list);

@@ -363,6 +363,9 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
 // fewer than 4, are listed for the kernel above (its list mode).  Same sums, same flags, same rows: rb_scan_finish is shared.
 // ------------------------------------------------------------------------------------------------------------------------------------
 #define RB_SQ_MAX 2048u
+#ifndef RB_SQ_DIAG
+#define RB_SQ_DIAG 0
+#endif
 #define RB_SQ_BATCH 8
 __global__ __launch_bounds__(256) void rb_k_scan_rows(rb_scan_params p, unsigned long long *n_long, uint32_t *long_list) {
     __shared__ unsigned long long hist_all[4][9][64];
@@ -425,8 +428,12 @@ __global__ __launch_bounds__(256) void rb_k_scan_rows(rb_scan_params p, unsigned
                         const uint32_t w = raw[q], opc = w & 15u, len = w >> 4;
                         if (ok) {
                             if (opc <= 8u) {
+#if RB_SQ_DIAG == 1 // (diagnostics, timing only: no LDS add -- what the counters cost)
+                                v_big += len;
+#else
                                 __hip_atomic_fetch_add(&hist[opc][lane], (unsigned long long)len | (1ull << RB_LEN_BITS), __ATOMIC_RELAXED,
                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
                             } else {
                                 v_big |= 8u;
                                 // a continuation word: bits 28.. of the length of the op in front of it (no event of its own)
