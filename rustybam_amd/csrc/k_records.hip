@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
 // Short records, FOUR per wavefront (round 6).  A record of a few hundred ops is one step of the kernel above: a wavefront that waits for
 // its op offsets, then for one load, then sums eighteen quantities over 64 lanes and lets lane 0 write two rows -- 1e7 records of 500 ops
 // took 9.7 ms, a quarter of what their bytes take (profiles/r05_reclen_summary.md).  Here a record is a ROW of 16 lanes (rb_device.h): a
-// lane takes the 16-byte groups gl, gl + 16, ... of its record (a row's load is 256 contiguous bytes), the loads of eight steps are in
+// lane takes the 16-byte groups gl, gl + 16, ... of its record (a row's load is 256 contiguous bytes), the loads of four steps are in
 // flight together, the per-class sums go through the same LDS counters, and the reductions are DPP sums inside the row, so one
 // instruction stream finishes four records and four lanes write their rows side by side.  Records of more than RB_SQ_MAX ops, and of
 // fewer than 4, are listed for the kernel above (its list mode).  Same sums, same flags, same rows: rb_scan_finish is shared.
@@ -366,7 +366,10 @@ __global__ __launch_bounds__(256) void rb_k_scan_records(rb_scan_params p) {
 #ifndef RB_SQ_DIAG
 #define RB_SQ_DIAG 0
 #endif
-#define RB_SQ_BATCH 8
+#ifndef RB_SQ_BATCH
+#define RB_SQ_BATCH 4 // steps of a row whose loads are in flight together (same box, 1e7 records of 300 - 700 ops: 1 -> 4.96 ms, 2 -> 4.47, 3 - 5 -> 4.25 - 4.34,
+                      // 8 -> 4.7 - 4.9, 12 -> 4.95, 16 -> 5.6: registers, i.e. wavefronts per SIMD, are worth more than loads per wavefront)
+#endif
 __global__ __launch_bounds__(256) void rb_k_scan_rows(rb_scan_params p, unsigned long long *n_long, uint32_t *long_list) {
     __shared__ unsigned long long hist_all[4][9][64];
     const int lane = rb_lane();
