@@ -368,7 +368,8 @@ int rb_dev_apply_pairs(rb_ctx *ctx, uint64_t n_pairs, const uint32_t *left, cons
  *     arrays the caller builds once).  Outputs: contained [n_rec] by RECORD (this pass's flags: the ones that count are the last
  *     pass's, :224), the chosen pairs dense in left / right / pair_out_off (room for n_groups each; pair k writes its clips at
  *     pair_out_off[k] >= out_base, n_ops(left) + n_ops(right) apart), and *pass (device memory, 64 bytes): n_pairs, n_deferred (pairs
- *     left for a later pass: the recursion of :286-288 goes on while it is not 0), ops_end (first op behind this pass's clips).
+ *     left for a later pass: the recursion of :286-288 goes on while it is not 0; the exact count as long as no single query group
+ *     leaves more than (2^32 - 1) / n_groups pairs, a lower bound above that), ops_end (first op behind this pass's clips).
  *     scratch: rb_trim_select_scratch_bytes(n_groups).  Then rb_dev_overlap_split + rb_dev_apply_pairs on the n_pairs pairs, and
  *     rb_dev_trim_check folds the pair rows' statuses into pass->bad_status (0: every pair was cut). */
 typedef struct rb_trim_pass {

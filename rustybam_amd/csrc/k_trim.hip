@@ -1164,11 +1164,13 @@ __device__ __forceinline__ void rb_tsel_pair(const rb_tsel_params &p, uint32_t r
         else b.l = rj, b.r = ri;
     }
 }
+template <bool BIG_ONLY> // BIG_ONLY: the groups of up to 16 records have been done by rb_k_trim_select_rows
 __global__ __launch_bounds__(256) void rb_k_trim_select(rb_tsel_params p) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = rb_lane();
-    const bool live = g < p.n_groups;
-    const uint64_t g0 = live ? p.grp_off[g] : 0, m = live ? p.grp_off[g + 1] - g0 : 0;
+    const uint64_t gg0 = g < p.n_groups ? p.grp_off[g] : 0, gm = g < p.n_groups ? p.grp_off[g + 1] - gg0 : 0;
+    const bool live = g < p.n_groups && (!BIG_ONLY || gm > 16u);
+    const uint64_t g0 = live ? gg0 : 0, m = live ? gm : 0;
     for (uint64_t k = 0; k < m && m <= RB_TS_BIG; k++) p.contained[p.order[g0 + k]] = 0;
     rb_tsel_best b = {0, 0, 0, 0};
     uint64_t n_pairs = 0;
@@ -1203,15 +1205,86 @@ __global__ __launch_bounds__(256) void rb_k_trim_select(rb_tsel_params p) {
     }
     if (!live) return;
     p.slot[g] = b.ov ? (uint64_t)p.norm[b.l].n_ops + (uint64_t)p.norm[b.r].n_ops : 0ull;
-    p.has[g] = b.ov ? 1ull : 0ull;
+    // has: 1 for a group with a pair, and in the high half the pairs the group leaves for a later pass (one pair per name and pass, :266-284):
+    // the scan that gives the pairs their dense slots sums those as well (no atomic: 2.5e6 adds to one word were most of a pass's selection)
+    // (a group's share is capped at (2^32 - 1) / n_groups so that the sum cannot leave its 32 bits: n_deferred is 0 exactly when nothing is left,
+    //  and the exact count whenever no single group leaves more than that)
+    const uint64_t dcap = 0xFFFFFFFFull / p.n_groups, dleft = n_pairs > 1 ? n_pairs - 1 : 0ull;
+    p.has[g] = (b.ov ? 1ull : 0ull) | ((dleft < dcap ? dleft : dcap) << 32);
     p.cand[2 * g] = b.l, p.cand[2 * g + 1] = b.r;
-    if (n_pairs > 1) atomicAdd((unsigned long long *)&p.pass->n_deferred, (unsigned long long)(n_pairs - 1)); // (one pair per name and pass, :266-284)
+}
+// The same selection for groups of up to 16 records, a group per ROW of 16 lanes (round 6): lane j holds record j of the group -- ONE read of its
+// norm row, where the thread-per-group form above walks every pair with four strided loads --, the outer index i runs row-uniform, record i's
+// span reaches the lanes by ds_bpermute, lane j keeps the best pair (i, j) it has seen, and the row's best (largest overlap, then the smallest
+// scan order i m + j) falls out of four rotate-and-compare steps.  Groups of more than 16 records are left to the kernel above (big_only).
+__global__ __launch_bounds__(256) void rb_k_trim_select_rows(rb_tsel_params p) {
+    const int lane = rb_lane();
+    const uint32_t gbase = (uint32_t)lane & 48u, gl = (uint32_t)lane & 15u;
+    const uint64_t g = ((uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6)) * 4u + ((uint32_t)lane >> 4);
+    const bool live = g < p.n_groups;
+    const uint64_t g0 = live ? p.grp_off[g] : 0, m64 = live ? p.grp_off[g + 1] - g0 : 0;
+    const bool mine = live && m64 <= 16u; // (row-uniform)
+    const uint32_t m = mine ? (uint32_t)m64 : 0u;
+    const bool have = gl < m;
+    const uint32_t r = have ? p.order[g0 + gl] : 0u;
+    uint64_t st = 0, en = 0;
+    if (have) st = p.norm[r].q_st, en = p.norm[r].q_en;
+    bool cont = false;
+    rb_tsel_best b = {0, 0, 0, 0};
+    uint32_t np = 0; // candidate pairs this lane has seen as their j
+    uint32_t w_m = m; // (the wavefront walks as far as its largest group)
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)w_m, off, 64);
+        w_m = w_m > o ? w_m : o;
+    }
+    w_m = rb_first(w_m);
+    for (uint32_t i = 0; i + 1u < w_m; i++) {
+        // record i of every row's group, to all lanes of the row (rows whose group is shorter see zeros and have no lane behind i)
+        const uint32_t ri = rb_row_read(r, gbase, i);
+        const uint64_t st1 = ((uint64_t)rb_row_read((uint32_t)(st >> 32), gbase, i) << 32) | rb_row_read((uint32_t)st, gbase, i);
+        const uint64_t en1 = ((uint64_t)rb_row_read((uint32_t)(en >> 32), gbase, i) << 32) | rb_row_read((uint32_t)en, gbase, i);
+        const bool pair = have && gl > i && i + 1u < m;
+        const uint64_t mn = en1 < en ? en1 : en, mx = st1 > st ? st1 : st;
+        const bool ovl = pair && mn > mx;                      // bed.rs:74-85
+        const uint64_t ov = ovl ? mn - mx : 0;
+        const bool c2 = ovl && ov == en - st;                  // paf.rs:244-249: record j is contained
+        const bool c1 = ovl && !c2 && ov == en1 - st1;         // ... record i is
+        cont |= c2;
+        if (rb_row_ballot(c1, gbase) != 0u && gl == i) cont = true;
+        if (ovl && !c2 && !c1) {
+            np++;
+            const uint64_t ord = (uint64_t)i * m + gl;
+            if (ov > b.ov || (ov == b.ov && ord < b.ord)) {
+                b.ov = ov, b.ord = ord;
+                if (st1 <= st) b.l = ri, b.r = r; // the smaller q_st is "left" (:252-256)
+                else b.l = r, b.r = ri;
+            }
+        }
+    }
+    // the row's best pair and its number of candidates
+    uint32_t np_row = rb_row_sum(np);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+        const uint64_t oov = ((uint64_t)rb_row_ror((uint32_t)(b.ov >> 32), off) << 32) | rb_row_ror((uint32_t)b.ov, off);
+        const uint64_t oord = ((uint64_t)rb_row_ror((uint32_t)(b.ord >> 32), off) << 32) | rb_row_ror((uint32_t)b.ord, off);
+        const uint32_t ol = rb_row_ror(b.l, off), orr = rb_row_ror(b.r, off);
+        if (oov > b.ov || (oov == b.ov && oov != 0 && oord < b.ord)) b.ov = oov, b.ord = oord, b.l = ol, b.r = orr;
+    }
+    if (have) p.contained[r] = cont ? 1 : 0;
+    if (mine && gl == 0u) {
+        p.slot[g] = b.ov ? (uint64_t)p.norm[b.l].n_ops + (uint64_t)p.norm[b.r].n_ops : 0ull;
+        const uint64_t dcap = 0xFFFFFFFFull / p.n_groups, dleft = np_row > 1u ? np_row - 1u : 0u; // (the cap: rb_k_trim_select)
+        p.has[g] = (b.ov ? 1ull : 0ull) | ((dleft < dcap ? dleft : dcap) << 32); // (high half: pairs left for a later pass)
+        p.cand[2 * g] = b.l, p.cand[2 * g + 1] = b.r;
+    }
 }
 __global__ __launch_bounds__(256) void rb_k_trim_place(rb_tsel_params p) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= p.n_groups) return;
-    const uint64_t k = p.has[g], k1 = p.has[g + 1];
-    if (g + 1 == p.n_groups) p.pass->n_pairs = k1, p.pass->ops_end = p.out_base + p.slot[g + 1];
+    const uint64_t h0 = p.has[g], h1 = p.has[g + 1]; // scanned: low half = pairs in front of the group, high half = deferred pairs in front of it
+    const uint64_t k = h0 & 0xFFFFFFFFull, k1 = h1 & 0xFFFFFFFFull;
+    if (g + 1 == p.n_groups) p.pass->n_pairs = k1, p.pass->n_deferred = h1 >> 32, p.pass->ops_end = p.out_base + p.slot[g + 1];
     if (k1 == k) return; // no pair in this group
     p.left[k] = p.cand[2 * g], p.right[k] = p.cand[2 * g + 1];
     p.pair_out_off[k] = p.out_base + p.slot[g];
@@ -1228,7 +1301,13 @@ extern "C" hipError_t rb_launch_trim_select(const rb_tsel_params *p, uint64_t *b
     if (e != hipSuccess) return e;
     if (p->n_groups == 0) return hipSuccess;
     const unsigned blocks = (unsigned)((p->n_groups + 255) / 256);
-    hipLaunchKernelGGL(rb_k_trim_select, dim3(blocks), dim3(256), 0, stream, *p);
+    static const bool rows_off = getenv("RB_TRIM_SELECT_ROWS") && atoi(getenv("RB_TRIM_SELECT_ROWS")) == 0; // diagnostics: the thread-per-group form for every group
+    if (rows_off) {
+        hipLaunchKernelGGL(rb_k_trim_select<false>, dim3(blocks), dim3(256), 0, stream, *p);
+    } else {
+        hipLaunchKernelGGL(rb_k_trim_select_rows, dim3((unsigned)((p->n_groups + 15) / 16)), dim3(256), 0, stream, *p);
+        hipLaunchKernelGGL(rb_k_trim_select<true>, dim3(blocks), dim3(256), 0, stream, *p);
+    }
     e = rb_launch_exclusive_scan(p->slot, p->n_groups, block_sums, nullptr, stream);
     if (e != hipSuccess) return e;
     e = rb_launch_exclusive_scan(p->has, p->n_groups, block_sums, nullptr, stream);
