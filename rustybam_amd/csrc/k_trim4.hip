@@ -318,7 +318,8 @@ __device__ __forceinline__ uint32_t rb_q4_clip(rb_qrec &v, const rb_q4_slab<T> &
 
 #ifndef RB_Q4_STOP
 #define RB_Q4_STOP 0 // diagnostics (tools/r06_quad_decomp.sh): != 0 ends a pair early -- 1 behind the staging of both records, 2 behind the searches
-                     // of the overlap's end ops, 3 behind the split, 4 behind the left clip; the rows are wrong then, only the time is of interest
+                     // of the overlap's end ops, 3 behind the split, 4 behind the left clip; 9: the whole pair, but a declined pair is listed without the atomic counter
+                     // (measured: 2.41 ms with it, 2.39 - 2.41 without, per 2.5e6 pairs); the rows are wrong then, only the time is of interest
 #endif
 template <int T>
 __device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64_t pi, const uint32_t gbase, const uint32_t gl, const uint32_t g) {
@@ -343,7 +344,11 @@ __device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64
     }
     auto pending = [&](uint32_t why) { // (why: diagnostics, RB_DEBUG_TRIM_NO_SERIAL; whoever does the pair rewrites the whole row)
         if (gl == 0) {
+#if RB_Q4_STOP == 9 // (diagnostics, timing only: what the one counter costs -- the list is garbage)
+            if (!p.only_pending) p.pend_list[pi] = (uint32_t)pi;
+#else
             if (!p.only_pending) p.pend_list[atomicAdd(p.pend, 1ull)] = (uint32_t)pi; // (listed once: by the first attempt)
+#endif
             p.rows[pi].status = RB_ST_PENDING_INTERNAL, p.rows[pi].split_idx = why;
         }
     };
