@@ -76,4 +76,17 @@ for k in ("split_idx", "split_score", "status", "t_st", "t_en", "q_st", "q_en", 
     assert np.array_equal(rows[k], orows[k]), k
 assert np.array_equal(out, oout)
 print(f"config-4 shape: {len(left4)} pairs identical; oracle alone, 1 core: {dt:.2f} s = {len(left4) / dt:.3g} pairs/s")
+# ... and the op-space CPU port of the pair step (oracle/rb_opspace.c, the checker of the full-size test) on the same pairs, timed: what a CPU
+# implementation that does not expand CIGARs achieves (the pairs tiled to a few hundred thousand so that the threads have something to do)
+z4 = np.zeros(n4, np.uint32)
+reps = 200
+L_, R_ = np.tile(left4, reps), np.tile(right4, reps)
+for nt in (1, min(64, os.cpu_count() or 1)):
+    t0 = time.perf_counter()
+    prow, bad = oracle.overlap_split_opspace(ops4, off4[:-1], np.diff(off4).astype(np.uint32), z4, z4, t_st, t_en, q_st, q_en, strand4, L_, R_, (1, 1, 1), n_threads=nt)
+    dt = time.perf_counter() - t0
+    assert bad == 0
+    for k in ("split_idx", "split_score", "t_st", "t_en", "q_st", "q_en", "nmatch", "aln_len"):
+        assert np.array_equal(prow[k][:len(left4)], orows[k]), k
+    print(f"op-space CPU port, {nt} thread(s): {len(L_)} pairs in {dt:.2f} s = {len(L_) / dt:.3g} pairs/s")
 print(f"trim soak ok: {n} cases, {tot} pairs compared")
