@@ -25,9 +25,11 @@ struct rb_q4_slab {
     uint32_t w[16 * T + 4];  // the op words of the region; [m ..] = zero-length M (ends every D / N run, contains nothing)
     uint32_t Qc[16 * T + 4]; // query bases before op i0 + k (absolute); [m ..] = at the region's end
     int32_t SP[16 * T + 4];  // score of the region's query bases before op i0 + k, in op order (rb_tw_stage, k_trim.hip)
-    uint32_t cU[20], cR[20]; // units / reference bases before op i0 + T c (absolute); [16] = at the region's end
-    uint32_t pad[20];        // two slabs = 96 T + 144 words: 16 mod 64 for T = 4 and 8 -- the four pairs of a wavefront, reading the same index
-                             // of their own slabs, land in four different quarters of the 64 banks
+    uint32_t pad[28];        // [0, 20): where a record's cut-only state waits during the split, and the left cut's results during the right cut.
+                             // Two slabs = 96 T + 80 words: 16 mod 64 for T = 4 and 8 -- the four pairs of a wavefront, reading the same index
+                             // of their own slabs, land in four different quarters of the 64 banks.  (The units / reference bases in front of the
+                             // 16 chunks are NOT here: lane c holds chunk c's -- rb_qrec.cu / .cr --, a ds_bpermute away: 7.4 KB per wavefront at
+                             // T = 4, so that the five wavefronts per SIMD the registers allow all find room)
 };
 static_assert((2 * sizeof(rb_q4_slab<4>) / 4) % 64 == 16 && (2 * sizeof(rb_q4_slab<8>) / 4) % 64 == 16, "slab stride");
 
@@ -43,7 +45,7 @@ struct rb_qrec { // row-uniform values, one copy per lane
 #ifdef RB_Q4_DEBUG
     uint32_t dbg[5];
 #endif
-    uint32_t cq;               // PER LANE: query bases before this lane's chunk (op i0 + T lane)
+    uint32_t cq, cu, cr;       // PER LANE: query bases / units / reference bases before this lane's chunk (op i0 + T lane), absolute
 };
 struct rb_qpos {
     uint32_t i, w, pre;
@@ -134,7 +136,7 @@ __device__ __forceinline__ bool rb_q4_build(rb_qrec &v, rb_q4_slab<T> &S, uint32
 #ifdef RB_Q4_DEBUG
     v.dbg[0] = bU, v.dbg[1] = bR, v.dbg[2] = tu, v.dbg[3] = tr, v.dbg[4] = tq;
 #endif
-    S.cU[gl] = bU + iu - su, S.cR[gl] = bR + ir - sr;
+    v.cu = bU + iu - su, v.cr = bR + ir - sr;
     uint32_t qv[T];
     int32_t sv[T];
 #pragma unroll
@@ -150,7 +152,6 @@ __device__ __forceinline__ bool rb_q4_build(rb_qrec &v, rb_q4_slab<T> &S, uint32
     }
     if (gl == 15u) { // the entry behind the last op: the prefixes at the region's end
         S.w[16 * T] = 0u, S.Qc[16 * T] = cq, S.SP[16 * T] = cs;
-        S.cU[16] = bU + iu, S.cR[16] = bR + ir;
     }
     // the region's last query op
     const uint32_t hm = rb_row_ballot(hq >= 0, gbase);
@@ -181,14 +182,14 @@ __device__ __forceinline__ rb_qpos rb_q4_find(const rb_qrec &v, const rb_q4_slab
 }
 // units (KIND 0) / reference bases (KIND 1) before op i of the region: its chunk's base + the ops of the chunk in front of it
 template <int T, int KIND>
-__device__ __forceinline__ uint32_t rb_q4_before(const rb_qrec &v, const rb_q4_slab<T> &S, uint32_t i, uint32_t gl) {
+__device__ __forceinline__ uint32_t rb_q4_before(const rb_qrec &v, const rb_q4_slab<T> &S, uint32_t i, uint32_t gl, uint32_t gbase) {
     const uint32_t k = i - v.i0, c = k / (uint32_t)T, j = c * T + gl;
     uint32_t x = 0;
     if (gl < (uint32_t)T && j < k) {
         const uint32_t w = S.w[j];
         x = (KIND == 0 || rb_in(RB_REF_MASK, rb_opc(w))) ? rb_len(w) : 0u;
     }
-    return (KIND == 0 ? S.cU[c] : S.cR[c]) + rb_row_sum(x);
+    return rb_row_read(KIND == 0 ? v.cu : v.cr, gbase, c) + rb_row_sum(x);
 }
 // truncate_record_by_query (paf.rs:785-823) on a staged regular record: rb_tw_clip (k_trim.hip) for a row of 16 lanes
 template <int T>
@@ -224,7 +225,7 @@ __device__ __forceinline__ uint32_t rb_q4_clip(rb_qrec &v, const rb_q4_slab<T> &
         const rb_qpos o = rb_q4_find<T>(v, S, x, gl, gbase);
         if (o.i >= n) return false;
         const uint32_t j = x - o.pre, len = rb_len(o.w);
-        const uint32_t ub = rb_q4_before<T, 0>(v, S, o.i, gl);
+        const uint32_t ub = rb_q4_before<T, 0>(v, S, o.i, gl, gbase);
         uint32_t u = ub + j;
         rb_qpos om;
         om.i = o.i, om.w = o.w, om.pre = ub;
@@ -262,7 +263,7 @@ __device__ __forceinline__ uint32_t rb_q4_clip(rb_qrec &v, const rb_q4_slab<T> &
                 om.i = v.i0 + k2, om.w = S.w[k2], om.pre = uu - rb_len(S.w[k2]);
             }
         }
-        e->k = km, e->o = om, e->R = rb_q4_before<T, 1>(v, S, om.i, gl), e->Q = S.Qc[om.i - v.i0];
+        e->k = km, e->o = om, e->R = rb_q4_before<T, 1>(v, S, om.i, gl, gbase), e->Q = S.Qc[om.i - v.i0];
         return true;
     };
     rb_qend A, B; // paf.rs:792-796: the start searches up on '+' and down on '-', the end the other way
@@ -398,6 +399,31 @@ __device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64
         pending(3);
         return;
     }
+    // What only the CUTS need of a record -- where its ops lie, its coordinates, its totals, its first two ops and its last -- waits in the slab's
+    // unused words while the split is found: held in registers through the searches it was a third of the kernel's 110 VGPRs, i.e. the
+    // difference between four and five wavefronts per SIMD.  (Lane 0 of the row writes, every lane reads it back in front of the record's cut.)
+    auto stash = [&](const rb_qrec &v, rb_q4_slab<T> &S) {
+        if (gl == 0u) {
+            const uint64_t base = (uint64_t)(v.ops - p.ops);
+            uint32_t *z = S.pad;
+            *reinterpret_cast<uint4 *>(z) = make_uint4((uint32_t)base, (uint32_t)(base >> 32), (uint32_t)v.t_st, (uint32_t)(v.t_st >> 32));
+            *reinterpret_cast<uint4 *>(z + 4) = make_uint4((uint32_t)v.q_st, (uint32_t)(v.q_st >> 32), (uint32_t)v.q_en, (uint32_t)(v.q_en >> 32));
+            *reinterpret_cast<uint4 *>(z + 8) = make_uint4(v.N, v.Qtot, v.Rtot, v.w0);
+            z[12] = v.w1, z[13] = v.wl;
+        }
+    };
+    auto unstash = [&](rb_qrec &v, const rb_q4_slab<T> &S) {
+        asm volatile("" ::: "memory"); // (read where they are needed, not before)
+        const uint32_t *z = S.pad;
+        const uint4 a = *reinterpret_cast<const uint4 *>(z), b = *reinterpret_cast<const uint4 *>(z + 4), c = *reinterpret_cast<const uint4 *>(z + 8);
+        v.ops = p.ops + (((uint64_t)a.y << 32) | a.x), v.t_st = ((uint64_t)a.w << 32) | a.z;
+        v.q_st = ((uint64_t)b.y << 32) | b.x, v.q_en = ((uint64_t)b.w << 32) | b.z;
+        v.N = c.x, v.Qtot = c.y, v.Rtot = c.z, v.w0 = c.w, v.w1 = z[12], v.wl = z[13];
+    };
+    stash(L, SL);
+    stash(R, SR);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #if RB_Q4_STOP == 1
     if (gl == 0) p.rows[pi].split_idx = L.eQ + R.eQ;
     return;
@@ -537,11 +563,22 @@ __device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64
     const bool inpl = p.in_place != 0;
     const uint64_t ob = inpl ? 0ull : p.pair_out_off[pi];
     rb_qcut cutL, cutR;
+    unstash(L, SL);
     uint32_t st = rb_q4_clip<T>(L, SL, L.q_st, split, p.out_ops + ob, &w, 0, ob, gl, gbase, inpl, cutL, (uint64_t)(L.ops - p.ops)); // trim_overlap.rs:77
 #if RB_Q4_STOP == 4
     if (gl == 0) p.rows[pi] = w;
     return;
 #endif
+    // ... and what the left cut left (its half of the row, its two end words) waits there while the right record is cut
+    if (gl == 0u) {
+        uint32_t *y = SL.pad;
+        *reinterpret_cast<uint4 *>(y) = make_uint4((uint32_t)w.t_st[0], (uint32_t)(w.t_st[0] >> 32), (uint32_t)w.t_en[0], (uint32_t)(w.t_en[0] >> 32));
+        *reinterpret_cast<uint4 *>(y + 4) = make_uint4((uint32_t)w.q_st[0], (uint32_t)(w.q_st[0] >> 32), (uint32_t)w.q_en[0], (uint32_t)(w.q_en[0] >> 32));
+        *reinterpret_cast<uint4 *>(y + 8) = make_uint4(w.nmatch[0], w.aln_len[0], (uint32_t)w.out_off[0], (uint32_t)(w.out_off[0] >> 32));
+        *reinterpret_cast<uint4 *>(y + 12) = make_uint4(w.out_n[0], cutL.w_first, cutL.w_last, (uint32_t)cutL.at_first);
+        *reinterpret_cast<uint4 *>(y + 16) = make_uint4((uint32_t)(cutL.at_first >> 32), (uint32_t)cutL.at_last, (uint32_t)(cutL.at_last >> 32), 0u);
+    }
+    unstash(R, SR);
     if (st == RB_ST_OK && !L.bad) {
         const uint64_t ob2 = ob + L.n;
         st = rb_q4_clip<T>(R, SR, split, R.q_en, p.out_ops + ob2, &w, 1, ob2, gl, gbase, inpl, cutR, (uint64_t)(R.ops - p.ops)); // :78
@@ -551,6 +588,15 @@ __device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64
         return;
     }
     if (gl == 0) {
+        {   // the left cut's half of the row and its end words, back from the slab
+            asm volatile("" ::: "memory");
+            const uint32_t *y = SL.pad;
+            const uint4 a = *reinterpret_cast<const uint4 *>(y), b = *reinterpret_cast<const uint4 *>(y + 4), c = *reinterpret_cast<const uint4 *>(y + 8),
+                        d = *reinterpret_cast<const uint4 *>(y + 12), e = *reinterpret_cast<const uint4 *>(y + 16);
+            w.t_st[0] = ((uint64_t)a.y << 32) | a.x, w.t_en[0] = ((uint64_t)a.w << 32) | a.z, w.q_st[0] = ((uint64_t)b.y << 32) | b.x, w.q_en[0] = ((uint64_t)b.w << 32) | b.z;
+            w.nmatch[0] = c.x, w.aln_len[0] = c.y, w.out_off[0] = ((uint64_t)c.w << 32) | c.z, w.out_n[0] = d.x;
+            cutL.w_first = d.y, cutL.w_last = d.z, cutL.at_first = ((uint64_t)e.x << 32) | d.w, cutL.at_last = ((uint64_t)e.z << 32) | e.y;
+        }
         if (inpl && st == RB_ST_OK) { // both clips stand: their end words, where they are (first before last: one op -> the same word twice)
             p.out_ops[cutL.at_first] = cutL.w_first, p.out_ops[cutL.at_last] = cutL.w_last;
             p.out_ops[cutR.at_first] = cutR.w_first, p.out_ops[cutR.at_last] = cutR.w_last;
