@@ -479,12 +479,11 @@ __device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64
         // the last index with Qc <= xo holds xo (the entries behind the region hold eQ): a 4-ary descent, three reads per level
         auto search = [&](const rb_qrec &o, const rb_q4_slab<T> &SO, uint32_t xo) -> hit_t {
             uint32_t lo = 0;
-#pragma unroll
-            for (int lv = 0; lv < 3; lv++) { // strides 4 T, T, T / 4
-                const uint32_t st = (4u * T) >> (2 * lv);
+            rb_static_for<3>([&](auto lv) { // strides 4 T, T, T / 4
+                constexpr uint32_t st = (4u * T) >> (2 * decltype(lv)::value);
                 const uint32_t a = SO.Qc[lo + st], b = SO.Qc[lo + 2u * st], c = SO.Qc[lo + 3u * st];
                 lo += ((a <= xo ? 1u : 0u) + (b <= xo ? 1u : 0u) + (c <= xo ? 1u : 0u)) * st;
-            }
+            });
             if constexpr (T == 8) lo += SO.Qc[lo + 1u] <= xo ? 1u : 0u; // (128 = 2 * 4^3)
             hit_t h;
             const uint32_t wo = SO.w[lo];
@@ -545,12 +544,12 @@ __device__ __forceinline__ void rb_q4_pair(const rb_trim_params &p, const uint64
                 late(lr, R, L, SL, lxa, lxb, false);
             }
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
+        rb_static_for<4>([&](auto s_) { // rotate by 8, 4, 2, 1: every lane ends with the row's best
+            constexpr int off = 8 >> decltype(s_)::value;
             const int32_t ob = (int32_t)rb_row_ror((uint32_t)cb, off);
             const uint32_t ok = rb_row_ror(ck, off);
             if (ob > cb || (ob == cb && ok < ck)) cb = ob, ck = ok;
-        }
+        });
         if (cb > best) best = cb, best_idx = ck;
     }
 #if RB_Q4_STOP == 3
