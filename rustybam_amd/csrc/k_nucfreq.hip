@@ -427,21 +427,42 @@ __global__ __launch_bounds__(256) void rb_k_nf_tile_desc(rb_nf_params p) {
 // 8 l + k -- are 17 dwords apart and fall on different banks
 #define NF_CNT_DW (17 * ((NF_TILE + 16) / 8))
 __device__ __forceinline__ uint32_t nf_slot(uint32_t i) { return 2u * (i + 8u) + ((i + 8u) >> 3); }
-__device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { return ((v & 0x0F0F0F0Fu) << 4) | ((v >> 4) & 0x0F0F0F0Fu); }
+__device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { // (two shifts and one v_bfi_b32: written as and / or the compiler makes five instructions of it)
+    uint32_t o;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(o) : "s"(0xF0F0F0F0u), "v"(v << 4), "v"(v >> 4));
+    return o;
+}
 
 // Two builds of the tile kernel.  U8T: tiles with at most 255 reads in range (byte counters, the coverage differences as 16-bit
 // halves of a dword, a staging buffer of 640 dwords): 49 KB of LDS, three workgroups per CU instead of two -- the kernel waits on
 // LDS and memory latency, and the third workgroup is worth 20 % (4.43 -> 3.6 ms on config 5).  The other build takes the tiles
 // crowded with reads (16-bit counters, 32-bit differences: 77 KB).  Both are launched over all tiles and leave the other's alone.
 #define NF_CNT8_DW (10 * ((NF_TILE + 16) / 8))
-#ifndef NF_STOP
-#define NF_STOP 0 // diagnostics (timing only, wrong counts): 1 = no output written, 2 = no LDS atomics (bases staged and decoded, nothing added), 3 = no read touched
+#ifndef NF_PIPE
+#define NF_PIPE 1 // 0: the wave's reads strictly one after the other (rounds 1 - 5)
 #endif
+#ifndef NF_STOP
+#define NF_STOP 0 // diagnostics (timing only, wrong counts): 1 = no output written, 2 = no LDS atomics (bases staged and decoded, nothing added), 3 = no read touched, 5 = chunks scanned and landed but not counted (9: no bases fetched either, 10: fetched and dropped), 6 = every op's set-up but none of its groups, 7 = only the launch, 8 = no read touched and no depth scan
+#endif
+// (at most) 64 ops of one read against a tile, between their scan and the counting (nf_one_tile: chunk_scan / chunk_land / chunk_count)
+template <int IT>
+struct nf_chunk { // (no implicit padding: the compiler copies a struct's padding through memory)
+    uint64_t m;      // the lanes whose op lays bases over the tile
+    int64_t wd_lo;   // the stretch of packed bases the ops of m cover: its first dword ...
+    int32_t ia, ib;  // the lane's op: the tile indices [ia, ib) of its bases ...
+    uint32_t qa;     // ... and where in the read the base at ia is (bam_pileup1_t::qpos)
+    uint32_t staged; // 1: the stretch fits the wave's buffer: v holds it (loads in flight until chunk_land)
+    int32_t n_dw;    // ... and how many dwords (meaningful while it fits: a longer stretch is capped)
+    int32_t s;       // 4-bit index of the read's first base relative to the stretch's first dword (mod 2^32)
+    uint32_t pad[2];
+    uint4 v[IT];
+};
 template <bool U8T>
 __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_t t) {
     constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + 128) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
     constexpr int STG_IT = (int)((STG + 255u) / 256u);
-    __shared__ __attribute__((aligned(16))) uint32_t cnt[U8T ? NF_CNT8_DW : NF_CNT_DW]; // per position: one dword of four byte counters / A | C << 16, G | T << 16
+    constexpr uint32_t CNT_DW = ((U8T ? NF_CNT8_DW : NF_CNT_DW) + 3) / 4 * 4; // (zeroed 16 bytes at a time)
+    __shared__ __attribute__((aligned(16))) uint32_t cnt[CNT_DW]; // per position: one dword of four byte counters / A | C << 16, G | T << 16
     __shared__ uint32_t lut[16];        // what a base code adds to its word: 1 4 = A G: 1; 2 8 = C T: 1 << 16; everything else 0 (nucfreq.rs:83-90)
     __shared__ uint32_t lut8[16];       // U8 tiles: 1 2 4 8 = A C G T: 1 << 0, 8, 16, 24
 #ifndef NF_LUT_SINGLE
@@ -453,7 +474,8 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
 #endif
     // +1 where a read starts covering, -1 where it stops; then the depth.  U8T: two positions a dword -- the halves are added as
     // whole 32-bit integers (a borrow of the low half travels into the high one and is taken back when the word is read)
-    __shared__ int32_t diff[U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8];
+    constexpr uint32_t NF_DIFF_DW = ((U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8) + 3) / 4 * 4;
+    __shared__ __attribute__((aligned(16))) int32_t diff[NF_DIFF_DW];
     __shared__ uint8_t covb[U8T ? NF_THREADS : 4]; // U8T: which of a thread's 8 positions are covered
     __shared__ int32_t wsum[NF_WAVES];
     __shared__ uint32_t blk_max, blk_cov;
@@ -463,14 +485,29 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     //  for the region followed by dependent loads of its arrays, of the region's first tile and of its dropped-read bitmap's place)
     const nf_tdesc D = nf_uniform(p.tdesc[t]);
     if ((D.u8 != 0u) != U8T) return; // the other build's
+#if NF_STOP == 7
+    if (D.n_pos != 0x7FFFFFFFu) return; // (timing only: what it costs to launch the tiles' workgroups)
+#endif
     nf_tile T;
     T.r = D.r, T.st = D.st, T.en = D.st + D.n_pos, T.out = D.out, T.tid = D.tid;
     nf_drop drop;
     drop.off = D.drop_off, drop.rlo = D.drop_rlo, drop.bits = p.drop_bits;
     const uint32_t n_pos = D.n_pos;
-    for (uint32_t k = threadIdx.x; k < (U8T ? NF_CNT8_DW : NF_CNT_DW); k += NF_THREADS) cnt[k] = 0;
+#if NF_PIPE
+    // the wave's reads (lo + wave + NF_WAVES j): lane j asks for read j's record now, before the tile is zeroed -- the first of the
+    // dependent trips (tile -> records -> ops -> bases) runs under the zeroing and the barrier.  (Not for the crowded tiles: lane-per-read.)
+    const bool nf_by_wave = U8T || D.hi - D.lo <= 8u * 64u;
+    const uint32_t nw = nf_by_wave && D.hi > D.lo + (threadIdx.x >> 6) ? (uint32_t)((D.hi - D.lo - (threadIdx.x >> 6) + NF_WAVES - 1) / NF_WAVES) : 0u;
+    nf_read hv;
+    hv.pos = 0, hv.end = 0, hv.tid = -1, hv.l_seq = 0, hv.op_off = 0, hv.n_ops = 0, hv.pad0 = 0, hv.nib0 = 0, hv.pad1 = 0;
+    const uint64_t hv_i = D.lo + (threadIdx.x >> 6) + (uint64_t)NF_WAVES * (threadIdx.x & 63u);
+    if ((threadIdx.x & 63u) < nw) hv = p.hd[hv_i];
+#endif
+    {   // (16 bytes a store: a quarter of the instructions)
+        for (uint32_t k = threadIdx.x; k < CNT_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(cnt)[k] = make_uint4(0, 0, 0, 0);
+    }
     if ((threadIdx.x & 63u) < 4u) stage_all[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
-    for (uint32_t k = threadIdx.x; k < (U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8); k += NF_THREADS) diff[k] = 0;
+    for (uint32_t k = threadIdx.x; k < NF_DIFF_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(diff)[k] = make_uint4(0, 0, 0, 0);
     auto diff_add = [&](uint32_t i, int32_t delta) {
         if constexpr (U8T) atomicAdd(&diff[i >> 1], (int32_t)((uint32_t)delta << (16u * (i & 1u))));
         else atomicAdd(&diff[i], delta);
@@ -490,135 +527,195 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     // ds_add_u64 covers two positions -- half the atomics of the 16-bit layout and no choice of word per base
     const uint32_t *__restrict__ sw32 = reinterpret_cast<const uint32_t *>(p.seq);
     uint32_t *stage = stage_all[wib] + 4;
-    // one read, the whole wave on it (w_first: its first 64 ops, already in registers)
-    auto read_by_wave = [&](auto U8, const nf_read &h, uint32_t w_first, uint64_t i) {
+    // ---- one read against the tile, in three pieces so that the pieces of consecutive reads can overlap (the loop further down):
+    //      chunk_scan  (at most) 64 ops of the read: where each starts on the reference / in the read, which of them lay bases over the
+    //                  tile, and the loads of that stretch of packed bases -- 16 bytes per lane, all in flight, nothing waited for
+    //      chunk_land  the stretch arrives and is parked in the wave's LDS buffer in base order
+    //      chunk_count every match-type op of the chunk: each lane takes 8 consecutive positions, table reads, LDS atomics
+    auto chunk_scan = [&](const nf_read &h, const uint32_t w, uint32_t &R, uint32_t &Q, const uint64_t i) -> nf_chunk<STG_IT> {
+        nf_chunk<STG_IT> k;
         const int64_t pos = h.pos;
-        const uint64_t rend = h.end;
-#if NF_STOP == 3
-        return;
+        const int64_t rel_st = (int64_t)T.st - pos, rel_en = (int64_t)T.en - pos; // the tile in read-relative reference offsets
+        const uint32_t c = rb_opc(w), len = rb_len(w);
+        const uint32_t rl = rb_in(RB_REF_MASK, c) ? len : 0u, ql = rb_in(RB_QRY_MASK, c) ? len : 0u;
+        const uint32_t ir = rb_wave_scan_incl(rl), iq = rb_wave_scan_incl(ql);
+        const uint32_t r0 = R + ir - rl, q0 = Q + iq - ql; // where my op starts on the reference / in the read
+        const uint32_t Q0 = Q;
+        R += rb_readlane<uint32_t>(ir, 63);
+        Q += rb_readlane<uint32_t>(iq, 63);
+        k.m = 0, k.wd_lo = 0, k.n_dw = 0, k.staged = 0, k.ia = 0, k.ib = 0, k.qa = 0, k.s = 0, k.pad[0] = k.pad[1] = 0;
+        // A read of the tile's fetch has pos < T.en and pos + span > T.st with span < 2^31 (rb_k_nf_read_spans), so rel_st lies in
+        // (-NF_TILE, 2^31), every op starts and ends below 2^31, and 32 bits hold all of it (rel_en only matters below a span; the wave-
+        // uniform tests are 32-bit on purpose: a 64-bit ordered compare has no scalar instruction and lands on the vector ALU).  Behind
+        // the last chunk -- null ops, the record of no read -- nothing hits whatever the numbers are.
+        const int32_t rs = (int32_t)rel_st, re = (uint64_t)rel_en < 0x7FFFFFFFull ? (int32_t)rel_en : 0x7FFFFFFF;
+        if ((int32_t)R <= rs) return k; // these 64 ops end before the tile
+        // every lane its op's share of the tile, once and for all lanes at once (round 6; it was scalar arithmetic per op): tile indices
+        // [ia, ib) and bam_pileup1_t::qpos of the base at ia
+        const int32_t r1 = (int32_t)(r0 + len);
+        const bool hit = rb_in(RB_MATCH_MASK, c) && (int32_t)r0 >= 0 && r1 >= (int32_t)r0 && (int32_t)r0 < re && r1 > rs;
+        k.m = __ballot(hit);
+        if (!k.m) return k;
+        const int32_t a = (int32_t)r0 > rs ? (int32_t)r0 : rs, b = r1 < re ? r1 : re;
+        const int64_t lseq = (int64_t)h.l_seq;
+        int32_t ia = a - rs, ib = b - rs;
+        const uint32_t qa = q0 + (uint32_t)(a - (int32_t)r0);
+        if ((uint64_t)Q > (uint64_t)h.l_seq || Q < Q0) { // (only a read whose ops ask for more bases than it has -- record().seq()[qpos] out of bounds: the reference panics)
+            const int64_t qa64 = (int64_t)q0 + (int64_t)(a - (int32_t)r0);
+            bool seq_short = false;
+            if (hit && qa64 + (int64_t)(ib - ia) > lseq) {
+                seq_short = true;
+                ib = lseq > qa64 ? ia + (int32_t)(lseq - qa64) : ia;
+            }
+            if (__ballot(seq_short) != 0 && lane == 0) p.read_status[i] = RB_RD_SEQ_SHORT;
+        }
+        k.ia = ia, k.ib = ib, k.qa = qa; // (an op that counts anything has qa < l_seq: 32 bits)
+        // the bases these ops lay over the tile are one contiguous stretch of the read: fetch all of it now, 16 bytes per lane and
+        // every load in flight at once -- the per-op loops then never wait for HBM.  (A stretch longer than the buffer -- a long
+        // insertion inside the tile -- is read from memory group by group instead.)
+        {
+            const int jf = __builtin_ctzll(k.m), jl = 63 - __builtin_clzll(k.m);
+            const int32_t fr0 = rb_readlane<int32_t>((int32_t)r0, jf), lr1 = rb_readlane<int32_t>(r1, jl);
+            const uint32_t fq0 = rb_readlane<uint32_t>(q0, jf), lq0 = rb_readlane<uint32_t>(q0, jl), lr0 = rb_readlane<uint32_t>(r0, jl);
+            const uint64_t nib0 = h.nib0;
+            const uint32_t q_lo = fq0 + (uint32_t)((fr0 > rs ? fr0 : rs) - fr0);
+            uint32_t q_hi = lq0 + ((uint32_t)(lr1 < re ? lr1 : re) - lr0);
+            q_hi = q_hi < h.l_seq ? q_hi : h.l_seq;
+            const uint64_t t_lo = nib0 + q_lo;
+            k.wd_lo = ((uint32_t)(t_lo >> 32) != 0u || (uint32_t)t_lo >= 7u) ? (int64_t)((t_lo - 7u) >> 3) : 0;
+            k.s = (int32_t)(uint32_t)(nib0 - 8ull * (uint64_t)k.wd_lo); // (4-bit index of the read's first base inside the stretch; small once an op's qa is added)
+            const uint64_t n_dw = ((nib0 + q_hi + 7u) >> 3) + 2u - (uint64_t)k.wd_lo; // (+ the second dword of the last group)
+            const bool fits = (uint32_t)(n_dw >> 32) == 0u && (uint32_t)n_dw <= STG;
+            k.staged = fits && q_hi > q_lo ? 1u : 0u;
+#if NF_STOP == 9
+            k.staged = 0u; // (timing only: no bases fetched)
 #endif
-        if (h.tid != T.tid || (uint64_t)pos >= T.en || rend <= T.st) return; // hts_itr_next: pos < en && endpos > st (end = 0: not in the pileup)
-        if (nf_dropped(drop, i)) return;
-        const uint64_t c0 = (uint64_t)pos > T.st ? (uint64_t)pos : T.st, c1 = rend < T.en ? rend : T.en;
+            k.n_dw = fits ? (int32_t)(uint32_t)n_dw : (int32_t)STG + 1;
+            if (k.staged) {
+#pragma unroll
+                for (int r = 0; r < STG_IT; r++) {
+                    int32_t idx = 4 * lane + 256 * r;
+                    idx = idx < k.n_dw ? idx : (k.n_dw - 1 > 0 ? (k.n_dw - 1) & ~3 : 0); // (past the stretch: re-read its last piece)
+                    k.v[r] = rb_load4_unaligned(sw32 + k.wd_lo + idx);
+                }
+            }
+        }
+        return k;
+    };
+    auto chunk_land = [&](const nf_chunk<STG_IT> &k) {
+        if (!k.staged) return;
+#if NF_STOP == 10
+        if (k.v[0].x != 0x12345678u || k.v[STG_IT - 1].w != 0x9ABCDEF0u) return; // (timing only: the bases fetched and dropped)
+#endif
+#pragma unroll
+        for (int r = 0; r < STG_IT; r++)
+            if (4 * lane + 256 * r < k.n_dw) // (kept in base order: BAM packs the first base of a byte into its high half)
+                *reinterpret_cast<uint4 *>(stage + 4 * lane + 256 * r) =
+                    make_uint4(nf_swap_nibbles(k.v[r].x), nf_swap_nibbles(k.v[r].y), nf_swap_nibbles(k.v[r].z), nf_swap_nibbles(k.v[r].w));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto chunk_count = [&](auto U8, const nf_read &h, const nf_chunk<STG_IT> &k) {
+        const bool staged = k.staged != 0u;
+        uint64_t m = k.m;
+#if NF_STOP == 5 || NF_STOP == 9 || NF_STOP == 10
+        if (m != 0x123456789ull) return; // (timing only: chunks scanned and landed, nothing counted)
+#endif
+        // lane l takes the 8 positions [P, P + 8) of an 8-aligned group (P = tile index + 8 = P0 + 8 l, then 512 on per turn); their
+        // bases are 8 consecutive 4-bit codes of the read: two dwords (nibbles already in base order), funnel-shifted to the group's
+        // first base; x = the 8 codes with the bases outside [ia, ib) made code 0 (they add nothing)
+        auto add_group = [&](const uint32_t x, uint32_t *const g32) {
+#if NF_STOP == 2
+            if (x == 0x12345678u) cnt[x & 1023u] = x; // (keeps x alive)
+            return;
+#endif
+            uint32_t inc[8]; // (the table reads first, all eight in flight, then the atomics)
+            if constexpr (decltype(U8)::value) {
+                unsigned long long *g = reinterpret_cast<unsigned long long *>(g32);
+#ifndef NF_LUT_SINGLE // (round 3: one 8-byte table read per TWO bases -- 256 entries, 2 KB -- instead of two 4-byte reads: 3.74 -> 3.57 ms per call, same box)
+                unsigned long long inc2[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) inc2[q] = lut16[(x >> (8 * q)) & 255u];
+#pragma unroll
+                for (int q = 0; q < 4; q++) atomicAdd(g + q, inc2[q]);
+#else
+#pragma unroll
+                for (int q = 0; q < 8; q++) inc[q] = lut8[(x >> (4 * q)) & 15u];
+#pragma unroll
+                for (int q = 0; q < 4; q++) atomicAdd(g + q, (unsigned long long)inc[2 * q] | ((unsigned long long)inc[2 * q + 1] << 32));
+#endif
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) inc[q] = lut[(x >> (4 * q)) & 15u];
+#pragma unroll
+                for (int q = 0; q < 8; q++) atomicAdd(g32 + 2 * q + __builtin_amdgcn_ubfe(0x110u, (x >> (4 * q)) & 15u, 1u), inc[q]);
+            }
+        };
+        constexpr uint32_t CNT_PER8 = decltype(U8)::value ? 10u : 17u; // dwords of counters per 8 positions (see nf_slot / NF_CNT8_DW)
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const int32_t ia = rb_readlane<int32_t>(k.ia, j), ib = rb_readlane<int32_t>(k.ib, j); // tile indices [ia, ib) of this op's bases
+            const uint32_t qa = rb_readlane<uint32_t>(k.qa, j);                                   // bam_pileup1_t::qpos of the base at ia
+            const int32_t sP0 = (ia + 8) & ~7;
+#if NF_STOP == 6
+            if (ia != 0x7FFFFFF0) { // (timing only: an op's set-up, none of its groups)
+                if (sP0 == 0x7FFFFFF1 + (int32_t)(qa & 1u) + ib) cnt[0] = 1u;
+                continue;
+            }
+#endif
+            // what moves from turn to turn is kept as running values (no multiply, no shift inside the loop): lo4 / hi4 = four times the
+            // number of positions the group starts before ia / ends behind ib (the masks' shift counts); the lane is in while hi4 < 32
+            int32_t lo4 = 4 * (ia + 8 - sP0) - 32 * lane, hi4 = 4 * (sP0 - ib) + 32 * lane;
+            uint32_t *g = &cnt[CNT_PER8 * (((uint32_t)sP0 >> 3) + (uint32_t)lane)];
+            if (staged) {
+                const int32_t an0 = (int32_t)((uint32_t)k.s + qa) - (ia + 8) + sP0; // 4-bit index of position sP0 inside the staged stretch
+                const uint32_t *sp = stage + (an0 >> 3) + lane; // ((an0 >> 3) = -1: only masked bases, in front of the buffer -- the zero guard)
+                const uint32_t shift4 = (uint32_t)(an0 & 7) * 4u;
+                for (; hi4 < 32; lo4 -= 2048, hi4 += 2048, sp += 64, g += CNT_PER8 * 64u) {
+                    const uint32_t raw = __builtin_amdgcn_alignbit(sp[1], sp[0], shift4);
+                    add_group(raw & (0xFFFFFFFFu << (uint32_t)(lo4 > 0 ? lo4 : 0)) & (0xFFFFFFFFu >> (uint32_t)(hi4 > 0 ? hi4 : 0)), g);
+                }
+            } else {
+                const int64_t An0 = (int64_t)h.nib0 + (int64_t)qa + (int64_t)(sP0 + 8 * lane - 8 - ia); // (>= -7: only masked bases can lie before the buffer)
+                for (int64_t An = An0; hi4 < 32; lo4 -= 2048, hi4 += 2048, An += 512, g += CNT_PER8 * 64u) {
+                    const int64_t wd = An >> 3;
+                    const uint32_t raw = __builtin_amdgcn_alignbit(nf_swap_nibbles(sw32[wd + 1]), wd >= 0 ? nf_swap_nibbles(sw32[wd]) : 0u, (uint32_t)(An & 7) * 4u);
+                    add_group(raw & (0xFFFFFFFFu << (uint32_t)(lo4 > 0 ? lo4 : 0)) & (0xFFFFFFFFu >> (uint32_t)(hi4 > 0 ? hi4 : 0)), g);
+                }
+            }
+        }
+    };
+    // does the tile's fetch hold this read?  (hts_itr_next: pos < en && endpos > st; end = 0: not in the pileup; dropped at the depth cap)
+    auto in_tile = [&](const nf_read &h, uint64_t i) -> bool {
+        if (h.tid != T.tid || (uint64_t)h.pos >= T.en || (uint64_t)h.end <= T.st) return false;
+        return !nf_dropped(drop, i);
+    };
+    auto cover = [&](const nf_read &h) { // the read's stretch of the tile in the difference array
+        const uint64_t c0 = (uint64_t)h.pos > T.st ? (uint64_t)h.pos : T.st, c1 = (uint64_t)h.end < T.en ? (uint64_t)h.end : T.en;
         if (lane == 0) {
             diff_add((uint32_t)(c0 - T.st), 1);
             diff_add((uint32_t)(c1 - T.st), -1);
         }
+    };
+    // one read from start to end, the whole wave on it, chunk after chunk (w_first: its first 64 ops, already in registers): reads
+    // of more than 64 ops, and the reads the crowded tiles leave to the wave
+    auto read_by_wave = [&](auto U8, const nf_read &h, uint32_t w_first, uint64_t i) {
+#if NF_STOP == 3
+        return;
+#endif
+        if (!in_tile(h, i)) return;
+        cover(h);
         const uint64_t o0 = h.op_off, o1 = h.op_off + h.n_ops;
-        const int64_t nib0 = (int64_t)h.nib0;
-        const int64_t lseq = (int64_t)h.l_seq;
-        const int64_t rel_st = (int64_t)T.st - pos, rel_en = (int64_t)T.en - pos; // the tile in read-relative reference offsets
-        const int64_t idx0 = pos - (int64_t)T.st;                                  // tile index of the read's first base
+        const int64_t rel_en = (int64_t)T.en - (int64_t)h.pos;
         uint32_t R = 0, Q = 0;
-        bool seq_short = false;
         for (uint64_t o = o0; o < o1; o += 64) {
             const uint32_t w = o == o0 ? w_first : ((o + (uint64_t)lane < o1) ? p.ops[o + (uint64_t)lane] : RB_NULL_OP);
-            const uint32_t c = rb_opc(w), len = rb_len(w);
-            const uint32_t rl = rb_in(RB_REF_MASK, c) ? len : 0u, ql = rb_in(RB_QRY_MASK, c) ? len : 0u;
-            const uint32_t ir = rb_wave_scan_incl(rl), iq = rb_wave_scan_incl(ql);
-            const uint32_t r0 = R + ir - rl, q0 = Q + iq - ql; // where my op starts on the reference / in the read
-            R += rb_readlane<uint32_t>(ir, 63);
-            Q += rb_readlane<uint32_t>(iq, 63);
-            if ((int64_t)R <= rel_st) continue; // these 64 ops end before the tile
-            const bool hit = rb_in(RB_MATCH_MASK, c) && (int64_t)r0 < rel_en && (int64_t)r0 + (int64_t)len > rel_st;
-            uint64_t m = __ballot(hit);
-            // the bases these ops lay over the tile are one contiguous stretch of the read: fetch all of it now, 16 bytes per lane and
-            // every load in flight at once, and park it in LDS -- the per-op loops below then never wait for HBM.  (A stretch longer
-            // than the buffer -- a long insertion inside the tile -- is read from memory group by group instead.)
-            int64_t wd_lo = 0;
-            bool staged = false;
-            if (m) {
-                const int jf = __builtin_ctzll(m), jl = 63 - __builtin_clzll(m);
-                const int64_t fr0 = rb_readlane<uint32_t>(r0, jf), fq0 = rb_readlane<uint32_t>(q0, jf);
-                const int64_t lr0 = rb_readlane<uint32_t>(r0, jl), lq0 = rb_readlane<uint32_t>(q0, jl), llen = rb_readlane<uint32_t>(len, jl);
-                const int64_t q_lo = fq0 + ((fr0 > rel_st ? fr0 : rel_st) - fr0);
-                int64_t q_hi = lq0 + ((lr0 + llen < rel_en ? lr0 + llen : rel_en) - lr0);
-                q_hi = q_hi < lseq ? q_hi : lseq;
-                wd_lo = (nib0 + q_lo - 7) >> 3;
-                wd_lo = wd_lo > 0 ? wd_lo : 0;
-                const int64_t n_dw = ((nib0 + q_hi + 7) >> 3) + 2 - wd_lo; // (+ the second dword of the last group)
-                staged = n_dw <= (int64_t)STG && q_hi > q_lo;
-                if (staged) {
-                    uint4 v[STG_IT];
-#pragma unroll
-                    for (int r = 0; r < STG_IT; r++) {
-                        int64_t idx = 4 * lane + 256 * r;
-                        idx = idx < n_dw ? idx : (n_dw - 1 > 0 ? (n_dw - 1) & ~3ll : 0); // (past the stretch: re-read its last piece)
-                        v[r] = rb_load4_unaligned(sw32 + wd_lo + idx);
-                    }
-#pragma unroll
-                    for (int r = 0; r < STG_IT; r++)
-                        if (4 * lane + 256 * r < n_dw) // (kept in base order: BAM packs the first base of a byte into its high half)
-                            *reinterpret_cast<uint4 *>(stage + 4 * lane + 256 * r) =
-                                make_uint4(nf_swap_nibbles(v[r].x), nf_swap_nibbles(v[r].y), nf_swap_nibbles(v[r].z), nf_swap_nibbles(v[r].w));
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            while (m) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                const int64_t jr0 = rb_readlane<uint32_t>(r0, j), jlen = rb_readlane<uint32_t>(len, j), jq0 = rb_readlane<uint32_t>(q0, j);
-                const int64_t a = jr0 > rel_st ? jr0 : rel_st, b = jr0 + jlen < rel_en ? jr0 + jlen : rel_en;
-                const int32_t ia = (int32_t)(idx0 + a); // tile indices [ia, ib) of this op's bases
-                int32_t ib = (int32_t)(idx0 + b);
-                const int64_t qa = jq0 + (a - jr0); // bam_pileup1_t::qpos of the base at ia
-                if (qa + (int64_t)(ib - ia) > lseq) { // record().seq()[qpos] would be out of bounds: the reference panics
-                    seq_short = true;
-                    ib = lseq > qa ? ia + (int32_t)(lseq - qa) : ia;
-                }
-                // lane l takes the 8 positions [P, P + 8) of an 8-aligned group (P = tile index + 8); their bases are 8 consecutive
-                // 4-bit codes of the read: two dwords (nibbles swapped into base order), funnel-shifted to the group's first base
-                auto add_group = [&](int32_t P, uint32_t d0, uint32_t d1, uint32_t shift4) {
-                    const int32_t j0 = ia + 8 - P > 0 ? ia + 8 - P : 0, j1 = ib + 8 - P < 8 ? ib + 8 - P : 8;
-                    uint32_t x = __builtin_amdgcn_alignbit(d1, d0, shift4); // (d0, d1: nibbles already in base order)
-                    const uint32_t width = (uint32_t)(j1 - j0) * 4u;
-                    x &= width >= 32u ? 0xFFFFFFFFu : (((1u << width) - 1u) << ((uint32_t)j0 * 4u)); // bases outside [ia, ib) become code 0: add nothing
-#if NF_STOP == 2
-                    if (x == 0x12345678u) cnt[(uint32_t)P & 1023u] = x; // (keeps x alive)
-                    return;
-#endif
-                    uint32_t inc[8]; // (the table reads first, all eight in flight, then the atomics)
-                    if constexpr (decltype(U8)::value) {
-                        unsigned long long *g = reinterpret_cast<unsigned long long *>(&cnt[10u * ((uint32_t)P >> 3)]);
-#ifndef NF_LUT_SINGLE // (round 3: one 8-byte table read per TWO bases -- 256 entries, 2 KB -- instead of two 4-byte reads: 3.74 -> 3.57 ms per call, same box)
-                        unsigned long long inc2[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) inc2[k] = lut16[(x >> (8 * k)) & 255u];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) atomicAdd(g + k, inc2[k]);
-#else
-#pragma unroll
-                        for (int k = 0; k < 8; k++) inc[k] = lut8[(x >> (4 * k)) & 15u];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) atomicAdd(g + k, (unsigned long long)inc[2 * k] | ((unsigned long long)inc[2 * k + 1] << 32));
-#endif
-                    } else {
-                        uint32_t *g = &cnt[17u * ((uint32_t)P >> 3)];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) inc[k] = lut[(x >> (4 * k)) & 15u];
-#pragma unroll
-                        for (int k = 0; k < 8; k++) atomicAdd(g + 2 * k + __builtin_amdgcn_ubfe(0x110u, (x >> (4 * k)) & 15u, 1u), inc[k]);
-                    }
-                };
-                const int32_t P0 = ((ia + 8) & ~7) + 8 * lane;
-                if (staged) {
-                    const int32_t rel = (int32_t)(nib0 + qa - 8 * wd_lo) - (ia + 8); // 4-bit index of position P inside the staged stretch = rel + P
-                    for (int32_t P = P0; P < ib + 8; P += 512) {
-                        const int32_t an = rel + P, sd = an >> 3; // (sd = -1: only masked bases, in front of the buffer -- the zero guard)
-                        add_group(P, stage[sd], stage[sd + 1], (uint32_t)(an & 7) * 4u);
-                    }
-                } else {
-                    for (int32_t P = P0; P < ib + 8; P += 512) {
-                        const int64_t An = nib0 + qa + (int64_t)(P - 8 - ia); // (>= -7: only masked bases can lie before the buffer)
-                        const int64_t wd = An >> 3;
-                        add_group(P, wd >= 0 ? nf_swap_nibbles(sw32[wd]) : 0u, nf_swap_nibbles(sw32[wd + 1]), (uint32_t)(An & 7) * 4u);
-                    }
-                }
-            }
+            const nf_chunk<STG_IT> k = chunk_scan(h, w, R, Q, i);
+            chunk_land(k);
+            chunk_count(U8, h, k);
             if ((int64_t)R >= rel_en) break;
         }
-        if (__ballot(seq_short) != 0 && lane == 0) p.read_status[i] = RB_RD_SEQ_SHORT;
     };
     if (!U8T && hi - lo > 8u * 64u) {
         // ---- a tile crowded with reads (short reads): 64 reads per wave and turn, one lane per read with at most NF_LANE_OPS ops
@@ -677,6 +774,76 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
             }
         }
     } else {
+#if NF_PIPE
+        // ---- the wave's reads as a stream of CHUNKS (a read's ops, 64 at a time), three chunks under way at any time (round 6).
+        //      The wave's reads are lo + wib + NF_WAVES j, j < nw <= 64: lane j fetched read j's record before the tile was zeroed
+        //      (hv), so a record is a row of v_readlane away; the lanes have each entered their own read into the coverage
+        //      differences, and `alive` says which reads the tile's fetch holds.  In a turn: the bases of chunk c (requested a turn
+        //      ago) are parked in LDS; chunk c + 1 (ops requested a turn ago) is scanned and ITS bases requested; the ops of chunk
+        //      c + 2 are requested; then chunk c is counted out of LDS.  Every trip to memory has a chunk's worth of work in front
+        //      of it -- before, a read's bases were waited for where they were requested: five reads a wave and tile, two
+        //      microseconds each. ----
+        bool mine = (uint32_t)lane < nw && in_tile(hv, hv_i);
+#if NF_STOP == 3 || NF_STOP == 8
+        mine = false;
+#endif
+        if (mine) { // (every lane its own read: the two atomics of up to 64 reads in one go)
+            const uint64_t c0 = (uint64_t)hv.pos > T.st ? (uint64_t)hv.pos : T.st, c1 = (uint64_t)hv.end < T.en ? (uint64_t)hv.end : T.en;
+            diff_add((uint32_t)(c0 - T.st), 1);
+            diff_add((uint32_t)(c1 - T.st), -1);
+        }
+        const uint64_t alive = __ballot(mine);
+        struct cursor { // a chunk to come: which read, where in its ops, the reference / read bases in front of it
+            nf_read h;
+            uint64_t i;
+            uint32_t j, o, R, Q;
+            uint32_t valid, pad;
+        };
+        auto read_at = [&](uint64_t from_mask) -> cursor { // the first chunk of the first live read among the lanes of from_mask
+            cursor c;
+            const uint64_t mk = alive & from_mask;
+            c.valid = mk != 0 ? 1u : 0u, c.pad = 0;
+            c.j = c.valid ? (uint32_t)__builtin_ctzll(mk) : 0u;
+            c.o = 0, c.R = 0, c.Q = 0;
+            c.i = lo + wib + (uint64_t)NF_WAVES * c.j;
+            c.h.pos = rb_readlane<uint32_t>(hv.pos, (int)c.j), c.h.l_seq = rb_readlane<uint32_t>(hv.l_seq, (int)c.j);
+            c.h.n_ops = c.valid ? rb_readlane<uint32_t>(hv.n_ops, (int)c.j) : 0u;
+            c.h.op_off = rb_readlane<uint64_t>(hv.op_off, (int)c.j), c.h.nib0 = rb_readlane<uint64_t>(hv.nib0, (int)c.j);
+            c.h.end = 0, c.h.tid = T.tid, c.h.pad0 = 0, c.h.pad1 = 0; // (what only the fetch's test needed)
+            return c;
+        };
+        auto after = [&](const cursor &c) -> cursor { // the chunk behind c (c scanned: c.R is the reference behind its ops)
+            if (c.valid && c.o + 64u < c.h.n_ops && (int64_t)c.R < (int64_t)T.en - (int64_t)c.h.pos) {
+                cursor d = c;
+                d.o = c.o + 64u;
+                return d;
+            }
+            return read_at(c.valid && c.j < 63u ? ~0ull << (c.j + 1u) : 0ull);
+        };
+        auto ops_at = [&](const cursor &c) -> uint32_t {
+            return c.o + (uint32_t)lane < c.h.n_ops ? p.ops[c.h.op_off + c.o + (uint32_t)lane] : RB_NULL_OP;
+        };
+        auto empty = []() -> nf_chunk<STG_IT> {
+            nf_chunk<STG_IT> k;
+            k.m = 0, k.wd_lo = 0, k.ia = 0, k.ib = 0, k.qa = 0, k.staged = 0, k.n_dw = 0, k.s = 0, k.pad[0] = k.pad[1] = 0;
+            return k;
+        };
+        cursor c_cur = read_at(~0ull);
+        nf_chunk<STG_IT> k_cur = empty();
+        if (c_cur.valid) k_cur = chunk_scan(c_cur.h, ops_at(c_cur), c_cur.R, c_cur.Q, c_cur.i);
+        cursor c_nxt = after(c_cur);
+        uint32_t w_nxt = ops_at(c_nxt);
+        while (c_cur.valid) {
+            chunk_land(k_cur);
+            // (scanned whether there is a chunk or not -- behind the last one the ops are null ops and nothing hits --: every path through
+            //  a turn then consumes the ops it asked for, and the compiler's wait in front of the next request is not for everything)
+            nf_chunk<STG_IT> k_nxt = chunk_scan(c_nxt.h, w_nxt, c_nxt.R, c_nxt.Q, c_nxt.i);
+            const cursor c_nn = after(c_nxt);
+            const uint32_t w_nn = ops_at(c_nn);
+            chunk_count(std::integral_constant<bool, U8T>{}, c_cur.h, k_cur);
+            c_cur = c_nxt, k_cur = k_nxt, c_nxt = c_nn, w_nxt = w_nn;
+        }
+#else
         // ---- the wave's reads, one after the other.  Two loads run ahead of the work: the record of the read after next, and the
         //      first 64 ops of the next read (whose record arrived one turn earlier) -- a read then starts with its ops in registers
         //      instead of waiting for three dependent trips to memory ----
@@ -697,9 +864,11 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
             h_cur = h_nxt, h_nxt = h_nn, w_cur = w_nxt;
             read_by_wave(std::integral_constant<bool, U8T>{}, h, w_first, i);
         }
+#endif
     }
     __syncthreads();
     // depth = prefix sum of the difference array: NF_PER_THREAD positions per thread
+#if NF_STOP != 8
     {
         const uint32_t b0 = threadIdx.x * NF_PER_THREAD;
         int32_t d[NF_PER_THREAD], s = 0;
@@ -737,7 +906,8 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         atomicAdd(&blk_cov, cov);
     }
     __syncthreads();
-#if NF_STOP != 4
+#endif
+#if NF_STOP != 4 && !defined(NF_NO_CTR)
     if (threadIdx.x == 0) {
         atomicMax((unsigned long long *)&p.counters->max_depth, (unsigned long long)blk_max);
         atomicAdd((unsigned long long *)&p.counters->n_covered, (unsigned long long)blk_cov);
@@ -765,7 +935,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
 // the byte-counter build: a workgroup per tile (it leaves the tiles of the other build alone); the 16-bit build: workgroups that stay and
 // walk the list of ITS tiles -- none on long-read data, where launching it over all 61 k tiles of config 5 to find that out took 0.13 ms a call
 template <bool U8T>
-__global__ __launch_bounds__(NF_THREADS) void rb_k_nf_tiles(rb_nf_params p) {
+__global__ __launch_bounds__(NF_THREADS) __attribute__((amdgpu_waves_per_eu(U8T ? 6 : 4))) void rb_k_nf_tiles(rb_nf_params p) {
     if constexpr (U8T) {
         nf_one_tile<true>(p, blockIdx.x);
     } else {
