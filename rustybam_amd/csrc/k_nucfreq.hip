@@ -15,13 +15,14 @@
 //                       a bitmap of the reads each such region's fetch drops (see the comment at rb_k_nf_admit)
 //   rb_k_nf_tiles       workgroup per tile: the tile's counters live in LDS (4 x u16 in one u64 per position, or 4 bytes in one dword
 //                       where at most 255 reads are in range: then one ds_add_u64 covers two positions; + a coverage
-//                       difference array); each wave takes reads of the range in turn, walks the CIGAR 64 ops at a time
-//                       (wave scans give every op its reference / query start), and for every match-type op that
-//                       overlaps the tile each lane takes 8 consecutive positions: the read's bases over the tile are fetched
-//                       into LDS in one go (16 bytes per lane, all loads in flight), two dwords of it give a lane its 8 base
-//                       codes, a 16-entry table turns a code into what it adds, one ds_add_u32 per base (no branch on the
-//                       base: N and the IUPAC codes add 0).  At the end a block scan of the difference array gives the
-//                       depth (coverage + the htslib depth-cap check), and the tile is written out with 16-byte stores.
+//                       difference array).  Each wave takes every NF_WAVES-th read of the tile's range: the reads' records sit one
+//                       per lane, and the reads go by as a stream of chunks of 64 ops, three under way (round 6: the bases of one
+//                       parked in LDS while the next is scanned -- wave scans give every op its reference / query start, all lanes
+//                       at once their op's share of the tile -- and the one after has its ops requested).  For every match-type op
+//                       that overlaps the tile each lane takes 8 consecutive positions: two dwords of the staged bases give a lane
+//                       its 8 base codes, a 256-entry table turns two codes into what they add, one ds_add_u64 per two bases (no
+//                       branch on the base: N and the IUPAC codes add 0).  At the end a block scan of the difference array gives
+//                       the depth (coverage + the htslib depth-cap check), and the tile is written out with 16-byte stores.
 // HBM traffic: each read's packed bases once per tile it overlaps (4 bits / base), its CIGAR likewise, 16 B written per
 // position.  Bound: HBM (the counters never leave LDS).
 #include "rb_device.h"

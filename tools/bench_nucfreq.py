@@ -118,7 +118,7 @@ def main():
     assert tot == m_bases or not check, (tot, m_bases)   # every M base lands inside the contig and is A/C/G/T: a checksum of the whole pile
     alg = n * bytes_per_read + 4 * len(ops) + 16 * a.contig + 44 * n
     traffic = None  # HBM-side bytes per launch from the committed PMC run of this same workload (this script is not run under --pmc)
-    for name in ("traffic_nf_r02.json", "traffic_nf_r01.json"):
+    for name in ("traffic_nf_r06.json", "traffic_nf_r02.json", "traffic_nf_r01.json"):
         try:
             tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", name)))
             if tj["workload"] == {"contig": a.contig, "coverage": a.coverage, "read_len": a.read_len}:
@@ -134,7 +134,7 @@ def main():
         "positions_per_s": a.contig / (ms * 1e-3), "max_depth": int(ctr[0]), "covered": int(ctr[1]),
         "roofline": {"bound": "hbm", "kernel": "rb_k_nf_tiles (whole call)", "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": alg / (ms * 1e-3) / 1e9 / 8000.0, "traffic": traffic, "algorithmic_bytes": alg,
-                     "note": "bound by instruction issue, not by HBM (profiles/r03_nf_summary.md)"},
+                     "note": "bound by instruction issue, not by HBM (profiles/r06_nf_summary.md)"},
         "setup_s": round(setup, 2)}))
 
 
