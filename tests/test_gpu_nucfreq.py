@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import rustybam_amd
-from nf_util import Reads, read_bam, random_reads, check_regions
+from nf_util import QRY_OPS, Reads, read_bam, random_reads, check_regions
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -172,3 +172,40 @@ def test_crowded_tile_lane_per_read_path(engine, oracle):
     rd2 = Reads([0] * 900, [poss[i] for i in order], [0] * 900, [cigs[i] for i in order], seqs2)
     counts, status, ctr = engine.nucfreq(*rd2.args(), [0], [0], [2000])
     assert set(np.flatnonzero(status == rustybam_amd.RD_SEQ_SHORT).tolist()) == short
+
+
+def test_chunk_boundaries_and_short_sequences(engine, oracle):
+    """round 6: a wave's reads go by as a stream of 64-op chunks, three under way.  Reads of 63 .. 200 ops (one chunk, exactly one, one
+    op into the next, three and a bit), several per wave and tile, tiles that start and end inside chunks -- against the oracle; then
+    the same reads with sequences cut short somewhere inside (record().seq()[qpos] out of bounds: the reference panics, the device
+    counts what is there and flags the read): the counts must be those of the reads with the missing bases present as code 0."""
+    rng = np.random.default_rng(606)
+    M, I, D, EQ, X = 0, 1, 2, 7, 8
+    cigs, seqs, poss = [], [], []
+    for k, n_ops in enumerate([63, 64, 65, 127, 128, 129, 200, 64, 65, 190, 1, 2, 66, 130] * 3):
+        c = []
+        for j in range(n_ops):
+            o = [M, I, M, D, EQ, X][j % 6] if n_ops > 2 else M
+            c.append((int(rng.integers(1, 8) if o in (I, D) else rng.integers(20, 160)) << 4) | o)
+        if (c[0] & 15) in (I, D):
+            c[0] = (c[0] & ~15) | M
+        if (c[-1] & 15) in (I, D):
+            c[-1] = (c[-1] & ~15) | M
+        q = sum(w >> 4 for w in c if (w & 15) in QRY_OPS)
+        cigs.append(c), seqs.append(rng.choice([1, 2, 4, 8, 15], size=q).tolist()), poss.append(int(rng.integers(0, 9000)))
+    order = np.argsort(poss, kind="stable")
+    cigs, seqs, poss = [cigs[i] for i in order], [seqs[i] for i in order], [poss[i] for i in order]
+    regions = [(0, 0, 50000), (0, 4000, 4200), (0, 8191, 12289)]
+    full = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, seqs)
+    counts_full, status, _ = check_regions(engine, oracle, full, regions)
+    assert (status == rustybam_amd.RD_OK).all()
+    # cut every third read's sequence short; expected = the full-length read with code 0 (counts nothing) where the bases are missing
+    cut = {i: int(rng.integers(0, len(seqs[i]))) for i in range(0, len(seqs), 3) if len(seqs[i]) > 1}
+    padded = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, [s[:cut[i]] + [0] * (len(s) - cut[i]) if i in cut else s for i, s in enumerate(seqs)])
+    short = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, [s[:cut[i]] if i in cut else s for i, s in enumerate(seqs)])
+    counts_pad, _, _ = check_regions(engine, oracle, padded, regions)
+    rg = np.array(regions, np.int64)
+    counts_short, status_short, _ = engine.nucfreq(*short.args(), rg[:, 0], rg[:, 1], rg[:, 2])
+    assert np.array_equal(counts_short, counts_pad)
+    want = np.array([rustybam_amd.RD_SEQ_SHORT if i in cut else rustybam_amd.RD_OK for i in range(len(cigs))])
+    assert np.array_equal(status_short, want)
