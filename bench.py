@@ -64,7 +64,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--early-exit", action="store_true", help="allow the kernel to stop a record early (off: full walk)")
     ap.add_argument("--unfused", action="store_true", help="run rb_dev_scan_records as its own pass inside the step instead of the fused scan")
-    ap.add_argument("--placement-tries", type=int, default=4,
+    ap.add_argument("--placement-tries", type=int, default=5,
                     help="candidates rb_dev_alloc_placed may allocate for the output arena (a store sweep over each, the fastest kept: set-up, "
                          "not timed); 1 = plain rb_dev_alloc")
     ap.add_argument("--placement-by", default="launch", choices=["launch", "sweep"],
