@@ -38,14 +38,14 @@ def test_a_failing_rank_fails_the_job():
 
 def test_defaults_place_the_arena_by_the_step_itself(monkeypatch):
     """the driver's `python bench.py` (no flags): N = 1, a K / W that finish in minutes, the output arena and the ops array placed by
-    measurement (four candidates, ranked by the step itself) -- and `--placement-tries 1` is the way back to plain rb_dev_alloc"""
+    measurement (five candidates, ranked by the step itself) -- and `--placement-tries 1` is the way back to plain rb_dev_alloc"""
     sys.path.insert(0, ROOT)
     import importlib
     bench = importlib.import_module("bench")
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
     assert (a.gpus, a.op, a.workload) == (1, "liftover", "config3") and 1 <= a.steps <= 100 and a.warmup >= 1
-    assert a.placement_tries == 4 and a.placement_by == "launch"
+    assert a.placement_tries == 5 and a.placement_by == "launch"
     monkeypatch.setattr(sys, "argv", ["bench.py", "--placement-tries", "1", "--placement-by", "sweep"])
     a = bench.parse()
     assert a.placement_tries == 1 and a.placement_by == "sweep"
