@@ -14,7 +14,7 @@
 //   rb_k_nf_crowded / _deep_regions / _admit   htslib's cap of 8000 buffered reads, replayed per region only where it can be reached:
 //                       a bitmap of the reads each such region's fetch drops (see the comment at rb_k_nf_admit)
 //   rb_k_nf_tiles       workgroup per tile: the tile's counters live in LDS (4 x u16 in one u64 per position, or 4 bytes in one dword
-//                       where at most 255 reads are in range: then one ds_add_u64 covers two positions; + a coverage
+//                       where at most 127 reads are in range: then one ds_add_u64 covers two positions; + a coverage
 //                       difference array).  Each wave takes every NF_WAVES-th read of the tile's range: the reads' records sit one
 //                       per lane, and the reads go by as a stream of chunks of 64 ops, three under way (round 6: the bases of one
 //                       parked in LDS while the next is scanned -- wave scans give every op its reference / query start, all lanes
@@ -384,8 +384,8 @@ __device__ __forceinline__ bool nf_dropped(const nf_drop &d, uint64_t i) { // di
     return (d.bits[b >> 6] >> (b & 63u)) & 1ull;
 }
 
-// a tile with at most this many reads in range cannot count past 255 anywhere: its counters are bytes (see rb_k_nf_tiles)
-#define NF_U8_MAX_READS 255u
+// a tile with at most this many reads in range cannot count past 127 anywhere: its counters are bytes (see rb_k_nf_tiles)
+#define NF_U8_MAX_READS 127u // (255 would do for the counters; 127 lets a position's coverage difference be a signed BYTE: see nf_one_tile)
 __device__ __forceinline__ bool nf_u8_tile(const rb_nf_params &p, uint64_t lo, uint64_t hi) { return !(p.flags & 1u) && hi - lo <= NF_U8_MAX_READS; }
 
 // everything a workgroup needs about a tile in ONE 64-byte record at a wave-uniform address (a scalar load), instead of the chain tile_off ->
@@ -434,11 +434,17 @@ __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { // (two shifts
     return o;
 }
 
-// Two builds of the tile kernel.  U8T: tiles with at most 255 reads in range (byte counters, the coverage differences as 16-bit
-// halves of a dword, a staging buffer of 640 dwords): 49 KB of LDS, three workgroups per CU instead of two -- the kernel waits on
-// LDS and memory latency, and the third workgroup is worth 20 % (4.43 -> 3.6 ms on config 5).  The other build takes the tiles
-// crowded with reads (16-bit counters, 32-bit differences: 77 KB).  Both are launched over all tiles and leave the other's alone.
+// Two builds of the tile kernel.  U8T: tiles with at most 127 reads in range (byte counters, the coverage differences as signed bytes in the
+// counters' own padding, staging buffers of 548 dwords): 40 KB of LDS, FOUR workgroups per CU (round 2: 49 KB and three instead of the
+// other build's two -- 4.43 -> 3.6 ms on config 5; round 6: the fourth).  The other build takes the tiles crowded with reads (16-bit
+// counters, 32-bit differences: 77 KB).  Each leaves the other's tiles alone.
 #define NF_CNT8_DW (10 * ((NF_TILE + 16) / 8))
+#ifndef NF_U8_WPE
+#define NF_U8_WPE 8 // waves per SIMD the byte-counter build is compiled for: four workgroups of eight waves a CU
+#endif
+#ifndef NF_U8_SLACK_DW
+#define NF_U8_SLACK_DW 28 // byte-counter tiles: dwords of staging beyond the tile's own 512 (224 inserted bases + alignment; more: the unstaged route)
+#endif
 #ifndef NF_PIPE
 #define NF_PIPE 1 // 0: the wave's reads strictly one after the other (rounds 1 - 5)
 #endif
@@ -460,7 +466,8 @@ struct nf_chunk { // (no implicit padding: the compiler copies a struct's paddin
 };
 template <bool U8T>
 __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_t t) {
-    constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + 128) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
+    constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + NF_U8_SLACK_DW) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
+    static_assert((STG + 8) % 4 == 0, "a wave's staging buffer starts 16-byte aligned");
     constexpr int STG_IT = (int)((STG + 255u) / 256u);
     constexpr uint32_t CNT_DW = ((U8T ? NF_CNT8_DW : NF_CNT_DW) + 3) / 4 * 4; // (zeroed 16 bytes at a time)
     __shared__ __attribute__((aligned(16))) uint32_t cnt[CNT_DW]; // per position: one dword of four byte counters / A | C << 16, G | T << 16
@@ -473,9 +480,14 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         lut16[threadIdx.x] = one(threadIdx.x & 15u) | (one(threadIdx.x >> 4) << 32);
     }
 #endif
-    // +1 where a read starts covering, -1 where it stops; then the depth.  U8T: two positions a dword -- the halves are added as
-    // whole 32-bit integers (a borrow of the low half travels into the high one and is taken back when the word is read)
-    constexpr uint32_t NF_DIFF_DW = ((U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8) + 3) / 4 * 4;
+    // +1 where a read starts covering, -1 where it stops; then the depth.  U8T (round 6): a signed BYTE per position, and the bytes live
+    // in the counters' own padding -- a group of 8 positions is 10 dwords, 8 of counters and 2 that only keep the lanes of an atomic on
+    // different banks: 8 bytes, one per position.  They are added as whole 32-bit integers (a borrow of a byte travels into the next one
+    // and is taken back when the dword is read: exact while |difference| <= 127, i.e. at most 127 reads in range, NF_U8_MAX_READS).
+    // With that, the eight staging buffers a little shorter and nothing else, a tile is 40 KB of LDS: FOUR workgroups a CU instead of
+    // three (51 KB before), eight waves per SIMD -- the kernel's vector ALU idled a quarter of the time for want of a fourth tile in
+    // another phase.
+    constexpr uint32_t NF_DIFF_DW = U8T ? 4u : ((uint32_t)(NF_TILE + 8) + 3u) / 4u * 4u;
     __shared__ __attribute__((aligned(16))) int32_t diff[NF_DIFF_DW];
     __shared__ uint8_t covb[U8T ? NF_THREADS : 4]; // U8T: which of a thread's 8 positions are covered
     __shared__ int32_t wsum[NF_WAVES];
@@ -508,10 +520,15 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         for (uint32_t k = threadIdx.x; k < CNT_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(cnt)[k] = make_uint4(0, 0, 0, 0);
     }
     if ((threadIdx.x & 63u) < 4u) stage_all[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
-    for (uint32_t k = threadIdx.x; k < NF_DIFF_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(diff)[k] = make_uint4(0, 0, 0, 0);
+    if constexpr (!U8T)
+        for (uint32_t k = threadIdx.x; k < NF_DIFF_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(diff)[k] = make_uint4(0, 0, 0, 0);
     auto diff_add = [&](uint32_t i, int32_t delta) {
-        if constexpr (U8T) atomicAdd(&diff[i >> 1], (int32_t)((uint32_t)delta << (16u * (i & 1u))));
-        else atomicAdd(&diff[i], delta);
+        if constexpr (U8T) { // position i = byte (i + 8) & 7 of the two spare dwords of its group (i + 8) >> 3
+            const uint32_t q = i + 8u;
+            atomicAdd(reinterpret_cast<int32_t *>(&cnt[10u * (q >> 3) + 8u + ((q >> 2) & 1u)]), (int32_t)((uint32_t)delta << (8u * (q & 3u))));
+        } else {
+            atomicAdd(&diff[i], delta);
+        }
     };
     if (threadIdx.x < 16) {
         const uint32_t n = threadIdx.x;
@@ -523,7 +540,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     const uint32_t wib = rb_first(threadIdx.x >> 6);
     const int lane = rb_lane();
     const uint64_t lo = D.lo, hi = D.hi;
-    // U8 tiles (at most 255 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
+    // U8 tiles (at most 127 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
     // per 8 positions (lane l of an add is 10 l dwords on: all of a half-wave's 8-byte accesses on different banks), and one
     // ds_add_u64 covers two positions -- half the atomics of the 16-bit layout and no choice of word per base
     const uint32_t *__restrict__ sw32 = reinterpret_cast<const uint32_t *>(p.seq);
@@ -873,17 +890,28 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     {
         const uint32_t b0 = threadIdx.x * NF_PER_THREAD;
         int32_t d[NF_PER_THREAD], s = 0;
+        if constexpr (U8T) {
+            // the thread's 8 positions are one group of the counters (tile position 8 t = slot 8 t + 8): its differences are the 8 bytes of
+            // the group's two spare dwords; byte by byte, each one's borrow taken back out of what is left
+            static_assert(NF_PER_THREAD == 8, "a thread scans one group of 8 positions");
+            const uint2 sp2 = *reinterpret_cast<const uint2 *>(&cnt[10u * (threadIdx.x + 1u) + 8u]);
 #pragma unroll
-        for (int k = 0; k < NF_PER_THREAD; k++) {
-            int32_t dk;
-            if constexpr (U8T) { // (b0 is even: positions b0 + k and b0 + k + 1, k even, share a dword)
-                const int32_t v = diff[(b0 + (uint32_t)k) >> 1], lo16 = (int32_t)(int16_t)(uint16_t)((uint32_t)v & 0xFFFFu);
-                dk = (k & 1) ? ((v - lo16) >> 16) : lo16;
-            } else {
-                dk = diff[b0 + k];
+            for (int h = 0; h < 2; h++) {
+                int32_t v = (int32_t)(h ? sp2.y : sp2.x);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int32_t dk = (int32_t)(int8_t)(uint8_t)((uint32_t)v & 255u);
+                    v = (v - dk) >> 8;
+                    s += dk;
+                    d[4 * h + k] = s;
+                }
             }
-            s += dk;
-            d[k] = s;
+        } else {
+#pragma unroll
+            for (int k = 0; k < NF_PER_THREAD; k++) {
+                s += diff[b0 + k];
+                d[k] = s;
+            }
         }
         const int32_t inc = (int32_t)rb_wave_scan_incl((uint32_t)s);
         if (lane == 63) wsum[wib] = inc;
@@ -936,7 +964,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
 // the byte-counter build: a workgroup per tile (it leaves the tiles of the other build alone); the 16-bit build: workgroups that stay and
 // walk the list of ITS tiles -- none on long-read data, where launching it over all 61 k tiles of config 5 to find that out took 0.13 ms a call
 template <bool U8T>
-__global__ __launch_bounds__(NF_THREADS) __attribute__((amdgpu_waves_per_eu(U8T ? 6 : 4))) void rb_k_nf_tiles(rb_nf_params p) {
+__global__ __launch_bounds__(NF_THREADS) __attribute__((amdgpu_waves_per_eu(U8T ? NF_U8_WPE : 4))) void rb_k_nf_tiles(rb_nf_params p) {
     if constexpr (U8T) {
         nf_one_tile<true>(p, blockIdx.x);
     } else {

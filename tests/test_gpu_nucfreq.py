@@ -209,3 +209,23 @@ def test_chunk_boundaries_and_short_sequences(engine, oracle):
     assert np.array_equal(counts_short, counts_pad)
     want = np.array([rustybam_amd.RD_SEQ_SHORT if i in cut else rustybam_amd.RD_OK for i in range(len(cigs))])
     assert np.array_equal(status_short, want)
+
+
+@pytest.mark.parametrize("n", [126, 127, 128, 129])
+def test_byte_counters_and_byte_differences_at_their_limit(engine, oracle, n):
+    """round 6: a tile with at most 127 reads in range keeps a position's coverage difference as a signed byte in the counters' padding
+    (borrows between the bytes of a dword taken back at the read).  n identical reads: +n where they start, -n behind their end, every
+    counter n; 127 is the last tile of the byte build, 128 the first of the 16-bit one.  Next to them reads that end and start on
+    neighbouring positions (differences of both signs inside one dword)."""
+    M, D = 0, 2
+    cig = [(300 << 4) | M, (5 << 4) | D, (200 << 4) | M]
+    cigs = [cig] * n
+    seqs = [[1, 2, 4, 8] * 125] * n
+    poss = [1001] * n
+    k = (n - 1) // 2   # a second pile that ends where a third one starts, one position apart
+    cigs += [[(100 << 4) | M]] * k + [[(64 << 4) | M]] * (n - 1 - k)
+    seqs += [[8] * 100] * k + [[2] * 64] * (n - 1 - k)
+    poss += [6000] * k + [6101] * (n - 1 - k)
+    rd = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, seqs)
+    counts, status, ctr = check_regions(engine, oracle, rd, [(0, 0, 8192), (0, 1000, 1002), (0, 1505, 1507)])
+    assert ctr["max_depth"] == n and (status == rustybam_amd.RD_OK).all()
