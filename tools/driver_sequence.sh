@@ -2,7 +2,7 @@
 # the driver's own sequence on the final tree: the whole GPU suite, smoke, the default bench line
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-tag=${1:-r06_full}
+tag=${1:-driver_sequence}
 out=gpurun_out/$tag
 mkdir -p $out
 timeout -k 5 2400 python3 -m pytest tests -q -m gpu -x > $out/tests.log 2>&1; echo "tests rc=$?"; tail -4 $out/tests.log
