@@ -70,7 +70,8 @@ struct rb_nf_params {
     uint32_t *deep_list;  // [n_regions + 1] regions whose fetch holds more reads than the cap; [n_regions] = how many
     uint32_t flags;       // bit 0: 16-bit counters for every tile (diagnostic)
     struct nf_tdesc *tdesc; // [max_tiles] what a workgroup needs to know about a tile, in one 64-byte record (rb_k_nf_tile_desc)
-    uint32_t *wide_list;    // [1 + max_tiles] how many tiles take the 16-bit build, then which (rb_k_nf_tile_desc lists them)
+    uint32_t *wide_list;    // [max_tiles + 2] the tiles of the two builds that walk lists (rb_k_nf_tile_desc): [0] = how many of kind 2, then which,
+                            // upwards from [1]; [max_tiles + 1] = how many of kind 0, then which, downwards from [max_tiles]
 };
 
 // one read as the tile kernel sees it: a single 48-byte record (one scalar load) instead of eight arrays
@@ -385,8 +386,13 @@ __device__ __forceinline__ bool nf_dropped(const nf_drop &d, uint64_t i) { // di
 }
 
 // a tile with at most this many reads in range cannot count past 127 anywhere: its counters are bytes (see rb_k_nf_tiles)
-#define NF_U8_MAX_READS 127u // (255 would do for the counters; 127 lets a position's coverage difference be a signed BYTE: see nf_one_tile)
-__device__ __forceinline__ bool nf_u8_tile(const rb_nf_params &p, uint64_t lo, uint64_t hi) { return !(p.flags & 1u) && hi - lo <= NF_U8_MAX_READS; }
+#define NF_U8_MAX_READS 255u
+#define NF_D8_MAX_READS 127u // up to here a position's coverage difference is a signed BYTE too (nf_one_tile: the 40 KB build)
+// which build of the tile kernel takes a tile: 1 = byte counters + byte differences, 2 = byte counters + 16-bit differences, 0 = 16-bit counters
+__device__ __forceinline__ uint32_t nf_tile_kind(const rb_nf_params &p, uint64_t lo, uint64_t hi) {
+    if (p.flags & 1u) return 0u;
+    return hi - lo <= NF_D8_MAX_READS ? 1u : hi - lo <= NF_U8_MAX_READS ? 2u : 0u;
+}
 
 // everything a workgroup needs about a tile in ONE 64-byte record at a wave-uniform address (a scalar load), instead of the chain tile_off ->
 // region (a binary search) -> region arrays -> drop_off -> tile_lo of the region's first tile that rb_k_nf_tiles walks at its start
@@ -394,7 +400,7 @@ struct __attribute__((aligned(64))) nf_tdesc {
     uint64_t st, out, lo, hi, drop_off, drop_rlo; // first position, first output position, reads [lo, hi), the region's dropped-read bitmap
     uint32_t n_pos;
     int32_t tid;
-    uint32_t r, u8; // region; 1: the byte-counter build takes the tile
+    uint32_t r, u8; // region; which build takes the tile (nf_tile_kind)
 };
 // a record loaded at a wave-uniform address, told to the compiler as the wave-uniform value it is
 __device__ __forceinline__ uint64_t nf_first64(uint64_t v) { return rb_first64(v); }
@@ -418,9 +424,11 @@ __global__ __launch_bounds__(256) void rb_k_nf_tile_desc(rb_nf_params p) {
     const nf_drop d = nf_drop_of(p, T);
     nf_tdesc D;
     D.st = T.st, D.out = T.out, D.lo = p.tile_lo[t], D.hi = p.tile_hi[t], D.drop_off = d.off, D.drop_rlo = d.rlo;
-    D.n_pos = (uint32_t)(T.en - T.st), D.tid = T.tid, D.r = (uint32_t)T.r, D.u8 = nf_u8_tile(p, D.lo, D.hi) ? 1u : 0u;
+    D.n_pos = (uint32_t)(T.en - T.st), D.tid = T.tid, D.r = (uint32_t)T.r, D.u8 = nf_tile_kind(p, D.lo, D.hi);
     p.tdesc[t] = D;
-    if (!D.u8) p.wide_list[1u + atomicAdd(&p.wide_list[0], 1u)] = (uint32_t)t; // (the 16-bit build walks this list: round 5 -- it used to be launched over all tiles to find its own)
+    // (the builds of the rarer kinds walk lists: round 5 -- the 16-bit build used to be launched over all tiles to find its own)
+    if (D.u8 == 2u) p.wide_list[1u + atomicAdd(&p.wide_list[0], 1u)] = (uint32_t)t;
+    else if (D.u8 == 0u) p.wide_list[p.max_tiles - atomicAdd(&p.wide_list[p.max_tiles + 1u], 1u)] = (uint32_t)t;
 }
 
 // LDS place of tile position i: two dwords (A | C << 16, G | T << 16); 8 guard positions in front (a lane's group of 8 may start
@@ -464,9 +472,14 @@ struct nf_chunk { // (no implicit padding: the compiler copies a struct's paddin
     uint32_t pad[2];
     uint4 v[IT];
 };
-template <bool U8T>
+template <bool U8T, bool D8>
 __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_t t) {
-    constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + NF_U8_SLACK_DW) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
+    // the thread's index through an opaque copy: what is derived from it (a dozen lane-times-constant addresses) is then computed per
+    // tile -- a few instructions -- instead of being kept in registers across the list-walking builds' loop over tiles, where it cost spills
+    uint32_t tix;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tix) : "v"(threadIdx.x));
+    static_assert(U8T || !D8, "byte differences live in the byte counters' padding");
+    constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + (D8 ? NF_U8_SLACK_DW : 128)) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
     static_assert((STG + 8) % 4 == 0, "a wave's staging buffer starts 16-byte aligned");
     constexpr int STG_IT = (int)((STG + 255u) / 256u);
     constexpr uint32_t CNT_DW = ((U8T ? NF_CNT8_DW : NF_CNT_DW) + 3) / 4 * 4; // (zeroed 16 bytes at a time)
@@ -475,9 +488,9 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     __shared__ uint32_t lut8[16];       // U8 tiles: 1 2 4 8 = A C G T: 1 << 0, 8, 16, 24
 #ifndef NF_LUT_SINGLE
     __shared__ unsigned long long lut16[U8T ? 256 : 1]; // two bases at once: low nibble -> low dword, high nibble -> high dword
-    if (U8T && threadIdx.x < 256) {
+    if (U8T && tix < 256) {
         auto one = [](uint32_t n) -> unsigned long long { return n == 1 ? 1ull : n == 2 ? 0x100ull : n == 4 ? 0x10000ull : n == 8 ? 0x1000000ull : 0ull; };
-        lut16[threadIdx.x] = one(threadIdx.x & 15u) | (one(threadIdx.x >> 4) << 32);
+        lut16[tix] = one(tix & 15u) | (one(tix >> 4) << 32);
     }
 #endif
     // +1 where a read starts covering, -1 where it stops; then the depth.  U8T (round 6): a signed BYTE per position, and the bytes live
@@ -487,7 +500,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     // With that, the eight staging buffers a little shorter and nothing else, a tile is 40 KB of LDS: FOUR workgroups a CU instead of
     // three (51 KB before), eight waves per SIMD -- the kernel's vector ALU idled a quarter of the time for want of a fourth tile in
     // another phase.
-    constexpr uint32_t NF_DIFF_DW = U8T ? 4u : ((uint32_t)(NF_TILE + 8) + 3u) / 4u * 4u;
+    constexpr uint32_t NF_DIFF_DW = D8 ? 4u : ((uint32_t)(U8T ? (NF_TILE + 8) / 2 + 2 : NF_TILE + 8) + 3u) / 4u * 4u; // (!D8, byte counters: two positions a dword, 16-bit halves added as whole integers)
     __shared__ __attribute__((aligned(16))) int32_t diff[NF_DIFF_DW];
     __shared__ uint8_t covb[U8T ? NF_THREADS : 4]; // U8T: which of a thread's 8 positions are covered
     __shared__ int32_t wsum[NF_WAVES];
@@ -497,7 +510,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     // (round 4: the tile's facts come as ONE 64-byte record at a wave-uniform address -- rb_k_nf_tile_desc -- instead of a binary search
     //  for the region followed by dependent loads of its arrays, of the region's first tile and of its dropped-read bitmap's place)
     const nf_tdesc D = nf_uniform(p.tdesc[t]);
-    if ((D.u8 != 0u) != U8T) return; // the other build's
+    if (D.u8 != (D8 ? 1u : U8T ? 2u : 0u)) return; // another build's
 #if NF_STOP == 7
     if (D.n_pos != 0x7FFFFFFFu) return; // (timing only: what it costs to launch the tiles' workgroups)
 #endif
@@ -510,35 +523,37 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     // the wave's reads (lo + wave + NF_WAVES j): lane j asks for read j's record now, before the tile is zeroed -- the first of the
     // dependent trips (tile -> records -> ops -> bases) runs under the zeroing and the barrier.  (Not for the crowded tiles: lane-per-read.)
     const bool nf_by_wave = U8T || D.hi - D.lo <= 8u * 64u;
-    const uint32_t nw = nf_by_wave && D.hi > D.lo + (threadIdx.x >> 6) ? (uint32_t)((D.hi - D.lo - (threadIdx.x >> 6) + NF_WAVES - 1) / NF_WAVES) : 0u;
+    const uint32_t nw = nf_by_wave && D.hi > D.lo + (tix >> 6) ? (uint32_t)((D.hi - D.lo - (tix >> 6) + NF_WAVES - 1) / NF_WAVES) : 0u;
     nf_read hv;
     hv.pos = 0, hv.end = 0, hv.tid = -1, hv.l_seq = 0, hv.op_off = 0, hv.n_ops = 0, hv.pad0 = 0, hv.nib0 = 0, hv.pad1 = 0;
-    const uint64_t hv_i = D.lo + (threadIdx.x >> 6) + (uint64_t)NF_WAVES * (threadIdx.x & 63u);
-    if ((threadIdx.x & 63u) < nw) hv = p.hd[hv_i];
+    const uint64_t hv_i = D.lo + (tix >> 6) + (uint64_t)NF_WAVES * (tix & 63u);
+    if ((tix & 63u) < nw) hv = p.hd[hv_i];
 #endif
     {   // (16 bytes a store: a quarter of the instructions)
-        for (uint32_t k = threadIdx.x; k < CNT_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(cnt)[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = tix; k < CNT_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(cnt)[k] = make_uint4(0, 0, 0, 0);
     }
-    if ((threadIdx.x & 63u) < 4u) stage_all[threadIdx.x >> 6][threadIdx.x & 63u] = 0;
-    if constexpr (!U8T)
-        for (uint32_t k = threadIdx.x; k < NF_DIFF_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(diff)[k] = make_uint4(0, 0, 0, 0);
+    if ((tix & 63u) < 4u) stage_all[tix >> 6][tix & 63u] = 0;
+    if constexpr (!D8)
+        for (uint32_t k = tix; k < NF_DIFF_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(diff)[k] = make_uint4(0, 0, 0, 0);
     auto diff_add = [&](uint32_t i, int32_t delta) {
-        if constexpr (U8T) { // position i = byte (i + 8) & 7 of the two spare dwords of its group (i + 8) >> 3
+        if constexpr (D8) { // position i = byte (i + 8) & 7 of the two spare dwords of its group (i + 8) >> 3
             const uint32_t q = i + 8u;
             atomicAdd(reinterpret_cast<int32_t *>(&cnt[10u * (q >> 3) + 8u + ((q >> 2) & 1u)]), (int32_t)((uint32_t)delta << (8u * (q & 3u))));
+        } else if constexpr (U8T) {
+            atomicAdd(&diff[i >> 1], (int32_t)((uint32_t)delta << (16u * (i & 1u))));
         } else {
             atomicAdd(&diff[i], delta);
         }
     };
-    if (threadIdx.x < 16) {
-        const uint32_t n = threadIdx.x;
+    if (tix < 16) {
+        const uint32_t n = tix;
         lut[n] = (n == 1 || n == 4) ? 1u : (n == 2 || n == 8) ? 0x10000u : 0u;
         lut8[n] = n == 1 ? 1u : n == 2 ? 0x100u : n == 4 ? 0x10000u : n == 8 ? 0x1000000u : 0u;
     }
-    if (threadIdx.x == 0) blk_max = 0, blk_cov = 0;
+    if (tix == 0) blk_max = 0, blk_cov = 0;
     __syncthreads();
-    const uint32_t wib = rb_first(threadIdx.x >> 6);
-    const int lane = rb_lane();
+    const uint32_t wib = rb_first(tix >> 6);
+    const int lane = (int)(tix & 63u);
     const uint64_t lo = D.lo, hi = D.hi;
     // U8 tiles (at most 127 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
     // per 8 positions (lane l of an add is 10 l dwords on: all of a half-wave's 8-byte accesses on different banks), and one
@@ -888,13 +903,13 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     // depth = prefix sum of the difference array: NF_PER_THREAD positions per thread
 #if NF_STOP != 8
     {
-        const uint32_t b0 = threadIdx.x * NF_PER_THREAD;
+        const uint32_t b0 = tix * NF_PER_THREAD;
         int32_t d[NF_PER_THREAD], s = 0;
-        if constexpr (U8T) {
+        if constexpr (D8) {
             // the thread's 8 positions are one group of the counters (tile position 8 t = slot 8 t + 8): its differences are the 8 bytes of
             // the group's two spare dwords; byte by byte, each one's borrow taken back out of what is left
             static_assert(NF_PER_THREAD == 8, "a thread scans one group of 8 positions");
-            const uint2 sp2 = *reinterpret_cast<const uint2 *>(&cnt[10u * (threadIdx.x + 1u) + 8u]);
+            const uint2 sp2 = *reinterpret_cast<const uint2 *>(&cnt[10u * (tix + 1u) + 8u]);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 int32_t v = (int32_t)(h ? sp2.y : sp2.x);
@@ -909,7 +924,14 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         } else {
 #pragma unroll
             for (int k = 0; k < NF_PER_THREAD; k++) {
-                s += diff[b0 + k];
+                int32_t dk;
+                if constexpr (U8T) { // (b0 is even: positions b0 + k and b0 + k + 1, k even, share a dword)
+                    const int32_t v = diff[(b0 + (uint32_t)k) >> 1], lo16 = (int32_t)(int16_t)(uint16_t)((uint32_t)v & 0xFFFFu);
+                    dk = (k & 1) ? ((v - lo16) >> 16) : lo16;
+                } else {
+                    dk = diff[b0 + k];
+                }
+                s += dk;
                 d[k] = s;
             }
         }
@@ -930,14 +952,14 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
                 cov += dep > 0;
             }
         }
-        if constexpr (U8T) covb[threadIdx.x] = (uint8_t)cbits;
+        if constexpr (U8T) covb[tix] = (uint8_t)cbits;
         atomicMax(&blk_max, (uint32_t)mx);
         atomicAdd(&blk_cov, cov);
     }
     __syncthreads();
 #endif
 #if NF_STOP != 4 && !defined(NF_NO_CTR)
-    if (threadIdx.x == 0) {
+    if (tix == 0) {
         atomicMax((unsigned long long *)&p.counters->max_depth, (unsigned long long)blk_max);
         atomicAdd((unsigned long long *)&p.counters->n_covered, (unsigned long long)blk_cov);
     }
@@ -948,13 +970,13 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
 #endif
     if constexpr (U8T) {
         static_assert(NF_PER_THREAD <= 8, "one byte of coverage flags per thread");
-        for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
+        for (uint32_t k = tix; k < n_pos; k += NF_THREADS) {
             const uint32_t v = cnt[10u * ((k + 8u) >> 3) + ((k + 8u) & 7u)];
             const bool covered = (covb[k / NF_PER_THREAD] >> (k % NF_PER_THREAD)) & 1u;
             out[k] = make_uint4((v & 255u) | (covered ? RB_NF_COVERED : 0u), (v >> 8) & 255u, (v >> 16) & 255u, v >> 24);
         }
     } else {
-        for (uint32_t k = threadIdx.x; k < n_pos; k += NF_THREADS) {
+        for (uint32_t k = tix; k < n_pos; k += NF_THREADS) {
             const uint32_t ac = cnt[nf_slot(k)], gt = cnt[nf_slot(k) + 1];
             out[k] = make_uint4((ac & 0xFFFFu) | (diff[k] > 0 ? RB_NF_COVERED : 0u), ac >> 16, gt & 0xFFFFu, gt >> 16);
         }
@@ -963,15 +985,24 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
 
 // the byte-counter build: a workgroup per tile (it leaves the tiles of the other build alone); the 16-bit build: workgroups that stay and
 // walk the list of ITS tiles -- none on long-read data, where launching it over all 61 k tiles of config 5 to find that out took 0.13 ms a call
-template <bool U8T>
-__global__ __launch_bounds__(NF_THREADS) __attribute__((amdgpu_waves_per_eu(U8T ? NF_U8_WPE : 4))) void rb_k_nf_tiles(rb_nf_params p) {
-    if constexpr (U8T) {
-        nf_one_tile<true>(p, blockIdx.x);
+// The build of the usual tiles (byte counters, byte differences): a workgroup per tile, the dispatcher hands them out.  The other two walk
+// the list of THEIR tiles (none on long-read data at ordinary coverage): workgroups that stay, each asking a cursor for its next entry
+// while it works on the current one (a static stride loses to the dispatcher's order: tiles differ in work).
+template <bool U8T, bool D8>
+__global__ __launch_bounds__(NF_THREADS) __attribute__((amdgpu_waves_per_eu(D8 ? NF_U8_WPE : U8T ? 6 : 4))) void rb_k_nf_tiles(rb_nf_params p) {
+    if constexpr (D8) {
+        nf_one_tile<true, true>(p, blockIdx.x);
     } else {
-        const uint32_t n = p.wide_list[0];
-        for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-            nf_one_tile<false>(p, p.wide_list[1u + i]);
-            __syncthreads(); // (the next tile zeroes the counters this one's output loop reads)
+        __shared__ uint32_t next_i[2];
+        const uint32_t n = U8T ? p.wide_list[0] : p.wide_list[p.max_tiles + 1u];
+        unsigned long long *cursor = reinterpret_cast<unsigned long long *>(p.blk) + (U8T ? 0 : 1); // (zeroed by the launch; the scans' partials are done with)
+        uint32_t i = blockIdx.x, par = 0;
+        while (i < n) {
+            if (threadIdx.x == 0) next_i[par] = (uint32_t)atomicAdd(cursor, 1ull);
+            nf_one_tile<U8T, false>(p, U8T ? p.wide_list[1u + i] : p.wide_list[p.max_tiles - i]);
+            __syncthreads(); // (the next tile zeroes the counters this one's output loop reads; and next_i is everybody's now)
+            i = gridDim.x + next_i[par];
+            par ^= 1u;
         }
     }
 }
@@ -1000,9 +1031,15 @@ extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stre
     hipLaunchKernelGGL(rb_k_nf_deep_regions, dim3((unsigned)((p.n_regions + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL(rb_k_nf_admit, dim3(512), dim3(64), 0, stream, p);
     e = rb_fill_async(p.wide_list, 0, 4, stream);
+    if (e == hipSuccess) e = rb_fill_async(p.wide_list + p.max_tiles + 1, 0, 4, stream);
+    if (e == hipSuccess) e = rb_fill_async(p.blk, 0, 16, stream); // (the two list walkers' cursors)
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rb_k_nf_tile_desc, dim3((unsigned)((p.max_tiles + 255) / 256)), dim3(256), 0, stream, p);
-    hipLaunchKernelGGL(rb_k_nf_tiles<true>, dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
-    hipLaunchKernelGGL(rb_k_nf_tiles<false>, dim3((unsigned)std::min<uint64_t>(p.max_tiles, 1024)), dim3(NF_THREADS), 0, stream, p);
+    hipLaunchKernelGGL((rb_k_nf_tiles<true, true>), dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);
+    // the list walkers: as many workgroups as the device holds at a time (three / two per CU by their LDS)
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    hipLaunchKernelGGL((rb_k_nf_tiles<true, false>), dim3((unsigned)std::min<uint64_t>(p.max_tiles, 3ull * (uint64_t)cus)), dim3(NF_THREADS), 0, stream, p);
+    hipLaunchKernelGGL((rb_k_nf_tiles<false, false>), dim3((unsigned)std::min<uint64_t>(p.max_tiles, 2ull * (uint64_t)cus)), dim3(NF_THREADS), 0, stream, p);
     return hipGetLastError();
 }

@@ -211,12 +211,13 @@ def test_chunk_boundaries_and_short_sequences(engine, oracle):
     assert np.array_equal(status_short, want)
 
 
-@pytest.mark.parametrize("n", [126, 127, 128, 129])
+@pytest.mark.parametrize("n", [126, 127, 128, 129, 255, 256, 257])
 def test_byte_counters_and_byte_differences_at_their_limit(engine, oracle, n):
     """round 6: a tile with at most 127 reads in range keeps a position's coverage difference as a signed byte in the counters' padding
     (borrows between the bytes of a dword taken back at the read).  n identical reads: +n where they start, -n behind their end, every
-    counter n; 127 is the last tile of the byte build, 128 the first of the 16-bit one.  Next to them reads that end and start on
-    neighbouring positions (differences of both signs inside one dword)."""
+    counter n; 127 is the last tile of that build, 128 the first of the one with byte counters and 16-bit differences, 255 its last, 256 the
+    first of the 16-bit counters.  Next to them reads that end and start on neighbouring positions (differences of both signs inside one
+    dword)."""
     M, D = 0, 2
     cig = [(300 << 4) | M, (5 << 4) | D, (200 << 4) | M]
     cigs = [cig] * n
@@ -229,3 +230,15 @@ def test_byte_counters_and_byte_differences_at_their_limit(engine, oracle, n):
     rd = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, seqs)
     counts, status, ctr = check_regions(engine, oracle, rd, [(0, 0, 8192), (0, 1000, 1002), (0, 1505, 1507)])
     assert ctr["max_depth"] == n and (status == rustybam_amd.RD_OK).all()
+
+
+@pytest.mark.parametrize("seed,n", [(0, 150), (1, 200), (2, 250), (3, 300)])
+def test_random_reads_128_to_255_per_tile(engine, oracle, seed, n):
+    """the middle build of the tile kernel (byte counters, 16-bit coverage differences: tiles with 128 .. 255 reads in range) walks a
+    list of its tiles, as the 16-bit build does: random reads of every op type packed so that tiles of all three kinds lie side by side"""
+    rng = np.random.default_rng(4242 + seed)
+    rd = random_reads(rng, n, n_contig=1, span=5000, long_frac=0.1, max_ops=30)
+    regions = [(0, 0, 16000), (0, 4000, 4200), (0, 4096, 8192)]
+    counts, status, ctr = check_regions(engine, oracle, rd, regions)
+    filt = (rd.flag & 0x704) != 0
+    assert np.array_equal(status == rustybam_amd.RD_FILTERED, filt)
