@@ -14,7 +14,7 @@
 //   rb_k_nf_crowded / _deep_regions / _admit   htslib's cap of 8000 buffered reads, replayed per region only where it can be reached:
 //                       a bitmap of the reads each such region's fetch drops (see the comment at rb_k_nf_admit)
 //   rb_k_nf_tiles       workgroup per tile: the tile's counters live in LDS (4 x u16 in one u64 per position, or 4 bytes in one dword
-//                       where at most 127 reads are in range: then one ds_add_u64 covers two positions; + a coverage
+//                       where at most 255 reads are in range: then one ds_add_u64 covers two positions; + a coverage
 //                       difference array).  Each wave takes every NF_WAVES-th read of the tile's range: the reads' records sit one
 //                       per lane, and the reads go by as a stream of chunks of 64 ops, three under way (round 6: the bases of one
 //                       parked in LDS while the next is scanned -- wave scans give every op its reference / query start, all lanes
@@ -385,7 +385,7 @@ __device__ __forceinline__ bool nf_dropped(const nf_drop &d, uint64_t i) { // di
     return (d.bits[b >> 6] >> (b & 63u)) & 1ull;
 }
 
-// a tile with at most this many reads in range cannot count past 127 anywhere: its counters are bytes (see rb_k_nf_tiles)
+// a tile with at most this many reads in range cannot count past 255 anywhere: its counters are bytes (see rb_k_nf_tiles)
 #define NF_U8_MAX_READS 255u
 #define NF_D8_MAX_READS 127u // up to here a position's coverage difference is a signed BYTE too (nf_one_tile: the 40 KB build)
 // which build of the tile kernel takes a tile: 1 = byte counters + byte differences, 2 = byte counters + 16-bit differences, 0 = 16-bit counters
@@ -442,10 +442,14 @@ __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { // (two shifts
     return o;
 }
 
-// Two builds of the tile kernel.  U8T: tiles with at most 127 reads in range (byte counters, the coverage differences as signed bytes in the
-// counters' own padding, staging buffers of 548 dwords): 40 KB of LDS, FOUR workgroups per CU (round 2: 49 KB and three instead of the
-// other build's two -- 4.43 -> 3.6 ms on config 5; round 6: the fourth).  The other build takes the tiles crowded with reads (16-bit
-// counters, 32-bit differences: 77 KB).  Each leaves the other's tiles alone.
+// Three builds of the tile kernel (nf_tile_kind):
+//   <U8T, D8>   tiles with at most 127 reads in range -- the usual ones with long reads: byte counters, the coverage differences as signed
+//               bytes in the counters' own padding, staging buffers of 548 dwords: 40 KB of LDS, FOUR workgroups per CU (round 6); a
+//               workgroup per tile, launched over all tiles
+//   <U8T, !D8>  128 .. 255 reads in range: byte counters, the differences as 16-bit halves of a dword, staging buffers of 648 dwords: 51 KB,
+//               three per CU (round 2's byte build: 4.43 -> 3.6 ms on config 5 against the 16-bit layout)
+//   <!U8T>      more reads than that: 16-bit counters, 32-bit differences: 77 KB, two per CU; beyond 512 reads a lane per read
+// The last two walk lists of their tiles (rb_k_nf_tile_desc writes them); each build leaves the others' tiles alone.
 #define NF_CNT8_DW (10 * ((NF_TILE + 16) / 8))
 #ifndef NF_U8_WPE
 #define NF_U8_WPE 8 // waves per SIMD the byte-counter build is compiled for: four workgroups of eight waves a CU
@@ -496,7 +500,8 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     // +1 where a read starts covering, -1 where it stops; then the depth.  U8T (round 6): a signed BYTE per position, and the bytes live
     // in the counters' own padding -- a group of 8 positions is 10 dwords, 8 of counters and 2 that only keep the lanes of an atomic on
     // different banks: 8 bytes, one per position.  They are added as whole 32-bit integers (a borrow of a byte travels into the next one
-    // and is taken back when the dword is read: exact while |difference| <= 127, i.e. at most 127 reads in range, NF_U8_MAX_READS).
+    // and is taken back when the dword is read: exact while |difference| <= 127, i.e. at most 127 reads in range, NF_D8_MAX_READS;
+    // tiles of 128 .. 255 reads keep 16-bit halves in an array of their own: the !D8 build).
     // With that, the eight staging buffers a little shorter and nothing else, a tile is 40 KB of LDS: FOUR workgroups a CU instead of
     // three (51 KB before), eight waves per SIMD -- the kernel's vector ALU idled a quarter of the time for want of a fourth tile in
     // another phase.
@@ -555,7 +560,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     const uint32_t wib = rb_first(tix >> 6);
     const int lane = (int)(tix & 63u);
     const uint64_t lo = D.lo, hi = D.hi;
-    // U8 tiles (at most 127 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
+    // U8 tiles (at most 255 reads in range, the usual case with long reads): a position is ONE dword of four byte counters, 10 dwords
     // per 8 positions (lane l of an add is 10 l dwords on: all of a half-wave's 8-byte accesses on different banks), and one
     // ds_add_u64 covers two positions -- half the atomics of the 16-bit layout and no choice of word per base
     const uint32_t *__restrict__ sw32 = reinterpret_cast<const uint32_t *>(p.seq);
