@@ -451,6 +451,14 @@ __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { // (two shifts
 //   <!U8T>      more reads than that: 16-bit counters, 32-bit differences: 77 KB, two per CU; beyond 512 reads a lane per read
 // The last two walk lists of their tiles (rb_k_nf_tile_desc writes them); each build leaves the others' tiles alone.
 #define NF_CNT8_DW (10 * ((NF_TILE + 16) / 8))
+// -DNF_DIAG (a diagnostics variant, tools/nf_phases.py): every 64th tile's waves add the shader-clock length of their phases to p.blk[8 ..]
+#ifdef NF_DIAG
+#define NF_STAMP(k) const uint64_t nf_t##k = __builtin_amdgcn_s_memtime()
+#define NF_PHASE(slot, a, b) do { if ((t & 63u) == 0u && (tix & 63u) == 0u) atomicAdd(reinterpret_cast<unsigned long long *>(p.blk) + 8 + (slot), (unsigned long long)(nf_t##b - nf_t##a)); } while (0)
+#else
+#define NF_STAMP(k) do { } while (0)
+#define NF_PHASE(slot, a, b) do { } while (0)
+#endif
 #ifndef NF_U8_WPE
 #define NF_U8_WPE 8 // waves per SIMD the byte-counter build is compiled for: four workgroups of eight waves a CU
 #endif
@@ -482,6 +490,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     // tile -- a few instructions -- instead of being kept in registers across the list-walking builds' loop over tiles, where it cost spills
     uint32_t tix;
     asm volatile("v_mov_b32 %0, %1" : "=v"(tix) : "v"(threadIdx.x));
+    NF_STAMP(0);
     static_assert(U8T || !D8, "byte differences live in the byte counters' padding");
     constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + (D8 ? NF_U8_SLACK_DW : 128)) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
     static_assert((STG + 8) % 4 == 0, "a wave's staging buffer starts 16-byte aligned");
@@ -557,6 +566,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     }
     if (tix == 0) blk_max = 0, blk_cov = 0;
     __syncthreads();
+    NF_STAMP(1);
     const uint32_t wib = rb_first(tix >> 6);
     const int lane = (int)(tix & 63u);
     const uint64_t lo = D.lo, hi = D.hi;
@@ -871,6 +881,8 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         if (c_cur.valid) k_cur = chunk_scan(c_cur.h, ops_at(c_cur), c_cur.R, c_cur.Q, c_cur.i);
         cursor c_nxt = after(c_cur);
         uint32_t w_nxt = ops_at(c_nxt);
+        NF_STAMP(2);
+        NF_PHASE(1, 1, 2);
         while (c_cur.valid) {
             chunk_land(k_cur);
             // (scanned whether there is a chunk or not -- behind the last one the ops are null ops and nothing hits --: every path through
@@ -881,6 +893,8 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
             chunk_count(std::integral_constant<bool, U8T>{}, c_cur.h, k_cur);
             c_cur = c_nxt, k_cur = k_nxt, c_nxt = c_nn, w_nxt = w_nn;
         }
+        NF_STAMP(3);
+        NF_PHASE(2, 2, 3);
 #else
         // ---- the wave's reads, one after the other.  Two loads run ahead of the work: the record of the read after next, and the
         //      first 64 ops of the next read (whose record arrived one turn earlier) -- a read then starts with its ops in registers
@@ -904,7 +918,11 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         }
 #endif
     }
+    NF_STAMP(3b);
     __syncthreads();
+    NF_STAMP(4);
+    NF_PHASE(0, 0, 1);
+    NF_PHASE(3, 3b, 4);
     // depth = prefix sum of the difference array: NF_PER_THREAD positions per thread
 #if NF_STOP != 8
     {
@@ -958,11 +976,17 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
             }
         }
         if constexpr (U8T) covb[tix] = (uint8_t)cbits;
-        atomicMax(&blk_max, (uint32_t)mx);
-        atomicAdd(&blk_cov, cov);
+        // (a wave's maximum and sum first: one LDS atomic per wave instead of 64 to one address)
+        const uint32_t wmx = rb_readlane<uint32_t>(rb_wave_scan_incl_max_u32((uint32_t)mx), 63), wcov = rb_wave_sum_u32(cov);
+        if (lane == 0) {
+            atomicMax(&blk_max, wmx);
+            atomicAdd(&blk_cov, wcov);
+        }
     }
     __syncthreads();
 #endif
+    NF_STAMP(5);
+    NF_PHASE(4, 4, 5);
 #if NF_STOP != 4 && !defined(NF_NO_CTR)
     if (tix == 0) {
         atomicMax((unsigned long long *)&p.counters->max_depth, (unsigned long long)blk_max);
@@ -986,10 +1010,14 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
             out[k] = make_uint4((ac & 0xFFFFu) | (diff[k] > 0 ? RB_NF_COVERED : 0u), ac >> 16, gt & 0xFFFFu, gt >> 16);
         }
     }
+    NF_STAMP(6);
+    NF_PHASE(5, 5, 6);
+    NF_PHASE(6, 0, 6);
+#ifdef NF_DIAG
+    if ((t & 63u) == 0u && (tix & 63u) == 0u) atomicAdd(reinterpret_cast<unsigned long long *>(p.blk) + 8 + 7, 1ull);
+#endif
 }
 
-// the byte-counter build: a workgroup per tile (it leaves the tiles of the other build alone); the 16-bit build: workgroups that stay and
-// walk the list of ITS tiles -- none on long-read data, where launching it over all 61 k tiles of config 5 to find that out took 0.13 ms a call
 // The build of the usual tiles (byte counters, byte differences): a workgroup per tile, the dispatcher hands them out.  The other two walk
 // the list of THEIR tiles (none on long-read data at ordinary coverage): workgroups that stay, each asking a cursor for its next entry
 // while it works on the current one (a static stride loses to the dispatcher's order: tiles differ in work).
@@ -1038,6 +1066,9 @@ extern "C" hipError_t rb_launch_nucfreq(const rb_nf_params *pp, hipStream_t stre
     e = rb_fill_async(p.wide_list, 0, 4, stream);
     if (e == hipSuccess) e = rb_fill_async(p.wide_list + p.max_tiles + 1, 0, 4, stream);
     if (e == hipSuccess) e = rb_fill_async(p.blk, 0, 16, stream); // (the two list walkers' cursors)
+#ifdef NF_DIAG
+    if (e == hipSuccess) e = rb_fill_async(p.blk + 8, 0, 64, stream);
+#endif
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(rb_k_nf_tile_desc, dim3((unsigned)((p.max_tiles + 255) / 256)), dim3(256), 0, stream, p);
     hipLaunchKernelGGL((rb_k_nf_tiles<true, true>), dim3((unsigned)p.max_tiles), dim3(NF_THREADS), 0, stream, p);

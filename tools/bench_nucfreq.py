@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--read-len", type=int, default=15000)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--phases", action="store_true", help="a -DNF_DIAG variant of the library (RB_VARIANT): print the shader-clock length of a tile's phases, sampled on every 64th tile")
     ap.add_argument("--placement-tries", type=int, default=1, help="candidates rb_dev_alloc_placed may take for the counts array (store sweep)")
     a = ap.parse_args()
     import torch
@@ -110,6 +111,17 @@ def main():
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
     ctr = d_ctr.cpu().numpy()
+    if a.phases:  # (the workspace's layout up to the scans' partials: capi.hip nf_ws_layout; the diagnostics build adds its sums behind the eighth word)
+        up = lambda x: (x + 255) & ~255
+        off = up((n + 1) * 8)
+        off = up(off + (n + 1) * 48)
+        off = up(off + (1 + 2) * 8)
+        base = ws_ptr - d_ws.data_ptr() + off + 64
+        v = d_ws[base:base + 64].view(torch.int64).cpu().numpy()
+        names = ["zeroing + first barrier", "first chunk scanned (records, ops: the dependent trips)", "the wave's reads", "waiting for the other waves",
+                 "depth scan", "output", "whole tile"]
+        waves = max(int(v[7]), 1)
+        print({"sampled_waves": waves, **{nm: round(float(v[k]) / waves, 1) for k, nm in enumerate(names)}, "unit": "shader clocks per wave and tile (last call)"}, file=sys.stderr)
     assert int((d_status[:n] != 0).sum()) == 0 and ctr[3] == 0
     check = not os.environ.get("NF_NO_CHECK")
     c = d_counts[:a.contig * 4].view(-1, 4)
