@@ -419,7 +419,10 @@ __device__ __forceinline__ nf_read nf_uniform(const nf_read &h) {
 }
 __global__ __launch_bounds__(256) void rb_k_nf_tile_desc(rb_nf_params p) {
     const uint64_t t = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (t >= p.tile_off[p.n_regions]) return;
+    if (t >= p.tile_off[p.n_regions]) { // (the launch over all tiles reads a record for every workgroup: behind the last tile one that says "nobody's")
+        if (t < p.max_tiles) p.tdesc[t].u8 = 3u;
+        return;
+    }
     const nf_tile T = nf_tile_of(p, t);
     const nf_drop d = nf_drop_of(p, T);
     nf_tdesc D;
@@ -454,9 +457,13 @@ __device__ __forceinline__ uint32_t nf_swap_nibbles(uint32_t v) { // (two shifts
 // -DNF_DIAG (a diagnostics variant, tools/nf_phases.py): every 64th tile's waves add the shader-clock length of their phases to p.blk[8 ..]
 #ifdef NF_DIAG
 #define NF_STAMP(k) const uint64_t nf_t##k = __builtin_amdgcn_s_memtime()
+#define NF_DECL(k) uint64_t nf_t##k = 0
+#define NF_SET(k) nf_t##k = __builtin_amdgcn_s_memtime()
 #define NF_PHASE(slot, a, b) do { if ((t & 63u) == 0u && (tix & 63u) == 0u) atomicAdd(reinterpret_cast<unsigned long long *>(p.blk) + 8 + (slot), (unsigned long long)(nf_t##b - nf_t##a)); } while (0)
 #else
 #define NF_STAMP(k) do { } while (0)
+#define NF_DECL(k) do { } while (0)
+#define NF_SET(k) do { } while (0)
 #define NF_PHASE(slot, a, b) do { } while (0)
 #endif
 #ifndef NF_U8_WPE
@@ -491,6 +498,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     uint32_t tix;
     asm volatile("v_mov_b32 %0, %1" : "=v"(tix) : "v"(threadIdx.x));
     NF_STAMP(0);
+    NF_DECL(1);
     static_assert(U8T || !D8, "byte differences live in the byte counters' padding");
     constexpr uint32_t STG = U8T ? (uint32_t)(NF_TILE / 8 + (D8 ? NF_U8_SLACK_DW : 128)) : (uint32_t)NF_STAGE_DW; // dwords of a read staged per tile (a longer stretch is read from memory group by group)
     static_assert((STG + 8) % 4 == 0, "a wave's staging buffer starts 16-byte aligned");
@@ -520,11 +528,24 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     __shared__ int32_t wsum[NF_WAVES];
     __shared__ uint32_t blk_max, blk_cov;
     __shared__ __attribute__((aligned(16))) uint32_t stage_all[NF_WAVES][STG + 8]; // per wave: the bases one read lays over the tile (4 zero dwords in front)
-    if (t >= p.tile_off[p.n_regions]) return;
     // (round 4: the tile's facts come as ONE 64-byte record at a wave-uniform address -- rb_k_nf_tile_desc -- instead of a binary search
-    //  for the region followed by dependent loads of its arrays, of the region's first tile and of its dropped-read bitmap's place)
-    const nf_tdesc D = nf_uniform(p.tdesc[t]);
-    if (D.u8 != (D8 ? 1u : U8T ? 2u : 0u)) return; // another build's
+    //  for the region followed by dependent loads of its arrays, of the region's first tile and of its dropped-read bitmap's place;
+    //  round 6: asked for first thing and looked at behind the zeroing -- the record's trip to memory runs under it; rb_k_nf_tile_desc
+    //  marks the records behind the last tile, so nothing else has to be fetched to know that a workgroup has no tile)
+    const nf_tdesc Draw = p.tdesc[t];
+    // ---- zero the tile (nothing of it depends on the record) ----
+    for (uint32_t k = tix; k < CNT_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(cnt)[k] = make_uint4(0, 0, 0, 0); // (16 bytes a store)
+    if ((tix & 63u) < 4u) stage_all[tix >> 6][tix & 63u] = 0;
+    if constexpr (!D8)
+        for (uint32_t k = tix; k < NF_DIFF_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(diff)[k] = make_uint4(0, 0, 0, 0);
+    if (tix < 16) {
+        const uint32_t n = tix;
+        lut[n] = (n == 1 || n == 4) ? 1u : (n == 2 || n == 8) ? 0x10000u : 0u;
+        lut8[n] = n == 1 ? 1u : n == 2 ? 0x100u : n == 4 ? 0x10000u : n == 8 ? 0x1000000u : 0u;
+    }
+    if (tix == 0) blk_max = 0, blk_cov = 0;
+    const nf_tdesc D = nf_uniform(Draw);
+    if (D.u8 != (D8 ? 1u : U8T ? 2u : 0u)) return; // another build's, or nobody's
 #if NF_STOP == 7
     if (D.n_pos != 0x7FFFFFFFu) return; // (timing only: what it costs to launch the tiles' workgroups)
 #endif
@@ -543,12 +564,6 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
     const uint64_t hv_i = D.lo + (tix >> 6) + (uint64_t)NF_WAVES * (tix & 63u);
     if ((tix & 63u) < nw) hv = p.hd[hv_i];
 #endif
-    {   // (16 bytes a store: a quarter of the instructions)
-        for (uint32_t k = tix; k < CNT_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(cnt)[k] = make_uint4(0, 0, 0, 0);
-    }
-    if ((tix & 63u) < 4u) stage_all[tix >> 6][tix & 63u] = 0;
-    if constexpr (!D8)
-        for (uint32_t k = tix; k < NF_DIFF_DW / 4; k += NF_THREADS) reinterpret_cast<uint4 *>(diff)[k] = make_uint4(0, 0, 0, 0);
     auto diff_add = [&](uint32_t i, int32_t delta) {
         if constexpr (D8) { // position i = byte (i + 8) & 7 of the two spare dwords of its group (i + 8) >> 3
             const uint32_t q = i + 8u;
@@ -559,14 +574,7 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
             atomicAdd(&diff[i], delta);
         }
     };
-    if (tix < 16) {
-        const uint32_t n = tix;
-        lut[n] = (n == 1 || n == 4) ? 1u : (n == 2 || n == 8) ? 0x10000u : 0u;
-        lut8[n] = n == 1 ? 1u : n == 2 ? 0x100u : n == 4 ? 0x10000u : n == 8 ? 0x1000000u : 0u;
-    }
-    if (tix == 0) blk_max = 0, blk_cov = 0;
-    __syncthreads();
-    NF_STAMP(1);
+    // (the barrier that makes the zeroing everybody's sits in front of the first LDS atomic: behind the first requests of the wave's reads)
     const uint32_t wib = rb_first(tix >> 6);
     const int lane = (int)(tix & 63u);
     const uint64_t lo = D.lo, hi = D.hi;
@@ -766,6 +774,8 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         }
     };
     if (!U8T && hi - lo > 8u * 64u) {
+        __syncthreads(); // (the zeroing)
+        NF_SET(1);
         // ---- a tile crowded with reads (short reads): 64 reads per wave and turn, one lane per read with at most NF_LANE_OPS ops
         //      -- it walks its ops and drops its bases one by one; the wave scans would idle on 150-base reads -- and the few
         //      reads with longer cigars one after the other with the whole wave ----
@@ -835,11 +845,6 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
 #if NF_STOP == 3 || NF_STOP == 8
         mine = false;
 #endif
-        if (mine) { // (every lane its own read: the two atomics of up to 64 reads in one go)
-            const uint64_t c0 = (uint64_t)hv.pos > T.st ? (uint64_t)hv.pos : T.st, c1 = (uint64_t)hv.end < T.en ? (uint64_t)hv.end : T.en;
-            diff_add((uint32_t)(c0 - T.st), 1);
-            diff_add((uint32_t)(c1 - T.st), -1);
-        }
         const uint64_t alive = __ballot(mine);
         struct cursor { // a chunk to come: which read, where in its ops, the reference / read bases in front of it
             nf_read h;
@@ -877,8 +882,16 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
             return k;
         };
         cursor c_cur = read_at(~0ull);
+        const uint32_t w_cur = ops_at(c_cur); // (the first read's ops: on their way while the workgroup meets at the barrier)
+        __syncthreads();                      // (the zeroing is everybody's: LDS atomics from here on)
+        NF_SET(1);
+        if (mine) { // (every lane its own read into the coverage differences: the two atomics of up to 64 reads in one go)
+            const uint64_t c0 = (uint64_t)hv.pos > T.st ? (uint64_t)hv.pos : T.st, c1 = (uint64_t)hv.end < T.en ? (uint64_t)hv.end : T.en;
+            diff_add((uint32_t)(c0 - T.st), 1);
+            diff_add((uint32_t)(c1 - T.st), -1);
+        }
         nf_chunk<STG_IT> k_cur = empty();
-        if (c_cur.valid) k_cur = chunk_scan(c_cur.h, ops_at(c_cur), c_cur.R, c_cur.Q, c_cur.i);
+        if (c_cur.valid) k_cur = chunk_scan(c_cur.h, w_cur, c_cur.R, c_cur.Q, c_cur.i);
         cursor c_nxt = after(c_cur);
         uint32_t w_nxt = ops_at(c_nxt);
         NF_STAMP(2);
@@ -896,6 +909,8 @@ __device__ __forceinline__ void nf_one_tile(const rb_nf_params &p, const uint64_
         NF_STAMP(3);
         NF_PHASE(2, 2, 3);
 #else
+        __syncthreads(); // (the zeroing)
+        NF_SET(1);
         // ---- the wave's reads, one after the other.  Two loads run ahead of the work: the record of the read after next, and the
         //      first 64 ops of the next read (whose record arrived one turn earlier) -- a read then starts with its ops in registers
         //      instead of waiting for three dependent trips to memory ----
