@@ -16,7 +16,7 @@ for f in sorted(glob.glob("gpurun_out/%s/**/*counter_collection.csv" % (tag or "
     acc = collections.defaultdict(lambda: [0.0, 0])
     for r in csv.DictReader(open(f)):
         if "nf_tiles" in r["Kernel_Name"]:
-            a = acc[r["Kernel_Name"].split("(")[0][:24] + " " + r["Counter_Name"]]
+            a = acc[r["Kernel_Name"].split("(")[0][:40] + " " + r["Counter_Name"]]
             a[0] += float(r["Counter_Value"]); a[1] += 1
     for k, (v, n) in acc.items():
         print(os.path.basename(f)[:12], k, "per launch: %.4g" % (v / max(n, 1) * (1 if True else 1)), "rows", n)
