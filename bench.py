@@ -141,6 +141,21 @@ def e2e_leg(n_rec, n_win, gpus=1):
             n_rec = min(n_rec, 100_000)
     except Exception:
         n_rec = min(n_rec, 100_000)
+    # The files live in memory (/dev/shm): a run that is ended from outside must not leave gigabytes behind.  SIGTERM (what launch_ranks sends
+    # the other ranks when one fails) becomes an exception for the length of this leg, so that the `finally` below runs; what an earlier
+    # run that was killed outright left is taken away here (directories of this name older than an hour).
+    import signal
+    for name in (os.listdir(shm) if shm else []):
+        q = os.path.join(shm, name)
+        try:
+            if name.startswith("rb_e2e_") and os.path.isdir(q) and time.time() - os.stat(q).st_mtime > 3600:
+                shutil.rmtree(q, ignore_errors=True)
+        except OSError:
+            pass
+
+    def _term(*_):
+        raise SystemExit(143)
+    old_term = signal.signal(signal.SIGTERM, _term)
     d = tempfile.mkdtemp(prefix="rb_e2e_", dir=shm)
     try:
         paf, bed, out = (os.path.join(d, x) for x in ("w.paf", "w.bed", "out.paf"))
@@ -170,6 +185,7 @@ def e2e_leg(n_rec, n_win, gpus=1):
                                                                 "setup_s": round(gen_s, 1)}}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+        signal.signal(signal.SIGTERM, old_term)
 
 
 def smi_facts():

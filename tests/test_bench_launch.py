@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -49,3 +51,39 @@ def test_defaults_place_the_arena_by_the_step_itself(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["bench.py", "--placement-tries", "1", "--placement-by", "sweep"])
     a = bench.parse()
     assert a.placement_tries == 1 and a.placement_by == "sweep"
+
+
+def test_an_ended_rank_leaves_nothing_in_shared_memory():
+    """bench.py's end-to-end leg keeps its files in /dev/shm (memory).  launch_ranks ends the other ranks with SIGTERM when one fails: the
+    leg's directory must go with the process -- and a directory an earlier run left after being killed outright is taken away too."""
+    import glob
+    import signal
+    import time
+    if not os.path.isdir("/dev/shm") or not os.path.exists(os.path.join(ROOT, "rustybam_amd", "rb")):
+        pytest.skip("no /dev/shm or the front end is not built")
+    stale = "/dev/shm/rb_e2e_stale_for_the_test"
+    os.makedirs(stale, exist_ok=True)
+    open(os.path.join(stale, "w.paf"), "wb").write(b"x" * 1000)
+    old = time.time() - 3 * 3600
+    os.utime(stale, (old, old))
+    before = set(glob.glob("/dev/shm/rb_e2e_*")) - {stale}
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); import bench; bench.e2e_leg(100000, 3000)"
+    p = subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        new = set()
+        for _ in range(300):  # (until the leg has made its directory and is writing the input)
+            new = set(glob.glob("/dev/shm/rb_e2e_*")) - before - {stale}
+            if new and any(os.path.exists(os.path.join(d, "w.paf")) for d in new):
+                break
+            if p.poll() is not None:
+                break
+            time.sleep(0.1)
+        assert new and p.poll() is None, "the leg did not get as far as writing its input"
+        p.send_signal(signal.SIGTERM)
+        p.wait(timeout=60)
+    finally:
+        if p.poll() is None:
+            p.kill()
+    assert p.returncode != 0
+    assert set(glob.glob("/dev/shm/rb_e2e_*")) - before == set()
+    assert not os.path.exists(stale)
