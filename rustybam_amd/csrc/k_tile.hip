@@ -106,7 +106,7 @@ __device__ __forceinline__ void rb_tile_body() {
     uint8_t *gq_s = reinterpret_cast<uint8_t *>(gq_all[wib]);
     uint32_t ra = rb_first(p.tile_first[3u * tile]);
     uint32_t nrec = rb_first(p.tile_first[3u * tile + 1u]);
-    const uint32_t slot0 = rb_first(p.tile_first[3u * tile + 2u]); // (the jobs of a tile's records lie side by side)
+    uint32_t slot0 = rb_first(p.tile_first[3u * tile + 2u]); // (the jobs of a tile's records lie side by side)
     const bool passthrough = (ra >> 31) != 0u;
     ra &= 0x7FFFFFFFu;
     // the tile goes to the per-record kernel as it is
@@ -127,43 +127,42 @@ __device__ __forceinline__ void rb_tile_body() {
     const uint32_t ns1 = n_slots ? n_slots : 1u;
 
     // ---- set-up, lane j = record ra + j ----
-    bool isrec = (uint32_t)lane < nrec;
-    const uint32_t r = ra + (isrec ? (uint32_t)lane : 0u);
-    const uint32_t slot = slot0 + (isrec ? (uint32_t)lane : 0u);
     // RB_LIFT_OP_STARTS (a batch trim-paf has cut in place, include/rustybam_amd.h): op_off is a table of starts, a record's extent is its
     // row's (the job's), and the records of a tile lie one behind the other with GAPS between them -- what the clips left of their ends
     const bool starts = p.op_starts != 0;
-    const uint64_t oo0 = p.op_off[r], oo1 = starts ? 0ull : p.op_off[r + 1];
-    uint32_t jflags, jn, jnh, jlo, jh0;
-    uint64_t jrec0, t_st, t_en;
-    {
+    bool isrec, active = false, gone = false;
+    uint32_t r, slot, jflags = 0, jn = 0, jnh = 0, jlo = 0, jh0 = 0, spanR = 0, spanQ = 0;
+    uint64_t oo0 = 0, oo1 = 0, jrec0 = 0, t_st = 0, t_en = 0, tot = 0;
+    // the records' jobs into the lanes; the cut where the tile's hits fill the lanes; which records the tile kernel can take.  Returns the
+    // lanes whose record it cannot (gone: the whole tile went to the per-record kernel).  Run once -- or twice: below.
+    auto setup = [&]() -> uint64_t {
+        isrec = (uint32_t)lane < nrec;
+        r = ra + (isrec ? (uint32_t)lane : 0u);
+        slot = slot0 + (isrec ? (uint32_t)lane : 0u);
+        oo0 = p.op_off[r], oo1 = starts ? 0ull : p.op_off[r + 1];
         const rb_job *jp = &p.jobs[slot];
         jrec0 = jp->rec0, jn = jp->n, jflags = jp->flags, jnh = jp->nh, jlo = jp->lo, jh0 = jp->h0;
         t_st = jp->t_st, t_en = jp->t_en;
-    }
-    if constexpr (!BRK) {
-        // more hits than lanes: the tile is cut behind the last record whose hits still fit -- the records behind it go to the per-record
-        // kernel, the tile kernel keeps the front (dense windows over short records: a tile of 31 records with three hits each)
-        const uint32_t nh0 = (isrec && (jflags & RB_JOB_VALID) != 0u) ? jnh : 0u;
-        const uint32_t inc0 = rb_wave_scan_incl(nh0);
-        if (rb_readlane<uint32_t>(inc0, 63) > RBT_HITS) {
-            const uint32_t m = (uint32_t)__builtin_popcountll(rb_ballot(isrec && inc0 <= RBT_HITS)); // (the counts do not decrease: a run of low lanes)
-            if (m == 0u) {
-                fallback();
-                return;
+        if constexpr (!BRK) {
+            // more hits than lanes: the tile is cut behind the last record whose hits still fit -- the records behind it go to the per-record
+            // kernel, the tile kernel keeps the front (dense windows over short records: a tile of 31 records with three hits each)
+            const uint32_t nh0 = (isrec && (jflags & RB_JOB_VALID) != 0u) ? jnh : 0u;
+            const uint32_t inc0 = rb_wave_scan_incl(nh0);
+            if (rb_readlane<uint32_t>(inc0, 63) > RBT_HITS) {
+                const uint32_t m = (uint32_t)__builtin_popcountll(rb_ballot(isrec && inc0 <= RBT_HITS)); // (the counts do not decrease: a run of low lanes)
+                if (m == 0u) {
+                    fallback();
+                    gone = true;
+                    return 0ull;
+                }
+                unsigned long long b0 = 0;
+                if (lane == 0) b0 = atomicAdd(p.fb_count, (unsigned long long)(nrec - m));
+                b0 = rb_first64(b0);
+                if ((uint32_t)lane >= m && (uint32_t)lane < nrec) p.fb_list[b0 + ((uint32_t)lane - m)] = ra + (uint32_t)lane;
+                nrec = m;
+                isrec = (uint32_t)lane < nrec;
             }
-            unsigned long long b0 = 0;
-            if (lane == 0) b0 = atomicAdd(p.fb_count, (unsigned long long)(nrec - m));
-            b0 = rb_first64(b0);
-            if ((uint32_t)lane >= m && (uint32_t)lane < nrec) p.fb_list[b0 + ((uint32_t)lane - m)] = ra + (uint32_t)lane;
-            nrec = m;
-            isrec = (uint32_t)lane < nrec;
         }
-    }
-    uint32_t spanR, spanQ;
-    bool active;
-    {
-        const rb_job *jp = &p.jobs[slot];
         const uint64_t q_st = jp->q_st, q_en = jp->q_en;
         active = (jflags & RB_JOB_VALID) != 0u;
         const bool passive = !BRK && (jflags & (RB_JOB_VALID | RB_JOB_ROWS_OVERFLOW)) == 0u && jnh == 0u; // (no window overlaps it and nothing is to be verified: its ops only run past)
@@ -172,11 +171,47 @@ __device__ __forceinline__ void rb_tile_body() {
                   (starts || (jrec0 == oo0 && (uint64_t)jn == oo1 - oo0)) && jn >= 8u && t_en >= t_st && q_en >= q_st && sR < (1ull << 31) && sQ < (1ull << 31);
         spanR = isrec ? (uint32_t)sR : 0u, spanQ = isrec ? (uint32_t)sQ : 0u;
         if (!isrec) ok = true, active = false;
-        const uint64_t tot = rb_wave_sum_u64(isrec ? sR + sQ : 0ull); // (U <= R + Q: below 2^32 every running total of the tile is exact)
-        if (rb_ballot(!ok) != 0ull || tot >= (1ull << 32)) {
+        tot = rb_wave_sum_u64(isrec && ok ? sR + sQ : 0ull); // (U <= R + Q: below 2^32 every running total of the tile is exact)
+        return rb_ballot(!ok);
+    };
+    uint64_t badm = setup();
+    if (gone) return;
+    if (badm != 0ull) {
+        // A record the tile kernel cannot take (irregular CIGAR, stripped end indels, an extent that is not its offsets', ...): the tile is
+        // cut to its longest run of records it can take, everything else goes to the per-record kernel -- the record itself, which that
+        // kernel hands to the general ones, and the shorter side of the tile -- and the set-up runs once more over the run (straight
+        // line, twice: a loop around the set-up cost the scalar bases of the ring their wave-uniformity in the compiler's eyes).
+        // (Round 5 handed the whole tile back: with 1 % of such records among records of 300 - 700 ops that was 7.7 % of all records
+        // and a quarter to a third more time for the step.)
+        uint32_t best_s = 0, best_n = 0, prev = 0; // longest run [best_s, best_s + best_n) of lanes without a bad record
+        uint64_t m = badm;
+        for (;;) {
+            const uint32_t bb = m ? (uint32_t)__builtin_ctzll(m) : nrec; // (bad records are records: bb < nrec)
+            if (bb - prev > best_n) best_s = prev, best_n = bb - prev;
+            if (!m) break;
+            m &= m - 1;
+            prev = bb + 1u;
+        }
+        if (best_n == 0u) {
             fallback();
             return;
         }
+        const uint64_t out_m = ((nrec < 64u ? (1ull << nrec) : 0ull) - 1ull) & ~(((best_n < 64u ? (1ull << best_n) : 0ull) - 1ull) << best_s); // the records outside the run
+        unsigned long long b0 = 0;
+        if (lane == 0) b0 = atomicAdd(p.fb_count, (unsigned long long)__builtin_popcountll(out_m));
+        b0 = rb_first64(b0);
+        if ((out_m >> lane) & 1ull) p.fb_list[b0 + (uint32_t)__builtin_popcountll(out_m & ((1ull << lane) - 1ull))] = ra + (uint32_t)lane;
+        ra = rb_first(ra + best_s), slot0 = rb_first(slot0 + best_s), nrec = rb_first(best_n);
+        badm = setup();
+        if (gone) return;
+        if (badm != 0ull) { // (cannot be: the run holds none)
+            fallback();
+            return;
+        }
+    }
+    if (tot >= (1ull << 32)) {
+        fallback();
+        return;
     }
     const uint32_t PassR = rb_wave_scan_incl(spanR) - spanR; // where record j starts in the tile's running reference total, if its CIGAR sums to its header
     const uint64_t g_first = rb_first64(jrec0);              // (lane 0: the tile's first op)

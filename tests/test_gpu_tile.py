@@ -178,8 +178,9 @@ def test_records_the_tile_kernel_hands_back(engine, oracle, mode):
 
 
 def test_one_bad_record_in_a_tile(engine, oracle):
-    """a record whose CIGAR does not sum to its header in the middle of a tile (check_integrity, paf.rs:825-857): the fused scan hands
-    the tile back, the record gets its status, its neighbours their rows"""
+    """a record whose CIGAR does not sum to its header in the middle of a tile (check_integrity, paf.rs:825-857): the record gets its
+    status, its neighbours their rows.  (Round 6: a record the tile kernel cannot take at SET-UP -- irregular, stripped -- cuts the tile to
+    its longest run of records it can take; this one is found by the fused scan behind the stream, and the tile goes back as a whole.)"""
     b = synth_batch(engine, 0xBAD, 64, 100, 160, span=100_000)
     b["t_en"][17] += np.uint64(3)
     b["q_en"][40] += np.uint64(1)
@@ -254,3 +255,34 @@ def test_windows_inside_one_op_and_on_record_ends(engine, oracle):
     for ms in (0, 1, 2, 4):
         # (--max-size 4: two pieces per record, 64 in the tile of 32; below that the tile holds more pieces than lanes and is handed back)
         break_both(engine, oracle, b, ms, FUSED | rustybam_amd.BREAK_ONE_WALK, f"ten-op records, break {ms}", expect_back=0 if ms == 4 else 32)
+
+
+def test_a_tile_is_cut_around_a_record_it_cannot_take(engine, oracle):
+    """round 6 (the advisor's second finding of round 5): one irregular record used to send its whole tile -- up to 32 records -- to the
+    per-record kernel.  The tile is cut to its longest run of records it can take; the irregular record and the shorter side go back.
+    Results as without tiles and as the oracle's; fewer records handed back than the tiles hold."""
+    n_rec = 96
+    b = synth_batch(engine, 0xC07, n_rec, 100, 160, span=150_000)
+    off = b["op_off"].astype(np.int64)
+    bad = [5, 41, 42, 90]
+    new_ops, new_off = [], [0]
+    for r in range(n_rec):  # op 3 of a bad record split in two ops of its type: irregular (paf.rs:602-620 merges them on the way out), same bases
+        seg = b["ops"][int(off[r]):int(off[r + 1])].tolist()
+        if r in bad:
+            k = next(i for i in range(3, len(seg)) if (seg[i] >> 4) >= 2)
+            w = seg[k]
+            seg[k:k + 1] = [((w >> 4) - 1) << 4 | (w & 15), 1 << 4 | (w & 15)]
+        new_ops += seg
+        new_off.append(len(new_ops))
+    b2 = dict(b)
+    b2["ops"] = np.array(new_ops, np.uint32)
+    b2["op_off"] = np.array(new_off, np.uint64)
+    w = sliding(span=300_000, step=49_999, width=12_000)  # (sparse enough that no tile is cut by its hits)
+    # (with the record scan done beforehand the set-up knows which records are irregular; with the FUSED scan it only knows what the peek at a
+    #  record's ends shows -- an irregularity in the middle is found behind the stream, and that tile still goes back as a whole)
+    c = lift_both(engine, oracle, b2, w, 0, "tiles cut around irregular records")
+    tiles, back = int(c["phase"][3]), int(c["phase"][4])
+    assert tiles > 0 and len(bad) <= back < n_rec // 2, (tiles, back)
+    lift_both(engine, oracle, b2, w, FUSED, "irregular records in the middle of tiles, fused scan", expect_back=len(bad))
+    c = break_both(engine, oracle, b2, 50, 0, "break-paf, tiles cut around irregular records")
+    assert int(c["phase"][3]) > 0 and len(bad) <= int(c["phase"][4]) < n_rec // 2, (int(c["phase"][3]), int(c["phase"][4]))
