@@ -132,12 +132,13 @@ def test_depth_cap_spread_starts_and_regions(engine, oracle):
 
 
 def test_long_insertions_inside_a_tile(engine, oracle):
-    """the tile kernel stages the stretch of a read that lies over a tile (at most 6144 bases); a longer stretch -- a long insertion
-    between two matches of the same tile -- is read from memory group by group instead: both routes, next to each other"""
+    """the tile kernel stages the stretch of a read that lies over a tile (the usual build: the tile's own 4096 bases plus 224 of slack;
+    the 16-bit build 6144); a longer stretch -- a long insertion between two matches of the same tile -- is read from memory group by group
+    instead: both routes, next to each other, insertions on either side of the slack"""
     rng = np.random.default_rng(11)
     M, I, D = 0, 1, 2
     cigs, seqs, poss = [], [], []
-    for k, ins in enumerate([10, 3000, 5900, 6200, 9000, 20000, 7000]):
+    for k, ins in enumerate([10, 3000, 3700, 3790, 3830, 3900, 5900, 6200, 9000, 20000, 7000]):
         c = [(int(rng.integers(50, 300)) << 4) | M, (ins << 4) | I, (int(rng.integers(50, 300)) << 4) | M, (7 << 4) | D, (120 << 4) | M]
         q = sum(w >> 4 for w in c if (w & 15) in (0, 1))
         cigs.append(c)
@@ -145,6 +146,15 @@ def test_long_insertions_inside_a_tile(engine, oracle):
         poss.append(100 + 37 * k)
     rd = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, seqs)
     check_regions(engine, oracle, rd, [(0, 0, 1200), (0, 300, 301), (0, 0, 5000)])
+    # reads that cover a whole tile: the stretch is the tile's 4096 bases plus the insertion -- on either side of the slack (224 bases, less
+    # what the stretch's alignment to a dword takes)
+    cigs, seqs, poss = [], [], []
+    for k, ins in enumerate([1, 100, 200, 210, 216, 220, 224, 228, 236, 300, 1100]):
+        c = [((2300 + 13 * k) << 4) | M, (ins << 4) | I, (2600 << 4) | M, (5 << 4) | D, (900 << 4) | M]
+        q = sum(w >> 4 for w in c if (w & 15) in (0, 1))
+        cigs.append(c), seqs.append(rng.choice([1, 2, 4, 8, 15], size=q).tolist()), poss.append(3 * k)
+    rd = Reads([0] * len(cigs), poss, [0] * len(cigs), cigs, seqs)
+    check_regions(engine, oracle, rd, [(0, 0, 8192), (0, 4090, 4100)])
 
 
 def test_crowded_tile_lane_per_read_path(engine, oracle):
