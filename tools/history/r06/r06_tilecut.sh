@@ -1,3 +1,6 @@
+# round 6, the tile kernel's cut around a record it cannot take: tile / trim / break tests, the tile soak, the starts soak, then the config-4 shape with and
+# without 1 % irregular records through two library variants interleaved -- tile_old = k_tile.hip of the commit before (tools/mkvariant.sh tile_old --src
+# k_tile.hip on that tree), tile_new = the tree's own (profiles/r06_alloc_summary.md has nothing of this; DESIGN.md section 0, the advisor's paragraph, has the numbers)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06_tilecut
 timeout 1200 python -m pytest tests/test_gpu_tile.py tests/test_gpu_trim.py tests/test_gpu_break_onewalk.py -x -q -m gpu > gpurun_out/r06_tilecut/tests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/r06_tilecut/tests.log
